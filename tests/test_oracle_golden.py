@@ -1,0 +1,40 @@
+"""CPU: the oracle restatement reproduces the golden vectors produced by the imported reference."""
+import pytest
+import torch
+
+from oracle import models as O
+from oracle.weightgen import checksum, fill_state_dict
+from tests.helpers import CASES, forward_args, load_case, rel_l2
+
+TOL = 2e-6   # same torch CPU kernels, different batching of the GEMMs
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_oracle_matches_reference_golden(tag):
+    name, hp, salt, batch, d = load_case(tag)
+    model = O.build(name, hp).eval()
+    fill_state_dict(model, salt)
+    assert abs(checksum(model) - float(d["weight_checksum"])) <= 1e-6 * float(d["weight_checksum"])
+    with torch.no_grad():
+        if name.startswith("mpnn"):
+            u = batch["u"].permute(0, 2, 1)
+            x = batch["x"].squeeze(-1) if name == "mpnn" else batch["x"]
+            t = batch["t"]
+            tw = hp.time_window
+            g = model._build_graph(u[:, :tw], t, x, [model._step_index(0)] * u.shape[0])
+            assert torch.equal(g.edge_index, torch.from_numpy(d["edge_index"]))
+            y = model(g, x[0, -1], t[0, -1], t[0][1] - t[0][0])
+            assert rel_l2(y, d["fwd_out"]) < TOL
+            inc = y - g.x[:, -1:]
+            inc_ref = torch.from_numpy(d["fwd_out"]) - g.x[:, -1:]
+            assert rel_l2(inc, inc_ref) < 50 * TOL
+            pred = model.validation_step(batch)
+            assert rel_l2(pred, d["val_pred"]) < 5 * TOL
+        else:
+            o = model(*forward_args(name, hp, batch))
+            for got, key in zip(o, ("fwd_out_hr", "fwd_out_lr", "fwd_hr_points")):
+                assert got.shape == d[key].shape
+                assert rel_l2(got, d[key]) < TOL, key
+            model.validation_step(batch)
+        assert abs(float(model.logged["val_mae_loss"]) - float(d["val_mae_loss"])) < 1e-5
+        assert abs(float(model.logged["val_loss"]) - float(d["val_loss"])) < 1e-5
