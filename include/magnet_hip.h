@@ -1,0 +1,148 @@
+/* magnet_hip.h - C ABI of libmagnet_hip.so: MI355X (gfx950) kernels for the MAgNet rollout hot path.
+ *
+ * Boundary.  The reference (jaggbow/magnet) is pure Python; its hot path reaches native code only
+ * through third-party wheels (ATen, torch_scatter, torch_cluster, PyG).  This library sits where
+ * those wheels sit: plain device pointers + sizes + a hipStream_t (passed as void*), nothing from
+ * torch in any signature.  Every function
+ *   - enqueues on `stream` and returns immediately (never allocates, never synchronises),
+ *   - returns 0 on success, a negative value for an unsupported argument, or a hipError_t,
+ *   - borrows all buffers for the duration of the enqueued work; the caller owns them.
+ * All floating point is fp32 (the reference runs precision=32, configs/trainer/default.yaml:5);
+ * indices are int32 on the device (the reference's int64 edge_index is converted at the boundary).
+ * Citations are file:line in the reference repository.
+ */
+#ifndef MAGNET_HIP_H
+#define MAGNET_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Packed weight layout ("fragment order") used by every Linear in this library.
+ * A torch Linear weight W[N_out][K] (row-major, models/backbones/mlp.py:16-21) is zero-padded to
+ * NT*32 x KT*32 and stored as float4 Wp[KT][NT][4][64]:
+ *     Wp[kt][nt][g][lane] = W[nt*32 + (lane & 31)][kt*32 + 8*g + 4*(lane >> 5) + 0..3]
+ * (one 1 KiB coalesced wave load per [kt][nt][g]); the bias is zero-padded to NT*32 floats.
+ * magnet_amd/packing.py builds it; a C caller can use the same two lines of index arithmetic.
+ * ---------------------------------------------------------------------------------------------- */
+
+#define MAGNET_MAX_KT 12
+#define MAGNET_MAX_LAYERS 6
+enum { MAGNET_ACT_NONE = 0, MAGNET_ACT_SWISH = 1, MAGNET_ACT_RELU = 2 };
+enum { MAGNET_EPI_STORE = 0, MAGNET_EPI_STORE_RES = 1, MAGNET_EPI_SEGMEAN = 2 };
+
+/* One source feeding a 32-wide k tile of the first Linear's input:
+ *   value[row][k] = scale * p[(idx ? idx[row] : row / rdiv) * ld + col + k],  k = 0..31
+ * p, ld and col must keep every 4-float group 16-byte aligned. */
+typedef struct {
+    const float* p;
+    const int32_t* idx;
+    int32_t ld, col;
+    float scale;
+    int32_t rdiv;
+} magnet_src_t;
+typedef struct {
+    magnet_src_t s[2]; /* n == 2: the two sources are summed (u_i - u_j style differences) */
+    int32_t n;
+    int32_t pad_[3];
+} magnet_ktile_t;
+typedef struct {
+    const void* w;  /* packed weights */
+    const float* b; /* padded bias    */
+} magnet_layer_t;
+typedef struct {
+    int32_t M;   /* rows (nodes, CSR-ordered edges or INR samples) */
+    int32_t nkt; /* k tiles of the first layer (K_padded / 32) */
+    magnet_ktile_t kt[MAGNET_MAX_KT];
+    magnet_layer_t layer[MAGNET_MAX_LAYERS];
+    const float* ln_g; /* LayerNorm gain / bias over the OT*32 outputs (eps = ln_eps) */
+    const float* ln_b;
+    float ln_eps;
+    float* y; /* STORE / STORE_RES: [M][ldy], first ncols columns.  SEGMEAN: agg [N][ncols] */
+    int32_t ldy, ncols;
+    const float* res; /* STORE_RES: y = mlp(x) + res */
+    int32_t ldres;
+    const int32_t* tgt;    /* SEGMEAN: target row of every edge (non-decreasing) */
+    const int32_t* rowptr; /* SEGMEAN: CSR row pointer [N+1] */
+    float* partials;       /* SEGMEAN: scratch [ceil(M/32)][2][ncols] */
+    int32_t pad2_;
+} magnet_mlp_args_t;
+
+/* Fused gather/concat -> NL x (Linear [+ activation]) -> [LayerNorm] -> store | +residual | CSR mean.
+ * nl = number of Linears (1, 2 or 5), ht/ot = hidden/output width in 32-column tiles.
+ * Replaces the torch.cat + nn.Linear + activation chains of models/mpnn.py:77-78,85-88,191-192 and
+ * models/backbones/mlp.py:23-28 (+ nn.LayerNorm, + torch_scatter mean for SEGMEAN) as called from
+ * models/magnet_gnn.py:38-42,79-90,135-137,339.  SEGMEAN must be followed by
+ * magnet_segmean_fixup_f32 on the same stream. */
+int magnet_mlp_f32(const magnet_mlp_args_t* args, int nl, int ht, int ot, int act, int last_act, int ln, int epi,
+                   void* stream);
+int magnet_mlp_supported(int nl, int ht, int ot, int act, int last_act, int ln, int epi);
+int magnet_segmean_fixup_f32(const int32_t* rowptr, int n_rows, int d, const float* partials, float* agg,
+                             void* stream);
+
+/* out[r][:] = mean(msg[rowptr[r] : rowptr[r+1]][:]), 0 for empty rows; h in {32, 64, 128, 256}.
+ * Replaces torch_scatter scatter(reduce='mean') behind PyG MessagePassing(aggr='mean')
+ * (models/mpnn.py:46, models/magnet_gnn.py:54) for CSR-sorted messages. */
+int magnet_segment_mean_f32(const float* msg, const int32_t* rowptr, int n_rows, int h, float* out, void* stream);
+
+/* ---- MPNN / MPNN_2d (hidden width 128) ---- */
+/* node_in[n] = [u[n,0:tw] | pos[n,1]/L[0..dpos) | pos[n,0]/tmax | 0-pad to kin]; models/mpnn.py:180-191,
+ * models/mpnn_2d.py:179 (the x/Lx, x/Ly quirk).  L and tmax are device scalars/vectors. */
+int magnet_mpnn_node_input_f32(const float* u, const float* pos, int pos_ld, const float* Lvec, const float* tmax,
+                               int n, int tw, int dpos, int kin, float* out, void* stream);
+/* agg[i] = mean_{e: tgt(e)=i} Swish(W2 * Swish(A[i] + Bm[src(e)]) + b2); GNN_Layer.message + aggregate,
+ * models/mpnn.py:73-79,46, with message_net_1 split per node.  Follow with
+ * magnet_segmean_fixup_f32(rowptr, n, 128, partials, agg). */
+int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
+                         const int32_t* rowptr, int n_edges, const void* w2_packed, const float* b2, float* agg,
+                         float* partials, void* stream);
+/* out[n][k] = u[n][tw-1] + dt*(k+1) * Conv1d(8->1,k2)([Swish](Conv1d(1->8,k1,stride s1)(h[n])))[k];
+ * models/mpnn.py:197-201 with the conv specs of :140-163. */
+int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1, int k1,
+                            int s1, const float* w2, const float* b2, int k2, int use_swish, const float* dt,
+                            float* out, void* stream);
+/* PyG InstanceNorm(x, batch) with batch = contiguous blocks of rows_per_graph rows (models/mpnn.py:63,70).
+ * workspace: (2*n_graphs*ceil(rows_per_graph/64) + 2*n_graphs) * H floats. */
+int magnet_instance_norm_f32(const float* x, int n_graphs, int rows_per_graph, int H, float eps, float* y,
+                             float* workspace, void* stream);
+
+/* ---- neighbour search / CSR (torch_cluster radius_graph / knn call sites: models/mpnn.py:245,
+ *      models/magnet_gnn.py:247,293) ---- */
+/* nbr[q*cap + 0..cnt[q]) = first `cap` nodes (ascending index, same graph) with dist^2 < r2 */
+int magnet_radius_search_f32(const float* x, int dim, int n_nodes, const int32_t* graph_ptr, int n_graphs, float r2,
+                             int cap, int32_t* nbr, int32_t* cnt, void* stream);
+int magnet_radius_offsets(const int32_t* nbr, const int32_t* cnt, int n_nodes, int cap, int loop, int32_t* qptr,
+                          void* stream);
+int magnet_radius_emit_pairs(const int32_t* nbr, const int32_t* cnt, const int32_t* qptr, int n_nodes, int cap,
+                             int loop, int32_t* found, int32_t* query, void* stream);
+int magnet_csr_by_target(const int32_t* src, const int32_t* tgt, int n_edges, int n_nodes, int32_t* rowptr,
+                         int32_t* cursor, int32_t* eid_scratch, int32_t* perm, int32_t* src_out, int32_t* tgt_out,
+                         void* stream);
+int magnet_i64_to_i32(const int64_t* a, int n, int32_t* b, void* stream);
+int magnet_pairs_to_edge_index(const int32_t* row0, const int32_t* row1, int n_edges, int64_t* edge_index,
+                               void* stream);
+int magnet_knn_f32(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_ptr, int n_graphs, int dim,
+                   int n_queries, int k, int32_t* out, void* stream);
+
+/* ---- MAgNet feature builders / INR decoders (magnet_kernels.hip) ---- */
+int magnet_node_features_f32(const float* u, const float* x, const float* t_last, int n_graphs, int nodes_per_graph,
+                             int T, int d, int ld, float* out, void* stream);
+int magnet_euler_update_f32(const float* ret, int ld_ret, const float* last, const float* t, int t_ld, int n_graphs,
+                            int nodes_per_graph, int T, int T_out, float* out, void* stream);
+int magnet_inr_knn_prepare_f32(const float* lr_coords, const float* hr_coords, const int32_t* nn, int k, int d,
+                               int n_graphs, int L, int Nq, int32_t* nn2, float* rel, float* w, void* stream);
+int magnet_inr_knn_blend_f32(const float* base, const float* w, const float* vals, const int32_t* nn2,
+                             const float* t, int t_ld, const float* wv, const float* wt, int n_graphs, int L, int Nq,
+                             int T, int C, int mode, float* z, void* stream);
+int magnet_inr_grid_prepare_f32(const float* coords, const float* cell, const float* x_t, const float* t, int t_ld,
+                                int n_graphs, int Nq, int T, int W, int d, int32_t* cell_idx, float* tail,
+                                float* area, void* stream);
+int magnet_inr_grid_blend_f32(const float* p, const float* area, int n_rows, int T, int C, int nshift, float* z,
+                              void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGNET_HIP_H */

@@ -1,0 +1,69 @@
+"""ctypes binding of libmagnet_hip.so (the C ABI declared in include/magnet_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a symbol cannot be resolved
+this module raises, and every op in magnet_amd.ops refuses tensors that are not on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libmagnet_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "magnet_hip.h")
+
+MAX_KT, MAX_LAYERS = 12, 6
+ACT_NONE, ACT_SWISH, ACT_RELU = 0, 1, 2
+EPI_STORE, EPI_STORE_RES, EPI_SEGMEAN = 0, 1, 2
+
+
+class Src(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("idx", C.c_void_p), ("ld", C.c_int32), ("col", C.c_int32),
+                ("scale", C.c_float), ("rdiv", C.c_int32)]
+
+
+class KTile(C.Structure):
+    _fields_ = [("s", Src * 2), ("n", C.c_int32), ("pad_", C.c_int32 * 3)]
+
+
+class Layer(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p)]
+
+
+class MlpArgs(C.Structure):
+    _fields_ = [("M", C.c_int32), ("nkt", C.c_int32), ("kt", KTile * MAX_KT), ("layer", Layer * MAX_LAYERS),
+                ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("ln_eps", C.c_float),
+                ("y", C.c_void_p), ("ldy", C.c_int32), ("ncols", C.c_int32),
+                ("res", C.c_void_p), ("ldres", C.c_int32),
+                ("tgt", C.c_void_p), ("rowptr", C.c_void_p), ("partials", C.c_void_p), ("pad2_", C.c_int32)]
+
+
+def declared_symbols() -> list[str]:
+    """every function name declared in include/magnet_hip.h"""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(magnet_\w+)\s*\(", txt)))
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m magnet_amd.build` (hipcc, gfx950). "
+                "magnet_amd has no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        for name in declared_symbols():
+            fn = getattr(_lib, name)          # AttributeError if the .so does not export it
+            fn.restype = C.c_int
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise RuntimeError(f"{what} failed with code {code}"
+                           + (" (unsupported argument)" if code < 0 else " (hipError_t)"))

@@ -1,0 +1,69 @@
+"""Compile magnet_amd/csrc/*.hip for gfx950 into magnet_amd/csrc/libmagnet_hip.so (in-tree).
+
+    python -m magnet_amd.build            # rebuild if sources are newer than the library
+    python -m magnet_amd.build --force
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so travels to the
+GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libmagnet_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.cuh"))
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def _compile(src: str) -> str:
+    obj = os.path.splitext(src)[0] + ".o"
+    hdr = max(os.path.getmtime(p) for p in glob.glob(os.path.join(CSRC, "*.cuh")))
+    if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr):
+        return obj
+    cmd = ["hipcc", *FLAGS, "-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB
+    srcs = sources()
+    if force:
+        for s in srcs:
+            o = os.path.splitext(s)[0] + ".o"
+            if os.path.exists(o):
+                os.remove(o)
+    with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        objs = list(ex.map(_compile, srcs))
+    r = subprocess.run(["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr)
+    if verbose:
+        print(f"[magnet_amd.build] built {LIB} from {len(srcs)} sources", file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

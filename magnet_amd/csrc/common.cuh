@@ -1,0 +1,274 @@
+// Shared device primitives for the gfx950 (MI355X) MAgNet kernels.
+//
+// Core idea ("register-chained transposed MLP"): a wave owns 32 rows (edges, nodes or INR
+// queries).  Every Linear is computed as  Y^T = W * X^T  with v_mfma_f32_32x32x2_f32:
+//   A operand = weight fragment  W[n0 + (lane&31)][k]      (pre-packed, 1 KiB coalesced loads)
+//   B operand = activation       X[row = lane&31][k]
+//   C/D       = Y^T tile: lane (row = lane&31, half = lane>>5) register r holds
+//               Y[row][n0 + (r&3) + 8*(r>>2) + 4*half]
+// The k index an MFMA step consumes is free to choose as long as A and B agree; step s of a
+// 32-wide k tile uses k = (s&3) + 8*(s>>2) + 4*half -- exactly the C/D register map.  So the
+// output registers of one layer ARE the B operands of the next: a whole MLP runs in VGPRs with
+// no LDS round trip, no transposes and no barriers.  fp32 MFMA is exact fp32 (fmaf chain), so
+// results match the reference's fp32 Linear up to summation order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MAGNET_MAX_KT 12      // first-layer K up to 384
+#define MAGNET_MAX_LAYERS 6
+
+enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
+enum { EPI_STORE = 0, EPI_STORE_RES = 1, EPI_SEGMEAN = 2 };
+
+// one source of a first-layer k tile: value = scale * p[(idx ? idx[row] : row / rdiv) * ld + col + k]
+struct MagnetSrc {
+    const float* p;
+    const int32_t* idx;
+    int32_t ld;
+    int32_t col;
+    float scale;
+    int32_t rdiv;      // >=1: dense sources may be shared by rdiv consecutive rows
+};
+struct MagnetKTile {
+    MagnetSrc s[2];
+    int32_t n;         // 1 or 2 sources (summed)
+    int32_t pad_[3];
+};
+struct MagnetLayer {
+    const f32x4* w;    // packed [KT][NT][4][64] float4 (see magnet_hip.h)
+    const float* b;    // [NT*32] zero padded
+};
+struct MagnetMlpArgs {
+    int32_t M;                     // rows
+    int32_t nkt;                   // first layer k tiles
+    MagnetKTile kt[MAGNET_MAX_KT];
+    MagnetLayer layer[MAGNET_MAX_LAYERS];
+    const float* ln_g;             // LayerNorm gain/bias (ncols), used when LN
+    const float* ln_b;
+    float ln_eps;
+    // store epilogue
+    float* y;
+    int32_t ldy;
+    int32_t ncols;                 // valid output columns (<= OT*32)
+    const float* res;              // residual (same layout as y) for EPI_STORE_RES
+    int32_t ldres;
+    // segment-mean epilogue (rows are CSR-ordered edges)
+    const int32_t* tgt;            // [M] target of each edge
+    const int32_t* rowptr;         // [N+1]
+    float* partials;               // [ntiles][2][ncols]
+    int32_t pad2_;
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float act_swish(float x) {
+    // x * sigmoid(x); exp overflow -> rcp(inf) = 0 -> -0, the correct limit
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+
+template <int ACT>
+__device__ __forceinline__ void apply_act(f32x16& v) {
+    if (ACT == ACT_SWISH) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = act_swish(v[i]);
+    } else if (ACT == ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.0f);
+    }
+}
+
+// accumulators <- bias (lane (row, half) register 4g+c holds column nt*32 + 8g + 4half + c)
+template <int NT>
+__device__ __forceinline__ void init_bias(f32x16 (&out)[NT], const float* __restrict__ b, int half) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(b + nt * 32 + 8 * g + 4 * half);
+            out[nt][4 * g + 0] = t[0];
+            out[nt][4 * g + 1] = t[1];
+            out[nt][4 * g + 2] = t[2];
+            out[nt][4 * g + 3] = t[3];
+        }
+    }
+}
+
+// out[nt] += W(kt, nt) * in   for one 32-wide k tile
+template <int NT>
+__device__ __forceinline__ void mma_ktile(const f32x16& in, f32x16 (&out)[NT], const f32x4* __restrict__ w,
+                                           int kt, int lane) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const f32x4* wp = w + (size_t)((kt * NT + nt) * 4) * 64 + lane;
+        const f32x4 w0 = wp[0], w1 = wp[64], w2 = wp[128], w3 = wp[192];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[nt] = mfma32(w0[c], in[c], out[nt]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[nt] = mfma32(w1[c], in[4 + c], out[nt]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[nt] = mfma32(w2[c], in[8 + c], out[nt]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[nt] = mfma32(w3[c], in[12 + c], out[nt]);
+    }
+}
+
+// register-resident layer: out = W * in + b
+template <int KT, int NT>
+__device__ __forceinline__ void dense_layer(const f32x16 (&in)[KT], f32x16 (&out)[NT], const MagnetLayer& L,
+                                             int lane) {
+    init_bias<NT>(out, L.b, lane >> 5);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) mma_ktile<NT>(in[kt], out, L.w, kt, lane);
+}
+
+// first-layer k tile from the (gathered / concatenated / differenced) sources
+__device__ __forceinline__ f32x16 load_ktile(const MagnetKTile& d, int row, int half) {
+    f32x16 v;
+    {
+        const MagnetSrc& a = d.s[0];
+        const long r = a.idx ? (long)a.idx[row] : (long)(row / a.rdiv);
+        const float* p = a.p + r * a.ld + a.col + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p + 8 * g);
+            v[4 * g + 0] = t[0] * a.scale;
+            v[4 * g + 1] = t[1] * a.scale;
+            v[4 * g + 2] = t[2] * a.scale;
+            v[4 * g + 3] = t[3] * a.scale;
+        }
+    }
+    if (d.n > 1) {
+        const MagnetSrc& a = d.s[1];
+        const long r = a.idx ? (long)a.idx[row] : (long)(row / a.rdiv);
+        const float* p = a.p + r * a.ld + a.col + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p + 8 * g);
+            v[4 * g + 0] += t[0] * a.scale;
+            v[4 * g + 1] += t[1] * a.scale;
+            v[4 * g + 2] += t[2] * a.scale;
+            v[4 * g + 3] += t[3] * a.scale;
+        }
+    }
+    return v;
+}
+
+// LayerNorm over the NT*32 columns of each row (row split across lanes l and l^32)
+template <int NT>
+__device__ __forceinline__ void layer_norm_rows(f32x16 (&v)[NT], const float* __restrict__ g,
+                                                 const float* __restrict__ b, float eps, int half) {
+    float s = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += v[nt][i];
+    s += __shfl_xor(s, 32);
+    const float mean = s / (float)(NT * 32);
+    float q = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float d = v[nt][i] - mean;
+            q += d * d;
+        }
+    q += __shfl_xor(q, 32);
+    const float rstd = 1.0f / sqrtf(q / (float)(NT * 32) + eps);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int n0 = nt * 32 + 8 * gq + 4 * half;
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + n0);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b + n0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[nt][4 * gq + c] = (v[nt][4 * gq + c] - mean) * rstd * gg[c] + bb[c];
+        }
+}
+
+// rows -> global memory (optionally + residual); ragged widths handled per element
+template <int NT, bool RES>
+__device__ __forceinline__ void store_rows(const f32x16 (&v)[NT], float* __restrict__ y, int ldy, int ncols,
+                                            const float* __restrict__ res, int ldres, int row, bool row_ok,
+                                            int half) {
+    if (!row_ok) return;
+    const bool vec = ((ldy & 3) == 0) && (!RES || (ldres & 3) == 0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n0 = nt * 32 + 8 * g + 4 * half;
+            if (n0 >= ncols) continue;
+            f32x4 t = {v[nt][4 * g], v[nt][4 * g + 1], v[nt][4 * g + 2], v[nt][4 * g + 3]};
+            if (vec && n0 + 3 < ncols) {
+                if (RES) t += *reinterpret_cast<const f32x4*>(res + (size_t)row * ldres + n0);
+                *reinterpret_cast<f32x4*>(y + (size_t)row * ldy + n0) = t;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (n0 + c < ncols) {
+                        float x = t[c];
+                        if (RES) x += res[(size_t)row * ldres + n0 + c];
+                        y[(size_t)row * ldy + n0 + c] = x;
+                    }
+            }
+        }
+}
+
+// Segment-mean epilogue.  The wave's 32 rows are consecutive CSR edges [e0, e0+nval).  Tile
+// values go through a wave-private LDS slab so that lanes become feature owners; runs of equal
+// target are summed in edge order.  A run that lies wholly inside the tile is divided by the
+// row's degree and written; a run cut by a tile boundary is written to partials[tile][0] (run
+// entered from the previous tile) or partials[tile][1] (run continues into the next tile) and
+// combined, in tile order, by k_segmean_fixup -> bitwise deterministic, no atomics.
+template <int NT>
+__device__ __forceinline__ void segmean_epilogue(const f32x16 (&v)[NT], float* lds /* [32][NT*32+4] */,
+                                                  int tile, int nval, int tgt, const int32_t* __restrict__ rowptr,
+                                                  float* __restrict__ agg, float* __restrict__ partials,
+                                                  int lane) {
+    constexpr int D = NT * 32;
+    constexpr int LD = D + 4;
+    constexpr int NM = (D + 63) / 64;
+    const int j = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 t = {v[nt][4 * g], v[nt][4 * g + 1], v[nt][4 * g + 2], v[nt][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(lds + j * LD + nt * 32 + 8 * g + 4 * half) = t;
+        }
+    __syncthreads();
+    float acc[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) acc[m] = 0.f;
+    const int e0 = tile * 32;
+    for (int jj = 0; jj < nval; ++jj) {
+        const int tj = __builtin_amdgcn_readlane(tgt, jj);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int f = lane + 64 * m;
+            if (f < D) acc[m] += lds[jj * LD + f];
+        }
+        const int tn = (jj + 1 < nval) ? __builtin_amdgcn_readlane(tgt, jj + 1) : -1;
+        if (tn != tj) {
+            const int s = rowptr[tj], e = rowptr[tj + 1];
+            const bool complete = (s >= e0) && (e <= e0 + 32);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int f = lane + 64 * m;
+                if (f < D) {
+                    if (complete) agg[(size_t)tj * D + f] = acc[m] / (float)(e - s);
+                    else partials[((size_t)tile * 2 + (s < e0 ? 0 : 1)) * D + f] = acc[m];
+                }
+                acc[m] = 0.f;
+            }
+        }
+    }
+    __syncthreads();
+}

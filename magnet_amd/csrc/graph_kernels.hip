@@ -1,0 +1,292 @@
+// Neighbour search, CSR construction and the standalone CSR segment-mean ("scatter mean").
+//
+// Search semantics restate torch_cluster's CUDA kernels (not vendored in the reference; called at
+// models/mpnn.py:245, models/magnet_gnn.py:247,293): per query, scan the query's graph segment in
+// ascending index, keep candidates with dist^2 < r^2 (strict), stop after `cap` hits; knn keeps an
+// insertion-sorted top-k with strict '>' (lower index wins ties).  dist^2 is accumulated
+// coordinate by coordinate with separately rounded multiply and add (no FMA contraction), the same
+// arithmetic the oracle uses.
+#include "common.cuh"
+
+__device__ __forceinline__ float dist2(const float* __restrict__ x, int a, const float* __restrict__ yq, int dim) {
+    float d = 0.f;
+    for (int k = 0; k < dim; ++k) {
+        const float t = __fsub_rn(yq[k], x[(size_t)a * dim + k]);
+        d = __fadd_rn(d, __fmul_rn(t, t));
+    }
+    return d;
+}
+
+__device__ __forceinline__ int graph_of(const int32_t* __restrict__ gptr, int ng, int q) {
+    int g = 0;
+    while (g + 1 < ng && q >= gptr[g + 1]) ++g;
+    return g;
+}
+
+// one wave per query; 64 candidates per step in ascending index order
+__global__ void __launch_bounds__(256) k_radius(const float* __restrict__ x, int dim, int N,
+                                                const int32_t* __restrict__ gptr, int ng, float r2, int cap,
+                                                int32_t* __restrict__ nbr, int32_t* __restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= N) return;
+    const int g = graph_of(gptr, ng, q);
+    const int s = gptr[g], e = gptr[g + 1];
+    float yq[3];
+    for (int k = 0; k < dim; ++k) yq[k] = x[(size_t)q * dim + k];
+    int count = 0;
+    for (int base = s; base < e && count < cap; base += 64) {
+        const int c = base + lane;
+        const bool hit = (c < e) && (dist2(x, c < e ? c : s, yq, dim) < r2);
+        const unsigned long long mask = __ballot(hit);
+        const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+        if (hit && pos < cap) nbr[(size_t)q * cap + pos] = c;
+        count += __popcll(mask);
+    }
+    if (lane == 0) cnt[q] = count < cap ? count : cap;
+}
+
+// kept[q] = number of neighbours kept for query q (self dropped when !loop)
+__global__ void k_kept(const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int N, int cap, int loop,
+                       int32_t* __restrict__ kept) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > N) return;
+    if (q == N) { kept[N] = 0; return; }
+    int c = cnt[q];
+    if (!loop)
+        for (int k = 0; k < cnt[q]; ++k) c -= (nbr[(size_t)q * cap + k] == q);
+    kept[q] = c;
+}
+
+// in-place exclusive scan of n ints by one 1024-thread block (n up to a few million)
+__global__ void __launch_bounds__(1024) k_exclusive_scan(int32_t* __restrict__ v, int n) {
+    __shared__ int sums[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = t * per, e = min(n, b + per);
+    int s = 0;
+    for (int i = b; i < e; ++i) s += v[i];
+    sums[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int add = t >= off ? sums[t - off] : 0;
+        __syncthreads();
+        sums[t] += add;
+        __syncthreads();
+    }
+    int run = sums[t] - s;
+    for (int i = b; i < e; ++i) {
+        const int x = v[i];
+        v[i] = run;
+        run += x;
+    }
+}
+
+// query-major edge list: found[qptr[q] + k], query[...] = q   (== torch_cluster / PyG edge order)
+__global__ void k_emit_pairs(const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt,
+                             const int32_t* __restrict__ qptr, int N, int cap, int loop, int32_t* __restrict__ found,
+                             int32_t* __restrict__ query) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    int o = qptr[q];
+    for (int k = 0; k < cnt[q]; ++k) {
+        const int f = nbr[(size_t)q * cap + k];
+        if (!loop && f == q) continue;
+        found[o] = f;
+        query[o] = q;
+        ++o;
+    }
+}
+
+// ---- generic CSR-by-target of an arbitrary (src, tgt) edge list, stable in edge order
+__global__ void k_count_tgt(const int32_t* __restrict__ tgt, int E, int32_t* __restrict__ deg) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) atomicAdd(&deg[tgt[e]], 1);
+}
+__global__ void k_fill_tgt(const int32_t* __restrict__ tgt, int E, const int32_t* __restrict__ rowptr,
+                           int32_t* __restrict__ cursor, int32_t* __restrict__ eid_unsorted) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int t = tgt[e];
+    eid_unsorted[rowptr[t] + atomicAdd(&cursor[t], 1)] = e;
+}
+// one wave per row: rank-sort the row's edge ids ascending, then emit (perm, src, tgt) in CSR order
+__global__ void __launch_bounds__(256) k_sort_rows(const int32_t* __restrict__ rowptr, int N,
+                                                   const int32_t* __restrict__ eid_unsorted,
+                                                   const int32_t* __restrict__ src_in, int32_t* __restrict__ perm,
+                                                   int32_t* __restrict__ src_out, int32_t* __restrict__ tgt_out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const int s = rowptr[r], d = rowptr[r + 1] - s;
+    for (int i = lane; i < d; i += 64) {
+        const int v = eid_unsorted[s + i];
+        int rank = 0;
+        for (int k = 0; k < d; ++k) rank += (eid_unsorted[s + k] < v);
+        perm[s + rank] = v;
+        src_out[s + rank] = src_in[v];
+        tgt_out[s + rank] = r;
+    }
+}
+
+__global__ void k_i64_to_i32(const int64_t* __restrict__ a, int n, int32_t* __restrict__ b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = (int32_t)a[i];
+}
+__global__ void k_pairs_to_i64(const int32_t* __restrict__ r0, const int32_t* __restrict__ r1, int E,
+                               int64_t* __restrict__ ei) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < E) {
+        ei[i] = r0[i];
+        ei[(size_t)E + i] = r1[i];
+    }
+}
+
+// ---- k nearest x for every y, same graph, thread per query, k <= 8
+__global__ void k_knn(const float* __restrict__ x, const int32_t* __restrict__ xptr, const float* __restrict__ y,
+                      const int32_t* __restrict__ yptr, int ng, int dim, int M, int k, int32_t* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= M) return;
+    const int g = graph_of(yptr, ng, q);
+    float bd[8];
+    int bi[8];
+    for (int i = 0; i < 8; ++i) { bd[i] = 1e10f; bi[i] = -1; }
+    float yq[3];
+    for (int c = 0; c < dim; ++c) yq[c] = y[(size_t)q * dim + c];
+    for (int n = xptr[g]; n < xptr[g + 1]; ++n) {
+        const float d = dist2(x, n, yq, dim);
+#pragma unroll
+        for (int e1 = 0; e1 < 8; ++e1) {
+            if (e1 < k && bd[e1] > d) {
+#pragma unroll
+                for (int e2 = 7; e2 > 0; --e2)
+                    if (e2 > e1 && e2 < k) { bd[e2] = bd[e2 - 1]; bi[e2] = bi[e2 - 1]; }
+                bd[e1] = d;
+                bi[e1] = n;
+                break;
+            }
+        }
+    }
+    for (int i = 0; i < k; ++i) out[(size_t)q * k + i] = bi[i];
+}
+
+// ---- standalone CSR segment mean: out[r] = mean of msg[rowptr[r] .. rowptr[r+1]) (0 when empty).
+// HBM-bound: every message row is read exactly once with 16 B per lane, LPR = H/4 lanes per row,
+// 64/LPR edges per wave pass, one wave per target row; partial sums meet in a __shfl_xor tree.
+// Replaces torch_scatter's atomic scatter-mean behind PyG aggr='mean' (models/mpnn.py:46,
+// models/magnet_gnn.py:54).  Algorithmic bytes: E*H*4 + N*H*4 + 4*(N+1).
+template <int H>
+__global__ void __launch_bounds__(256) k_segment_mean(const float* __restrict__ msg,
+                                                      const int32_t* __restrict__ rowptr, int N,
+                                                      float* __restrict__ out) {
+    constexpr int LPR = H / 4;          // lanes per message row
+    constexpr int EPP = 64 / LPR;       // edges per pass
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const int s = rowptr[r], e = rowptr[r + 1];
+    const int sub = lane / LPR, col = (lane % LPR) * 4;
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
+    int i = s + sub;
+    for (; i + 3 * EPP < e; i += 4 * EPP) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(msg + (size_t)i * H + col);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(msg + (size_t)(i + EPP) * H + col);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(msg + (size_t)(i + 2 * EPP) * H + col);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(msg + (size_t)(i + 3 * EPP) * H + col);
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; i < e; i += EPP) a0 += *reinterpret_cast<const f32x4*>(msg + (size_t)i * H + col);
+    f32x4 a = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] += __shfl_xor(a[c], off);
+    }
+    if (sub == 0) {
+        const float dn = (float)max(e - s, 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = a[c] / dn;
+        *reinterpret_cast<f32x4*>(out + (size_t)r * H + col) = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------ C entry points
+#define S_ (hipStream_t) stream
+#define LAUNCH_CHECK() return (int)hipGetLastError()
+static inline unsigned nb(long n, int b) { return (unsigned)((n + b - 1) / b); }
+
+extern "C" int magnet_radius_search_f32(const float* x, int dim, int n_nodes, const int32_t* graph_ptr, int n_graphs,
+                                        float r2, int cap, int32_t* nbr, int32_t* cnt, void* stream) {
+    if (n_nodes <= 0) return 0;
+    if (dim < 1 || dim > 3 || cap < 1) return -2;
+    hipLaunchKernelGGL(k_radius, dim3(nb(n_nodes, 4)), dim3(256), 0, S_, x, dim, n_nodes, graph_ptr, n_graphs, r2, cap,
+                       nbr, cnt);
+    LAUNCH_CHECK();
+}
+
+// qptr[n_nodes + 1] <- exclusive scan of the kept-neighbour counts; qptr[n_nodes] = E
+extern "C" int magnet_radius_offsets(const int32_t* nbr, const int32_t* cnt, int n_nodes, int cap, int loop,
+                                     int32_t* qptr, void* stream) {
+    hipLaunchKernelGGL(k_kept, dim3(nb(n_nodes + 1, 256)), dim3(256), 0, S_, nbr, cnt, n_nodes, cap, loop, qptr);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, S_, qptr, n_nodes + 1);
+    LAUNCH_CHECK();
+}
+
+extern "C" int magnet_radius_emit_pairs(const int32_t* nbr, const int32_t* cnt, const int32_t* qptr, int n_nodes,
+                                        int cap, int loop, int32_t* found, int32_t* query, void* stream) {
+    if (n_nodes <= 0) return 0;
+    hipLaunchKernelGGL(k_emit_pairs, dim3(nb(n_nodes, 256)), dim3(256), 0, S_, nbr, cnt, qptr, n_nodes, cap, loop,
+                       found, query);
+    LAUNCH_CHECK();
+}
+
+// CSR by target, stable in input edge order.  rowptr[n+1], cursor[n] (scratch), eid_scratch[E],
+// perm/src_out/tgt_out[E].  rowptr and cursor must be zero on entry.
+extern "C" int magnet_csr_by_target(const int32_t* src, const int32_t* tgt, int n_edges, int n_nodes, int32_t* rowptr,
+                                    int32_t* cursor, int32_t* eid_scratch, int32_t* perm, int32_t* src_out,
+                                    int32_t* tgt_out, void* stream) {
+    if (n_edges > 0) hipLaunchKernelGGL(k_count_tgt, dim3(nb(n_edges, 256)), dim3(256), 0, S_, tgt, n_edges, rowptr);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, S_, rowptr, n_nodes + 1);
+    if (n_edges > 0) {
+        hipLaunchKernelGGL(k_fill_tgt, dim3(nb(n_edges, 256)), dim3(256), 0, S_, tgt, n_edges, rowptr, cursor,
+                           eid_scratch);
+        hipLaunchKernelGGL(k_sort_rows, dim3(nb(n_nodes, 4)), dim3(256), 0, S_, rowptr, n_nodes, eid_scratch, src, perm,
+                           src_out, tgt_out);
+    }
+    LAUNCH_CHECK();
+}
+
+extern "C" int magnet_i64_to_i32(const int64_t* a, int n, int32_t* b, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_i64_to_i32, dim3(nb(n, 256)), dim3(256), 0, S_, a, n, b);
+    LAUNCH_CHECK();
+}
+extern "C" int magnet_pairs_to_edge_index(const int32_t* row0, const int32_t* row1, int n_edges, int64_t* edge_index,
+                                          void* stream) {
+    if (n_edges <= 0) return 0;
+    hipLaunchKernelGGL(k_pairs_to_i64, dim3(nb(n_edges, 256)), dim3(256), 0, S_, row0, row1, n_edges, edge_index);
+    LAUNCH_CHECK();
+}
+
+extern "C" int magnet_knn_f32(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_ptr, int n_graphs,
+                              int dim, int n_queries, int k, int32_t* out, void* stream) {
+    if (n_queries <= 0) return 0;
+    if (k < 1 || k > 8 || dim < 1 || dim > 3) return -2;
+    hipLaunchKernelGGL(k_knn, dim3(nb(n_queries, 128)), dim3(128), 0, S_, x, x_ptr, y, y_ptr, n_graphs, dim, n_queries,
+                       k, out);
+    LAUNCH_CHECK();
+}
+
+extern "C" int magnet_segment_mean_f32(const float* msg, const int32_t* rowptr, int n_rows, int h, float* out,
+                                       void* stream) {
+    if (n_rows <= 0) return 0;
+    const dim3 grid(nb(n_rows, 4)), block(256);
+    switch (h) {
+        case 32: hipLaunchKernelGGL(k_segment_mean<32>, grid, block, 0, S_, msg, rowptr, n_rows, out); break;
+        case 64: hipLaunchKernelGGL(k_segment_mean<64>, grid, block, 0, S_, msg, rowptr, n_rows, out); break;
+        case 128: hipLaunchKernelGGL(k_segment_mean<128>, grid, block, 0, S_, msg, rowptr, n_rows, out); break;
+        case 256: hipLaunchKernelGGL(k_segment_mean<256>, grid, block, 0, S_, msg, rowptr, n_rows, out); break;
+        default: return -2;
+    }
+    LAUNCH_CHECK();
+}

@@ -1,0 +1,222 @@
+// MAgNet[GNN] / MAgNet[CNN] feature builders, Euler update and the two INR decoders' gather /
+// blend stages.  The MLPs between them run in magnet_mlp_f32 (mlp_kernels.hip).
+#include "common.cuh"
+
+// node features [u (T) | x (d) | t_last[k mod B] | 0-pad]  (models/magnet_gnn.py:298-302; the
+// repeat(N,1) tile gives node k the time of sample k mod B - quirk Q5, reproduced on purpose)
+__global__ void k_node_features(const float* __restrict__ u, const float* __restrict__ x,
+                                const float* __restrict__ t_last, int B, long n_total, int T, int d, int ld,
+                                float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total * ld) return;
+    const long n = i / ld;
+    const int c = (int)(i % ld);
+    float v = 0.f;
+    if (c < T) v = u[n * T + c];
+    else if (c < T + d) v = x[n * d + (c - T)];
+    else if (c == T + d) v = t_last[n % B];
+    out[i] = v;
+}
+
+// out[b][k][i] = last[b*n + i] + (t[b][T+k] - t[b][T-1]) * ret[(b*n + i)*ld + k]
+// (models/magnet_gnn.py:359-369)
+__global__ void k_euler_update(const float* __restrict__ ret, int ld, const float* __restrict__ last,
+                               const float* __restrict__ t, int t_ld, int B, int n, int T, int T_out,
+                               float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * T_out * n) return;
+    const int node = (int)(i % n);
+    const int k = (int)((i / n) % T_out);
+    const int b = (int)(i / ((long)n * T_out));
+    const float delta = t[(size_t)b * t_ld + T + k] - t[(size_t)b * t_ld + T - 1];
+    const size_t r = (size_t)b * n + node;
+    out[i] = last[r] + delta * ret[r * ld + k];
+}
+
+// ---- k-NN INR (models/magnet_gnn.py:247-268): per query and j in {0,1} (only the two nearest are
+// blended, Q9): gather row of the neighbour, rel = X[nb] - hr, w = ||rel||_2 ** 2
+__global__ void k_inr_knn_prepare(const float* __restrict__ lr, const float* __restrict__ hr,
+                                  const int32_t* __restrict__ nn, int k, int d, long nq_total,
+                                  int32_t* __restrict__ nn2, float* __restrict__ rel, float* __restrict__ w) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;   // r = q*2 + j
+    if (r >= nq_total * 2) return;
+    const long q = r >> 1;
+    const int j = (int)(r & 1);
+    const int nb = nn[q * k + j];
+    nn2[r] = nb;
+    float s = 0.f;
+    for (int c = 0; c < 32; ++c) {
+        float v = 0.f;
+        if (c < d) {
+            v = lr[(size_t)nb * d + c] - hr[q * d + c];
+            s = __fadd_rn(s, __fmul_rn(v, v));
+        }
+        rel[r * 32 + c] = v;
+    }
+    const float nrm = sqrtf(s);
+    w[r] = nrm * nrm;
+}
+
+// z[(q, i)][c] = blend_j( base[(q, j)][c] + wv[c] * vals[nb_j][i] + wt[c] * t[b][i] )
+__global__ void k_inr_knn_blend(const float* __restrict__ base, const float* __restrict__ w,
+                                const float* __restrict__ vals, const int32_t* __restrict__ nn2,
+                                const float* __restrict__ t, int t_ld, const float* __restrict__ wv,
+                                const float* __restrict__ wt, int L, int Nq, int T, int C, int mode, long total,
+                                float* __restrict__ z) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int ti = (int)((i / C) % T);
+    const long q = i / ((long)C * T);
+    const int b = (int)(q / Nq);
+    const float tt = t[(size_t)b * t_ld + ti];
+    const float l0 = base[(2 * q) * C + c] + wv[c] * vals[(size_t)nn2[2 * q] * T + ti] + wt[c] * tt;
+    const float l1 = base[(2 * q + 1) * C + c] + wv[c] * vals[(size_t)nn2[2 * q + 1] * T + ti] + wt[c] * tt;
+    float w0 = w[2 * q], w1 = w[2 * q + 1];
+    float r;
+    if (mode == 0) {
+        r = (l0 * w1 + l1 * w0) / (w1 + w0);                    // 'area': weights swapped
+    } else {
+        if (mode == 1) { w0 = 1.f / w0; w1 = 1.f / w1; }          // 'knn'
+        else { const float a = 1.f - L * w0, bb = 1.f - L * w1; w0 = a * a * a; w1 = bb * bb * bb; }   // 'sph'
+        r = (l0 * w0 + l1 * w1) / (w1 + w0);
+    }
+    z[i] = r;
+}
+
+// ---- grid INR (models/magnet_cnn.py:249-276, models/magnet_cnn_2d.py:248-283): per query and
+// shift: nearest cell (grid_sample nearest / border / align_corners=False), rel, cell*W, area,
+// and per input step the tail [q_inp_i | rel | cell*W | t_i | 0-pad] + the gather row index.
+__device__ __forceinline__ int nearest_cell(float c, int W) {
+    float u = ((c + 1.f) * (float)W - 1.f) / 2.f;
+    u = fminf((float)(W - 1), fmaxf(u, 0.f));
+    return (int)rintf(u);                                         // round half to even == nearbyint
+}
+__global__ void k_inr_grid_prepare(const float* __restrict__ coords, const float* __restrict__ cell,
+                                   const float* __restrict__ x_t, const float* __restrict__ t, int t_ld, int B,
+                                   int Nq, int T, int W, int d, int32_t* __restrict__ cell_idx,
+                                   float* __restrict__ tail, float* __restrict__ area) {
+    const int S = d == 2 ? 4 : 2;
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;   // r = (b*Nq + q)*S + s
+    if (r >= (long)B * Nq * S) return;
+    const int s = (int)(r % S);
+    const long bq = r / S;
+    const int b = (int)(bq / Nq);
+    const float lo = (float)(-1.0 + 1e-6), hi = (float)(1.0 - 1e-6);
+    const float c0 = (float)(-1.0 + 1.0 / (double)W), c1 = (float)(2.0 / (double)W);
+    const long cells = d == 2 ? (long)W * W : W;
+    int idx[2] = {0, 0};
+    float rel[2] = {0.f, 0.f}, cw[2] = {0.f, 0.f};
+    for (int a = 0; a < d; ++a) {
+        const int v = d == 2 ? (a == 0 ? (s >> 1) * 2 - 1 : (s & 1) * 2 - 1) : s * 2 - 1;   // (-,-),(-,+),(+,-),(+,+)
+        const float off = (float)((double)v / (double)W + 1e-6);
+        const float co = coords[bq * d + a];
+        const float c = fminf(hi, fmaxf(lo, co + off));
+        idx[a] = nearest_cell(c, W);
+        const float qc = __fadd_rn(c0, __fmul_rn(c1, (float)idx[a]));
+        rel[a] = (co - qc) * (float)W;
+        cw[a] = cell[bq * d + a] * (float)W;
+    }
+    const long flat = d == 2 ? (long)idx[0] * W + idx[1] : idx[0];
+    area[r] = d == 2 ? fabsf(rel[0] * rel[1]) + 1e-9f : fabsf(rel[0]);
+    for (int i = 0; i < T; ++i) {
+        const long row = r * T + i;
+        cell_idx[row] = (int32_t)((long)b * cells + flat);
+        float* o = tail + row * 32;
+        o[0] = x_t[((size_t)b * T + i) * cells + flat];
+        for (int a = 0; a < d; ++a) { o[1 + a] = rel[a]; o[1 + d + a] = cw[a]; }
+        o[1 + 2 * d] = t[(size_t)b * t_ld + i];
+        for (int c = 2 + 2 * d; c < 32; ++c) o[c] = 0.f;
+    }
+}
+
+// z[(bq, i)][c] = sum_s p[((bq*S + s)*T + i)][c] * area[bq*S + opposite(s)] / sum_s area   (2D)
+//               = (p0*a1 + p1*a0) / (a1 + a0)                                               (1D)
+__global__ void k_inr_grid_blend(const float* __restrict__ p, const float* __restrict__ area, int T, int C, int S,
+                                 long total, float* __restrict__ z) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int ti = (int)((i / C) % T);
+    const long bq = i / ((long)C * T);
+    if (S == 2) {
+        const float a0 = area[bq * 2], a1 = area[bq * 2 + 1];
+        const float p0 = p[((bq * 2 + 0) * T + ti) * C + c], p1 = p[((bq * 2 + 1) * T + ti) * C + c];
+        z[i] = (p0 * a1 + p1 * a0) / (a1 + a0);
+    } else {
+        const float a0 = area[bq * 4], a1 = area[bq * 4 + 1], a2 = area[bq * 4 + 2], a3 = area[bq * 4 + 3];
+        const float tot = ((a0 + a1) + a2) + a3;
+        float r = 0.f;
+        r = r + p[((bq * 4 + 0) * T + ti) * C + c] * (a3 / tot);
+        r = r + p[((bq * 4 + 1) * T + ti) * C + c] * (a2 / tot);
+        r = r + p[((bq * 4 + 2) * T + ti) * C + c] * (a1 / tot);
+        r = r + p[((bq * 4 + 3) * T + ti) * C + c] * (a0 / tot);
+        z[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------ C entry points
+#define S_ (hipStream_t) stream
+#define LAUNCH_CHECK() return (int)hipGetLastError()
+static inline unsigned nb(long n, int b) { return (unsigned)((n + b - 1) / b); }
+
+extern "C" int magnet_node_features_f32(const float* u, const float* x, const float* t_last, int n_graphs,
+                                        int nodes_per_graph, int T, int d, int ld, float* out, void* stream) {
+    const long n = (long)n_graphs * nodes_per_graph;
+    if (n <= 0) return 0;
+    if (T + d + 1 > ld) return -2;
+    hipLaunchKernelGGL(k_node_features, dim3(nb(n * ld, 256)), dim3(256), 0, S_, u, x, t_last, n_graphs, n, T, d, ld,
+                       out);
+    LAUNCH_CHECK();
+}
+
+extern "C" int magnet_euler_update_f32(const float* ret, int ld_ret, const float* last, const float* t, int t_ld,
+                                       int n_graphs, int nodes_per_graph, int T, int T_out, float* out, void* stream) {
+    const long total = (long)n_graphs * nodes_per_graph * T_out;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_euler_update, dim3(nb(total, 256)), dim3(256), 0, S_, ret, ld_ret, last, t, t_ld, n_graphs,
+                       nodes_per_graph, T, T_out, out);
+    LAUNCH_CHECK();
+}
+
+extern "C" int magnet_inr_knn_prepare_f32(const float* lr_coords, const float* hr_coords, const int32_t* nn, int k,
+                                          int d, int n_graphs, int L, int Nq, int32_t* nn2, float* rel, float* w,
+                                          void* stream) {
+    const long nq = (long)n_graphs * Nq;
+    if (nq <= 0) return 0;
+    if (k < 2 || d > 3) return -2;
+    (void)L;
+    hipLaunchKernelGGL(k_inr_knn_prepare, dim3(nb(nq * 2, 256)), dim3(256), 0, S_, lr_coords, hr_coords, nn, k, d, nq,
+                       nn2, rel, w);
+    LAUNCH_CHECK();
+}
+
+extern "C" int magnet_inr_knn_blend_f32(const float* base, const float* w, const float* vals, const int32_t* nn2,
+                                        const float* t, int t_ld, const float* wv, const float* wt, int n_graphs,
+                                        int L, int Nq, int T, int C, int mode, float* z, void* stream) {
+    const long total = (long)n_graphs * Nq * T * C;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_inr_knn_blend, dim3(nb(total, 256)), dim3(256), 0, S_, base, w, vals, nn2, t, t_ld, wv, wt, L,
+                       Nq, T, C, mode, total, z);
+    LAUNCH_CHECK();
+}
+
+extern "C" int magnet_inr_grid_prepare_f32(const float* coords, const float* cell, const float* x_t, const float* t,
+                                           int t_ld, int n_graphs, int Nq, int T, int W, int d, int32_t* cell_idx,
+                                           float* tail, float* area, void* stream) {
+    if (d != 1 && d != 2) return -2;
+    const long rows = (long)n_graphs * Nq * (d == 2 ? 4 : 2);
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_inr_grid_prepare, dim3(nb(rows, 256)), dim3(256), 0, S_, coords, cell, x_t, t, t_ld, n_graphs,
+                       Nq, T, W, d, cell_idx, tail, area);
+    LAUNCH_CHECK();
+}
+
+extern "C" int magnet_inr_grid_blend_f32(const float* p, const float* area, int n_rows, int T, int C, int nshift,
+                                         float* z, void* stream) {
+    const long total = (long)n_rows * T * C;
+    if (total <= 0) return 0;
+    if (nshift != 2 && nshift != 4) return -2;
+    hipLaunchKernelGGL(k_inr_grid_blend, dim3(nb(total, 256)), dim3(256), 0, S_, p, area, T, C, nshift, total, z);
+    LAUNCH_CHECK();
+}

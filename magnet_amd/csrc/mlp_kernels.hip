@@ -1,0 +1,144 @@
+// Generic register-chained MLP kernel (see common.cuh) and its C entry point.
+//
+//   rows M (nodes / edges / INR samples), one 32-row tile per wave, 4 waves per workgroup.
+//   layer 0   : K streamed in 32-wide tiles straight from (gathered, concatenated, differenced)
+//               global sources -> HT*32 hidden (or OT*32 outputs when NL == 1)
+//   layers 1..NL-2 : HT*32 -> HT*32 in registers
+//   layer NL-1: HT*32 -> OT*32
+//   epilogue  : optional activation, optional LayerNorm, then store / store+residual /
+//               CSR segment mean.
+// Replaces the reference's per-edge / per-node torch.cat + nn.Linear + activation chains:
+// models/mpnn.py:77-78,85-88,191-192; models/backbones/mlp.py:23-28 as used by
+// models/magnet_gnn.py:22-36,55-68,129-132,193-197.
+#include "common.cuh"
+
+template <int NL, int HT, int OT, int ACT, bool LAST_ACT, bool LN, int EPI>
+__global__ void __launch_bounds__(256) k_mlp(const MagnetMlpArgs a) {
+    constexpr int LDS_FLOATS = (EPI == EPI_SEGMEAN) ? 4 * 32 * (OT * 32 + 4) : 1;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5;
+    const int tile = blockIdx.x * 4 + wave;
+    const int row_raw = tile * 32 + (lane & 31);
+    const bool row_ok = row_raw < a.M;
+    const int row = row_ok ? row_raw : (a.M - 1);
+
+    f32x16 out[OT];
+    if (NL == 1) {
+        init_bias<OT>(out, a.layer[0].b, half);
+        for (int kt = 0; kt < a.nkt; ++kt) {
+            const f32x16 x = load_ktile(a.kt[kt], row, half);
+            mma_ktile<OT>(x, out, a.layer[0].w, kt, lane);
+        }
+    } else {
+        f32x16 h0[HT], h1[HT];
+        init_bias<HT>(h0, a.layer[0].b, half);
+        for (int kt = 0; kt < a.nkt; ++kt) {
+            const f32x16 x = load_ktile(a.kt[kt], row, half);
+            mma_ktile<HT>(x, h0, a.layer[0].w, kt, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < HT; ++t) apply_act<ACT>(h0[t]);
+        // middle layers, ping-pong h0 <-> h1 (fully unrolled so register arrays stay static)
+#pragma unroll
+        for (int l = 1; l < NL - 1; ++l) {
+            if (l & 1) {
+                dense_layer<HT, HT>(h0, h1, a.layer[l], lane);
+#pragma unroll
+                for (int t = 0; t < HT; ++t) apply_act<ACT>(h1[t]);
+            } else {
+                dense_layer<HT, HT>(h1, h0, a.layer[l], lane);
+#pragma unroll
+                for (int t = 0; t < HT; ++t) apply_act<ACT>(h0[t]);
+            }
+        }
+        if ((NL - 1) & 1) dense_layer<HT, OT>(h0, out, a.layer[NL - 1], lane);
+        else dense_layer<HT, OT>(h1, out, a.layer[NL - 1], lane);
+    }
+    if (LAST_ACT) {
+#pragma unroll
+        for (int t = 0; t < OT; ++t) apply_act<ACT>(out[t]);
+    }
+    if (LN) layer_norm_rows<OT>(out, a.ln_g, a.ln_b, a.ln_eps, half);
+
+    if (EPI == EPI_SEGMEAN) {
+        const int ntiles = (a.M + 31) / 32;
+        const int nval = tile < ntiles ? min(32, a.M - tile * 32) : 0;
+        const int tgt = a.tgt[row];
+        segmean_epilogue<OT>(out, lds + wave * 32 * (OT * 32 + 4), tile, nval, tgt, a.rowptr, a.y, a.partials, lane);
+    } else {
+        store_rows<OT, EPI == EPI_STORE_RES>(out, a.y, a.ldy, a.ncols, a.res, a.ldres, row, row_ok, half);
+    }
+}
+
+// Combine the tile-boundary partial sums of segmean_epilogue and zero the empty rows.
+__global__ void __launch_bounds__(256) k_segmean_fixup(const int32_t* __restrict__ rowptr, int N, int D,
+                                                       const float* __restrict__ partials, float* __restrict__ agg) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= N) return;
+    const int s = rowptr[r], e = rowptr[r + 1];
+    if (e == s) {
+        for (int f = lane; f < D; f += 64) agg[(size_t)r * D + f] = 0.f;
+        return;
+    }
+    const int ta = s >> 5, tb = (e - 1) >> 5;
+    if (ta == tb) return;
+    for (int f = lane; f < D; f += 64) {
+        float acc = partials[((size_t)ta * 2 + 1) * D + f];
+        for (int t = ta + 1; t <= tb; ++t) acc += partials[((size_t)t * 2 + 0) * D + f];
+        agg[(size_t)r * D + f] = acc / (float)(e - s);
+    }
+}
+
+// ------------------------------------------------------------------------------------ dispatch
+typedef void (*mlp_fn)(const MagnetMlpArgs);
+
+#define MLP_CASE(NL_, HT_, OT_, ACT_, LA_, LN_, EPI_)                                              \
+    if (nl == NL_ && ht == HT_ && ot == OT_ && act == ACT_ && last_act == LA_ && ln == LN_ && epi == EPI_) \
+        fn = k_mlp<NL_, HT_, OT_, ACT_, LA_, LN_, EPI_>;
+
+static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int epi) {
+    mlp_fn fn = nullptr;
+    // MPNN: embedding / node update (Swish after every Linear), factorised first edge layer
+    MLP_CASE(2, 4, 4, ACT_SWISH, true, false, EPI_STORE)
+    MLP_CASE(2, 4, 4, ACT_SWISH, true, false, EPI_STORE_RES)
+    MLP_CASE(1, 4, 4, ACT_NONE, false, false, EPI_STORE)
+    MLP_CASE(1, 2, 2, ACT_NONE, false, false, EPI_STORE)
+    MLP_CASE(1, 1, 1, ACT_NONE, false, false, EPI_STORE)
+    // MAgNet 5-Linear ReLU MLPs: hidden 128 (HT 4) or 64 (HT 2)
+    MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_STORE)
+    MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_STORE_RES)
+    MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_SEGMEAN)
+    MLP_CASE(5, 4, 1, ACT_RELU, false, false, EPI_STORE)
+    MLP_CASE(5, 2, 1, ACT_RELU, false, true, EPI_STORE)
+    MLP_CASE(5, 2, 1, ACT_RELU, false, true, EPI_STORE_RES)
+    MLP_CASE(5, 2, 1, ACT_RELU, false, true, EPI_SEGMEAN)
+    MLP_CASE(5, 2, 1, ACT_RELU, false, false, EPI_STORE)
+    MLP_CASE(5, 2, 2, ACT_RELU, false, true, EPI_STORE)
+    MLP_CASE(5, 2, 4, ACT_RELU, false, true, EPI_STORE)
+    return fn;
+}
+
+extern "C" int magnet_mlp_supported(int nl, int ht, int ot, int act, int last_act, int ln, int epi) {
+    return pick(nl, ht, ot, act, last_act, ln, epi) != nullptr;
+}
+
+extern "C" int magnet_mlp_f32(const MagnetMlpArgs* args, int nl, int ht, int ot, int act, int last_act, int ln,
+                              int epi, void* stream) {
+    if (!args || args->M <= 0) return args && args->M == 0 ? 0 : -1;
+    if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
+    mlp_fn fn = pick(nl, ht, ot, act, last_act, ln, epi);
+    if (!fn) return -3;
+    const int tiles = (args->M + 31) / 32;
+    hipLaunchKernelGGL(fn, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, *args);
+    return (int)hipGetLastError();
+}
+
+extern "C" int magnet_segmean_fixup_f32(const int32_t* rowptr, int n_rows, int d, const float* partials, float* agg,
+                                        void* stream) {
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(k_segmean_fixup, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rowptr, n_rows, d,
+                       partials, agg);
+    return (int)hipGetLastError();
+}

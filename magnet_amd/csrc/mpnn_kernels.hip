@@ -1,0 +1,196 @@
+// MPNN / MPNN_2d specific kernels (hidden width fixed at 128 by the reference's read-out
+// convolution, models/mpnn.py:140-163).
+#include "common.cuh"
+
+// ---------------------------------------------------------------------------- node input
+// node_in[n, :] = [ u[n, 0:tw] | pos[n, 1] / L[0..dpos) | pos[n, 0] / tmax | 0 ... ]   (ld = KIN)
+// Restates models/mpnn.py:180-191 (and the (x/Lx, x/Ly) broadcast of models/mpnn_2d.py:179, Q4).
+__global__ void k_mpnn_node_input(const float* __restrict__ u, const float* __restrict__ pos, int pos_ld,
+                                  const float* __restrict__ Lvec, const float* __restrict__ tmax, int N, int tw,
+                                  int dpos, int kin, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * kin) return;
+    const int n = (int)(i / kin), c = (int)(i % kin);
+    float v = 0.f;
+    if (c < tw) v = u[(size_t)n * tw + c];
+    else if (c < tw + dpos) v = pos[(size_t)n * pos_ld + 1] / Lvec[c - tw];
+    else if (c == tw + dpos) v = pos[(size_t)n * pos_ld] / tmax[0];
+    out[i] = v;
+}
+
+// ---------------------------------------------------------------------------- fused edge kernel
+// For every CSR edge e = (i <- j):  m_e = Swish(W2 * Swish(A[i] + Bm[j]) + b2), then the mean of
+// m_e over each target row.  A / Bm are the per-node halves of message_net_1 (exact algebra:
+// W1*[x_i, x_j, u_i-u_j, p_i-p_j, v_i] + b1 = (W1a x_i + W1c u_i + W1d p_i + W1e v_i + b1)
+// + (W1b x_j - W1c u_j - W1d p_j)), so the [E, 2H+tw+d+1] concat and the [E, H] messages of
+// models/mpnn.py:73-79 + the scatter-mean of :46 never touch HBM.
+__global__ void __launch_bounds__(256) k_mpnn_edge(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                   const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
+                                                   const int32_t* __restrict__ rowptr, int E, MagnetLayer W2,
+                                                   float* __restrict__ agg, float* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * 132];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5;
+    const int tile = blockIdx.x * 4 + wave;
+    const int ntiles = (E + 31) / 32;
+    const int e_raw = tile * 32 + (lane & 31);
+    const int e = e_raw < E ? e_raw : E - 1;
+    const int ti = tgt[e], sj = src[e];
+    const float* pa = A + (size_t)ti * 128 + 4 * half;
+    const float* pb = Bm + (size_t)sj * 128 + 4 * half;
+    f32x16 in[4], out[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(pa + kt * 32 + 8 * g);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(pb + kt * 32 + 8 * g);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) in[kt][4 * g + c] = act_swish(a[c] + b[c]);
+        }
+    dense_layer<4, 4>(in, out, W2, lane);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) apply_act<ACT_SWISH>(out[t]);
+    const int nval = tile < ntiles ? min(32, E - tile * 32) : 0;
+    segmean_epilogue<4>(out, lds + wave * 32 * 132, tile, nval, ti, rowptr, agg, partials, lane);
+}
+
+// ---------------------------------------------------------------------------- read-out + Euler step
+// diff = Conv1d(8->1,k2)( [Swish]( Conv1d(1->8,k1,stride s1)(h[:, None, :]) ) ),
+// out[n, k] = u[n, tw-1] + dt*(k+1) * diff[n, k]        (models/mpnn.py:197-201, conv specs :140-163)
+// One wave per node; conv1 output (8 x L1) lives in LDS.
+__global__ void __launch_bounds__(256) k_mpnn_readout(const float* __restrict__ h, const float* __restrict__ u, int N,
+                                                      int tw, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      int k1, int s1, const float* __restrict__ w2,
+                                                      const float* __restrict__ b2, int k2, int use_swish,
+                                                      const float* __restrict__ dt, float* __restrict__ out) {
+    __shared__ float sh[4][128];
+    __shared__ float sz[4][8 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    const int L1 = (128 - k1) / s1 + 1;
+    if (n < N) {
+        sh[wave][lane] = h[(size_t)n * 128 + lane];
+        sh[wave][lane + 64] = h[(size_t)n * 128 + lane + 64];
+    }
+    __syncthreads();
+    if (n < N) {
+        for (int o = lane; o < 8 * L1; o += 64) {
+            const int c = o / L1, p = o % L1;
+            float acc = b1[c];
+            for (int k = 0; k < k1; ++k) acc += w1[c * k1 + k] * sh[wave][p * s1 + k];
+            sz[wave][o] = use_swish ? act_swish(acc) : acc;
+        }
+    }
+    __syncthreads();
+    if (n < N && lane < tw) {
+        float acc = b2[0];
+        for (int c = 0; c < 8; ++c)
+            for (int k = 0; k < k2; ++k) acc += w2[c * k2 + k] * sz[wave][c * L1 + lane + k];
+        out[(size_t)n * tw + lane] = u[(size_t)n * tw + tw - 1] + dt[0] * (float)(lane + 1) * acc;
+    }
+}
+
+// ---------------------------------------------------------------------------- per-graph InstanceNorm
+// y = (x - mean_g) / sqrt(var_g + eps), biased variance per graph and channel, two-pass
+// (PyG InstanceNorm defaults; models/mpnn.py:63,70).  Graphs are contiguous row blocks of
+// `rows_per_graph` rows.  Deterministic: chunk partials are combined in a fixed order.
+#define NORM_CHUNK 64
+__global__ void k_colsum_partial(const float* __restrict__ x, int rows_per_graph, int H,
+                                 const float* __restrict__ mean /* null: plain sum; else sum of (x-mean)^2 */,
+                                 float* __restrict__ part) {
+    const int g = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int r0 = chunk * NORM_CHUNK, r1 = min(rows_per_graph, r0 + NORM_CHUNK);
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float m = mean ? mean[(size_t)g * H + c] : 0.f;
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const float v = x[((size_t)g * rows_per_graph + r) * H + c] - m;
+            acc += mean ? v * v : v;
+        }
+        part[((size_t)g * nchunks + chunk) * H + c] = acc;
+    }
+}
+__global__ void k_colsum_final(const float* __restrict__ part, int nchunks, int H, float n_rows,
+                               float* __restrict__ outv) {
+    const int g = blockIdx.x;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        float acc = 0.f;
+        for (int k = 0; k < nchunks; ++k) acc += part[((size_t)g * nchunks + k) * H + c];
+        outv[(size_t)g * H + c] = acc / n_rows;
+    }
+}
+__global__ void k_norm_apply(const float* __restrict__ x, const float* __restrict__ mean,
+                             const float* __restrict__ var, int rows_per_graph, int H, float eps, long total,
+                             float* __restrict__ y) {
+    const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= total) return;
+    const int c = (int)(i4 % H);
+    const int g = (int)((i4 / H) / rows_per_graph);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i4);
+    const f32x4 mv = *reinterpret_cast<const f32x4*>(mean + (size_t)g * H + c);
+    const f32x4 vv = *reinterpret_cast<const f32x4*>(var + (size_t)g * H + c);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (xv[k] - mv[k]) / sqrtf(vv[k] + eps);
+    *reinterpret_cast<f32x4*>(y + i4) = o;
+}
+
+// ------------------------------------------------------------------------------------ C entry points
+#define LAUNCH_CHECK() return (int)hipGetLastError()
+
+extern "C" int magnet_mpnn_node_input_f32(const float* u, const float* pos, int pos_ld, const float* Lvec,
+                                          const float* tmax, int n, int tw, int dpos, int kin, float* out,
+                                          void* stream) {
+    if (n <= 0) return 0;
+    if (tw + dpos + 1 > kin) return -2;
+    const long total = (long)n * kin;
+    hipLaunchKernelGGL(k_mpnn_node_input, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u,
+                       pos, pos_ld, Lvec, tmax, n, tw, dpos, kin, out);
+    LAUNCH_CHECK();
+}
+
+extern "C" int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
+                                    const int32_t* rowptr, int n_edges, const void* w2_packed, const float* b2,
+                                    float* agg, float* partials, void* stream) {
+    if (n_edges <= 0) return 0;
+    MagnetLayer L{reinterpret_cast<const f32x4*>(w2_packed), b2};
+    const int tiles = (n_edges + 31) / 32;
+    hipLaunchKernelGGL(k_mpnn_edge, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, A, Bm, src, tgt, rowptr,
+                       n_edges, L, agg, partials);
+    LAUNCH_CHECK();
+}
+
+extern "C" int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1,
+                                       int k1, int s1, const float* w2, const float* b2, int k2, int use_swish,
+                                       const float* dt, float* out, void* stream) {
+    if (n <= 0) return 0;
+    const int L1 = (128 - k1) / s1 + 1;
+    if (L1 > 64 || tw > 64 || L1 - k2 + 1 != tw) return -2;
+    hipLaunchKernelGGL(k_mpnn_readout, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, u, n, tw, w1, b1, k1,
+                       s1, w2, b2, k2, use_swish, dt, out);
+    LAUNCH_CHECK();
+}
+
+// workspace: (2 * n_graphs * nchunks + 2 * n_graphs) * H floats, nchunks = ceil(rows_per_graph / 64)
+extern "C" int magnet_instance_norm_f32(const float* x, int n_graphs, int rows_per_graph, int H, float eps, float* y,
+                                        float* workspace, void* stream) {
+    if (n_graphs <= 0 || rows_per_graph <= 0) return 0;
+    if (H % 4) return -2;
+    const int nchunks = (rows_per_graph + NORM_CHUNK - 1) / NORM_CHUNK;
+    float* part = workspace;
+    float* mean = part + (size_t)n_graphs * nchunks * H;
+    float* var = mean + (size_t)n_graphs * H;
+    hipStream_t s = (hipStream_t)stream;
+    const float inv_n = (float)rows_per_graph;   // divisor (kept as a true division like the reference)
+    hipLaunchKernelGGL(k_colsum_partial, dim3(nchunks, n_graphs), dim3(128), 0, s, x, rows_per_graph, H,
+                       (const float*)nullptr, part);
+    hipLaunchKernelGGL(k_colsum_final, dim3(n_graphs), dim3(128), 0, s, part, nchunks, H, inv_n, mean);
+    hipLaunchKernelGGL(k_colsum_partial, dim3(nchunks, n_graphs), dim3(128), 0, s, x, rows_per_graph, H,
+                       (const float*)mean, part);
+    hipLaunchKernelGGL(k_colsum_final, dim3(n_graphs), dim3(128), 0, s, part, nchunks, H, inv_n, var);
+    const long total = (long)n_graphs * rows_per_graph * H;
+    hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, x, mean, var,
+                       rows_per_graph, H, eps, total, y);
+    LAUNCH_CHECK();
+}

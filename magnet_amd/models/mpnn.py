@@ -1,0 +1,251 @@
+"""MPNN (message-passing neural PDE solver) on MI355X - drop-in for the reference's
+``models/mpnn.py`` (``MPNN``) and, via ``dim=2``, ``models/mpnn_2d.py`` (``MPNN_2d``).
+
+Same constructor (one attribute-style hparams object), same ``forward(data, L, tmax, dt)``,
+``_build_graph``, ``training_step`` / ``validation_step`` / ``configure_optimizers`` and the same
+state-dict keys; the arithmetic runs in libmagnet_hip.so:
+
+  embedding MLP            -> magnet_mlp_f32 (2 Linears, Swish)           models/mpnn.py:131-136,191-192
+  GNN_Layer.message + mean -> per-node halves of message_net_1 (magnet_mlp_f32, 1 Linear, two
+                              launches) + magnet_mpnn_edge_f32             models/mpnn.py:73-79,46
+  GNN_Layer.update         -> magnet_mlp_f32 (2 Linears, Swish, +residual) models/mpnn.py:81-90
+  InstanceNorm             -> magnet_instance_norm_f32                     models/mpnn.py:63,70
+  Conv1d read-out + Euler  -> magnet_mpnn_readout_f32                      models/mpnn.py:197-201
+  radius_graph             -> magnet_radius_search_f32 (+ CSR), cached while the mesh is unchanged
+"""
+from __future__ import annotations
+
+import types
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..lightning_compat import LightningModule
+from ..packing import pack_linear, pad_to
+
+_READOUT = {10: (16, 6, 10), 16: (16, 5, 8), 20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}  # mpnn.py:140-163
+
+
+class Swish(nn.Module):
+    """Parameter-free placeholder keeping the reference's Sequential indices (mpnn.py:15-24)."""
+
+    def forward(self, x):  # pragma: no cover - the HIP kernels apply the activation
+        return x * torch.sigmoid(x)
+
+
+class GNN_Layer(nn.Module):
+    """Parameter container with the reference's names (mpnn.py:27-63); compute is in HIP."""
+
+    def __init__(self, in_features, out_features, hidden_features, time_window, n_variables, dpos=1):
+        super().__init__()
+        self.message_net_1 = nn.Sequential(nn.Linear(2 * in_features + time_window + dpos + n_variables, hidden_features), Swish())
+        self.message_net_2 = nn.Sequential(nn.Linear(hidden_features, hidden_features), Swish())
+        self.update_net_1 = nn.Sequential(nn.Linear(in_features + hidden_features + n_variables, hidden_features), Swish())
+        self.update_net_2 = nn.Sequential(nn.Linear(hidden_features, out_features), Swish())
+
+
+class MeshGraph:
+    """What ``_build_graph`` returns: the attributes of a PyG ``Data`` (x, pos, edge_index, batch)
+    plus the cached CSR topology the kernels consume."""
+
+    def __init__(self, x, pos, batch, topo):
+        self.x, self.pos, self.batch, self.topo = x, pos, batch, topo
+
+    @property
+    def edge_index(self):
+        t = self.topo
+        if t.edge_index is None:
+            t.edge_index = ops.edge_index_from_pairs(t.csr.src, t.csr.tgt)   # [found j; query i], query-major
+        return t.edge_index
+
+
+class MPNN(LightningModule):
+    DIM = 1
+
+    def __init__(self, hparams):
+        super().__init__()
+        self.save_hyperparameters()
+        self.lr, self.weight_decay = hparams.lr, hparams.weight_decay
+        self.factor, self.step_size, self.loss = hparams.factor, hparams.step_size, hparams.loss
+        self.out_features = self.time_window = hparams.time_window
+        self.hidden_features, self.hidden_layer = hparams.hidden_features, hparams.hidden_layer
+        self.teacher_forcing, self.n = hparams.teacher_forcing, hparams.neighbors
+        if self.hidden_features != 128:
+            raise ValueError("the read-out convolution (mpnn.py:140-163) fixes hidden_features at 128")
+        self.dpos = 1 if self.DIM == 1 else 2                 # mpnn_2d.py:179: (x/Lx, x/Ly)
+        H, tw = self.hidden_features, self.time_window
+        self.gnn_layers = nn.ModuleList([GNN_Layer(H, H, H, tw, 1, self.dpos) for _ in range(self.hidden_layer)])
+        self.embedding_mlp = nn.Sequential(nn.Linear(tw + self.dpos + 1, H), Swish(), nn.Linear(H, H), Swish())
+        k1, s1, k2 = _READOUT[tw]
+        self.readout_swish = not (self.DIM == 1 and tw == 10)  # mpnn.py:141-143 has no Swish
+        mods = [nn.Conv1d(1, 8, k1, stride=s1)] + ([Swish()] if self.readout_swish else []) + [nn.Conv1d(8, 1, k2)]
+        self.output_mlp = nn.Sequential(*mods)
+        self.criterion = {"l1": nn.L1Loss(), "l2": nn.MSELoss(), "smooth_l1": nn.SmoothL1Loss()}[self.loss]
+        self.mse_criterion, self.mae_criterion = nn.MSELoss(), nn.L1Loss()
+        self.kin = pad_to(tw + self.dpos + 1)
+        self._pack_key, self._pack = None, None
+        self._topo_key, self._topo = None, None
+
+    # ------------------------------------------------------------------ packed weights (cached)
+    def _packed(self):
+        params = list(self.parameters())
+        key = (params[0].device, sum(p._version for p in params))
+        if self._pack_key == key:
+            return self._pack
+        H, tw, dp, kin = self.hidden_features, self.time_window, self.dpos, self.kin
+        nin = tw + dp + 1
+        dev = params[0].device
+        P = types.SimpleNamespace(layers=[])
+        e0, e1 = self.embedding_mlp[0], self.embedding_mlp[2]
+        P.emb = [pack_linear(e0.weight, e0.bias, k_pad=kin), pack_linear(e1.weight, e1.bias)]
+        for lyr in self.gnn_layers:
+            m1, m2 = lyr.message_net_1[0], lyr.message_net_2[0]
+            u1, u2 = lyr.update_net_1[0], lyr.update_net_2[0]
+            W1 = m1.weight.detach()
+            # message_net_1 split per node: input [h | node_in(u, pos_x, var)]
+            wa = torch.cat([W1[:, :H], W1[:, 2 * H:]], 1)
+            wb = torch.cat([W1[:, H:2 * H], -W1[:, 2 * H:2 * H + tw + dp], torch.zeros(H, 1, device=dev)], 1)
+            L = types.SimpleNamespace()
+            L.pre_a = pack_linear(wa, m1.bias, k_pad=H + kin)
+            L.pre_b = pack_linear(wb, None, k_pad=H + kin)
+            L.msg2 = pack_linear(m2.weight, m2.bias)
+            cmap = torch.cat([torch.arange(2 * H), torch.tensor([2 * H + tw + dp])])   # var column inside node_in
+            L.upd1 = pack_linear(u1.weight, u1.bias, k_pad=2 * H + kin, col_map=cmap)
+            L.upd2 = pack_linear(u2.weight, u2.bias)
+            P.layers.append(L)
+        c1, c2 = self.output_mlp[0], self.output_mlp[-1]
+        P.conv = (c1.weight.detach().reshape(-1).contiguous(), c1.bias.detach().contiguous(),
+                  c2.weight.detach().reshape(-1).contiguous(), c2.bias.detach().contiguous())
+        assert nin <= kin
+        self._pack_key, self._pack = key, P
+        return P
+
+    # ------------------------------------------------------------------ forward (mpnn.py:175-203)
+    @torch.no_grad()
+    def forward(self, data, L, tmax, dt):
+        u = ops._f32(data.x, "data.x")
+        pos = ops._f32(data.pos, "data.pos")
+        dev = u.device
+        N, tw, H, kin = u.shape[0], self.time_window, self.hidden_features, self.kin
+        topo = self._topology_of(data, N)
+        csr, B, Ns = topo.csr, topo.n_graphs, topo.nodes_per_graph
+        P = self._packed()
+        as_t = lambda v: v.to(dev).float().reshape(-1) if torch.is_tensor(v) else torch.tensor([float(v)], device=dev)  # noqa: E731
+        Lv, tm, dtv = as_t(L), as_t(tmax), as_t(dt)
+        if Lv.numel() < self.dpos:
+            Lv = Lv.expand(self.dpos).contiguous()
+
+        node_in = ops.mpnn_node_input(u, pos, Lv, tm, tw, self.dpos, kin)
+        new = lambda: torch.empty(N, H, device=dev, dtype=torch.float32)  # noqa: E731
+        h, g, A, Bm, agg = new(), new(), new(), new(), new()
+        partials = torch.empty(((csr.E + 31) // 32) * 2 * H, device=dev, dtype=torch.float32)
+        T = ops.Term
+        ops.mlp(N, ops.ktiles(T(node_in, kin)), P.emb, nl=2, ht=4, ot=4, act=ops.ACT_SWISH, last_act=True, y=h)
+        for lyr in P.layers:
+            pre_in = ops.ktiles(T(h, H), T(node_in, kin))
+            ops.mlp(N, pre_in, [lyr.pre_a], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=A)
+            ops.mlp(N, pre_in, [lyr.pre_b], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=Bm)
+            ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials)
+            ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
+                    act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g)
+            ops.instance_norm(g, B, Ns, out=h)
+        k1, s1, k2 = _READOUT[tw]
+        return ops.mpnn_readout(h, u, tw, P.conv[0], P.conv[1], k1, s1, P.conv[2], P.conv[3], k2, self.readout_swish, dtv)
+
+    # ------------------------------------------------------------------ graph (mpnn.py:216-251)
+    def _radius(self, x0, nx):
+        if self.DIM == 1:
+            return self.n * (x0[1] - x0[0]) + 0.0001
+        dx = x0[1] - x0[0]
+        dy = x0[int(nx ** 0.5)] - x0[0]
+        return self.n * torch.norm(dx - dy, p=2) + 0.0001     # mpnn_2d.py:240-243
+
+    def _build_topology(self, x0, B):
+        """radius graph of sample 0's mesh replicated for the B samples (Q8), as CSR by target."""
+        Ns = x0.shape[0]
+        coords = x0.reshape(Ns, -1).repeat(B, 1)
+        gptr = ops.graph_ptr(B, Ns, x0.device)
+        found, query, qptr, E = ops.radius_pairs(coords, self._radius(x0, Ns), gptr, loop=False)
+        csr = ops.CSR(qptr, found, query, B * Ns, E)          # query-major == sorted by target already
+        return types.SimpleNamespace(csr=csr, n_graphs=B, nodes_per_graph=Ns, edge_index=None, coords=coords)
+
+    def _build_graph(self, data, t, x, steps):
+        """data [B, tw, N], t [B, T], x [B, N(, 2)], steps [B] -> MeshGraph (Data-like)."""
+        B, tw, Ns = data.shape
+        x0 = x[0]
+        key = (x0.data_ptr(), x0._version, tuple(x0.shape), B, str(x0.device))
+        if self._topo_key != key:
+            self._topo, self._topo_key = self._build_topology(x0, B), key
+        topo = self._topo
+        u = data.permute(0, 2, 1).reshape(B * Ns, tw).contiguous()
+        t_pos = t[torch.arange(B, device=t.device), torch.as_tensor(steps, device=t.device)].repeat_interleave(Ns)
+        pos = torch.cat([t_pos[:, None], topo.coords], 1)
+        batch = torch.arange(B, device=u.device).repeat_interleave(Ns)
+        return MeshGraph(u, pos, batch, topo)
+
+    def _topology_of(self, data, N):
+        topo = getattr(data, "topo", None)
+        if topo is not None:
+            return topo
+        # foreign PyG-style Data: sort its edge_index by target on the device
+        batch = data.batch
+        B = int(batch.max().item()) + 1
+        if N % B:
+            raise NotImplementedError("graphs of unequal size in one batch")
+        csr = ops.csr_from_edge_index(data.edge_index, N)
+        return types.SimpleNamespace(csr=csr, n_graphs=B, nodes_per_graph=N // B, edge_index=data.edge_index)
+
+    # ------------------------------------------------------------------ Lightning protocol
+    def configure_optimizers(self):
+        opt = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        sch = torch.optim.lr_scheduler.StepLR(opt, step_size=self.step_size, gamma=self.factor)
+        return {"optimizer": opt, "lr_scheduler": {"scheduler": sch}}
+
+    def _first_step(self):
+        return 0 if self.DIM == 1 else self.time_window - 1   # mpnn.py:265 vs mpnn_2d.py:265
+
+    def _next_step(self, i):
+        return 0 if self.DIM == 1 else (i + 2) * self.time_window - 1
+
+    def _unpack(self, batch):
+        u = batch["u"].float().permute(0, 2, 1)
+        x = batch["x"].float()
+        if self.DIM == 1:
+            x = x.squeeze(-1)
+        t = batch["t"].float()
+        return u, x, t
+
+    def rollout(self, batch, teacher_forcing=False):
+        """Free-running (or teacher-forced) rollout; mpnn.py:261-289 / :306-327.  Returns (u_hat, target)."""
+        u, x, t = self._unpack(batch)
+        B, _, N = u.shape
+        tw = self.time_window
+        dt = t[0][1] - t[0][0]
+        graph = self._build_graph(u[:, :tw], t, x, [self._first_step()] * B)
+        target = u[:, tw:]
+        u_hat = []
+        for i in range(target.shape[1] // tw):
+            y = self.forward(graph, x[0, -1], t[0, -1], dt)
+            y_hat = y.reshape(B, N, -1).permute(0, 2, 1)
+            u_hat.append(y_hat)
+            nxt = u[:, (i + 1) * tw:(i + 2) * tw] if teacher_forcing else y_hat
+            graph = self._build_graph(nxt, t, x, [self._next_step(i)] * B)
+        return torch.cat(u_hat, dim=1), target
+
+    def training_step(self, train_batch, batch_idx):
+        if torch.is_grad_enabled():
+            raise NotImplementedError(
+                "magnet_amd round 1 ships the forward / rollout kernels only; the backward kernels "
+                "(SURVEY.md 8(f) rank 2) are not built yet, so training_step cannot produce gradients")
+        u_hat, target = self.rollout(train_batch, self.teacher_forcing)
+        loss = self.criterion(u_hat, target)
+        self.log("train_loss", loss, prog_bar=True)
+        self.log("train_mae_loss", self.mae_criterion(u_hat, target), prog_bar=True)
+        return loss
+
+    def validation_step(self, val_batch, batch_idx):
+        u_hat, target = self.rollout(val_batch)
+        self.log("val_loss", self.criterion(u_hat, target), prog_bar=True)
+        self.log("val_mae_loss", self.mae_criterion(u_hat, target), prog_bar=True)
+        return u_hat

@@ -1,0 +1,220 @@
+"""Thin Python wrappers over the C ABI (include/magnet_hip.h).  torch is used for device memory
+and the current stream only; all arithmetic happens in libmagnet_hip.so.  No CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib as L
+from ._lib import ACT_NONE, ACT_RELU, ACT_SWISH, EPI_SEGMEAN, EPI_STORE, EPI_STORE_RES  # noqa: F401
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t: torch.Tensor, name="tensor") -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"magnet_amd: {name} must live on a HIP device (got {t.device}); there is no CPU path")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.float().contiguous()
+    return t
+
+
+def _i32(t: torch.Tensor, name="index") -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"magnet_amd: {name} must live on a HIP device")
+    assert t.dtype == torch.int32 and t.is_contiguous()
+    return t
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# ------------------------------------------------------------------------------------ MLP chain
+@dataclass
+class Term:
+    """``width`` (multiple of 32) input columns taken from t[(idx[row] | row // rdiv), col : col + width]."""
+    t: torch.Tensor
+    width: int
+    col: int = 0
+    idx: torch.Tensor | None = None
+    scale: float = 1.0
+    rdiv: int = 1
+
+
+def ktiles(*groups):
+    """groups: Term or (Term, Term) (summed, equal widths) -> flat list of per-32-column tile specs."""
+    out = []
+    for g in groups:
+        terms = g if isinstance(g, (tuple, list)) else (g,)
+        w = terms[0].width
+        assert w % 32 == 0 and all(t.width == w for t in terms) and len(terms) <= 2
+        for k in range(w // 32):
+            out.append([(t, t.col + 32 * k) for t in terms])
+    return out
+
+
+def mlp(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STORE, y=None, ldy=None, ncols=None,
+        res=None, tgt=None, rowptr=None, partials=None):
+    """Run the fused MLP kernel.  ``layers``: list of (packed_w, padded_b).  Returns y."""
+    a = L.MlpArgs()
+    a.M, a.nkt = int(M), len(kts)
+    assert 1 <= len(kts) <= L.MAX_KT and len(layers) == nl
+    keep = []
+    for i, tile in enumerate(kts):
+        a.kt[i].n = len(tile)
+        for j, (term, col) in enumerate(tile):
+            t = _f32(term.t, "mlp source")
+            keep.append(t)
+            ld = t.stride(0) if t.dim() == 2 else t.shape[-1]
+            assert ld % 4 == 0 and col % 4 == 0 and col + 32 <= ld, (ld, col)
+            s = a.kt[i].s[j]
+            s.p, s.ld, s.col, s.scale, s.rdiv = t.data_ptr(), ld, col, float(term.scale), int(term.rdiv)
+            s.idx = term.idx.data_ptr() if term.idx is not None else None
+    for i, (w, b) in enumerate(layers):
+        a.layer[i].w, a.layer[i].b = w.data_ptr(), b.data_ptr()
+    if ln is not None:
+        a.ln_g, a.ln_b, a.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+    a.y, a.ldy, a.ncols = y.data_ptr(), int(ldy if ldy is not None else y.shape[-1]), int(ncols if ncols is not None else ot * 32)
+    if res is not None:
+        a.res, a.ldres = res.data_ptr(), res.shape[-1]
+    if epi == EPI_SEGMEAN:
+        a.tgt, a.rowptr, a.partials = tgt.data_ptr(), rowptr.data_ptr(), partials.data_ptr()
+    L.check(L.lib().magnet_mlp_f32(C.byref(a), nl, ht, ot, act, int(last_act), int(ln is not None), epi, _stream()),
+            f"magnet_mlp_f32(nl={nl},ht={ht},ot={ot},act={act},ln={ln is not None},epi={epi})")
+    return y
+
+
+def segmean_fixup(rowptr, n_rows, d, partials, agg):
+    L.check(L.lib().magnet_segmean_fixup_f32(_p(rowptr), n_rows, d, _p(partials), _p(agg), _stream()), "segmean_fixup")
+
+
+def segment_mean(msg: torch.Tensor, rowptr: torch.Tensor, n_rows: int, out: torch.Tensor | None = None):
+    msg = _f32(msg, "msg")
+    h = msg.shape[1]
+    out = torch.empty(n_rows, h, device=msg.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().magnet_segment_mean_f32(_p(msg), _p(_i32(rowptr)), n_rows, h, _p(out), _stream()), "segment_mean")
+    return out
+
+
+# ------------------------------------------------------------------------------------ MPNN pieces
+def mpnn_node_input(u, pos, Lvec, tmax, tw, dpos, kin):
+    u, pos = _f32(u, "u"), _f32(pos, "pos")
+    n = u.shape[0]
+    out = torch.empty(n, kin, device=u.device, dtype=torch.float32)
+    L.check(L.lib().magnet_mpnn_node_input_f32(_p(u), _p(pos), pos.shape[1], _p(_f32(Lvec)), _p(_f32(tmax)), n, tw,
+                                               dpos, kin, _p(out), _stream()), "mpnn_node_input")
+    return out
+
+
+def mpnn_edge(A, Bm, csr, w2, b2, agg, partials):
+    L.check(L.lib().magnet_mpnn_edge_f32(_p(A), _p(Bm), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.E, _p(w2), _p(b2),
+                                         _p(agg), _p(partials), _stream()), "mpnn_edge")
+    segmean_fixup(csr.rowptr, csr.N, 128, partials, agg)
+    return agg
+
+
+def mpnn_readout(h, u, tw, w1, b1, k1, s1, w2, b2, k2, use_swish, dt):
+    n = h.shape[0]
+    out = torch.empty(n, tw, device=h.device, dtype=torch.float32)
+    L.check(L.lib().magnet_mpnn_readout_f32(_p(h), _p(u), n, tw, _p(w1), _p(b1), k1, s1, _p(w2), _p(b2), k2,
+                                            int(use_swish), _p(_f32(dt)), _p(out), _stream()), "mpnn_readout")
+    return out
+
+
+def instance_norm(x, n_graphs, rows_per_graph, eps=1e-5, out=None):
+    x = _f32(x, "x")
+    h = x.shape[1]
+    nchunks = (rows_per_graph + 63) // 64
+    ws = torch.empty((2 * n_graphs * nchunks + 2 * n_graphs) * h, device=x.device, dtype=torch.float32)
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().magnet_instance_norm_f32(_p(x), n_graphs, rows_per_graph, h, C.c_float(float(eps)), _p(out), _p(ws),
+                                             _stream()), "instance_norm")
+    return out
+
+
+# ------------------------------------------------------------------------------------ graphs
+@dataclass
+class CSR:
+    """edges sorted by target: rowptr [N+1], src/tgt [E] (int32, device)."""
+    rowptr: torch.Tensor
+    src: torch.Tensor
+    tgt: torch.Tensor
+    N: int
+    E: int
+    perm: torch.Tensor | None = None   # CSR position -> input edge id (None when already sorted)
+
+
+def graph_ptr(n_graphs: int, nodes_per_graph: int, device) -> torch.Tensor:
+    return torch.arange(0, (n_graphs + 1) * nodes_per_graph, nodes_per_graph, dtype=torch.int32, device=device)
+
+
+def radius_search(x: torch.Tensor, r, gptr: torch.Tensor, cap: int):
+    """first ``cap`` same-graph nodes with dist^2 < r^2 per node, ascending index."""
+    x = _f32(x.reshape(x.shape[0], -1), "coords")
+    n, dim = x.shape
+    r64 = float(r)
+    r2 = float(torch.tensor(r64 * r64, dtype=torch.float64).to(torch.float32))   # as torch_cluster passes it
+    nbr = torch.empty(n * cap, dtype=torch.int32, device=x.device)
+    cnt = torch.empty(n, dtype=torch.int32, device=x.device)
+    L.check(L.lib().magnet_radius_search_f32(_p(x), dim, n, _p(_i32(gptr)), gptr.numel() - 1, C.c_float(r2), cap,
+                                             _p(nbr), _p(cnt), _stream()), "radius_search")
+    return nbr, cnt
+
+
+def radius_pairs(x, r, gptr, loop: bool, max_num_neighbors: int = 32):
+    """(found, query, qptr, E): the edge list torch_cluster.radius_graph would return, query-major."""
+    cap = max_num_neighbors if loop else max_num_neighbors + 1
+    nbr, cnt = radius_search(x, r, gptr, cap)
+    n = cnt.numel()
+    qptr = torch.empty(n + 1, dtype=torch.int32, device=nbr.device)
+    L.check(L.lib().magnet_radius_offsets(_p(nbr), _p(cnt), n, cap, int(loop), _p(qptr), _stream()), "radius_offsets")
+    E = int(qptr[-1].item())                          # one host sync per graph build
+    found = torch.empty(max(E, 1), dtype=torch.int32, device=nbr.device)
+    query = torch.empty(max(E, 1), dtype=torch.int32, device=nbr.device)
+    L.check(L.lib().magnet_radius_emit_pairs(_p(nbr), _p(cnt), _p(qptr), n, cap, int(loop), _p(found), _p(query),
+                                             _stream()), "radius_emit_pairs")
+    return found[:E], query[:E], qptr, E
+
+
+def csr_by_target(src: torch.Tensor, tgt: torch.Tensor, n_nodes: int) -> CSR:
+    E = src.numel()
+    dev = src.device
+    rowptr = torch.zeros(n_nodes + 1, dtype=torch.int32, device=dev)
+    cursor = torch.zeros(max(n_nodes, 1), dtype=torch.int32, device=dev)
+    scratch = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    perm, s_out, t_out = (torch.empty(max(E, 1), dtype=torch.int32, device=dev) for _ in range(3))
+    L.check(L.lib().magnet_csr_by_target(_p(_i32(src.contiguous())), _p(_i32(tgt.contiguous())), E, n_nodes, _p(rowptr),
+                                         _p(cursor), _p(scratch), _p(perm), _p(s_out), _p(t_out), _stream()), "csr_by_target")
+    return CSR(rowptr, s_out[:E], t_out[:E], n_nodes, E, perm[:E])
+
+
+def csr_from_edge_index(edge_index: torch.Tensor, n_nodes: int) -> CSR:
+    """PyG-style int64 [2, E] (row 0 = source j, row 1 = target i) -> CSR by target."""
+    if not edge_index.is_cuda:
+        raise RuntimeError("magnet_amd: edge_index must live on a HIP device")
+    ei = edge_index.contiguous()
+    E = ei.shape[1]
+    both = torch.empty(2 * max(E, 1), dtype=torch.int32, device=ei.device)
+    L.check(L.lib().magnet_i64_to_i32(_p(ei), 2 * E, _p(both), _stream()), "i64_to_i32")
+    return csr_by_target(both[:E], both[E:2 * E], n_nodes)
+
+
+def edge_index_from_pairs(row0: torch.Tensor, row1: torch.Tensor) -> torch.Tensor:
+    E = row0.numel()
+    ei = torch.empty(2, E, dtype=torch.int64, device=row0.device)
+    L.check(L.lib().magnet_pairs_to_edge_index(_p(row0), _p(row1), E, _p(ei), _stream()), "pairs_to_edge_index")
+    return ei
+
+
+def knn(x, x_ptr, y, y_ptr, k: int):
+    x, y = _f32(x.reshape(x.shape[0], -1)), _f32(y.reshape(y.shape[0], -1))
+    m = y.shape[0]
+    out = torch.empty(m, k, dtype=torch.int32, device=x.device)
+    L.check(L.lib().magnet_knn_f32(_p(x), _p(_i32(x_ptr)), _p(y), _p(_i32(y_ptr)), x_ptr.numel() - 1, x.shape[1], m, k,
+                                   _p(out), _stream()), "knn")
+    return out

@@ -1,0 +1,34 @@
+"""Quick GPU timing of one mpnn_2d forward at W x W (dev helper, not the bench)."""
+import sys, time, types
+sys.path.insert(0, ".")
+import torch
+from magnet_amd.models.factory import FACTORY
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+hp = types.SimpleNamespace(lr=1e-3, weight_decay=0, factor=0.3, step_size=50, loss="l1", hidden_features=128,
+                           hidden_layer=5, time_window=10, teacher_forcing=False, neighbors=4)
+torch.manual_seed(0)
+m = FACTORY["mpnn_2d"](hp).cuda().eval()
+g = torch.linspace(0, 1, W)
+x = torch.stack(torch.meshgrid(g, g, indexing="ij"), -1).reshape(1, -1, 2).repeat(B, 1, 1).cuda()
+nt = 50
+t = torch.linspace(0, 1, nt)[None].repeat(B, 1).cuda()
+u = torch.randn(B, W * W, nt).cuda()
+batch = {"u": u, "x": x, "t": t}
+torch.cuda.synchronize(); t0 = time.time()
+y = m.validation_step(batch, 0); torch.cuda.synchronize()
+print("first rollout (incl graph build)", time.time() - t0, "E =", m._topo.csr.E)
+for _ in range(2):
+    m.validation_step(batch, 0)
+torch.cuda.synchronize(); t0 = time.time()
+K = 5
+for _ in range(K):
+    m.validation_step(batch, 0)
+torch.cuda.synchronize(); dt = (time.time() - t0) / K
+print(f"W={W} B={B}: rollout {dt*1e3:.2f} ms -> {B*W*W*40/dt:.3e} node-updates/s")
+# graph build alone
+m._topo_key = None
+torch.cuda.synchronize(); t0 = time.time()
+m._build_graph(u.permute(0, 2, 1)[:, :10], t, x, [9] * B); torch.cuda.synchronize()
+print("graph build", time.time() - t0)

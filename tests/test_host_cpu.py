@@ -1,0 +1,68 @@
+"""CPU-only checks: the C-ABI library loads and exports every declared symbol, host-side model
+logic (state-dict keys, weight packing, factory) - no kernels are launched."""
+import ctypes
+
+import pytest
+import torch
+
+from magnet_amd import _lib
+from magnet_amd.packing import pack_linear
+from tests.helpers import CASES, load_case
+
+
+def test_library_exports_every_declared_symbol():
+    from magnet_amd.build import build
+    build()
+    names = _lib.declared_symbols()
+    assert len(names) >= 15
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert _lib.lib() is not None
+
+
+def test_mlp_struct_layout_matches_header():
+    # sizes follow from the C declarations in include/magnet_hip.h
+    assert ctypes.sizeof(_lib.Src) == 32
+    assert ctypes.sizeof(_lib.KTile) == 80
+    assert ctypes.sizeof(_lib.Layer) == 16
+    assert ctypes.sizeof(_lib.MlpArgs) == 8 + 80 * 12 + 16 * 6 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+
+
+def test_supported_mlp_variants():
+    lib = _lib.lib()
+    assert lib.magnet_mlp_supported(2, 4, 4, _lib.ACT_SWISH, 1, 0, _lib.EPI_STORE_RES) == 1
+    assert lib.magnet_mlp_supported(5, 4, 4, _lib.ACT_RELU, 0, 1, _lib.EPI_SEGMEAN) == 1
+    assert lib.magnet_mlp_supported(3, 4, 4, _lib.ACT_RELU, 0, 1, _lib.EPI_STORE) == 0
+
+
+def test_pack_linear_layout():
+    w = torch.arange(40 * 70, dtype=torch.float32).reshape(40, 70)
+    b = torch.arange(40, dtype=torch.float32)
+    wp, bp = pack_linear(w, b)
+    kt, nt = 3, 2
+    v = wp.view(kt, nt, 4, 64, 4)
+    for (k_t, n_t, g, lane, c) in [(0, 0, 0, 0, 0), (2, 1, 3, 63, 3), (1, 0, 2, 37, 1), (2, 1, 0, 5, 2)]:
+        n, k = n_t * 32 + (lane & 31), k_t * 32 + 8 * g + 4 * (lane >> 5) + c
+        want = float(w[n, k]) if (n < 40 and k < 70) else 0.0
+        assert float(v[k_t, n_t, g, lane, c]) == want
+    assert bp.shape[0] == 64 and float(bp[39]) == 39 and float(bp[40]) == 0
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_state_dict_keys_match_reference_layout(tag):
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    name, hp, salt, batch, d = load_case(tag)
+    if name not in FACTORY:
+        pytest.skip(f"{name} not built yet")
+    ours = FACTORY[name](hp)
+    ref = O.build(name, hp)        # oracle key layout == reference key layout (test_oracle_golden pins it)
+    assert {k: tuple(v.shape) for k, v in ours.state_dict().items()} == \
+           {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+
+
+def test_no_cpu_fallback():
+    from magnet_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.segment_mean(torch.zeros(4, 32), torch.zeros(3, dtype=torch.int32), 2)
