@@ -1,0 +1,191 @@
+"""Pieces shared by MAgNet[GNN] and MAgNet[CNN]: the Encoder / InteractionNetwork / Processor /
+Decoder parameter containers (reference models/magnet_gnn.py:11-137, copied verbatim into
+magnet_cnn.py:13-140 and magnet_cnn_2d.py:13-140 there) and the HIP execution of the
+encode-process part on a CSR graph.
+
+Reference semantics kept on purpose: mean aggregation (Q1); edge latents are only
+doubled per hop, e_k = 2^k e_0 (Q2) - so e_0 is stored once and scaled on load; the radius graph is
+capped at 32 neighbours in ascending index and then *swapped*, i.e. messages are averaged at the
+found neighbour, not at the query (Q3, Q11); node k gets the time of sample k mod B (Q5).
+"""
+from __future__ import annotations
+
+import types
+
+import torch
+from torch import nn
+
+from .. import _lib as L
+from .. import ops
+from ..lightning_compat import LightningModule
+from ..packing import pad_to, pad_vec
+from .backbones.mlp import MLP
+
+
+def _mlp_ln(i, hidden, layers, o):
+    return nn.Sequential(MLP(i, [hidden] * layers, o), nn.LayerNorm(o))
+
+
+class Encoder(nn.Module):
+    def __init__(self, node_in, node_out, edge_in, edge_out, mlp_layers, mlp_hidden):
+        super().__init__()
+        self.node_fn = _mlp_ln(node_in, mlp_hidden, mlp_layers, node_out)
+        self.edge_fn = _mlp_ln(edge_in, mlp_hidden, mlp_layers, edge_out)
+
+
+class InteractionNetwork(nn.Module):
+    def __init__(self, node_in, node_out, edge_in, edge_out, mlp_layers, mlp_hidden):
+        super().__init__()
+        self.node_fn = _mlp_ln(node_in + edge_out, mlp_hidden, mlp_layers, node_out)
+        self.edge_fn = _mlp_ln(node_in + node_in + edge_in, mlp_hidden, mlp_layers, edge_out)
+
+
+class Processor(nn.Module):
+    def __init__(self, node_in, node_out, edge_in, edge_out, num_message_passing_steps, mlp_num_layers, mlp_hidden_dim):
+        super().__init__()
+        self.gnn_stacks = nn.ModuleList([
+            InteractionNetwork(node_in, node_out, edge_in, edge_out, mlp_num_layers, mlp_hidden_dim)
+            for _ in range(num_message_passing_steps)])
+
+
+class Decoder(nn.Module):
+    def __init__(self, node_in, node_out, mlp_layers, mlp_hidden):
+        super().__init__()
+        self.node_fn = MLP(node_in, [mlp_hidden] * mlp_layers, node_out)
+
+
+def pack_mlp_ln(seq, k_pad=None, col_map=None):
+    """(packed 5 Linears, (gain, bias, eps)) of a Sequential(MLP, LayerNorm)."""
+    mlp, ln = seq[0], seq[1]
+    return types.SimpleNamespace(layers=mlp.packed(k_pad=k_pad, col_map=col_map),
+                                 ln=(ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps),
+                                 ht=mlp.hidden // 32, ot=pad_to(mlp.out_dim) // 32, out_dim=mlp.out_dim)
+
+
+def pack_mlp(mlp, k_pad=None):
+    return types.SimpleNamespace(layers=mlp.packed(k_pad=k_pad), ln=None, ht=mlp.hidden // 32,
+                                 ot=pad_to(mlp.out_dim) // 32, out_dim=mlp.out_dim)
+
+
+def pack_graph_net(enc: Encoder, proc: Processor, ldn: int):
+    return types.SimpleNamespace(
+        node=pack_mlp_ln(enc.node_fn, k_pad=ldn), edge=pack_mlp_ln(enc.edge_fn, k_pad=ldn),
+        hops=[types.SimpleNamespace(edge=pack_mlp_ln(g.edge_fn), node=pack_mlp_ln(g.node_fn)) for g in proc.gnn_stacks])
+
+
+def run_mlp(M, kts, pk, y, *, epi=ops.EPI_STORE, res=None, ncols=None, ldy=None, **seg):
+    return ops.mlp(M, kts, pk.layers, nl=len(pk.layers), ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU, last_act=False,
+                   ln=pk.ln, epi=epi, y=y, res=res, ncols=ncols if ncols is not None else pk.out_dim, ldy=ldy, **seg)
+
+
+class MagnetBase(LightningModule):
+    """Graph building + encode-process on HIP, shared by the three MAgNet models."""
+
+    def _init_common(self, hparams):
+        self.lr, self.weight_decay = hparams.lr, hparams.weight_decay
+        self.factor, self.step_size, self.loss = hparams.factor, hparams.step_size, hparams.loss
+        self.criterion = {"l1": nn.L1Loss(), "l2": nn.MSELoss(), "smooth_l1": nn.SmoothL1Loss()}[self.loss]
+        self.mse_criterion, self.mae_criterion = nn.MSELoss(), nn.L1Loss()
+        self._pack_key, self._pack = None, None
+        self._topo_cache = {}
+
+    # ---- packed-weight cache -------------------------------------------------------------
+    def _packed(self):
+        params = list(self.parameters())
+        key = (params[0].device, sum(p._version for p in params))
+        if self._pack_key != key:
+            self._pack, self._pack_key = self._pack_weights(), key
+        return self._pack
+
+    # ---- graph (reference _build_graph, models/magnet_gnn.py:286-310) ---------------------
+    def _topology(self, coords: torch.Tensor, key):
+        """radius_graph(loop=True, cap 32) on [B, N, d] coords, swapped (senders = query, receivers =
+        found neighbour) and sorted by receiver; cached while the coordinate tensors are unchanged."""
+        hit = self._topo_cache.get(key)
+        if hit is not None:
+            return hit
+        B, N, d = coords.shape
+        flat = coords.reshape(B * N, d).float().contiguous()
+        gptr = ops.graph_ptr(B, N, flat.device)
+        found, query, _, E = ops.radius_pairs(flat, self.radius, gptr, loop=True)
+        csr = ops.csr_by_target(query, found, B * N)      # src = senders (query), tgt = receivers (found)
+        topo = types.SimpleNamespace(csr=csr, n_graphs=B, nodes_per_graph=N, flat=flat)
+        if len(self._topo_cache) > 8:
+            self._topo_cache.clear()
+        self._topo_cache[key] = topo
+        return topo
+
+    @staticmethod
+    def _tkey(*tensors):
+        return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+
+    def _build_graph(self, u, x, t, key=None):
+        """u [B, N, T], x [B, N, d], t [B, T] -> (node_features [B*N, ld], topology).  Edge features
+        (u_s - u_r, x_s - x_r) are formed inside the edge-encoder kernel from node_features."""
+        B, N, T = u.shape
+        d = x.shape[-1]
+        topo = self._topology(x, key if key is not None else self._tkey(x))
+        ld = pad_to(T + d + 1)
+        nf = torch.empty(B * N, ld, device=u.device, dtype=torch.float32)
+        uf = ops._f32(u.reshape(B * N, T))
+        t_last = ops._f32(t[:, -1])
+        L.check(L.lib().magnet_node_features_f32(ops._p(uf), ops._p(topo.flat), ops._p(t_last), B, N, T, d, ld,
+                                                 ops._p(nf), ops._stream()), "node_features")
+        return nf, topo
+
+    # ---- Encoder + Processor (models/magnet_gnn.py:38-42, 70-117) --------------------------
+    def _graph_net(self, pk, nf, topo, D):
+        csr = topo.csr
+        N, E, dev = csr.N, csr.E, nf.device
+        ldn = nf.shape[1]
+        T_ = ops.Term
+        x = torch.empty(N, D, device=dev, dtype=torch.float32)
+        x2 = torch.empty_like(x)
+        agg = torch.empty_like(x)
+        e0 = torch.empty(max(E, 1), D, device=dev, dtype=torch.float32)
+        partials = torch.empty(((E + 31) // 32) * 2 * D + 1, device=dev, dtype=torch.float32)
+        run_mlp(N, ops.ktiles(T_(nf, ldn)), pk.node, x)
+        run_mlp(E, ops.ktiles((T_(nf, ldn, idx=csr.src, scale=1.0), T_(nf, ldn, idx=csr.tgt, scale=-1.0))), pk.edge, e0)
+        for k, hop in enumerate(pk.hops):
+            kts = ops.ktiles(T_(x, D, idx=csr.tgt), T_(x, D, idx=csr.src), T_(e0, D, scale=float(2 ** k)))
+            run_mlp(E, kts, hop.edge, agg, epi=ops.EPI_SEGMEAN, tgt=csr.tgt, rowptr=csr.rowptr, partials=partials)
+            ops.segmean_fixup(csr.rowptr, N, D, partials, agg)
+            run_mlp(N, ops.ktiles(T_(agg, D), T_(x, D)), hop.node, x2, epi=ops.EPI_STORE_RES, res=x)
+            x, x2 = x2, x
+        return x
+
+    # ---- second half of every MAgNet forward: joint graph, decoder, Euler update ------------
+    def _interaction_and_update(self, pk, feats, coords, t, T, last, key):
+        """feats [B, n, T], coords [B, n, d] -> out [B, T_out, n, 1] (models/magnet_gnn.py:351-369)."""
+        B, n, _ = feats.shape
+        nf, topo = self._build_graph(feats, coords, t[:, :T], key=key)
+        x = self._graph_net(pk.graph2, nf, topo, self.latent_dim)
+        T_out = t.shape[1] - T
+        ret = torch.empty(B * n, pk.decoder.out_dim, device=x.device, dtype=torch.float32)
+        run_mlp(B * n, ops.ktiles(ops.Term(x, self.latent_dim)), pk.decoder, ret)
+        out = torch.empty(B, T_out, n, 1, device=x.device, dtype=torch.float32)
+        tt = ops._f32(t)
+        L.check(L.lib().magnet_euler_update_f32(ops._p(ret), ret.shape[1], ops._p(ops._f32(last.reshape(-1))), ops._p(tt),
+                                                tt.shape[1], B, n, T, T_out, ops._p(out), ops._stream()), "euler_update")
+        return out
+
+    def _projector(self, pk, z, rows):
+        """projector MLP n_chan -> hidden x4 -> 1 on [rows, n_chan] (models/magnet_gnn.py:339)."""
+        out = torch.empty(rows, 1, device=z.device, dtype=torch.float32)
+        run_mlp(rows, ops.ktiles(ops.Term(z, z.shape[1])), pk.projector, out)
+        return out
+
+    def configure_optimizers(self):
+        opt = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        sch = torch.optim.lr_scheduler.StepLR(opt, step_size=self.step_size, gamma=self.factor)
+        return {"optimizer": opt, "lr_scheduler": {"scheduler": sch}}
+
+    def _no_backward_yet(self):
+        if torch.is_grad_enabled():
+            raise NotImplementedError(
+                "magnet_amd round 1 ships the forward / rollout kernels only; the backward kernels "
+                "(SURVEY.md 8(f) rank 2) are not built yet, so training_step cannot produce gradients")
+
+
+__all__ = ["Encoder", "InteractionNetwork", "Processor", "Decoder", "MagnetBase", "pack_mlp", "pack_mlp_ln",
+           "pack_graph_net", "run_mlp", "pad_vec"]

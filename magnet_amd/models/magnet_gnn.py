@@ -1,0 +1,140 @@
+"""MAgNet[GNN] on MI355X - drop-in for the reference's ``models/magnet_gnn.py`` (``MAgNetGNN``).
+
+forward(x_lr, lr_coords, hr_coords, t, hr_last) -> (out_hr, out_lr, hr_points), same shapes and
+state-dict keys.  ``coord_dim`` (optional hparam, default 2 = the reference, which is hard-wired to
+2-D coordinates) parametrises the +3 / +2 / +4 widths for the 1-D configs.
+
+  encoder + processor on the LR mesh   -> MagnetBase._graph_net (magnet_mlp_f32, fused CSR mean)
+  knn(k = codec_neighbors)             -> magnet_knn_f32                     magnet_gnn.py:247
+  proj_head on the two nearest + blend -> magnet_mlp_f32 (1 Linear on [enc[nn] | rel]) +
+                                          magnet_inr_knn_blend_f32           magnet_gnn.py:254-280
+  projector                            -> magnet_mlp_f32                     magnet_gnn.py:339
+  joint graph, decoder, Euler update   -> MagnetBase._interaction_and_update magnet_gnn.py:342-369
+"""
+from __future__ import annotations
+
+import types
+
+import torch
+from torch import nn
+
+from .. import _lib as L
+from .. import ops
+from ..packing import pack_linear, pad_to
+from .backbones.mlp import MLP
+from .magnet_common import (Decoder, Encoder, MagnetBase, Processor, pack_graph_net, pack_mlp)
+
+_MODES = {"area": 0, "knn": 1, "sph": 2}
+
+
+class MAgNetGNN(MagnetBase):
+    def __init__(self, hparams):
+        super().__init__()
+        self.save_hyperparameters()
+        self._init_common(hparams)
+        self.time_slice = hparams.time_slice
+        self.num_message_passing_steps = hparams.num_message_passing_steps
+        self.latent_dim, self.mlp_layers, self.mlp_hidden = hparams.latent_dim, hparams.mlp_layers, hparams.mlp_hidden
+        self.n_chan, self.radius = hparams.n_chan, hparams.radius
+        self.codec_neighbors, self.teacher_forcing = hparams.codec_neighbors, hparams.teacher_forcing
+        self.noise, self.interpolation = hparams.noise, hparams.interpolation
+        self.coord_dim = d = getattr(hparams, "coord_dim", 2)
+        if self.mlp_layers != 4:
+            raise NotImplementedError("the HIP MLP kernel is instantiated for mlp_layers == 4 (5 Linears)")
+        T, D, Lm, Hm, K = self.time_slice, self.latent_dim, self.mlp_layers, self.mlp_hidden, self.num_message_passing_steps
+        self.encoder = Encoder(T + d + 1, D, T + d, D, Lm, Hm)
+        self.processor = Processor(D, D, D, D, K, Lm, Hm)
+        self.proj_head = nn.Linear(D + d + 2, self.n_chan)
+        self.projector = MLP(self.n_chan, [Hm] * Lm, 1)
+        self._encoder = Encoder(T + d + 1, D, T + d, D, Lm, Hm)
+        self._processor = Processor(D, D, D, D, K, Lm, Hm)
+        self._decoder = Decoder(D, T, Lm, Hm)
+
+    def _pack_weights(self):
+        T, D, d = self.time_slice, self.latent_dim, self.coord_dim
+        ldn = pad_to(T + d + 1)
+        W = self.proj_head.weight.detach()
+        cols = torch.cat([torch.arange(D), D + 1 + torch.arange(d)])           # enc, rel
+        cmap = torch.cat([torch.arange(D), D + torch.arange(d)])
+        return types.SimpleNamespace(
+            graph1=pack_graph_net(self.encoder, self.processor, ldn),
+            graph2=pack_graph_net(self._encoder, self._processor, ldn),
+            proj_base=pack_linear(W[:, cols], self.proj_head.bias, k_pad=D + 32, col_map=cmap),
+            proj_wv=W[:, D].float().contiguous(), proj_wt=W[:, D + d + 1].float().contiguous(),
+            projector=pack_mlp(self.projector), decoder=pack_mlp(self._decoder.node_fn))
+
+    @torch.no_grad()
+    def forward(self, x_lr, lr_coords, hr_coords, t, hr_last):
+        B, T, C, Lr = x_lr.shape
+        Nq, d, D, Cn = hr_coords.shape[1], self.coord_dim, self.latent_dim, self.n_chan
+        dev = x_lr.device
+        pk = self._packed()
+        t = t.float()
+        lr_coords = lr_coords.reshape(B, Lr, d).float()
+        hr_coords = hr_coords.reshape(B, Nq, d).float()
+        u = x_lr.permute(0, 3, 1, 2).reshape(B, Lr, T * C).float().contiguous()      # magnet_gnn.py:331-332
+        # encode-process the LR mesh
+        nf, topo = self._build_graph(u, lr_coords, t[:, :T], key=("lr",) + self._tkey(lr_coords))
+        enc = self._graph_net(pk.graph1, nf, topo, D)
+        # INR decoder (continuous_decoder, magnet_gnn.py:224-283)
+        flr, fhr = topo.flat, ops._f32(hr_coords.reshape(B * Nq, d))
+        nn_idx = ops.knn(flr, ops.graph_ptr(B, Lr, dev), fhr, ops.graph_ptr(B, Nq, dev), self.codec_neighbors)
+        M2 = 2 * B * Nq
+        nn2 = torch.empty(M2, dtype=torch.int32, device=dev)
+        rel = torch.empty(M2, 32, device=dev, dtype=torch.float32)
+        w = torch.empty(M2, device=dev, dtype=torch.float32)
+        L.check(L.lib().magnet_inr_knn_prepare_f32(ops._p(flr), ops._p(fhr), ops._p(nn_idx), self.codec_neighbors, d, B,
+                                                   Lr, Nq, ops._p(nn2), ops._p(rel), ops._p(w), ops._stream()), "inr_knn_prepare")
+        base = torch.empty(M2, Cn, device=dev, dtype=torch.float32)
+        ot = Cn // 32
+        ops.mlp(M2, ops.ktiles(ops.Term(enc, D, idx=nn2), ops.Term(rel, 32)), [pk.proj_base], nl=1, ht=ot, ot=ot,
+                act=ops.ACT_NONE, y=base)
+        z = torch.empty(B * Nq * T, Cn, device=dev, dtype=torch.float32)
+        vals = u.reshape(B * Lr, T)
+        L.check(L.lib().magnet_inr_knn_blend_f32(ops._p(base), ops._p(w), ops._p(vals), ops._p(nn2), ops._p(t), t.shape[1],
+                                                 ops._p(pk.proj_wv), ops._p(pk.proj_wt), B, Lr, Nq, T, Cn,
+                                                 _MODES[self.interpolation], ops._p(z), ops._stream()), "inr_knn_blend")
+        hr_points = self._projector(pk, z, B * Nq * T).reshape(B, Nq, T)
+        # joint graph over LR nodes + queries
+        feats = torch.cat([u, hr_points], dim=1)
+        coords = torch.cat([lr_coords, hr_coords], dim=1)
+        last = torch.cat([x_lr[:, -1].permute(0, 2, 1).float(), hr_last.float()], dim=1)
+        out = self._interaction_and_update(pk, feats, coords, t, T, last, key=("all",) + self._tkey(lr_coords, hr_coords))
+        return out[:, :, Lr:], out[:, :, :Lr], hr_points.permute(0, 2, 1)[..., None]
+
+    def _rollout(self, batch, teacher_forcing=False):
+        t, u = batch["t"].float(), batch["lr_frames"].float()
+        vals = batch["hr_points"].float()
+        hr_c, lr_c = batch["coords_hr"].float(), batch["coords_lr"].float()
+        T = self.time_slice
+        fut = vals[:, T:]
+        inp, hr_last, outs, hrs = u[:, :T], vals[:, T - 1], [], []
+        for i in range(fut.shape[1] // T):
+            out_hr, out_lr, hr_points = self.forward(inp, lr_c, hr_c, t[:, i * T:(i + 2) * T], hr_last)
+            outs.append(torch.cat([out_hr, out_lr], dim=2))
+            hrs.append(hr_points)
+            if teacher_forcing:
+                inp, hr_last = u[:, (i + 1) * T:(i + 2) * T], vals[:, (i + 2) * T - 1]
+            else:
+                inp, hr_last = out_lr.permute(0, 1, 3, 2), out_hr[:, -1]
+        pred = torch.cat(outs, dim=1)
+        target = torch.cat([fut, u[:, T:].permute(0, 1, 3, 2)], dim=2)
+        return pred, target, torch.cat(hrs, dim=1), vals
+
+    def training_step(self, train_batch, batch_idx):
+        self._no_backward_yet()
+        if self.noise:
+            raise NotImplementedError("input noise (magnet_gnn.py:402-407) is a training-only feature")
+        pred, target, hr_hat, vals = self._rollout(train_batch, self.teacher_forcing)
+        T = self.time_slice
+        loss = self.criterion(pred, target) + self.criterion(hr_hat, vals[:, :-T])
+        self.log("train_loss", loss, prog_bar=True)
+        self.log("train_mae_loss", self.mae_criterion(pred, target), prog_bar=True)
+        self.log("train_interp_loss", self.mae_criterion(hr_hat, vals[:, :-T]), prog_bar=True)
+        return loss
+
+    def validation_step(self, val_batch, batch_idx):
+        pred, target, _, _ = self._rollout(val_batch)
+        self.log("val_loss", self.criterion(pred, target), prog_bar=True)
+        self.log("val_mae_loss", self.mae_criterion(pred, target), prog_bar=True)
+        return pred

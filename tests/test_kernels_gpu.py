@@ -1,0 +1,151 @@
+"""GPU unit parity of the individual C-ABI ops against the oracle's restatements."""
+import pytest
+import torch
+
+from tests.helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_csr(n, max_deg, seed, empty_frac=0.2, long_rows=2):
+    g = torch.Generator().manual_seed(seed)
+    deg = torch.randint(0, max_deg + 1, (n,), generator=g)
+    deg[torch.rand(n, generator=g) < empty_frac] = 0
+    for r in torch.randint(0, n, (long_rows,), generator=g):
+        deg[r] = 200 + int(torch.randint(0, 100, (1,), generator=g))
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(deg, 0)
+    tgt = torch.repeat_interleave(torch.arange(n), deg)
+    return rowptr.int(), tgt
+
+
+@pytest.mark.parametrize("h", [32, 64, 128])
+def test_segment_mean_matches_scatter_mean(h):
+    from magnet_amd import ops
+    from oracle.pyg_semantics import scatter_mean
+    n = 777
+    rowptr, tgt = _random_csr(n, 40, seed=h)
+    msg = torch.randn(tgt.numel(), h, generator=torch.Generator().manual_seed(1))
+    out = ops.segment_mean(msg.cuda(), rowptr.cuda(), n)
+    want = scatter_mean(msg, tgt, n)
+    assert rel_l2(out, want) < 1e-6
+    assert float(out.cpu()[(rowptr[1:] == rowptr[:-1])].abs().max()) == 0.0      # empty rows -> 0
+
+
+def test_segment_mean_empty_and_single():
+    from magnet_amd import ops
+    rowptr = torch.tensor([0, 0, 1, 1], dtype=torch.int32).cuda()
+    msg = torch.arange(128, dtype=torch.float32)[None].cuda()
+    out = ops.segment_mean(msg, rowptr, 3).cpu()
+    assert torch.equal(out[1], msg[0].cpu()) and out[0].abs().sum() == 0 and out[2].abs().sum() == 0
+
+
+@pytest.mark.parametrize("dim,loop", [(1, False), (2, False), (2, True)])
+def test_radius_graph_matches_torch_cluster_restatement(dim, loop):
+    from magnet_amd import ops
+    from oracle.pyg_semantics import radius_graph
+    g = torch.Generator().manual_seed(dim * 7 + loop)
+    B, N = 3, 150
+    x = torch.rand(B * N, dim, generator=g)
+    x[:40] *= 0.1                                        # dense cluster: the 32-neighbour cap is hit
+    r = 0.25
+    batch = torch.arange(B).repeat_interleave(N)
+    want = radius_graph(x, r, batch, loop=loop)
+    found, query, qptr, E = ops.radius_pairs(x.cuda(), r, ops.graph_ptr(B, N, "cuda"), loop=loop)
+    got = torch.stack([found.long(), query.long()]).cpu()
+    assert E == want.shape[1]
+    assert torch.equal(got, want)
+    deg = torch.bincount(want[1], minlength=B * N)
+    assert int(deg.max()) >= 32                            # the cap was exercised
+
+
+def test_csr_by_target_is_stable_transpose():
+    from magnet_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n, E = 300, 5000
+    src = torch.randint(0, n, (E,), generator=g).int()
+    tgt = torch.randint(0, n // 3, (E,), generator=g).int()       # leaves empty rows
+    csr = ops.csr_by_target(src.cuda(), tgt.cuda(), n)
+    order = torch.sort(tgt.long(), stable=True).indices
+    assert torch.equal(csr.perm.cpu().long(), order)
+    assert torch.equal(csr.src.cpu(), src[order]) and torch.equal(csr.tgt.cpu(), tgt[order])
+    assert torch.equal(csr.rowptr.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(torch.bincount(tgt.long(), minlength=n), 0)]))
+
+
+def test_knn_matches_restatement():
+    from magnet_amd import ops
+    from oracle.pyg_semantics import knn
+    g = torch.Generator().manual_seed(5)
+    B, L, Nq = 2, 37, 91
+    x, y = torch.rand(B * L, 2, generator=g), torch.rand(B * Nq, 2, generator=g)
+    y[:5] = x[:5]                                         # exact hits / ties with distance 0
+    bx, by = torch.arange(B).repeat_interleave(L), torch.arange(B).repeat_interleave(Nq)
+    want = knn(x, y, 4, bx, by)[1].view(B * Nq, 4)
+    got = ops.knn(x.cuda(), ops.graph_ptr(B, L, "cuda"), y.cuda(), ops.graph_ptr(B, Nq, "cuda"), 4)
+    assert torch.equal(got.cpu().long(), want)
+
+
+def test_instance_norm_matches_pyg_restatement():
+    from magnet_amd import ops
+    from oracle.pyg_semantics import instance_norm
+    g = torch.Generator().manual_seed(9)
+    B, N, H = 3, 333, 128
+    x = torch.randn(B * N, H, generator=g) * 3 + 5
+    want = instance_norm(x, torch.arange(B).repeat_interleave(N))
+    got = ops.instance_norm(x.cuda(), B, N)
+    assert rel_l2(got, want) < 1e-6
+
+
+@pytest.mark.parametrize("hidden,out,k_in,ln", [(128, 128, 45, True), (64, 32, 96, True), (128, 7, 128, False), (64, 64, 40, True)])
+def test_generic_mlp_matches_torch(hidden, out, k_in, ln):
+    """5 Linears + ReLU (+LayerNorm) through magnet_mlp_f32 vs torch fp64 on the host."""
+    from magnet_amd import ops
+    from magnet_amd.models.backbones.mlp import MLP
+    from magnet_amd.models.magnet_common import pack_mlp, pack_mlp_ln, run_mlp
+    from magnet_amd.packing import pad_to
+    torch.manual_seed(0)
+    m = MLP(k_in, [hidden] * 4, out)
+    norm = torch.nn.LayerNorm(out)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5), norm.bias.uniform_(-0.5, 0.5)
+    M = 1000 + 13
+    kp = pad_to(k_in)
+    x = torch.zeros(M, kp)
+    x[:, :k_in] = torch.randn(M, k_in)
+    seq = torch.nn.Sequential(m, norm).cuda()
+    pk = pack_mlp_ln(seq, k_pad=kp) if ln else pack_mlp(seq[0], k_pad=kp)
+    y = torch.full((M, out), float("nan"), device="cuda")
+    run_mlp(M, ops.ktiles(ops.Term(x.cuda(), kp)), pk, y)
+    with torch.no_grad():
+        ref = m.double().cpu()(x[:, :k_in].double())
+        if ln:
+            ref = norm.double().cpu()(ref)
+    assert rel_l2(y, ref) < 2e-6
+
+
+def test_mlp_gather_difference_and_segmean_epilogue():
+    """the edge path: gathered / differenced sources -> MLP -> LayerNorm -> fused CSR mean == unfused."""
+    from magnet_amd import ops
+    from magnet_amd.models.backbones.mlp import MLP
+    from magnet_amd.models.magnet_common import pack_mlp_ln, run_mlp
+    from oracle.pyg_semantics import scatter_mean
+    torch.manual_seed(1)
+    n, D = 500, 32
+    rowptr, tgt = _random_csr(n, 20, seed=11)
+    E = tgt.numel()
+    src = torch.randint(0, n, (E,))
+    x = torch.randn(n, D)
+    e0 = torch.randn(E, D)
+    seq = torch.nn.Sequential(MLP(3 * D, [64] * 4, D), torch.nn.LayerNorm(D)).cuda()
+    pk = pack_mlp_ln(seq)
+    xc, ec = x.cuda(), e0.cuda()
+    kts = ops.ktiles(ops.Term(xc, D, idx=tgt.int().cuda()), ops.Term(xc, D, idx=src.int().cuda()), ops.Term(ec, D, scale=4.0))
+    agg = torch.full((n, D), float("nan"), device="cuda")
+    partials = torch.empty(((E + 31) // 32) * 2 * D, device="cuda")
+    run_mlp(E, kts, pk, agg, epi=ops.EPI_SEGMEAN, tgt=tgt.int().cuda(), rowptr=rowptr.cuda(), partials=partials)
+    ops.segmean_fixup(rowptr.cuda(), n, D, partials, agg)
+    with torch.no_grad():
+        m = seq.double().cpu()(torch.cat([x[tgt], x[src], 4.0 * e0], -1).double())
+    want = scatter_mean(m, tgt, n)
+    assert not torch.isnan(agg).any()
+    assert rel_l2(agg, want) < 2e-6
