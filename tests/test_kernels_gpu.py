@@ -7,6 +7,14 @@ from tests.helpers import rel_l2
 pytestmark = pytest.mark.gpu
 
 
+def _torch_mlp(m, x):
+    """host fp64 evaluation of a magnet_amd MLP parameter container"""
+    m = m.double().cpu()
+    for layer in m.layers:
+        x = layer(x)
+    return x
+
+
 def _random_csr(n, max_deg, seed, empty_frac=0.2, long_rows=2):
     g = torch.Generator().manual_seed(seed)
     deg = torch.randint(0, max_deg + 1, (n,), generator=g)
@@ -117,7 +125,7 @@ def test_generic_mlp_matches_torch(hidden, out, k_in, ln):
     y = torch.full((M, out), float("nan"), device="cuda")
     run_mlp(M, ops.ktiles(ops.Term(x.cuda(), kp)), pk, y)
     with torch.no_grad():
-        ref = m.double().cpu()(x[:, :k_in].double())
+        ref = _torch_mlp(m, x[:, :k_in].double())
         if ln:
             ref = norm.double().cpu()(ref)
     assert rel_l2(y, ref) < 2e-6
@@ -145,7 +153,7 @@ def test_mlp_gather_difference_and_segmean_epilogue():
     run_mlp(E, kts, pk, agg, epi=ops.EPI_SEGMEAN, tgt=tgt.int().cuda(), rowptr=rowptr.cuda(), partials=partials)
     ops.segmean_fixup(rowptr.cuda(), n, D, partials, agg)
     with torch.no_grad():
-        m = seq.double().cpu()(torch.cat([x[tgt], x[src], 4.0 * e0], -1).double())
+        m = seq[1].double().cpu()(_torch_mlp(seq[0], torch.cat([x[tgt], x[src], 4.0 * e0], -1).double()))
     want = scatter_mean(m, tgt, n)
     assert not torch.isnan(agg).any()
     assert rel_l2(agg, want) < 2e-6
