@@ -1,0 +1,211 @@
+"""bench.py - headline benchmark: mesh-node-updates/s of the free-running 2D Burgers 256^2 rollout.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--traj B] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric, SURVEY.md 8(d) "metric case"): ``mpnn_2d`` on a regular 256 x 256
+mesh (N = 65 536 nodes / trajectory, E ~= 2.16 M edges after the reference's 32(+1)-neighbour cap),
+nt = 50, time_window = 10 -> 4 forward calls = 40 predicted time steps per rollout, B independent
+trajectories per GPU (weak scaling: per-GPU work is fixed).  One "step" = one complete free-running
+rollout (validation_step semantics, no grad) of the B trajectories, INCLUDING one radius-graph + CSR
+build (the topology cache is dropped before every step; inside a rollout the graph is reused because
+the mesh does not move - the reference rebuilds an identical graph every call).  Inputs are synthetic
+and already resident in HBM when the clock starts; weights are random-init (torch default init,
+seed 0).  value = nodes x predicted steps x trajectories (all ranks) / max-over-ranks wall time.
+
+Extra objects on the JSON line:
+  roofline      - dominant kernel (k_mpnn_edge, fp32-MFMA bound): executed flops per launch
+                  (2*E*128*128, the message_net_2 GEMM; message_net_1 is factorised per node, see
+                  DESIGN.md) / mean launch time measured with HIP events on the launch stream,
+                  against the 157.3 TFLOP/s dense fp32 MFMA peak.
+  roofline_scatter - the standalone CSR segment-mean ("scatter mean") kernel on the same graph's
+                  [E,128] messages: algorithmic bytes E*H*4 + N*H*4 + 4*(N+1) per launch / mean
+                  launch time, against the 8 TB/s HBM3E peak.
+  cpu_baseline  - the oracle (torch-CPU restatement of the reference op sequence) timed on this
+                  box's host cores on a bounded sample (one rollout of one 128 x 128 trajectory;
+                  forward calls only, graph construction excluded), rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HP = dict(lr=1e-3, weight_decay=0.0, factor=0.3, step_size=50, loss="l1", hidden_features=128, hidden_layer=5,
+          time_window=10, teacher_forcing=False, neighbors=4)     # configs/model/mpnn_2d.yaml
+NT = 50
+MFMA_F32_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_batch(W, B, seed, device):
+    """u = sum of 4 low-frequency sinusoids + 0.01 N(0,1) on linspace(0,1,W)^2 ('ij'), t = linspace(0,1,50)."""
+    g = torch.Generator().manual_seed(seed)
+    lin = torch.linspace(0, 1, W)
+    xy = torch.stack(torch.meshgrid(lin, lin, indexing="ij"), -1).reshape(-1, 2)
+    t = torch.linspace(0, 1, NT)
+    u = torch.zeros(B, W * W, NT)
+    for b in range(B):
+        for _ in range(4):
+            k = torch.rand(2, generator=g) * 2.5 + 0.5
+            w, ph, a = torch.rand(1, generator=g) * 1.5 + 0.5, torch.rand(1, generator=g) * 6.28, torch.rand(1, generator=g) * 0.7 + 0.3
+            u[b] += a * torch.sin((xy @ k)[:, None] * 3.0 + w * t[None, :] * 4.0 + ph)
+    u += 0.01 * torch.randn(u.shape, generator=g)
+    return {"u": u.to(device), "x": xy[None].repeat(B, 1, 1).to(device), "t": t[None].repeat(B, 1).to(device)}
+
+
+def cpu_baseline(W=128):
+    """oracle rollout of ONE trajectory on a W x W mesh on the host cores (forward time only)."""
+    from oracle import models as O
+    torch.manual_seed(0)
+    hp = types.SimpleNamespace(**HP)
+    model = O.build("mpnn_2d", hp).eval()
+    batch = synthetic_batch(W, 1, 0, "cpu")
+    u = batch["u"].permute(0, 2, 1)
+    x, t = batch["x"], batch["t"]
+    tw = hp.time_window
+    t0 = time.perf_counter()
+    graph = model._build_graph(u[:, :tw], t, x, [tw - 1])
+    t_graph = time.perf_counter() - t0
+    t_fwd, n_calls = 0.0, (NT - tw) // tw
+    with torch.no_grad():
+        for i in range(n_calls):
+            t0 = time.perf_counter()
+            y = model(graph, x[0, -1], t[0, -1], t[0][1] - t[0][0])
+            t_fwd += time.perf_counter() - t0
+            graph.x = y                                                   # same mesh: reuse the edge list
+            graph.pos = torch.cat([torch.full((W * W, 1), float(t[0, (i + 2) * tw - 1])), graph.pos[:, 1:]], 1)
+    return {"value": W * W * tw * n_calls / t_fwd, "unit": "mesh-node-updates/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle mpnn_2d, {W}x{W} mesh, 1 trajectory, 1 free-running rollout = {n_calls} forward calls "
+                      f"({t_fwd:.1f} s; radius-graph build {t_graph:.1f} s excluded), fp32, torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--traj", type=int, default=4, help="trajectories per GPU")
+    ap.add_argument("--mesh", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from magnet_amd import ops
+    from magnet_amd.models.factory import FACTORY
+    from magnet_amd.sharding import env_world, max_over_ranks
+
+    rank, local_rank, world = env_world()
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    W, B, K, Wm = args.mesh, args.traj, args.steps, args.warmup
+
+    torch.manual_seed(0)
+    model = FACTORY["mpnn_2d"](types.SimpleNamespace(**HP)).to(dev).eval()
+    batch = synthetic_batch(W, B, 1000 + rank, dev)          # every rank owns B different trajectories
+
+    def step():
+        model._topo_key = None                                # rebuild radius graph + CSR every step
+        return model.validation_step(batch, 0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(Wm):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+    tw = HP["time_window"]
+    pred_steps = (NT - tw) // tw * tw
+    value = world * B * W * W * pred_steps * K / elapsed
+
+    # ---- per-kernel roofline, measured live with HIP events on the launch stream (untimed extra pass)
+    roof = roof_sc = None
+    if rank == 0:
+        csr = model._topo.csr
+        E, N, H = csr.E, csr.N, 128
+        ev = []
+        orig = ops.L.lib().magnet_mpnn_edge_f32
+
+        def timed_edge(*a):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = orig(*a)
+            e.record()
+            ev.append((s, e))
+            return rc
+
+        ops.L._lib.magnet_mpnn_edge_f32 = timed_edge
+        try:
+            model.validation_step(batch, 0)
+            torch.cuda.synchronize()
+        finally:
+            ops.L._lib.magnet_mpnn_edge_f32 = orig
+        ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
+        flops = 2.0 * E * H * H
+        ach = flops / (ms * 1e-3) / 1e12
+        roof = {"kernel": "k_mpnn_edge", "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "launch_ms": round(ms, 4), "launches_timed": len(ev), "flops_per_launch": flops}
+        msg = torch.randn(E, H, device=dev)
+        out = torch.empty(N, H, device=dev)
+        for _ in range(3):
+            ops.segment_mean(msg, csr.rowptr, N, out)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        s.record()
+        for _ in range(reps):
+            ops.segment_mean(msg, csr.rowptr, N, out)
+        e.record()
+        torch.cuda.synchronize()
+        ms_sc = s.elapsed_time(e) / reps
+        nbytes = E * H * 4 + N * H * 4 + 4 * (N + 1)
+        gbs = nbytes / (ms_sc * 1e-3) / 1e9
+        roof_sc = {"kernel": "k_segment_mean<128>", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                   "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(ms_sc, 4),
+                   "bytes_per_launch": nbytes}
+        del msg, out
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(128)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        line = {"metric": "mesh-node-updates/s (nodes x steps x batch), 2D Burgers 256^2 rollout",
+                "value": value, "unit": "mesh-node-updates/s", "n_gpus": world, "steps": K, "warmup": Wm,
+                "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"mpnn_2d free-running rollout, {W}x{W} regular mesh (N={W * W}, E={model._topo.csr.E // B} per "
+                                       f"trajectory), nt={NT}, time_window={tw} -> {pred_steps} predicted steps, {B} trajectories per GPU, "
+                                       "radius graph + CSR rebuilt every step",
+                           "trajectories_per_gpu": B, "global_trajectories": B * world, "parallelism": f"batch-shard x{world}, no data-path collective"},
+                "roofline": roof, "roofline_scatter": roof_sc, "cpu_baseline": cpu}
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

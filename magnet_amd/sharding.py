@@ -1,0 +1,59 @@
+"""Batch-parallel sharding of independent PDE trajectories.
+
+Trajectories in a batch never interact in any forward (block-diagonal graphs, per-graph norms), so
+the rollout shards over ranks with NO data-path collective; the only communication is the reduction
+of scalar metrics / timings at the end.  One process per GPU, torch.distributed ('nccl' = RCCL on
+ROCm; 'gloo' in the CPU tests).  The gradient all-reduce of the training step belongs to the
+backward row and is not built yet.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torch.distributed.run environment (1-process default)."""
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
+
+
+def shard_range(n_items: int, rank: int, world: int) -> range:
+    """Contiguous, balanced slice of ``n_items`` trajectories owned by ``rank`` (what Lightning's
+    DistributedSampler does for strategy='ddp', minus the shuffling)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+def shard_batch(batch: dict, rank: int, world: int) -> dict:
+    """Slice every tensor of a batch dict along dim 0."""
+    n = next(iter(batch.values())).shape[0]
+    r = shard_range(n, rank, world)
+    return {k: v[r.start:r.stop] for k, v in batch.items()}
+
+
+def max_over_ranks(value: float, device="cpu") -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device="cpu") -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_predictions(pred: torch.Tensor) -> torch.Tensor:
+    """Concatenate per-rank predictions along dim 0 on every rank (evaluation only)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return pred
+    parts = [torch.empty_like(pred) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, pred.contiguous())
+    return torch.cat(parts, 0)
