@@ -142,6 +142,9 @@ int magnet_inr_grid_prepare_f32(const float* coords, const float* cell, const fl
 int magnet_inr_grid_blend_f32(const float* p, const float* area, int n_rows, int T, int C, int nshift, float* z,
                               void* stream);
 
+/* development knob (kernel variant selection for A/B measurements); not part of the data path */
+int magnet_debug_set_variant(int which, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MAGNET_MAX_KT 12      // first-layer K up to 384
 #define MAGNET_MAX_LAYERS 6
+#ifndef MAGNET_PF
+#define MAGNET_PF 0
+#endif
 
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
 enum { EPI_STORE = 0, EPI_STORE_RES = 1, EPI_SEGMEAN = 2 };
@@ -118,13 +121,61 @@ __device__ __forceinline__ void mma_ktile(const f32x16& in, f32x16 (&out)[NT], c
     }
 }
 
-// register-resident layer: out = W * in + b
-template <int KT, int NT>
+// load the 4 float4 weight fragments of block (kt, nt)
+template <int NT>
+__device__ __forceinline__ void load_wblock(f32x4 (&w)[4], const f32x4* __restrict__ wp, int kt, int nt, int lane) {
+    const f32x4* p = wp + (size_t)((kt * NT + nt) * 4) * 64 + lane;
+    w[0] = p[0];
+    w[1] = p[64];
+    w[2] = p[128];
+    w[3] = p[192];
+}
+__device__ __forceinline__ void mma_block(const f32x4 (&w)[4], const f32x16& in, f32x16& out) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out = mfma32(w[g][c], in[4 * g + c], out);
+}
+
+// register-resident layer: out = W * in + b.  PF selects how weight fragments reach the MFMAs:
+//   0  plain loop, hipcc schedules the loads
+//   1  3-deep register ring, sched_barriers pin each prefetch two blocks (32 MFMAs) ahead
+//   2  3-deep register ring without the barriers
+template <int KT, int NT, int PF = MAGNET_PF>
 __device__ __forceinline__ void dense_layer(const f32x16 (&in)[KT], f32x16 (&out)[NT], const MagnetLayer& L,
                                              int lane) {
     init_bias<NT>(out, L.b, lane >> 5);
+    if (PF == 0) {
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) mma_ktile<NT>(in[kt], out, L.w, kt, lane);
+        for (int kt = 0; kt < KT; ++kt) mma_ktile<NT>(in[kt], out, L.w, kt, lane);
+        return;
+    }
+    if (PF == 3) {      // all NT accumulators interleaved per k step (no back-to-back dependent MFMAs)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            f32x4 w[NT][4];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) load_wblock<NT>(w[nt], L.w, kt, nt, lane);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) out[nt] = mfma32(w[nt][g][c], in[kt][4 * g + c], out[nt]);
+        }
+        return;
+    }
+    constexpr int NB = KT * NT;
+    f32x4 w[3][4];
+    load_wblock<NT>(w[0], L.w, 0, 0, lane);
+    if (NB > 1) load_wblock<NT>(w[1], L.w, 1 / NT, 1 % NT, lane);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b + 2 < NB) load_wblock<NT>(w[(b + 2) % 3], L.w, (b + 2) / NT, (b + 2) % NT, lane);
+        if (PF == 1) __builtin_amdgcn_sched_barrier(0);
+        mma_block(w[b % 3], in[b / NT], out[b % NT]);
+        if (PF == 1) __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // first-layer k tile from the (gathered / concatenated / differenced) sources
@@ -221,6 +272,15 @@ __device__ __forceinline__ void store_rows(const f32x16 (&v)[NT], float* __restr
         }
 }
 
+// The LDS slab of segmean_epilogue is private to one wave and a wave's DS operations execute in
+// program order, so ordering the slab's writes against its reads only needs the compiler not to
+// reorder them: a wavefront-scope fence pair around a wave barrier (no s_barrier, no cross-wave stall).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Segment-mean epilogue.  The wave's 32 rows are consecutive CSR edges [e0, e0+nval).  Tile
 // values go through a wave-private LDS slab so that lanes become feature owners; runs of equal
 // target are summed in edge order.  A run that lies wholly inside the tile is divided by the
@@ -228,47 +288,49 @@ __device__ __forceinline__ void store_rows(const f32x16 (&v)[NT], float* __restr
 // entered from the previous tile) or partials[tile][1] (run continues into the next tile) and
 // combined, in tile order, by k_segmean_fixup -> bitwise deterministic, no atomics.
 template <int NT>
-__device__ __forceinline__ void segmean_epilogue(const f32x16 (&v)[NT], float* lds /* [32][NT*32+4] */,
+struct SegSlab {
+    static constexpr int PT = NT < 2 ? NT : 2;        // 32-column tiles per pass (slab = [32][PT*32+4] floats)
+    static constexpr int LD = PT * 32 + 4;
+    static constexpr int FLOATS = 32 * LD;            // per wave
+};
+
+template <int NT>
+__device__ __forceinline__ void segmean_epilogue(const f32x16 (&v)[NT], float* lds /* [32][SegSlab<NT>::LD] */,
                                                   int tile, int nval, int tgt, const int32_t* __restrict__ rowptr,
                                                   float* __restrict__ agg, float* __restrict__ partials,
                                                   int lane) {
     constexpr int D = NT * 32;
-    constexpr int LD = D + 4;
-    constexpr int NM = (D + 63) / 64;
+    constexpr int PT = SegSlab<NT>::PT, LD = SegSlab<NT>::LD;
+    constexpr int PW = PT * 32;                       // columns per pass (32 or 64): one per lane
     const int j = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 t = {v[nt][4 * g], v[nt][4 * g + 1], v[nt][4 * g + 2], v[nt][4 * g + 3]};
-            *reinterpret_cast<f32x4*>(lds + j * LD + nt * 32 + 8 * g + 4 * half) = t;
-        }
-    __syncthreads();
-    float acc[NM];
-#pragma unroll
-    for (int m = 0; m < NM; ++m) acc[m] = 0.f;
     const int e0 = tile * 32;
-    for (int jj = 0; jj < nval; ++jj) {
-        const int tj = __builtin_amdgcn_readlane(tgt, jj);
 #pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            const int f = lane + 64 * m;
-            if (f < D) acc[m] += lds[jj * LD + f];
-        }
-        const int tn = (jj + 1 < nval) ? __builtin_amdgcn_readlane(tgt, jj + 1) : -1;
-        if (tn != tj) {
-            const int s = rowptr[tj], e = rowptr[tj + 1];
-            const bool complete = (s >= e0) && (e <= e0 + 32);
+    for (int p0 = 0; p0 < NT; p0 += PT) {
 #pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const int f = lane + 64 * m;
-                if (f < D) {
-                    if (complete) agg[(size_t)tj * D + f] = acc[m] / (float)(e - s);
-                    else partials[((size_t)tile * 2 + (s < e0 ? 0 : 1)) * D + f] = acc[m];
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 x = {v[p0 + t][4 * g], v[p0 + t][4 * g + 1], v[p0 + t][4 * g + 2], v[p0 + t][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(lds + j * LD + t * 32 + 8 * g + 4 * half) = x;
+            }
+        wave_lds_sync();
+        const int f = p0 * 32 + lane;                 // this lane's output column in the pass
+        const bool fok = lane < PW;
+        float acc = 0.f;
+        for (int jj = 0; jj < nval; ++jj) {
+            const int tj = __builtin_amdgcn_readlane(tgt, jj);
+            if (fok) acc += lds[jj * LD + lane];
+            const int tn = (jj + 1 < nval) ? __builtin_amdgcn_readlane(tgt, jj + 1) : -1;
+            if (tn != tj) {
+                const int s = rowptr[tj], e = rowptr[tj + 1];
+                const bool complete = (s >= e0) && (e <= e0 + 32);
+                if (fok) {
+                    if (complete) agg[(size_t)tj * D + f] = acc / (float)(e - s);
+                    else partials[((size_t)tile * 2 + (s < e0 ? 0 : 1)) * D + f] = acc;
                 }
-                acc[m] = 0.f;
+                acc = 0.f;
             }
         }
+        wave_lds_sync();
     }
-    __syncthreads();
 }

@@ -12,9 +12,21 @@
 // models/magnet_gnn.py:22-36,55-68,129-132,193-197.
 #include "common.cuh"
 
+// layer 0: K streamed tile by tile from the gathered sources (hipcc schedules the loads; a hand
+// pipelined version with sched_barriers measured 20-30 % slower, see DESIGN.md "what did not work")
+template <int NT>
+__device__ __forceinline__ void stream_layer(const MagnetMlpArgs& a, f32x16 (&out)[NT], int row, int lane) {
+    const int half = lane >> 5;
+    init_bias<NT>(out, a.layer[0].b, half);
+    for (int kt = 0; kt < a.nkt; ++kt) {
+        const f32x16 x = load_ktile(a.kt[kt], row, half);
+        mma_ktile<NT>(x, out, a.layer[0].w, kt, lane);
+    }
+}
+
 template <int NL, int HT, int OT, int ACT, bool LAST_ACT, bool LN, int EPI>
 __global__ void __launch_bounds__(256) k_mlp(const MagnetMlpArgs a) {
-    constexpr int LDS_FLOATS = (EPI == EPI_SEGMEAN) ? 4 * 32 * (OT * 32 + 4) : 1;
+    constexpr int LDS_FLOATS = (EPI == EPI_SEGMEAN) ? 4 * SegSlab<OT>::FLOATS : 1;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5;
@@ -25,18 +37,10 @@ __global__ void __launch_bounds__(256) k_mlp(const MagnetMlpArgs a) {
 
     f32x16 out[OT];
     if (NL == 1) {
-        init_bias<OT>(out, a.layer[0].b, half);
-        for (int kt = 0; kt < a.nkt; ++kt) {
-            const f32x16 x = load_ktile(a.kt[kt], row, half);
-            mma_ktile<OT>(x, out, a.layer[0].w, kt, lane);
-        }
+        stream_layer<OT>(a, out, row, lane);
     } else {
         f32x16 h0[HT], h1[HT];
-        init_bias<HT>(h0, a.layer[0].b, half);
-        for (int kt = 0; kt < a.nkt; ++kt) {
-            const f32x16 x = load_ktile(a.kt[kt], row, half);
-            mma_ktile<HT>(x, h0, a.layer[0].w, kt, lane);
-        }
+        stream_layer<HT>(a, h0, row, lane);
 #pragma unroll
         for (int t = 0; t < HT; ++t) apply_act<ACT>(h0[t]);
         // middle layers, ping-pong h0 <-> h1 (fully unrolled so register arrays stay static)
@@ -65,7 +69,7 @@ __global__ void __launch_bounds__(256) k_mlp(const MagnetMlpArgs a) {
         const int ntiles = (a.M + 31) / 32;
         const int nval = tile < ntiles ? min(32, a.M - tile * 32) : 0;
         const int tgt = a.tgt[row];
-        segmean_epilogue<OT>(out, lds + wave * 32 * (OT * 32 + 4), tile, nval, tgt, a.rowptr, a.y, a.partials, lane);
+        segmean_epilogue<OT>(out, lds + wave * SegSlab<OT>::FLOATS, tile, nval, tgt, a.rowptr, a.y, a.partials, lane);
     } else {
         store_rows<OT, EPI == EPI_STORE_RES>(out, a.y, a.ldy, a.ncols, a.res, a.ldres, row, row_ok, half);
     }

@@ -24,11 +24,12 @@ __global__ void k_mpnn_node_input(const float* __restrict__ u, const float* __re
 // W1*[x_i, x_j, u_i-u_j, p_i-p_j, v_i] + b1 = (W1a x_i + W1c u_i + W1d p_i + W1e v_i + b1)
 // + (W1b x_j - W1c u_j - W1d p_j)), so the [E, 2H+tw+d+1] concat and the [E, H] messages of
 // models/mpnn.py:73-79 + the scatter-mean of :46 never touch HBM.
+template <int PF, int ABL = 0>
 __global__ void __launch_bounds__(256) k_mpnn_edge(const float* __restrict__ A, const float* __restrict__ Bm,
                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
                                                    const int32_t* __restrict__ rowptr, int E, MagnetLayer W2,
                                                    float* __restrict__ agg, float* __restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * 132];
+    __shared__ __attribute__((aligned(16))) float lds[4 * SegSlab<4>::FLOATS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5;
     const int tile = blockIdx.x * 4 + wave;
@@ -43,16 +44,163 @@ __global__ void __launch_bounds__(256) k_mpnn_edge(const float* __restrict__ A, 
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(pa + kt * 32 + 8 * g);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(pb + kt * 32 + 8 * g);
+            f32x4 a, b;
+            if (ABL & 1) {          // ablation: no gather (synthetic operands, still per-lane distinct)
+                a = f32x4{0.001f * lane, 0.002f * kt, 0.003f * g, 0.1f};
+                b = f32x4{0.5f, 0.25f * ti, 0.125f, 0.0625f * sj};
+            } else {
+                a = *reinterpret_cast<const f32x4*>(pa + kt * 32 + 8 * g);
+                b = *reinterpret_cast<const f32x4*>(pb + kt * 32 + 8 * g);
+            }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) in[kt][4 * g + c] = act_swish(a[c] + b[c]);
+            for (int c = 0; c < 4; ++c) in[kt][4 * g + c] = (ABL & 4) ? (a[c] + b[c]) : act_swish(a[c] + b[c]);
         }
-    dense_layer<4, 4>(in, out, W2, lane);
+    dense_layer<4, 4, PF>(in, out, W2, lane);
+    if (!(ABL & 4)) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) apply_act<ACT_SWISH>(out[t]);
+        for (int t = 0; t < 4; ++t) apply_act<ACT_SWISH>(out[t]);
+    }
+    if (ABL & 2) {                  // ablation: no segment-mean epilogue (keep the result live)
+        float sacc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc += out[t][i];
+        if (sacc == 123.456f) agg[tile] = sacc;
+        return;
+    }
     const int nval = tile < ntiles ? min(32, E - tile * 32) : 0;
-    segmean_epilogue<4>(out, lds + wave * 32 * 132, tile, nval, ti, rowptr, agg, partials, lane);
+    segmean_epilogue<4>(out, lds + wave * SegSlab<4>::FLOATS, tile, nval, ti, rowptr, agg, partials, lane);
+}
+
+// ---------------------------------------------------------------------------- fused edge kernel, v2
+// Same arithmetic as k_mpnn_edge, restructured after profiling (profiles/r1):
+//  * message_net_2's packed weights (64 KiB) live in LDS, loaded once per persistent workgroup, so the
+//    MFMA stream no longer pulls 64 KiB per 32-edge tile through L1/L2 (7.5 TB/s of L2 reads before);
+//  * the segment mean is a segmented inclusive scan across the 32 edge lanes done with DPP
+//    (row_shr 1/2/4/8 inside 16-lane rows + row_bcast:15 across them) - no LDS slab, no barrier -
+//    and only the last lane of every run of equal targets stores;
+//  * persistent grid: NW waves per workgroup, 2 workgroups per CU, tiles strided over the grid.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xF, true));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_i(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, ROWMASK, 0xF, true);
+}
+#define DPP_SHR1 0x111
+#define DPP_SHR2 0x112
+#define DPP_SHR4 0x114
+#define DPP_SHR8 0x118
+#define DPP_BCAST15 0x142
+
+template <int NW, int ABL = 0>
+__global__ void __launch_bounds__(NW * 64, (NW == 12 ? 3 : 2)) k_mpnn_edge2(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                        const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
+                                                        const int32_t* __restrict__ rowptr, int E, MagnetLayer W2,
+                                                        float* __restrict__ agg, float* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) f32x4 wl[16 * 4 * 64];          // 64 KiB: W2 in fragment order
+    for (int i = threadIdx.x; i < 16 * 4 * 64; i += NW * 64) wl[i] = W2.w[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    const int ntiles = (E + 31) / 32;
+    for (int tile = blockIdx.x * NW + wave; tile < ntiles; tile += gridDim.x * NW) {
+        const int e0 = tile * 32;
+        const int e_raw = e0 + j;
+        const bool e_ok = e_raw < E;
+        const int e = e_ok ? e_raw : E - 1;
+        const int ti = tgt[e], sj = src[e];
+        const int tnext = (e_raw + 1 < E && j < 31) ? tgt[e_raw + 1] : -2;
+        const float* pa = A + (size_t)ti * 128 + 4 * half;
+        const float* pb = Bm + (size_t)sj * 128 + 4 * half;
+        f32x16 in[4], out[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 a, b;
+                if (ABL & 1) {
+                    a = f32x4{0.001f * lane, 0.002f * kt, 0.003f * g, 0.1f};
+                    b = f32x4{0.5f, 0.25f * ti, 0.125f, 0.0625f * sj};
+                } else {
+                    a = *reinterpret_cast<const f32x4*>(pa + kt * 32 + 8 * g);
+                    b = *reinterpret_cast<const f32x4*>(pb + kt * 32 + 8 * g);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) in[kt][4 * g + c] = (ABL & 4) ? (a[c] + b[c]) : act_swish(a[c] + b[c]);
+            }
+        init_bias<4>(out, W2.b, half);
+        {   // 16 (kt, nt) blocks; fragments for block b+1 are read from LDS while block b's MFMAs issue.
+            // The sched_barriers stop hipcc from hoisting all 64 ds_read_b128 to the top (256 VGPRs + spills).
+            f32x4 w[2][4];
+            const f32x4* wp = wl + lane;
+            w[0][0] = wp[0]; w[0][1] = wp[64]; w[0][2] = wp[128]; w[0][3] = wp[192];
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                if (b + 1 < 16) {
+                    const f32x4* wn = wl + (b + 1) * 256 + lane;
+                    w[(b + 1) & 1][0] = wn[0]; w[(b + 1) & 1][1] = wn[64];
+                    w[(b + 1) & 1][2] = wn[128]; w[(b + 1) & 1][3] = wn[192];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_block(w[b & 1], in[b >> 2], out[b & 3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (ABL & 2) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sacc += out[tt][i];
+            if (sacc == 123.456f) agg[tile] = sacc;
+            continue;
+        }
+        // ---- segmented scan over the 32 edge lanes (targets are non-decreasing along j)
+        const int t = e_ok ? ti : (-16 - j);                                   // padding lanes: singleton runs
+        const int jr = j & 15;
+        // the DPP moves must execute with every lane enabled: evaluate them before (not inside) the
+        // lane predicates - a short-circuit '&&' lets hipcc sink them under an exec mask, and a DPP
+        // read from a disabled lane returns 0
+        const int t1 = dpp_i<DPP_SHR1, 0xF>(t), t2 = dpp_i<DPP_SHR2, 0xF>(t), t4 = dpp_i<DPP_SHR4, 0xF>(t);
+        const int t8 = dpp_i<DPP_SHR8, 0xF>(t), tb = dpp_i<DPP_BCAST15, 0xA>(t);
+        const float m1 = ((jr >= 1) & (t1 == t)) ? 1.f : 0.f;
+        const float m2 = ((jr >= 2) & (t2 == t)) ? 1.f : 0.f;
+        const float m4 = ((jr >= 4) & (t4 == t)) ? 1.f : 0.f;
+        const float m8 = ((jr >= 8) & (t8 == t)) ? 1.f : 0.f;
+        const float mb = ((j >= 16) & (tb == t)) ? 1.f : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float x = act_swish(out[nt][i]);
+                x += m1 * dpp_f<DPP_SHR1, 0xF>(x);
+                x += m2 * dpp_f<DPP_SHR2, 0xF>(x);
+                x += m4 * dpp_f<DPP_SHR4, 0xF>(x);
+                x += m8 * dpp_f<DPP_SHR8, 0xF>(x);
+                x += mb * dpp_f<DPP_BCAST15, 0xA>(x);
+                out[nt][i] = x;
+            }
+        if (e_ok && tnext != ti) {                                             // last edge of a run: holds the run's sum
+            const int s = rowptr[ti], en = rowptr[ti + 1];
+            const bool complete = (s >= e0) && (en <= e0 + 32);
+            const float dn = complete ? (float)(en - s) : 1.f;
+            float* dst = complete ? agg + (size_t)ti * 128 : partials + ((size_t)tile * 2 + (s < e0 ? 0 : 1)) * 128;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {out[nt][4 * g], out[nt][4 * g + 1], out[nt][4 * g + 2], out[nt][4 * g + 3]};
+                    if (complete) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = v[c] / dn;
+                    }
+                    *reinterpret_cast<f32x4*>(dst + nt * 32 + 8 * g + 4 * half) = v;
+                }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------- read-out + Euler step
@@ -148,6 +296,14 @@ __global__ void k_norm_apply(const float* __restrict__ x, const float* __restric
 // ------------------------------------------------------------------------------------ C entry points
 #define LAUNCH_CHECK() return (int)hipGetLastError()
 
+static int g_edge_variant = 102;   // persistent v2 kernel, 8 waves / workgroup
+// development knob for A/B measurements: 102 = k_mpnn_edge2<8> (default), 0 = first-generation k_mpnn_edge,
+// 1x/11x = ablations (results invalid)
+extern "C" int magnet_debug_set_variant(int which, int value) {
+    if (which == 0) g_edge_variant = value;
+    return 0;
+}
+
 extern "C" int magnet_mpnn_node_input_f32(const float* u, const float* pos, int pos_ld, const float* Lvec,
                                           const float* tmax, int n, int tw, int dpos, int kin, float* out,
                                           void* stream) {
@@ -165,8 +321,43 @@ extern "C" int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32
     if (n_edges <= 0) return 0;
     MagnetLayer L{reinterpret_cast<const f32x4*>(w2_packed), b2};
     const int tiles = (n_edges + 31) / 32;
-    hipLaunchKernelGGL(k_mpnn_edge, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, A, Bm, src, tgt, rowptr,
-                       n_edges, L, agg, partials);
+    const dim3 g((tiles + 3) / 4), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (g_edge_variant) {
+        case 1: hipLaunchKernelGGL(k_mpnn_edge<1>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
+        case 2: hipLaunchKernelGGL(k_mpnn_edge<2>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
+        case 110: case 111: case 112: case 113: {
+            static int ncu2 = 0;
+            if (!ncu2) { hipDeviceProp_t prop; int dev; hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev); ncu2 = prop.multiProcessorCount; }
+            const int nw = 8; const dim3 gg(min((tiles + nw - 1) / nw, 2 * ncu2)), bb(nw * 64);
+            if (g_edge_variant == 110) hipLaunchKernelGGL((k_mpnn_edge2<8, 1>), gg, bb, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials);
+            else if (g_edge_variant == 111) hipLaunchKernelGGL((k_mpnn_edge2<8, 2>), gg, bb, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials);
+            else if (g_edge_variant == 112) hipLaunchKernelGGL((k_mpnn_edge2<8, 3>), gg, bb, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials);
+            else hipLaunchKernelGGL((k_mpnn_edge2<8, 7>), gg, bb, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials);
+            break;
+        }
+        case 100: case 101: case 102: case 103: {
+            // persistent v2: 2 workgroups per CU (64 KiB LDS each)
+            hipDeviceProp_t prop;
+            static int ncu = 0;
+            if (!ncu) { int dev; hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev); ncu = prop.multiProcessorCount; }
+            if (g_edge_variant == 103) { const int nw = 12; hipLaunchKernelGGL(k_mpnn_edge2<12>, dim3(min((tiles + nw - 1) / nw, ncu)), dim3(nw * 64), 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); }
+            else if (g_edge_variant == 100) { const int nw = 4; hipLaunchKernelGGL(k_mpnn_edge2<4>, dim3(min((tiles + nw - 1) / nw, 2 * ncu)), dim3(nw * 64), 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); }
+            else if (g_edge_variant == 101) { const int nw = 6; hipLaunchKernelGGL(k_mpnn_edge2<6>, dim3(min((tiles + nw - 1) / nw, 2 * ncu)), dim3(nw * 64), 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); }
+            else { const int nw = 8; hipLaunchKernelGGL(k_mpnn_edge2<8>, dim3(min((tiles + nw - 1) / nw, 2 * ncu)), dim3(nw * 64), 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); }
+            break;
+        }
+        case 3: hipLaunchKernelGGL(k_mpnn_edge<3>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
+        case 23: hipLaunchKernelGGL((k_mpnn_edge<3, 7>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
+        case 22: hipLaunchKernelGGL((k_mpnn_edge<2, 7>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
+        case 21: hipLaunchKernelGGL((k_mpnn_edge<1, 7>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
+        case 10: hipLaunchKernelGGL((k_mpnn_edge<0, 1>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
+        case 11: hipLaunchKernelGGL((k_mpnn_edge<0, 2>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
+        case 12: hipLaunchKernelGGL((k_mpnn_edge<0, 3>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
+        case 13: hipLaunchKernelGGL((k_mpnn_edge<0, 7>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
+        case 14: hipLaunchKernelGGL((k_mpnn_edge<0, 4>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
+        default: hipLaunchKernelGGL(k_mpnn_edge<0>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
+    }
     LAUNCH_CHECK();
 }
 
