@@ -113,6 +113,10 @@ int magnet_instance_norm_f32(const float* x, int n_graphs, int rows_per_graph, i
 /* nbr[q*cap + 0..cnt[q]) = first `cap` nodes (ascending index, same graph) with dist^2 < r2 */
 int magnet_radius_search_f32(const float* x, int dim, int n_nodes, const int32_t* graph_ptr, int n_graphs, float r2,
                              int cap, int32_t* nbr, int32_t* cnt, void* stream);
+/* identical output, chunk-bounding-box pruning (chunk_ptr[g] = first 64-node chunk of graph g) */
+int magnet_radius_search_bbox_f32(const float* x, int dim, int n_nodes, const int32_t* graph_ptr,
+                                  const int32_t* chunk_ptr, int n_graphs, int n_chunks, float r2, int cap,
+                                  float* bbox_scratch, int32_t* nbr, int32_t* cnt, void* stream);
 int magnet_radius_offsets(const int32_t* nbr, const int32_t* cnt, int n_nodes, int cap, int loop, int32_t* qptr,
                           void* stream);
 int magnet_radius_emit_pairs(const int32_t* nbr, const int32_t* cnt, const int32_t* qptr, int n_nodes, int cap,

@@ -59,10 +59,11 @@ def test_radius_graph_matches_torch_cluster_restatement(dim, loop):
     r = 0.25
     batch = torch.arange(B).repeat_interleave(N)
     want = radius_graph(x, r, batch, loop=loop)
-    found, query, qptr, E = ops.radius_pairs(x.cuda(), r, ops.graph_ptr(B, N, "cuda"), loop=loop)
-    got = torch.stack([found.long(), query.long()]).cpu()
-    assert E == want.shape[1]
-    assert torch.equal(got, want)
+    for brute in (False, True):                            # bounding-box pruned and brute-force kernels
+        found, query, qptr, E = ops.radius_pairs(x.cuda(), r, ops.graph_ptr(B, N, "cuda"), loop=loop, brute_force=brute)
+        got = torch.stack([found.long(), query.long()]).cpu()
+        assert E == want.shape[1]
+        assert torch.equal(got, want)
     deg = torch.bincount(want[1], minlength=B * N)
     assert int(deg.max()) >= 32                            # the cap was exercised
 
