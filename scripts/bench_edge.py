@@ -48,3 +48,7 @@ ms = timeit(lambda: ops.mlp(N, ops.ktiles(T(h, H), T(node_in, 32)), [lyr.pre_a],
 print(f"node pre (one of two): {ms:.3f} ms  {2*N*160*128/ms/1e9:.1f} TFLOP/s")
 ms = timeit(lambda: ops.instance_norm(gbuf, B, N // B, out=h))
 print(f"instance norm: {ms:.3f} ms")
+msg = torch.randn(E, H, device="cuda"); outm = torch.empty(N, H, device="cuda")
+ms = timeit(lambda: ops.segment_mean(msg, csr.rowptr, N, outm))
+nbytes = E * H * 4 + N * H * 4 + 4 * (N + 1)
+print(f"segment_mean<128>: {ms:.3f} ms  {nbytes/ms/1e6:.0f} GB/s  ({nbytes/1e9:.3f} GB algorithmic)")
