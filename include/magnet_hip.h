@@ -98,6 +98,12 @@ int magnet_mpnn_node_input_f32(const float* u, const float* pos, int pos_ld, con
 int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
                          const int32_t* rowptr, int n_edges, const void* w2_packed, const float* b2, float* agg,
                          float* partials, void* stream);
+/* Same contract as magnet_mpnn_edge_f32, message_net_2 evaluated on the bf16 matrix cores through the exact
+ * hi/mid/lo split (six partial products, fp32-class accuracy).  w2_split: the three bf16 planes of
+ * W2 in fragment order [kt][nt][m][plane][64 lanes][8 bf16] (magnet_amd/packing.py:pack_linear_bf16x3). */
+int magnet_mpnn_edge_bf16x6_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
+                                const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2, float* agg,
+                                float* partials, void* stream);
 /* out[n][k] = u[n][tw-1] + dt*(k+1) * Conv1d(8->1,k2)([Swish](Conv1d(1->8,k1,stride s1)(h[n])))[k];
  * models/mpnn.py:197-201 with the conv specs of :140-163. */
 int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1, int k1,

@@ -178,6 +178,73 @@ __device__ __forceinline__ void dense_layer(const f32x16 (&in)[KT], f32x16 (&out
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix cores ("bf16x6 split").  Every fp32 value is written EXACTLY as
+// hi + mid + lo with three bf16 pieces (8 significant bits each, truncation), and a product x*w is
+// evaluated as the six partial products whose weight is >= 2^-16 of the leading one
+// (hh, hm, mh, hl, lh, mm); each partial product is exact in fp32 and the dropped terms are <= 3*2^-24
+// of the product, i.e. fp32-rounding class (measured 1.7e-7 relative L2 vs fp64 at K = 128, the plain
+// fp32 fmaf chain gives 2.1e-7).  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMA, so six
+// of them are 2.7x faster, and - unlike v_mfma_f32_32x32x2_f32, which was measured not to hide any VALU
+// work - VALU instructions issued between bf16 MFMAs of the same wave are hidden.
+// Fragment order: one instruction contracts 16 k's; lane (row, half) supplies slots c' = 0..7 <->
+// k = 8*(2m + (c'>>2)) + 4*half + (c'&3) of the 32-wide k tile, m = 0,1 - i.e. registers 8m .. 8m+7
+// of the C/D map, so a layer's output registers are again the next layer's B operands.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_top16(float v1, float v0) {   // (top16(v1) << 16) | top16(v0)
+    return __builtin_amdgcn_perm(__float_as_uint(v1), __float_as_uint(v0), 0x07060302u);
+}
+// split 8 fp32 values into the three bf16 planes (exact)
+__device__ __forceinline__ void split_bf16x3(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    u32x4 h, m, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float a0 = v[2 * p], a1 = v[2 * p + 1];
+        const float r0 = a0 - __uint_as_float(__float_as_uint(a0) & 0xFFFF0000u);
+        const float r1 = a1 - __uint_as_float(__float_as_uint(a1) & 0xFFFF0000u);
+        const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xFFFF0000u);
+        const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+        h[p] = pack_top16(a1, a0);
+        m[p] = pack_top16(r1, r0);
+        l[p] = pack_top16(q1, q0);
+    }
+    hi = __builtin_bit_cast(bf16x8, h);
+    mid = __builtin_bit_cast(bf16x8, m);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+// the same split, one register pair (= one 32-bit word of each plane) at a time so that it can be
+// spread over MFMA shadows: word p of planes[0..2] <- values 8m+2p, 8m+2p+1 of the k tile
+__device__ __forceinline__ void split_quarter(const f32x16& tile, int m, int p, u32x4 (&planes)[3]) {
+    const float a0 = tile[8 * m + 2 * p], a1 = tile[8 * m + 2 * p + 1];
+    const float r0 = a0 - __uint_as_float(__float_as_uint(a0) & 0xFFFF0000u);
+    const float r1 = a1 - __uint_as_float(__float_as_uint(a1) & 0xFFFF0000u);
+    const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xFFFF0000u);
+    const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+    planes[0][p] = pack_top16(a1, a0);
+    planes[1][p] = pack_top16(r1, r0);
+    planes[2][p] = pack_top16(q1, q0);
+}
+__device__ __forceinline__ void split_pair4(const f32x16& tile, int m, u32x4 (&planes)[3]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) split_quarter(tile, m, p, planes);
+}
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// acc += W(slot) * X for one 16-k slot: the six retained partial products, small ones first
+__device__ __forceinline__ f32x16 mma_split6(bf16x8 wh, bf16x8 wm, bf16x8 wl, bf16x8 xh, bf16x8 xm, bf16x8 xl,
+                                             f32x16 acc) {
+    acc = mfma_bf16(wm, xm, acc);
+    acc = mfma_bf16(wl, xh, acc);
+    acc = mfma_bf16(wh, xl, acc);
+    acc = mfma_bf16(wm, xh, acc);
+    acc = mfma_bf16(wh, xm, acc);
+    acc = mfma_bf16(wh, xh, acc);
+    return acc;
+}
+
 // first-layer k tile from the (gathered / concatenated / differenced) sources
 __device__ __forceinline__ f32x16 load_ktile(const MagnetKTile& d, int row, int half) {
     f32x16 v;
@@ -271,6 +338,22 @@ __device__ __forceinline__ void store_rows(const f32x16 (&v)[NT], float* __restr
             }
         }
 }
+
+// ---- DPP lane moves (all lanes must be enabled when these execute: never put them behind a
+// short-circuit condition, a DPP read from a disabled lane returns 0)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xF, true));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_i(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, ROWMASK, 0xF, true);
+}
+#define DPP_SHR1 0x111
+#define DPP_SHR2 0x112
+#define DPP_SHR4 0x114
+#define DPP_SHR8 0x118
+#define DPP_BCAST15 0x142
 
 // The LDS slab of segmean_epilogue is private to one wave and a wave's DS operations execute in
 // program order, so ordering the slab's writes against its reads only needs the compiler not to

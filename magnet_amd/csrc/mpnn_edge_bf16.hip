@@ -1,0 +1,198 @@
+// Fused MPNN edge kernel on the bf16 matrix cores - generation 6 (see DESIGN.md 3.2 for the measurements
+// that led here).
+//
+//   m_e = Swish(W2 * Swish(A[i] + Bm[j]) + b2),  agg[i] = mean_e m_e          (models/mpnn.py:73-79,46)
+//
+// * message_net_2 is evaluated with the exact hi/mid/lo bf16 split (common.cuh, "bf16x6"): 192
+//   v_mfma_f32_32x32x16_bf16 per 32-edge tile, fp32-class accuracy, weight planes (96 KiB) resident in LDS.
+// * ONE wave per SIMD (4 waves per CU, up to 512 registers each).  Measured on gfx950: MFMA and VALU work of
+//   two different waves on one SIMD do not overlap, but VALU instructions placed between the bf16 MFMAs of
+//   the same wave are hidden.  So all overlap is built inside the wave, as an explicit software pipeline over
+//   the 32 MFMA groups (6 MFMAs each) of tile t:
+//       - weight fragments of the next group        (LDS reads)
+//       - a quarter of the next k-slot's split      (VALU)
+//       - the A[i] / Bm[j] rows of tile t+1, one k tile at a time as soon as tile t has consumed the
+//         matching registers, and Swish(A + Bm) two k tiles later           (global loads + VALU)
+//       - the Swish + segmented DPP scan of two of tile t-1's 64 output registers          (VALU)
+//   sched_barriers after every group keep hipcc from undoing the placement.
+#include "common.cuh"
+
+struct TileMeta {            // what the epilogue of a tile needs, carried one iteration
+    int tile, ti, tnext;
+    bool e_ok;
+    float m1, m2, m4, m8, mb;
+};
+
+__device__ __forceinline__ TileMeta tile_meta(int tile, int E, const int32_t* __restrict__ tgt, int j) {
+    TileMeta md;
+    md.tile = tile;
+    const int e_raw = tile * 32 + j;
+    md.e_ok = e_raw < E;
+    md.ti = tgt[md.e_ok ? e_raw : E - 1];
+    md.tnext = (e_raw + 1 < E && j < 31) ? tgt[e_raw + 1] : -2;
+    const int t = md.e_ok ? md.ti : (-16 - j);
+    const int jr = j & 15;
+    const int t1 = dpp_i<DPP_SHR1, 0xF>(t), t2 = dpp_i<DPP_SHR2, 0xF>(t), t4 = dpp_i<DPP_SHR4, 0xF>(t);
+    const int t8 = dpp_i<DPP_SHR8, 0xF>(t), tb = dpp_i<DPP_BCAST15, 0xA>(t);
+    md.m1 = ((jr >= 1) & (t1 == t)) ? 1.f : 0.f;
+    md.m2 = ((jr >= 2) & (t2 == t)) ? 1.f : 0.f;
+    md.m4 = ((jr >= 4) & (t4 == t)) ? 1.f : 0.f;
+    md.m8 = ((jr >= 8) & (t8 == t)) ? 1.f : 0.f;
+    md.mb = ((j >= 16) & (tb == t)) ? 1.f : 0.f;
+    return md;
+}
+
+// Swish + segmented inclusive scan of one output register across the 32 edge lanes
+__device__ __forceinline__ float scan_reg(float v, const TileMeta& md) {
+    float x = act_swish(v);
+    x += md.m1 * dpp_f<DPP_SHR1, 0xF>(x);
+    x += md.m2 * dpp_f<DPP_SHR2, 0xF>(x);
+    x += md.m4 * dpp_f<DPP_SHR4, 0xF>(x);
+    x += md.m8 * dpp_f<DPP_SHR8, 0xF>(x);
+    x += md.mb * dpp_f<DPP_BCAST15, 0xA>(x);
+    return x;
+}
+
+// the last lane of every run of equal targets holds the run's sum: finished mean or tile-boundary partial
+__device__ __forceinline__ void store_runs(const f32x16 (&v)[4], const TileMeta& md, const int32_t* __restrict__ rowptr,
+                                           float* __restrict__ agg, float* __restrict__ partials, int half) {
+    if (md.e_ok && md.tnext != md.ti) {
+        const int e0 = md.tile * 32;
+        const int s = rowptr[md.ti], en = rowptr[md.ti + 1];
+        const bool complete = (s >= e0) && (en <= e0 + 32);
+        const float dn = complete ? (float)(en - s) : 1.f;
+        float* dst = complete ? agg + (size_t)md.ti * 128 : partials + ((size_t)md.tile * 2 + (s < e0 ? 0 : 1)) * 128;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o = {v[nt][4 * g], v[nt][4 * g + 1], v[nt][4 * g + 2], v[nt][4 * g + 3]};
+                if (complete) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = o[c] / dn;
+                }
+                *reinterpret_cast<f32x4*>(dst + nt * 32 + 8 * g + 4 * half) = o;
+            }
+    }
+}
+
+__global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                       const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
+                                                       const int32_t* __restrict__ rowptr, int E,
+                                                       const u32x4* __restrict__ w2s /* [32 slots][3 planes][64] */,
+                                                       const float* __restrict__ b2, float* __restrict__ agg,
+                                                       float* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) u32x4 wl[32 * 3 * 64];           // 96 KiB
+    for (int i = threadIdx.x; i < 32 * 3 * 64; i += 256) wl[i] = w2s[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    const int ntiles = (E + 31) / 32;
+    const int stride = gridDim.x * 4;
+    int tile = blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+    f32x16 in[4], out[4], prev[4];
+    f32x4 la[4], lb[4];                       // one k tile (32 columns) of A[i] / Bm[j] in flight
+    {   // prologue: gather + Swish for the first tile
+        const int e = min(tile * 32 + j, E - 1);
+        const float* pa = A + (size_t)tgt[e] * 128 + 4 * half;
+        const float* pb = Bm + (size_t)src[e] * 128 + 4 * half;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(pa + kt * 32 + 8 * g);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(pb + kt * 32 + 8 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) in[kt][4 * g + c] = act_swish(a[c] + b[c]);
+            }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) prev[nt][i] = 0.f;
+    }
+    TileMeta pmd = tile_meta(tile, E, tgt, j);      // placeholder until a real previous tile exists
+    bool have_prev = false;
+    for (; tile < ntiles; tile += stride) {
+        const TileMeta md = tile_meta(tile, E, tgt, j);
+        const int tn = tile + stride < ntiles ? tile + stride : tile;     // clamped: last iteration prefetches unused data
+        const int en = min(tn * 32 + j, E - 1);
+        const float* pan = A + (size_t)tgt[en] * 128 + 4 * half;
+        const float* pbn = Bm + (size_t)src[en] * 128 + 4 * half;
+        init_bias<4>(out, b2, half);
+        {
+            u32x4 xs[2][3], wr[2][3];
+            split_pair4(in[0], 0, xs[0]);
+            {
+                const u32x4* wp = wl + lane;
+                wr[0][0] = wp[0]; wr[0][1] = wp[64]; wr[0][2] = wp[128];
+            }
+#pragma unroll
+            for (int gq = 0; gq < 32; ++gq) {     // gq = slot * 4 + nt, slot = kt * 2 + m
+                const int slot = gq >> 2, nt = gq & 3;
+                if (gq + 1 < 32) {
+                    const int s1 = (gq + 1) >> 2, n1 = (gq + 1) & 3;
+                    const u32x4* wp = wl + ((((s1 >> 1) * 4 + n1) * 2 + (s1 & 1)) * 3) * 64 + lane;
+                    wr[(gq + 1) & 1][0] = wp[0]; wr[(gq + 1) & 1][1] = wp[64]; wr[(gq + 1) & 1][2] = wp[128];
+                }
+                if (slot + 1 < 8) split_quarter(in[(slot + 1) >> 1], (slot + 1) & 1, nt, xs[(slot + 1) & 1]);
+                out[nt] = mma_split6(__builtin_bit_cast(bf16x8, wr[gq & 1][0]), __builtin_bit_cast(bf16x8, wr[gq & 1][1]),
+                                     __builtin_bit_cast(bf16x8, wr[gq & 1][2]), __builtin_bit_cast(bf16x8, xs[slot & 1][0]),
+                                     __builtin_bit_cast(bf16x8, xs[slot & 1][1]), __builtin_bit_cast(bf16x8, xs[slot & 1][2]),
+                                     out[nt]);
+                // epilogue of the previous tile, two registers per group
+                prev[(2 * gq) >> 4][(2 * gq) & 15] = scan_reg(prev[(2 * gq) >> 4][(2 * gq) & 15], pmd);
+                prev[(2 * gq + 1) >> 4][(2 * gq + 1) & 15] = scan_reg(prev[(2 * gq + 1) >> 4][(2 * gq + 1) & 15], pmd);
+                // rolling gather prefetch for the next tile (k tile kt of `in` is dead after group 8kt+3)
+                if ((gq & 7) == 4) {
+                    const int kt = gq >> 3;
+                    if (kt > 0) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) in[kt - 1][4 * g + c] = act_swish(la[g][c] + lb[g][c]);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        la[g] = *reinterpret_cast<const f32x4*>(pan + kt * 32 + 8 * g);
+                        lb[g] = *reinterpret_cast<const f32x4*>(pbn + kt * 32 + 8 * g);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (have_prev) store_runs(prev, pmd, rowptr, agg, partials, half);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) prev[nt] = out[nt];
+        pmd = md;
+        have_prev = true;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) in[3][4 * g + c] = act_swish(la[g][c] + lb[g][c]);
+    }
+    // epilogue of the last tile
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) prev[nt][i] = scan_reg(prev[nt][i], pmd);
+    store_runs(prev, pmd, rowptr, agg, partials, half);
+}
+
+extern "C" int magnet_mpnn_edge_bf16x6_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
+                                           const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2,
+                                           float* agg, float* partials, void* stream) {
+    if (n_edges <= 0) return 0;
+    static int ncu = 0;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        int dev;
+        hipGetDevice(&dev);
+        hipGetDeviceProperties(&prop, dev);
+        ncu = prop.multiProcessorCount;
+    }
+    const int tiles = (n_edges + 31) / 32;
+    hipLaunchKernelGGL(k_mpnn_edge6, dim3(min((tiles + 3) / 4, ncu)), dim3(256), 0, (hipStream_t)stream, A, Bm, src, tgt,
+                       rowptr, n_edges, reinterpret_cast<const u32x4*>(w2_split), b2, agg, partials);
+    return (int)hipGetLastError();
+}

@@ -111,6 +111,14 @@ def mpnn_node_input(u, pos, Lvec, tmax, tw, dpos, kin):
     return out
 
 
+def mpnn_edge_bf16x6(A, Bm, csr, w2_split, b2, agg, partials):
+    """fused MPNN edge kernel with message_net_2 on the bf16 matrix cores (exact 3-piece split)."""
+    L.check(L.lib().magnet_mpnn_edge_bf16x6_f32(_p(A), _p(Bm), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.E,
+                                                _p(w2_split), _p(b2), _p(agg), _p(partials), _stream()), "mpnn_edge_bf16x6")
+    segmean_fixup(csr.rowptr, csr.N, 128, partials, agg)
+    return agg
+
+
 def mpnn_edge(A, Bm, csr, w2, b2, agg, partials):
     L.check(L.lib().magnet_mpnn_edge_f32(_p(A), _p(Bm), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.E, _p(w2), _p(b2),
                                          _p(agg), _p(partials), _stream()), "mpnn_edge")

@@ -39,3 +39,41 @@ def pad_vec(v: torch.Tensor, n_pad: int) -> torch.Tensor:
     out = torch.zeros(n_pad, dtype=torch.float32, device=v.device)
     out[: v.numel()] = v.detach().float()
     return out
+
+
+def split_bf16x3(w: torch.Tensor):
+    """Exact 3-piece bf16 split of an fp32 tensor (truncation): w == hi + mid + lo, each piece has 8
+    significant bits.  Returned as int16 tensors holding the bf16 bit patterns."""
+    def top(t):
+        return (t.contiguous().view(torch.int32) >> 16).to(torch.int16)
+
+    def trunc(t):
+        return (t.contiguous().view(torch.int32) & -65536).view(torch.float32)
+
+    w = w.detach().float().contiguous()
+    hi = trunc(w)
+    r1 = w - hi
+    mid = trunc(r1)
+    lo = r1 - mid
+    return top(hi), top(mid), top(lo)
+
+
+def pack_linear_bf16x3(w: torch.Tensor, b: torch.Tensor | None, k_pad: int | None = None, n_pad: int | None = None):
+    """Split planes in MFMA fragment order [kt][nt][m][plane][lane][8] (int16) + padded fp32 bias.
+
+        slot c' of lane (i, h), k-slot m  <->  W[nt*32 + i][kt*32 + 8*(2m + (c'>>2)) + 4*h + (c'&3)]
+    """
+    n, k = w.shape
+    kp, np_ = k_pad or pad_to(k), n_pad or pad_to(n)
+    wp = torch.zeros(np_, kp, dtype=torch.float32, device=w.device)
+    wp[:n, :k] = w.detach().float()
+    kt, nt = kp // 32, np_ // 32
+    planes = []
+    for pl in split_bf16x3(wp):
+        # [nt, i, kt, m, gg, h, c] -> [kt, nt, m, h, i, gg, c]
+        planes.append(pl.view(nt, 32, kt, 2, 2, 2, 4).permute(2, 0, 3, 5, 1, 4, 6).reshape(kt, nt, 2, 64, 8))
+    out = torch.stack(planes, dim=3).contiguous()           # [kt, nt, m, plane, lane, 8]
+    bp = torch.zeros(np_, dtype=torch.float32, device=w.device)
+    if b is not None:
+        bp[:n] = b.detach().float()
+    return out.view(-1), bp

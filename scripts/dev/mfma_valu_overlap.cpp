@@ -35,6 +35,32 @@ __global__ void __launch_bounds__(512) k(float* out, int iters) {
         }
     }
 }
+// same wave: NV independent FMAs (+ optional exp) between consecutive fp32 MFMAs
+template <int NV, int NEXP>
+__global__ void __launch_bounds__(256) k_same(float* out, int iters) {
+    float a = threadIdx.x * 0.001f, b = 1.0001f;
+    f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    float x[16];
+    for (int i = 0; i < 16; ++i) x[i] = a + i;
+    for (int i = 0; i < iters; ++i) {
+#define GAP() { _Pragma("unroll") for (int q = 0; q < NV; ++q) x[q] = fmaf(x[q], b, a); _Pragma("unroll") for (int q = 0; q < NEXP; ++q) x[8 + q] = __expf(x[8 + q]) * 0.1f; }
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0); GAP();
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c1, 0, 0, 0); GAP();
+        c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c2, 0, 0, 0); GAP();
+        c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c3, 0, 0, 0); GAP();
+    }
+    float s = c0[0] + c1[1] + c2[2] + c3[3];
+    for (int i = 0; i < 16; ++i) s += x[i];
+    out[threadIdx.x + blockIdx.x * 256] = s;
+}
+template <int NV, int NEXP> float run_same(float* d, int iters) {
+    hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
+    hipLaunchKernelGGL((k_same<NV, NEXP>), dim3(256), dim3(256), 0, 0, d, iters);
+    hipEventRecord(s);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k_same<NV, NEXP>), dim3(256), dim3(256), 0, 0, d, iters);
+    hipEventRecord(e); hipEventSynchronize(e);
+    float ms; hipEventElapsedTime(&ms, s, e); return ms / 5;
+}
 template <int MODE> float run(float* d, int iters) {
     hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
     hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(512), 0, 0, d, iters);
@@ -53,5 +79,7 @@ int main() {
     printf("MFMA + VALU fma: %.3f ms  (sum would be %.3f, max %.3f)\n", t2, t0 + t1, t0 > t1 ? t0 : t1);
     printf("exp only       : %.3f ms\n", t3);
     printf("MFMA + exp     : %.3f ms  (sum would be %.3f, max %.3f)\n", t4, t0 + t3, t0 > t3 ? t0 : t3);
+    printf("same wave, fp32 MFMA + N FMA per gap: N=0 %.3f  N=4 %.3f  N=8 %.3f  N=8+2exp %.3f  N=8+4exp %.3f ms\n",
+           run_same<0, 0>(d, iters), run_same<4, 0>(d, iters), run_same<8, 0>(d, iters), run_same<8, 2>(d, iters), run_same<8, 4>(d, iters));
     return 0;
 }

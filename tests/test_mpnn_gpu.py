@@ -10,12 +10,13 @@ OUT_TOL = 1e-5      # relative L2 on the forward output (BASELINE.json north_sta
 INC_TOL = 1e-4      # relative L2 on the increment out - u_last ("hard parts")
 
 
-def _models(tag):
+def _models(tag, edge_gemm="bf16x6"):
     from magnet_amd.models.factory import FACTORY
     from oracle import models as O
     from oracle.weightgen import fill_state_dict
 
     name, hp, salt, batch, d = load_case(tag)
+    hp.edge_gemm = edge_gemm
     oracle = O.build(name, hp).eval()
     fill_state_dict(oracle, salt)
     model = FACTORY[name](hp).eval()
@@ -23,9 +24,10 @@ def _models(tag):
     return name, hp, batch, d, oracle, model.cuda()
 
 
+@pytest.mark.parametrize("edge_gemm", ["bf16x6", "fp32"])
 @pytest.mark.parametrize("tag", ["mpnn_1d", "mpnn_2d"])
-def test_forward_and_rollout_match(tag):
-    name, hp, batch, d, oracle, model = _models(tag)
+def test_forward_and_rollout_match(tag, edge_gemm):
+    name, hp, batch, d, oracle, model = _models(tag, edge_gemm)
     cb = {k: v.cuda() for k, v in batch.items()}
     u, x, t = model._unpack(cb)
     tw = hp.time_window
