@@ -76,6 +76,7 @@ __device__ __forceinline__ void store_runs(const f32x16 (&v)[4], const TileMeta&
     }
 }
 
+template <int ABL>
 __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__ A, const float* __restrict__ Bm,
                                                        const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
                                                        const int32_t* __restrict__ rowptr, int E,
@@ -135,16 +136,18 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__
                     const u32x4* wp = wl + ((((s1 >> 1) * 4 + n1) * 2 + (s1 & 1)) * 3) * 64 + lane;
                     wr[(gq + 1) & 1][0] = wp[0]; wr[(gq + 1) & 1][1] = wp[64]; wr[(gq + 1) & 1][2] = wp[128];
                 }
-                if (slot + 1 < 8) split_quarter(in[(slot + 1) >> 1], (slot + 1) & 1, nt, xs[(slot + 1) & 1]);
+                if (!(ABL & 1) && slot + 1 < 8) split_quarter(in[(slot + 1) >> 1], (slot + 1) & 1, nt, xs[(slot + 1) & 1]);
                 out[nt] = mma_split6(__builtin_bit_cast(bf16x8, wr[gq & 1][0]), __builtin_bit_cast(bf16x8, wr[gq & 1][1]),
                                      __builtin_bit_cast(bf16x8, wr[gq & 1][2]), __builtin_bit_cast(bf16x8, xs[slot & 1][0]),
                                      __builtin_bit_cast(bf16x8, xs[slot & 1][1]), __builtin_bit_cast(bf16x8, xs[slot & 1][2]),
                                      out[nt]);
                 // epilogue of the previous tile, two registers per group
-                prev[(2 * gq) >> 4][(2 * gq) & 15] = scan_reg(prev[(2 * gq) >> 4][(2 * gq) & 15], pmd);
-                prev[(2 * gq + 1) >> 4][(2 * gq + 1) & 15] = scan_reg(prev[(2 * gq + 1) >> 4][(2 * gq + 1) & 15], pmd);
+                if (!(ABL & 2)) {
+                    prev[(2 * gq) >> 4][(2 * gq) & 15] = scan_reg(prev[(2 * gq) >> 4][(2 * gq) & 15], pmd);
+                    prev[(2 * gq + 1) >> 4][(2 * gq + 1) & 15] = scan_reg(prev[(2 * gq + 1) >> 4][(2 * gq + 1) & 15], pmd);
+                }
                 // rolling gather prefetch for the next tile (k tile kt of `in` is dead after group 8kt+3)
-                if ((gq & 7) == 4) {
+                if (!(ABL & 4) && (gq & 7) == 4) {
                     const int kt = gq >> 3;
                     if (kt > 0) {
 #pragma unroll
@@ -179,6 +182,8 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__
     store_runs(prev, pmd, rowptr, agg, partials, half);
 }
 
+int g_edge6_ablation = 0;
+
 extern "C" int magnet_mpnn_edge_bf16x6_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
                                            const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2,
                                            float* agg, float* partials, void* stream) {
@@ -192,7 +197,15 @@ extern "C" int magnet_mpnn_edge_bf16x6_f32(const float* A, const float* Bm, cons
         ncu = prop.multiProcessorCount;
     }
     const int tiles = (n_edges + 31) / 32;
-    hipLaunchKernelGGL(k_mpnn_edge6, dim3(min((tiles + 3) / 4, ncu)), dim3(256), 0, (hipStream_t)stream, A, Bm, src, tgt,
-                       rowptr, n_edges, reinterpret_cast<const u32x4*>(w2_split), b2, agg, partials);
+    const dim3 g(min((tiles + 3) / 4, ncu)), b(256);
+    const u32x4* ws = reinterpret_cast<const u32x4*>(w2_split);
+    hipStream_t s = (hipStream_t)stream;
+    switch (g_edge6_ablation) {   // development only: ablations produce invalid results
+        case 1: hipLaunchKernelGGL(k_mpnn_edge6<1>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
+        case 2: hipLaunchKernelGGL(k_mpnn_edge6<2>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
+        case 4: hipLaunchKernelGGL(k_mpnn_edge6<4>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
+        case 7: hipLaunchKernelGGL(k_mpnn_edge6<7>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
+        default: hipLaunchKernelGGL(k_mpnn_edge6<0>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
+    }
     return (int)hipGetLastError();
 }

@@ -190,424 +190,6 @@ __global__ void __launch_bounds__(NW * 64, (NW == 12 ? 3 : 2)) k_mpnn_edge2(cons
     }
 }
 
-// ---------------------------------------------------------------------------- fused edge kernel, v3
-// k_mpnn_edge2 with message_net_2 evaluated on the bf16 matrix cores through the exact 3-piece split
-// (common.cuh, "bf16x6"): 192 v_mfma_f32_32x32x16_bf16 per 32-edge tile instead of 256
-// v_mfma_f32_32x32x2_f32 (6 144 vs 16 384 matrix-pipe cycles), fp32-class accuracy.  The weight planes
-// (3 x 32 KiB, pre-split and pre-packed on the host) live in LDS; activations are split per 8-k slot
-// right before use so the split's VALU work sits in the MFMA shadows.
-template <int NW, int ABL = 0>
-__global__ void __launch_bounds__(NW * 64, 2) k_mpnn_edge3(const float* __restrict__ A, const float* __restrict__ Bm,
-                                                           const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
-                                                           const int32_t* __restrict__ rowptr, int E,
-                                                           const u32x4* __restrict__ w2s /* [32 slots][3 planes][64] */,
-                                                           const float* __restrict__ b2, float* __restrict__ agg,
-                                                           float* __restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) u32x4 wl[32 * 3 * 64];           // 96 KiB
-    for (int i = threadIdx.x; i < 32 * 3 * 64; i += NW * 64) wl[i] = w2s[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = lane >> 5, j = lane & 31;
-    const int ntiles = (E + 31) / 32;
-    for (int tile = blockIdx.x * NW + wave; tile < ntiles; tile += gridDim.x * NW) {
-        const int e0 = tile * 32;
-        const int e_raw = e0 + j;
-        const bool e_ok = e_raw < E;
-        const int e = e_ok ? e_raw : E - 1;
-        const int ti = tgt[e], sj = src[e];
-        const int tnext = (e_raw + 1 < E && j < 31) ? tgt[e_raw + 1] : -2;
-        const float* pa = A + (size_t)ti * 128 + 4 * half;
-        const float* pb = Bm + (size_t)sj * 128 + 4 * half;
-        f32x16 in[4], out[4];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 a, b;
-                if (ABL & 1) {
-                    a = f32x4{0.001f * lane, 0.002f * kt, 0.003f * g, 0.1f};
-                    b = f32x4{0.5f, 0.25f * ti, 0.125f, 0.0625f * sj};
-                } else {
-                    a = *reinterpret_cast<const f32x4*>(pa + kt * 32 + 8 * g);
-                    b = *reinterpret_cast<const f32x4*>(pb + kt * 32 + 8 * g);
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) in[kt][4 * g + c] = (ABL & 4) ? (a[c] + b[c]) : act_swish(a[c] + b[c]);
-            }
-        init_bias<4>(out, b2, half);
-        {   // 8 k-slots (kt, m) x 4 output tiles; software pipeline written out in source and pinned with
-            // sched_barriers: while group (slot, nt) issues its 6 MFMAs, the weight fragments of the next
-            // group are read from LDS and a quarter of the next slot's activation split runs on the VALU.
-            u32x4 xs[2][3];                       // activation planes (hi, mid, lo) of the current / next slot
-            u32x4 wr[2][3];                       // weight planes ring
-            split_pair4(in[0], 0, xs[0]);
-            {
-                const u32x4* wp = wl + lane;
-                wr[0][0] = wp[0]; wr[0][1] = wp[64]; wr[0][2] = wp[128];
-            }
-#pragma unroll
-            for (int gq = 0; gq < 32; ++gq) {     // gq = slot * 4 + nt, slot = kt * 2 + m
-                const int slot = gq >> 2, nt = gq & 3;
-                if (gq + 1 < 32) {
-                    const int s1 = (gq + 1) >> 2, n1 = (gq + 1) & 3;
-                    const u32x4* wp = wl + ((((s1 >> 1) * 4 + n1) * 2 + (s1 & 1)) * 3) * 64 + lane;
-                    wr[(gq + 1) & 1][0] = wp[0]; wr[(gq + 1) & 1][1] = wp[64]; wr[(gq + 1) & 1][2] = wp[128];
-                }
-                if (slot + 1 < 8) split_quarter(in[(slot + 1) >> 1], (slot + 1) & 1, nt, xs[(slot + 1) & 1]);
-                out[nt] = mma_split6(__builtin_bit_cast(bf16x8, wr[gq & 1][0]), __builtin_bit_cast(bf16x8, wr[gq & 1][1]),
-                                     __builtin_bit_cast(bf16x8, wr[gq & 1][2]), __builtin_bit_cast(bf16x8, xs[slot & 1][0]),
-                                     __builtin_bit_cast(bf16x8, xs[slot & 1][1]), __builtin_bit_cast(bf16x8, xs[slot & 1][2]),
-                                     out[nt]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (ABL & 2) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sacc += out[tt][i];
-            if (sacc == 123.456f) agg[tile] = sacc;
-            continue;
-        }
-        // ---- segmented scan over the 32 edge lanes (see k_mpnn_edge2)
-        const int t = e_ok ? ti : (-16 - j);
-        const int jr = j & 15;
-        const int t1 = dpp_i<DPP_SHR1, 0xF>(t), t2 = dpp_i<DPP_SHR2, 0xF>(t), t4 = dpp_i<DPP_SHR4, 0xF>(t);
-        const int t8 = dpp_i<DPP_SHR8, 0xF>(t), tb = dpp_i<DPP_BCAST15, 0xA>(t);
-        const float m1 = ((jr >= 1) & (t1 == t)) ? 1.f : 0.f;
-        const float m2 = ((jr >= 2) & (t2 == t)) ? 1.f : 0.f;
-        const float m4 = ((jr >= 4) & (t4 == t)) ? 1.f : 0.f;
-        const float m8 = ((jr >= 8) & (t8 == t)) ? 1.f : 0.f;
-        const float mb = ((j >= 16) & (tb == t)) ? 1.f : 0.f;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float x = act_swish(out[nt][i]);
-                x += m1 * dpp_f<DPP_SHR1, 0xF>(x);
-                x += m2 * dpp_f<DPP_SHR2, 0xF>(x);
-                x += m4 * dpp_f<DPP_SHR4, 0xF>(x);
-                x += m8 * dpp_f<DPP_SHR8, 0xF>(x);
-                x += mb * dpp_f<DPP_BCAST15, 0xA>(x);
-                out[nt][i] = x;
-            }
-        if (e_ok && tnext != ti) {
-            const int s = rowptr[ti], en = rowptr[ti + 1];
-            const bool complete = (s >= e0) && (en <= e0 + 32);
-            const float dn = complete ? (float)(en - s) : 1.f;
-            float* dst = complete ? agg + (size_t)ti * 128 : partials + ((size_t)tile * 2 + (s < e0 ? 0 : 1)) * 128;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {out[nt][4 * g], out[nt][4 * g + 1], out[nt][4 * g + 2], out[nt][4 * g + 3]};
-                    if (complete) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = v[c] / dn;
-                    }
-                    *reinterpret_cast<f32x4*>(dst + nt * 32 + 8 * g + 4 * half) = v;
-                }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------- fused edge kernel, v4
-// k_mpnn_edge3 plus a rolling gather prefetch: profiling v3 showed the MFMA phase shrunk to ~6k cycles per
-// tile while the A[i] / Bm[j] gather of the *next* tile stayed fully exposed (1.2 of 2.6 ms).  Here the rows
-// of tile t+1 are requested quarter by quarter as soon as the matching k tile of tile t has been consumed
-// (its `in` registers are dead), and Swish(A+Bm) is evaluated into those registers two k tiles later, all
-// inside the MFMA groups of tile t.
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, (NW == 4 ? 1 : 2)) k_mpnn_edge4(const float* __restrict__ A, const float* __restrict__ Bm,
-                                                           const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
-                                                           const int32_t* __restrict__ rowptr, int E,
-                                                           const u32x4* __restrict__ w2s, const float* __restrict__ b2,
-                                                           float* __restrict__ agg, float* __restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) u32x4 wl[32 * 3 * 64];           // 96 KiB
-    for (int i = threadIdx.x; i < 32 * 3 * 64; i += NW * 64) wl[i] = w2s[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = lane >> 5, j = lane & 31;
-    const int ntiles = (E + 31) / 32;
-    const int stride = gridDim.x * NW;
-    int tile = blockIdx.x * NW + wave;
-    if (tile >= ntiles) return;
-    f32x16 in[4], out[4];
-    f32x4 la[4], lb[4];                       // one k tile (32 columns) of A[i] / Bm[j] in flight
-    // ---- prologue: gather + Swish for the first tile
-    {
-        const int e = min(tile * 32 + j, E - 1);
-        const float* pa = A + (size_t)tgt[e] * 128 + 4 * half;
-        const float* pb = Bm + (size_t)src[e] * 128 + 4 * half;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(pa + kt * 32 + 8 * g);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(pb + kt * 32 + 8 * g);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) in[kt][4 * g + c] = act_swish(a[c] + b[c]);
-            }
-    }
-    for (; tile < ntiles; tile += stride) {
-        const int e0 = tile * 32;
-        const int e_raw = e0 + j;
-        const bool e_ok = e_raw < E;
-        const int ti = tgt[e_ok ? e_raw : E - 1];
-        const int tnext = (e_raw + 1 < E && j < 31) ? tgt[e_raw + 1] : -2;
-        // next tile's rows (clamped: the last iteration prefetches valid but unused data)
-        const int tn = tile + stride < ntiles ? tile + stride : tile;
-        const int en = min(tn * 32 + j, E - 1);
-        const float* pan = A + (size_t)tgt[en] * 128 + 4 * half;
-        const float* pbn = Bm + (size_t)src[en] * 128 + 4 * half;
-        init_bias<4>(out, b2, half);
-        {
-            u32x4 xs[2][3], wr[2][3];
-            split_pair4(in[0], 0, xs[0]);
-            {
-                const u32x4* wp = wl + lane;
-                wr[0][0] = wp[0]; wr[0][1] = wp[64]; wr[0][2] = wp[128];
-            }
-#pragma unroll
-            for (int gq = 0; gq < 32; ++gq) {     // gq = slot * 4 + nt, slot = kt * 2 + m
-                const int slot = gq >> 2, nt = gq & 3;
-                if (gq + 1 < 32) {
-                    const int s1 = (gq + 1) >> 2, n1 = (gq + 1) & 3;
-                    const u32x4* wp = wl + ((((s1 >> 1) * 4 + n1) * 2 + (s1 & 1)) * 3) * 64 + lane;
-                    wr[(gq + 1) & 1][0] = wp[0]; wr[(gq + 1) & 1][1] = wp[64]; wr[(gq + 1) & 1][2] = wp[128];
-                }
-                if (slot + 1 < 8) split_quarter(in[(slot + 1) >> 1], (slot + 1) & 1, nt, xs[(slot + 1) & 1]);
-                out[nt] = mma_split6(__builtin_bit_cast(bf16x8, wr[gq & 1][0]), __builtin_bit_cast(bf16x8, wr[gq & 1][1]),
-                                     __builtin_bit_cast(bf16x8, wr[gq & 1][2]), __builtin_bit_cast(bf16x8, xs[slot & 1][0]),
-                                     __builtin_bit_cast(bf16x8, xs[slot & 1][1]), __builtin_bit_cast(bf16x8, xs[slot & 1][2]),
-                                     out[nt]);
-                // rolling prefetch: k tile kt of `in` is dead once both of its slots have been split
-                // (the split of slot 2kt+1 finishes in group 8kt+3) -> request tile t+1's k tile kt in
-                // group 8kt+4, turn the previous request into in[kt-1] in the same group
-                if ((gq & 7) == 4) {
-                    const int kt = gq >> 3;
-                    if (kt > 0) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) in[kt - 1][4 * g + c] = act_swish(la[g][c] + lb[g][c]);
-                    }
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        la[g] = *reinterpret_cast<const f32x4*>(pan + kt * 32 + 8 * g);
-                        lb[g] = *reinterpret_cast<const f32x4*>(pbn + kt * 32 + 8 * g);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // ---- segmented scan over the 32 edge lanes (see k_mpnn_edge2)
-        const int t = e_ok ? ti : (-16 - j);
-        const int jr = j & 15;
-        const int t1 = dpp_i<DPP_SHR1, 0xF>(t), t2 = dpp_i<DPP_SHR2, 0xF>(t), t4 = dpp_i<DPP_SHR4, 0xF>(t);
-        const int t8 = dpp_i<DPP_SHR8, 0xF>(t), tb = dpp_i<DPP_BCAST15, 0xA>(t);
-        const float m1 = ((jr >= 1) & (t1 == t)) ? 1.f : 0.f;
-        const float m2 = ((jr >= 2) & (t2 == t)) ? 1.f : 0.f;
-        const float m4 = ((jr >= 4) & (t4 == t)) ? 1.f : 0.f;
-        const float m8 = ((jr >= 8) & (t8 == t)) ? 1.f : 0.f;
-        const float mb = ((j >= 16) & (tb == t)) ? 1.f : 0.f;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float x = act_swish(out[nt][i]);
-                x += m1 * dpp_f<DPP_SHR1, 0xF>(x);
-                x += m2 * dpp_f<DPP_SHR2, 0xF>(x);
-                x += m4 * dpp_f<DPP_SHR4, 0xF>(x);
-                x += m8 * dpp_f<DPP_SHR8, 0xF>(x);
-                x += mb * dpp_f<DPP_BCAST15, 0xA>(x);
-                out[nt][i] = x;
-            }
-        if (e_ok && tnext != ti) {
-            const int s = rowptr[ti], en2 = rowptr[ti + 1];
-            const bool complete = (s >= e0) && (en2 <= e0 + 32);
-            const float dn = complete ? (float)(en2 - s) : 1.f;
-            float* dst = complete ? agg + (size_t)ti * 128 : partials + ((size_t)tile * 2 + (s < e0 ? 0 : 1)) * 128;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {out[nt][4 * g], out[nt][4 * g + 1], out[nt][4 * g + 2], out[nt][4 * g + 3]};
-                    if (complete) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = v[c] / dn;
-                    }
-                    *reinterpret_cast<f32x4*>(dst + nt * 32 + 8 * g + 4 * half) = v;
-                }
-        }
-        // last k tile of the next tile's input
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) in[3][4 * g + c] = act_swish(la[g][c] + lb[g][c]);
-    }
-}
-
-// lb[q] holds 16 B of row 8q + (lane>>3), column chunk lane&7 (row-contiguous load); bring it into operand
-// layout (lane (j, half): columns 8g + 4half + c of row j) through the wave-private slab and finish
-// in = Swish(A + Bm).  Row stride 36 floats: conflict-free ds_write_b128 / ds_read_b128.
-__device__ __forceinline__ void transpose_swish(float* slab, const f32x4 (&la)[4], const f32x4 (&lb)[4], f32x16& dst,
-                                                int lane) {
-    wave_lds_sync();
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<f32x4*>(slab + (8 * q + (lane >> 3)) * 36 + (lane & 7) * 4) = lb[q];
-    wave_lds_sync();
-    const int j = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(slab + j * 36 + 8 * g + 4 * half);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dst[4 * g + c] = act_swish(la[g][c] + b[c]);
-    }
-}
-
-// ---------------------------------------------------------------------------- fused edge kernel, v5
-// k_mpnn_edge4 with a line-efficient Bm gather.  PMC/ablation on v3/v4: the Bm[j] gather is bound by the
-// CU's texture-addresser, not by latency - each of the 16 per-lane-row loads touches 32 cache lines and uses
-// 32 B of each.  Here a wave fetches the 32 source rows of one k tile as 4 loads of 8 *full* 128-B lines
-// (8 lanes per row), and transposes them into operand layout through a 4.5 KiB wave-private LDS slab.
-// (k_mpnn_edge4 =) k_mpnn_edge3 plus a rolling gather prefetch: profiling v3 showed the MFMA phase shrunk to ~6k cycles per
-// tile while the A[i] / Bm[j] gather of the *next* tile stayed fully exposed (1.2 of 2.6 ms).  Here the rows
-// of tile t+1 are requested quarter by quarter as soon as the matching k tile of tile t has been consumed
-// (its `in` registers are dead), and Swish(A+Bm) is evaluated into those registers two k tiles later, all
-// inside the MFMA groups of tile t.
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, 2) k_mpnn_edge5(const float* __restrict__ A, const float* __restrict__ Bm,
-                                                           const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
-                                                           const int32_t* __restrict__ rowptr, int E,
-                                                           const u32x4* __restrict__ w2s, const float* __restrict__ b2,
-                                                           float* __restrict__ agg, float* __restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) u32x4 wl[32 * 3 * 64];           // 96 KiB
-    __shared__ __attribute__((aligned(16))) float slab_all[NW * 32 * 36];    // 32 rows x (32 + 4 pad) floats per wave
-    for (int i = threadIdx.x; i < 32 * 3 * 64; i += NW * 64) wl[i] = w2s[i];
-    __syncthreads();
-    float* slab = slab_all + (threadIdx.x >> 6) * 32 * 36;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = lane >> 5, j = lane & 31;
-    const int ntiles = (E + 31) / 32;
-    const int stride = gridDim.x * NW;
-    int tile = blockIdx.x * NW + wave;
-    if (tile >= ntiles) return;
-    f32x16 in[4], out[4];
-    f32x4 la[4], lb[4];                       // one k tile (32 columns) of A[i] / Bm[j] in flight
-    // ---- prologue: gather + Swish for the first tile
-    {
-        const int e = min(tile * 32 + j, E - 1);
-        const float* pa = A + (size_t)tgt[e] * 128 + 4 * half;
-        const float* pb = Bm + (size_t)src[e] * 128 + 4 * half;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(pa + kt * 32 + 8 * g);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(pb + kt * 32 + 8 * g);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) in[kt][4 * g + c] = act_swish(a[c] + b[c]);
-            }
-    }
-    for (; tile < ntiles; tile += stride) {
-        const int e0 = tile * 32;
-        const int e_raw = e0 + j;
-        const bool e_ok = e_raw < E;
-        const int ti = tgt[e_ok ? e_raw : E - 1];
-        const int tnext = (e_raw + 1 < E && j < 31) ? tgt[e_raw + 1] : -2;
-        // next tile's rows (clamped: the last iteration prefetches valid but unused data)
-        const int tn = tile + stride < ntiles ? tile + stride : tile;
-        const int en = min(tn * 32 + j, E - 1);
-        const float* pan = A + (size_t)tgt[en] * 128 + 4 * half;
-        // row-contiguous Bm loads: load q covers rows 8q .. 8q+7, 8 lanes (16 B each) per row
-        const float* pbq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pbq[q] = Bm + (size_t)src[min(tn * 32 + 8 * q + (lane >> 3), E - 1)] * 128 + (lane & 7) * 4;
-        init_bias<4>(out, b2, half);
-        {
-            u32x4 xs[2][3], wr[2][3];
-            split_pair4(in[0], 0, xs[0]);
-            {
-                const u32x4* wp = wl + lane;
-                wr[0][0] = wp[0]; wr[0][1] = wp[64]; wr[0][2] = wp[128];
-            }
-#pragma unroll
-            for (int gq = 0; gq < 32; ++gq) {     // gq = slot * 4 + nt, slot = kt * 2 + m
-                const int slot = gq >> 2, nt = gq & 3;
-                if (gq + 1 < 32) {
-                    const int s1 = (gq + 1) >> 2, n1 = (gq + 1) & 3;
-                    const u32x4* wp = wl + ((((s1 >> 1) * 4 + n1) * 2 + (s1 & 1)) * 3) * 64 + lane;
-                    wr[(gq + 1) & 1][0] = wp[0]; wr[(gq + 1) & 1][1] = wp[64]; wr[(gq + 1) & 1][2] = wp[128];
-                }
-                if (slot + 1 < 8) split_quarter(in[(slot + 1) >> 1], (slot + 1) & 1, nt, xs[(slot + 1) & 1]);
-                out[nt] = mma_split6(__builtin_bit_cast(bf16x8, wr[gq & 1][0]), __builtin_bit_cast(bf16x8, wr[gq & 1][1]),
-                                     __builtin_bit_cast(bf16x8, wr[gq & 1][2]), __builtin_bit_cast(bf16x8, xs[slot & 1][0]),
-                                     __builtin_bit_cast(bf16x8, xs[slot & 1][1]), __builtin_bit_cast(bf16x8, xs[slot & 1][2]),
-                                     out[nt]);
-                // rolling prefetch: k tile kt of `in` is dead once both of its slots have been split
-                // (the split of slot 2kt+1 finishes in group 8kt+3) -> request tile t+1's k tile kt in
-                // group 8kt+4, turn the previous request into in[kt-1] in the same group
-                if ((gq & 7) == 4) {
-                    const int kt = gq >> 3;
-                    if (kt > 0) {
-                        transpose_swish(slab, la, lb, in[kt - 1], lane);
-                    }
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        la[g] = *reinterpret_cast<const f32x4*>(pan + kt * 32 + 8 * g);
-                        lb[g] = *reinterpret_cast<const f32x4*>(pbq[g] + kt * 32);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // ---- segmented scan over the 32 edge lanes (see k_mpnn_edge2)
-        const int t = e_ok ? ti : (-16 - j);
-        const int jr = j & 15;
-        const int t1 = dpp_i<DPP_SHR1, 0xF>(t), t2 = dpp_i<DPP_SHR2, 0xF>(t), t4 = dpp_i<DPP_SHR4, 0xF>(t);
-        const int t8 = dpp_i<DPP_SHR8, 0xF>(t), tb = dpp_i<DPP_BCAST15, 0xA>(t);
-        const float m1 = ((jr >= 1) & (t1 == t)) ? 1.f : 0.f;
-        const float m2 = ((jr >= 2) & (t2 == t)) ? 1.f : 0.f;
-        const float m4 = ((jr >= 4) & (t4 == t)) ? 1.f : 0.f;
-        const float m8 = ((jr >= 8) & (t8 == t)) ? 1.f : 0.f;
-        const float mb = ((j >= 16) & (tb == t)) ? 1.f : 0.f;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float x = act_swish(out[nt][i]);
-                x += m1 * dpp_f<DPP_SHR1, 0xF>(x);
-                x += m2 * dpp_f<DPP_SHR2, 0xF>(x);
-                x += m4 * dpp_f<DPP_SHR4, 0xF>(x);
-                x += m8 * dpp_f<DPP_SHR8, 0xF>(x);
-                x += mb * dpp_f<DPP_BCAST15, 0xA>(x);
-                out[nt][i] = x;
-            }
-        if (e_ok && tnext != ti) {
-            const int s = rowptr[ti], en2 = rowptr[ti + 1];
-            const bool complete = (s >= e0) && (en2 <= e0 + 32);
-            const float dn = complete ? (float)(en2 - s) : 1.f;
-            float* dst = complete ? agg + (size_t)ti * 128 : partials + ((size_t)tile * 2 + (s < e0 ? 0 : 1)) * 128;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {out[nt][4 * g], out[nt][4 * g + 1], out[nt][4 * g + 2], out[nt][4 * g + 3]};
-                    if (complete) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = v[c] / dn;
-                    }
-                    *reinterpret_cast<f32x4*>(dst + nt * 32 + 8 * g + 4 * half) = v;
-                }
-        }
-        // last k tile of the next tile's input
-        transpose_swish(slab, la, lb, in[3], lane);
-    }
-}
-
 // ---------------------------------------------------------------------------- read-out + Euler step
 // diff = Conv1d(8->1,k2)( [Swish]( Conv1d(1->8,k1,stride s1)(h[:, None, :]) ) ),
 // out[n, k] = u[n, tw-1] + dt*(k+1) * diff[n, k]        (models/mpnn.py:197-201, conv specs :140-163)
@@ -701,11 +283,13 @@ __global__ void k_norm_apply(const float* __restrict__ x, const float* __restric
 // ------------------------------------------------------------------------------------ C entry points
 #define LAUNCH_CHECK() return (int)hipGetLastError()
 
+extern int g_edge6_ablation;
 static int g_edge_variant = 102;   // persistent v2 kernel, 8 waves / workgroup
 // development knob for A/B measurements: 102 = k_mpnn_edge2<8> (default), 0 = first-generation k_mpnn_edge,
 // 1x/11x = ablations (results invalid)
 extern "C" int magnet_debug_set_variant(int which, int value) {
     if (which == 0) g_edge_variant = value;
+    if (which == 1) g_edge6_ablation = value;
     return 0;
 }
 
@@ -766,28 +350,6 @@ extern "C" int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32
     LAUNCH_CHECK();
 }
 
-extern "C" int magnet_dev_edge_bf16_old(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
-                                           const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2,
-                                           float* agg, float* partials, void* stream) {
-    if (n_edges <= 0) return 0;
-    static int ncu = 0;
-    if (!ncu) { hipDeviceProp_t prop; int dev; hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev); ncu = prop.multiProcessorCount; }
-    const int tiles = (n_edges + 31) / 32, nw = 8;
-    const dim3 g3(min((tiles + nw - 1) / nw, ncu)), b3(nw * 64);
-    const u32x4* ws = reinterpret_cast<const u32x4*>(w2_split);
-    hipStream_t s3 = (hipStream_t)stream;
-    switch (g_edge_variant) {
-        case 301: hipLaunchKernelGGL(k_mpnn_edge5<8>, g3, b3, 0, s3, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
-        case 304: hipLaunchKernelGGL(k_mpnn_edge4<4>, dim3(min((tiles + 3) / 4, ncu)), dim3(256), 0, s3, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
-        case 300: hipLaunchKernelGGL(k_mpnn_edge4<8>, g3, b3, 0, s3, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
-        case 210: hipLaunchKernelGGL((k_mpnn_edge3<8, 1>), g3, b3, 0, s3, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
-        case 211: hipLaunchKernelGGL((k_mpnn_edge3<8, 2>), g3, b3, 0, s3, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
-        case 212: hipLaunchKernelGGL((k_mpnn_edge3<8, 3>), g3, b3, 0, s3, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
-        case 213: hipLaunchKernelGGL((k_mpnn_edge3<8, 7>), g3, b3, 0, s3, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
-        default: hipLaunchKernelGGL((k_mpnn_edge3<8, 0>), g3, b3, 0, s3, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
-    }
-    LAUNCH_CHECK();
-}
 
 extern "C" int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1,
                                        int k1, int s1, const float* w2, const float* b2, int k2, int use_swish,

@@ -39,13 +39,13 @@ for v in variants:
         ref = agg.clone()
     err = float((agg - ref).norm() / ref.norm())
     print(f"edge variant {v}: {ms:.3f} ms  {2*E*H*H/ms/1e9:.1f} TFLOP/s (incl fixup)  rel-diff vs first {err:.2e} nan={int(torch.isnan(agg).sum())}")
-for v3 in (102, 102):
-    _lib.lib().magnet_debug_set_variant(0, v3)
+for v3 in (0, 1, 2, 4, 7, 0):
+    _lib.lib().magnet_debug_set_variant(1, v3)
     agg.fill_(float("nan"))
     ms = timeit(lambda: ops.mpnn_edge_bf16x6(A, Bm, csr, lyr.msg2_split[0], lyr.msg2_split[1], agg, partials))
     err = float((agg - ref).norm() / ref.norm())
     print(f"edge bf16x6 [{v3}]: {ms:.3f} ms  {2*E*H*H/ms/1e9:.1f} TFLOP/s-equivalent (incl fixup)  rel-diff vs first {err:.2e} nan={int(torch.isnan(agg).sum())}")
-_lib.lib().magnet_debug_set_variant(0, 102)
+_lib.lib().magnet_debug_set_variant(1, 0)
 h = torch.randn(N, H, device="cuda"); node_in = torch.randn(N, 32, device="cuda"); gbuf = torch.empty_like(h)
 T = ops.Term
 ms = timeit(lambda: ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, 32)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4, act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=gbuf))
