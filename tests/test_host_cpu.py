@@ -66,3 +66,12 @@ def test_no_cpu_fallback():
     from magnet_amd import ops
     with pytest.raises(RuntimeError):
         ops.segment_mean(torch.zeros(4, 32), torch.zeros(3, dtype=torch.int32), 2)
+
+
+def test_split_bf16x3_is_exact():
+    """hi + mid + lo reproduces every fp32 value bit for bit (the basis of the bf16x6 edge kernel)."""
+    from magnet_amd.packing import split_bf16x3
+    x = torch.randn(10000) * torch.logspace(-6, 6, 10000)
+    hi, mid, lo = split_bf16x3(x)
+    back = sum((p.to(torch.int32) << 16).view(torch.float32).double() for p in (hi, mid, lo))
+    assert torch.equal(back.float(), x)

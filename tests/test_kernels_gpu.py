@@ -158,3 +158,33 @@ def test_mlp_gather_difference_and_segmean_epilogue():
     want = scatter_mean(m, tgt, n)
     assert not torch.isnan(agg).any()
     assert rel_l2(agg, want) < 2e-6
+
+
+def test_mpnn_edge_kernels_agree_on_ragged_graph():
+    """fp32-MFMA and bf16-split edge kernels vs a host evaluation, on a graph with empty rows, rows longer
+    than several tiles and an edge count that is not a multiple of 32."""
+    from magnet_amd import ops
+    from magnet_amd.packing import pack_linear, pack_linear_bf16x3
+    from oracle.pyg_semantics import scatter_mean
+    torch.manual_seed(2)
+    n, H = 301, 128
+    rowptr, tgt = _random_csr(n, 45, seed=5, long_rows=3)
+    E = tgt.numel()
+    assert E % 32 != 0
+    src = torch.randint(0, n, (E,))
+    A, Bm = torch.randn(n, H), torch.randn(n, H)
+    lin = torch.nn.Linear(H, H)
+    csr = ops.CSR(rowptr.cuda(), src.int().cuda(), tgt.int().cuda(), n, E)
+    sw = lambda x: x * torch.sigmoid(x)  # noqa: E731
+    with torch.no_grad():
+        m = sw(lin.double()(sw((A[tgt] + Bm[src]).double())))
+    want = scatter_mean(m, tgt, n)
+    lin = lin.float().cuda()
+    w32, b32 = pack_linear(lin.weight, lin.bias)
+    ws, bs = pack_linear_bf16x3(lin.weight, lin.bias)
+    for fn, w, b in ((ops.mpnn_edge, w32, b32), (ops.mpnn_edge_bf16x6, ws, bs)):
+        agg = torch.full((n, H), float("nan"), device="cuda")
+        partials = torch.zeros(((E + 31) // 32) * 2 * H, device="cuda")
+        fn(A.cuda(), Bm.cuda(), csr, w, b, agg, partials)
+        assert not torch.isnan(agg).any()
+        assert rel_l2(agg, want) < 1e-6, fn.__name__
