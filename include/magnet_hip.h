@@ -79,6 +79,12 @@ typedef struct {
 int magnet_mlp_f32(const magnet_mlp_args_t* args, int nl, int ht, int ot, int act, int last_act, int ln, int epi,
                    void* stream);
 int magnet_mlp_supported(int nl, int ht, int ot, int act, int last_act, int ln, int epi);
+/* Same contract with every Linear evaluated on the bf16 matrix cores through the exact hi/mid/lo split (six partial
+ * products, fp32-class accuracy).  layer[l].w: the three bf16 planes of the padded weight in
+ * fragment order [kt][nt][m][plane][64 lanes][8 bf16] (magnet_amd/packing.py:pack_linear_bf16x3); the planes of one
+ * k tile are DMA'd into LDS and shared by the 4 waves of a workgroup. */
+int magnet_mlp_bf16x6_f32(const magnet_mlp_args_t* args, int nl, int ht, int ot, int act, int last_act, int ln, int epi,
+                          void* stream);
 int magnet_segmean_fixup_f32(const int32_t* rowptr, int n_rows, int d, const float* partials, float* agg,
                              void* stream);
 

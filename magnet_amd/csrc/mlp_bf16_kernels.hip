@@ -1,0 +1,172 @@
+// Generic register-chained MLP kernel on the bf16 matrix cores (exact hi/mid/lo split, see common.cuh "bf16x6").
+//
+// Same contract as k_mlp (mlp_kernels.hip): 32 rows per wave, layer 0 streamed from gathered / concatenated /
+// differenced sources, hidden layers chained in registers, epilogues store | +residual | CSR mean.  Differences:
+//   * every Linear is 6 v_mfma_f32_32x32x16_bf16 per 16-k slot instead of 8 v_mfma_f32_32x32x2_f32
+//     (2.7x fewer matrix-pipe cycles, fp32-class accuracy);
+//   * the split weight planes do not come from L2 per tile: the 4 waves of a workgroup walk the layers in
+//     lockstep and the planes of one k tile (NT * 6 KiB) are DMA'd (global_load_lds, no VGPR round trip) into
+//     a double-buffered LDS chunk one k tile ahead - one __syncthreads per k tile;
+//   * activations are split per 8-k slot right before use, so the split's VALU work sits in MFMA shadows.
+// layer[l].w points at that layer's planes in fragment order [kt][nt][m][plane][64 lanes][8 bf16]
+// (packing.pack_linear_bf16x3), layer[l].b at the zero-padded fp32 bias.
+#include "common.cuh"
+
+template <int A, int B>
+struct MaxI { static constexpr int v = A > B ? A : B; };
+
+// DMA one chunk (npieces x 1 KiB, contiguous in global memory) into LDS; piece p is handled by wave p % 4
+__device__ __forceinline__ void dma_chunk(const f32x4* __restrict__ gw, u32x4* l, int npieces, int wave, int lane) {
+    const u32x4* g = reinterpret_cast<const u32x4*>(gw);
+    for (int p = wave; p < npieces; p += 4)
+        __builtin_amdgcn_global_load_lds(g + p * 64 + lane, l + p * 64, 16, 0, 0);
+}
+
+// out[nt] += W(chunk)[nt] * x   for one k tile whose planes sit in LDS at `wl` ([nt][m][plane][64])
+template <int NT>
+__device__ __forceinline__ void mma_chunk(const f32x16& x, f32x16 (&out)[NT], const u32x4* wl, int lane) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        u32x4 xs[3];
+        split_pair4(x, m, xs);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const u32x4* wp = wl + ((nt * 2 + m) * 3) * 64 + lane;
+            out[nt] = mma_split6(__builtin_bit_cast(bf16x8, wp[0]), __builtin_bit_cast(bf16x8, wp[64]),
+                                 __builtin_bit_cast(bf16x8, wp[128]), __builtin_bit_cast(bf16x8, xs[0]),
+                                 __builtin_bit_cast(bf16x8, xs[1]), __builtin_bit_cast(bf16x8, xs[2]), out[nt]);
+        }
+    }
+}
+
+template <int NL, int HT, int OT, int ACT, bool LAST_ACT, bool LN, int EPI>
+__global__ void __launch_bounds__(256) k_mlp_bf16(const MagnetMlpArgs a) {
+    constexpr int NTMAX = MaxI<HT, OT>::v;
+    constexpr int CH = NTMAX * 6 * 64;                                   // u32x4 per chunk buffer
+    constexpr int SLAB = (EPI == EPI_SEGMEAN) ? 4 * SegSlab<OT>::FLOATS : 0;
+    __shared__ __attribute__((aligned(16))) u32x4 smem[2 * CH + (SLAB + 3) / 4];   // ONE LDS object (chunks + slab)
+    u32x4* wbuf = smem;
+    float* slab = reinterpret_cast<float*>(smem + 2 * CH);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    const int tile = blockIdx.x * 4 + wave;
+    const int row_raw = tile * 32 + (lane & 31);
+    const bool row_ok = row_raw < a.M;
+    const int row = row_ok ? row_raw : (a.M - 1);
+
+    constexpr int NT0 = (NL == 1) ? OT : HT;
+    int cbuf = 0;                                     // LDS buffer holding the chunk about to be consumed
+    // chunk protocol: the DMA of chunk c+1 is issued right after the barrier that precedes the compute of chunk c
+    dma_chunk(a.layer[0].w, wbuf, NT0 * 6, wave, lane);
+
+    f32x16 out[OT];
+    f32x16 h0[HT], h1[HT];
+    // ---------------- layer 0: K streamed from the sources
+    {
+        f32x16 acc[NT0];
+        init_bias<NT0>(acc, a.layer[0].b, half);
+        f32x16 x = load_ktile(a.kt[0], row, half);
+        for (int kt = 0; kt < a.nkt; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // next chunk: layer 0's next k tile, or the first k tile of layer 1
+            if (kt + 1 < a.nkt) dma_chunk(a.layer[0].w + (size_t)(kt + 1) * NT0 * 6 * 64, wbuf + (cbuf ^ 1) * CH, NT0 * 6, wave, lane);
+            else if (NL > 1) dma_chunk(a.layer[1].w, wbuf + (cbuf ^ 1) * CH, ((NL == 2) ? OT : HT) * 6, wave, lane);
+            const f32x16 xn = load_ktile(a.kt[kt + 1 < a.nkt ? kt + 1 : kt], row, half);
+            mma_chunk<NT0>(x, acc, wbuf + cbuf * CH, lane);
+            x = xn;
+            cbuf ^= 1;
+        }
+        if (NL == 1) {
+#pragma unroll
+            for (int t = 0; t < NT0; ++t) out[t < OT ? t : 0] = acc[t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT0; ++t) {
+                apply_act<ACT>(acc[t]);
+                h0[t < HT ? t : 0] = acc[t];
+            }
+        }
+    }
+    // ---------------- layers 1 .. NL-1, activations in registers (fully unrolled: static register indices)
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+        const bool last = (l == NL - 1);
+        const bool src0 = (l & 1);                     // odd layers read h0, even layers read h1
+        if (last) init_bias<OT>(out, a.layer[l].b, half);
+        else if (src0) init_bias<HT>(h1, a.layer[l].b, half);
+        else init_bias<HT>(h0, a.layer[l].b, half);
+#pragma unroll
+        for (int kt = 0; kt < HT; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int nt_here = last ? OT : HT;
+            if (kt + 1 < HT) dma_chunk(a.layer[l].w + (size_t)(kt + 1) * nt_here * 6 * 64, wbuf + (cbuf ^ 1) * CH, nt_here * 6, wave, lane);
+            else if (l + 1 < NL) dma_chunk(a.layer[l + 1].w, wbuf + (cbuf ^ 1) * CH, ((l + 1 == NL - 1) ? OT : HT) * 6, wave, lane);
+            if (last) mma_chunk<OT>(src0 ? h0[kt] : h1[kt], out, wbuf + cbuf * CH, lane);
+            else if (src0) mma_chunk<HT>(h0[kt], h1, wbuf + cbuf * CH, lane);
+            else mma_chunk<HT>(h1[kt], h0, wbuf + cbuf * CH, lane);
+            cbuf ^= 1;
+        }
+        if (!last) {
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                if (src0) apply_act<ACT>(h1[t]);
+                else apply_act<ACT>(h0[t]);
+            }
+        }
+    }
+    if (LAST_ACT) {
+#pragma unroll
+        for (int t = 0; t < OT; ++t) apply_act<ACT>(out[t]);
+    }
+    if (LN) layer_norm_rows<OT>(out, a.ln_g, a.ln_b, a.ln_eps, half);
+
+    if (EPI == EPI_SEGMEAN) {
+        const int ntiles = (a.M + 31) / 32;
+        const int nval = tile < ntiles ? min(32, a.M - tile * 32) : 0;
+        const int tgt = a.tgt[row];
+        segmean_epilogue<OT>(out, slab + wave * SegSlab<OT>::FLOATS, tile, nval, tgt, a.rowptr, a.y, a.partials, lane);
+    } else {
+        store_rows<OT, EPI == EPI_STORE_RES>(out, a.y, a.ldy, a.ncols, a.res, a.ldres, row, row_ok, half);
+    }
+}
+
+// ------------------------------------------------------------------------------------ dispatch
+typedef void (*mlp_fn)(const MagnetMlpArgs);
+
+#define MLP_CASE(NL_, HT_, OT_, ACT_, LA_, LN_, EPI_)                                              \
+    if (nl == NL_ && ht == HT_ && ot == OT_ && act == ACT_ && last_act == LA_ && ln == LN_ && epi == EPI_) \
+        fn = k_mlp_bf16<NL_, HT_, OT_, ACT_, LA_, LN_, EPI_>;
+
+static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int epi) {
+    mlp_fn fn = nullptr;
+    MLP_CASE(2, 4, 4, ACT_SWISH, true, false, EPI_STORE)
+    MLP_CASE(2, 4, 4, ACT_SWISH, true, false, EPI_STORE_RES)
+    MLP_CASE(1, 4, 4, ACT_NONE, false, false, EPI_STORE)
+    MLP_CASE(1, 2, 2, ACT_NONE, false, false, EPI_STORE)
+    MLP_CASE(1, 1, 1, ACT_NONE, false, false, EPI_STORE)
+    MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_STORE)
+    MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_STORE_RES)
+    MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_SEGMEAN)
+    MLP_CASE(5, 4, 1, ACT_RELU, false, false, EPI_STORE)
+    MLP_CASE(5, 2, 1, ACT_RELU, false, true, EPI_STORE)
+    MLP_CASE(5, 2, 1, ACT_RELU, false, true, EPI_STORE_RES)
+    MLP_CASE(5, 2, 1, ACT_RELU, false, true, EPI_SEGMEAN)
+    MLP_CASE(5, 2, 1, ACT_RELU, false, false, EPI_STORE)
+    MLP_CASE(5, 2, 2, ACT_RELU, false, true, EPI_STORE)
+    MLP_CASE(5, 2, 4, ACT_RELU, false, true, EPI_STORE)
+    return fn;
+}
+
+extern "C" int magnet_mlp_bf16x6_f32(const MagnetMlpArgs* args, int nl, int ht, int ot, int act, int last_act, int ln,
+                                     int epi, void* stream) {
+    if (!args || args->M <= 0) return args && args->M == 0 ? 0 : -1;
+    if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
+    mlp_fn fn = pick(nl, ht, ot, act, last_act, ln, epi);
+    if (!fn) return -3;
+    const int tiles = (args->M + 31) / 32;
+    hipLaunchKernelGGL(fn, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, *args);
+    return (int)hipGetLastError();
+}

@@ -20,7 +20,7 @@ from torch import nn
 
 from .. import _lib as L
 from .. import ops
-from ..packing import pack_linear, pad_to
+from ..packing import default_gemm, pack, pad_to
 from .backbones.mlp import MLP
 from .magnet_common import (Decoder, Encoder, MagnetBase, Processor, pack_graph_net, pack_mlp)
 
@@ -59,7 +59,7 @@ class MAgNetGNN(MagnetBase):
         return types.SimpleNamespace(
             graph1=pack_graph_net(self.encoder, self.processor, ldn),
             graph2=pack_graph_net(self._encoder, self._processor, ldn),
-            proj_base=pack_linear(W[:, cols], self.proj_head.bias, k_pad=D + 32, col_map=cmap),
+            proj_base=pack(W[:, cols], self.proj_head.bias, default_gemm(), k_pad=D + 32, col_map=cmap),
             proj_wv=W[:, D].float().contiguous(), proj_wt=W[:, D + d + 1].float().contiguous(),
             projector=pack_mlp(self.projector), decoder=pack_mlp(self._decoder.node_fn))
 

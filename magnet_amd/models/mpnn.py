@@ -22,7 +22,7 @@ from torch import nn
 
 from .. import ops
 from ..lightning_compat import LightningModule
-from ..packing import pack_linear, pack_linear_bf16x3, pad_to
+from ..packing import default_gemm, pack, pack_linear, pack_linear_bf16x3, pad_to
 
 _READOUT = {10: (16, 6, 10), 16: (16, 5, 8), 20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}  # mpnn.py:140-163
 
@@ -86,8 +86,9 @@ class MPNN(LightningModule):
         self.kin = pad_to(tw + self.dpos + 1)
         # message_net_2 on the bf16 matrix cores through the exact hi/mid/lo split (fp32-class accuracy, DESIGN.md
         # 3.2) or on the fp32 MFMA path ("fp32"); optional hparam, not part of the reference's config
-        self.edge_gemm = getattr(hparams, "edge_gemm", "bf16x6")
+        self.edge_gemm = getattr(hparams, "edge_gemm", default_gemm())
         assert self.edge_gemm in ("bf16x6", "fp32")
+        self.gemm = getattr(hparams, "gemm", self.edge_gemm)     # node-level Linears (same two choices)
         self._pack_key, self._pack = None, None
         self._topo_key, self._topo = None, None
 
@@ -102,7 +103,7 @@ class MPNN(LightningModule):
         dev = params[0].device
         P = types.SimpleNamespace(layers=[])
         e0, e1 = self.embedding_mlp[0], self.embedding_mlp[2]
-        P.emb = [pack_linear(e0.weight, e0.bias, k_pad=kin), pack_linear(e1.weight, e1.bias)]
+        P.emb = [pack(e0.weight, e0.bias, self.gemm, k_pad=kin), pack(e1.weight, e1.bias, self.gemm)]
         for lyr in self.gnn_layers:
             m1, m2 = lyr.message_net_1[0], lyr.message_net_2[0]
             u1, u2 = lyr.update_net_1[0], lyr.update_net_2[0]
@@ -111,13 +112,13 @@ class MPNN(LightningModule):
             wa = torch.cat([W1[:, :H], W1[:, 2 * H:]], 1)
             wb = torch.cat([W1[:, H:2 * H], -W1[:, 2 * H:2 * H + tw + dp], torch.zeros(H, 1, device=dev)], 1)
             L = types.SimpleNamespace()
-            L.pre_a = pack_linear(wa, m1.bias, k_pad=H + kin)
-            L.pre_b = pack_linear(wb, None, k_pad=H + kin)
+            L.pre_a = pack(wa, m1.bias, self.gemm, k_pad=H + kin)
+            L.pre_b = pack(wb, None, self.gemm, k_pad=H + kin)
             L.msg2 = pack_linear(m2.weight, m2.bias)
             L.msg2_split = pack_linear_bf16x3(m2.weight, m2.bias)
             cmap = torch.cat([torch.arange(2 * H), torch.tensor([2 * H + tw + dp])])   # var column inside node_in
-            L.upd1 = pack_linear(u1.weight, u1.bias, k_pad=2 * H + kin, col_map=cmap)
-            L.upd2 = pack_linear(u2.weight, u2.bias)
+            L.upd1 = pack(u1.weight, u1.bias, self.gemm, k_pad=2 * H + kin, col_map=cmap)
+            L.upd2 = pack(u2.weight, u2.bias, self.gemm)
             P.layers.append(L)
         c1, c2 = self.output_mlp[0], self.output_mlp[-1]
         P.conv = (c1.weight.detach().reshape(-1).contiguous(), c1.bias.detach().contiguous(),

@@ -84,8 +84,11 @@ def mlp(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STO
         a.res, a.ldres = res.data_ptr(), res.shape[-1]
     if epi == EPI_SEGMEAN:
         a.tgt, a.rowptr, a.partials = tgt.data_ptr(), rowptr.data_ptr(), partials.data_ptr()
-    L.check(L.lib().magnet_mlp_f32(C.byref(a), nl, ht, ot, act, int(last_act), int(ln is not None), epi, _stream()),
-            f"magnet_mlp_f32(nl={nl},ht={ht},ot={ot},act={act},ln={ln is not None},epi={epi})")
+    split = layers[0][0].dtype == torch.int16                 # bf16x3 planes -> matrix-core kernel
+    assert all((w.dtype == torch.int16) == split for w, _ in layers)
+    fn = L.lib().magnet_mlp_bf16x6_f32 if split else L.lib().magnet_mlp_f32
+    L.check(fn(C.byref(a), nl, ht, ot, act, int(last_act), int(ln is not None), epi, _stream()),
+            f"magnet_mlp_{'bf16x6_' if split else ''}f32(nl={nl},ht={ht},ot={ot},act={act},ln={ln is not None},epi={epi})")
     return y
 
 

@@ -58,15 +58,20 @@ def split_bf16x3(w: torch.Tensor):
     return top(hi), top(mid), top(lo)
 
 
-def pack_linear_bf16x3(w: torch.Tensor, b: torch.Tensor | None, k_pad: int | None = None, n_pad: int | None = None):
+def pack_linear_bf16x3(w: torch.Tensor, b: torch.Tensor | None, k_pad: int | None = None, n_pad: int | None = None,
+                       col_map: torch.Tensor | None = None):
     """Split planes in MFMA fragment order [kt][nt][m][plane][lane][8] (int16) + padded fp32 bias.
 
         slot c' of lane (i, h), k-slot m  <->  W[nt*32 + i][kt*32 + 8*(2m + (c'>>2)) + 4*h + (c'&3)]
     """
     n, k = w.shape
-    kp, np_ = k_pad or pad_to(k), n_pad or pad_to(n)
+    kp = k_pad or pad_to(k if col_map is None else int(col_map.max()) + 1)
+    np_ = n_pad or pad_to(n)
     wp = torch.zeros(np_, kp, dtype=torch.float32, device=w.device)
-    wp[:n, :k] = w.detach().float()
+    if col_map is None:
+        wp[:n, :k] = w.detach().float()
+    else:
+        wp[:n, col_map.to(w.device)] = w.detach().float()
     kt, nt = kp // 32, np_ // 32
     planes = []
     for pl in split_bf16x3(wp):
@@ -77,3 +82,21 @@ def pack_linear_bf16x3(w: torch.Tensor, b: torch.Tensor | None, k_pad: int | Non
     if b is not None:
         bp[:n] = b.detach().float()
     return out.view(-1), bp
+
+
+# ---- which arithmetic the Linears run on: "bf16x6" = exact 3-piece bf16 split on the matrix cores (default),
+# "fp32" = v_mfma_f32_32x32x2_f32.  ops.mlp picks the kernel from the dtype of the packed weights.
+GEMM_MODES = ("bf16x6", "fp32")
+
+
+def default_gemm() -> str:
+    import os
+    mode = os.environ.get("MAGNET_GEMM", "bf16x6")
+    assert mode in GEMM_MODES, mode
+    return mode
+
+
+def pack(w, b, mode: str, k_pad=None, n_pad=None, col_map=None):
+    if mode == "bf16x6":
+        return pack_linear_bf16x3(w, b, k_pad=k_pad, n_pad=n_pad, col_map=col_map)
+    return pack_linear(w, b, k_pad=k_pad, n_pad=n_pad, col_map=col_map)
