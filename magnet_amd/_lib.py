@@ -9,6 +9,8 @@ import ctypes as C
 import os
 import re
 
+import torch  # noqa: F401  (must come first: the library has to bind to the HIP runtime torch has loaded, not a second copy)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libmagnet_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "magnet_hip.h")

@@ -283,6 +283,7 @@ static inline unsigned nb(long n, int b) { return (unsigned)((n + b - 1) / b); }
 
 extern "C" int magnet_radius_search_f32(const float* x, int dim, int n_nodes, const int32_t* graph_ptr, int n_graphs,
                                         float r2, int cap, int32_t* nbr, int32_t* cnt, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n_nodes <= 0) return 0;
     if (dim < 1 || dim > 3 || cap < 1) return -2;
     hipLaunchKernelGGL(k_radius, dim3(nb(n_nodes, 4)), dim3(256), 0, S_, x, dim, n_nodes, graph_ptr, n_graphs, r2, cap,
@@ -295,6 +296,7 @@ extern "C" int magnet_radius_search_f32(const float* x, int dim, int n_nodes, co
 extern "C" int magnet_radius_search_bbox_f32(const float* x, int dim, int n_nodes, const int32_t* graph_ptr,
                                              const int32_t* chunk_ptr, int n_graphs, int n_chunks, float r2, int cap,
                                              float* bbox_scratch, int32_t* nbr, int32_t* cnt, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n_nodes <= 0) return 0;
     if (dim < 1 || dim > 3 || cap < 1) return -2;
     hipLaunchKernelGGL(k_chunk_bbox, dim3(nb(n_chunks, 4)), dim3(256), 0, S_, x, dim, graph_ptr, chunk_ptr, n_graphs,
@@ -307,6 +309,7 @@ extern "C" int magnet_radius_search_bbox_f32(const float* x, int dim, int n_node
 // qptr[n_nodes + 1] <- exclusive scan of the kept-neighbour counts; qptr[n_nodes] = E
 extern "C" int magnet_radius_offsets(const int32_t* nbr, const int32_t* cnt, int n_nodes, int cap, int loop,
                                      int32_t* qptr, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     hipLaunchKernelGGL(k_kept, dim3(nb(n_nodes + 1, 256)), dim3(256), 0, S_, nbr, cnt, n_nodes, cap, loop, qptr);
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, S_, qptr, n_nodes + 1);
     LAUNCH_CHECK();
@@ -314,6 +317,7 @@ extern "C" int magnet_radius_offsets(const int32_t* nbr, const int32_t* cnt, int
 
 extern "C" int magnet_radius_emit_pairs(const int32_t* nbr, const int32_t* cnt, const int32_t* qptr, int n_nodes,
                                         int cap, int loop, int32_t* found, int32_t* query, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n_nodes <= 0) return 0;
     hipLaunchKernelGGL(k_emit_pairs, dim3(nb(n_nodes, 256)), dim3(256), 0, S_, nbr, cnt, qptr, n_nodes, cap, loop,
                        found, query);
@@ -325,6 +329,7 @@ extern "C" int magnet_radius_emit_pairs(const int32_t* nbr, const int32_t* cnt, 
 extern "C" int magnet_csr_by_target(const int32_t* src, const int32_t* tgt, int n_edges, int n_nodes, int32_t* rowptr,
                                     int32_t* cursor, int32_t* eid_scratch, int32_t* perm, int32_t* src_out,
                                     int32_t* tgt_out, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n_edges > 0) hipLaunchKernelGGL(k_count_tgt, dim3(nb(n_edges, 256)), dim3(256), 0, S_, tgt, n_edges, rowptr);
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, S_, rowptr, n_nodes + 1);
     if (n_edges > 0) {
@@ -337,12 +342,14 @@ extern "C" int magnet_csr_by_target(const int32_t* src, const int32_t* tgt, int 
 }
 
 extern "C" int magnet_i64_to_i32(const int64_t* a, int n, int32_t* b, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_i64_to_i32, dim3(nb(n, 256)), dim3(256), 0, S_, a, n, b);
     LAUNCH_CHECK();
 }
 extern "C" int magnet_pairs_to_edge_index(const int32_t* row0, const int32_t* row1, int n_edges, int64_t* edge_index,
                                           void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n_edges <= 0) return 0;
     hipLaunchKernelGGL(k_pairs_to_i64, dim3(nb(n_edges, 256)), dim3(256), 0, S_, row0, row1, n_edges, edge_index);
     LAUNCH_CHECK();
@@ -350,6 +357,7 @@ extern "C" int magnet_pairs_to_edge_index(const int32_t* row0, const int32_t* ro
 
 extern "C" int magnet_knn_f32(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_ptr, int n_graphs,
                               int dim, int n_queries, int k, int32_t* out, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n_queries <= 0) return 0;
     if (k < 1 || k > 8 || dim < 1 || dim > 3) return -2;
     hipLaunchKernelGGL(k_knn, dim3(nb(n_queries, 128)), dim3(128), 0, S_, x, x_ptr, y, y_ptr, n_graphs, dim, n_queries,
@@ -359,6 +367,7 @@ extern "C" int magnet_knn_f32(const float* x, const int32_t* x_ptr, const float*
 
 extern "C" int magnet_segment_mean_f32(const float* msg, const int32_t* rowptr, int n_rows, int h, float* out,
                                        void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n_rows <= 0) return 0;
     const dim3 grid(nb(n_rows, 4)), block(256);
     switch (h) {

@@ -162,6 +162,7 @@ static inline unsigned nb(long n, int b) { return (unsigned)((n + b - 1) / b); }
 
 extern "C" int magnet_node_features_f32(const float* u, const float* x, const float* t_last, int n_graphs,
                                         int nodes_per_graph, int T, int d, int ld, float* out, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     const long n = (long)n_graphs * nodes_per_graph;
     if (n <= 0) return 0;
     if (T + d + 1 > ld) return -2;
@@ -172,6 +173,7 @@ extern "C" int magnet_node_features_f32(const float* u, const float* x, const fl
 
 extern "C" int magnet_euler_update_f32(const float* ret, int ld_ret, const float* last, const float* t, int t_ld,
                                        int n_graphs, int nodes_per_graph, int T, int T_out, float* out, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     const long total = (long)n_graphs * nodes_per_graph * T_out;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(k_euler_update, dim3(nb(total, 256)), dim3(256), 0, S_, ret, ld_ret, last, t, t_ld, n_graphs,
@@ -182,6 +184,7 @@ extern "C" int magnet_euler_update_f32(const float* ret, int ld_ret, const float
 extern "C" int magnet_inr_knn_prepare_f32(const float* lr_coords, const float* hr_coords, const int32_t* nn, int k,
                                           int d, int n_graphs, int L, int Nq, int32_t* nn2, float* rel, float* w,
                                           void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     const long nq = (long)n_graphs * Nq;
     if (nq <= 0) return 0;
     if (k < 2 || d > 3) return -2;
@@ -194,6 +197,7 @@ extern "C" int magnet_inr_knn_prepare_f32(const float* lr_coords, const float* h
 extern "C" int magnet_inr_knn_blend_f32(const float* base, const float* w, const float* vals, const int32_t* nn2,
                                         const float* t, int t_ld, const float* wv, const float* wt, int n_graphs,
                                         int L, int Nq, int T, int C, int mode, float* z, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     const long total = (long)n_graphs * Nq * T * C;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(k_inr_knn_blend, dim3(nb(total, 256)), dim3(256), 0, S_, base, w, vals, nn2, t, t_ld, wv, wt, L,
@@ -204,6 +208,7 @@ extern "C" int magnet_inr_knn_blend_f32(const float* base, const float* w, const
 extern "C" int magnet_inr_grid_prepare_f32(const float* coords, const float* cell, const float* x_t, const float* t,
                                            int t_ld, int n_graphs, int Nq, int T, int W, int d, int32_t* cell_idx,
                                            float* tail, float* area, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (d != 1 && d != 2) return -2;
     const long rows = (long)n_graphs * Nq * (d == 2 ? 4 : 2);
     if (rows <= 0) return 0;
@@ -214,6 +219,7 @@ extern "C" int magnet_inr_grid_prepare_f32(const float* coords, const float* cel
 
 extern "C" int magnet_inr_grid_blend_f32(const float* p, const float* area, int n_rows, int T, int C, int nshift,
                                          float* z, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     const long total = (long)n_rows * T * C;
     if (total <= 0) return 0;
     if (nshift != 2 && nshift != 4) return -2;

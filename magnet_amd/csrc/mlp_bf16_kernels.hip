@@ -162,6 +162,7 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
 
 extern "C" int magnet_mlp_bf16x6_f32(const MagnetMlpArgs* args, int nl, int ht, int ot, int act, int last_act, int ln,
                                      int epi, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (!args || args->M <= 0) return args && args->M == 0 ? 0 : -1;
     if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
     mlp_fn fn = pick(nl, ht, ot, act, last_act, ln, epi);

@@ -125,11 +125,13 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
 }
 
 extern "C" int magnet_mlp_supported(int nl, int ht, int ot, int act, int last_act, int ln, int epi) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     return pick(nl, ht, ot, act, last_act, ln, epi) != nullptr;
 }
 
 extern "C" int magnet_mlp_f32(const MagnetMlpArgs* args, int nl, int ht, int ot, int act, int last_act, int ln,
                               int epi, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (!args || args->M <= 0) return args && args->M == 0 ? 0 : -1;
     if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
     mlp_fn fn = pick(nl, ht, ot, act, last_act, ln, epi);
@@ -141,6 +143,7 @@ extern "C" int magnet_mlp_f32(const MagnetMlpArgs* args, int nl, int ht, int ot,
 
 extern "C" int magnet_segmean_fixup_f32(const int32_t* rowptr, int n_rows, int d, const float* partials, float* agg,
                                         void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n_rows <= 0) return 0;
     hipLaunchKernelGGL(k_segmean_fixup, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rowptr, n_rows, d,
                        partials, agg);

@@ -187,6 +187,7 @@ int g_edge6_ablation = 0;
 extern "C" int magnet_mpnn_edge_bf16x6_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
                                            const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2,
                                            float* agg, float* partials, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n_edges <= 0) return 0;
     static int ncu = 0;
     if (!ncu) {

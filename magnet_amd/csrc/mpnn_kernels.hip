@@ -288,6 +288,7 @@ static int g_edge_variant = 102;   // persistent v2 kernel, 8 waves / workgroup
 // development knob for A/B measurements: 102 = k_mpnn_edge2<8> (default), 0 = first-generation k_mpnn_edge,
 // 1x/11x = ablations (results invalid)
 extern "C" int magnet_debug_set_variant(int which, int value) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (which == 0) g_edge_variant = value;
     if (which == 1) g_edge6_ablation = value;
     return 0;
@@ -296,6 +297,7 @@ extern "C" int magnet_debug_set_variant(int which, int value) {
 extern "C" int magnet_mpnn_node_input_f32(const float* u, const float* pos, int pos_ld, const float* Lvec,
                                           const float* tmax, int n, int tw, int dpos, int kin, float* out,
                                           void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n <= 0) return 0;
     if (tw + dpos + 1 > kin) return -2;
     const long total = (long)n * kin;
@@ -307,6 +309,7 @@ extern "C" int magnet_mpnn_node_input_f32(const float* u, const float* pos, int 
 extern "C" int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
                                     const int32_t* rowptr, int n_edges, const void* w2_packed, const float* b2,
                                     float* agg, float* partials, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n_edges <= 0) return 0;
     MagnetLayer L{reinterpret_cast<const f32x4*>(w2_packed), b2};
     const int tiles = (n_edges + 31) / 32;
@@ -354,6 +357,7 @@ extern "C" int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32
 extern "C" int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1,
                                        int k1, int s1, const float* w2, const float* b2, int k2, int use_swish,
                                        const float* dt, float* out, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n <= 0) return 0;
     const int L1 = (128 - k1) / s1 + 1;
     if (L1 > 64 || tw > 64 || L1 - k2 + 1 != tw) return -2;
@@ -365,6 +369,7 @@ extern "C" int magnet_mpnn_readout_f32(const float* h, const float* u, int n, in
 // workspace: (2 * n_graphs * nchunks + 2 * n_graphs) * H floats, nchunks = ceil(rows_per_graph / 64)
 extern "C" int magnet_instance_norm_f32(const float* x, int n_graphs, int rows_per_graph, int H, float eps, float* y,
                                         float* workspace, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n_graphs <= 0 || rows_per_graph <= 0) return 0;
     if (H % 4 || H > 1024 || 1024 % H) return -2;
     const int nchunks = (rows_per_graph + NORM_CHUNK - 1) / NORM_CHUNK;
