@@ -61,3 +61,42 @@ def test_forward_is_deterministic():
     a = model.validation_step(cb, 0).clone()
     b = model.validation_step(cb, 0)
     assert torch.equal(a, b)
+
+
+def test_batch_sharding_invariance():
+    """trajectories are independent, so a sample's rollout does not depend on which other
+    samples share its batch / rank (tile boundaries move, hence rounding-level rather than bitwise equality)."""
+    from magnet_amd.sharding import shard_batch
+    name, hp, batch, d, oracle, model = _models("mpnn_2d")
+    cb = {k: v.cuda() for k, v in batch.items()}
+    full = model.validation_step(cb, 0)
+    parts = [model.validation_step(shard_batch(cb, r, 2), 0) for r in range(2)]
+    assert rel_l2(torch.cat(parts, 0), full) < 1e-6
+
+
+def test_graph_without_edges_and_odd_sizes():
+    """neighbors = 0 -> radius 1e-4 -> no edges at all (every mean is 0, A.6); 7 x 7 mesh: node and edge counts
+    that are not multiples of the 32-row tiles."""
+    import types
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    for neighbors in (0, 2):
+        hp = types.SimpleNamespace(lr=1e-3, weight_decay=0.0, factor=0.3, step_size=50, loss="l1", hidden_features=128,
+                                   hidden_layer=5, time_window=10, teacher_forcing=False, neighbors=neighbors)
+        g = torch.Generator().manual_seed(3)
+        W, B, nt = 7, 3, 30
+        lin = torch.linspace(0, 1, W)
+        xy = torch.stack(torch.meshgrid(lin, lin, indexing="ij"), -1).reshape(-1, 2)
+        batch = {"u": torch.randn(B, W * W, nt, generator=g), "x": xy[None].repeat(B, 1, 1), "t": torch.linspace(0, 1, nt)[None].repeat(B, 1)}
+        oracle = O.build("mpnn_2d", hp).eval()
+        fill_state_dict(oracle, 31)
+        model = FACTORY["mpnn_2d"](hp).eval()
+        model.load_state_dict(oracle.state_dict())
+        model = model.cuda()
+        pred = model.validation_step({k: v.cuda() for k, v in batch.items()}, 0)
+        assert model._topo.csr.E == (0 if neighbors == 0 else model._topo.csr.E)
+        with torch.no_grad():
+            want = oracle.validation_step(batch)
+        assert not torch.isnan(pred).any()
+        assert rel_l2(pred, want) < 5 * OUT_TOL, neighbors
