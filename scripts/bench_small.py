@@ -19,6 +19,14 @@ K = 20
 for _ in range(K): m.validation_step(cb, 0)
 torch.cuda.synchronize(); dt = (time.time() - t0) / K
 print(f"C1 GPU rollout (9 forwards): {dt*1e3:.2f} ms -> {B*N*225/dt:.3e} node-updates/s")
+ref = m.validation_step(cb, 0).clone()
+m.hip_graph = True
+for _ in range(3): got = m.validation_step(cb, 0)
+print("hipGraph replay equals eager:", bool(torch.equal(got, ref)))
+torch.cuda.synchronize(); t0 = time.time()
+for _ in range(K): m.validation_step(cb, 0)
+torch.cuda.synchronize(); dg = (time.time() - t0) / K
+print(f"C1 GPU rollout with hipGraph replay: {dg*1e3:.2f} ms -> {B*N*225/dg:.3e} node-updates/s")
 with torch.no_grad():
     oracle.validation_step(batch)
     t0 = time.time()
