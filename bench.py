@@ -18,9 +18,10 @@ Extra objects on the JSON line:
   roofline      - dominant kernel (k_mpnn_edge6, MFMA bound): algorithmic flops per launch
                   (2*E*128*128, the message_net_2 GEMM; message_net_1 is factorised per node, see
                   DESIGN.md) / mean launch time measured with HIP events on the launch stream.  The
-                  kernel evaluates every fp32 product exactly as 6 bf16 partial products on the matrix
-                  cores, so its ceiling is the dense bf16 MFMA peak / 6 = 416.7 TFLOP/s of fp32-equivalent
-                  work (`peak`); `executed_bf16_tflops` / 2500 is the same fraction.
+                  kernel evaluates every fp32 product through an exact split into 16-bit pieces on the
+                  matrix cores (default fp16x3: 3 fp16 MFMA products per fp32 product; bf16x6: 6), so its
+                  ceiling is the dense 16-bit MFMA peak / 3 = 833 TFLOP/s of fp32-equivalent work (`peak`);
+                  `executed_mfma_tflops` / 2500 is the same fraction.
   roofline_scatter - the standalone CSR segment-mean ("scatter mean") kernel on the same graph's
                   [E,128] messages: algorithmic bytes E*H*4 + N*H*4 + 4*(N+1) per launch / mean
                   launch time, against the 8 TB/s HBM3E peak.
@@ -48,7 +49,7 @@ HP = dict(lr=1e-3, weight_decay=0.0, factor=0.3, step_size=50, loss="l1", hidden
 NT = 50
 MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_BF16_PEAK_TFLOPS = 2500.0
-SPLIT_PRODUCTS = 6            # bf16 partial products per fp32 product in k_mpnn_edge6
+SPLIT_PRODUCTS = {"fp16x3": 3, "bf16x6": 6}   # MFMA partial products per fp32 product in k_mpnn_edge6
 HBM_PEAK_GBS = 8000.0
 
 
@@ -150,7 +151,8 @@ def main():
         csr = model._topo.csr
         E, N, H = csr.E, csr.N, 128
         ev = []
-        orig = ops.L.lib().magnet_mpnn_edge_bf16x6_f32
+        entry = ops.EDGE_ENTRY[model._packed().layers[0].msg2[0].dtype]
+        orig = getattr(ops.L.lib(), entry)
 
         def timed_edge(*a):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -160,22 +162,26 @@ def main():
             ev.append((s, e))
             return rc
 
-        ops.L._lib.magnet_mpnn_edge_bf16x6_f32 = timed_edge
+        setattr(ops.L._lib, entry, timed_edge)
         try:
             model.validation_step(batch, 0)
             torch.cuda.synchronize()
         finally:
-            ops.L._lib.magnet_mpnn_edge_bf16x6_f32 = orig
+            setattr(ops.L._lib, entry, orig)
         ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
         flops = 2.0 * E * H * H
         ach = flops / (ms * 1e-3) / 1e12
-        peak = MFMA_BF16_PEAK_TFLOPS / SPLIT_PRODUCTS
-        roof = {"kernel": "k_mpnn_edge6", "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
+        mode = model.edge_gemm
+        nprod = SPLIT_PRODUCTS.get(mode, 1)
+        peak = MFMA_BF16_PEAK_TFLOPS / nprod if mode in SPLIT_PRODUCTS else MFMA_F32_PEAK_TFLOPS
+        roof = {"kernel": "k_mpnn_edge6" if mode in SPLIT_PRODUCTS else "k_mpnn_edge2", "bound": "mfma",
+                "achieved": round(ach, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                "launch_ms": round(ms, 4), "launches_timed": len(ev), "flops_per_launch": flops,
-                "executed_bf16_tflops": round(ach * SPLIT_PRODUCTS, 1), "bf16_dense_peak": MFMA_BF16_PEAK_TFLOPS,
+                "launch_ms": round(ms, 4), "launches_timed": len(ev), "flops_per_launch": flops, "gemm_mode": mode,
+                "executed_mfma_tflops": round(ach * nprod, 1), "mfma_16bit_dense_peak": MFMA_BF16_PEAK_TFLOPS,
                 "fp32_mfma_peak_for_reference": MFMA_F32_PEAK_TFLOPS,
-                "note": "fp32 GEMM evaluated exactly as 6 bf16 MFMA products (hi/mid/lo split, fp32 accumulate)"}
+                "note": "fp32 GEMM evaluated through an exact split into 16-bit pieces on the matrix cores "
+                        f"({nprod} MFMA products per fp32 product, fp32 accumulate); peak = 2500 / {nprod}"}
         msg = torch.randn(E, H, device=dev)
         out = torch.empty(N, H, device=dev)
         for _ in range(3):
@@ -206,7 +212,7 @@ def main():
         line = {"metric": "mesh-node-updates/s (nodes x steps x batch), 2D Burgers 256^2 rollout",
                 "value": value, "unit": "mesh-node-updates/s", "n_gpus": world, "steps": K, "warmup": Wm,
                 "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32 (edge GEMM: exact 3xbf16 split on the matrix cores, fp32 accumulate)", "data": "synthetic",
+                "dtype": "f32 (GEMMs: exact 2-piece fp16 split on the matrix cores, fp32 accumulate)", "data": "synthetic",
                 "config": {"workload": f"mpnn_2d free-running rollout, {W}x{W} regular mesh (N={W * W}, E={model._topo.csr.E // B} per "
                                        f"trajectory), nt={NT}, time_window={tw} -> {pred_steps} predicted steps, {B} trajectories per GPU, "
                                        "radius graph + CSR rebuilt every step",

@@ -85,6 +85,11 @@ int magnet_mlp_supported(int nl, int ht, int ot, int act, int last_act, int ln, 
  * k tile are DMA'd into LDS and shared by the 4 waves of a workgroup. */
 int magnet_mlp_bf16x6_f32(const magnet_mlp_args_t* args, int nl, int ht, int ot, int act, int last_act, int ln, int epi,
                           void* stream);
+/* Same again with the two-piece fp16 split (x = h + l/2048, three fp16 MFMA products, cross terms in their own
+ * accumulator): half the matrix-pipe work of bf16x6, fp32-class accuracy, |values| < 65504 required.
+ * layer[l].w: planes [kt][nt][m][2][64 lanes][8 fp16] (magnet_amd/packing.py:pack_linear_fp16x2). */
+int magnet_mlp_fp16x3_f32(const magnet_mlp_args_t* args, int nl, int ht, int ot, int act, int last_act, int ln, int epi,
+                          void* stream);
 int magnet_segmean_fixup_f32(const int32_t* rowptr, int n_rows, int d, const float* partials, float* agg,
                              void* stream);
 
@@ -108,6 +113,9 @@ int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32_t* src, co
  * hi/mid/lo split (six partial products, fp32-class accuracy).  w2_split: the three bf16 planes of
  * W2 in fragment order [kt][nt][m][plane][64 lanes][8 bf16] (magnet_amd/packing.py:pack_linear_bf16x3). */
 int magnet_mpnn_edge_bf16x6_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
+                                const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2, float* agg,
+                                float* partials, void* stream);
+int magnet_mpnn_edge_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
                                 const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2, float* agg,
                                 float* partials, void* stream);
 /* out[n][k] = u[n][tw-1] + dt*(k+1) * Conv1d(8->1,k2)([Swish](Conv1d(1->8,k1,stride s1)(h[n])))[k];

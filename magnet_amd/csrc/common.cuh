@@ -245,6 +245,72 @@ __device__ __forceinline__ f32x16 mma_split6(bf16x8 wh, bf16x8 wm, bf16x8 wl, bf
     return acc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// "fp16x3": the same idea with two fp16 pieces.  x = h + l/2048 with h = RTZ_fp16(x) and
+// l = RNE_fp16((x - h) * 2048) (the remainder is exact and the 2^11 scaling keeps it out of the fp16 subnormals);
+// x*w = h*hw + 2^-11 (h*lw + l*hw) + O(2^-22): three v_mfma_f32_32x32x16_f16 per 16-k slot - half the matrix-pipe
+// cycles and about half the split instructions of bf16x6 - with the cross terms kept in their own accumulator
+// and folded in once per layer.  Measured 2.2-3.1e-7 relative L2 vs fp64 at K = 128 (fp32 fmaf chain 2.0e-7).
+// Range: |x| must stay below the fp16 maximum 65504 (true for normalised PDE fields, coordinates and every
+// post-norm hidden state on this path); bf16x6 has the full fp32 range and remains selectable.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+enum { GEMM_BF16X6 = 0, GEMM_FP16X3 = 1 };
+
+template <int MODE>
+struct Split;
+
+template <>
+struct Split<GEMM_BF16X6> {
+    static constexpr int NP = 3;                       // planes per slot
+    static __device__ __forceinline__ void quarter(const f32x16& tile, int m, int p, u32x4 (&planes)[3]) {
+        split_quarter(tile, m, p, planes);
+    }
+    // wp: plane 0 of the slot for this lane, planes 64 u32x4 apart (LDS or registers copied from it)
+    static __device__ __forceinline__ void mma(const u32x4 (&w)[3], const u32x4 (&x)[3], f32x16& accM, f32x16&) {
+        accM = mma_split6(__builtin_bit_cast(bf16x8, w[0]), __builtin_bit_cast(bf16x8, w[1]), __builtin_bit_cast(bf16x8, w[2]),
+                          __builtin_bit_cast(bf16x8, x[0]), __builtin_bit_cast(bf16x8, x[1]), __builtin_bit_cast(bf16x8, x[2]), accM);
+    }
+    static __device__ __forceinline__ void fold(f32x16&, const f32x16&) {}
+};
+
+template <>
+struct Split<GEMM_FP16X3> {
+    static constexpr int NP = 2;
+    static __device__ __forceinline__ void quarter(const f32x16& tile, int m, int p, u32x4 (&planes)[2]) {
+        const float a0 = tile[8 * m + 2 * p], a1 = tile[8 * m + 2 * p + 1];
+        const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+        const float r0 = (a0 - (float)h[0]) * 2048.f, r1 = (a1 - (float)h[1]) * 2048.f;
+        const _Float16 l0 = (_Float16)r0, l1 = (_Float16)r1;
+        planes[0][p] = __builtin_bit_cast(unsigned, h);
+        planes[1][p] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    }
+    static __device__ __forceinline__ void mma(const u32x4 (&w)[2], const u32x4 (&x)[2], f32x16& accM, f32x16& accC) {
+        const f16x8 wh = __builtin_bit_cast(f16x8, w[0]), wl = __builtin_bit_cast(f16x8, w[1]);
+        const f16x8 xh = __builtin_bit_cast(f16x8, x[0]), xl = __builtin_bit_cast(f16x8, x[1]);
+        accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, accC, 0, 0, 0);
+        accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accC, 0, 0, 0);
+        accM = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, accM, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void fold(f32x16& accM, const f32x16& accC) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accM[i] = fmaf(accC[i], 1.0f / 2048.0f, accM[i]);
+    }
+};
+
+template <int MODE>
+__device__ __forceinline__ void split_slot(const f32x16& tile, int m, u32x4 (&planes)[Split<MODE>::NP]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) Split<MODE>::quarter(tile, m, p, planes);
+}
+template <int NT>
+__device__ __forceinline__ void zero_tiles(f32x16 (&t)[NT]) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[n][i] = 0.f;
+}
+
 // first-layer k tile from the (gathered / concatenated / differenced) sources
 __device__ __forceinline__ f32x16 load_ktile(const MagnetKTile& d, int row, int half) {
     f32x16 v;

@@ -22,27 +22,37 @@ __device__ __forceinline__ void dma_chunk(const f32x4* __restrict__ gw, u32x4* l
         __builtin_amdgcn_global_load_lds(g + p * 64 + lane, l + p * 64, 16, 0, 0);
 }
 
-// out[nt] += W(chunk)[nt] * x   for one k tile whose planes sit in LDS at `wl` ([nt][m][plane][64])
-template <int NT>
-__device__ __forceinline__ void mma_chunk(const f32x16& x, f32x16 (&out)[NT], const u32x4* wl, int lane) {
+// acc[nt] += W(chunk)[nt] * x   for one k tile whose planes sit in LDS at `wl` ([nt][m][plane][64])
+template <int NT, int MODE>
+__device__ __forceinline__ void mma_chunk(const f32x16& x, f32x16 (&accM)[NT], f32x16 (&accC)[NT], const u32x4* wl, int lane) {
+    constexpr int NP = Split<MODE>::NP;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        u32x4 xs[3];
-        split_pair4(x, m, xs);
+        u32x4 xs[NP];
+        split_slot<MODE>(x, m, xs);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const u32x4* wp = wl + ((nt * 2 + m) * 3) * 64 + lane;
-            out[nt] = mma_split6(__builtin_bit_cast(bf16x8, wp[0]), __builtin_bit_cast(bf16x8, wp[64]),
-                                 __builtin_bit_cast(bf16x8, wp[128]), __builtin_bit_cast(bf16x8, xs[0]),
-                                 __builtin_bit_cast(bf16x8, xs[1]), __builtin_bit_cast(bf16x8, xs[2]), out[nt]);
+            const u32x4* wp = wl + ((nt * 2 + m) * NP) * 64 + lane;
+            u32x4 w[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) w[q] = wp[64 * q];
+            Split<MODE>::mma(w, xs, accM[nt], accC[nt]);
         }
     }
 }
+template <int NT, int MODE>
+__device__ __forceinline__ void fold_tiles(f32x16 (&accM)[NT], f32x16 (&accC)[NT]) {
+    if (MODE == GEMM_FP16X3) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) Split<MODE>::fold(accM[n], accC[n]);
+    }
+}
 
-template <int NL, int HT, int OT, int ACT, bool LAST_ACT, bool LN, int EPI>
-__global__ void __launch_bounds__(256) k_mlp_bf16(const MagnetMlpArgs a) {
+template <int MODE, int NL, int HT, int OT, int ACT, bool LAST_ACT, bool LN, int EPI>
+__global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const MagnetMlpArgs a) {
     constexpr int NTMAX = MaxI<HT, OT>::v;
-    constexpr int CH = NTMAX * 6 * 64;                                   // u32x4 per chunk buffer
+    constexpr int PPN = 2 * Split<MODE>::NP;                              // 1 KiB pieces per output tile and k tile
+    constexpr int CH = NTMAX * PPN * 64;                                   // u32x4 per chunk buffer
     constexpr int SLAB = (EPI == EPI_SEGMEAN) ? 4 * SegSlab<OT>::FLOATS : 0;
     __shared__ __attribute__((aligned(16))) u32x4 smem[2 * CH + (SLAB + 3) / 4];   // ONE LDS object (chunks + slab)
     u32x4* wbuf = smem;
@@ -58,26 +68,28 @@ __global__ void __launch_bounds__(256) k_mlp_bf16(const MagnetMlpArgs a) {
     constexpr int NT0 = (NL == 1) ? OT : HT;
     int cbuf = 0;                                     // LDS buffer holding the chunk about to be consumed
     // chunk protocol: the DMA of chunk c+1 is issued right after the barrier that precedes the compute of chunk c
-    dma_chunk(a.layer[0].w, wbuf, NT0 * 6, wave, lane);
+    dma_chunk(a.layer[0].w, wbuf, NT0 * PPN, wave, lane);
 
     f32x16 out[OT];
     f32x16 h0[HT], h1[HT];
     // ---------------- layer 0: K streamed from the sources
     {
-        f32x16 acc[NT0];
+        f32x16 acc[NT0], accc[NT0];
         init_bias<NT0>(acc, a.layer[0].b, half);
+        zero_tiles<NT0>(accc);
         f32x16 x = load_ktile(a.kt[0], row, half);
         for (int kt = 0; kt < a.nkt; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             // next chunk: layer 0's next k tile, or the first k tile of layer 1
-            if (kt + 1 < a.nkt) dma_chunk(a.layer[0].w + (size_t)(kt + 1) * NT0 * 6 * 64, wbuf + (cbuf ^ 1) * CH, NT0 * 6, wave, lane);
-            else if (NL > 1) dma_chunk(a.layer[1].w, wbuf + (cbuf ^ 1) * CH, ((NL == 2) ? OT : HT) * 6, wave, lane);
+            if (kt + 1 < a.nkt) dma_chunk(a.layer[0].w + (size_t)(kt + 1) * NT0 * PPN * 64, wbuf + (cbuf ^ 1) * CH, NT0 * PPN, wave, lane);
+            else if (NL > 1) dma_chunk(a.layer[1].w, wbuf + (cbuf ^ 1) * CH, ((NL == 2) ? OT : HT) * PPN, wave, lane);
             const f32x16 xn = load_ktile(a.kt[kt + 1 < a.nkt ? kt + 1 : kt], row, half);
-            mma_chunk<NT0>(x, acc, wbuf + cbuf * CH, lane);
+            mma_chunk<NT0, MODE>(x, acc, accc, wbuf + cbuf * CH, lane);
             x = xn;
             cbuf ^= 1;
         }
+        fold_tiles<NT0, MODE>(acc, accc);
         if (NL == 1) {
 #pragma unroll
             for (int t = 0; t < NT0; ++t) out[t < OT ? t : 0] = acc[t];
@@ -94,6 +106,10 @@ __global__ void __launch_bounds__(256) k_mlp_bf16(const MagnetMlpArgs a) {
     for (int l = 1; l < NL; ++l) {
         const bool last = (l == NL - 1);
         const bool src0 = (l & 1);                     // odd layers read h0, even layers read h1
+        f32x16 cc[NTMAX];
+        zero_tiles<NTMAX>(cc);
+        f32x16(&cco)[OT] = reinterpret_cast<f32x16(&)[OT]>(cc);
+        f32x16(&cch)[HT] = reinterpret_cast<f32x16(&)[HT]>(cc);
         if (last) init_bias<OT>(out, a.layer[l].b, half);
         else if (src0) init_bias<HT>(h1, a.layer[l].b, half);
         else init_bias<HT>(h0, a.layer[l].b, half);
@@ -102,13 +118,16 @@ __global__ void __launch_bounds__(256) k_mlp_bf16(const MagnetMlpArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             const int nt_here = last ? OT : HT;
-            if (kt + 1 < HT) dma_chunk(a.layer[l].w + (size_t)(kt + 1) * nt_here * 6 * 64, wbuf + (cbuf ^ 1) * CH, nt_here * 6, wave, lane);
-            else if (l + 1 < NL) dma_chunk(a.layer[l + 1].w, wbuf + (cbuf ^ 1) * CH, ((l + 1 == NL - 1) ? OT : HT) * 6, wave, lane);
-            if (last) mma_chunk<OT>(src0 ? h0[kt] : h1[kt], out, wbuf + cbuf * CH, lane);
-            else if (src0) mma_chunk<HT>(h0[kt], h1, wbuf + cbuf * CH, lane);
-            else mma_chunk<HT>(h1[kt], h0, wbuf + cbuf * CH, lane);
+            if (kt + 1 < HT) dma_chunk(a.layer[l].w + (size_t)(kt + 1) * nt_here * PPN * 64, wbuf + (cbuf ^ 1) * CH, nt_here * PPN, wave, lane);
+            else if (l + 1 < NL) dma_chunk(a.layer[l + 1].w, wbuf + (cbuf ^ 1) * CH, ((l + 1 == NL - 1) ? OT : HT) * PPN, wave, lane);
+            if (last) mma_chunk<OT, MODE>(src0 ? h0[kt] : h1[kt], out, cco, wbuf + cbuf * CH, lane);
+            else if (src0) mma_chunk<HT, MODE>(h0[kt], h1, cch, wbuf + cbuf * CH, lane);
+            else mma_chunk<HT, MODE>(h1[kt], h0, cch, wbuf + cbuf * CH, lane);
             cbuf ^= 1;
         }
+        if (last) fold_tiles<OT, MODE>(out, cco);
+        else if (src0) fold_tiles<HT, MODE>(h1, cch);
+        else fold_tiles<HT, MODE>(h0, cch);
         if (!last) {
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
@@ -138,8 +157,9 @@ typedef void (*mlp_fn)(const MagnetMlpArgs);
 
 #define MLP_CASE(NL_, HT_, OT_, ACT_, LA_, LN_, EPI_)                                              \
     if (nl == NL_ && ht == HT_ && ot == OT_ && act == ACT_ && last_act == LA_ && ln == LN_ && epi == EPI_) \
-        fn = k_mlp_bf16<NL_, HT_, OT_, ACT_, LA_, LN_, EPI_>;
+        fn = k_mlp_bf16<MODE, NL_, HT_, OT_, ACT_, LA_, LN_, EPI_>;
 
+template <int MODE>
 static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int epi) {
     mlp_fn fn = nullptr;
     MLP_CASE(2, 4, 4, ACT_SWISH, true, false, EPI_STORE)
@@ -160,14 +180,25 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
     return fn;
 }
 
+static int launch_mlp(mlp_fn fn, const MagnetMlpArgs* args, void* stream) {
+    if (!fn) return -3;
+    const int tiles = (args->M + 31) / 32;
+    hipLaunchKernelGGL(fn, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, *args);
+    return (int)hipGetLastError();
+}
+
 extern "C" int magnet_mlp_bf16x6_f32(const MagnetMlpArgs* args, int nl, int ht, int ot, int act, int last_act, int ln,
                                      int epi, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (!args || args->M <= 0) return args && args->M == 0 ? 0 : -1;
     if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
-    mlp_fn fn = pick(nl, ht, ot, act, last_act, ln, epi);
-    if (!fn) return -3;
-    const int tiles = (args->M + 31) / 32;
-    hipLaunchKernelGGL(fn, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, *args);
-    return (int)hipGetLastError();
+    return launch_mlp(pick<GEMM_BF16X6>(nl, ht, ot, act, last_act, ln, epi), args, stream);
+}
+
+extern "C" int magnet_mlp_fp16x3_f32(const MagnetMlpArgs* args, int nl, int ht, int ot, int act, int last_act, int ln,
+                                     int epi, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
+    if (!args || args->M <= 0) return args && args->M == 0 ? 0 : -1;
+    if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
+    return launch_mlp(pick<GEMM_FP16X3>(nl, ht, ot, act, last_act, ln, epi), args, stream);
 }

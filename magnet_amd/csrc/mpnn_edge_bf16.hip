@@ -76,15 +76,16 @@ __device__ __forceinline__ void store_runs(const f32x16 (&v)[4], const TileMeta&
     }
 }
 
-template <int ABL>
+template <int MODE, int ABL>
 __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__ A, const float* __restrict__ Bm,
                                                        const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
                                                        const int32_t* __restrict__ rowptr, int E,
-                                                       const u32x4* __restrict__ w2s /* [32 slots][3 planes][64] */,
+                                                       const u32x4* __restrict__ w2s /* [32 slots][NP planes][64] */,
                                                        const float* __restrict__ b2, float* __restrict__ agg,
                                                        float* __restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) u32x4 wl[32 * 3 * 64];           // 96 KiB
-    for (int i = threadIdx.x; i < 32 * 3 * 64; i += 256) wl[i] = w2s[i];
+    constexpr int NP = Split<MODE>::NP;
+    __shared__ __attribute__((aligned(16))) u32x4 wl[32 * NP * 64];          // 96 KiB (bf16x6) / 64 KiB (fp16x3)
+    for (int i = threadIdx.x; i < 32 * NP * 64; i += 256) wl[i] = w2s[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, j = lane & 31;
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__
     const int stride = gridDim.x * 4;
     int tile = blockIdx.x * 4 + wave;
     if (tile >= ntiles) return;
-    f32x16 in[4], out[4], prev[4];
+    f32x16 in[4], out[4], outc[4], prev[4];
     f32x4 la[4], lb[4];                       // one k tile (32 columns) of A[i] / Bm[j] in flight
     {   // prologue: gather + Swish for the first tile
         const int e = min(tile * 32 + j, E - 1);
@@ -121,26 +122,26 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__
         const float* pan = A + (size_t)tgt[en] * 128 + 4 * half;
         const float* pbn = Bm + (size_t)src[en] * 128 + 4 * half;
         init_bias<4>(out, b2, half);
+        zero_tiles<4>(outc);
         {
-            u32x4 xs[2][3], wr[2][3];
-            split_pair4(in[0], 0, xs[0]);
+            u32x4 xs[2][NP], wr[2][NP];
+            split_slot<MODE>(in[0], 0, xs[0]);
             {
                 const u32x4* wp = wl + lane;
-                wr[0][0] = wp[0]; wr[0][1] = wp[64]; wr[0][2] = wp[128];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) wr[0][q] = wp[64 * q];
             }
 #pragma unroll
             for (int gq = 0; gq < 32; ++gq) {     // gq = slot * 4 + nt, slot = kt * 2 + m
                 const int slot = gq >> 2, nt = gq & 3;
                 if (gq + 1 < 32) {
                     const int s1 = (gq + 1) >> 2, n1 = (gq + 1) & 3;
-                    const u32x4* wp = wl + ((((s1 >> 1) * 4 + n1) * 2 + (s1 & 1)) * 3) * 64 + lane;
-                    wr[(gq + 1) & 1][0] = wp[0]; wr[(gq + 1) & 1][1] = wp[64]; wr[(gq + 1) & 1][2] = wp[128];
+                    const u32x4* wp = wl + ((((s1 >> 1) * 4 + n1) * 2 + (s1 & 1)) * NP) * 64 + lane;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) wr[(gq + 1) & 1][q] = wp[64 * q];
                 }
-                if (!(ABL & 1) && slot + 1 < 8) split_quarter(in[(slot + 1) >> 1], (slot + 1) & 1, nt, xs[(slot + 1) & 1]);
-                out[nt] = mma_split6(__builtin_bit_cast(bf16x8, wr[gq & 1][0]), __builtin_bit_cast(bf16x8, wr[gq & 1][1]),
-                                     __builtin_bit_cast(bf16x8, wr[gq & 1][2]), __builtin_bit_cast(bf16x8, xs[slot & 1][0]),
-                                     __builtin_bit_cast(bf16x8, xs[slot & 1][1]), __builtin_bit_cast(bf16x8, xs[slot & 1][2]),
-                                     out[nt]);
+                if (!(ABL & 1) && slot + 1 < 8) Split<MODE>::quarter(in[(slot + 1) >> 1], (slot + 1) & 1, nt, xs[(slot + 1) & 1]);
+                Split<MODE>::mma(wr[gq & 1], xs[slot & 1], out[nt], outc[nt]);
                 // epilogue of the previous tile, two registers per group
                 if (!(ABL & 2)) {
                     prev[(2 * gq) >> 4][(2 * gq) & 15] = scan_reg(prev[(2 * gq) >> 4][(2 * gq) & 15], pmd);
@@ -166,7 +167,10 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__
         }
         if (have_prev) store_runs(prev, pmd, rowptr, agg, partials, half);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) prev[nt] = out[nt];
+        for (int nt = 0; nt < 4; ++nt) {
+            Split<MODE>::fold(out[nt], outc[nt]);
+            prev[nt] = out[nt];
+        }
         pmd = md;
         have_prev = true;
 #pragma unroll
@@ -184,9 +188,9 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__
 
 int g_edge6_ablation = 0;
 
-extern "C" int magnet_mpnn_edge_bf16x6_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
-                                           const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2,
-                                           float* agg, float* partials, void* stream) {
+template <int MODE>
+static int launch_edge6(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt, const int32_t* rowptr,
+                        int n_edges, const void* w2_split, const float* b2, float* agg, float* partials, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n_edges <= 0) return 0;
     static int ncu = 0;
@@ -202,11 +206,23 @@ extern "C" int magnet_mpnn_edge_bf16x6_f32(const float* A, const float* Bm, cons
     const u32x4* ws = reinterpret_cast<const u32x4*>(w2_split);
     hipStream_t s = (hipStream_t)stream;
     switch (g_edge6_ablation) {   // development only: ablations produce invalid results
-        case 1: hipLaunchKernelGGL(k_mpnn_edge6<1>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
-        case 2: hipLaunchKernelGGL(k_mpnn_edge6<2>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
-        case 4: hipLaunchKernelGGL(k_mpnn_edge6<4>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
-        case 7: hipLaunchKernelGGL(k_mpnn_edge6<7>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
-        default: hipLaunchKernelGGL(k_mpnn_edge6<0>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
+        case 1: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 1>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
+        case 2: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 2>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
+        case 4: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 4>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
+        case 7: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 7>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
+        default: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 0>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int magnet_mpnn_edge_bf16x6_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
+                                           const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2,
+                                           float* agg, float* partials, void* stream) {
+    return launch_edge6<GEMM_BF16X6>(A, Bm, src, tgt, rowptr, n_edges, w2_split, b2, agg, partials, stream);
+}
+
+extern "C" int magnet_mpnn_edge_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
+                                           const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2,
+                                           float* agg, float* partials, void* stream) {
+    return launch_edge6<GEMM_FP16X3>(A, Bm, src, tgt, rowptr, n_edges, w2_split, b2, agg, partials, stream);
 }

@@ -54,16 +54,16 @@ class Decoder(nn.Module):
         self.node_fn = MLP(node_in, [mlp_hidden] * mlp_layers, node_out)
 
 
-def pack_mlp_ln(seq, k_pad=None, col_map=None):
+def pack_mlp_ln(seq, k_pad=None, col_map=None, mode=None):
     """(packed 5 Linears, (gain, bias, eps)) of a Sequential(MLP, LayerNorm)."""
     mlp, ln = seq[0], seq[1]
-    return types.SimpleNamespace(layers=mlp.packed(k_pad=k_pad, col_map=col_map),
+    return types.SimpleNamespace(layers=mlp.packed(k_pad=k_pad, col_map=col_map, mode=mode),
                                  ln=(ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps),
                                  ht=mlp.hidden // 32, ot=pad_to(mlp.out_dim) // 32, out_dim=mlp.out_dim)
 
 
-def pack_mlp(mlp, k_pad=None):
-    return types.SimpleNamespace(layers=mlp.packed(k_pad=k_pad), ln=None, ht=mlp.hidden // 32,
+def pack_mlp(mlp, k_pad=None, mode=None):
+    return types.SimpleNamespace(layers=mlp.packed(k_pad=k_pad, mode=mode), ln=None, ht=mlp.hidden // 32,
                                  ot=pad_to(mlp.out_dim) // 32, out_dim=mlp.out_dim)
 
 

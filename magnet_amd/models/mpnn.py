@@ -22,7 +22,7 @@ from torch import nn
 
 from .. import ops
 from ..lightning_compat import LightningModule
-from ..packing import default_gemm, pack, pack_linear, pack_linear_bf16x3, pad_to
+from ..packing import GEMM_MODES, default_gemm, pack, pad_to
 
 _READOUT = {10: (16, 6, 10), 16: (16, 5, 8), 20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}  # mpnn.py:140-163
 
@@ -84,10 +84,10 @@ class MPNN(LightningModule):
         self.criterion = {"l1": nn.L1Loss(), "l2": nn.MSELoss(), "smooth_l1": nn.SmoothL1Loss()}[self.loss]
         self.mse_criterion, self.mae_criterion = nn.MSELoss(), nn.L1Loss()
         self.kin = pad_to(tw + self.dpos + 1)
-        # message_net_2 on the bf16 matrix cores through the exact hi/mid/lo split (fp32-class accuracy, DESIGN.md
-        # 3.2) or on the fp32 MFMA path ("fp32"); optional hparam, not part of the reference's config
+        # arithmetic of the Linears: "fp16x3" / "bf16x6" = fp32 GEMMs on the fp16 / bf16 matrix cores through an exact
+        # split (fp32-class accuracy), "fp32" = fp32 MFMA; optional hparams, not in the reference's config
         self.edge_gemm = getattr(hparams, "edge_gemm", default_gemm())
-        assert self.edge_gemm in ("bf16x6", "fp32")
+        assert self.edge_gemm in GEMM_MODES
         self.gemm = getattr(hparams, "gemm", self.edge_gemm)     # node-level Linears (same two choices)
         self._pack_key, self._pack = None, None
         self._topo_key, self._topo = None, None
@@ -116,8 +116,7 @@ class MPNN(LightningModule):
             L = types.SimpleNamespace()
             L.pre_a = pack(wa, m1.bias, self.gemm, k_pad=H + kin)
             L.pre_b = pack(wb, None, self.gemm, k_pad=H + kin)
-            L.msg2 = pack_linear(m2.weight, m2.bias)
-            L.msg2_split = pack_linear_bf16x3(m2.weight, m2.bias)
+            L.msg2 = pack(m2.weight, m2.bias, self.edge_gemm)
             cmap = torch.cat([torch.arange(2 * H), torch.tensor([2 * H + tw + dp])])   # var column inside node_in
             L.upd1 = pack(u1.weight, u1.bias, self.gemm, k_pad=2 * H + kin, col_map=cmap)
             L.upd2 = pack(u2.weight, u2.bias, self.gemm)
@@ -154,10 +153,7 @@ class MPNN(LightningModule):
             pre_in = ops.ktiles(T(h, H), T(node_in, kin))
             ops.mlp(N, pre_in, [lyr.pre_a], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=A)
             ops.mlp(N, pre_in, [lyr.pre_b], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=Bm)
-            if self.edge_gemm == "bf16x6":
-                ops.mpnn_edge_bf16x6(A, Bm, csr, lyr.msg2_split[0], lyr.msg2_split[1], agg, partials)
-            else:
-                ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials)
+            ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials)
             ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
                     act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g)
             ops.instance_norm(g, B, Ns, out=h)

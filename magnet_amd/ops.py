@@ -84,11 +84,11 @@ def mlp(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STO
         a.res, a.ldres = res.data_ptr(), res.shape[-1]
     if epi == EPI_SEGMEAN:
         a.tgt, a.rowptr, a.partials = tgt.data_ptr(), rowptr.data_ptr(), partials.data_ptr()
-    split = layers[0][0].dtype == torch.int16                 # bf16x3 planes -> matrix-core kernel
-    assert all((w.dtype == torch.int16) == split for w, _ in layers)
-    fn = L.lib().magnet_mlp_bf16x6_f32 if split else L.lib().magnet_mlp_f32
-    L.check(fn(C.byref(a), nl, ht, ot, act, int(last_act), int(ln is not None), epi, _stream()),
-            f"magnet_mlp_{'bf16x6_' if split else ''}f32(nl={nl},ht={ht},ot={ot},act={act},ln={ln is not None},epi={epi})")
+    kind = layers[0][0].dtype                                 # float16: fp16x3, int16: bf16x6, float32: fp32 MFMA
+    assert all(w.dtype == kind for w, _ in layers)
+    name = {torch.float16: "magnet_mlp_fp16x3_f32", torch.int16: "magnet_mlp_bf16x6_f32", torch.float32: "magnet_mlp_f32"}[kind]
+    L.check(getattr(L.lib(), name)(C.byref(a), nl, ht, ot, act, int(last_act), int(ln is not None), epi, _stream()),
+            f"{name}(nl={nl},ht={ht},ot={ot},act={act},ln={ln is not None},epi={epi})")
     return y
 
 
@@ -114,19 +114,21 @@ def mpnn_node_input(u, pos, Lvec, tmax, tw, dpos, kin):
     return out
 
 
-def mpnn_edge_bf16x6(A, Bm, csr, w2_split, b2, agg, partials):
-    """fused MPNN edge kernel with message_net_2 on the bf16 matrix cores (exact 3-piece split)."""
-    L.check(L.lib().magnet_mpnn_edge_bf16x6_f32(_p(A), _p(Bm), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.E,
-                                                _p(w2_split), _p(b2), _p(agg), _p(partials), _stream()), "mpnn_edge_bf16x6")
-    segmean_fixup(csr.rowptr, csr.N, 128, partials, agg)
-    return agg
+EDGE_ENTRY = {torch.float16: "magnet_mpnn_edge_fp16x3_f32", torch.int16: "magnet_mpnn_edge_bf16x6_f32",
+              torch.float32: "magnet_mpnn_edge_f32"}
 
 
 def mpnn_edge(A, Bm, csr, w2, b2, agg, partials):
-    L.check(L.lib().magnet_mpnn_edge_f32(_p(A), _p(Bm), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.E, _p(w2), _p(b2),
-                                         _p(agg), _p(partials), _stream()), "mpnn_edge")
+    """fused MPNN edge kernel; the dtype of the packed message_net_2 weights selects the arithmetic
+    (float16 planes: fp16x3 split, int16 planes: bf16x6 split, float32 fragments: fp32 MFMA)."""
+    name = EDGE_ENTRY[w2.dtype]
+    L.check(getattr(L.lib(), name)(_p(A), _p(Bm), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.E, _p(w2), _p(b2),
+                                   _p(agg), _p(partials), _stream()), name)
     segmean_fixup(csr.rowptr, csr.N, 128, partials, agg)
     return agg
+
+
+mpnn_edge_bf16x6 = mpnn_edge     # kept for scripts: the weights' dtype decides
 
 
 def mpnn_readout(h, u, tw, w1, b1, k1, s1, w2, b2, k2, use_swish, dt):

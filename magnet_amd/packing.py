@@ -84,19 +84,56 @@ def pack_linear_bf16x3(w: torch.Tensor, b: torch.Tensor | None, k_pad: int | Non
     return out.view(-1), bp
 
 
-# ---- which arithmetic the Linears run on: "bf16x6" = exact 3-piece bf16 split on the matrix cores (default),
-# "fp32" = v_mfma_f32_32x32x2_f32.  ops.mlp picks the kernel from the dtype of the packed weights.
-GEMM_MODES = ("bf16x6", "fp32")
+def split_fp16x2(w: torch.Tensor):
+    """Two-piece fp16 split: w ~= h + l / 2048 with h = fp16(w), l = fp16((w - h) * 2048) (both round-to-nearest;
+    the remainder is exact in fp32 and the 2^11 scaling keeps it a normal fp16).  |w| must be < 65504."""
+    w = w.detach().float().contiguous()
+    if not bool(torch.isfinite(w).all()) or float(w.abs().max()) >= 65504.0:
+        raise ValueError("fp16x3 GEMM mode needs finite weights with |w| < 65504; use MAGNET_GEMM=bf16x6")
+    h = w.half()
+    lo = ((w - h.float()) * 2048.0).half()
+    return h, lo
+
+
+def pack_linear_fp16x2(w: torch.Tensor, b: torch.Tensor | None, k_pad: int | None = None, n_pad: int | None = None,
+                       col_map: torch.Tensor | None = None):
+    """fp16 planes in MFMA fragment order [kt][nt][m][2][lane][8] (float16) + padded fp32 bias (same slot map as
+    pack_linear_bf16x3)."""
+    n, k = w.shape
+    kp = k_pad or pad_to(k if col_map is None else int(col_map.max()) + 1)
+    np_ = n_pad or pad_to(n)
+    wp = torch.zeros(np_, kp, dtype=torch.float32, device=w.device)
+    if col_map is None:
+        wp[:n, :k] = w.detach().float()
+    else:
+        wp[:n, col_map.to(w.device)] = w.detach().float()
+    kt, nt = kp // 32, np_ // 32
+    planes = [pl.view(nt, 32, kt, 2, 2, 2, 4).permute(2, 0, 3, 5, 1, 4, 6).reshape(kt, nt, 2, 64, 8) for pl in split_fp16x2(wp)]
+    out = torch.stack(planes, dim=3).contiguous()           # [kt, nt, m, plane, lane, 8]
+    bp = torch.zeros(np_, dtype=torch.float32, device=w.device)
+    if b is not None:
+        bp[:n] = b.detach().float()
+    return out.view(-1), bp
+
+
+# ---- which arithmetic the Linears run on (ops picks the kernel from the dtype of the packed weights):
+#   "fp16x3" (default)  two fp16 pieces, 3 MFMA products, |values| < 65504   -> float16 planes
+#   "bf16x6"            three bf16 pieces, 6 MFMA products, full fp32 range    -> int16 planes
+#   "fp32"              v_mfma_f32_32x32x2_f32                                 -> float32 fragments
+GEMM_MODES = ("fp16x3", "bf16x6", "fp32")
 
 
 def default_gemm() -> str:
     import os
-    mode = os.environ.get("MAGNET_GEMM", "bf16x6")
+    mode = os.environ.get("MAGNET_GEMM", "fp16x3")
     assert mode in GEMM_MODES, mode
     return mode
 
 
 def pack(w, b, mode: str, k_pad=None, n_pad=None, col_map=None):
+    if mode == "fp16x3":
+        return pack_linear_fp16x2(w, b, k_pad=k_pad, n_pad=n_pad, col_map=col_map)
     if mode == "bf16x6":
         return pack_linear_bf16x3(w, b, k_pad=k_pad, n_pad=n_pad, col_map=col_map)
+    assert mode == "fp32", mode
     return pack_linear(w, b, k_pad=k_pad, n_pad=n_pad, col_map=col_map)

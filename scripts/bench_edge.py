@@ -31,10 +31,13 @@ def timeit(fn, reps=10):
     return s.elapsed_time(e) / reps
 
 ref = None
+from magnet_amd.packing import pack
+_m2 = m.gnn_layers[0].message_net_2[0]
+w32 = pack(_m2.weight, _m2.bias, "fp32")
 for v in variants:
     _lib.lib().magnet_debug_set_variant(0, v)
     agg.fill_(float("nan"))
-    ms = timeit(lambda: ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials))
+    ms = timeit(lambda: ops.mpnn_edge(A, Bm, csr, w32[0], w32[1], agg, partials))
     if ref is None:
         ref = agg.clone()
     err = float((agg - ref).norm() / ref.norm())
@@ -42,7 +45,7 @@ for v in variants:
 for v3 in (0, 1, 2, 4, 7, 0):
     _lib.lib().magnet_debug_set_variant(1, v3)
     agg.fill_(float("nan"))
-    ms = timeit(lambda: ops.mpnn_edge_bf16x6(A, Bm, csr, lyr.msg2_split[0], lyr.msg2_split[1], agg, partials))
+    ms = timeit(lambda: ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials))
     err = float((agg - ref).norm() / ref.norm())
     print(f"edge bf16x6 [{v3}]: {ms:.3f} ms  {2*E*H*H/ms/1e9:.1f} TFLOP/s-equivalent (incl fixup)  rel-diff vs first {err:.2e} nan={int(torch.isnan(agg).sum())}")
 _lib.lib().magnet_debug_set_variant(1, 0)

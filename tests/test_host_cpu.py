@@ -75,3 +75,15 @@ def test_split_bf16x3_is_exact():
     hi, mid, lo = split_bf16x3(x)
     back = sum((p.to(torch.int32) << 16).view(torch.float32).double() for p in (hi, mid, lo))
     assert torch.equal(back.float(), x)
+
+
+def test_split_fp16x2_reconstructs_to_fp32_class():
+    """h + l/2048 reproduces fp32 weights to ~2^-22 of max(|w|, fp16's smallest normal) - i.e. fp32-class for
+    everything a dot product can see - and refuses values outside the fp16 range instead of producing inf."""
+    from magnet_amd.packing import split_fp16x2
+    x = torch.randn(10000) * torch.logspace(-4, 3, 10000)
+    h, lo = split_fp16x2(x)
+    back = h.double() + lo.double() / 2048.0
+    assert float(((back - x.double()).abs() / x.double().abs().clamp_min(6.1e-5)).max()) < 2.5e-7
+    with pytest.raises(ValueError):
+        split_fp16x2(torch.tensor([1.0, 7e4]))

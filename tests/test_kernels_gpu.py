@@ -105,8 +105,9 @@ def test_instance_norm_matches_pyg_restatement():
     assert rel_l2(got, want) < 1e-6
 
 
+@pytest.mark.parametrize("mode", ["fp16x3", "bf16x6", "fp32"])
 @pytest.mark.parametrize("hidden,out,k_in,ln", [(128, 128, 45, True), (64, 32, 96, True), (128, 7, 128, False), (64, 64, 40, True)])
-def test_generic_mlp_matches_torch(hidden, out, k_in, ln):
+def test_generic_mlp_matches_torch(hidden, out, k_in, ln, mode):
     """5 Linears + ReLU (+LayerNorm) through magnet_mlp_f32 vs torch fp64 on the host."""
     from magnet_amd import ops
     from magnet_amd.models.backbones.mlp import MLP
@@ -122,7 +123,7 @@ def test_generic_mlp_matches_torch(hidden, out, k_in, ln):
     x = torch.zeros(M, kp)
     x[:, :k_in] = torch.randn(M, k_in)
     seq = torch.nn.Sequential(m, norm).cuda()
-    pk = pack_mlp_ln(seq, k_pad=kp) if ln else pack_mlp(seq[0], k_pad=kp)
+    pk = pack_mlp_ln(seq, k_pad=kp, mode=mode) if ln else pack_mlp(seq[0], k_pad=kp, mode=mode)
     y = torch.full((M, out), float("nan"), device="cuda")
     run_mlp(M, ops.ktiles(ops.Term(x.cuda(), kp)), pk, y)
     with torch.no_grad():
@@ -132,7 +133,8 @@ def test_generic_mlp_matches_torch(hidden, out, k_in, ln):
     assert rel_l2(y, ref) < 2e-6
 
 
-def test_mlp_gather_difference_and_segmean_epilogue():
+@pytest.mark.parametrize("mode", ["fp16x3", "bf16x6", "fp32"])
+def test_mlp_gather_difference_and_segmean_epilogue(mode):
     """the edge path: gathered / differenced sources -> MLP -> LayerNorm -> fused CSR mean == unfused."""
     from magnet_amd import ops
     from magnet_amd.models.backbones.mlp import MLP
@@ -146,7 +148,7 @@ def test_mlp_gather_difference_and_segmean_epilogue():
     x = torch.randn(n, D)
     e0 = torch.randn(E, D)
     seq = torch.nn.Sequential(MLP(3 * D, [64] * 4, D), torch.nn.LayerNorm(D)).cuda()
-    pk = pack_mlp_ln(seq)
+    pk = pack_mlp_ln(seq, mode=mode)
     xc, ec = x.cuda(), e0.cuda()
     kts = ops.ktiles(ops.Term(xc, D, idx=tgt.int().cuda()), ops.Term(xc, D, idx=src.int().cuda()), ops.Term(ec, D, scale=4.0))
     agg = torch.full((n, D), float("nan"), device="cuda")
@@ -164,7 +166,7 @@ def test_mpnn_edge_kernels_agree_on_ragged_graph():
     """fp32-MFMA and bf16-split edge kernels vs a host evaluation, on a graph with empty rows, rows longer
     than several tiles and an edge count that is not a multiple of 32."""
     from magnet_amd import ops
-    from magnet_amd.packing import pack_linear, pack_linear_bf16x3
+    from magnet_amd.packing import pack
     from oracle.pyg_semantics import scatter_mean
     torch.manual_seed(2)
     n, H = 301, 128
@@ -180,11 +182,10 @@ def test_mpnn_edge_kernels_agree_on_ragged_graph():
         m = sw(lin.double()(sw((A[tgt] + Bm[src]).double())))
     want = scatter_mean(m, tgt, n)
     lin = lin.float().cuda()
-    w32, b32 = pack_linear(lin.weight, lin.bias)
-    ws, bs = pack_linear_bf16x3(lin.weight, lin.bias)
-    for fn, w, b in ((ops.mpnn_edge, w32, b32), (ops.mpnn_edge_bf16x6, ws, bs)):
+    for mode in ("fp16x3", "bf16x6", "fp32"):
+        w, b = pack(lin.weight, lin.bias, mode)
         agg = torch.full((n, H), float("nan"), device="cuda")
         partials = torch.zeros(((E + 31) // 32) * 2 * H, device="cuda")
-        fn(A.cuda(), Bm.cuda(), csr, w, b, agg, partials)
+        ops.mpnn_edge(A.cuda(), Bm.cuda(), csr, w, b, agg, partials)
         assert not torch.isnan(agg).any()
-        assert rel_l2(agg, want) < 1e-6, fn.__name__
+        assert rel_l2(agg, want) < 1e-6, mode

@@ -10,7 +10,7 @@ OUT_TOL = 1e-5      # relative L2 on the forward output (BASELINE.json north_sta
 INC_TOL = 1e-4      # relative L2 on the increment out - u_last ("hard parts")
 
 
-def _models(tag, edge_gemm="bf16x6"):
+def _models(tag, edge_gemm="fp16x3"):
     from magnet_amd.models.factory import FACTORY
     from oracle import models as O
     from oracle.weightgen import fill_state_dict
@@ -24,7 +24,7 @@ def _models(tag, edge_gemm="bf16x6"):
     return name, hp, batch, d, oracle, model.cuda()
 
 
-@pytest.mark.parametrize("edge_gemm", ["bf16x6", "fp32"])
+@pytest.mark.parametrize("edge_gemm", ["fp16x3", "bf16x6", "fp32"])
 @pytest.mark.parametrize("tag", ["mpnn_1d", "mpnn_2d"])
 def test_forward_and_rollout_match(tag, edge_gemm):
     name, hp, batch, d, oracle, model = _models(tag, edge_gemm)
