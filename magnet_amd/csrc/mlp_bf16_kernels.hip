@@ -6,7 +6,7 @@
 //     (2.7x fewer matrix-pipe cycles, fp32-class accuracy);
 //   * the split weight planes do not come from L2 per tile: the 4 waves of a workgroup walk the layers in
 //     lockstep and the planes of one k tile (NT * 6 KiB) are DMA'd (global_load_lds, no VGPR round trip) into
-//     a double-buffered LDS chunk one k tile ahead - one __syncthreads per k tile;
+//     an LDS ring one or two k tiles ahead (counted s_waitcnt) - one __syncthreads per k tile;
 //   * activations are split per 8-k slot right before use, so the split's VALU work sits in MFMA shadows.
 // layer[l].w points at that layer's planes in fragment order [kt][nt][m][plane][64 lanes][8 bf16]
 // (packing.pack_linear_bf16x3), layer[l].b at the zero-padded fp32 bias.
@@ -15,11 +15,25 @@
 template <int A, int B>
 struct MaxI { static constexpr int v = A > B ? A : B; };
 
-// DMA one chunk (npieces x 1 KiB, contiguous in global memory) into LDS; piece p is handled by wave p % 4
-__device__ __forceinline__ void dma_chunk(const f32x4* __restrict__ gw, u32x4* l, int npieces, int wave, int lane) {
+// DMA one chunk (npieces x 1 KiB, contiguous in global memory) into LDS.  Every wave issues exactly
+// ceil(npieces / 4) loads (indices past the end repeat the last piece: same bytes to the same place), so that a
+// counted s_waitcnt can leave exactly one younger chunk in flight.
+template <int NPIECES>
+__device__ __forceinline__ void dma_chunk(const f32x4* __restrict__ gw, u32x4* l, int wave, int lane) {
     const u32x4* g = reinterpret_cast<const u32x4*>(gw);
-    for (int p = wave; p < npieces; p += 4)
+    constexpr int PW = (NPIECES + 3) / 4;
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        int p = wave + 4 * i;
+        p = p < NPIECES ? p : NPIECES - 1;
         __builtin_amdgcn_global_load_lds(g + p * 64 + lane, l + p * 64, 16, 0, 0);
+    }
+}
+// wait until at most the PW loads of the youngest chunk are outstanding
+template <int NPIECES>
+__device__ __forceinline__ void wait_all_but_one_chunk() {
+    constexpr int PW = (NPIECES + 3) / 4;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
 }
 
 // acc[nt] += W(chunk)[nt] * x   for one k tile whose planes sit in LDS at `wl` ([nt][m][plane][64])
@@ -52,11 +66,13 @@ template <int MODE, int NL, int HT, int OT, int ACT, bool LAST_ACT, bool LN, int
 __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const MagnetMlpArgs a) {
     constexpr int NTMAX = MaxI<HT, OT>::v;
     constexpr int PPN = 2 * Split<MODE>::NP;                              // 1 KiB pieces per output tile and k tile
+    constexpr int DIST = (NL >= 5 && HT >= 4) ? 2 : 1;                   // chunks requested ahead (measured: 2 pays only for the long 128-wide chains)
+    constexpr int NBUF = DIST + 1;
     constexpr int CH = NTMAX * PPN * 64;                                   // u32x4 per chunk buffer
     constexpr int SLAB = (EPI == EPI_SEGMEAN) ? 4 * SegSlab<OT>::FLOATS : 0;
-    __shared__ __attribute__((aligned(16))) u32x4 smem[2 * CH + (SLAB + 3) / 4];   // ONE LDS object (chunks + slab)
+    __shared__ __attribute__((aligned(16))) u32x4 smem[NBUF * CH + (SLAB + 3) / 4];   // ONE LDS object (chunk ring + slab)
     u32x4* wbuf = smem;
-    float* slab = reinterpret_cast<float*>(smem + 2 * CH);
+    float* slab = reinterpret_cast<float*>(smem + NBUF * CH);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
@@ -66,9 +82,16 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
     const int row = row_ok ? row_raw : (a.M - 1);
 
     constexpr int NT0 = (NL == 1) ? OT : HT;
-    int cbuf = 0;                                     // LDS buffer holding the chunk about to be consumed
-    // chunk protocol: the DMA of chunk c+1 is issued right after the barrier that precedes the compute of chunk c
-    dma_chunk(a.layer[0].w, wbuf, NT0 * PPN, wave, lane);
+    constexpr int NT1 = (NL == 2) ? OT : HT;            // output tiles of layer 1 (when it exists)
+    // Chunk c (one k tile of one layer) lives in ring slot c % NBUF and is requested DIST chunks ahead; iteration c:
+    //   wait (DIST 2: counted, chunk c+1 stays in flight) -> barrier (chunk c visible, slot of c-1 free) ->
+    //   request chunk c+DIST -> compute chunk c.
+    int c = 0;                                         // running chunk index (uniform)
+    dma_chunk<NT0 * PPN>(a.layer[0].w, wbuf, wave, lane);
+    if (DIST == 2) {
+        if (a.nkt > 1) dma_chunk<NT0 * PPN>(a.layer[0].w + (size_t)NT0 * PPN * 64, wbuf + CH, wave, lane);
+        else if (NL > 1) dma_chunk<NT1 * PPN>(a.layer[1].w, wbuf + CH, wave, lane);
+    }
 
     f32x16 out[OT];
     f32x16 h0[HT], h1[HT];
@@ -78,16 +101,19 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
         init_bias<NT0>(acc, a.layer[0].b, half);
         zero_tiles<NT0>(accc);
         f32x16 x = load_ktile(a.kt[0], row, half);
-        for (int kt = 0; kt < a.nkt; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int kt = 0; kt < a.nkt; ++kt, ++c) {
+            // outstanding, oldest first: chunk c, x tile kt, chunk c+1  ->  leave only chunk c+1 in flight
+            if (DIST == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (kt + 1 < a.nkt) wait_all_but_one_chunk<NT0 * PPN>();
+            else if (NL > 1) wait_all_but_one_chunk<NT1 * PPN>();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            // next chunk: layer 0's next k tile, or the first k tile of layer 1
-            if (kt + 1 < a.nkt) dma_chunk(a.layer[0].w + (size_t)(kt + 1) * NT0 * PPN * 64, wbuf + (cbuf ^ 1) * CH, NT0 * PPN, wave, lane);
-            else if (NL > 1) dma_chunk(a.layer[1].w, wbuf + (cbuf ^ 1) * CH, ((NL == 2) ? OT : HT) * PPN, wave, lane);
+            // x tile of kt+1 first, then chunk c+2: the next iteration's counted wait then covers the x tile
             const f32x16 xn = load_ktile(a.kt[kt + 1 < a.nkt ? kt + 1 : kt], row, half);
-            mma_chunk<NT0, MODE>(x, acc, accc, wbuf + cbuf * CH, lane);
+            if (kt + DIST < a.nkt) dma_chunk<NT0 * PPN>(a.layer[0].w + (size_t)(kt + DIST) * NT0 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+            else if (NL > 1 && kt + DIST - a.nkt < HT) dma_chunk<NT1 * PPN>(a.layer[1].w + (size_t)(kt + DIST - a.nkt) * NT1 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+            mma_chunk<NT0, MODE>(x, acc, accc, wbuf + (c % NBUF) * CH, lane);
             x = xn;
-            cbuf ^= 1;
         }
         fold_tiles<NT0, MODE>(acc, accc);
         if (NL == 1) {
@@ -102,6 +128,8 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
         }
     }
     // ---------------- layers 1 .. NL-1, activations in registers (fully unrolled: static register indices)
+    // here the only VMEM traffic is the weight DMA, so the waits are counted: chunks c+1 (already requested) stays
+    // in flight while chunk c is consumed.
 #pragma unroll
     for (int l = 1; l < NL; ++l) {
         const bool last = (l == NL - 1);
@@ -114,16 +142,29 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
         else if (src0) init_bias<HT>(h1, a.layer[l].b, half);
         else init_bias<HT>(h0, a.layer[l].b, half);
 #pragma unroll
-        for (int kt = 0; kt < HT; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int kt = 0; kt < HT; ++kt, ++c) {
+            // chunk c+1: next k tile of this layer, or the first k tile of the next layer, or nothing (very last chunk)
+            const bool has_next = (kt + 1 < HT) || (l + 1 < NL);
+            const bool next_is_last_layer = (kt + 1 < HT) ? last : (l + 1 == NL - 1);
+            if (!has_next || DIST == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (next_is_last_layer) wait_all_but_one_chunk<OT * PPN>();
+            else wait_all_but_one_chunk<HT * PPN>();
             __syncthreads();
-            const int nt_here = last ? OT : HT;
-            if (kt + 1 < HT) dma_chunk(a.layer[l].w + (size_t)(kt + 1) * nt_here * PPN * 64, wbuf + (cbuf ^ 1) * CH, nt_here * PPN, wave, lane);
-            else if (l + 1 < NL) dma_chunk(a.layer[l + 1].w, wbuf + (cbuf ^ 1) * CH, ((l + 1 == NL - 1) ? OT : HT) * PPN, wave, lane);
-            if (last) mma_chunk<OT, MODE>(src0 ? h0[kt] : h1[kt], out, cco, wbuf + cbuf * CH, lane);
-            else if (src0) mma_chunk<HT, MODE>(h0[kt], h1, cch, wbuf + cbuf * CH, lane);
-            else mma_chunk<HT, MODE>(h1[kt], h0, cch, wbuf + cbuf * CH, lane);
-            cbuf ^= 1;
+            // chunk c+2
+            {
+                const int k2 = kt + DIST;
+                if (k2 < HT) {
+                    if (last) dma_chunk<OT * PPN>(a.layer[l].w + (size_t)k2 * OT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+                    else dma_chunk<HT * PPN>(a.layer[l].w + (size_t)k2 * HT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+                } else if (l + 1 < NL) {
+                    const int k3 = k2 - HT;                               // 0 or 1: k tile of the next layer
+                    if (l + 1 == NL - 1) dma_chunk<OT * PPN>(a.layer[l + 1 < NL ? l + 1 : l].w + (size_t)k3 * OT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+                    else dma_chunk<HT * PPN>(a.layer[l + 1 < NL ? l + 1 : l].w + (size_t)k3 * HT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+                }
+            }
+            if (last) mma_chunk<OT, MODE>(src0 ? h0[kt] : h1[kt], out, cco, wbuf + (c % NBUF) * CH, lane);
+            else if (src0) mma_chunk<HT, MODE>(h0[kt], h1, cch, wbuf + (c % NBUF) * CH, lane);
+            else mma_chunk<HT, MODE>(h1[kt], h0, cch, wbuf + (c % NBUF) * CH, lane);
         }
         if (last) fold_tiles<OT, MODE>(out, cco);
         else if (src0) fold_tiles<HT, MODE>(h1, cch);
