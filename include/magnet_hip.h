@@ -166,6 +166,40 @@ int magnet_inr_grid_prepare_f32(const float* coords, const float* cell, const fl
 int magnet_inr_grid_blend_f32(const float* p, const float* area, int n_rows, int T, int C, int nshift, float* z,
                               void* stream);
 
+/* ---- backward pass of the MPNN training step (train_kernels.hip).  Replaces what torch autograd does for the
+ *      reference's training_step (models/mpnn.py:254-297 -> forward :175-203, GNN_Layer :65-90); the Linear
+ *      backward-data products reuse magnet_mlp_* with transposed packed weights. ---- */
+int magnet_swish_fwd_f32(const float* z, float* r, long n, void* stream);                       /* mpnn.py:15-24 */
+int magnet_swish_bwd_f32(const float* dr, const float* z, float* dz, long n, void* stream);
+int magnet_axpy_f32(const float* a, const float* b, float alpha, float* out, long n, void* stream);
+int magnet_mul_f32(const float* a, const float* b, float* out, long n, void* stream);
+int magnet_copy_cols_f32(const float* src, int ld_src, int scol, float* dst, int ld_dst, int dcol, int w, long rows,
+                         int accumulate, void* stream);
+/* p[e] = A[tgt[e]] + Bm[src[e]]: pre-activation of message_net_1 (mpnn.py:75-76), recomputed for the backward */
+int magnet_edge_pre_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt, long n_edges, float* p,
+                        void* stream);
+/* dm[e] = dagg[tgt[e]] / deg(tgt[e]): backward of aggr='mean' (mpnn.py:46) */
+int magnet_edge_mean_bwd_f32(const float* dagg, const int32_t* tgt, const int32_t* rowptr, long n_edges, float* dm,
+                             void* stream);
+/* out[r] = sum_{k in row r} x[perm ? perm[k] : k], 128 columns (scatter-add of edge gradients to nodes) */
+int magnet_segment_sum128_f32(const float* x, const int32_t* rowptr, const int32_t* perm, int n_rows, float* out,
+                              void* stream);
+/* dW[0:128, wcol:wcol+kc] (+)= dY[M,128]^T X[M, xcol:xcol+kc]; db[128] (+)= column sums of dY (db may be null);
+ * kc in {32,64,96,128}; workspace: nblk*(128*kc+128) + 128*kc floats, nblk = min(256, ceil(M/64)) */
+int magnet_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, int xcol, int kc, long M, float* dW, int ldw,
+                     int wcol, float* db, float* workspace, int accumulate, void* stream);
+int magnet_reduce_partials_f32(const float* partial, int nblk, long n, float scale, float* out, int accumulate,
+                               void* stream);
+/* backward of InstanceNorm (mpnn.py:63,70) from the kept output yhat and biased variance var [n_graphs][H];
+ * workspace: (2*n_graphs*ceil(rows/128) + 2*n_graphs)*H floats */
+int magnet_instance_norm_bwd_f32(const float* dy, const float* yhat, const float* var, int n_graphs, int rows_per_graph,
+                                 int H, float eps, float* dx, float* workspace, void* stream);
+/* backward of the Conv1d read-out + Euler update (mpnn.py:197-201): dh [n,128], du_last [n] (= d u[:, tw-1]),
+ * gpart [min(1024, ceil(n/4))][8*k1+8+8*k2+1] partial gradients laid out [dw1 | db1 | dw2 | db2] */
+int magnet_mpnn_readout_bwd_f32(const float* h, const float* dout, int n, int tw, const float* w1, const float* b1,
+                                int k1, int s1, const float* w2, int k2, int use_swish, const float* dt, float* dh,
+                                float* du_last, float* gpart, void* stream);
+
 /* development knob (kernel variant selection for A/B measurements); not part of the data path */
 int magnet_debug_set_variant(int which, int value);
 

@@ -1,0 +1,435 @@
+// Backward-pass building blocks for the MPNN training step (reference autograd through
+// models/mpnn.py:175-203 and the rollout of :254-297).  First generation: correct and deterministic, tensors at
+// edge granularity are materialised (the fused forward kernels stay in use for the forward half of the step).
+#include "common.cuh"
+
+__device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+// Elementwise kernels: thread i owns elements 4i..4i+3 (one float4 when whole, scalars at the tail).
+#define EW_BODY(EXPR_VEC_DECL, EXPR)                                                                  \
+    const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;                                \
+    if (i4 >= n) return;                                                                              \
+    const int cnt = (n - i4) < 4 ? (int)(n - i4) : 4;
+
+__device__ __forceinline__ f32x4 ld4(const float* p, long i4, int cnt) {
+    if (cnt == 4) return *reinterpret_cast<const f32x4*>(p + i4);
+    f32x4 v = {0, 0, 0, 0};
+    for (int c = 0; c < cnt; ++c) v[c] = p[i4 + c];
+    return v;
+}
+__device__ __forceinline__ void st4(float* p, long i4, int cnt, f32x4 v) {
+    if (cnt == 4) { *reinterpret_cast<f32x4*>(p + i4) = v; return; }
+    for (int c = 0; c < cnt; ++c) p[i4 + c] = v[c];
+}
+// r = z * sigmoid(z)
+__global__ void k_swish_fwd(const float* __restrict__ z, float* __restrict__ r, long n) {
+    EW_BODY(, )
+    const f32x4 v = ld4(z, i4, cnt);
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = act_swish(v[c]);
+    st4(r, i4, cnt, o);
+}
+// dz = dr * d/dz (z sigmoid(z)) = dr * s * (1 + z * (1 - s))
+__global__ void k_swish_bwd(const float* __restrict__ dr, const float* __restrict__ z, float* __restrict__ dz, long n) {
+    EW_BODY(, )
+    const f32x4 g = ld4(dr, i4, cnt), v = ld4(z, i4, cnt);
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float s = sigmoidf_fast(v[c]);
+        o[c] = g[c] * s * (1.0f + v[c] * (1.0f - s));
+    }
+    st4(dz, i4, cnt, o);
+}
+// out = a + alpha * b   (out may alias a)
+__global__ void k_axpy(const float* a, const float* b, float alpha, float* out, long n) {
+    EW_BODY(, )
+    const f32x4 x = ld4(a, i4, cnt), y = ld4(b, i4, cnt);
+    st4(out, i4, cnt, x + alpha * y);
+}
+__global__ void k_mul(const float* a, const float* b, float* out, long n) {
+    EW_BODY(, )
+    st4(out, i4, cnt, ld4(a, i4, cnt) * ld4(b, i4, cnt));
+}
+// dst[r, dcol : dcol+w] (+)= src[r, scol : scol+w]
+__global__ void k_copy_cols(const float* __restrict__ src, int lds_, int scol, float* __restrict__ dst, int ldd, int dcol,
+                            int w, long rows, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * w) return;
+    const long r = i / w;
+    const int c = (int)(i % w);
+    const float v = src[r * lds_ + scol + c];
+    float* d = dst + r * ldd + dcol + c;
+    *d = accumulate ? *d + v : v;
+}
+
+// p[e] = A[tgt[e]] + Bm[src[e]]                                  (recomputed pre-activation of message_net_1)
+__global__ void k_edge_pre(const float* __restrict__ A, const float* __restrict__ Bm, const int32_t* __restrict__ src,
+                           const int32_t* __restrict__ tgt, long E, float* __restrict__ p) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of one edge
+    if (i >= E * 32) return;
+    const long e = i >> 5;
+    const int c = (int)(i & 31) * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(A + (size_t)tgt[e] * 128 + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(Bm + (size_t)src[e] * 128 + c);
+    *reinterpret_cast<f32x4*>(p + e * 128 + c) = a + b;
+}
+// dm[e] = dagg[tgt[e]] / deg(tgt[e])                             (backward of the CSR mean)
+__global__ void k_edge_dm(const float* __restrict__ dagg, const int32_t* __restrict__ tgt, const int32_t* __restrict__ rowptr,
+                          long E, float* __restrict__ dm) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E * 32) return;
+    const long e = i >> 5;
+    const int c = (int)(i & 31) * 4;
+    const int t = tgt[e];
+    const float inv = 1.0f / (float)(rowptr[t + 1] - rowptr[t]);
+    *reinterpret_cast<f32x4*>(dm + e * 128 + c) = *reinterpret_cast<const f32x4*>(dagg + (size_t)t * 128 + c) * inv;
+}
+
+// out[r] = sum_{k in [rowptr[r], rowptr[r+1])} x[perm ? perm[k] : k]      (H = 128)
+__global__ void __launch_bounds__(256) k_segment_sum128(const float* __restrict__ x, const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ perm, int N, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const int s = rowptr[r], e = rowptr[r + 1];
+    const int sub = lane >> 5, col = (lane & 31) * 4;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int k = s + sub; k < e; k += 2) {
+        const long row = perm ? perm[k] : k;
+        acc += *reinterpret_cast<const f32x4*>(x + row * 128 + col);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], 32);
+    if (sub == 0) *reinterpret_cast<f32x4*>(out + (size_t)r * 128 + col) = acc;
+}
+
+// ---- weight gradient: partial[b][n][k] = sum over the row slabs of workgroup b of dY[m][n] * X[m][k]
+// (+ column sums of dY for the bias).  v_mfma_f32_32x32x2_f32 with BOTH operands read as rows from LDS:
+// A[i = n][kk = m] = dY[m][n0 + i], B[kk = m][j] = X[m][k0 + j] - consecutive lanes read consecutive floats.
+// N = 128 (4 waves <-> 4 n tiles), KC = columns of X handled (multiple of 32, <= 128).
+template <int KT>
+__global__ void __launch_bounds__(256) k_wgrad_partial(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
+                                                       int ldx, int xcol, long M, float* __restrict__ partial /* [grid][128][KT*32] */,
+                                                       float* __restrict__ bpartial /* [grid][128] or null */) {
+    constexpr int SLAB = 64, KC = KT * 32;
+    __shared__ __attribute__((aligned(16))) float sy[SLAB * 128];
+    __shared__ __attribute__((aligned(16))) float sx[SLAB * KC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    f32x16 acc[KT];
+    zero_tiles<KT>(acc);
+    float bsum = 0.f;
+    const long nslabs = (M + SLAB - 1) / SLAB;
+    for (long sl = blockIdx.x; sl < nslabs; sl += gridDim.x) {
+        const long m0 = sl * SLAB;
+        __syncthreads();
+        for (int t = threadIdx.x; t < SLAB * 32; t += 256) {            // dY slab, float4 per thread
+            const int r = t >> 5, c = (t & 31) * 4;
+            f32x4 v = {0, 0, 0, 0};
+            if (m0 + r < M) v = *reinterpret_cast<const f32x4*>(dY + (m0 + r) * ldy + c);
+            *reinterpret_cast<f32x4*>(sy + r * 128 + c) = v;
+        }
+        for (int t = threadIdx.x; t < SLAB * (KC / 4); t += 256) {
+            const int r = t / (KC / 4), c = (t % (KC / 4)) * 4;
+            f32x4 v = {0, 0, 0, 0};
+            if (m0 + r < M) v = *reinterpret_cast<const f32x4*>(X + (m0 + r) * ldx + xcol + c);
+            *reinterpret_cast<f32x4*>(sx + r * KC + c) = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s = 0; s < SLAB / 2; ++s) {
+            const int m = 2 * s + half;
+            const float a = sy[m * 128 + wave * 32 + i];
+            bsum += a;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) acc[kt] = mfma32(a, sx[m * KC + kt * 32 + i], acc[kt]);
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * 128 * KC;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // C/D row = A's i = n
+            out[(size_t)n * KC + kt * 32 + i] = acc[kt][r];                    // C/D col = B's j = k
+        }
+    if (bpartial) {
+        bsum += __shfl_xor(bsum, 32);
+        if (half == 0) bpartial[(size_t)blockIdx.x * 128 + wave * 32 + i] = bsum;
+    }
+}
+// out[g][j] (+)= scale * sum_b partial[g][b][j]   (fixed summation order: deterministic).  32 consecutive j per
+// workgroup (coalesced), 8 interleaved sub-sums per j combined through LDS.
+__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ partial, int nblk, long n, float scale,
+                                                         float* __restrict__ out, int accumulate) {
+    __shared__ float sm[8][32];
+    const int jj = threadIdx.x & 31, sub = threadIdx.x >> 5;
+    const long j = (long)blockIdx.x * 32 + jj;
+    const float* p = partial + (size_t)blockIdx.y * nblk * n;
+    float acc = 0.f;
+    if (j < n)
+        for (int b = sub; b < nblk; b += 8) acc += p[(size_t)b * n + j];
+    sm[sub][jj] = acc;
+    __syncthreads();
+    if (sub == 0 && j < n) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tot += sm[q][jj];
+        float* o = out + (size_t)blockIdx.y * n + j;
+        *o = accumulate ? *o + scale * tot : scale * tot;
+    }
+}
+
+// per-graph column sums of dy and of dy * yhat over chunks of STAT_CHUNK rows (H <= 1024)
+#define STAT_CHUNK 128
+__global__ void k_colstat2_partial(const float* __restrict__ dy, const float* __restrict__ yhat, int rows_per_graph, int H,
+                                   float* __restrict__ part1, float* __restrict__ part2) {
+    const int g = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int r0 = chunk * STAT_CHUNK, r1 = min(rows_per_graph, r0 + STAT_CHUNK);
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const size_t o = ((size_t)g * rows_per_graph + r) * H + c;
+            const float d = dy[o];
+            a1 += d;
+            a2 += d * yhat[o];
+        }
+        part1[((size_t)g * nchunks + chunk) * H + c] = a1;
+        part2[((size_t)g * nchunks + chunk) * H + c] = a2;
+    }
+}
+
+// ---- InstanceNorm backward (two statistics per graph and channel are computed by the caller with the column-sum
+// kernels): dx = (dy - m1 - yhat * m2) / sqrt(var + eps)
+__global__ void k_instnorm_bwd_apply(const float* __restrict__ dy, const float* __restrict__ yhat, const float* __restrict__ m1,
+                                     const float* __restrict__ m2, const float* __restrict__ var, int rows_per_graph, int H,
+                                     float eps, long total, float* __restrict__ dx) {
+    const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= total) return;
+    const int c = (int)(i4 % H);
+    const int g = (int)((i4 / H) / rows_per_graph);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dy + i4), y = *reinterpret_cast<const f32x4*>(yhat + i4);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(m1 + (size_t)g * H + c), b = *reinterpret_cast<const f32x4*>(m2 + (size_t)g * H + c);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(var + (size_t)g * H + c);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (d[k] - a[k] - y[k] * b[k]) / sqrtf(v[k] + eps);
+    *reinterpret_cast<f32x4*>(dx + i4) = o;
+}
+
+// ---- read-out backward: out[n,k] = u[n,tw-1] + dt (k+1) conv2(act(conv1(h[n])))[k]
+// one wave per node, workgroups stride over the nodes; weight / bias gradients are accumulated per wave in LDS and
+// written once per workgroup as partials [grid][GP], GP = [dw1 8*k1 | db1 8 | dw2 8*k2 | db2 1].
+__global__ void __launch_bounds__(256) k_mpnn_readout_bwd(const float* __restrict__ h, const float* __restrict__ dout, int N, int tw,
+                                                          const float* __restrict__ w1, const float* __restrict__ b1, int k1, int s1,
+                                                          const float* __restrict__ w2, int k2, int use_swish,
+                                                          const float* __restrict__ dt, float* __restrict__ dh,
+                                                          float* __restrict__ du_last, float* __restrict__ gpart) {
+    __shared__ float sh[4][128], sz[4][8 * 64], sdz[4][8 * 64], sd[4][64], sg[4][8 * 16 + 8 + 8 * 16 + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int L1 = (128 - k1) / s1 + 1;
+    const int GP = 8 * k1 + 8 + 8 * k2 + 1;
+    for (int q = lane; q < GP; q += 64) sg[wave][q] = 0.f;
+    // every array is private to its wave: wave-level ordering of LDS traffic is enough
+    for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
+        sh[wave][lane] = h[(size_t)n * 128 + lane];
+        sh[wave][lane + 64] = h[(size_t)n * 128 + lane + 64];
+        wave_lds_sync();
+        for (int o = lane; o < 8 * L1; o += 64) {                       // recompute conv1 pre-activations
+            const int c = o / L1, p = o % L1;
+            float acc = b1[c];
+            for (int k = 0; k < k1; ++k) acc += w1[c * k1 + k] * sh[wave][p * s1 + k];
+            sz[wave][o] = acc;
+        }
+        float dsum = 0.f;
+        if (lane < tw) {
+            const float d = dout[(size_t)n * tw + lane];
+            dsum = d;
+            sd[wave][lane] = d * dt[0] * (float)(lane + 1);             // d diff
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
+        if (lane == 0) du_last[n] = dsum;                               // d u[n, tw-1]
+        wave_lds_sync();
+        for (int o = lane; o < 8 * L1; o += 64) {                       // d act(z1)[c][p] = sum_k w2[c][k] ddiff[p - k]
+            const int c = o / L1, p = o % L1;
+            float g = 0.f;
+            for (int k = 0; k < k2; ++k) {
+                const int j = p - k;
+                if (j >= 0 && j < tw) g += w2[c * k2 + k] * sd[wave][j];
+            }
+            const float z = sz[wave][o];
+            float dz = g;
+            if (use_swish) {
+                const float s = sigmoidf_fast(z);
+                dz = g * s * (1.0f + z * (1.0f - s));
+            }
+            sdz[wave][o] = dz;
+        }
+        wave_lds_sync();
+        for (int x = lane; x < 128; x += 64) {                          // dh[x] = sum_{c,p,k: p*s1+k = x} w1[c][k] dz[c][p]
+            float g = 0.f;
+            for (int c = 0; c < 8; ++c)
+                for (int k = 0; k < k1; ++k) {
+                    const int pp = x - k;
+                    if (pp >= 0 && pp % s1 == 0 && pp / s1 < L1) g += w1[c * k1 + k] * sdz[wave][c * L1 + pp / s1];
+                }
+            dh[(size_t)n * 128 + x] = g;
+        }
+        for (int q = lane; q < 8 * k1; q += 64) {                       // dw1[c][k] += sum_p dz[c][p] h[p*s1+k]
+            const int c = q / k1, k = q % k1;
+            float g = 0.f;
+            for (int p = 0; p < L1; ++p) g += sdz[wave][c * L1 + p] * sh[wave][p * s1 + k];
+            sg[wave][q] += g;
+        }
+        if (lane < 8) {                                                 // db1[c]
+            float g = 0.f;
+            for (int p = 0; p < L1; ++p) g += sdz[wave][lane * L1 + p];
+            sg[wave][8 * k1 + lane] += g;
+        }
+        for (int q = lane; q < 8 * k2; q += 64) {                       // dw2[c][k] += sum_j ddiff[j] a[c][j+k]
+            const int c = q / k2, k = q % k2;
+            float g = 0.f;
+            for (int j = 0; j < tw; ++j) {
+                const float z = sz[wave][c * L1 + j + k];
+                g += sd[wave][j] * (use_swish ? act_swish(z) : z);
+            }
+            sg[wave][8 * k1 + 8 + q] += g;
+        }
+        if (lane == 0) {                                                // db2
+            float g = 0.f;
+            for (int j = 0; j < tw; ++j) g += sd[wave][j];
+            sg[wave][8 * k1 + 8 + 8 * k2] += g;
+        }
+        wave_lds_sync();
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < GP; q += 256)
+        gpart[(size_t)blockIdx.x * GP + q] = sg[0][q] + sg[1][q] + sg[2][q] + sg[3][q];
+}
+
+// ------------------------------------------------------------------------------------ C entry points
+#define S_ (hipStream_t) stream
+static inline unsigned nb(long n, int b) { return (unsigned)((n + b - 1) / b); }
+#define BEGIN() (void)hipGetLastError()
+#define END() return (int)hipGetLastError()
+
+extern "C" int magnet_swish_fwd_f32(const float* z, float* r, long n, void* stream) {
+    BEGIN();
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_swish_fwd, dim3(nb((n + 3) / 4, 256)), dim3(256), 0, S_, z, r, n);
+    END();
+}
+extern "C" int magnet_swish_bwd_f32(const float* dr, const float* z, float* dz, long n, void* stream) {
+    BEGIN();
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_swish_bwd, dim3(nb((n + 3) / 4, 256)), dim3(256), 0, S_, dr, z, dz, n);
+    END();
+}
+extern "C" int magnet_axpy_f32(const float* a, const float* b, float alpha, float* out, long n, void* stream) {
+    BEGIN();
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_axpy, dim3(nb((n + 3) / 4, 256)), dim3(256), 0, S_, a, b, alpha, out, n);
+    END();
+}
+extern "C" int magnet_mul_f32(const float* a, const float* b, float* out, long n, void* stream) {
+    BEGIN();
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_mul, dim3(nb((n + 3) / 4, 256)), dim3(256), 0, S_, a, b, out, n);
+    END();
+}
+extern "C" int magnet_copy_cols_f32(const float* src, int ld_src, int scol, float* dst, int ld_dst, int dcol, int w, long rows,
+                                    int accumulate, void* stream) {
+    BEGIN();
+    if (rows <= 0 || w <= 0) return 0;
+    hipLaunchKernelGGL(k_copy_cols, dim3(nb(rows * w, 256)), dim3(256), 0, S_, src, ld_src, scol, dst, ld_dst, dcol, w, rows,
+                       accumulate);
+    END();
+}
+extern "C" int magnet_edge_pre_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt, long n_edges,
+                                   float* p, void* stream) {
+    BEGIN();
+    if (n_edges <= 0) return 0;
+    hipLaunchKernelGGL(k_edge_pre, dim3(nb(n_edges * 32, 256)), dim3(256), 0, S_, A, Bm, src, tgt, n_edges, p);
+    END();
+}
+extern "C" int magnet_edge_mean_bwd_f32(const float* dagg, const int32_t* tgt, const int32_t* rowptr, long n_edges, float* dm,
+                                        void* stream) {
+    BEGIN();
+    if (n_edges <= 0) return 0;
+    hipLaunchKernelGGL(k_edge_dm, dim3(nb(n_edges * 32, 256)), dim3(256), 0, S_, dagg, tgt, rowptr, n_edges, dm);
+    END();
+}
+extern "C" int magnet_segment_sum128_f32(const float* x, const int32_t* rowptr, const int32_t* perm, int n_rows, float* out,
+                                         void* stream) {
+    BEGIN();
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(k_segment_sum128, dim3(nb(n_rows, 4)), dim3(256), 0, S_, x, rowptr, perm, n_rows, out);
+    END();
+}
+// dW[128][kc] (+)= dY^T X[:, xcol : xcol+kc], db[128] (+)= column sums of dY (db may be null).
+// workspace: nblk * (128 * kc + 128) floats, nblk = min(256, ceil(M / 64)).
+extern "C" int magnet_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, int xcol, int kc, long M, float* dW, int ldw,
+                                int wcol, float* db, float* workspace, int accumulate, void* stream) {
+    BEGIN();
+    if (M <= 0) return 0;
+    if (kc % 32 || kc < 32 || kc > 128) return -2;
+    const int nblk = (int)((M + 63) / 64 < 256 ? (M + 63) / 64 : 256);
+    float* part = workspace;
+    float* bpart = db ? workspace + (size_t)nblk * 128 * kc : nullptr;
+    switch (kc / 32) {
+        case 1: hipLaunchKernelGGL(k_wgrad_partial<1>, dim3(nblk), dim3(256), 0, S_, dY, ldy, X, ldx, xcol, M, part, bpart); break;
+        case 2: hipLaunchKernelGGL(k_wgrad_partial<2>, dim3(nblk), dim3(256), 0, S_, dY, ldy, X, ldx, xcol, M, part, bpart); break;
+        case 3: hipLaunchKernelGGL(k_wgrad_partial<3>, dim3(nblk), dim3(256), 0, S_, dY, ldy, X, ldx, xcol, M, part, bpart); break;
+        default: hipLaunchKernelGGL(k_wgrad_partial<4>, dim3(nblk), dim3(256), 0, S_, dY, ldy, X, ldx, xcol, M, part, bpart); break;
+    }
+    // reduce into a scratch tile then scatter into dW[:, wcol:wcol+kc] (ldw) - done column-block wise
+    float* tile = workspace + (size_t)nblk * (128 * kc + 128);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nb(128L * kc, 32)), dim3(256), 0, S_, part, nblk, 128L * kc, 1.0f, tile, 0);
+    hipLaunchKernelGGL(k_copy_cols, dim3(nb(128L * kc, 256)), dim3(256), 0, S_, tile, kc, 0, dW, ldw, wcol, kc, 128L, accumulate);
+    if (db) hipLaunchKernelGGL(k_reduce_partials, dim3(4), dim3(256), 0, S_, bpart, nblk, 128L, 1.0f, db, accumulate);
+    END();
+}
+extern "C" int magnet_reduce_partials_f32(const float* partial, int nblk, long n, float scale, float* out, int accumulate,
+                                          void* stream) {
+    BEGIN();
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nb(n, 32)), dim3(256), 0, S_, partial, nblk, n, scale, out, accumulate);
+    END();
+}
+// dx = InstanceNorm backward of dy given the normalised output yhat and the biased variance var [n_graphs][H]
+// (both kept by the forward).  workspace: (2 * n_graphs * ceil(rows / 128) + 2 * n_graphs) * H floats.
+extern "C" int magnet_instance_norm_bwd_f32(const float* dy, const float* yhat, const float* var, int n_graphs,
+                                            int rows_per_graph, int H, float eps, float* dx, float* workspace, void* stream) {
+    BEGIN();
+    const long total = (long)n_graphs * rows_per_graph * H;
+    if (total <= 0) return 0;
+    if (H % 4) return -2;
+    const int nchunks = (rows_per_graph + STAT_CHUNK - 1) / STAT_CHUNK;
+    float* p1 = workspace;
+    float* p2 = p1 + (size_t)n_graphs * nchunks * H;
+    float* m1 = p2 + (size_t)n_graphs * nchunks * H;
+    float* m2 = m1 + (size_t)n_graphs * H;
+    hipLaunchKernelGGL(k_colstat2_partial, dim3(nchunks, n_graphs), dim3(128), 0, S_, dy, yhat, rows_per_graph, H, p1, p2);
+    const float inv = 1.0f / (float)rows_per_graph;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nb(H, 32), n_graphs), dim3(256), 0, S_, p1, nchunks, (long)H, inv, m1, 0);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nb(H, 32), n_graphs), dim3(256), 0, S_, p2, nchunks, (long)H, inv, m2, 0);
+    hipLaunchKernelGGL(k_instnorm_bwd_apply, dim3(nb(total / 4, 256)), dim3(256), 0, S_, dy, yhat, m1, m2, var, rows_per_graph, H,
+                       eps, total, dx);
+    END();
+}
+// gpart: [min(1024, ceil(n/4))][8*k1 + 8 + 8*k2 + 1] partial parameter gradients (reduce with magnet_reduce_partials_f32)
+extern "C" int magnet_mpnn_readout_bwd_f32(const float* h, const float* dout, int n, int tw, const float* w1, const float* b1,
+                                           int k1, int s1, const float* w2, int k2, int use_swish, const float* dt, float* dh,
+                                           float* du_last, float* gpart, void* stream) {
+    BEGIN();
+    if (n <= 0) return 0;
+    const int L1 = (128 - k1) / s1 + 1;
+    if (L1 > 64 || tw > 64 || k1 > 16 || k2 > 16 || L1 - k2 + 1 != tw) return -2;
+    const unsigned grid = nb(n, 4) < 1024u ? nb(n, 4) : 1024u;
+    hipLaunchKernelGGL(k_mpnn_readout_bwd, dim3(grid), dim3(256), 0, S_, h, dout, n, tw, w1, b1, k1, s1, w2, k2, use_swish, dt,
+                       dh, du_last, gpart);
+    END();
+}

@@ -89,6 +89,10 @@ class MPNN(LightningModule):
         self.edge_gemm = getattr(hparams, "edge_gemm", default_gemm())
         assert self.edge_gemm in GEMM_MODES
         self.gemm = getattr(hparams, "gemm", self.edge_gemm)     # node-level Linears (same two choices)
+        # backward-data GEMMs: gradients of a mean loss are ~1e-7, inside fp16's subnormal range, so the fp16 split is
+        # not offered there ("bf16x6" keeps the fp32 exponent range; "fp32" = fp32 MFMA)
+        self.bwd_gemm = getattr(hparams, "bwd_gemm", "bf16x6")
+        assert self.bwd_gemm in ("bf16x6", "fp32")
         self._pack_key, self._pack = None, None
         self._topo_key, self._topo = None, None
         self.hip_graph = bool(getattr(hparams, "hip_graph", False))
@@ -131,6 +135,12 @@ class MPNN(LightningModule):
     # ------------------------------------------------------------------ forward (mpnn.py:175-203)
     @torch.no_grad()
     def forward(self, data, L, tmax, dt):
+        return self._forward(data, L, tmax, dt, None)
+
+    def _forward(self, data, L, tmax, dt, tape):
+        """``tape`` (training only): a namespace that receives what the backward needs - per layer the input h, the
+        per-node halves A / Bm, the aggregated messages, the InstanceNorm variance and output.  With a tape every
+        layer gets fresh buffers; without one they are reused."""
         u = ops._f32(data.x, "data.x")
         pos = ops._f32(data.pos, "data.pos")
         dev = u.device
@@ -149,14 +159,25 @@ class MPNN(LightningModule):
         partials = torch.empty(((csr.E + 31) // 32) * 2 * H, device=dev, dtype=torch.float32)
         T = ops.Term
         ops.mlp(N, ops.ktiles(T(node_in, kin)), P.emb, nl=2, ht=4, ot=4, act=ops.ACT_SWISH, last_act=True, y=h)
+        if tape is not None:
+            tape.topo, tape.node_in, tape.u, tape.dt, tape.layers = topo, node_in, u, dtv, []
         for lyr in P.layers:
+            if tape is not None:
+                A, Bm, agg = new(), new(), new()
             pre_in = ops.ktiles(T(h, H), T(node_in, kin))
             ops.mlp(N, pre_in, [lyr.pre_a], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=A)
             ops.mlp(N, pre_in, [lyr.pre_b], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=Bm)
             ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials)
             ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
                     act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g)
-            ops.instance_norm(g, B, Ns, out=h)
+            if tape is None:
+                ops.instance_norm(g, B, Ns, out=h)
+            else:
+                h_in = h
+                h, var = ops.instance_norm(g, B, Ns, out=new(), return_var=True)
+                tape.layers.append(types.SimpleNamespace(h_in=h_in, A=A, Bm=Bm, agg=agg, var=var, h_out=h))
+        if tape is not None:
+            tape.h = h
         k1, s1, k2 = _READOUT[tw]
         return ops.mpnn_readout(h, u, tw, P.conv[0], P.conv[1], k1, s1, P.conv[2], P.conv[3], k2, self.readout_swish, dtv)
 
@@ -259,8 +280,9 @@ class MPNN(LightningModule):
         t = batch["t"].float()
         return u, x, t
 
-    def rollout(self, batch, teacher_forcing=False):
-        """Free-running (or teacher-forced) rollout; mpnn.py:261-289 / :306-327.  Returns (u_hat, target)."""
+    def rollout(self, batch, teacher_forcing=False, tapes=None):
+        """Free-running (or teacher-forced) rollout; mpnn.py:261-289 / :306-327.  Returns (u_hat, target).
+        ``tapes`` (a list, training only) collects one tape per forward call for the backward pass."""
         u, x, t = self._unpack(batch)
         B, _, N = u.shape
         tw = self.time_window
@@ -269,8 +291,12 @@ class MPNN(LightningModule):
         target = u[:, tw:]
         u_hat = []
         for i in range(target.shape[1] // tw):
-            fwd = self._graphed_forward if self.hip_graph else self.forward
-            y = fwd(graph, x[0, -1], t[0, -1], dt)
+            if tapes is not None:
+                tapes.append(types.SimpleNamespace())
+                y = self._forward(graph, x[0, -1], t[0, -1], dt, tapes[-1])
+            else:
+                fwd = self._graphed_forward if self.hip_graph else self.forward
+                y = fwd(graph, x[0, -1], t[0, -1], dt)
             y_hat = y.reshape(B, N, -1).permute(0, 2, 1)
             u_hat.append(y_hat)
             nxt = u[:, (i + 1) * tw:(i + 2) * tw] if teacher_forcing else y_hat
@@ -278,14 +304,16 @@ class MPNN(LightningModule):
         return torch.cat(u_hat, dim=1), target
 
     def training_step(self, train_batch, batch_idx):
+        """mpnn.py:254-297.  With gradients enabled the returned loss carries a grad_fn whose backward runs the HIP
+        backward kernels (models/mpnn_backward.py) over the whole rollout and fills ``.grad`` of every parameter."""
         if torch.is_grad_enabled():
-            raise NotImplementedError(
-                "magnet_amd round 1 ships the forward / rollout kernels only; the backward kernels "
-                "(SURVEY.md 8(f) rank 2) are not built yet, so training_step cannot produce gradients")
-        u_hat, target = self.rollout(train_batch, self.teacher_forcing)
+            from .mpnn_backward import rollout_with_grad
+            u_hat, target = rollout_with_grad(self, train_batch, self.teacher_forcing)
+        else:
+            u_hat, target = self.rollout(train_batch, self.teacher_forcing)
         loss = self.criterion(u_hat, target)
         self.log("train_loss", loss, prog_bar=True)
-        self.log("train_mae_loss", self.mae_criterion(u_hat, target), prog_bar=True)
+        self.log("train_mae_loss", self.mae_criterion(u_hat.detach(), target), prog_bar=True)
         return loss
 
     def validation_step(self, val_batch, batch_idx):

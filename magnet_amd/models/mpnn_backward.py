@@ -1,0 +1,234 @@
+"""Backward pass of the MPNN rollout on MI355X.
+
+The reference trains by letting torch autograd differentiate ``training_step`` (models/mpnn.py:254-297): the loss
+of the concatenated rollout, back through every ``forward`` call (:175-203) and - when teacher forcing is off -
+through the predicted window that became the next graph's ``x``.  Here the same gradients are produced by explicit
+HIP kernels (csrc/train_kernels.hip + the MLP kernels with transposed weights):
+
+  forward of a training step   the inference kernels, unchanged, plus a *tape* of per-layer node tensors
+                               (h_in, A, Bm, agg, InstanceNorm variance / output)
+  backward of one forward call read-out -> [InstanceNorm -> update MLP -> mean -> message MLP -> node halves] x layers
+                               -> embedding; edge-granular tensors (p, Swish(p), q) are recomputed, not stored
+  across forward calls         d out_i = d loss / d out_i + d u_{i+1}  (free running), in the [B*N, tw] node layout
+
+Gradients are accumulated in the padded layouts the kernels use and mapped to the parameters' shapes at the end.
+``rollout_with_grad`` wraps all of it in one ``torch.autograd.Function`` so that ``loss.backward()`` - what Lightning
+calls on the value ``training_step`` returns - fills ``.grad`` exactly as it does for the reference.
+
+Arithmetic: backward-data GEMMs run in the ``bwd_gemm`` mode (default "bf16x6": exact 3-piece bf16 split, fp32
+exponent range - gradients of a mean loss are ~1e-7 and would fall into fp16's subnormals, so the 2-piece fp16
+split of the forward is not used here); weight gradients use fp32 MFMA with a fixed-order two-stage reduction
+(deterministic).
+"""
+from __future__ import annotations
+
+import types
+
+import torch
+
+from .. import ops
+from ..packing import pack
+from .mpnn import _READOUT
+
+
+def _packed_bwd(m):
+    """transposed / concatenated packs for the backward-data products (cached with the forward packs)."""
+    fwd = m._packed()
+    if getattr(m, "_pack_bwd_key", None) == m._pack_key:
+        return m._pack_bwd
+    H, tw, dp, kin = m.hidden_features, m.time_window, m.dpos, m.kin
+    mode = m.bwd_gemm
+    dev = next(m.parameters()).device
+    Q = types.SimpleNamespace(layers=[], mode=mode)
+    padk = lambda w: torch.cat([w, torch.zeros(w.shape[0], kin - w.shape[1], device=dev)], 1)  # noqa: E731
+    for lyr in m.gnn_layers:
+        W1 = lyr.message_net_1[0].weight.detach().float()
+        W2 = lyr.message_net_2[0].weight.detach().float()
+        W3 = lyr.update_net_1[0].weight.detach().float()
+        W4 = lyr.update_net_2[0].weight.detach().float()
+        tail = W1[:, 2 * H:]                                             # columns of (u_i - u_j, x_i - x_j, var)
+        wan = padk(tail)                                                 # d A / d node_in
+        wbn = padk(-tail[:, :tw + dp])                                   # d Bm / d node_in
+        q = types.SimpleNamespace()
+        # dh = [dz1 | dA | dBm] . [W3_h ; W1a ; W1b]
+        q.dh = pack(torch.cat([W3[:, :H].t(), W1[:, :H].t(), W1[:, H:2 * H].t()], 1), None, mode)
+        q.dnin = pack(torch.cat([wan.t(), wbn.t()], 1), None, mode)     # [kin, 2H]
+        q.dagg = pack(W3[:, H:2 * H].t(), None, mode)
+        q.w2t = pack(W2.t(), None, mode)
+        q.w4t = pack(W4.t(), None, mode)
+        Q.layers.append(q)
+    e0, e1 = m.embedding_mlp[0].weight.detach().float(), m.embedding_mlp[2].weight.detach().float()
+    Q.e1t = pack(e1.t(), None, mode)
+    Q.e0t = pack(padk(e0).t(), None, mode)                               # [kin, H]
+    m._pack_bwd, m._pack_bwd_key = Q, m._pack_key
+    return Q
+
+
+def _grad_buffers(m, dev):
+    H, kin = m.hidden_features, m.kin
+    z = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.float32)  # noqa: E731
+    k1, _, k2 = _READOUT[m.time_window]
+    G = types.SimpleNamespace(layers=[], e0=z(H, kin), be0=z(H), e1=z(H, H), be1=z(H), conv=z(8 * k1 + 8 + 8 * k2 + 1))
+    for _ in m.gnn_layers:
+        G.layers.append(types.SimpleNamespace(w1a=z(H, H + kin), w1b=z(H, H + kin), b1=z(H), w2=z(H, H), b2=z(H),
+                                              w3=z(H, 2 * H + kin), b3=z(H), w4=z(H, H), b4=z(H)))
+    return G
+
+
+def _source_csr(topo):
+    """edges grouped by *source* node (for the scatter of d Bm): rowptr + permutation into the by-target order."""
+    if getattr(topo, "by_source", None) is None:
+        c = topo.csr
+        topo.by_source = ops.csr_by_target(c.tgt, c.src, c.N)           # "targets" of the flipped graph = sources
+    return topo.by_source
+
+
+def backward_call(m, tape, dout, G, ws):
+    """Backward of one ``forward`` call.  dout [N, tw] -> d u [N, tw]; parameter gradients accumulate into G."""
+    P, Q = m._packed(), _packed_bwd(m)
+    H, kin, tw = m.hidden_features, m.kin, m.time_window
+    topo = tape.topo
+    csr, B, Ns = topo.csr, topo.n_graphs, topo.nodes_per_graph
+    bs = _source_csr(topo)
+    N, E, dev = csr.N, csr.E, dout.device
+    T = ops.Term
+    nin = tape.node_in
+    lin = lambda rows, kts, layer, y, o=4: ops.mlp(rows, kts, [layer], nl=1, ht=o, ot=o, act=ops.ACT_NONE, y=y)  # noqa: E731
+    new = lambda: torch.empty(N, H, device=dev, dtype=torch.float32)  # noqa: E731
+    enew = lambda: torch.empty(max(E, 1), H, device=dev, dtype=torch.float32)  # noqa: E731
+
+    k1, s1, k2 = _READOUT[tw]
+    dh, du_last, gp = ops.mpnn_readout_bwd(tape.h, dout, tw, P.conv[0], P.conv[1], k1, s1, P.conv[2], k2, m.readout_swish,
+                                           tape.dt)
+    ops.reduce_partials(gp, gp.shape[0], gp.shape[1], G.conv)
+    dnin = torch.zeros(N, kin, device=dev, dtype=torch.float32)
+    dnin_l = torch.empty_like(dnin)
+    z1, r1, z2, t1, t2, dagg, dA, dBm = (new() for _ in range(8))
+    p, sp, q, d1, d2 = (enew() for _ in range(5))
+    o_k = kin // 32
+
+    for li in reversed(range(len(P.layers))):
+        lyr, qb, tp, g = P.layers[li], Q.layers[li], tape.layers[li], G.layers[li]
+        dg = ops.instance_norm_bwd(dh, tp.h_out, tp.var, B, Ns)
+        # ---- update MLP (recomputed pre-activations)                                 mpnn.py:81-90
+        lin(N, ops.ktiles(T(tp.h_in, H), T(tp.agg, H), T(nin, kin)), lyr.upd1, z1)
+        ops.swish_fwd(z1, r1)
+        lin(N, ops.ktiles(T(r1, H)), lyr.upd2, z2)
+        dz2 = ops.swish_bwd(dg, z2, t1)
+        ops.wgrad(dz2, r1, 0, H, g.w4, 0, g.b4, ws)
+        lin(N, ops.ktiles(T(dz2, H)), qb.w4t, t2)
+        dz1 = ops.swish_bwd(t2, z1, t2)
+        ops.wgrad(dz1, tp.h_in, 0, H, g.w3, 0, g.b3, ws)
+        ops.wgrad(dz1, tp.agg, 0, H, g.w3, H, None, ws)
+        ops.wgrad(dz1, nin, 0, kin, g.w3, 2 * H, None, ws)
+        lin(N, ops.ktiles(T(dz1, H)), qb.dagg, dagg)
+        # ---- mean aggregation + message MLP at edge granularity                      mpnn.py:73-79, :46
+        if E > 0:
+            ops.edge_mean_bwd(dagg, csr, d1)
+            ops.edge_pre(tp.A, tp.Bm, csr, p)
+            ops.swish_fwd(p, sp)
+            lin(E, ops.ktiles(T(sp, H)), lyr.msg2, q)
+            dq = ops.swish_bwd(d1, q, d1)
+            ops.wgrad(dq, sp, 0, H, g.w2, 0, g.b2, ws, M=E)
+            lin(E, ops.ktiles(T(dq, H)), qb.w2t, d2)
+            dp = ops.swish_bwd(d2, p, d2)
+            ops.segment_sum128(dp, csr.rowptr, N, out=dA)
+            ops.segment_sum128(dp, bs.rowptr, N, perm=bs.perm, out=dBm)
+        else:
+            dA.zero_()
+            dBm.zero_()
+        # ---- per-node halves of message_net_1
+        ops.wgrad(dA, tp.h_in, 0, H, g.w1a, 0, g.b1, ws)
+        ops.wgrad(dA, nin, 0, kin, g.w1a, H, None, ws)
+        ops.wgrad(dBm, tp.h_in, 0, H, g.w1b, 0, None, ws)
+        ops.wgrad(dBm, nin, 0, kin, g.w1b, H, None, ws)
+        lin(N, ops.ktiles(T(dz1, H), T(dA, H), T(dBm, H)), qb.dh, t1)
+        dh = ops.axpy(dg, t1, 1.0, out=dg)
+        lin(N, ops.ktiles(T(dA, H), T(dBm, H)), qb.dnin, dnin_l, o_k)
+        ops.axpy(dnin, dnin_l, 1.0, out=dnin)
+
+    # ---- embedding MLP                                                                mpnn.py:131-136
+    lin(N, ops.ktiles(T(nin, kin)), P.emb[0], z1)
+    ops.swish_fwd(z1, r1)
+    lin(N, ops.ktiles(T(r1, H)), P.emb[1], z2)
+    dz2 = ops.swish_bwd(dh, z2, t1)
+    ops.wgrad(dz2, r1, 0, H, G.e1, 0, G.be1, ws)
+    lin(N, ops.ktiles(T(dz2, H)), Q.e1t, t2)
+    dz1 = ops.swish_bwd(t2, z1, t2)
+    ops.wgrad(dz1, nin, 0, kin, G.e0, 0, G.be0, ws)
+    lin(N, ops.ktiles(T(dz1, H)), Q.e0t, dnin_l, o_k)
+    ops.axpy(dnin, dnin_l, 1.0, out=dnin)
+
+    du = torch.empty(N, tw, device=dev, dtype=torch.float32)
+    ops.copy_cols(dnin, 0, du, 0, tw)
+    ops.copy_cols(du_last[:, None], 0, du, tw - 1, 1, accumulate=True)
+    return du
+
+
+def parameter_grads(m, G):
+    """kernel-layout gradient buffers -> one tensor per parameter, in ``m.parameters()`` order."""
+    H, tw, dp = m.hidden_features, m.time_window, m.dpos
+    nin = tw + dp + 1
+    k1, _, k2 = _READOUT[tw]
+    by_name = {}
+    for i, g in enumerate(G.layers):
+        tail = g.w1a[:, H:H + nin].clone()
+        tail[:, :tw + dp] -= g.w1b[:, H:H + tw + dp]
+        pre = f"gnn_layers.{i}."
+        by_name[pre + "message_net_1.0.weight"] = torch.cat([g.w1a[:, :H], g.w1b[:, :H], tail], 1)
+        by_name[pre + "message_net_1.0.bias"] = g.b1
+        by_name[pre + "message_net_2.0.weight"], by_name[pre + "message_net_2.0.bias"] = g.w2, g.b2
+        by_name[pre + "update_net_1.0.weight"] = torch.cat([g.w3[:, :2 * H], g.w3[:, 2 * H + tw + dp:2 * H + nin]], 1)
+        by_name[pre + "update_net_1.0.bias"] = g.b3
+        by_name[pre + "update_net_2.0.weight"], by_name[pre + "update_net_2.0.bias"] = g.w4, g.b4
+    by_name["embedding_mlp.0.weight"], by_name["embedding_mlp.0.bias"] = G.e0[:, :nin], G.be0
+    by_name["embedding_mlp.2.weight"], by_name["embedding_mlp.2.bias"] = G.e1, G.be1
+    c = G.conv
+    last = len(m.output_mlp) - 1
+    by_name["output_mlp.0.weight"] = c[:8 * k1].view(8, 1, k1)
+    by_name["output_mlp.0.bias"] = c[8 * k1:8 * k1 + 8]
+    by_name[f"output_mlp.{last}.weight"] = c[8 * k1 + 8:8 * k1 + 8 + 8 * k2].view(1, 8, k2)
+    by_name[f"output_mlp.{last}.bias"] = c[8 * k1 + 8 + 8 * k2:]
+    return [by_name[n].contiguous() for n, _ in m.named_parameters()]
+
+
+class _Rollout(torch.autograd.Function):
+    """u_hat = rollout(batch); backward = the HIP backward over every forward call of the rollout."""
+
+    @staticmethod
+    def forward(ctx, m, batch, teacher_forcing, *params):
+        tapes = []
+        with torch.no_grad():
+            u_hat, target = m.rollout(batch, teacher_forcing, tapes=tapes)
+        ctx.m, ctx.tapes, ctx.tf = m, tapes, teacher_forcing
+        m._last_target = target
+        return u_hat.contiguous()
+
+    @staticmethod
+    def backward(ctx, d_u_hat):
+        m, tapes = ctx.m, ctx.tapes
+        tw = m.time_window
+        B, _, Ns = d_u_hat.shape
+        dev = d_u_hat.device
+        with torch.no_grad():
+            G = _grad_buffers(m, dev)
+            E = tapes[0].topo.csr.E
+            ws = ops.wgrad_workspace(max(B * Ns, E), dev)
+            carry = None
+            for i in reversed(range(len(tapes))):
+                # d loss / d out_i in the node layout [B*N, tw] (out_i -> y_hat = reshape(B, N, tw).permute(0, 2, 1))
+                dout = d_u_hat[:, i * tw:(i + 1) * tw].permute(0, 2, 1).reshape(B * Ns, tw).float().contiguous()
+                if carry is not None:
+                    ops.axpy(dout, carry, 1.0, out=dout)
+                du = backward_call(m, tapes[i], dout, G, ws)
+                carry = None if ctx.tf else du
+            grads = parameter_grads(m, G)
+        ctx.tapes = None
+        return (None, None, None, *grads)
+
+
+def rollout_with_grad(m, batch, teacher_forcing=False):
+    """-> (u_hat with a grad_fn, target)"""
+    u_hat = _Rollout.apply(m, batch, teacher_forcing, *m.parameters())
+    target, m._last_target = m._last_target, None
+    return u_hat, target

@@ -139,7 +139,7 @@ def mpnn_readout(h, u, tw, w1, b1, k1, s1, w2, b2, k2, use_swish, dt):
     return out
 
 
-def instance_norm(x, n_graphs, rows_per_graph, eps=1e-5, out=None):
+def instance_norm(x, n_graphs, rows_per_graph, eps=1e-5, out=None, return_var=False):
     x = _f32(x, "x")
     h = x.shape[1]
     nchunks = (rows_per_graph + 63) // 64
@@ -147,7 +147,98 @@ def instance_norm(x, n_graphs, rows_per_graph, eps=1e-5, out=None):
     out = torch.empty_like(x) if out is None else out
     L.check(L.lib().magnet_instance_norm_f32(_p(x), n_graphs, rows_per_graph, h, C.c_float(float(eps)), _p(out), _p(ws),
                                              _stream()), "instance_norm")
+    if return_var:                                            # biased variance [n_graphs, h] (kept for the backward)
+        o = (n_graphs * nchunks + n_graphs) * h
+        return out, ws[o:o + n_graphs * h].view(n_graphs, h)
     return out
+
+
+# ------------------------------------------------------------------------------------ backward building blocks
+def swish_fwd(z, out=None):
+    out = torch.empty_like(z) if out is None else out
+    L.check(L.lib().magnet_swish_fwd_f32(_p(z), _p(out), C.c_long(z.numel()), _stream()), "swish_fwd")
+    return out
+
+
+def swish_bwd(dr, z, out=None):
+    out = torch.empty_like(z) if out is None else out
+    L.check(L.lib().magnet_swish_bwd_f32(_p(dr), _p(z), _p(out), C.c_long(z.numel()), _stream()), "swish_bwd")
+    return out
+
+
+def axpy(a, b, alpha=1.0, out=None):
+    """out = a + alpha * b (out may be a)"""
+    out = torch.empty_like(a) if out is None else out
+    assert a.numel() == b.numel()
+    L.check(L.lib().magnet_axpy_f32(_p(a), _p(b), C.c_float(alpha), _p(out), C.c_long(a.numel()), _stream()), "axpy")
+    return out
+
+
+def copy_cols(src, scol, dst, dcol, w, accumulate=False):
+    rows = src.shape[0]
+    L.check(L.lib().magnet_copy_cols_f32(_p(src), src.stride(0), scol, _p(dst), dst.stride(0), dcol, w, C.c_long(rows),
+                                         int(accumulate), _stream()), "copy_cols")
+    return dst
+
+
+def edge_pre(A, Bm, csr, out=None):
+    out = torch.empty(max(csr.E, 1), 128, device=A.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().magnet_edge_pre_f32(_p(A), _p(Bm), _p(csr.src), _p(csr.tgt), C.c_long(csr.E), _p(out), _stream()),
+            "edge_pre")
+    return out
+
+
+def edge_mean_bwd(dagg, csr, out=None):
+    out = torch.empty(max(csr.E, 1), 128, device=dagg.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().magnet_edge_mean_bwd_f32(_p(dagg), _p(csr.tgt), _p(csr.rowptr), C.c_long(csr.E), _p(out), _stream()),
+            "edge_mean_bwd")
+    return out
+
+
+def segment_sum128(x, rowptr, n_rows, perm=None, out=None):
+    out = torch.empty(n_rows, 128, device=x.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().magnet_segment_sum128_f32(_p(x), _p(rowptr), _p(perm), n_rows, _p(out), _stream()), "segment_sum128")
+    return out
+
+
+def wgrad_workspace(M, device):
+    nblk = min(256, (M + 63) // 64)
+    return torch.empty(nblk * (128 * 128 + 128) + 128 * 128, device=device, dtype=torch.float32)
+
+
+def wgrad(dY, X, xcol, kc, dW, wcol, db, ws, accumulate=True, M=None):
+    """dW[:, wcol:wcol+kc] (+)= dY^T X[:, xcol:xcol+kc]; db (+)= colsum(dY) (db may be None)."""
+    M = dY.shape[0] if M is None else M
+    assert dY.shape[1] == 128 and dW.shape[0] == 128 and dY.is_contiguous()
+    L.check(L.lib().magnet_wgrad_f32(_p(dY), dY.stride(0), _p(X), X.stride(0), xcol, kc, C.c_long(M), _p(dW), dW.stride(0),
+                                     wcol, _p(db), _p(ws), int(accumulate), _stream()), "wgrad")
+
+
+def reduce_partials(partial, nblk, n, out, scale=1.0, accumulate=True):
+    L.check(L.lib().magnet_reduce_partials_f32(_p(partial), nblk, C.c_long(n), C.c_float(scale), _p(out), int(accumulate),
+                                               _stream()), "reduce_partials")
+
+
+def instance_norm_bwd(dy, yhat, var, n_graphs, rows_per_graph, eps=1e-5, out=None):
+    h = dy.shape[1]
+    nchunks = (rows_per_graph + 127) // 128
+    ws = torch.empty((2 * n_graphs * nchunks + 2 * n_graphs) * h, device=dy.device, dtype=torch.float32)
+    out = torch.empty_like(dy) if out is None else out
+    L.check(L.lib().magnet_instance_norm_bwd_f32(_p(dy), _p(yhat), _p(var), n_graphs, rows_per_graph, h,
+                                                 C.c_float(float(eps)), _p(out), _p(ws), _stream()), "instance_norm_bwd")
+    return out
+
+
+def mpnn_readout_bwd(h, dout, tw, w1, b1, k1, s1, w2, k2, use_swish, dt):
+    """-> (dh [n,128], du_last [n], gpart [min(1024, ceil(n/4)), 8*k1+8+8*k2+1])"""
+    n = h.shape[0]
+    dh = torch.empty(n, 128, device=h.device, dtype=torch.float32)
+    du = torch.empty(n, device=h.device, dtype=torch.float32)
+    gp = torch.empty(min(1024, (n + 3) // 4), 8 * k1 + 8 + 8 * k2 + 1, device=h.device, dtype=torch.float32)
+    L.check(L.lib().magnet_mpnn_readout_bwd_f32(_p(h), _p(_f32(dout)), n, tw, _p(w1), _p(b1), k1, s1, _p(w2), k2,
+                                                int(use_swish), _p(_f32(dt)), _p(dh), _p(du), _p(gp), _stream()),
+            "mpnn_readout_bwd")
+    return dh, du, gp
 
 
 # ------------------------------------------------------------------------------------ graphs
