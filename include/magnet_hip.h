@@ -200,6 +200,15 @@ int magnet_mpnn_readout_bwd_f32(const float* h, const float* dout, int n, int tw
                                 int k1, int s1, const float* w2, int k2, int use_swish, const float* dt, float* dh,
                                 float* du_last, float* gpart, void* stream);
 
+/* Fused backward of the edge block (adjoint of magnet_mpnn_edge_*: mpnn.py:73-79,46 under autograd).  Recomputes
+ * p = A[i]+Bm[j], s1 = Swish(p), q = W2 s1 + b2; dq = dagg[i]/deg(i) * Swish'(q); dp = (W2^T dq) * Swish'(p);
+ * dA[i] = sum_e dp (all n_nodes rows written).  s1, dq, dp [n_edges][128] are written for the follow-up kernels
+ * (dW2 = dq^T s1 via magnet_wgrad_f32; dBm = by-source segment sum of dp).  w2_f16 / w2t_f16: fp16x2 planes of W2
+ * and W2^T (packing.py:pack_linear_fp16x2); partials: ceil(n_edges/32)*2*128 floats. */
+int magnet_mpnn_edge_bwd_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src, const int32_t* tgt,
+                             const int32_t* rowptr, int n_nodes, int n_edges, const void* w2_f16, const void* w2t_f16,
+                             const float* b2, float* s1, float* dq, float* dp, float* dA, float* partials, void* stream);
+
 /* development knob (kernel variant selection for A/B measurements); not part of the data path */
 int magnet_debug_set_variant(int which, int value);
 

@@ -1,0 +1,229 @@
+// Fused backward of the MPNN edge block (message_net_1 pre-activation -> Swish -> message_net_2 -> Swish -> mean),
+// the adjoint of mpnn_edge_bf16.hip.  Reference: torch autograd through GNN_Layer.message / aggr='mean',
+// models/mpnn.py:73-79,46.
+//
+// Per 32-edge tile (one wave, edges sorted by target i, source j), everything in registers in the transposed
+// "lane = edge, registers = features" layout of the forward kernel:
+//     p   = A[i] + Bm[j]                      s1 = Swish(p)                 (recomputed, gathers)
+//     q   = W2 s1 + b2                        GEMM 1  (fp16x3 split, as the forward)
+//     dq  = dagg[i] / deg(i) * Swish'(q)
+//     ds1 = W2^T dq                           GEMM 2  (fp16x3 split of dq scaled PER EDGE by a power of two:
+//                                             gradients of a mean loss are ~1e-7, below fp16's normal range;
+//                                             a row scale is exact for a linear map and is undone afterwards)
+//     dp  = ds1 * Swish'(p)
+//     dA[i] = sum_e dp                        segmented DPP scan over the target-sorted lanes (+ tile-boundary partials)
+// Written to HBM for the follow-up kernels: s1 and dq (weight gradient dW2 = dq^T s1, db2), dp (scatter to the
+// *source* nodes for dBm through the by-source CSR permutation).
+// Both weight packings (W2 and W2^T, 64 KiB of fp16 planes each) stay resident in LDS; one wave per SIMD.
+#include "common.cuh"
+#include "edge_tile.cuh"
+
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float dswish(float x) {
+    const float s = sigmoid_fast(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+
+// segmented inclusive sum of one register across the 32 edge lanes
+__device__ __forceinline__ float scan_sum(float x, const TileMeta& md) {
+    x += md.m1 * dpp_f<DPP_SHR1, 0xF>(x);
+    x += md.m2 * dpp_f<DPP_SHR2, 0xF>(x);
+    x += md.m4 * dpp_f<DPP_SHR4, 0xF>(x);
+    x += md.m8 * dpp_f<DPP_SHR8, 0xF>(x);
+    x += md.mb * dpp_f<DPP_BCAST15, 0xA>(x);
+    return x;
+}
+
+// the last lane of every run of equal targets holds the run's sum: a finished row of dA or a tile-boundary partial
+__device__ __forceinline__ void store_run_sums(const f32x16 (&v)[4], const TileMeta& md, const int32_t* __restrict__ rowptr,
+                                               float* __restrict__ dA, float* __restrict__ partials, int half) {
+    if (md.e_ok && md.tnext != md.ti) {
+        const int e0 = md.tile * 32;
+        const int s = rowptr[md.ti], en = rowptr[md.ti + 1];
+        const bool complete = (s >= e0) && (en <= e0 + 32);
+        float* dst = complete ? dA + (size_t)md.ti * 128 : partials + ((size_t)md.tile * 2 + (s < e0 ? 0 : 1)) * 128;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 o = {v[nt][4 * g], v[nt][4 * g + 1], v[nt][4 * g + 2], v[nt][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(dst + nt * 32 + 8 * g + 4 * half) = o;
+            }
+    }
+}
+
+// acc[nt] (+ cross accumulators) += W(planes in LDS) * x, x = the wave's [128 x 32] register tile
+template <int MODE>
+__device__ __forceinline__ void gemm128(const u32x4* __restrict__ wl, const f32x16 (&x)[4], f32x16 (&acc)[4], f32x16 (&accc)[4],
+                                        int lane) {
+    constexpr int NP = Split<MODE>::NP;
+    u32x4 xs[2][NP], wr[2][NP];
+    split_slot<MODE>(x[0], 0, xs[0]);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) wr[0][q] = wl[64 * q + lane];
+#pragma unroll
+    for (int gq = 0; gq < 32; ++gq) {             // gq = slot * 4 + nt, slot = kt * 2 + m
+        const int slot = gq >> 2, nt = gq & 3;
+        if (gq + 1 < 32) {
+            const int s1 = (gq + 1) >> 2, n1 = (gq + 1) & 3;
+            const u32x4* wp = wl + ((((s1 >> 1) * 4 + n1) * 2 + (s1 & 1)) * NP) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) wr[(gq + 1) & 1][q] = wp[64 * q];
+        }
+        if (slot + 1 < 8) Split<MODE>::quarter(x[(slot + 1) >> 1], (slot + 1) & 1, nt, xs[(slot + 1) & 1]);
+        Split<MODE>::mma(wr[gq & 1], xs[slot & 1], acc[nt], accc[nt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) Split<MODE>::fold(acc[nt], accc[nt]);
+}
+
+__device__ __forceinline__ void store_tile(float* __restrict__ dst_row /* row e, + 4*half */, const f32x16 (&v)[4]) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 o = {v[nt][4 * g], v[nt][4 * g + 1], v[nt][4 * g + 2], v[nt][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(dst_row + nt * 32 + 8 * g) = o;
+        }
+}
+
+__global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                          const float* __restrict__ dagg, const int32_t* __restrict__ src,
+                                                          const int32_t* __restrict__ tgt, const int32_t* __restrict__ rowptr,
+                                                          int E, const u32x4* __restrict__ w2s, const u32x4* __restrict__ w2ts,
+                                                          const float* __restrict__ b2, float* __restrict__ s1_out,
+                                                          float* __restrict__ dq_out, float* __restrict__ dp_out,
+                                                          float* __restrict__ dA, float* __restrict__ partials) {
+    constexpr int MODE = GEMM_FP16X3;
+    constexpr int NP = Split<MODE>::NP;
+    __shared__ __attribute__((aligned(16))) u32x4 wl[32 * NP * 64];          // W2   planes, 64 KiB
+    __shared__ __attribute__((aligned(16))) u32x4 wt[32 * NP * 64];          // W2^T planes, 64 KiB
+    for (int i = threadIdx.x; i < 32 * NP * 64; i += 256) {
+        wl[i] = w2s[i];
+        wt[i] = w2ts[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    const int ntiles = (E + 31) / 32;
+    const int stride = gridDim.x * 4;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += stride) {
+        const TileMeta md = tile_meta(tile, E, tgt, j);
+        const int e = min(tile * 32 + j, E - 1);
+        const int ti = md.ti, sj = src[e];
+        const float inv_deg = 1.0f / (float)(rowptr[ti + 1] - rowptr[ti]);
+        const size_t row = (size_t)e * 128 + 4 * half;
+        f32x16 p[4], x[4], acc[4], accc[4];
+        {   // p = A[i] + Bm[j],  x = s1 = Swish(p)
+            const float* pa = A + (size_t)ti * 128 + 4 * half;
+            const float* pb = Bm + (size_t)sj * 128 + 4 * half;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(pa + kt * 32 + 8 * g);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(pb + kt * 32 + 8 * g);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        p[kt][4 * g + c] = a[c] + b[c];
+                        x[kt][4 * g + c] = act_swish(a[c] + b[c]);
+                    }
+                }
+        }
+        if (md.e_ok) store_tile(s1_out + row, x);
+        // ---- GEMM 1: q = W2 s1 + b2
+        init_bias<4>(acc, b2, half);
+        zero_tiles<4>(accc);
+        gemm128<MODE>(wl, x, acc, accc, lane);
+        // ---- dq = dagg[i] / deg * Swish'(q)   (into x), per-edge power-of-two scale for the fp16 split
+        float mx = 0.f;
+        {
+            const float* pd = dagg + (size_t)ti * 128 + 4 * half;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 d = *reinterpret_cast<const f32x4*>(pd + nt * 32 + 8 * g);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float v = d[c] * inv_deg * dswish(acc[nt][4 * g + c]);
+                        x[nt][4 * g + c] = v;
+                        mx = fmaxf(mx, fabsf(v));
+                    }
+                }
+        }
+        if (md.e_ok) store_tile(dq_out + row, x);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const unsigned eb = (__float_as_uint(mx) >> 23) & 0xFFu;              // max in [2^(eb-127), 2^(eb-126))
+        const float sc = __uint_as_float((254u - eb) << 23);                   // 2^(127-eb): scaled max in [1, 2)
+        const float usc = __uint_as_float(eb << 23);                           // 2^(eb-127)  (0 for an all-zero row)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[nt][i] *= sc;
+        // ---- GEMM 2: ds1 = W2^T dq
+        zero_tiles<4>(acc);
+        zero_tiles<4>(accc);
+        gemm128<MODE>(wt, x, acc, accc, lane);
+        // ---- dp = ds1 * Swish'(p)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[kt][i] = acc[kt][i] * usc * dswish(p[kt][i]);
+        if (md.e_ok) store_tile(dp_out + row, acc);
+        // ---- dA[i] = sum over the edges of target i
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[kt][i] = scan_sum(acc[kt][i], md);
+        store_run_sums(acc, md, rowptr, dA, partials, half);
+    }
+}
+
+// combine the tile-boundary partial sums and zero the rows without edges
+__global__ void __launch_bounds__(256) k_segsum_fixup(const int32_t* __restrict__ rowptr, int N, const float* __restrict__ partials,
+                                                      float* __restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= N) return;
+    const int s = rowptr[r], e = rowptr[r + 1];
+    if (e == s) {
+        for (int f = lane; f < 128; f += 64) out[(size_t)r * 128 + f] = 0.f;
+        return;
+    }
+    const int ta = s >> 5, tb = (e - 1) >> 5;
+    if (ta == tb) return;
+    for (int f = lane; f < 128; f += 64) {
+        float acc = partials[((size_t)ta * 2 + 1) * 128 + f];
+        for (int t = ta + 1; t <= tb; ++t) acc += partials[((size_t)t * 2 + 0) * 128 + f];
+        out[(size_t)r * 128 + f] = acc;
+    }
+}
+
+// w2_f16 / w2t_f16: fp16 planes of W2 and of W2^T (magnet_amd/packing.py:pack_linear_fp16x2); partials: ceil(E/32)*2*128
+// floats.  s1, dq, dp: [E][128]; dA: [n_nodes][128] (every row is written).
+extern "C" int magnet_mpnn_edge_bwd_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src,
+                                        const int32_t* tgt, const int32_t* rowptr, int n_nodes, int n_edges,
+                                        const void* w2_f16, const void* w2t_f16, const float* b2, float* s1, float* dq,
+                                        float* dp, float* dA, float* partials, void* stream) {
+    (void)hipGetLastError();
+    if (n_nodes <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_edges > 0) {
+        static int ncu = 0;
+        if (!ncu) {
+            hipDeviceProp_t prop;
+            int dev;
+            hipGetDevice(&dev);
+            hipGetDeviceProperties(&prop, dev);
+            ncu = prop.multiProcessorCount;
+        }
+        const int tiles = (n_edges + 31) / 32;
+        hipLaunchKernelGGL(k_mpnn_edge_bwd, dim3(min((tiles + 3) / 4, ncu)), dim3(256), 0, s, A, Bm, dagg, src, tgt, rowptr,
+                           n_edges, reinterpret_cast<const u32x4*>(w2_f16), reinterpret_cast<const u32x4*>(w2t_f16), b2, s1,
+                           dq, dp, dA, partials);
+    }
+    hipLaunchKernelGGL(k_segsum_fixup, dim3((n_nodes + 3) / 4), dim3(256), 0, s, rowptr, n_nodes, partials, dA);
+    return (int)hipGetLastError();
+}

@@ -228,79 +228,104 @@ __global__ void __launch_bounds__(256) k_mpnn_readout_bwd(const float* __restric
                                                           const float* __restrict__ dt, float* __restrict__ dh,
                                                           float* __restrict__ du_last, float* __restrict__ gpart) {
     __shared__ float sh[4][128], sz[4][8 * 64], sdz[4][8 * 64], sd[4][64], sg[4][8 * 16 + 8 + 8 * 16 + 1];
+    __shared__ float sw1[8 * 16], sw2[8 * 16], sb1[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L1 = (128 - k1) / s1 + 1;
     const int GP = 8 * k1 + 8 + 8 * k2 + 1;
+    for (int q = threadIdx.x; q < 8 * k1; q += 256) sw1[q] = w1[q];
+    for (int q = threadIdx.x; q < 8 * k2; q += 256) sw2[q] = w2[q];
+    if (threadIdx.x < 8) sb1[threadIdx.x] = b1[threadIdx.x];
     for (int q = lane; q < GP; q += 64) sg[wave][q] = 0.f;
-    // every array is private to its wave: wave-level ordering of LDS traffic is enough
+    __syncthreads();
+    // index arithmetic that does not depend on the node, hoisted (integer division is slow)
+    int plo[2], phi[2];                                                 // conv1 positions p touching h[x], x = lane + 64 i
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int x = lane + 64 * i;
+        phi[i] = min(x / s1, L1 - 1);
+        plo[i] = x - k1 + 1 <= 0 ? 0 : (x - k1 + s1) / s1;
+    }
+    int c1_[2], k1_[2];                                                 // dw1 element q = lane + 64 i -> (c, k)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = lane + 64 * i;
+        c1_[i] = q / k1;
+        k1_[i] = q % k1;
+    }
+    int c2_[2], k2_[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = lane + 64 * i;
+        c2_[i] = q / k2;
+        k2_[i] = q % k2;
+    }
+    const float dt0 = dt[0];
+    // every array below is private to its wave: wave-level ordering of LDS traffic is enough
     for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
         sh[wave][lane] = h[(size_t)n * 128 + lane];
         sh[wave][lane + 64] = h[(size_t)n * 128 + lane + 64];
-        wave_lds_sync();
-        for (int o = lane; o < 8 * L1; o += 64) {                       // recompute conv1 pre-activations
-            const int c = o / L1, p = o % L1;
-            float acc = b1[c];
-            for (int k = 0; k < k1; ++k) acc += w1[c * k1 + k] * sh[wave][p * s1 + k];
-            sz[wave][o] = acc;
-        }
         float dsum = 0.f;
         if (lane < tw) {
             const float d = dout[(size_t)n * tw + lane];
             dsum = d;
-            sd[wave][lane] = d * dt[0] * (float)(lane + 1);             // d diff
+            sd[wave][lane] = d * dt0 * (float)(lane + 1);               // d diff
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
         if (lane == 0) du_last[n] = dsum;                               // d u[n, tw-1]
         wave_lds_sync();
-        for (int o = lane; o < 8 * L1; o += 64) {                       // d act(z1)[c][p] = sum_k w2[c][k] ddiff[p - k]
-            const int c = o / L1, p = o % L1;
-            float g = 0.f;
-            for (int k = 0; k < k2; ++k) {
-                const int j = p - k;
-                if (j >= 0 && j < tw) g += w2[c * k2 + k] * sd[wave][j];
+        if (lane < L1) {                                                // lane = conv1 position p
+            for (int c = 0; c < 8; ++c) {
+                float z = sb1[c];
+                for (int k = 0; k < k1; ++k) z += sw1[c * k1 + k] * sh[wave][lane * s1 + k];
+                float g = 0.f;                                          // d act(z)[c][p] = sum_k w2[c][k] ddiff[p - k]
+                for (int k = 0; k < k2; ++k) {
+                    const int jj = lane - k;
+                    if (jj >= 0 && jj < tw) g += sw2[c * k2 + k] * sd[wave][jj];
+                }
+                sz[wave][c * L1 + lane] = use_swish ? act_swish(z) : z; // activation output (for dw2)
+                if (use_swish) {
+                    const float sg_ = sigmoidf_fast(z);
+                    g *= sg_ * (1.0f + z * (1.0f - sg_));
+                }
+                sdz[wave][c * L1 + lane] = g;
             }
-            const float z = sz[wave][o];
-            float dz = g;
-            if (use_swish) {
-                const float s = sigmoidf_fast(z);
-                dz = g * s * (1.0f + z * (1.0f - s));
-            }
-            sdz[wave][o] = dz;
         }
         wave_lds_sync();
-        for (int x = lane; x < 128; x += 64) {                          // dh[x] = sum_{c,p,k: p*s1+k = x} w1[c][k] dz[c][p]
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                                   // dh[x] = sum_{c,p} w1[c][x - p s1] dz[c][p]
+            const int x = lane + 64 * i;
             float g = 0.f;
             for (int c = 0; c < 8; ++c)
-                for (int k = 0; k < k1; ++k) {
-                    const int pp = x - k;
-                    if (pp >= 0 && pp % s1 == 0 && pp / s1 < L1) g += w1[c * k1 + k] * sdz[wave][c * L1 + pp / s1];
-                }
+                for (int pp = plo[i]; pp <= phi[i]; ++pp) g += sw1[c * k1 + x - pp * s1] * sdz[wave][c * L1 + pp];
             dh[(size_t)n * 128 + x] = g;
         }
-        for (int q = lane; q < 8 * k1; q += 64) {                       // dw1[c][k] += sum_p dz[c][p] h[p*s1+k]
-            const int c = q / k1, k = q % k1;
-            float g = 0.f;
-            for (int p = 0; p < L1; ++p) g += sdz[wave][c * L1 + p] * sh[wave][p * s1 + k];
-            sg[wave][q] += g;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                                   // dw1[c][k] += sum_p dz[c][p] h[p*s1+k]
+            const int q = lane + 64 * i;
+            if (q < 8 * k1) {
+                float g = 0.f;
+                for (int pp = 0; pp < L1; ++pp) g += sdz[wave][c1_[i] * L1 + pp] * sh[wave][pp * s1 + k1_[i]];
+                sg[wave][q] += g;
+            }
         }
         if (lane < 8) {                                                 // db1[c]
             float g = 0.f;
-            for (int p = 0; p < L1; ++p) g += sdz[wave][lane * L1 + p];
+            for (int pp = 0; pp < L1; ++pp) g += sdz[wave][lane * L1 + pp];
             sg[wave][8 * k1 + lane] += g;
         }
-        for (int q = lane; q < 8 * k2; q += 64) {                       // dw2[c][k] += sum_j ddiff[j] a[c][j+k]
-            const int c = q / k2, k = q % k2;
-            float g = 0.f;
-            for (int j = 0; j < tw; ++j) {
-                const float z = sz[wave][c * L1 + j + k];
-                g += sd[wave][j] * (use_swish ? act_swish(z) : z);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                                   // dw2[c][k] += sum_j ddiff[j] a[c][j+k]
+            const int q = lane + 64 * i;
+            if (q < 8 * k2) {
+                float g = 0.f;
+                for (int jj = 0; jj < tw; ++jj) g += sd[wave][jj] * sz[wave][c2_[i] * L1 + jj + k2_[i]];
+                sg[wave][8 * k1 + 8 + q] += g;
             }
-            sg[wave][8 * k1 + 8 + q] += g;
         }
         if (lane == 0) {                                                // db2
             float g = 0.f;
-            for (int j = 0; j < tw; ++j) g += sd[wave][j];
+            for (int jj = 0; jj < tw; ++jj) g += sd[wave][jj];
             sg[wave][8 * k1 + 8 + 8 * k2] += g;
         }
         wave_lds_sync();

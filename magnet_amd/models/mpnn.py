@@ -93,6 +93,9 @@ class MPNN(LightningModule):
         # not offered there ("bf16x6" keeps the fp32 exponent range; "fp32" = fp32 MFMA)
         self.bwd_gemm = getattr(hparams, "bwd_gemm", "bf16x6")
         assert self.bwd_gemm in ("bf16x6", "fp32")
+        # edge block of the backward: "fused" (one kernel, mpnn_edge_bwd.hip) or "unfused" (materialising reference path)
+        self.edge_bwd = getattr(hparams, "edge_bwd", "fused")
+        assert self.edge_bwd in ("fused", "unfused")
         self._pack_key, self._pack = None, None
         self._topo_key, self._topo = None, None
         self.hip_graph = bool(getattr(hparams, "hip_graph", False))

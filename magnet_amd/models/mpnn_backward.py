@@ -55,6 +55,8 @@ def _packed_bwd(m):
         q.dnin = pack(torch.cat([wan.t(), wbn.t()], 1), None, mode)     # [kin, 2H]
         q.dagg = pack(W3[:, H:2 * H].t(), None, mode)
         q.w2t = pack(W2.t(), None, mode)
+        q.w2_f16 = pack(W2, lyr.message_net_2[0].bias, "fp16x3")         # fused edge backward: both packings as fp16 planes
+        q.w2t_f16 = pack(W2.t(), None, "fp16x3")
         q.w4t = pack(W4.t(), None, mode)
         Q.layers.append(q)
     e0, e1 = m.embedding_mlp[0].weight.detach().float(), m.embedding_mlp[2].weight.detach().float()
@@ -104,7 +106,10 @@ def backward_call(m, tape, dout, G, ws):
     dnin = torch.zeros(N, kin, device=dev, dtype=torch.float32)
     dnin_l = torch.empty_like(dnin)
     z1, r1, z2, t1, t2, dagg, dA, dBm = (new() for _ in range(8))
-    p, sp, q, d1, d2 = (enew() for _ in range(5))
+    fused = m.edge_bwd == "fused"
+    sp, d1, d2 = (enew() for _ in range(3))
+    p, q = (None, None) if fused else (enew(), enew())
+    partials = torch.empty(((E + 31) // 32) * 2 * H + 1, device=dev, dtype=torch.float32) if fused else None
     o_k = kin // 32
 
     for li in reversed(range(len(P.layers))):
@@ -123,7 +128,11 @@ def backward_call(m, tape, dout, G, ws):
         ops.wgrad(dz1, nin, 0, kin, g.w3, 2 * H, None, ws)
         lin(N, ops.ktiles(T(dz1, H)), qb.dagg, dagg)
         # ---- mean aggregation + message MLP at edge granularity                      mpnn.py:73-79, :46
-        if E > 0:
+        if E > 0 and m.edge_bwd == "fused":
+            ops.mpnn_edge_bwd(tp.A, tp.Bm, dagg, csr, qb.w2_f16[0], qb.w2t_f16[0], qb.w2_f16[1], sp, d1, d2, dA, partials)
+            ops.wgrad(d1, sp, 0, H, g.w2, 0, g.b2, ws, M=E)
+            ops.segment_sum128(d2, bs.rowptr, N, perm=bs.perm, out=dBm)
+        elif E > 0:
             ops.edge_mean_bwd(dagg, csr, d1)
             ops.edge_pre(tp.A, tp.Bm, csr, p)
             ops.swish_fwd(p, sp)

@@ -195,6 +195,14 @@ def edge_mean_bwd(dagg, csr, out=None):
     return out
 
 
+def mpnn_edge_bwd(A, Bm, dagg, csr, w2_f16, w2t_f16, b2, s1, dq, dp, dA, partials):
+    """fused backward of the edge block: fills s1, dq, dp [E,128] and dA [N,128]"""
+    L.check(L.lib().magnet_mpnn_edge_bwd_f32(_p(A), _p(Bm), _p(dagg), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.N, csr.E,
+                                             _p(w2_f16), _p(w2t_f16), _p(b2), _p(s1), _p(dq), _p(dp), _p(dA), _p(partials),
+                                             _stream()), "mpnn_edge_bwd")
+    return dA
+
+
 def segment_sum128(x, rowptr, n_rows, perm=None, out=None):
     out = torch.empty(n_rows, 128, device=x.device, dtype=torch.float32) if out is None else out
     L.check(L.lib().magnet_segment_sum128_f32(_p(x), _p(rowptr), _p(perm), n_rows, _p(out), _stream()), "segment_sum128")

@@ -3,8 +3,10 @@
 Trajectories in a batch never interact in any forward (block-diagonal graphs, per-graph norms), so
 the rollout shards over ranks with NO data-path collective; the only communication is the reduction
 of scalar metrics / timings at the end.  One process per GPU, torch.distributed ('nccl' = RCCL on
-ROCm; 'gloo' in the CPU tests).  The gradient all-reduce of the training step belongs to the
-backward row and is not built yet.
+ROCm; 'gloo' in the CPU tests).  Training adds exactly one collective per step: the all-reduce of
+the parameter gradients (``allreduce_gradients``, what Lightning's strategy='ddp' does for the
+reference, configs/trainer/default.yaml) - one flat 2.5 MB buffer, issued once after the rollout's
+backward, because the gradients accumulate over the rollout's forward calls and are final only then.
 """
 from __future__ import annotations
 
@@ -57,3 +59,21 @@ def gather_predictions(pred: torch.Tensor) -> torch.Tensor:
     parts = [torch.empty_like(pred) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, pred.contiguous())
     return torch.cat(parts, 0)
+
+
+def allreduce_gradients(parameters, average: bool = True) -> None:
+    """Sum (or average) ``.grad`` of every parameter over the ranks with ONE all-reduce of a flat buffer
+    (RCCL over xGMI when the gradients live on GPUs).  DDP semantics: every rank ends with identical
+    gradients; with equal shard sizes and a mean loss the average equals the full-batch gradient."""
+    params = [p for p in parameters if p.grad is not None]
+    if not params or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= dist.get_world_size()
+    o = 0
+    for p in params:
+        n = p.grad.numel()
+        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        o += n

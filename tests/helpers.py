@@ -32,3 +32,47 @@ def forward_args(name, hp, batch):
                 batch["hr_points"][:, T - 1])
     return (batch["lr_frames"][:, :T], batch["coords"], batch["cells"], batch["t"][:, :2 * T],
             batch["hr_points"][:, T - 1])
+
+
+def oracle_grads(oracle, batch, teacher_forcing, loss_name, dtype=torch.float64):
+    """loss + gradients by torch autograd through the oracle's rollout (models/mpnn.py:254-297), on the CPU,
+    arithmetic in ``dtype`` (fp64 gives a clean target; fp32 is what the reference runs)."""
+    from oracle.models import _criterion
+    o = oracle.to(dtype)
+    f32 = {k: v.float() for k, v in batch.items()}
+    u = f32["u"].permute(0, 2, 1)
+    x = f32["x"] if o.dim == 2 else f32["x"].squeeze(-1)
+    t = f32["t"]
+    B, _, N = u.shape
+    tw = o.tw
+    dt = (t[0][1] - t[0][0]).to(dtype)
+
+    def graph_of(window, step):
+        # topology / positions from the fp32 inputs (what the reference sees), features in fp64 with their graph
+        g = o._build_graph(window.detach().float(), t, x, [step] * B)
+        g.x = window.to(dtype).permute(0, 2, 1).reshape(B * N, tw)
+        g.pos = g.pos.to(dtype)
+        return g
+
+    graph = graph_of(u[:, :tw], o._step_index(0))
+    target = u[:, tw:].to(dtype)
+    outs = []
+    for i in range(target.shape[1] // tw):
+        y = o.forward(graph, x[0, -1].to(dtype), t[0, -1].to(dtype), dt).reshape(B, N, -1).permute(0, 2, 1)
+        outs.append(y)
+        nxt = u[:, (i + 1) * tw:(i + 2) * tw] if teacher_forcing else y
+        graph = graph_of(nxt, o._step_index(i + 1))
+    loss = _criterion(loss_name)(torch.cat(outs, 1), target)
+    o.zero_grad()
+    loss.backward()
+    return float(loss.detach()), {n: p.grad.clone() for n, p in o.named_parameters()}
+
+
+def load_grads(tag, teacher_forcing):
+    """tests/golden/<tag>_grad.npz -> (loss, {param name: (norm, strided sample, stride)})"""
+    d = np.load(os.path.join(GOLDEN, tag + "_grad.npz"), allow_pickle=False)
+    key = "tf" if teacher_forcing else "free"
+    stride = int(d["stride"])
+    names = [k.split(":", 1)[1] for k in d.files if k.startswith(key + "_norm:")]
+    return float(d[key + "_loss"]), {n: (float(d[f"{key}_norm:{n}"]), torch.from_numpy(d[f"{key}_sample:{n}"]), stride)
+                                     for n in names}

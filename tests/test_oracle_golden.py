@@ -38,3 +38,22 @@ def test_oracle_matches_reference_golden(tag):
             model.validation_step(batch)
         assert abs(float(model.logged["val_mae_loss"]) - float(d["val_mae_loss"])) < 1e-5
         assert abs(float(model.logged["val_loss"]) - float(d["val_loss"])) < 1e-5
+
+
+@pytest.mark.parametrize("teacher_forcing", [False, True])
+@pytest.mark.parametrize("tag", ["mpnn_1d", "mpnn_2d"])
+def test_oracle_gradients_match_reference_training_step(tag, teacher_forcing):
+    """torch autograd through the oracle's rollout vs the gradients of the reference's own training_step
+    (tests/golden/*_grad.npz) - pins the gradient oracle the GPU training tests compare against."""
+    from tests.helpers import load_grads, oracle_grads
+    name, hp, salt, batch, d = load_case(tag)
+    model = O.build(name, hp)
+    fill_state_dict(model, salt)
+    gold_loss, gold = load_grads(tag, teacher_forcing)
+    for dtype, tol in ((torch.float32, 1e-4), (torch.float64, 1e-4)):
+        loss, grads = oracle_grads(model, batch, teacher_forcing, hp.loss, dtype=dtype)
+        assert abs(loss - gold_loss) < 1e-5 * max(1.0, abs(gold_loss))
+        assert set(grads) == set(gold)
+        for n, (norm, sample, stride) in gold.items():
+            assert abs(float(grads[n].norm()) - norm) < tol * norm, (n, dtype)
+            assert rel_l2(grads[n].flatten()[::stride], sample) < tol, (n, dtype)

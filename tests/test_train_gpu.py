@@ -10,11 +10,12 @@ import types
 import pytest
 import torch
 
-from tests.helpers import load_case, rel_l2
+from tests.helpers import load_case, load_grads, oracle_grads, rel_l2
 
 pytestmark = pytest.mark.gpu
 
-GRAD_TOL = 2e-4      # relative L2 per parameter gradient (fp32 accumulation order differs; values ~1e-6)
+GRAD_TOL = 2e-4      # relative L2 per parameter gradient vs fp64 autograd through the oracle
+GOLD_TOL = 1e-3      # vs the reference's own fp32 autograd gradients (both sides carry fp32 rounding)
 
 
 def test_swish_and_axpy_kernels():
@@ -139,44 +140,48 @@ def _pair(tag, **extra):
     return hp, batch, oracle, model.cuda()
 
 
-def _oracle_grads(oracle, batch, teacher_forcing, loss_name):
-    """loss + gradients by torch autograd through the oracle's rollout (fp64 on the CPU for a clean target)."""
-    from oracle.models import _criterion
-    o = oracle.double()
-    f32 = {k: v.float() for k, v in batch.items()}
-    u = f32["u"].permute(0, 2, 1)
-    x = f32["x"] if o.dim == 2 else f32["x"].squeeze(-1)
-    t = f32["t"]
-    B, _, N = u.shape
-    tw = o.tw
-    dt = (t[0][1] - t[0][0]).double()
+def test_fused_edge_backward_matches_autograd():
+    """magnet_mpnn_edge_bwd_f32 against torch autograd (fp64) of the same edge block, gradient magnitudes ~1e-7."""
+    from magnet_amd import ops
+    from magnet_amd.packing import pack
+    torch.manual_seed(5)
+    N, E = 500, 7001
+    src = torch.randint(0, N, (E,), dtype=torch.int32, device="cuda")
+    tgt = torch.randint(0, N - 3, (E,), dtype=torch.int32, device="cuda")
+    csr = ops.csr_by_target(src, tgt, N)
+    A, Bm = torch.randn(N, 128, device="cuda"), torch.randn(N, 128, device="cuda")
+    W2 = torch.randn(128, 128, device="cuda") / 11
+    b2 = torch.randn(128, device="cuda") * 0.1
+    dagg = torch.randn(N, 128, device="cuda") * 1e-7
+    dagg[7] = 0                                                        # a target whose incoming gradient is exactly zero
+    s, t = csr.src.long(), csr.tgt.long()
+    A64, B64 = A.double().requires_grad_(), Bm.double().requires_grad_()
+    W64, b64 = W2.double().requires_grad_(), b2.double().requires_grad_()
+    sw = lambda v: v * torch.sigmoid(v)  # noqa: E731
+    msg = sw(sw(A64[t] + B64[s]) @ W64.t() + b64)
+    deg = torch.bincount(t, minlength=N).clamp(min=1).double()
+    agg = torch.zeros(N, 128, dtype=torch.float64, device="cuda").index_add_(0, t, msg) / deg[:, None]
+    agg.backward(dagg.double())
+    w2p, w2tp = pack(W2, b2, "fp16x3"), pack(W2.t(), None, "fp16x3")
+    s1, dq, dp = (torch.empty(E, 128, device="cuda") for _ in range(3))
+    dA = torch.full((N, 128), 7.0, device="cuda")
+    partials = torch.empty(((E + 31) // 32) * 2 * 128 + 1, device="cuda")
+    ops.mpnn_edge_bwd(A, Bm, dagg, csr, w2p[0], w2tp[0], w2p[1], s1, dq, dp, dA, partials)
+    assert rel_l2(dA, A64.grad) < 2e-6
+    bs = ops.csr_by_target(csr.tgt, csr.src, N)
+    assert rel_l2(ops.segment_sum128(dp, bs.rowptr, N, perm=bs.perm), B64.grad) < 2e-6
+    gW, gb = torch.zeros(128, 128, device="cuda"), torch.zeros(128, device="cuda")
+    ops.wgrad(dq, s1, 0, 128, gW, 0, gb, ops.wgrad_workspace(E, "cuda"))
+    assert rel_l2(gW, W64.grad) < 2e-6 and rel_l2(gb, b64.grad) < 2e-6
+    assert rel_l2(s1, sw(A64[t] + B64[s]).detach()) < 1e-6
 
-    def graph_of(window, step):
-        # topology / positions from the fp32 inputs (what the reference sees), features in fp64 with their graph
-        g = o._build_graph(window.detach().float(), t, x, [step] * B)
-        g.x = window.double().permute(0, 2, 1).reshape(B * N, tw)
-        g.pos = g.pos.double()
-        return g
 
-    graph = graph_of(u[:, :tw], o._step_index(0))
-    target = u[:, tw:].double()
-    outs = []
-    for i in range(target.shape[1] // tw):
-        y = o.forward(graph, x[0, -1].double(), t[0, -1].double(), dt).reshape(B, N, -1).permute(0, 2, 1)
-        outs.append(y)
-        nxt = u[:, (i + 1) * tw:(i + 2) * tw] if teacher_forcing else y
-        graph = graph_of(nxt, o._step_index(i + 1))
-    loss = _criterion(loss_name)(torch.cat(outs, 1), target)
-    o.zero_grad()
-    loss.backward()
-    return float(loss.detach()), {n: p.grad.clone() for n, p in o.named_parameters()}
-
-
+@pytest.mark.parametrize("edge_bwd", ["fused", "unfused"])
 @pytest.mark.parametrize("teacher_forcing", [False, True])
 @pytest.mark.parametrize("tag", ["mpnn_1d", "mpnn_2d"])
-def test_training_step_gradients_match_autograd(tag, teacher_forcing):
-    hp, batch, oracle, model = _pair(tag, teacher_forcing=teacher_forcing)
-    want_loss, want = _oracle_grads(oracle, batch, teacher_forcing, hp.loss)
+def test_training_step_gradients_match_autograd(tag, teacher_forcing, edge_bwd):
+    hp, batch, oracle, model = _pair(tag, teacher_forcing=teacher_forcing, edge_bwd=edge_bwd)
+    want_loss, want = oracle_grads(oracle, batch, teacher_forcing, hp.loss)
     cb = {k: v.cuda() for k, v in batch.items()}
     model.train()
     model.zero_grad()
@@ -190,6 +195,13 @@ def test_training_step_gradients_match_autograd(tag, teacher_forcing):
         worst[n] = rel_l2(p.grad, want[n])
     bad = {n: e for n, e in worst.items() if not e < GRAD_TOL}
     assert not bad, bad
+    # and against the gradients the reference itself produced (tests/golden/*_grad.npz: norm + strided sample)
+    gold_loss, gold = load_grads(tag, teacher_forcing)
+    assert abs(float(loss) - gold_loss) < 2e-5 * max(1.0, abs(gold_loss))
+    for n, p in model.named_parameters():
+        norm, sample, stride = gold[n]
+        assert abs(float(p.grad.norm()) - norm) < GOLD_TOL * norm, n
+        assert rel_l2(p.grad.flatten()[::stride], sample) < GOLD_TOL, n
 
 
 def test_training_step_is_deterministic_and_optimizer_steps():
