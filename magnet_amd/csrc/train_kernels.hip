@@ -107,44 +107,65 @@ __global__ void __launch_bounds__(256) k_segment_sum128(const float* __restrict_
 
 // ---- weight gradient: partial[b][n][k] = sum over the row slabs of workgroup b of dY[m][n] * X[m][k]
 // (+ column sums of dY for the bias).  v_mfma_f32_32x32x2_f32 with BOTH operands read as rows from LDS:
-// A[i = n][kk = m] = dY[m][n0 + i], B[kk = m][j] = X[m][k0 + j] - consecutive lanes read consecutive floats.
-// N = 128 (4 waves <-> 4 n tiles), KC = columns of X handled (multiple of 32, <= 128).
+// A[i = n][kk = m] = dY[m][n0 + i], B[kk = m][j] = X[m][k0 + j] - consecutive lanes read consecutive floats, no
+// transposes anywhere.  N = 128 (4 waves <-> 4 n tiles), KC = KT*32 columns of X.
+// Slabs of 32 rows are DMA'd straight into a two-stage LDS ring (global_load_lds, 1 KiB per wave instruction) while
+// the previous slab is consumed; two workgroups per CU.  HBM-bound at the edge level: 2 x 4 B per (row, column).
+#define WG_SLAB 32
 template <int KT>
-__global__ void __launch_bounds__(256) k_wgrad_partial(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
-                                                       int ldx, int xcol, long M, float* __restrict__ partial /* [grid][128][KT*32] */,
-                                                       float* __restrict__ bpartial /* [grid][128] or null */) {
-    constexpr int SLAB = 64, KC = KT * 32;
-    __shared__ __attribute__((aligned(16))) float sy[SLAB * 128];
-    __shared__ __attribute__((aligned(16))) float sx[SLAB * KC];
+__device__ __forceinline__ void wgrad_dma(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, int xcol,
+                                          long m0, long M, float* sy, float* sx, int wave, int lane) {
+    constexpr int KC = KT * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                      // dY slab: 16 pieces of 2 rows
+        const int pi = wave + 4 * i;
+        long r = m0 + 2 * pi + (lane >> 5);
+        r = r < M ? r : M - 1;                                          // tail rows: valid address, masked at use
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32x4*>(dY + r * ldy + (lane & 31) * 4),
+                                         reinterpret_cast<u32x4*>(sy + pi * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {                                     // X slab: 32*KC/256 = 4 KT pieces
+        const int pi = wave + 4 * i;
+        const int f = pi * 256 + lane * 4;
+        long r = m0 + f / KC;
+        r = r < M ? r : M - 1;
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32x4*>(X + r * ldx + xcol + f % KC),
+                                         reinterpret_cast<u32x4*>(sx + pi * 256), 16, 0, 0);
+    }
+}
+
+template <int KT>
+__global__ void __launch_bounds__(256, 2) k_wgrad_partial(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
+                                                          int ldx, int xcol, long M, float* __restrict__ partial /* [grid][128][KT*32] */,
+                                                          float* __restrict__ bpartial /* [grid][128] or null */) {
+    constexpr int KC = KT * 32;
+    __shared__ __attribute__((aligned(16))) float sy[2][WG_SLAB * 128];
+    __shared__ __attribute__((aligned(16))) float sx[2][WG_SLAB * KC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, half = lane >> 5;
     f32x16 acc[KT];
     zero_tiles<KT>(acc);
     float bsum = 0.f;
-    const long nslabs = (M + SLAB - 1) / SLAB;
-    for (long sl = blockIdx.x; sl < nslabs; sl += gridDim.x) {
-        const long m0 = sl * SLAB;
-        __syncthreads();
-        for (int t = threadIdx.x; t < SLAB * 32; t += 256) {            // dY slab, float4 per thread
-            const int r = t >> 5, c = (t & 31) * 4;
-            f32x4 v = {0, 0, 0, 0};
-            if (m0 + r < M) v = *reinterpret_cast<const f32x4*>(dY + (m0 + r) * ldy + c);
-            *reinterpret_cast<f32x4*>(sy + r * 128 + c) = v;
-        }
-        for (int t = threadIdx.x; t < SLAB * (KC / 4); t += 256) {
-            const int r = t / (KC / 4), c = (t % (KC / 4)) * 4;
-            f32x4 v = {0, 0, 0, 0};
-            if (m0 + r < M) v = *reinterpret_cast<const f32x4*>(X + (m0 + r) * ldx + xcol + c);
-            *reinterpret_cast<f32x4*>(sx + r * KC + c) = v;
-        }
-        __syncthreads();
+    const long nslabs = (M + WG_SLAB - 1) / WG_SLAB;
+    long sl = blockIdx.x;
+    if (sl < nslabs) wgrad_dma<KT>(dY, ldy, X, ldx, xcol, sl * WG_SLAB, M, sy[0], sx[0], wave, lane);
+    for (int it = 0; sl < nslabs; sl += gridDim.x, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // my pieces of slab `it` have landed
+        __syncthreads();                                                // everybody's have; stage (it+1)&1 is free again
+        const long nxt = sl + gridDim.x;
+        if (nxt < nslabs) wgrad_dma<KT>(dY, ldy, X, ldx, xcol, nxt * WG_SLAB, M, sy[(it + 1) & 1], sx[(it + 1) & 1], wave, lane);
+        const float* cy = sy[it & 1];
+        const float* cx = sx[it & 1];
+        const long m0 = sl * WG_SLAB;
 #pragma unroll 4
-        for (int s = 0; s < SLAB / 2; ++s) {
+        for (int s = 0; s < WG_SLAB / 2; ++s) {
             const int m = 2 * s + half;
-            const float a = sy[m * 128 + wave * 32 + i];
+            float a = cy[m * 128 + wave * 32 + i];
+            a = (m0 + m < M) ? a : 0.f;
             bsum += a;
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) acc[kt] = mfma32(a, sx[m * KC + kt * 32 + i], acc[kt]);
+            for (int kt = 0; kt < KT; ++kt) acc[kt] = mfma32(a, cx[m * KC + kt * 32 + i], acc[kt]);
         }
     }
     float* out = partial + (size_t)blockIdx.x * 128 * KC;
@@ -395,13 +416,13 @@ extern "C" int magnet_segment_sum128_f32(const float* x, const int32_t* rowptr, 
     END();
 }
 // dW[128][kc] (+)= dY^T X[:, xcol : xcol+kc], db[128] (+)= column sums of dY (db may be null).
-// workspace: nblk * (128 * kc + 128) floats, nblk = min(256, ceil(M / 64)).
+// workspace: nblk * (128 * kc + 128) + 128 * kc floats, nblk = min(512, ceil(M / 32)).
 extern "C" int magnet_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, int xcol, int kc, long M, float* dW, int ldw,
                                 int wcol, float* db, float* workspace, int accumulate, void* stream) {
     BEGIN();
     if (M <= 0) return 0;
     if (kc % 32 || kc < 32 || kc > 128) return -2;
-    const int nblk = (int)((M + 63) / 64 < 256 ? (M + 63) / 64 : 256);
+    const int nblk = (int)((M + WG_SLAB - 1) / WG_SLAB < 512 ? (M + WG_SLAB - 1) / WG_SLAB : 512);
     float* part = workspace;
     float* bpart = db ? workspace + (size_t)nblk * 128 * kc : nullptr;
     switch (kc / 32) {

@@ -210,7 +210,7 @@ def segment_sum128(x, rowptr, n_rows, perm=None, out=None):
 
 
 def wgrad_workspace(M, device):
-    nblk = min(256, (M + 63) // 64)
+    nblk = min(512, (M + 31) // 32)
     return torch.empty(nblk * (128 * 128 + 128) + 128 * 128, device=device, dtype=torch.float32)
 
 
