@@ -18,6 +18,10 @@
 #include "common.cuh"
 #include "edge_tile.cuh"
 
+#ifndef EB_INTERLEAVE
+#define EB_INTERLEAVE 0
+#endif
+
 __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float dswish(float x) {
     const float s = sigmoid_fast(x);
@@ -52,10 +56,13 @@ __device__ __forceinline__ void store_run_sums(const f32x16 (&v)[4], const TileM
     }
 }
 
-// acc[nt] (+ cross accumulators) += W(planes in LDS) * x, x = the wave's [128 x 32] register tile
+// acc[nt] (+ cross accumulators) += W(planes in LDS) * x, x = the wave's [128 x 32] register tile.
+// While the matrix pipe works, x * store_scale is also written to HBM (row `dst`, may be null), one 16-byte chunk every
+// other MFMA group: HBM absorbs ~9 bytes per cycle and CU, so a burst of 16 stores would stall the wave on the full
+// memory queue; spread out, the stores drain behind the GEMM.
 template <int MODE>
 __device__ __forceinline__ void gemm128(const u32x4* __restrict__ wl, const f32x16 (&x)[4], f32x16 (&acc)[4], f32x16 (&accc)[4],
-                                        int lane) {
+                                        int lane, float* __restrict__ dst, float store_scale) {
     constexpr int NP = Split<MODE>::NP;
     u32x4 xs[2][NP], wr[2][NP];
     split_slot<MODE>(x[0], 0, xs[0]);
@@ -72,6 +79,12 @@ __device__ __forceinline__ void gemm128(const u32x4* __restrict__ wl, const f32x
         }
         if (slot + 1 < 8) Split<MODE>::quarter(x[(slot + 1) >> 1], (slot + 1) & 1, nt, xs[(slot + 1) & 1]);
         Split<MODE>::mma(wr[gq & 1], xs[slot & 1], acc[nt], accc[nt]);
+        if (dst && !(gq & 1)) {
+            const int c = gq >> 1, t = c >> 2, g = c & 3;
+            const f32x4 o = {x[t][4 * g] * store_scale, x[t][4 * g + 1] * store_scale, x[t][4 * g + 2] * store_scale,
+                             x[t][4 * g + 3] * store_scale};
+            *reinterpret_cast<f32x4*>(dst + t * 32 + 8 * g) = o;
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -108,37 +121,40 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
     const int half = lane >> 5, j = lane & 31;
     const int ntiles = (E + 31) / 32;
     const int stride = gridDim.x * 4;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += stride) {
+    int tile = blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+    // software pipeline over the tiles of this wave: the Bm rows of tile t+1 are requested before GEMM 2 of tile t, its A
+    // rows after it, the dagg rows of tile t before its GEMM 1 - with one wave per SIMD nothing else hides the latency.
+    f32x16 ga[4], gb[4];
+    {
+        const int e = min(tile * 32 + j, E - 1);
+        const float* pa = A + (size_t)tgt[e] * 128 + 4 * half;
+        const float* pb = Bm + (size_t)src[e] * 128 + 4 * half;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(pa + kt * 32 + 8 * g);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(pb + kt * 32 + 8 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ga[kt][4 * g + c] = a[c];
+                    gb[kt][4 * g + c] = b[c];
+                }
+            }
+    }
+    for (; tile < ntiles; tile += stride) {
         const TileMeta md = tile_meta(tile, E, tgt, j);
         const int e = min(tile * 32 + j, E - 1);
-        const int ti = md.ti, sj = src[e];
+        const int ti = md.ti;
         const float inv_deg = 1.0f / (float)(rowptr[ti + 1] - rowptr[ti]);
         const size_t row = (size_t)e * 128 + 4 * half;
-        f32x16 p[4], x[4], acc[4], accc[4];
-        {   // p = A[i] + Bm[j],  x = s1 = Swish(p)
-            const float* pa = A + (size_t)ti * 128 + 4 * half;
-            const float* pb = Bm + (size_t)sj * 128 + 4 * half;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(pa + kt * 32 + 8 * g);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(pb + kt * 32 + 8 * g);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        p[kt][4 * g + c] = a[c] + b[c];
-                        x[kt][4 * g + c] = act_swish(a[c] + b[c]);
-                    }
-                }
-        }
-        if (md.e_ok) store_tile(s1_out + row, x);
-        // ---- GEMM 1: q = W2 s1 + b2
-        init_bias<4>(acc, b2, half);
-        zero_tiles<4>(accc);
-        gemm128<MODE>(wl, x, acc, accc, lane);
-        // ---- dq = dagg[i] / deg * Swish'(q)   (into x), per-edge power-of-two scale for the fp16 split
-        float mx = 0.f;
-        {
+        const int tn = tile + stride < ntiles ? tile + stride : tile;     // clamped: the last iteration prefetches unused rows
+        const int en = min(tn * 32 + j, E - 1);
+        const float* pan = A + (size_t)tgt[en] * 128 + 4 * half;
+        const float* pbn = Bm + (size_t)src[en] * 128 + 4 * half;
+        f32x16 p[4], x[4], acc[4], accc[4], gd[4];
+        {   // dagg rows (consumed after GEMM 1)
             const float* pd = dagg + (size_t)ti * 128 + 4 * half;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
@@ -146,37 +162,93 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 d = *reinterpret_cast<const f32x4*>(pd + nt * 32 + 8 * g);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float v = d[c] * inv_deg * dswish(acc[nt][4 * g + c]);
-                        x[nt][4 * g + c] = v;
-                        mx = fmaxf(mx, fabsf(v));
-                    }
+                    for (int c = 0; c < 4; ++c) gd[nt][4 * g + c] = d[c];
                 }
         }
-        if (md.e_ok) store_tile(dq_out + row, x);
+        // p = A[i] + Bm[j], x = s1 = Swish(p)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = ga[kt][i] + gb[kt][i];
+                p[kt][i] = v;
+                x[kt][i] = act_swish(v);
+            }
+        // ---- GEMM 1: q = W2 s1 + b2
+        init_bias<4>(acc, b2, half);
+        zero_tiles<4>(accc);
+#if EB_INTERLEAVE
+        gemm128<MODE>(wl, x, acc, accc, lane, md.e_ok ? s1_out + row : nullptr, 1.0f);
+#else
+        if (md.e_ok) store_tile(s1_out + row, x);
+        gemm128<MODE>(wl, x, acc, accc, lane, nullptr, 1.0f);
+#endif
+        // ---- dq = dagg[i] / deg * Swish'(q)   (into x), per-edge power-of-two scale for the fp16 split
+        float mx = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = gd[nt][i] * inv_deg * dswish(acc[nt][i]);
+                x[nt][i] = v;
+                mx = fmaxf(mx, fabsf(v));
+            }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const unsigned eb = (__float_as_uint(mx) >> 23) & 0xFFu;              // max in [2^(eb-127), 2^(eb-126))
         const float sc = __uint_as_float((254u - eb) << 23);                   // 2^(127-eb): scaled max in [1, 2)
         const float usc = __uint_as_float(eb << 23);                           // 2^(eb-127)  (0 for an all-zero row)
+#if !EB_INTERLEAVE
+        if (md.e_ok) store_tile(dq_out + row, x);
+#endif
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) x[nt][i] *= sc;
+        // next tile's Bm rows (scattered sources, long latency): in flight during GEMM 2 and the dp phase
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(pbn + kt * 32 + 8 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gb[kt][4 * g + c] = b[c];
+            }
         // ---- GEMM 2: ds1 = W2^T dq
         zero_tiles<4>(acc);
         zero_tiles<4>(accc);
-        gemm128<MODE>(wt, x, acc, accc, lane);
+#if EB_INTERLEAVE
+        gemm128<MODE>(wt, x, acc, accc, lane, md.e_ok ? dq_out + row : nullptr, usc);   // stores the unscaled dq
+#else
+        gemm128<MODE>(wt, x, acc, accc, lane, nullptr, 1.0f);
+#endif
+        // next tile's A rows (a handful of distinct targets, cache hits): requested once GEMM 2 has freed its cross
+        // accumulators, in flight during the dp phase
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(pan + kt * 32 + 8 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ga[kt][4 * g + c] = a[c];
+            }
         // ---- dp = ds1 * Swish'(p)
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[kt][i] = acc[kt][i] * usc * dswish(p[kt][i]);
-        if (md.e_ok) store_tile(dp_out + row, acc);
-        // ---- dA[i] = sum over the edges of target i
+        // ---- store dp and form dA[i] = sum over the edges of target i, k tile by k tile (stores spread between the scans)
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[kt][i] = scan_sum(acc[kt][i], md);
+            for (int g = 0; g < 4; ++g) {
+                if (md.e_ok) {
+                    const f32x4 o = {acc[kt][4 * g], acc[kt][4 * g + 1], acc[kt][4 * g + 2], acc[kt][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(dp_out + row + kt * 32 + 8 * g) = o;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[kt][4 * g + c] = scan_sum(acc[kt][4 * g + c], md);
+            }
+        }
         store_run_sums(acc, md, rowptr, dA, partials, half);
     }
 }
@@ -220,9 +292,10 @@ extern "C" int magnet_mpnn_edge_bwd_f32(const float* A, const float* Bm, const f
             ncu = prop.multiProcessorCount;
         }
         const int tiles = (n_edges + 31) / 32;
-        hipLaunchKernelGGL(k_mpnn_edge_bwd, dim3(min((tiles + 3) / 4, ncu)), dim3(256), 0, s, A, Bm, dagg, src, tgt, rowptr,
-                           n_edges, reinterpret_cast<const u32x4*>(w2_f16), reinterpret_cast<const u32x4*>(w2t_f16), b2, s1,
-                           dq, dp, dA, partials);
+        const dim3 g(min((tiles + 3) / 4, ncu)), b(256);
+        const u32x4* w = reinterpret_cast<const u32x4*>(w2_f16);
+        const u32x4* wT = reinterpret_cast<const u32x4*>(w2t_f16);
+hipLaunchKernelGGL(k_mpnn_edge_bwd, g, b, 0, s, A, Bm, dagg, src, tgt, rowptr, n_edges, w, wT, b2, s1, dq, dp, dA, partials);
     }
     hipLaunchKernelGGL(k_segsum_fixup, dim3((n_nodes + 3) / 4), dim3(256), 0, s, rowptr, n_nodes, partials, dA);
     return (int)hipGetLastError();
