@@ -28,6 +28,9 @@ Extra objects on the JSON line:
   cpu_baseline  - the oracle (torch-CPU restatement of the reference op sequence) timed on this
                   box's host cores on a bounded sample (one rollout of one 128 x 128 trajectory;
                   forward calls only, graph construction excluded), rank 0, N = 1 only.
+  training_step - the same workload trained: rollout with tape, HIP backward
+                  kernels, ONE flat gradient all-reduce over RCCL, fused Adam; ms per step and the node-updates/s it
+                  corresponds to (all ranks), `--train-steps` timed steps after one warm-up.  Never part of `value`.
 """
 from __future__ import annotations
 
@@ -104,6 +107,7 @@ def main():
     ap.add_argument("--traj", type=int, default=4, help="trajectories per GPU")
     ap.add_argument("--mesh", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=3, help="timed training steps of the extra 'training_step' leg (0: skip)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -144,6 +148,38 @@ def main():
     tw = HP["time_window"]
     pred_steps = (NT - tw) // tw * tw
     value = world * B * W * W * pred_steps * K / elapsed
+
+    # ---- training step on the same workload ("plus training-step throughput with the all-reduce"):
+    # rollout with tape -> HIP backward -> ONE flat gradient all-reduce (RCCL) -> fused Adam.  Reported beside the
+    # headline, never mixed into `value`.
+    train = None
+    if args.train_steps > 0:
+        from magnet_amd.sharding import allreduce_gradients
+        tmodel = FACTORY["mpnn_2d"](types.SimpleNamespace(**HP)).to(dev).train()
+        opt = tmodel.configure_optimizers()["optimizer"]
+
+        def train_step():
+            opt.zero_grad(set_to_none=True)
+            loss = tmodel.training_step(batch, 0)
+            loss.backward()
+            allreduce_gradients(tmodel.parameters())
+            opt.step()
+            return loss
+
+        first = float(train_step().detach())
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            last = train_step()
+        barrier()
+        t_el = max_over_ranks(time.perf_counter() - t0, dev)
+        train = {"ms_per_step": round(t_el / args.train_steps * 1e3, 3), "steps": args.train_steps, "warmup": 1,
+                 "value": world * B * W * W * pred_steps * args.train_steps / t_el, "unit": "mesh-node-updates/s",
+                 "what": "free-running rollout with tape + HIP backward + one flat RCCL gradient all-reduce + fused Adam",
+                 "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],
+                 "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
+        del tmodel, opt
+        torch.cuda.empty_cache()
 
     # ---- per-kernel roofline, measured live with HIP events on the launch stream (untimed extra pass)
     roof = roof_sc = None
@@ -217,7 +253,7 @@ def main():
                                        f"trajectory), nt={NT}, time_window={tw} -> {pred_steps} predicted steps, {B} trajectories per GPU, "
                                        "radius graph + CSR rebuilt every step",
                            "trajectories_per_gpu": B, "global_trajectories": B * world, "parallelism": f"batch-shard x{world}, no data-path collective"},
-                "roofline": roof, "roofline_scatter": roof_sc, "cpu_baseline": cpu}
+                "roofline": roof, "roofline_scatter": roof_sc, "cpu_baseline": cpu, "training_step": train}
         print(json.dumps(line))
 
 

@@ -200,6 +200,12 @@ int magnet_mpnn_readout_bwd_f32(const float* h, const float* dout, int n, int tw
                                 int k1, int s1, const float* w2, int k2, int use_swish, const float* dt, float* dh,
                                 float* du_last, float* gpart, void* stream);
 
+/* One Adam step on a flat fp32 parameter buffer (torch.optim.Adam semantics: L2 weight decay folded into the gradient,
+ * bias-corrected moments, eps after the square root); `step` counts from 1.  Replaces the optimizer of
+ * configure_optimizers (models/mpnn.py:206-214); the StepLR schedule stays host-side scalar logic. */
+int magnet_adam_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int step, void* stream);
+
 /* Fused backward of the edge block (adjoint of magnet_mpnn_edge_*: mpnn.py:73-79,46 under autograd).  Recomputes
  * p = A[i]+Bm[j], s1 = Swish(p), q = W2 s1 + b2; dq = dagg[i]/deg(i) * Swish'(q); dp = (W2^T dq) * Swish'(p);
  * dA[i] = sum_e dp (all n_nodes rows written).  s1, dq, dp [n_edges][128] are written for the follow-up kernels

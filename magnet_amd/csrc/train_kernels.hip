@@ -479,3 +479,35 @@ extern "C" int magnet_mpnn_readout_bwd_f32(const float* h, const float* dout, in
                        dh, du_last, gpart);
     END();
 }
+
+// ---- fused Adam over one flat parameter buffer (torch.optim.Adam semantics, configure_optimizers models/mpnn.py:206-214:
+// L2 weight decay added to the gradient, bias-corrected moments, eps added after the square root).
+//   g' = g + wd p;  m += (g' - m)(1-b1);  v = b2 v + (1-b2) g'^2;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                       float lr_over_bc1, float beta1, float beta2, float eps, float wd, float sqrt_bc2) {
+    EW_BODY(, )
+    const f32x4 pv = ld4(p, i4, cnt), gv = ld4(g, i4, cnt), mv = ld4(m, i4, cnt), vv = ld4(v, i4, cnt);
+    f32x4 po, mo, vo;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float gg = fmaf(wd, pv[c], gv[c]);
+        mo[c] = fmaf(gg - mv[c], 1.0f - beta1, mv[c]);              // torch: exp_avg.lerp_(grad, 1 - beta1)
+        vo[c] = fmaf((1.0f - beta2) * gg, gg, beta2 * vv[c]);       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(vo[c]) / sqrt_bc2 + eps;
+        po[c] = pv[c] - lr_over_bc1 * (mo[c] / denom);
+    }
+    st4(p, i4, cnt, po);
+    st4(m, i4, cnt, mo);
+    st4(v, i4, cnt, vo);
+}
+
+extern "C" int magnet_adam_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int step, void* stream) {
+    BEGIN();
+    if (n <= 0) return 0;
+    if (step < 1) return -2;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(k_adam, dim3(nb((n + 3) / 4, 256)), dim3(256), 0, S_, p, g, m, v, n, (float)((double)lr / bc1), beta1, beta2,
+                       eps, weight_decay, (float)sqrt(bc2));
+    END();
+}

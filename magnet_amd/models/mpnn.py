@@ -94,9 +94,10 @@ class MPNN(LightningModule):
         self.bwd_gemm = getattr(hparams, "bwd_gemm", "bf16x6")
         assert self.bwd_gemm in ("bf16x6", "fp32")
         # edge block of the backward: "fused" (one kernel, mpnn_edge_bwd.hip) or "unfused" (materialising reference path)
+        self.optimizer_kind = getattr(hparams, "optimizer", "fused")     # "fused" (magnet_amd.optim.FusedAdam) | "torch"
         self.edge_bwd = getattr(hparams, "edge_bwd", "fused")
         assert self.edge_bwd in ("fused", "unfused")
-        self._pack_key, self._pack = None, None
+        self._pack_key, self._pack, self._pack_gen = None, None, 0
         self._topo_key, self._topo = None, None
         self.hip_graph = bool(getattr(hparams, "hip_graph", False))
         self._fwd_graphs = {}
@@ -104,7 +105,7 @@ class MPNN(LightningModule):
     # ------------------------------------------------------------------ packed weights (cached)
     def _packed(self):
         params = list(self.parameters())
-        key = (params[0].device, sum(p._version for p in params))
+        key = (params[0].device, sum(p._version for p in params), self._pack_gen)
         if self._pack_key == key:
             return self._pack
         H, tw, dp, kin = self.hidden_features, self.time_window, self.dpos, self.kin
@@ -265,9 +266,21 @@ class MPNN(LightningModule):
 
     # ------------------------------------------------------------------ Lightning protocol
     def configure_optimizers(self):
-        opt = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        """mpnn.py:206-214: Adam(lr, weight_decay) + StepLR(step_size, gamma=factor).  On a HIP device the optimizer is
+        magnet_amd.optim.FusedAdam (same update rule, one kernel over a flat parameter buffer); the scheduler is
+        torch's StepLR acting on its param_groups.  ``optimizer="torch"`` in the hparams keeps torch.optim.Adam."""
+        on_gpu = next(self.parameters()).is_cuda
+        if on_gpu and self.optimizer_kind == "fused":
+            from ..optim import FusedAdam
+            opt = FusedAdam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+            opt.on_step = self._weights_changed
+        else:
+            opt = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
         sch = torch.optim.lr_scheduler.StepLR(opt, step_size=self.step_size, gamma=self.factor)
         return {"optimizer": opt, "lr_scheduler": {"scheduler": sch}}
+
+    def _weights_changed(self):
+        self._pack_gen += 1
 
     def _first_step(self):
         return 0 if self.DIM == 1 else self.time_window - 1   # mpnn.py:265 vs mpnn_2d.py:265

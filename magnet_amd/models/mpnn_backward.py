@@ -198,7 +198,12 @@ def parameter_grads(m, G):
     by_name["output_mlp.0.bias"] = c[8 * k1:8 * k1 + 8]
     by_name[f"output_mlp.{last}.weight"] = c[8 * k1 + 8:8 * k1 + 8 + 8 * k2].view(1, 8, k2)
     by_name[f"output_mlp.{last}.bias"] = c[8 * k1 + 8 + 8 * k2:]
-    return [by_name[n].contiguous() for n, _ in m.named_parameters()]
+    # one flat buffer in parameter order (what FusedAdam and the gradient all-reduce consume without a gather)
+    from ..optim import FlatGrads
+    fg = FlatGrads(list(m.parameters()))
+    for (n, _), view in zip(m.named_parameters(), fg.views):
+        view.copy_(by_name[n].reshape(view.shape))
+    return fg.views
 
 
 class _Rollout(torch.autograd.Function):

@@ -1,0 +1,105 @@
+"""Fused Adam for the training step (reference ``configure_optimizers``, models/mpnn.py:206-214:
+``torch.optim.Adam(lr, weight_decay)`` + ``StepLR(step_size, gamma=factor)``).
+
+All parameters of the model are moved into ONE flat fp32 buffer (each ``p.data`` becomes a view of it), with flat
+moment buffers beside it, so that an optimizer step is a single kernel launch (``magnet_adam_f32``) instead of one
+launch group per parameter tensor, and the gradient all-reduce (``magnet_amd.sharding.allreduce_gradients``) is one
+RCCL call on one buffer.  The class is a ``torch.optim.Optimizer`` - ``param_groups[0]['lr']`` is what ``StepLR``
+rewrites, ``state_dict`` / ``zero_grad`` come from the base class - so Lightning drives it like the reference's Adam.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+class FlatGrads:
+    """A flat gradient buffer laid out like the flat parameter buffer; ``views[i]`` is the slice of parameter i."""
+
+    def __init__(self, params):
+        self.sizes = [p.numel() for p in params]
+        self.total = sum(self.sizes)
+        dev = params[0].device
+        self.flat = torch.zeros(self.total, device=dev, dtype=torch.float32)
+        self.views, o = [], 0
+        for p, n in zip(params, self.sizes):
+            self.views.append(self.flat[o:o + n].view(p.shape))
+            o += n
+
+
+def flat_gradient(params):
+    """the flat buffer behind ``[p.grad for p in params]`` if they are consecutive slices of one, else None"""
+    g0 = params[0].grad
+    if g0 is None:
+        return None
+    base, o = g0.data_ptr(), 0
+    for p in params:
+        g = p.grad
+        if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.data_ptr() != base + 4 * o:
+            return None
+        o += g.numel()
+    store = g0.untyped_storage()
+    off = (base - store.data_ptr()) // 4
+    if store.nbytes() < 4 * (off + o):
+        return None
+    return torch.empty(0, device=g0.device, dtype=torch.float32).set_(store, off, (o,))
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        params = [p for p in params if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._params = params
+        if not params[0].is_cuda:
+            raise RuntimeError("magnet_amd.optim.FusedAdam: parameters must live on a HIP device (no CPU path)")
+        n = sum(p.numel() for p in params)
+        self.flat_p = torch.empty(n, device=params[0].device, dtype=torch.float32)
+        o = 0
+        with torch.no_grad():
+            for p in params:                                   # parameters become views of the flat buffer
+                k = p.numel()
+                self.flat_p[o:o + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[o:o + k].view(p.shape)
+                o += k
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self._scratch_g = None
+        self.steps = 0
+        self.on_step = None
+
+    def _gradient(self):
+        g = flat_gradient(self._params)
+        if g is not None:
+            return g
+        if self._scratch_g is None:
+            self._scratch_g = torch.empty_like(self.flat_p)
+        o = 0
+        for p in self._params:                                 # gradients from elsewhere (not our backward): gather
+            k = p.numel()
+            if p.grad is None:
+                self._scratch_g[o:o + k].zero_()
+            else:
+                self._scratch_g[o:o + k].copy_(p.grad.reshape(-1))
+            o += k
+        return self._scratch_g
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        grp = self.param_groups[0]
+        g = self._gradient()
+        self.steps += 1
+        L.check(L.lib().magnet_adam_f32(ops._p(self.flat_p), ops._p(g), ops._p(self.flat_m), ops._p(self.flat_v),
+                                        C.c_long(self.flat_p.numel()), C.c_float(grp["lr"]), C.c_float(grp["betas"][0]),
+                                        C.c_float(grp["betas"][1]), C.c_float(grp["eps"]), C.c_float(grp["weight_decay"]),
+                                        self.steps, ops._stream()), "adam")
+        if self.on_step is not None:                           # the kernel wrote behind torch's version counters:
+            self.on_step()                                     # tell the model its packed-weight caches are stale
+        return loss

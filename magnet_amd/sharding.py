@@ -68,6 +68,13 @@ def allreduce_gradients(parameters, average: bool = True) -> None:
     params = [p for p in parameters if p.grad is not None]
     if not params or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
+    from .optim import flat_gradient
+    flat = flat_gradient(params)                    # the HIP backward leaves all gradients in one buffer: reduce in place
+    if flat is not None:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if average:
+            flat /= dist.get_world_size()
+        return
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:

@@ -222,3 +222,52 @@ def test_training_step_is_deterministic_and_optimizer_steps():
         loss.backward()
         opt.step()
     assert float(model.training_step(cb, 0)) < l0          # a few Adam steps on one batch reduce its loss
+
+
+def test_fused_adam_matches_torch_adam():
+    """magnet_adam_f32 on the flat buffer vs torch.optim.Adam (+ StepLR) on the same gradients, several steps."""
+    from magnet_amd.optim import FusedAdam
+    torch.manual_seed(6)
+    shapes = [(128, 37), (128,), (1, 8, 10), (3,)]
+    pa = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = FusedAdam(pa, lr=1e-2, weight_decay=1e-3)
+    ob = torch.optim.Adam(pb, lr=1e-2, weight_decay=1e-3)
+    sa = torch.optim.lr_scheduler.StepLR(oa, step_size=3, gamma=0.3)
+    sb = torch.optim.lr_scheduler.StepLR(ob, step_size=3, gamma=0.3)
+    for it in range(8):
+        for x, y in zip(pa, pb):
+            g = torch.randn_like(x) * (10.0 ** -(it % 4))
+            x.grad, y.grad = g.clone(), g.clone()
+        oa.step(), ob.step()
+        sa.step(), sb.step()
+        assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
+    for x, y in zip(pa, pb):
+        assert rel_l2(x, y) < 1e-6
+
+
+def test_training_with_fused_adam_tracks_torch_adam():
+    """five optimizer steps of the HIP training step: FusedAdam (flat gradients, one kernel) vs torch.optim.Adam"""
+    losses = {}
+    for kind in ("fused", "torch"):
+        hp, batch, oracle, model = _pair("mpnn_2d", optimizer=kind)
+        cb = {k: v.cuda() for k, v in batch.items()}
+        model.train()
+        cfg = model.configure_optimizers()
+        opt, sch = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+        assert type(opt).__name__ == ("FusedAdam" if kind == "fused" else "Adam")
+        out = []
+        for _ in range(5):
+            opt.zero_grad()
+            loss = model.training_step(cb, 0)
+            loss.backward()
+            opt.step()
+            sch.step()
+            out.append(float(loss.detach()))
+        losses[kind] = out
+        if kind == "fused":
+            from magnet_amd.optim import flat_gradient
+            assert flat_gradient(list(model.parameters())) is not None      # the backward left one flat buffer
+    assert losses["fused"][-1] < losses["fused"][0]
+    for a, b in zip(losses["fused"], losses["torch"]):
+        assert abs(a - b) < 2e-4 * abs(b)
