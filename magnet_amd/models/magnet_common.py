@@ -183,8 +183,8 @@ class MagnetBase(LightningModule):
     def _no_backward_yet(self):
         if torch.is_grad_enabled():
             raise NotImplementedError(
-                "magnet_amd round 1 ships the forward / rollout kernels only; the backward kernels "
-                "(SURVEY.md 8(f) rank 2) are not built yet, so training_step cannot produce gradients")
+                "the HIP backward (SURVEY.md 8(f) rank 2) exists for MPNN / MPNN_2d only so far; the MAgNet models "
+                "ship the forward / rollout kernels, so their training_step cannot produce gradients yet")
 
 
 __all__ = ["Encoder", "InteractionNetwork", "Processor", "Decoder", "MagnetBase", "pack_mlp", "pack_mlp_ln",
