@@ -265,8 +265,9 @@ def graph_ptr(n_graphs: int, nodes_per_graph: int, device) -> torch.Tensor:
     return torch.arange(0, (n_graphs + 1) * nodes_per_graph, nodes_per_graph, dtype=torch.int32, device=device)
 
 
-def radius_search(x: torch.Tensor, r, gptr: torch.Tensor, cap: int, brute_force: bool = False):
-    """first ``cap`` same-graph nodes with dist^2 < r^2 per node, ascending index."""
+def radius_search(x: torch.Tensor, r, gptr: torch.Tensor, cap: int, brute_force: bool = False, ragged: bool = False):
+    """first ``cap`` same-graph nodes with dist^2 < r^2 per node, ascending index.  ``ragged``: graphs of different sizes
+    (no reference caller produces them; costs one host sync for the chunk count)."""
     x = _f32(x.reshape(x.shape[0], -1), "coords")
     n, dim = x.shape
     r64 = float(r)
@@ -278,21 +279,26 @@ def radius_search(x: torch.Tensor, r, gptr: torch.Tensor, cap: int, brute_force:
         L.check(L.lib().magnet_radius_search_f32(_p(x), dim, n, _p(_i32(gptr)), ng, C.c_float(r2), cap,
                                                  _p(nbr), _p(cnt), _stream()), "radius_search")
         return nbr, cnt
-    # chunk table: graphs are equal-sized blocks in every caller, so the prefix is closed-form (no sync)
-    per = (n // ng + 63) // 64 if ng else 0
-    assert n % max(ng, 1) == 0, "equal-sized graphs expected"
-    cptr = torch.arange(0, (ng + 1) * per, max(per, 1), dtype=torch.int32, device=x.device)[: ng + 1]
-    nchunks = ng * per
+    if ragged:
+        sizes = (gptr[1:] - gptr[:-1]).long()
+        cptr = torch.cat([torch.zeros(1, dtype=torch.long, device=x.device), torch.cumsum((sizes + 63) // 64, 0)]).int()
+        nchunks = int(cptr[-1].item())
+    else:
+        # chunk table: graphs are equal-sized blocks in every caller, so the prefix is closed-form (no sync)
+        per = (n // ng + 63) // 64 if ng else 0
+        assert n % max(ng, 1) == 0, "equal-sized graphs expected (pass ragged=True otherwise)"
+        cptr = torch.arange(0, (ng + 1) * per, max(per, 1), dtype=torch.int32, device=x.device)[: ng + 1]
+        nchunks = ng * per
     bbox = torch.empty(max(nchunks, 1) * 6, dtype=torch.float32, device=x.device)
     L.check(L.lib().magnet_radius_search_bbox_f32(_p(x), dim, n, _p(_i32(gptr)), _p(cptr), ng, nchunks, C.c_float(r2), cap,
                                                   _p(bbox), _p(nbr), _p(cnt), _stream()), "radius_search_bbox")
     return nbr, cnt
 
 
-def radius_pairs(x, r, gptr, loop: bool, max_num_neighbors: int = 32, brute_force: bool = False):
+def radius_pairs(x, r, gptr, loop: bool, max_num_neighbors: int = 32, brute_force: bool = False, ragged: bool = False):
     """(found, query, qptr, E): the edge list torch_cluster.radius_graph would return, query-major."""
     cap = max_num_neighbors if loop else max_num_neighbors + 1
-    nbr, cnt = radius_search(x, r, gptr, cap, brute_force)
+    nbr, cnt = radius_search(x, r, gptr, cap, brute_force, ragged)
     n = cnt.numel()
     qptr = torch.empty(n + 1, dtype=torch.int32, device=nbr.device)
     L.check(L.lib().magnet_radius_offsets(_p(nbr), _p(cnt), n, cap, int(loop), _p(qptr), _stream()), "radius_offsets")

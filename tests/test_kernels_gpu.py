@@ -189,3 +189,31 @@ def test_mpnn_edge_kernels_agree_on_ragged_graph():
         ops.mpnn_edge(A.cuda(), Bm.cuda(), csr, w, b, agg, partials)
         assert not torch.isnan(agg).any()
         assert rel_l2(agg, want) < 1e-6, mode
+
+
+@pytest.mark.parametrize("dim,loop", [(1, False), (2, False), (2, True)])
+def test_radius_search_ragged_graphs_duplicates_and_isolated_nodes(dim, loop):
+    """graphs of different sizes (one of them empty, one a single node), duplicate coordinates, isolated nodes and a
+    cluster beyond the 32-neighbour cap - against the oracle's torch_cluster restatement."""
+    from magnet_amd import ops
+    from oracle.pyg_semantics import radius_graph
+    sizes = [70, 0, 1, 130, 65, 3]
+    g = torch.Generator().manual_seed(17 + dim + loop)
+    xs, batch = [], []
+    for b, n in enumerate(sizes):
+        x = torch.rand(n, dim, generator=g)
+        if n >= 60:
+            x[:45] = x[:45] * 0.05 + 0.3
+            x[50], x[52] = x[48].clone(), x[48].clone()         # duplicates
+            x[-1] = 7.0 + b                                      # isolated
+        xs.append(x)
+        batch.append(torch.full((n,), b, dtype=torch.long))
+    x, batch = torch.cat(xs), torch.cat(batch)
+    gptr = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device="cuda")
+    # the oracle wants consecutive graph ids: relabel (empty graph 1 disappears)
+    want = radius_graph(x, 0.2, torch.unique_consecutive(batch, return_inverse=True)[1], loop=loop)
+    for brute in (False, True):
+        found, query, qptr, E = ops.radius_pairs(x.cuda(), 0.2, gptr, loop=loop, brute_force=brute, ragged=True)
+        assert E == want.shape[1]
+        assert torch.equal(torch.stack([found.long(), query.long()]).cpu(), want)
+    assert int(torch.bincount(want[1]).max()) == (32 if loop else 33)

@@ -1,0 +1,112 @@
+"""CPU unit tests of oracle/pyg_semantics.py against independent naive (pure-Python loop) statements of the published
+torch_scatter / torch_cluster / PyG semantics ("unit" level).  These libraries cannot be installed
+here, so this does not pin the oracle to them ("parity unpinned") - it guards the vectorised
+restatement against its own bugs on the awkward inputs: empty neighbourhoods, isolated nodes, more than 32 in-radius
+neighbours, duplicate coordinates, graphs of different sizes."""
+import math
+
+import pytest
+import torch
+
+from oracle import pyg_semantics as S
+
+
+def _random_points(seed, sizes, dim, dup=True):
+    g = torch.Generator().manual_seed(seed)
+    xs, batch = [], []
+    for b, n in enumerate(sizes):
+        x = torch.rand(n, dim, generator=g)
+        if n >= 60:
+            x[:45] = x[:45] * 0.05 + 0.3              # dense cluster: more than 32 neighbours inside the radius
+        if dup and n >= 8:
+            x[5] = x[2]                               # duplicate coordinates
+            x[7] = x[2]
+        if n >= 3:
+            x[-1] = 5.0 + b                           # isolated node
+        xs.append(x)
+        batch.append(torch.full((n,), b, dtype=torch.long))
+    return torch.cat(xs), torch.cat(batch)
+
+
+def _naive_radius_graph(x, r, batch, loop, cap=32):
+    """torch_cluster.radius_graph as documented: per query the first `cap` (+1 when loop=False, self then removed)
+    same-graph points in ascending index with squared distance < r^2; edge = (found j -> query i)."""
+    r2 = float(torch.tensor(float(r) * float(r), dtype=torch.float64).to(torch.float32))
+    n = x.shape[0]
+    limit = cap if loop else cap + 1
+    src, dst = [], []
+    for i in range(n):
+        cnt = 0
+        for j in range(n):
+            if batch[j] != batch[i]:
+                continue
+            d = torch.zeros((), dtype=torch.float32)
+            for k in range(x.shape[1]):
+                diff = x[i, k] - x[j, k]
+                d = d + diff * diff
+            if float(d) < r2:
+                cnt += 1
+                if cnt > limit:
+                    break
+                if loop or i != j:
+                    src.append(j)
+                    dst.append(i)
+    return torch.tensor([src, dst], dtype=torch.long).reshape(2, -1)
+
+
+@pytest.mark.parametrize("dim,loop,sizes", [(1, False, [40, 70]), (2, False, [80, 3, 61]), (2, True, [64, 90]), (2, True, [1, 2])])
+def test_radius_graph_vs_naive_loops(dim, loop, sizes):
+    x, batch = _random_points(11 * dim + loop + len(sizes), sizes, dim)
+    r = 0.2
+    got = S.radius_graph(x, r, batch, loop=loop)
+    want = _naive_radius_graph(x, r, batch, loop)
+    assert torch.equal(got, want)
+    if max(sizes) >= 60:
+        # the cap was hit (Q3): 32 with self-loops; without, 33 are searched and self is dropped only if it was among them
+        assert int(torch.bincount(want[1]).max()) == (32 if loop else 33)
+    iso = sum(sizes[:1]) - 1                                      # the isolated node of graph 0
+    if sizes[0] >= 3 and not loop:
+        assert not bool((want[1] == iso).any()) and not bool((want[0] == iso).any())
+
+
+def test_knn_vs_naive_loops_with_ties():
+    x, bx = _random_points(3, [20, 33], 2)
+    y, by = _random_points(4, [15, 9], 2, dup=False)
+    y[:3] = x[:3]                                                 # exact hits; x[2] has duplicates -> distance ties
+    k = 4
+    got = S.knn(x, y, k, bx, by)
+    rows, cols = [], []
+    for q in range(y.shape[0]):
+        cand = [(float(((y[q] - x[j]) * (y[q] - x[j])).sum()), j) for j in range(x.shape[0]) if bx[j] == by[q]]
+        cand.sort(key=lambda t: (t[0], t[1]))                     # nearest first, lower index first on ties
+        for _, j in cand[:k]:
+            rows.append(q)
+            cols.append(j)
+    assert torch.equal(got, torch.tensor([rows, cols]))
+
+
+def test_scatter_mean_vs_naive_loops():
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(50, 7, generator=g)
+    idx = torch.randint(0, 12, (50,), generator=g)
+    idx[idx == 4] = 3                                             # row 4 receives nothing -> 0
+    got = S.scatter_mean(src, idx, 14)
+    for r in range(14):
+        rows = [src[e] for e in range(50) if idx[e] == r]
+        want = torch.stack(rows).mean(0) if rows else torch.zeros(7)
+        assert torch.allclose(got[r], want, atol=1e-6)
+
+
+def test_instance_norm_vs_functional():
+    g = torch.Generator().manual_seed(6)
+    sizes = [17, 40, 5]
+    x = torch.randn(sum(sizes), 9, generator=g) * 3 + 1
+    batch = torch.cat([torch.full((n,), b) for b, n in enumerate(sizes)])
+    got = S.instance_norm(x, batch)
+    o = 0
+    for n in sizes:
+        blk = x[o:o + n]                                          # PyG InstanceNorm: per graph and channel, biased variance
+        want = torch.nn.functional.instance_norm(blk.t()[None], eps=1e-5)[0].t()
+        assert torch.allclose(got[o:o + n], want, atol=2e-6)
+        o += n
+    assert not math.isnan(float(got.sum()))
