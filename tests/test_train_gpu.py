@@ -188,7 +188,7 @@ def test_training_step_gradients_match_autograd(tag, teacher_forcing, edge_bwd):
     loss = model.training_step(cb, 0)
     assert loss.requires_grad
     loss.backward()
-    assert abs(float(loss) - want_loss) < 1e-5 * max(1.0, abs(want_loss))
+    assert abs(float(loss.detach()) - want_loss) < 1e-5 * max(1.0, abs(want_loss))
     worst = {}
     for n, p in model.named_parameters():
         assert p.grad is not None, n
@@ -197,7 +197,7 @@ def test_training_step_gradients_match_autograd(tag, teacher_forcing, edge_bwd):
     assert not bad, bad
     # and against the gradients the reference itself produced (tests/golden/*_grad.npz: norm + strided sample)
     gold_loss, gold = load_grads(tag, teacher_forcing)
-    assert abs(float(loss) - gold_loss) < 2e-5 * max(1.0, abs(gold_loss))
+    assert abs(float(loss.detach()) - gold_loss) < 2e-5 * max(1.0, abs(gold_loss))
     for n, p in model.named_parameters():
         norm, sample, stride = gold[n]
         assert abs(float(p.grad.norm()) - norm) < GOLD_TOL * norm, n
