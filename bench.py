@@ -116,12 +116,17 @@ def main():
     from magnet_amd.sharding import env_world, max_over_ranks
 
     rank, local_rank, world = env_world()
+    # one process per GPU over RCCL ("nccl" on ROCm).  MAGNET_DIST_BACKEND=gloo is a test hook: it lets several ranks
+    # share one GPU (RCCL refuses that) so that the N > 1 control flow can be exercised on a 1-GPU box.
+    backend = os.environ.get("MAGNET_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1) if world > 1 else 0)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     W, B, K, Wm = args.mesh, args.traj, args.steps, args.warmup
 
     torch.manual_seed(0)

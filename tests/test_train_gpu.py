@@ -271,3 +271,18 @@ def test_training_with_fused_adam_tracks_torch_adam():
     assert losses["fused"][-1] < losses["fused"][0]
     for a, b in zip(losses["fused"], losses["torch"]):
         assert abs(a - b) < 2e-4 * abs(b)
+
+
+def test_two_ranks_gradient_allreduce_on_gpu_tensors():
+    """scripts/ddp_check.py under torch.distributed.run with 2 ranks sharing this GPU (gloo on GPU tensors; RCCL needs
+    one device per rank): all-reduced shard gradients == full-batch gradients, parameters identical after Adam."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MAGNET_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "scripts", "ddp_check.py")],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("DDP_OK") == 2
