@@ -28,7 +28,7 @@ extern "C" {
  * magnet_amd/packing.py builds it; a C caller can use the same two lines of index arithmetic.
  * ---------------------------------------------------------------------------------------------- */
 
-#define MAGNET_MAX_KT 12
+#define MAGNET_MAX_KT 36
 #define MAGNET_MAX_LAYERS 6
 enum { MAGNET_ACT_NONE = 0, MAGNET_ACT_SWISH = 1, MAGNET_ACT_RELU = 2 };
 enum { MAGNET_EPI_STORE = 0, MAGNET_EPI_STORE_RES = 1, MAGNET_EPI_SEGMEAN = 2 };
@@ -67,7 +67,8 @@ typedef struct {
     const int32_t* tgt;    /* SEGMEAN: target row of every edge (non-decreasing) */
     const int32_t* rowptr; /* SEGMEAN: CSR row pointer [N+1] */
     float* partials;       /* SEGMEAN: scratch [ceil(M/32)][2][ncols] */
-    int32_t pad2_;
+    int32_t ncolgroups;    /* nl == 1 only, 0/1 = off: G > 1 launches G workgroup columns; group g multiplies by layer[g]
+                            * (the packed slice of its OT*32 output columns) and writes y / reads res at column g*OT*32 */
 } magnet_mlp_args_t;
 
 /* Fused gather/concat -> NL x (Linear [+ activation]) -> [LayerNorm] -> store | +residual | CSR mean.
@@ -165,6 +166,12 @@ int magnet_inr_grid_prepare_f32(const float* coords, const float* cell, const fl
                                 float* area, void* stream);
 int magnet_inr_grid_blend_f32(const float* p, const float* area, int n_rows, int T, int C, int nshift, float* z,
                               void* stream);
+
+/* EDSR convolutions (models/backbones/edsr.py:32-60) run as gathered-tap GEMMs through magnet_mlp_*: a "same" k x k
+ * (d = 2) or k (d = 1, H = 1) convolution over a channels-last map [P = n_images*H*W rows (+1 all-zero row), C] is one
+ * Linear over the k^d shifted neighbours.  tap[t*P + p] = row of pixel p's neighbour for tap t (row-major dy, dx), or
+ * P (the zero row) outside the image. */
+int magnet_conv_tap_index(int n_images, int H, int W, int k, int d, int32_t* tap, void* stream);
 
 /* ---- backward pass of the MPNN training step (train_kernels.hip).  Replaces what torch autograd does for the
  *      reference's training_step (models/mpnn.py:254-297 -> forward :175-203, GNN_Layer :65-90); the Linear

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libmagnet_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "magnet_hip.h")
 
-MAX_KT, MAX_LAYERS = 12, 6
+MAX_KT, MAX_LAYERS = 36, 6
 ACT_NONE, ACT_SWISH, ACT_RELU = 0, 1, 2
 EPI_STORE, EPI_STORE_RES, EPI_SEGMEAN = 0, 1, 2
 
@@ -38,7 +38,7 @@ class MlpArgs(C.Structure):
                 ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("ln_eps", C.c_float),
                 ("y", C.c_void_p), ("ldy", C.c_int32), ("ncols", C.c_int32),
                 ("res", C.c_void_p), ("ldres", C.c_int32),
-                ("tgt", C.c_void_p), ("rowptr", C.c_void_p), ("partials", C.c_void_p), ("pad2_", C.c_int32)]
+                ("tgt", C.c_void_p), ("rowptr", C.c_void_p), ("partials", C.c_void_p), ("ncolgroups", C.c_int32)]
 
 
 def declared_symbols() -> list[str]:

@@ -18,7 +18,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define MAGNET_MAX_KT 12      // first-layer K up to 384
+#define MAGNET_MAX_KT 36      // first-layer K up to 1152 (a 3x3 convolution over 128 channels as 9 gathered taps)
 #define MAGNET_MAX_LAYERS 6
 #ifndef MAGNET_PF
 #define MAGNET_PF 0
@@ -63,7 +63,7 @@ struct MagnetMlpArgs {
     const int32_t* tgt;            // [M] target of each edge
     const int32_t* rowptr;         // [N+1]
     float* partials;               // [ntiles][2][ncols]
-    int32_t pad2_;
+    int32_t ncolgroups;            // NL == 1 only: > 1 splits the output columns over gridDim.y, group g uses layer[g] (own packed slice)
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {

@@ -226,3 +226,31 @@ extern "C" int magnet_inr_grid_blend_f32(const float* p, const float* area, int 
     hipLaunchKernelGGL(k_inr_grid_blend, dim3(nb(total, 256)), dim3(256), 0, S_, p, area, T, C, nshift, total, z);
     LAUNCH_CHECK();
 }
+
+// ---- EDSR convolutions (models/backbones/edsr.py:32-60) as gathered-tap GEMMs --------------------------------------
+// A k x k (or k) "same" convolution over a channels-last feature map [P = B*H*W rows, C] is one Linear over the
+// concatenation of the k^d shifted neighbours of every pixel.  tap[t][p] = row of the neighbour of pixel p for tap t
+// (dy, dx = t / k - k/2, t % k - k/2), or P - the index of an all-zero row appended to the map - outside the image
+// (zero padding).  The fused MLP kernel then gathers its k tiles through these indices: an implicit GEMM, no im2col.
+__global__ void k_conv_tap_index(int B, int H, int W, int k, int d, int32_t* __restrict__ tap) {
+    const long P = (long)B * H * W;
+    const int ntaps = d == 2 ? k * k : k;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * ntaps) return;
+    const int t = (int)(i / P);
+    const long p = i % P;
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    const int dy = d == 2 ? t / k - k / 2 : 0, dx = (d == 2 ? t % k : t) - k / 2;
+    const int yy = y + dy, xx = x + dx;
+    const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    tap[i] = in ? (int32_t)(p + (long)dy * W + dx) : (int32_t)P;
+}
+
+extern "C" int magnet_conv_tap_index(int n_images, int H, int W, int k, int d, int32_t* tap, void* stream) {
+    (void)hipGetLastError();
+    if ((d != 1 && d != 2) || !(k & 1) || (d == 1 && H != 1)) return -2;
+    const long total = (long)n_images * H * W * (d == 2 ? k * k : k);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_conv_tap_index, dim3(nb(total, 256)), dim3(256), 0, S_, n_images, H, W, k, d, tap);
+    LAUNCH_CHECK();
+}

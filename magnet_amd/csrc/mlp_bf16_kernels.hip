@@ -83,13 +83,15 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
 
     constexpr int NT0 = (NL == 1) ? OT : HT;
     constexpr int NT1 = (NL == 2) ? OT : HT;            // output tiles of layer 1 (when it exists)
+    const int cg = (NL == 1) ? blockIdx.y : 0;          // column group (single-Linear launches may split their outputs)
+    const MagnetLayer l0 = a.layer[cg];
     // Chunk c (one k tile of one layer) lives in ring slot c % NBUF and is requested DIST chunks ahead; iteration c:
     //   wait (DIST 2: counted, chunk c+1 stays in flight) -> barrier (chunk c visible, slot of c-1 free) ->
     //   request chunk c+DIST -> compute chunk c.
     int c = 0;                                         // running chunk index (uniform)
-    dma_chunk<NT0 * PPN>(a.layer[0].w, wbuf, wave, lane);
+    dma_chunk<NT0 * PPN>(l0.w, wbuf, wave, lane);
     if (DIST == 2) {
-        if (a.nkt > 1) dma_chunk<NT0 * PPN>(a.layer[0].w + (size_t)NT0 * PPN * 64, wbuf + CH, wave, lane);
+        if (a.nkt > 1) dma_chunk<NT0 * PPN>(l0.w + (size_t)NT0 * PPN * 64, wbuf + CH, wave, lane);
         else if (NL > 1) dma_chunk<NT1 * PPN>(a.layer[1].w, wbuf + CH, wave, lane);
     }
 
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
     // ---------------- layer 0: K streamed from the sources
     {
         f32x16 acc[NT0], accc[NT0];
-        init_bias<NT0>(acc, a.layer[0].b, half);
+        init_bias<NT0>(acc, l0.b, half);
         zero_tiles<NT0>(accc);
         f32x16 x = load_ktile(a.kt[0], row, half);
         for (int kt = 0; kt < a.nkt; ++kt, ++c) {
@@ -110,7 +112,7 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
             __syncthreads();
             // x tile of kt+1 first, then chunk c+2: the next iteration's counted wait then covers the x tile
             const f32x16 xn = load_ktile(a.kt[kt + 1 < a.nkt ? kt + 1 : kt], row, half);
-            if (kt + DIST < a.nkt) dma_chunk<NT0 * PPN>(a.layer[0].w + (size_t)(kt + DIST) * NT0 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+            if (kt + DIST < a.nkt) dma_chunk<NT0 * PPN>(l0.w + (size_t)(kt + DIST) * NT0 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
             else if (NL > 1 && kt + DIST - a.nkt < HT) dma_chunk<NT1 * PPN>(a.layer[1].w + (size_t)(kt + DIST - a.nkt) * NT1 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
             mma_chunk<NT0, MODE>(x, acc, accc, wbuf + (c % NBUF) * CH, lane);
             x = xn;
@@ -189,7 +191,7 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
         const int tgt = a.tgt[row];
         segmean_epilogue<OT>(out, slab + wave * SegSlab<OT>::FLOATS, tile, nval, tgt, a.rowptr, a.y, a.partials, lane);
     } else {
-        store_rows<OT, EPI == EPI_STORE_RES>(out, a.y, a.ldy, a.ncols, a.res, a.ldres, row, row_ok, half);
+        store_rows<OT, EPI == EPI_STORE_RES>(out, a.y + cg * OT * 32, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
     }
 }
 
@@ -206,8 +208,15 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
     MLP_CASE(2, 4, 4, ACT_SWISH, true, false, EPI_STORE)
     MLP_CASE(2, 4, 4, ACT_SWISH, true, false, EPI_STORE_RES)
     MLP_CASE(1, 4, 4, ACT_NONE, false, false, EPI_STORE)
+    // EDSR convolutions as gathered-tap GEMMs (conv + ReLU, conv + skip)
+    MLP_CASE(1, 4, 4, ACT_RELU, true, false, EPI_STORE)
+    MLP_CASE(1, 4, 4, ACT_NONE, false, false, EPI_STORE_RES)
+    MLP_CASE(1, 2, 2, ACT_RELU, true, false, EPI_STORE)
+    MLP_CASE(1, 2, 2, ACT_NONE, false, false, EPI_STORE_RES)
     MLP_CASE(1, 2, 2, ACT_NONE, false, false, EPI_STORE)
     MLP_CASE(1, 1, 1, ACT_NONE, false, false, EPI_STORE)
+    MLP_CASE(1, 1, 1, ACT_RELU, true, false, EPI_STORE)
+    MLP_CASE(1, 1, 1, ACT_NONE, false, false, EPI_STORE_RES)
     MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_STORE)
     MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_STORE_RES)
     MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_SEGMEAN)
@@ -224,7 +233,7 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
 static int launch_mlp(mlp_fn fn, const MagnetMlpArgs* args, void* stream) {
     if (!fn) return -3;
     const int tiles = (args->M + 31) / 32;
-    hipLaunchKernelGGL(fn, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, *args);
+    hipLaunchKernelGGL(fn, dim3((tiles + 3) / 4, args->ncolgroups > 1 ? args->ncolgroups : 1), dim3(256), 0, (hipStream_t)stream, *args);
     return (int)hipGetLastError();
 }
 
@@ -233,6 +242,7 @@ extern "C" int magnet_mlp_bf16x6_f32(const MagnetMlpArgs* args, int nl, int ht, 
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (!args || args->M <= 0) return args && args->M == 0 ? 0 : -1;
     if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
+    if (args->ncolgroups > 1 && (nl != 1 || args->ncolgroups > MAGNET_MAX_LAYERS)) return -2;
     return launch_mlp(pick<GEMM_BF16X6>(nl, ht, ot, act, last_act, ln, epi), args, stream);
 }
 
@@ -241,5 +251,6 @@ extern "C" int magnet_mlp_fp16x3_f32(const MagnetMlpArgs* args, int nl, int ht, 
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (!args || args->M <= 0) return args && args->M == 0 ? 0 : -1;
     if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
+    if (args->ncolgroups > 1 && (nl != 1 || args->ncolgroups > MAGNET_MAX_LAYERS)) return -2;
     return launch_mlp(pick<GEMM_FP16X3>(nl, ht, ot, act, last_act, ln, epi), args, stream);
 }

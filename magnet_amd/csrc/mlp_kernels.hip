@@ -15,12 +15,12 @@
 // layer 0: K streamed tile by tile from the gathered sources (hipcc schedules the loads; a hand
 // pipelined version with sched_barriers measured 20-30 % slower, see DESIGN.md "what did not work")
 template <int NT>
-__device__ __forceinline__ void stream_layer(const MagnetMlpArgs& a, f32x16 (&out)[NT], int row, int lane) {
+__device__ __forceinline__ void stream_layer(const MagnetMlpArgs& a, const MagnetLayer l0, f32x16 (&out)[NT], int row, int lane) {
     const int half = lane >> 5;
-    init_bias<NT>(out, a.layer[0].b, half);
+    init_bias<NT>(out, l0.b, half);
     for (int kt = 0; kt < a.nkt; ++kt) {
         const f32x16 x = load_ktile(a.kt[kt], row, half);
-        mma_ktile<NT>(x, out, a.layer[0].w, kt, lane);
+        mma_ktile<NT>(x, out, l0.w, kt, lane);
     }
 }
 
@@ -35,12 +35,13 @@ __global__ void __launch_bounds__(256) k_mlp(const MagnetMlpArgs a) {
     const bool row_ok = row_raw < a.M;
     const int row = row_ok ? row_raw : (a.M - 1);
 
+    const int cg = (NL == 1) ? blockIdx.y : 0;          // column group (single-Linear launches may split their outputs)
     f32x16 out[OT];
     if (NL == 1) {
-        stream_layer<OT>(a, out, row, lane);
+        stream_layer<OT>(a, a.layer[cg], out, row, lane);
     } else {
         f32x16 h0[HT], h1[HT];
-        stream_layer<HT>(a, h0, row, lane);
+        stream_layer<HT>(a, a.layer[0], h0, row, lane);
 #pragma unroll
         for (int t = 0; t < HT; ++t) apply_act<ACT>(h0[t]);
         // middle layers, ping-pong h0 <-> h1 (fully unrolled so register arrays stay static)
@@ -71,7 +72,7 @@ __global__ void __launch_bounds__(256) k_mlp(const MagnetMlpArgs a) {
         const int tgt = a.tgt[row];
         segmean_epilogue<OT>(out, lds + wave * SegSlab<OT>::FLOATS, tile, nval, tgt, a.rowptr, a.y, a.partials, lane);
     } else {
-        store_rows<OT, EPI == EPI_STORE_RES>(out, a.y, a.ldy, a.ncols, a.res, a.ldres, row, row_ok, half);
+        store_rows<OT, EPI == EPI_STORE_RES>(out, a.y + cg * OT * 32, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
     }
 }
 
@@ -108,8 +109,15 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
     MLP_CASE(2, 4, 4, ACT_SWISH, true, false, EPI_STORE)
     MLP_CASE(2, 4, 4, ACT_SWISH, true, false, EPI_STORE_RES)
     MLP_CASE(1, 4, 4, ACT_NONE, false, false, EPI_STORE)
+    // EDSR convolutions as gathered-tap GEMMs (conv + ReLU, conv + skip)
+    MLP_CASE(1, 4, 4, ACT_RELU, true, false, EPI_STORE)
+    MLP_CASE(1, 4, 4, ACT_NONE, false, false, EPI_STORE_RES)
+    MLP_CASE(1, 2, 2, ACT_RELU, true, false, EPI_STORE)
+    MLP_CASE(1, 2, 2, ACT_NONE, false, false, EPI_STORE_RES)
     MLP_CASE(1, 2, 2, ACT_NONE, false, false, EPI_STORE)
     MLP_CASE(1, 1, 1, ACT_NONE, false, false, EPI_STORE)
+    MLP_CASE(1, 1, 1, ACT_RELU, true, false, EPI_STORE)
+    MLP_CASE(1, 1, 1, ACT_NONE, false, false, EPI_STORE_RES)
     // MAgNet 5-Linear ReLU MLPs: hidden 128 (HT 4) or 64 (HT 2)
     MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_STORE)
     MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_STORE_RES)
@@ -134,10 +142,11 @@ extern "C" int magnet_mlp_f32(const MagnetMlpArgs* args, int nl, int ht, int ot,
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (!args || args->M <= 0) return args && args->M == 0 ? 0 : -1;
     if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
+    if (args->ncolgroups > 1 && (nl != 1 || args->ncolgroups > MAGNET_MAX_LAYERS)) return -2;
     mlp_fn fn = pick(nl, ht, ot, act, last_act, ln, epi);
     if (!fn) return -3;
     const int tiles = (args->M + 31) / 32;
-    hipLaunchKernelGGL(fn, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, *args);
+    hipLaunchKernelGGL(fn, dim3((tiles + 3) / 4, args->ncolgroups > 1 ? args->ncolgroups : 1), dim3(256), 0, (hipStream_t)stream, *args);
     return (int)hipGetLastError();
 }
 

@@ -1,8 +1,19 @@
-"""EDSR feature encoder (reference models/backbones/edsr.py:32-60; effective res_scale is always 1
-because the reference passes it positionally into ``bias``).  A dense convolution stack:
-it runs through torch's MIOpen convolutions (SURVEY.md 8(f) rank 3 keeps a custom implicit-GEMM kernel
-as a later row); everything downstream of it is hand-written HIP."""
+"""EDSR feature encoder (reference models/backbones/edsr.py:32-60; effective res_scale is always 1 because the
+reference passes it positionally into ``bias``).
+
+Parameters keep the reference's names and torch ``Conv1d`` / ``Conv2d`` layouts (checkpoints load unchanged); the
+arithmetic runs in libmagnet_hip.so: every "same" convolution is ONE launch of the fused MLP
+kernel as an implicit GEMM - the k^d shifted neighbours of a pixel are gathered as k tiles through tap index tables
+(``magnet_conv_tap_index``), zero padding is an all-zero row appended to the channels-last map, ReLU and the skip
+connections are the kernel's activation / residual epilogues.  No im2col buffer, no MIOpen.
+"""
+from __future__ import annotations
+
+import torch
 from torch import nn
+
+from ... import ops
+from ...packing import default_gemm, pack, pad_to
 
 
 class ResBlock(nn.Module):
@@ -13,8 +24,15 @@ class ResBlock(nn.Module):
         self.act = nn.ReLU(True)
         self.conv_2 = conv(n_chan, n_chan, kernel_size, padding=kernel_size // 2)
 
-    def forward(self, x):
-        return self.conv_2(self.act(self.conv_1(x))) + x
+
+def _as_linear(conv, c_pad):
+    """conv weight [Co, Ci, k(, k)] -> Linear weight [Co, taps * c_pad], tap-major (row-major dy, dx), channels inside"""
+    w = conv.weight.detach().float()
+    co, ci = w.shape[:2]
+    w = w.reshape(co, ci, -1).permute(0, 2, 1)                  # [Co, taps, Ci]
+    if c_pad != ci:
+        w = torch.cat([w, torch.zeros(co, w.shape[1], c_pad - ci, device=w.device)], 2)
+    return w.reshape(co, -1)
 
 
 class EDSR(nn.Module):
@@ -24,8 +42,92 @@ class EDSR(nn.Module):
         self.head_conv = conv(in_chan, n_chan, kernel_size, padding=kernel_size // 2)
         self.res_layers = nn.Sequential(*[ResBlock(n_chan, kernel_size, mode) for _ in range(res_layers)])
         self.tail_conv = conv(n_chan, n_chan, kernel_size, padding=kernel_size // 2)
-        self.out_dim = n_chan
+        self.out_dim, self.in_chan, self.n_chan = n_chan, in_chan, n_chan
+        self.kernel_size, self.dim = kernel_size, 2 if mode == "2d" else 1
+        if n_chan % 32 or n_chan // 32 not in (2, 4):
+            raise NotImplementedError("the convolution kernels are instantiated for n_chan = 64 or 128")
+        if (kernel_size ** self.dim) * (n_chan // 32) > 36 or not kernel_size & 1:
+            raise NotImplementedError("odd kernel sizes with k^d * n_chan / 32 <= 36 k tiles are supported")
+        self._pack_key, self._pack, self._taps = None, None, {}
 
+    # ------------------------------------------------------------------ packed weights / tap tables (cached)
+    def packed(self, mode=None):
+        mode = mode or default_gemm()
+        params = list(self.parameters())
+        key = (params[0].device, sum(p._version for p in params), mode)
+        if self._pack_key != key:
+            cin = pad_to(self.in_chan)
+
+            def mk(conv, cp):
+                """(whole pack, per-32-output-column packs): the second form feeds the column-split launch"""
+                w, b = _as_linear(conv, cp), conv.bias.detach().float()
+                return pack(w, b, mode), [pack(w[g:g + 32], b[g:g + 32], mode) for g in range(0, w.shape[0], 32)]
+
+            self._pack = dict(head=mk(self.head_conv, cin), tail=mk(self.tail_conv, self.n_chan),
+                              blocks=[(mk(b.conv_1, self.n_chan), mk(b.conv_2, self.n_chan)) for b in self.res_layers])
+            self._pack_key = key
+        return self._pack
+
+    def _tap_table(self, B, spatial, device):
+        key = (B, tuple(spatial), str(device))
+        if key not in self._taps:
+            H, W = (spatial[0], spatial[1]) if self.dim == 2 else (1, spatial[0])
+            if len(self._taps) > 4:
+                self._taps.clear()
+            self._taps[key] = ops.conv_tap_index(B, H, W, self.kernel_size, self.dim, device)
+        return self._taps[key]
+
+    # ------------------------------------------------------------------ forward
+    def _plan(self, B, cin, spatial, dev):
+        """buffers + the 2 * res_layers + 2 prebuilt launches for one input geometry (cached with the packed weights)"""
+        pk = self.packed()
+        key = (B, cin, tuple(spatial), str(dev), self._pack_key)
+        if getattr(self, "_plan_key", None) == key:
+            return self._plan_val
+        P = B * int(torch.tensor(spatial).prod())
+        C, ot = self.n_chan, self.n_chan // 32
+        taps = self._tap_table(B, spatial, dev)
+        cp = pad_to(cin)
+        xin = torch.zeros(P + 1, cp, device=dev, dtype=torch.float32)           # + the zero-padding row
+        head = torch.zeros(P + 1, C, device=dev, dtype=torch.float32)           # row P of every map stays zero
+        work = [torch.zeros_like(head) for _ in range(3)]
+        launches = []
+
+        split = P < 16384                     # fewer than 128 workgroups of 128 rows: split the output columns as well
+
+        def conv(src, width, layer, dst, relu=False, res=None):
+            kts = ops.ktiles(*[ops.Term(src, width, idx=taps[t]) for t in range(taps.shape[0])])
+            kw = dict(nl=1, act=ops.ACT_RELU if relu else ops.ACT_NONE, last_act=relu,
+                      epi=ops.EPI_STORE_RES if res is not None else ops.EPI_STORE, res=res, y=dst, ldy=C)
+            if split:
+                launches.append(ops.mlp_plan(P, kts, layer[1], ht=1, ot=1, ncols=32, colgroups=ot, **kw))
+            else:
+                launches.append(ops.mlp_plan(P, kts, [layer[0]], ht=ot, ot=ot, **kw))
+            return dst
+
+        cur = conv(xin, cp, pk["head"], head)
+        for c1, c2 in pk["blocks"]:                                              # conv_2(relu(conv_1(x))) + x
+            mid, out = [w for w in work if w is not cur][:2]
+            conv(cur, C, c1, mid, relu=True)
+            cur = conv(mid, C, c2, out, res=cur)
+        out = conv(cur, C, pk["tail"], [w for w in work if w is not cur][0], res=head)   # tail_conv(res) + head
+        self._plan_key, self._plan_val = key, (xin, out, launches, P)
+        return self._plan_val
+
+    def rows(self, x):
+        """x [B, in_chan, W(, W)] -> channels-last feature rows [B * W^d, n_chan] (row-major pixels).  The returned
+        tensor is a view of a buffer that the next call overwrites."""
+        x = ops._f32(x, "EDSR input")
+        B, cin = x.shape[:2]
+        xin, out, launches, P = self._plan(B, cin, x.shape[2:], x.device)
+        xin[:P, :cin] = x.reshape(B, cin, -1).permute(0, 2, 1).reshape(P, cin)
+        for go in launches:
+            go()
+        return out[:P]
+
+    @torch.no_grad()
     def forward(self, x):
-        x = self.head_conv(x)
-        return self.tail_conv(self.res_layers(x)) + x
+        """[B, in_chan, W(, W)] -> [B, n_chan, W(, W)] (the reference's layout; the models consume ``rows`` directly)."""
+        B = x.shape[0]
+        r = self.rows(x)
+        return r.reshape(B, -1, self.n_chan).permute(0, 2, 1).reshape(B, self.n_chan, *x.shape[2:]).contiguous()

@@ -3,7 +3,7 @@ and, through ``DIM = 2``, ``models/magnet_cnn_2d.py`` (``MAgNetCNN_2d``).
 
 forward(x_t, coords, cell, t, hr_last, hiddens=None) -> (out_hr, out_lr, hr_points).
 
-  EDSR feature map                       -> torch (MIOpen) convolutions         backbones/edsr.py
+  EDSR feature map                       -> magnet_mlp_* as gathered-tap implicit GEMMs (backbones/edsr.py)
   shifted nearest-cell lookups (LIIF)    -> magnet_inr_grid_prepare_f32         magnet_cnn_2d.py:248-283
   proj_head MLP + LayerNorm per shift    -> magnet_mlp_f32 (row gather of the channels-last feature map)
   area blend with the opposite cell      -> magnet_inr_grid_blend_f32           magnet_cnn_2d.py:285-290
@@ -77,8 +77,7 @@ class MAgNetCNN(MagnetBase):
         t = ops._f32(t)
         x_t = ops._f32(x_t)
         coords = coords.reshape(B, Nq, d).float()
-        feat = self.feature_encoding(x_t)                                        # [B, C, W(, W)]
-        featT = feat.reshape(B, C, nlr).permute(0, 2, 1).reshape(B * nlr, C).contiguous()   # channels-last rows
+        featT = self.encoder.rows(x_t.reshape(B, T * x_t.shape[2], *x_t.shape[3:]))   # channels-last rows [B * W^d, C]
         # continuous_decoder
         rows = B * Nq * S
         cell_idx = torch.empty(rows * T, dtype=torch.int32, device=dev)

@@ -58,18 +58,23 @@ def ktiles(*groups):
     return out
 
 
-def mlp(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STORE, y=None, ldy=None, ncols=None,
-        res=None, tgt=None, rowptr=None, partials=None):
-    """Run the fused MLP kernel.  ``layers``: list of (packed_w, padded_b).  Returns y."""
+def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STORE, y=None, ldy=None, ncols=None,
+             res=None, tgt=None, rowptr=None, partials=None, colgroups=1):
+    """Build the argument block of one fused-MLP launch once and return a zero-argument callable that enqueues it on the
+    current stream.  For call sites that repeat the same launch on the same buffers (the EDSR convolution stack: 34
+    launches of up to 36 gathered k tiles each) this removes the per-call descriptor marshalling from the host path."""
     a = L.MlpArgs()
     a.M, a.nkt = int(M), len(kts)
-    assert 1 <= len(kts) <= L.MAX_KT and len(layers) == nl
-    keep = []
+    # colgroups G > 1 (single Linear only): ``layers`` holds G packed column slices of ot*32 outputs each; the launch
+    # gets G workgroup columns - more parallelism when M alone cannot fill the chip (a 64 x 64 EDSR map is 4096 rows)
+    assert 1 <= len(kts) <= L.MAX_KT and len(layers) == nl * colgroups and (colgroups == 1 or nl == 1)
+    a.ncolgroups = int(colgroups)
+    keep = [layers, ln, y, res, tgt, rowptr, partials]
     for i, tile in enumerate(kts):
         a.kt[i].n = len(tile)
         for j, (term, col) in enumerate(tile):
             t = _f32(term.t, "mlp source")
-            keep.append(t)
+            keep.append((t, term.idx))
             ld = t.stride(0) if t.dim() == 2 else t.shape[-1]
             assert ld % 4 == 0 and col % 4 == 0 and col + 32 <= ld, (ld, col)
             s = a.kt[i].s[j]
@@ -87,8 +92,21 @@ def mlp(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STO
     kind = layers[0][0].dtype                                 # float16: fp16x3, int16: bf16x6, float32: fp32 MFMA
     assert all(w.dtype == kind for w, _ in layers)
     name = {torch.float16: "magnet_mlp_fp16x3_f32", torch.int16: "magnet_mlp_bf16x6_f32", torch.float32: "magnet_mlp_f32"}[kind]
-    L.check(getattr(L.lib(), name)(C.byref(a), nl, ht, ot, act, int(last_act), int(ln is not None), epi, _stream()),
-            f"{name}(nl={nl},ht={ht},ot={ot},act={act},ln={ln is not None},epi={epi})")
+    fn = getattr(L.lib(), name)
+    ref = C.byref(a)
+    what = f"{name}(nl={nl},ht={ht},ot={ot},act={act},ln={ln is not None},epi={epi})"
+    scalars = (nl, ht, ot, act, int(last_act), int(ln is not None), epi)
+
+    def launch(_keep=keep, _a=a):
+        L.check(fn(ref, *scalars, _stream()), what)
+    return launch
+
+
+def mlp(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STORE, y=None, ldy=None, ncols=None,
+        res=None, tgt=None, rowptr=None, partials=None):
+    """Run the fused MLP kernel.  ``layers``: list of (packed_w, padded_b).  Returns y."""
+    mlp_plan(M, kts, layers, nl=nl, ht=ht, ot=ot, act=act, last_act=last_act, ln=ln, epi=epi, y=y, ldy=ldy, ncols=ncols,
+             res=res, tgt=tgt, rowptr=rowptr, partials=partials)()
     return y
 
 
@@ -151,6 +169,14 @@ def instance_norm(x, n_graphs, rows_per_graph, eps=1e-5, out=None, return_var=Fa
         o = (n_graphs * nchunks + n_graphs) * h
         return out, ws[o:o + n_graphs * h].view(n_graphs, h)
     return out
+
+
+def conv_tap_index(n_images, H, W, k, d, device):
+    """[k^d, P] int32 neighbour rows of every pixel of a channels-last map, P = zero-padding row"""
+    ntaps = k * k if d == 2 else k
+    tap = torch.empty(ntaps, n_images * H * W, dtype=torch.int32, device=device)
+    L.check(L.lib().magnet_conv_tap_index(n_images, H, W, k, d, _p(tap), _stream()), "conv_tap_index")
+    return tap
 
 
 # ------------------------------------------------------------------------------------ backward building blocks

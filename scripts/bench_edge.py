@@ -1,6 +1,6 @@
 """Dev microbench: time the MPNN hop kernels in isolation on the 256^2 graph (B trajectories)."""
 import sys, types
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from magnet_amd import ops, _lib
 from magnet_amd.models.factory import FACTORY

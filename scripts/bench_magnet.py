@@ -1,6 +1,6 @@
 """Dev timing of the full-size MAgNet configs of BASELINE.json (C4b magnet_cnn_2d, C5 magnet_gnn), 1 GPU."""
 import sys, time, types
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from magnet_amd.models.factory import FACTORY
 from magnet_amd.utils import make_coord

@@ -1,6 +1,6 @@
 """Dev timing of the small BASELINE configs (launch-latency regime): C1 mpnn 1D N=50 B=2 tw=25 nt=250."""
 import sys, time, types
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from magnet_amd.models.factory import FACTORY
 from oracle import models as O

@@ -1,6 +1,6 @@
 """Quick GPU timing of one mpnn_2d forward at W x W (dev helper, not the bench)."""
 import sys, time, types
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from magnet_amd.models.factory import FACTORY
 

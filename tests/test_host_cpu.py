@@ -23,10 +23,14 @@ def test_library_exports_every_declared_symbol():
 
 def test_mlp_struct_layout_matches_header():
     # sizes follow from the C declarations in include/magnet_hip.h
+    import re
+    hdr = open(_lib.HEADER).read()
+    assert int(re.search(r"#define MAGNET_MAX_KT (\d+)", hdr).group(1)) == _lib.MAX_KT
+    assert int(re.search(r"#define MAGNET_MAX_LAYERS (\d+)", hdr).group(1)) == _lib.MAX_LAYERS
     assert ctypes.sizeof(_lib.Src) == 32
     assert ctypes.sizeof(_lib.KTile) == 80
     assert ctypes.sizeof(_lib.Layer) == 16
-    assert ctypes.sizeof(_lib.MlpArgs) == 8 + 80 * 12 + 16 * 6 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(_lib.MlpArgs) == 8 + 80 * _lib.MAX_KT + 16 * 6 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
 
 
 def test_supported_mlp_variants():

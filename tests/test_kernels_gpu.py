@@ -217,3 +217,25 @@ def test_radius_search_ragged_graphs_duplicates_and_isolated_nodes(dim, loop):
         assert E == want.shape[1]
         assert torch.equal(torch.stack([found.long(), query.long()]).cpu(), want)
     assert int(torch.bincount(want[1]).max()) == (32 if loop else 33)
+
+
+@pytest.mark.parametrize("mode,n_chan,k,res_layers,shape", [("2d", 128, 3, 3, (2, 10, 13, 9)), ("1d", 128, 3, 2, (3, 25, 31)),
+                                                             ("1d", 64, 5, 1, (1, 7, 40)), ("2d", 64, 3, 1, (1, 4, 8, 8)),
+                                                             ("2d", 128, 3, 1, (4, 10, 64, 64))])   # 16384 rows: unsplit launch
+def test_edsr_gathered_tap_convolutions_match_torch(mode, n_chan, k, res_layers, shape):
+    """the HIP EDSR (convolutions as gathered-tap GEMMs, zero row for the padding) vs the oracle's torch convolutions"""
+    from magnet_amd.models.backbones.edsr import EDSR
+    from oracle.models import EDSR as OracleEDSR
+    torch.manual_seed(8)
+    ref = OracleEDSR(shape[1], n_chan, res_layers, k, mode)
+    net = EDSR(shape[1], n_chan, res_layers, k, 1, mode)
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda()
+    x = torch.randn(*shape)
+    with torch.no_grad():
+        want = ref(x)
+    got = net(x.cuda())
+    assert got.shape == want.shape
+    assert rel_l2(got, want) < 2e-6
+    rows = net.rows(x.cuda())                                    # channels-last rows, what the models consume
+    assert rel_l2(rows, want.reshape(shape[0], n_chan, -1).permute(0, 2, 1).reshape(-1, n_chan)) < 2e-6
