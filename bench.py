@@ -72,6 +72,38 @@ def synthetic_batch(W, B, seed, device):
     return {"u": u.to(device), "x": xy[None].repeat(B, 1, 1).to(device), "t": t[None].repeat(B, 1).to(device)}
 
 
+OPT = dict(lr=1e-3, weight_decay=0.0, factor=0.3, step_size=50, loss="l1")
+MAGNET_HP = {   # configs/model/magnet_cnn_2d.yaml (C4b) and configs/model/magnet_gnn.yaml with the 2-D data of C5
+    "magnet_cnn_2d": dict(OPT, time_slice=10, latent_dim=32, num_message_passing_steps=10, mlp_layers=4, mlp_hidden=64, radius=0.1,
+                          scales=1, n_chan=128, kernel_size=3, res_scale=1, res_layers=16, teacher_forcing=False,
+                          interpolation="area"),
+    "magnet_gnn": dict(OPT, time_slice=10, latent_dim=128, num_message_passing_steps=5, mlp_layers=4, mlp_hidden=128, radius=0.08,
+                       n_chan=128, teacher_forcing=False, codec_neighbors=4, noise=0, interpolation="area"),
+}
+
+
+def synthetic_magnet_batch(name, B, Wq, seed, device):
+    """SURVEY.md 8(d) C4b / C5 inputs: LR frames + HR query values over nt = 50 steps, queries = make_coord([Wq, Wq])."""
+    from magnet_amd.utils import make_coord
+    g = torch.Generator().manual_seed(seed)
+    hr_c = make_coord([Wq, Wq])[None].repeat(B, 1, 1)
+    t = torch.linspace(0, 1, NT)[None].repeat(B, 1)
+    hr = torch.randn(B, NT, Wq * Wq, 1, generator=g)
+    if name == "magnet_cnn_2d":
+        W = 64
+        batch = {"t": t, "lr_frames": torch.randn(B, NT, 1, W, W, generator=g), "hr_points": hr, "coords": hr_c,
+                 "cells": torch.full((B, Wq * Wq, 2), 2.0 / Wq)}
+        n_lr = W * W
+    else:
+        pts = torch.clamp(torch.randn(512, 2, generator=g) * 0.25, -1, 1)
+        pts = 2 * (pts - pts.min(0).values) / (pts.max(0).values - pts.min(0).values) - 1
+        lr_c = pts[::2][None].repeat(B, 1, 1)
+        n_lr = lr_c.shape[1]
+        batch = {"t": t, "lr_frames": torch.randn(B, NT, 1, n_lr, generator=g), "hr_points": hr, "coords_hr": hr_c,
+                 "coords_lr": lr_c}
+    return {k: v.to(device) for k, v in batch.items()}, n_lr + Wq * Wq
+
+
 def cpu_baseline(W=128):
     """oracle rollout of ONE trajectory on a W x W mesh on the host cores (forward time only)."""
     from oracle import models as O
@@ -99,6 +131,85 @@ def cpu_baseline(W=128):
                       f"({t_fwd:.1f} s; radius-graph build {t_graph:.1f} s excluded), fp32, torch {torch.__version__} CPU"}
 
 
+def bench_magnet(args, dev, rank, world, dist, max_over_ranks):
+    """C4b (magnet_cnn_2d, 64^2 LR grid -> 256^2 queries) / C5 (magnet_gnn, 256 LR nodes -> 256^2 queries): free-running
+    validation_step rollout (4 forwards = 40 predicted steps), nodes = LR nodes + queries; same JSON contract."""
+    from magnet_amd import ops
+    from magnet_amd.models.factory import FACTORY
+    name, B, K, Wm, Wq = args.workload, args.traj, args.steps, args.warmup, args.mesh
+    torch.manual_seed(0)
+    hp = MAGNET_HP[name]
+    model = FACTORY[name](types.SimpleNamespace(**hp)).to(dev).eval()
+    batch, nodes = synthetic_magnet_batch(name, B, Wq, 2000 + rank, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(Wm):
+        model.validation_step(batch, 0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        model.validation_step(batch, 0)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+    T = hp["time_slice"]
+    pred_steps = (NT - T) // T * T
+    value = world * B * nodes * pred_steps * K / elapsed
+    roof = None
+    if rank == 0:      # dominant kernel: the InteractionNetwork edge MLP (5 Linears + LayerNorm + CSR mean) of the joint graph
+        D, H = hp["latent_dim"], hp["mlp_hidden"]
+        mode = __import__("magnet_amd.packing", fromlist=["default_gemm"]).default_gemm()
+        entry = {"fp16x3": "magnet_mlp_fp16x3_f32", "bf16x6": "magnet_mlp_bf16x6_f32", "fp32": "magnet_mlp_f32"}[mode]
+        orig = getattr(ops.L.lib(), entry)
+        ev = []
+
+        def timed(a, nl, ht, ot, act, la, ln, epi, st):
+            big = nl == 5 and epi == ops.EPI_SEGMEAN
+            if big:
+                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record()
+            rc = orig(a, nl, ht, ot, act, la, ln, epi, st)
+            if big:
+                e_.record()
+                ev.append((s_, e_, a._obj.M))
+            return rc
+
+        setattr(ops.L._lib, entry, timed)
+        try:
+            model.validation_step(batch, 0)
+            torch.cuda.synchronize()
+        finally:
+            setattr(ops.L._lib, entry, orig)
+        Emax = max(m for _, _, m in ev)
+        sel = [(s_, e_) for s_, e_, m in ev if m == Emax]           # the joint-graph launches (the LR-only graph is tiny)
+        ms = sum(s_.elapsed_time(e_) for s_, e_ in sel) / len(sel)
+        flops = 2.0 * Emax * (3 * D * H + 3 * H * H + H * D)
+        ach = flops / (ms * 1e-3) / 1e12
+        nprod = SPLIT_PRODUCTS.get(mode, 1)
+        peak = MFMA_BF16_PEAK_TFLOPS / nprod if mode in SPLIT_PRODUCTS else MFMA_F32_PEAK_TFLOPS
+        roof = {"kernel": f"k_mlp_bf16<5 Linears, hidden {H}, LayerNorm, CSR-mean epilogue>", "bound": "mfma",
+                "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": None, "launch_ms": round(ms, 4), "launches_timed": len(sel), "flops_per_launch": flops,
+                "gemm_mode": mode, "edges": Emax}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"mesh-node-updates/s (nodes x steps x batch), {name} 256^2-query rollout", "value": value,
+            "unit": "mesh-node-updates/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (GEMMs: exact 2-piece fp16 split on the matrix cores, fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": f"{name} free-running rollout, {nodes - Wq * Wq} LR nodes + {Wq}x{Wq} queries, nt={NT}, "
+                                   f"time_slice={T} -> {pred_steps} predicted steps, {B} trajectories per GPU",
+                       "trajectories_per_gpu": B, "global_trajectories": B * world,
+                       "parallelism": f"batch-shard x{world}, no data-path collective"},
+            "roofline": roof, "cpu_baseline": None, "training_step": None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +219,8 @@ def main():
     ap.add_argument("--mesh", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=3, help="timed training steps of the extra 'training_step' leg (0: skip)")
+    ap.add_argument("--workload", default="mpnn_2d", choices=["mpnn_2d", "magnet_cnn_2d", "magnet_gnn"],
+                    help="mpnn_2d = the headline metric case; the two MAgNet 256^2 cases of SURVEY.md 8(d) (C4b, C5) on request")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -128,6 +241,8 @@ def main():
         else:
             dist.init_process_group(backend)
     W, B, K, Wm = args.mesh, args.traj, args.steps, args.warmup
+    if args.workload != "mpnn_2d":
+        return bench_magnet(args, dev, rank, world, dist, max_over_ranks)
 
     torch.manual_seed(0)
     model = FACTORY["mpnn_2d"](types.SimpleNamespace(**HP)).to(dev).eval()

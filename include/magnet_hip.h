@@ -167,6 +167,10 @@ int magnet_inr_grid_prepare_f32(const float* coords, const float* cell, const fl
 int magnet_inr_grid_blend_f32(const float* p, const float* area, int n_rows, int T, int C, int nshift, float* z,
                               void* stream);
 
+/* y[n_images][Ho][Wo] = F.interpolate(x[n_images][Hi][Wi], mode='bilinear' (d = 2) | 'linear' (d = 1, Hi = Ho = 1),
+ * align_corners=False): the rollout feedback of MAgNet[CNN], models/magnet_cnn.py:456-461, magnet_cnn_2d.py:466-472. */
+int magnet_resize_linear_f32(const float* x, int n_images, int Hi, int Wi, int Ho, int Wo, int d, float* y, void* stream);
+
 /* EDSR convolutions (models/backbones/edsr.py:32-60) run as gathered-tap GEMMs through magnet_mlp_*: a "same" k x k
  * (d = 2) or k (d = 1, H = 1) convolution over a channels-last map [P = n_images*H*W rows (+1 all-zero row), C] is one
  * Linear over the k^d shifted neighbours.  tap[t*P + p] = row of pixel p's neighbour for tap t (row-major dy, dx), or

@@ -254,3 +254,48 @@ extern "C" int magnet_conv_tap_index(int n_images, int H, int W, int k, int d, i
     hipLaunchKernelGGL(k_conv_tap_index, dim3(nb(total, 256)), dim3(256), 0, S_, n_images, H, W, k, d, tap);
     LAUNCH_CHECK();
 }
+
+// ---- rollout feedback of MAgNet[CNN]: F.interpolate(mode='(bi)linear', align_corners=False) of the predicted HR field
+// back onto the LR grid (models/magnet_cnn.py:456-461, models/magnet_cnn_2d.py:466-472).  Same arithmetic as ATen's
+// upsample_(bi)linear kernels: src = (dst + 0.5) * (in / out) - 0.5 clamped at 0, the two neighbours along each axis.
+__device__ __forceinline__ void lin_coeff(int dst, float scale, int in_size, int& i0, int& step, float& l0, float& l1) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i0 = i0 < in_size - 1 ? i0 : in_size - 1;
+    step = i0 < in_size - 1 ? 1 : 0;
+    l1 = src - (float)i0;
+    l0 = 1.0f - l1;
+}
+__global__ void k_resize_linear(const float* __restrict__ x, int n_images, int Hi, int Wi, int Ho, int Wo, int d,
+                                float* __restrict__ y) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n_images * Ho * Wo;
+    if (i >= total) return;
+    const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho);
+    const long img = i / ((long)Ho * Wo);
+    const float* src = x + img * Hi * Wi;
+    int w0, ws;
+    float wl0, wl1;
+    lin_coeff(xo, (float)Wi / (float)Wo, Wi, w0, ws, wl0, wl1);
+    if (d == 1) {
+        y[i] = wl0 * src[w0] + wl1 * src[w0 + ws];
+        return;
+    }
+    int h0, hs;
+    float hl0, hl1;
+    lin_coeff(yo, (float)Hi / (float)Ho, Hi, h0, hs, hl0, hl1);
+    const float* r0 = src + (long)h0 * Wi;
+    const float* r1 = src + (long)(h0 + hs) * Wi;
+    y[i] = hl0 * (wl0 * r0[w0] + wl1 * r0[w0 + ws]) + hl1 * (wl0 * r1[w0] + wl1 * r1[w0 + ws]);
+}
+
+extern "C" int magnet_resize_linear_f32(const float* x, int n_images, int Hi, int Wi, int Ho, int Wo, int d, float* y,
+                                        void* stream) {
+    (void)hipGetLastError();
+    if ((d != 1 && d != 2) || (d == 1 && (Hi != 1 || Ho != 1))) return -2;
+    const long total = (long)n_images * Ho * Wo;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_resize_linear, dim3(nb(total, 256)), dim3(256), 0, S_, x, n_images, Hi, Wi, Ho, Wo, d, y);
+    LAUNCH_CHECK();
+}

@@ -14,7 +14,6 @@ from __future__ import annotations
 import types
 
 import torch
-import torch.nn.functional as F
 
 from .. import _lib as L
 from .. import ops
@@ -148,9 +147,9 @@ class MAgNetCNN(MagnetBase):
             img = y.permute(0, 1, 3, 2)
             if self.DIM == 2:
                 wi = int(img.shape[-1] ** 0.5)
-                inp = F.interpolate(img.reshape(-1, 1, wi, wi), size=W, mode="bilinear", align_corners=False).reshape(B, -1, 1, W, W)
+                inp = ops.resize_linear(img.reshape(-1, wi, wi), (W, W), 2).reshape(B, -1, 1, W, W)
             else:
-                inp = F.interpolate(img.reshape(-1, 1, img.shape[-1]), size=W, mode="linear", align_corners=False).reshape(B, -1, 1, W)
+                inp = ops.resize_linear(img.reshape(-1, img.shape[-1]), (W,), 1).reshape(B, -1, 1, W)
             hr_last = y[:, -1]
         pred = torch.cat(outs, dim=1)
         self.log("val_loss", self.criterion(pred, fut), prog_bar=True)

@@ -171,6 +171,17 @@ def instance_norm(x, n_graphs, rows_per_graph, eps=1e-5, out=None, return_var=Fa
     return out
 
 
+def resize_linear(x, out_hw, d):
+    """x [n, Hi, Wi] (d = 2) or [n, Wi] (d = 1) -> [n, Ho, Wo] / [n, Wo], F.interpolate(..., align_corners=False)"""
+    x = _f32(x, "resize source")
+    n = x.shape[0]
+    Hi, Wi = (x.shape[1], x.shape[2]) if d == 2 else (1, x.shape[1])
+    Ho, Wo = (out_hw[0], out_hw[1]) if d == 2 else (1, out_hw[-1])
+    y = torch.empty((n, Ho, Wo) if d == 2 else (n, Wo), device=x.device, dtype=torch.float32)
+    L.check(L.lib().magnet_resize_linear_f32(_p(x), n, Hi, Wi, Ho, Wo, d, _p(y), _stream()), "resize_linear")
+    return y
+
+
 def conv_tap_index(n_images, H, W, k, d, device):
     """[k^d, P] int32 neighbour rows of every pixel of a channels-last map, P = zero-padding row"""
     ntaps = k * k if d == 2 else k

@@ -239,3 +239,17 @@ def test_edsr_gathered_tap_convolutions_match_torch(mode, n_chan, k, res_layers,
     assert rel_l2(got, want) < 2e-6
     rows = net.rows(x.cuda())                                    # channels-last rows, what the models consume
     assert rel_l2(rows, want.reshape(shape[0], n_chan, -1).permute(0, 2, 1).reshape(-1, n_chan)) < 2e-6
+
+
+@pytest.mark.parametrize("d,shape,out", [(2, (6, 40, 40), (16, 16)), (2, (3, 256, 256), (64, 64)), (2, (2, 17, 23), (30, 9)),
+                                         (1, (5, 40), (16,)), (1, (4, 33), (70,))])
+def test_resize_linear_matches_interpolate(d, shape, out):
+    from magnet_amd import ops
+    import torch.nn.functional as F
+    torch.manual_seed(9)
+    x = torch.randn(*shape, device="cuda")
+    want = F.interpolate(x[:, None], size=out if d == 2 else out[0], mode="bilinear" if d == 2 else "linear",
+                         align_corners=False)[:, 0]
+    got = ops.resize_linear(x, out, d)
+    assert got.shape == want.shape
+    assert rel_l2(got, want) < 1e-6
