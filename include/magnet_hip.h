@@ -228,6 +228,7 @@ int magnet_mpnn_edge_bwd_f32(const float* A, const float* Bm, const float* dagg,
 
 /* development knob (kernel variant selection for A/B measurements); not part of the data path */
 int magnet_debug_set_variant(int which, int value);
+int magnet_debug_set_mlp_ablation(int value); /* development: run-time ablation flags of the split-GEMM MLP kernel */
 
 #ifdef __cplusplus
 }

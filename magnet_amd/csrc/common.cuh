@@ -312,12 +312,24 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&t)[NT]) {
 }
 
 // first-layer k tile from the (gathered / concatenated / differenced) sources
-__device__ __forceinline__ f32x16 load_ktile(const MagnetKTile& d, int row, int half) {
+// Row selection and data fetch are separate steps so that a kernel can request the indices of k tile kt+2 while the
+// data of k tile kt+1 is in flight (a gathered load is two dependent memory round trips; done back to back inside the k
+// loop they stall the wave twice per tile).
+struct KRows {
+    long r0, r1;
+};
+__device__ __forceinline__ KRows ktile_rows(const MagnetKTile& d, int row) {
+    KRows r;
+    r.r0 = d.s[0].idx ? (long)d.s[0].idx[row] : (long)(row / d.s[0].rdiv);
+    r.r1 = 0;
+    if (d.n > 1) r.r1 = d.s[1].idx ? (long)d.s[1].idx[row] : (long)(row / d.s[1].rdiv);
+    return r;
+}
+__device__ __forceinline__ f32x16 ktile_data(const MagnetKTile& d, const KRows& r, int half) {
     f32x16 v;
     {
         const MagnetSrc& a = d.s[0];
-        const long r = a.idx ? (long)a.idx[row] : (long)(row / a.rdiv);
-        const float* p = a.p + r * a.ld + a.col + 4 * half;
+        const float* p = a.p + r.r0 * a.ld + a.col + 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(p + 8 * g);
@@ -329,8 +341,7 @@ __device__ __forceinline__ f32x16 load_ktile(const MagnetKTile& d, int row, int 
     }
     if (d.n > 1) {
         const MagnetSrc& a = d.s[1];
-        const long r = a.idx ? (long)a.idx[row] : (long)(row / a.rdiv);
-        const float* p = a.p + r * a.ld + a.col + 4 * half;
+        const float* p = a.p + r.r1 * a.ld + a.col + 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(p + 8 * g);
@@ -341,6 +352,9 @@ __device__ __forceinline__ f32x16 load_ktile(const MagnetKTile& d, int row, int 
         }
     }
     return v;
+}
+__device__ __forceinline__ f32x16 load_ktile(const MagnetKTile& d, int row, int half) {
+    return ktile_data(d, ktile_rows(d, row), half);
 }
 
 // LayerNorm over the NT*32 columns of each row (row split across lanes l and l^32)
@@ -430,56 +444,4 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Segment-mean epilogue.  The wave's 32 rows are consecutive CSR edges [e0, e0+nval).  Tile
-// values go through a wave-private LDS slab so that lanes become feature owners; runs of equal
-// target are summed in edge order.  A run that lies wholly inside the tile is divided by the
-// row's degree and written; a run cut by a tile boundary is written to partials[tile][0] (run
-// entered from the previous tile) or partials[tile][1] (run continues into the next tile) and
-// combined, in tile order, by k_segmean_fixup -> bitwise deterministic, no atomics.
-template <int NT>
-struct SegSlab {
-    static constexpr int PT = NT < 2 ? NT : 2;        // 32-column tiles per pass (slab = [32][PT*32+4] floats)
-    static constexpr int LD = PT * 32 + 4;
-    static constexpr int FLOATS = 32 * LD;            // per wave
-};
 
-template <int NT>
-__device__ __forceinline__ void segmean_epilogue(const f32x16 (&v)[NT], float* lds /* [32][SegSlab<NT>::LD] */,
-                                                  int tile, int nval, int tgt, const int32_t* __restrict__ rowptr,
-                                                  float* __restrict__ agg, float* __restrict__ partials,
-                                                  int lane) {
-    constexpr int D = NT * 32;
-    constexpr int PT = SegSlab<NT>::PT, LD = SegSlab<NT>::LD;
-    constexpr int PW = PT * 32;                       // columns per pass (32 or 64): one per lane
-    const int j = lane & 31, half = lane >> 5;
-    const int e0 = tile * 32;
-#pragma unroll
-    for (int p0 = 0; p0 < NT; p0 += PT) {
-#pragma unroll
-        for (int t = 0; t < PT; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 x = {v[p0 + t][4 * g], v[p0 + t][4 * g + 1], v[p0 + t][4 * g + 2], v[p0 + t][4 * g + 3]};
-                *reinterpret_cast<f32x4*>(lds + j * LD + t * 32 + 8 * g + 4 * half) = x;
-            }
-        wave_lds_sync();
-        const int f = p0 * 32 + lane;                 // this lane's output column in the pass
-        const bool fok = lane < PW;
-        float acc = 0.f;
-        for (int jj = 0; jj < nval; ++jj) {
-            const int tj = __builtin_amdgcn_readlane(tgt, jj);
-            if (fok) acc += lds[jj * LD + lane];
-            const int tn = (jj + 1 < nval) ? __builtin_amdgcn_readlane(tgt, jj + 1) : -1;
-            if (tn != tj) {
-                const int s = rowptr[tj], e = rowptr[tj + 1];
-                const bool complete = (s >= e0) && (e <= e0 + 32);
-                if (fok) {
-                    if (complete) agg[(size_t)tj * D + f] = acc / (float)(e - s);
-                    else partials[((size_t)tile * 2 + (s < e0 ? 0 : 1)) * D + f] = acc;
-                }
-                acc = 0.f;
-            }
-        }
-        wave_lds_sync();
-    }
-}

@@ -5,17 +5,21 @@
 
 struct TileMeta {            // what the epilogue of a tile needs, carried one iteration
     int tile, ti, tnext;
+    int rs, re;              // rowptr[ti], rowptr[ti + 1]: requested here, long before the epilogue needs them
     bool e_ok;
     float m1, m2, m4, m8, mb;
 };
 
-__device__ __forceinline__ TileMeta tile_meta(int tile, int E, const int32_t* __restrict__ tgt, int j) {
+__device__ __forceinline__ TileMeta tile_meta(int tile, int E, const int32_t* __restrict__ tgt,
+                                              const int32_t* __restrict__ rowptr, int j) {
     TileMeta md;
     md.tile = tile;
     const int e_raw = tile * 32 + j;
     md.e_ok = e_raw < E;
     md.ti = tgt[md.e_ok ? e_raw : E - 1];
     md.tnext = (e_raw + 1 < E && j < 31) ? tgt[e_raw + 1] : -2;
+    md.rs = rowptr[md.ti];
+    md.re = rowptr[md.ti + 1];
     const int t = md.e_ok ? md.ti : (-16 - j);
     const int jr = j & 15;
     const int t1 = dpp_i<DPP_SHR1, 0xF>(t), t2 = dpp_i<DPP_SHR2, 0xF>(t), t4 = dpp_i<DPP_SHR4, 0xF>(t);
@@ -28,3 +32,53 @@ __device__ __forceinline__ TileMeta tile_meta(int tile, int E, const int32_t* __
     return md;
 }
 
+
+// segmented inclusive sum of one register across the 32 row lanes (runs of equal targets)
+__device__ __forceinline__ float seg_scan_sum(float x, const TileMeta& md) {
+    x += md.m1 * dpp_f<DPP_SHR1, 0xF>(x);
+    x += md.m2 * dpp_f<DPP_SHR2, 0xF>(x);
+    x += md.m4 * dpp_f<DPP_SHR4, 0xF>(x);
+    x += md.m8 * dpp_f<DPP_SHR8, 0xF>(x);
+    x += md.mb * dpp_f<DPP_BCAST15, 0xA>(x);
+    return x;
+}
+
+// After seg_scan_sum the last lane of every run holds the run's sum: a finished row of `out` (divided by the row's
+// degree when MEAN) or a tile-boundary partial (partials[tile][0 = run entered from the previous tile | 1 = run continues
+// into the next tile][D]); k_segmean_fixup / k_segsum_fixup combine the partials in tile order (deterministic).
+template <int NT, bool MEAN>
+__device__ __forceinline__ void store_run_results(const f32x16 (&v)[NT], const TileMeta& md, float* __restrict__ out,
+                                                  float* __restrict__ partials, int half) {
+    constexpr int D = NT * 32;
+    if (md.e_ok && md.tnext != md.ti) {
+        const int e0 = md.tile * 32;
+        const int s = md.rs, en = md.re;
+        const bool complete = (s >= e0) && (en <= e0 + 32);
+        const float dn = (MEAN && complete) ? (float)(en - s) : 1.f;
+        float* dst = complete ? out + (size_t)md.ti * D : partials + ((size_t)md.tile * 2 + (s < e0 ? 0 : 1)) * D;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o = {v[nt][4 * g], v[nt][4 * g + 1], v[nt][4 * g + 2], v[nt][4 * g + 3]};
+                if (MEAN && complete) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = o[c] / dn;
+                }
+                *reinterpret_cast<f32x4*>(dst + nt * 32 + 8 * g + 4 * half) = o;
+            }
+    }
+}
+
+// CSR segment-mean epilogue of the MLP kernels: the wave's 32 rows are consecutive target-sorted edges of `tile`
+// (md = tile_meta(...) computed at the top of the kernel so that its loads are hidden behind the GEMMs)
+template <int NT>
+__device__ __forceinline__ void segmean_epilogue_dpp(f32x16 (&v)[NT], const TileMeta& md, int M, float* __restrict__ agg,
+                                                     float* __restrict__ partials, int lane) {
+    if (md.tile * 32 >= M) return;                                // wave-uniform: no rows in this tile
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[nt][i] = seg_scan_sum(v[nt][i], md);
+    store_run_results<NT, true>(v, md, agg, partials, lane >> 5);
+}

@@ -11,6 +11,7 @@
 // layer[l].w points at that layer's planes in fragment order [kt][nt][m][plane][64 lanes][8 bf16]
 // (packing.pack_linear_bf16x3), layer[l].b at the zero-padded fp32 bias.
 #include "common.cuh"
+#include "edge_tile.cuh"
 
 template <int A, int B>
 struct MaxI { static constexpr int v = A > B ? A : B; };
@@ -62,17 +63,27 @@ __device__ __forceinline__ void fold_tiles(f32x16 (&accM)[NT], f32x16 (&accC)[NT
     }
 }
 
+// development ablation flags (results invalid): 1 = no MFMA/LDS-read work, 2 = no weight DMA after the prologue, 4 = no epilogue,
+// 8 = no workgroup barriers, 16 = no gathered x loads after the first k tile.  Compiled in only with -DMAGNET_MLP_ABLATION:
+// even as never-taken run-time branches they cost the product kernel 20 % (the conditional loads break hipcc's software
+// pipelining of the gathers).
+#ifdef MAGNET_MLP_ABLATION
+__device__ int g_mlp_abl = 0;
+#define MLP_ABL_INIT const int abl = __builtin_amdgcn_readfirstlane(g_mlp_abl);
+#else
+#define MLP_ABL_INIT constexpr int abl = 0;
+#endif
+
 template <int MODE, int NL, int HT, int OT, int ACT, bool LAST_ACT, bool LN, int EPI>
 __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const MagnetMlpArgs a) {
+    MLP_ABL_INIT
     constexpr int NTMAX = MaxI<HT, OT>::v;
     constexpr int PPN = 2 * Split<MODE>::NP;                              // 1 KiB pieces per output tile and k tile
     constexpr int DIST = (NL >= 5 && HT >= 4) ? 2 : 1;                   // chunks requested ahead (measured: 2 pays only for the long 128-wide chains)
     constexpr int NBUF = DIST + 1;
     constexpr int CH = NTMAX * PPN * 64;                                   // u32x4 per chunk buffer
-    constexpr int SLAB = (EPI == EPI_SEGMEAN) ? 4 * SegSlab<OT>::FLOATS : 0;
-    __shared__ __attribute__((aligned(16))) u32x4 smem[NBUF * CH + (SLAB + 3) / 4];   // ONE LDS object (chunk ring + slab)
+    __shared__ __attribute__((aligned(16))) u32x4 smem[NBUF * CH];                    // weight chunk ring
     u32x4* wbuf = smem;
-    float* slab = reinterpret_cast<float*>(smem + NBUF * CH);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
@@ -80,6 +91,8 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
     const int row_raw = tile * 32 + (lane & 31);
     const bool row_ok = row_raw < a.M;
     const int row = row_ok ? row_raw : (a.M - 1);
+    TileMeta md;                                        // CSR-mean epilogue: requested now, hidden behind the GEMMs
+    if (EPI == EPI_SEGMEAN) md = tile_meta(tile, a.M, a.tgt, a.rowptr, lane & 31);
 
     constexpr int NT0 = (NL == 1) ? OT : HT;
     constexpr int NT1 = (NL == 2) ? OT : HT;            // output tiles of layer 1 (when it exists)
@@ -103,18 +116,22 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
         init_bias<NT0>(acc, l0.b, half);
         zero_tiles<NT0>(accc);
         f32x16 x = load_ktile(a.kt[0], row, half);
+        KRows rn = ktile_rows(a.kt[a.nkt > 1 ? 1 : 0], row);          // indices of k tile 1, requested one iteration early
         for (int kt = 0; kt < a.nkt; ++kt, ++c) {
-            // outstanding, oldest first: chunk c, x tile kt, chunk c+1  ->  leave only chunk c+1 in flight
+            // outstanding, oldest first: chunk c, x tile kt, indices of kt+1, chunk c+1  ->  leave only chunk c+1 in flight
             if (DIST == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (kt + 1 < a.nkt) wait_all_but_one_chunk<NT0 * PPN>();
             else if (NL > 1) wait_all_but_one_chunk<NT1 * PPN>();
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            // x tile of kt+1 first, then chunk c+2: the next iteration's counted wait then covers the x tile
-            const f32x16 xn = load_ktile(a.kt[kt + 1 < a.nkt ? kt + 1 : kt], row, half);
-            if (kt + DIST < a.nkt) dma_chunk<NT0 * PPN>(l0.w + (size_t)(kt + DIST) * NT0 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+            if (!(abl & 8)) __syncthreads();
+            // data of x tile kt+1 (its indices arrived during the previous iteration), indices of x tile kt+2, then
+            // chunk c+2: the next iteration's counted wait then covers both
+            const f32x16 xn = (abl & 16) ? x : ktile_data(a.kt[kt + 1 < a.nkt ? kt + 1 : kt], rn, half);
+            rn = ktile_rows(a.kt[kt + 2 < a.nkt ? kt + 2 : a.nkt - 1], row);
+            if (abl & 2) {
+            } else if (kt + DIST < a.nkt) dma_chunk<NT0 * PPN>(l0.w + (size_t)(kt + DIST) * NT0 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
             else if (NL > 1 && kt + DIST - a.nkt < HT) dma_chunk<NT1 * PPN>(a.layer[1].w + (size_t)(kt + DIST - a.nkt) * NT1 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
-            mma_chunk<NT0, MODE>(x, acc, accc, wbuf + (c % NBUF) * CH, lane);
+            if (!(abl & 1)) mma_chunk<NT0, MODE>(x, acc, accc, wbuf + (c % NBUF) * CH, lane);
             x = xn;
         }
         fold_tiles<NT0, MODE>(acc, accc);
@@ -151,9 +168,9 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
             if (!has_next || DIST == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (next_is_last_layer) wait_all_but_one_chunk<OT * PPN>();
             else wait_all_but_one_chunk<HT * PPN>();
-            __syncthreads();
+            if (!(abl & 8)) __syncthreads();
             // chunk c+2
-            {
+            if (!(abl & 2)) {
                 const int k2 = kt + DIST;
                 if (k2 < HT) {
                     if (last) dma_chunk<OT * PPN>(a.layer[l].w + (size_t)k2 * OT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
@@ -164,7 +181,8 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
                     else dma_chunk<HT * PPN>(a.layer[l + 1 < NL ? l + 1 : l].w + (size_t)k3 * HT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
                 }
             }
-            if (last) mma_chunk<OT, MODE>(src0 ? h0[kt] : h1[kt], out, cco, wbuf + (c % NBUF) * CH, lane);
+            if (abl & 1) {
+            } else if (last) mma_chunk<OT, MODE>(src0 ? h0[kt] : h1[kt], out, cco, wbuf + (c % NBUF) * CH, lane);
             else if (src0) mma_chunk<HT, MODE>(h0[kt], h1, cch, wbuf + (c % NBUF) * CH, lane);
             else mma_chunk<HT, MODE>(h1[kt], h0, cch, wbuf + (c % NBUF) * CH, lane);
         }
@@ -185,11 +203,10 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
     }
     if (LN) layer_norm_rows<OT>(out, a.ln_g, a.ln_b, a.ln_eps, half);
 
-    if (EPI == EPI_SEGMEAN) {
-        const int ntiles = (a.M + 31) / 32;
-        const int nval = tile < ntiles ? min(32, a.M - tile * 32) : 0;
-        const int tgt = a.tgt[row];
-        segmean_epilogue<OT>(out, slab + wave * SegSlab<OT>::FLOATS, tile, nval, tgt, a.rowptr, a.y, a.partials, lane);
+    if (abl & 4) {
+        if (out[0][0] == 12345.678f) a.y[0] = 1.f;      // keep the computation alive
+    } else if (EPI == EPI_SEGMEAN) {
+        segmean_epilogue_dpp<OT>(out, md, a.M, a.y, a.partials, lane);
     } else {
         store_rows<OT, EPI == EPI_STORE_RES>(out, a.y + cg * OT * 32, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
     }
@@ -253,4 +270,12 @@ extern "C" int magnet_mlp_fp16x3_f32(const MagnetMlpArgs* args, int nl, int ht, 
     if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
     if (args->ncolgroups > 1 && (nl != 1 || args->ncolgroups > MAGNET_MAX_LAYERS)) return -2;
     return launch_mlp(pick<GEMM_FP16X3>(nl, ht, ot, act, last_act, ln, epi), args, stream);
+}
+
+extern "C" int magnet_debug_set_mlp_ablation(int value) {
+#ifdef MAGNET_MLP_ABLATION
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_abl), &value, sizeof(int));
+#else
+    return value == 0 ? 0 : -2;      // ablations are not compiled into the product library
+#endif
 }

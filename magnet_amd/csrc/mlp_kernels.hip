@@ -11,6 +11,7 @@
 // models/mpnn.py:77-78,85-88,191-192; models/backbones/mlp.py:23-28 as used by
 // models/magnet_gnn.py:22-36,55-68,129-132,193-197.
 #include "common.cuh"
+#include "edge_tile.cuh"
 
 // layer 0: K streamed tile by tile from the gathered sources (hipcc schedules the loads; a hand
 // pipelined version with sched_barriers measured 20-30 % slower, see DESIGN.md "what did not work")
@@ -26,14 +27,14 @@ __device__ __forceinline__ void stream_layer(const MagnetMlpArgs& a, const Magne
 
 template <int NL, int HT, int OT, int ACT, bool LAST_ACT, bool LN, int EPI>
 __global__ void __launch_bounds__(256) k_mlp(const MagnetMlpArgs a) {
-    constexpr int LDS_FLOATS = (EPI == EPI_SEGMEAN) ? 4 * SegSlab<OT>::FLOATS : 1;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5;
     const int tile = blockIdx.x * 4 + wave;
     const int row_raw = tile * 32 + (lane & 31);
     const bool row_ok = row_raw < a.M;
     const int row = row_ok ? row_raw : (a.M - 1);
+    TileMeta md;                                        // CSR-mean epilogue: requested now, hidden behind the GEMMs
+    if (EPI == EPI_SEGMEAN) md = tile_meta(tile, a.M, a.tgt, a.rowptr, lane & 31);
 
     const int cg = (NL == 1) ? blockIdx.y : 0;          // column group (single-Linear launches may split their outputs)
     f32x16 out[OT];
@@ -67,10 +68,7 @@ __global__ void __launch_bounds__(256) k_mlp(const MagnetMlpArgs a) {
     if (LN) layer_norm_rows<OT>(out, a.ln_g, a.ln_b, a.ln_eps, half);
 
     if (EPI == EPI_SEGMEAN) {
-        const int ntiles = (a.M + 31) / 32;
-        const int nval = tile < ntiles ? min(32, a.M - tile * 32) : 0;
-        const int tgt = a.tgt[row];
-        segmean_epilogue<OT>(out, lds + wave * SegSlab<OT>::FLOATS, tile, nval, tgt, a.rowptr, a.y, a.partials, lane);
+        segmean_epilogue_dpp<OT>(out, md, a.M, a.y, a.partials, lane);
     } else {
         store_rows<OT, EPI == EPI_STORE_RES>(out, a.y + cg * OT * 32, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
     }

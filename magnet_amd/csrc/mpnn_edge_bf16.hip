@@ -19,38 +19,7 @@
 #include "edge_tile.cuh"
 
 // Swish + segmented inclusive scan of one output register across the 32 edge lanes
-__device__ __forceinline__ float scan_reg(float v, const TileMeta& md) {
-    float x = act_swish(v);
-    x += md.m1 * dpp_f<DPP_SHR1, 0xF>(x);
-    x += md.m2 * dpp_f<DPP_SHR2, 0xF>(x);
-    x += md.m4 * dpp_f<DPP_SHR4, 0xF>(x);
-    x += md.m8 * dpp_f<DPP_SHR8, 0xF>(x);
-    x += md.mb * dpp_f<DPP_BCAST15, 0xA>(x);
-    return x;
-}
-
-// the last lane of every run of equal targets holds the run's sum: finished mean or tile-boundary partial
-__device__ __forceinline__ void store_runs(const f32x16 (&v)[4], const TileMeta& md, const int32_t* __restrict__ rowptr,
-                                           float* __restrict__ agg, float* __restrict__ partials, int half) {
-    if (md.e_ok && md.tnext != md.ti) {
-        const int e0 = md.tile * 32;
-        const int s = rowptr[md.ti], en = rowptr[md.ti + 1];
-        const bool complete = (s >= e0) && (en <= e0 + 32);
-        const float dn = complete ? (float)(en - s) : 1.f;
-        float* dst = complete ? agg + (size_t)md.ti * 128 : partials + ((size_t)md.tile * 2 + (s < e0 ? 0 : 1)) * 128;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 o = {v[nt][4 * g], v[nt][4 * g + 1], v[nt][4 * g + 2], v[nt][4 * g + 3]};
-                if (complete) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = o[c] / dn;
-                }
-                *reinterpret_cast<f32x4*>(dst + nt * 32 + 8 * g + 4 * half) = o;
-            }
-    }
-}
+__device__ __forceinline__ float scan_reg(float v, const TileMeta& md) { return seg_scan_sum(act_swish(v), md); }
 
 template <int MODE, int ABL>
 __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__ A, const float* __restrict__ Bm,
@@ -89,10 +58,10 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < 16; ++i) prev[nt][i] = 0.f;
     }
-    TileMeta pmd = tile_meta(tile, E, tgt, j);      // placeholder until a real previous tile exists
+    TileMeta pmd = tile_meta(tile, E, tgt, rowptr, j);      // placeholder until a real previous tile exists
     bool have_prev = false;
     for (; tile < ntiles; tile += stride) {
-        const TileMeta md = tile_meta(tile, E, tgt, j);
+        const TileMeta md = tile_meta(tile, E, tgt, rowptr, j);
         const int tn = tile + stride < ntiles ? tile + stride : tile;     // clamped: last iteration prefetches unused data
         const int en = min(tn * 32 + j, E - 1);
         const float* pan = A + (size_t)tgt[en] * 128 + 4 * half;
@@ -141,7 +110,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (have_prev) store_runs(prev, pmd, rowptr, agg, partials, half);
+        if (have_prev) store_run_results<4, true>(prev, pmd, agg, partials, half);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             Split<MODE>::fold(out[nt], outc[nt]);
@@ -159,7 +128,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) prev[nt][i] = scan_reg(prev[nt][i], pmd);
-    store_runs(prev, pmd, rowptr, agg, partials, half);
+    store_run_results<4, true>(prev, pmd, agg, partials, half);
 }
 
 int g_edge6_ablation = 0;

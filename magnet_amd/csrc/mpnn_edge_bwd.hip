@@ -28,34 +28,6 @@ __device__ __forceinline__ float dswish(float x) {
     return s * (1.0f + x * (1.0f - s));
 }
 
-// segmented inclusive sum of one register across the 32 edge lanes
-__device__ __forceinline__ float scan_sum(float x, const TileMeta& md) {
-    x += md.m1 * dpp_f<DPP_SHR1, 0xF>(x);
-    x += md.m2 * dpp_f<DPP_SHR2, 0xF>(x);
-    x += md.m4 * dpp_f<DPP_SHR4, 0xF>(x);
-    x += md.m8 * dpp_f<DPP_SHR8, 0xF>(x);
-    x += md.mb * dpp_f<DPP_BCAST15, 0xA>(x);
-    return x;
-}
-
-// the last lane of every run of equal targets holds the run's sum: a finished row of dA or a tile-boundary partial
-__device__ __forceinline__ void store_run_sums(const f32x16 (&v)[4], const TileMeta& md, const int32_t* __restrict__ rowptr,
-                                               float* __restrict__ dA, float* __restrict__ partials, int half) {
-    if (md.e_ok && md.tnext != md.ti) {
-        const int e0 = md.tile * 32;
-        const int s = rowptr[md.ti], en = rowptr[md.ti + 1];
-        const bool complete = (s >= e0) && (en <= e0 + 32);
-        float* dst = complete ? dA + (size_t)md.ti * 128 : partials + ((size_t)md.tile * 2 + (s < e0 ? 0 : 1)) * 128;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 o = {v[nt][4 * g], v[nt][4 * g + 1], v[nt][4 * g + 2], v[nt][4 * g + 3]};
-                *reinterpret_cast<f32x4*>(dst + nt * 32 + 8 * g + 4 * half) = o;
-            }
-    }
-}
-
 // acc[nt] (+ cross accumulators) += W(planes in LDS) * x, x = the wave's [128 x 32] register tile.
 // While the matrix pipe works, x * store_scale is also written to HBM (row `dst`, may be null), one 16-byte chunk every
 // other MFMA group: HBM absorbs ~9 bytes per cycle and CU, so a burst of 16 stores would stall the wave on the full
@@ -144,10 +116,10 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
             }
     }
     for (; tile < ntiles; tile += stride) {
-        const TileMeta md = tile_meta(tile, E, tgt, j);
+        const TileMeta md = tile_meta(tile, E, tgt, rowptr, j);
         const int e = min(tile * 32 + j, E - 1);
         const int ti = md.ti;
-        const float inv_deg = 1.0f / (float)(rowptr[ti + 1] - rowptr[ti]);
+        const float inv_deg = 1.0f / (float)(md.re - md.rs);
         const size_t row = (size_t)e * 128 + 4 * half;
         const int tn = tile + stride < ntiles ? tile + stride : tile;     // clamped: the last iteration prefetches unused rows
         const int en = min(tn * 32 + j, E - 1);
@@ -246,10 +218,10 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
                     *reinterpret_cast<f32x4*>(dp_out + row + kt * 32 + 8 * g) = o;
                 }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[kt][4 * g + c] = scan_sum(acc[kt][4 * g + c], md);
+                for (int c = 0; c < 4; ++c) acc[kt][4 * g + c] = seg_scan_sum(acc[kt][4 * g + c], md);
             }
         }
-        store_run_sums(acc, md, rowptr, dA, partials, half);
+        store_run_results<4, false>(acc, md, dA, partials, half);
     }
 }
 

@@ -1,6 +1,7 @@
 // MPNN / MPNN_2d specific kernels (hidden width fixed at 128 by the reference's read-out
 // convolution, models/mpnn.py:140-163).
 #include "common.cuh"
+#include "edge_tile.cuh"
 
 // ---------------------------------------------------------------------------- node input
 // node_in[n, :] = [ u[n, 0:tw] | pos[n, 1] / L[0..dpos) | pos[n, 0] / tmax | 0 ... ]   (ld = KIN)
@@ -29,7 +30,6 @@ __global__ void __launch_bounds__(256) k_mpnn_edge(const float* __restrict__ A, 
                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
                                                    const int32_t* __restrict__ rowptr, int E, MagnetLayer W2,
                                                    float* __restrict__ agg, float* __restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * SegSlab<4>::FLOATS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5;
     const int tile = blockIdx.x * 4 + wave;
@@ -69,8 +69,7 @@ __global__ void __launch_bounds__(256) k_mpnn_edge(const float* __restrict__ A, 
         if (sacc == 123.456f) agg[tile] = sacc;
         return;
     }
-    const int nval = tile < ntiles ? min(32, E - tile * 32) : 0;
-    segmean_epilogue<4>(out, lds + wave * SegSlab<4>::FLOATS, tile, nval, ti, rowptr, agg, partials, lane);
+    segmean_epilogue_dpp<4>(out, tile_meta(tile < ntiles ? tile : 0, E, tgt, rowptr, lane & 31), tile < ntiles ? E : 0, agg, partials, lane);
 }
 
 // ---------------------------------------------------------------------------- fused edge kernel, v2
