@@ -288,9 +288,11 @@ struct Split<GEMM_FP16X3> {
     static __device__ __forceinline__ void mma(const u32x4 (&w)[2], const u32x4 (&x)[2], f32x16& accM, f32x16& accC) {
         const f16x8 wh = __builtin_bit_cast(f16x8, w[0]), wl = __builtin_bit_cast(f16x8, w[1]);
         const f16x8 xh = __builtin_bit_cast(f16x8, x[0]), xl = __builtin_bit_cast(f16x8, x[1]);
+        // the main product sits between the two cross products: no two consecutive MFMAs write the same accumulator
+        // (the matrix pipe stalls on a back-to-back dependent accumulate), and each accumulator's own order is unchanged
         accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, accC, 0, 0, 0);
-        accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accC, 0, 0, 0);
         accM = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, accM, 0, 0, 0);
+        accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accC, 0, 0, 0);
     }
     static __device__ __forceinline__ void fold(f32x16& accM, const f32x16& accC) {
 #pragma unroll

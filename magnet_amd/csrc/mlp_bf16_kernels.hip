@@ -38,21 +38,57 @@ __device__ __forceinline__ void wait_all_but_one_chunk() {
 }
 
 // acc[nt] += W(chunk)[nt] * x   for one k tile whose planes sit in LDS at `wl` ([nt][m][plane][64])
-template <int NT, int MODE>
+// acc[nt] += W(chunk)[nt] * x   for one k tile whose planes sit in LDS at `wl` ([nt][m][plane][64]).
+// PIPE (the 128-wide 5-Linear chains, one wave per SIMD at ~400 registers): left alone hipcc emits
+// "ds_read, s_waitcnt lgkmcnt(0), v_mfma" - a full LDS latency per MFMA group with nobody else on the SIMD to hide it.
+// So the weight fragments of group g+1 are requested before the MFMAs of group g (double-buffered registers), the
+// split of the second 16-k slot is spread over the groups of the first, and a sched_barrier pins the order
+// (C5 edge MLP 2.42 -> 2.25 ms).  For the narrower / shorter chains, which run two waves per SIMD, the plain form is
+// faster (the pinned order costs registers: +48 spills in the 2-Linear node update).
+template <int NT, int MODE, bool PIPE>
 __device__ __forceinline__ void mma_chunk(const f32x16& x, f32x16 (&accM)[NT], f32x16 (&accC)[NT], const u32x4* wl, int lane) {
     constexpr int NP = Split<MODE>::NP;
+    if (!PIPE) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        u32x4 xs[NP];
-        split_slot<MODE>(x, m, xs);
+        for (int m = 0; m < 2; ++m) {
+            u32x4 xs[NP];
+            split_slot<MODE>(x, m, xs);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const u32x4* wp = wl + ((nt * 2 + m) * NP) * 64 + lane;
-            u32x4 w[NP];
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x4* wp = wl + ((nt * 2 + m) * NP) * 64 + lane;
+                u32x4 w[NP];
 #pragma unroll
-            for (int q = 0; q < NP; ++q) w[q] = wp[64 * q];
-            Split<MODE>::mma(w, xs, accM[nt], accC[nt]);
+                for (int q = 0; q < NP; ++q) w[q] = wp[64 * q];
+                Split<MODE>::mma(w, xs, accM[nt], accC[nt]);
+            }
         }
+        return;
+    }
+    constexpr int NG = 2 * NT;                          // groups g = m * NT + nt
+    constexpr int AHEAD = 2;                            // fragments requested this many groups ahead
+    u32x4 xs[2][NP], wr[AHEAD + 1][NP];
+    split_slot<MODE>(x, 0, xs[0]);
+#pragma unroll
+    for (int g0 = 0; g0 < AHEAD && g0 < NG; ++g0) {
+        const u32x4* wp = wl + (((g0 % NT) * 2 + g0 / NT) * NP) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) wr[g0][q] = wp[64 * q];
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int m = g / NT, nt = g % NT;
+        if (g + AHEAD < NG) {
+            const int m1 = (g + AHEAD) / NT, n1 = (g + AHEAD) % NT;
+            const u32x4* wp = wl + ((n1 * 2 + m1) * NP) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) wr[(g + AHEAD) % (AHEAD + 1)][q] = wp[64 * q];
+        }
+        if (m == 0) {                                   // quarters of slot 1: 4 / NT per group
+#pragma unroll
+            for (int p = nt * 4 / NT; p < (nt + 1) * 4 / NT; ++p) Split<MODE>::quarter(x, 1, p, xs[1]);
+        }
+        Split<MODE>::mma(wr[g % (AHEAD + 1)], xs[m], accM[nt], accC[nt]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 template <int NT, int MODE>
@@ -75,12 +111,13 @@ __device__ int g_mlp_abl = 0;
 #endif
 
 template <int MODE, int NL, int HT, int OT, int ACT, bool LAST_ACT, bool LN, int EPI>
-__global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const MagnetMlpArgs a) {
+__global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
     MLP_ABL_INIT
     constexpr int NTMAX = MaxI<HT, OT>::v;
     constexpr int PPN = 2 * Split<MODE>::NP;                              // 1 KiB pieces per output tile and k tile
     constexpr int DIST = (NL >= 5 && HT >= 4) ? 2 : 1;                   // chunks requested ahead (measured: 2 pays only for the long 128-wide chains)
     constexpr int NBUF = DIST + 1;
+    constexpr bool PIPE = (NL >= 5 && HT >= 4);                          // see mma_chunk
     constexpr int CH = NTMAX * PPN * 64;                                   // u32x4 per chunk buffer
     __shared__ __attribute__((aligned(16))) u32x4 smem[NBUF * CH];                    // weight chunk ring
     u32x4* wbuf = smem;
@@ -131,7 +168,7 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
             if (abl & 2) {
             } else if (kt + DIST < a.nkt) dma_chunk<NT0 * PPN>(l0.w + (size_t)(kt + DIST) * NT0 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
             else if (NL > 1 && kt + DIST - a.nkt < HT) dma_chunk<NT1 * PPN>(a.layer[1].w + (size_t)(kt + DIST - a.nkt) * NT1 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
-            if (!(abl & 1)) mma_chunk<NT0, MODE>(x, acc, accc, wbuf + (c % NBUF) * CH, lane);
+            if (!(abl & 1)) mma_chunk<NT0, MODE, PIPE>(x, acc, accc, wbuf + (c % NBUF) * CH, lane);
             x = xn;
         }
         fold_tiles<NT0, MODE>(acc, accc);
@@ -182,9 +219,9 @@ __global__ void __launch_bounds__(256, (NL <= 2 ? 2 : 1)) k_mlp_bf16(const Magne
                 }
             }
             if (abl & 1) {
-            } else if (last) mma_chunk<OT, MODE>(src0 ? h0[kt] : h1[kt], out, cco, wbuf + (c % NBUF) * CH, lane);
-            else if (src0) mma_chunk<HT, MODE>(h0[kt], h1, cch, wbuf + (c % NBUF) * CH, lane);
-            else mma_chunk<HT, MODE>(h1[kt], h0, cch, wbuf + (c % NBUF) * CH, lane);
+            } else if (last) mma_chunk<OT, MODE, PIPE>(src0 ? h0[kt] : h1[kt], out, cco, wbuf + (c % NBUF) * CH, lane);
+            else if (src0) mma_chunk<HT, MODE, PIPE>(h0[kt], h1, cch, wbuf + (c % NBUF) * CH, lane);
+            else mma_chunk<HT, MODE, PIPE>(h1[kt], h0, cch, wbuf + (c % NBUF) * CH, lane);
         }
         if (last) fold_tiles<OT, MODE>(out, cco);
         else if (src0) fold_tiles<HT, MODE>(h1, cch);
