@@ -82,3 +82,39 @@ __device__ __forceinline__ void segmean_epilogue_dpp(f32x16 (&v)[NT], const Tile
         for (int i = 0; i < 16; ++i) v[nt][i] = seg_scan_sum(v[nt][i], md);
     store_run_results<NT, true>(v, md, agg, partials, lane >> 5);
 }
+
+// acc[nt] (+ cross accumulators) += W(planes in LDS) * x, x = the wave's [128 x 32] register tile.
+// While the matrix pipe works, x * store_scale is also written to HBM (row `dst`, may be null), one 16-byte chunk every
+// other MFMA group: HBM absorbs ~9 bytes per cycle and CU, so a burst of 16 stores would stall the wave on the full
+// memory queue; spread out, the stores drain behind the GEMM.
+template <int MODE>
+__device__ __forceinline__ void gemm128(const u32x4* __restrict__ wl, const f32x16 (&x)[4], f32x16 (&acc)[4], f32x16 (&accc)[4],
+                                        int lane, float* __restrict__ dst, float store_scale) {
+    constexpr int NP = Split<MODE>::NP;
+    u32x4 xs[2][NP], wr[2][NP];
+    split_slot<MODE>(x[0], 0, xs[0]);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) wr[0][q] = wl[64 * q + lane];
+#pragma unroll
+    for (int gq = 0; gq < 32; ++gq) {             // gq = slot * 4 + nt, slot = kt * 2 + m
+        const int slot = gq >> 2, nt = gq & 3;
+        if (gq + 1 < 32) {
+            const int s1 = (gq + 1) >> 2, n1 = (gq + 1) & 3;
+            const u32x4* wp = wl + ((((s1 >> 1) * 4 + n1) * 2 + (s1 & 1)) * NP) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) wr[(gq + 1) & 1][q] = wp[64 * q];
+        }
+        if (slot + 1 < 8) Split<MODE>::quarter(x[(slot + 1) >> 1], (slot + 1) & 1, nt, xs[(slot + 1) & 1]);
+        Split<MODE>::mma(wr[gq & 1], xs[slot & 1], acc[nt], accc[nt]);
+        if (dst && !(gq & 1)) {
+            const int c = gq >> 1, t = c >> 2, g = c & 3;
+            const f32x4 o = {x[t][4 * g] * store_scale, x[t][4 * g + 1] * store_scale, x[t][4 * g + 2] * store_scale,
+                             x[t][4 * g + 3] * store_scale};
+            *reinterpret_cast<f32x4*>(dst + t * 32 + 8 * g) = o;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) Split<MODE>::fold(acc[nt], accc[nt]);
+}
+
