@@ -100,3 +100,45 @@ def test_graph_without_edges_and_odd_sizes():
             want = oracle.validation_step(batch)
         assert not torch.isnan(pred).any()
         assert rel_l2(pred, want) < 5 * OUT_TOL, neighbors
+
+
+def test_full_size_256x256_properties():
+    """BASELINE.json's metric case at full size (256 x 256 mesh, nt = 50, tw = 10), where the CPU oracle would take minutes:
+    size-independent properties instead - the radius graph against its closed form on a regular grid, bitwise
+    run-to-run determinism, independence of a trajectory from its batch mates and from the batch order, linearity of the
+    Euler read-out in dt."""
+    import bench
+    from magnet_amd.models.factory import FACTORY
+    import types
+    W, B = 256, 2
+    torch.manual_seed(0)
+    model = FACTORY["mpnn_2d"](types.SimpleNamespace(**bench.HP)).cuda().eval()
+    batch = bench.synthetic_batch(W, B, 7, "cuda")
+    # ---- graph: neighbors = 4 on a regular grid -> radius 4 * |dx - dy| + 1e-4 with dx = (0, h), dy = (h, 0): 4 sqrt(2) h.
+    # Offsets (a, b) with a^2 + b^2 <= 32 (the +1e-4 admits the corner (4, 4)): 101 points incl. self -> more than the cap: every interior node keeps the 33 lowest
+    # indices of its disc and drops itself if it is among them (Q3) -> in-degree 32 or 33 everywhere.
+    pred = model.validation_step(batch, 0)
+    csr = model._topo.csr
+    deg = (csr.rowptr[1:] - csr.rowptr[:-1]).cpu()
+    assert csr.N == B * W * W and int(deg.max()) == 33 and int(deg.min()) >= 14
+    interior = deg.view(B, W, W)[:, 8:-8, 8:-8]
+    assert int(interior.min()) >= 32
+    src, tgt = csr.src.long().cpu(), csr.tgt.long().cpu()
+    assert bool((src // (W * W) == tgt // (W * W)).all())                       # no edge crosses trajectories
+    ds = (src % (W * W) // W - tgt % (W * W) // W) ** 2 + (src % W - tgt % W) ** 2
+    assert int(ds.max()) <= 32 and int(ds.min()) >= 1                           # inside the disc, no self loops
+    # ---- determinism (bitwise) and finiteness
+    assert torch.isfinite(pred).all()
+    assert torch.equal(pred, model.validation_step(batch, 0))
+    # ---- a trajectory does not depend on its batch mates or on the batch order (rounding level: tile boundaries move)
+    swapped = {k: v.flip(0) for k, v in batch.items()}
+    assert rel_l2(model.validation_step(swapped, 0).flip(0), pred) < 1e-6
+    alone = model.validation_step({k: v[1:2] for k, v in batch.items()}, 0)
+    assert rel_l2(alone, pred[1:2]) < 1e-6
+    # ---- Euler read-out: out - u_last is linear in dt (mpnn.py:197-201) for a fixed graph input
+    u, x, t = model._unpack(batch)
+    g = model._build_graph(u[:, :10], t, x, [model._first_step()] * B)
+    dt = t[0][1] - t[0][0]
+    y1 = model(g, x[0, -1], t[0, -1], dt) - g.x[:, -1:]
+    y2 = model(g, x[0, -1], t[0, -1], 2 * dt) - g.x[:, -1:]
+    assert rel_l2(y2, 2 * y1) < 1e-5
