@@ -28,6 +28,11 @@ Extra objects on the JSON line:
   cpu_baseline  - the oracle (torch-CPU restatement of the reference op sequence) timed on this
                   box's host cores on a bounded sample (one rollout of one 128 x 128 trajectory;
                   forward calls only, graph construction excluded), rank 0, N = 1 only.
+  traffic (inside both roofline objects) - HBM bytes per launch from the newest committed PMC measurement of this same
+                  command (profiles/r*/traffic_v*.json <- scripts/collect_traffic.py <- two separate rocprofv3 --pmc passes,
+                  FETCH_SIZE doubled per the gfx950 correction); null when the workload differs from the recorded one.
+                  Edge kernel 1.58 GB (2.1x its 0.75 GB algorithmic minimum: gathered Bm rows are fetched once per XCD L2),
+                  scatter-mean 4.57 GB = 1.00x algorithmic.
   training_step - the same workload trained: rollout with tape, HIP backward
                   kernels, ONE flat gradient all-reduce over RCCL, fused Adam; ms per step and the node-updates/s it
                   corresponds to (all ranks), `--train-steps` timed steps after one warm-up.  Never part of `value`.
@@ -102,6 +107,24 @@ def synthetic_magnet_batch(name, B, Wq, seed, device):
         batch = {"t": t, "lr_frames": torch.randn(B, NT, 1, n_lr, generator=g), "hr_points": hr, "coords_hr": hr_c,
                  "coords_lr": lr_c}
     return {k: v.to(device) for k, v in batch.items()}, n_lr + Wq * Wq
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the newest committed PMC measurement of this same bench command
+    (profiles/r*/traffic_v*.json, written by scripts/collect_traffic.py from two separate rocprofv3 --pmc passes -
+    FETCH_SIZE and WRITE_SIZE cannot share a pass - with the gfx950 FETCH_SIZE correction).  bench.py cannot run the
+    profiler on itself, so this is a recorded measurement, not a live one; None when no file is present."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_v*.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(os.path.dirname(f)) + os.path.basename(f))])
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel)
+    except Exception:  # noqa: BLE001
+        return None, None
+    return (k["traffic"], os.path.relpath(files[-1], ROOT)) if k else (None, None)
 
 
 def cpu_baseline(W=128):
@@ -334,10 +357,13 @@ def main():
                 "achieved": round(ach, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "launch_ms": round(ms, 4), "launches_timed": len(ev), "flops_per_launch": flops, "gemm_mode": mode,
+                "algorithmic_hbm_bytes": 3 * N * H * 4 + 2 * E * 4 + 4 * (N + 1),
                 "executed_mfma_tflops": round(ach * nprod, 1), "mfma_16bit_dense_peak": MFMA_BF16_PEAK_TFLOPS,
                 "fp32_mfma_peak_for_reference": MFMA_F32_PEAK_TFLOPS,
                 "note": "fp32 GEMM evaluated through an exact split into 16-bit pieces on the matrix cores "
                         f"({nprod} MFMA products per fp32 product, fp32 accumulate); peak = 2500 / {nprod}"}
+        if W == 256 and B == 4 and mode in SPLIT_PRODUCTS:     # the recorded PMC passes are of this exact workload
+            roof["traffic"], roof["traffic_source"] = measured_traffic("k_mpnn_edge6")
         msg = torch.randn(E, H, device=dev)
         out = torch.empty(N, H, device=dev)
         for _ in range(3):
@@ -355,6 +381,8 @@ def main():
         roof_sc = {"kernel": "k_segment_mean<128>", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(ms_sc, 4),
                    "bytes_per_launch": nbytes}
+        if W == 256 and B == 4:
+            roof_sc["traffic"], roof_sc["traffic_source"] = measured_traffic("k_segment_mean<128>")
         del msg, out
 
     cpu = None
