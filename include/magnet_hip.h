@@ -199,8 +199,35 @@ int magnet_segment_sum128_f32(const float* x, const int32_t* rowptr, const int32
  * kc in {32,64,96,128}; workspace: nblk*(128*kc+128) + 128*kc floats, nblk = min(512, ceil(M/32)) */
 int magnet_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, int xcol, int kc, long M, float* dW, int ldw,
                      int wcol, float* db, float* workspace, int accumulate, void* stream);
+/* general form: dY has n_out in {32, 64, 128} columns, dW is [n_out][ldw] (same workspace formula) */
+int magnet_wgrad_n_f32(const float* dY, int ldy, int n_out, const float* X, int ldx, int xcol, int kc, long M, float* dW,
+                       int ldw, int wcol, float* db, float* workspace, int accumulate, void* stream);
 int magnet_reduce_partials_f32(const float* partial, int nblk, long n, float scale, float* out, int accumulate,
                                void* stream);
+
+/* ---- backward of the generic fused MLP op and of the MAgNet[GNN]-specific kernels (magnet_train_kernels.hip): what torch
+ *      autograd does for models/magnet_gnn.py:312-376 and models/backbones/mlp.py:23-28 + nn.LayerNorm in the reference. ---- */
+/* x0[M][nkt*32] = the first-layer input magnet_mlp_* streams from its k-tile descriptors (materialised for the backward) */
+int magnet_mlp_materialize_input_f32(const magnet_mlp_args_t* args, float* x0, int ldx, void* stream);
+int magnet_relu_bwd_f32(const float* dy, const float* y, float* dz, long n, void* stream);
+/* LayerNorm backward over rows of D <= 256 columns from the pre-norm z; part: [min(1024, ceil(rows/4))][2][D] partial
+ * (dgamma | dbeta) sums for magnet_reduce_partials_f32 */
+int magnet_layernorm_bwd_f32(const float* z, int ldz, const float* dy, int ldd, const float* gamma, long rows, int D, float eps,
+                             float* dz, int ldo, float* part, void* stream);
+/* dm[e][0:D] = dagg[tgt[e]][0:D] / deg(tgt[e]) */
+int magnet_edge_mean_bwd_cols_f32(const float* dagg, const int32_t* tgt, const int32_t* rowptr, long n_edges, int D, float* dm,
+                                  int ldm, void* stream);
+/* out[r][ocol:ocol+width] (+)= scale * sum_{k in CSR row r} x[perm ? perm[k] : k][xcol:xcol+width]; width in {4..256}, a
+ * power of two times 4: the scatter-add that undoes a row gather */
+int magnet_segment_sum_cols_f32(const float* x, int ldx, int xcol, const int32_t* rowptr, const int32_t* perm, int n_rows,
+                                int width, float scale, float* out, int ldo, int ocol, int accumulate, void* stream);
+/* backward of magnet_inr_knn_blend_f32: dbase [2*nq][C], dvq [2*nq][T] (per (query, neighbour), to be scatter-added to the
+ * LR nodes), part: [min(1024, ceil(nq/4))][2][C] partial (dwv | dwt) sums */
+int magnet_inr_knn_blend_bwd_f32(const float* dz, const float* w, const float* vals, const int32_t* nn2, const float* t,
+                                 int t_ld, const float* wv, int n_graphs, int L, int Nq, int T, int C, int mode, float* dbase,
+                                 float* dvq, float* part, void* stream);
+int magnet_euler_update_bwd_f32(const float* dout, const float* t, int t_ld, int n_graphs, int nodes_per_graph, int T,
+                                int T_out, float* dret, int ld_ret, float* dlast, void* stream);
 /* backward of InstanceNorm (mpnn.py:63,70) from the kept output yhat and biased variance var [n_graphs][H];
  * workspace: (2*n_graphs*ceil(rows/128) + 2*n_graphs)*H floats */
 int magnet_instance_norm_bwd_f32(const float* dy, const float* yhat, const float* var, int n_graphs, int rows_per_graph,

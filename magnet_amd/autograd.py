@@ -1,0 +1,353 @@
+"""Differentiable wrappers of the HIP ops used by the MAgNet models (training of MAgNet[GNN], BASELINE.json configs[4]).
+
+The reference trains through torch autograd over ATen / PyG ops.  Here every arithmetic op of the forward is a HIP
+kernel, so each one is wrapped in a ``torch.autograd.Function`` whose backward is again HIP kernels; torch's autograd
+only chains them and differentiates the data movement in between (``cat`` / ``permute`` / ``reshape`` / slicing), which
+keeps the rollout feedback (``models/magnet_gnn.py:442-475``) differentiable without bespoke glue.
+
+``mlp`` is the workhorse: the fused gather/concat -> N x (Linear + ReLU) -> [LayerNorm] -> store | +residual | CSR-mean
+kernel.  Its forward is the inference kernel, unchanged.  Its backward recomputes the chain layer by layer (one-Linear
+launches of the same kernel, activations materialised), then walks it back: LayerNorm backward, weight gradients with
+``magnet_wgrad_n_f32`` (fp32 MFMA, fixed-order reduction), data gradients with transposed packs in the bf16x6 split
+(full fp32 exponent range for ~1e-7 gradients), ReLU masks, and finally the scatter-add of the first-layer input
+gradient back through every gathered / concatenated / differenced source (``magnet_segment_sum_cols_f32`` over the
+inverse CSR of the gather index).  Correctness-first: nothing here is fused yet.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import types
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .packing import pack, pad_to
+
+BWD_GEMM = "bf16x6"
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def _inverse_csr(idx: torch.Tensor, n_rows: int, cache: dict):
+    """CSR over the *values* of a gather index: rows = gathered-from rows, perm = gathering positions"""
+    key = (idx.data_ptr(), idx.numel(), n_rows)
+    if key not in cache:
+        pos = torch.arange(idx.numel(), dtype=torch.int32, device=idx.device)
+        c = ops.csr_by_target(pos, idx, n_rows)
+        cache[key] = (c.rowptr, c.perm)
+    return cache[key]
+
+
+def _segment_sum_cols(x, xcol, rowptr, perm, n_rows, width, scale, out, ocol):
+    L.check(L.lib().magnet_segment_sum_cols_f32(ops._p(x), x.stride(0), xcol, ops._p(rowptr), ops._p(perm), n_rows, width,
+                                                C.c_float(scale), ops._p(out), out.stride(0), ocol, 1, ops._stream()),
+            "segment_sum_cols")
+
+
+def _pad_cols(t, width):
+    if t.shape[1] == width and t.is_contiguous():
+        return t
+    out = torch.zeros(t.shape[0], width, device=t.device, dtype=torch.float32)
+    ops.copy_cols(t.contiguous(), 0, out, 0, t.shape[1])
+    return out
+
+
+def _linear(rows, x, layer, out_tiles, relu):
+    """one Linear (+ ReLU) of the chain on dense rows x [rows, K]"""
+    y = torch.empty(rows, out_tiles * 32, device=x.device, dtype=torch.float32)
+    ops.mlp(rows, ops.ktiles(ops.Term(x, x.shape[1])), [layer], nl=1, ht=out_tiles, ot=out_tiles,
+            act=ops.ACT_RELU if relu else ops.ACT_NONE, last_act=relu, y=y)
+    return y
+
+
+def _tiles_of(width):
+    """decompose a padded width into launchable output widths (128 / 64 / 32 columns)"""
+    out, c = [], 0
+    while c < width:
+        w = 128 if width - c >= 128 else (64 if width - c >= 64 else 32)
+        out.append((c, w))
+        c += w
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ fused MLP
+class _Mlp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        m = meta
+        srcs = tensors[:m.n_src]
+        res = tensors[-1] if m.has_res else None
+        kts = [[(ops.Term(srcs[si], 32, idx=idx, scale=scale, rdiv=rdiv), col) for (si, col, idx, scale, rdiv) in tile]
+               for tile in m.tiles]
+        pk = m.pk
+        y = torch.empty(m.out_rows, pk.out_dim, device=srcs[0].device, dtype=torch.float32)
+        seg = {}
+        if m.epi == ops.EPI_SEGMEAN:
+            seg = dict(tgt=m.tgt, rowptr=m.rowptr,
+                       partials=torch.empty(((m.M + 31) // 32) * 2 * pk.ot * 32 + 1, device=y.device, dtype=torch.float32))
+        nl = len(pk.layers)
+        ops.mlp(m.M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU if nl > 1 else ops.ACT_NONE, last_act=False,
+                ln=pk.ln, epi=m.epi, y=y, res=res, ncols=pk.out_dim, **seg)
+        if m.epi == ops.EPI_SEGMEAN:
+            ops.segmean_fixup(m.rowptr, m.out_rows, pk.ot * 32, seg["partials"], y)
+        ctx.meta = m
+        ctx.save_for_backward(*tensors)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        m, tensors = ctx.meta, ctx.saved_tensors
+        pk = m.pk
+        srcs = tensors[:m.n_src]
+        params = tensors[m.n_src:m.n_src + m.n_par]
+        dev = dy.device
+        nl, M = len(pk.layers), m.M
+        Dp, D = pk.ot * 32, pk.out_dim
+        dy = dy.contiguous().float()
+        with torch.no_grad():
+            # ---- epilogue
+            d_res = dy if m.has_res else None
+            if m.epi == ops.EPI_SEGMEAN:
+                d_rows = torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32)
+                L.check(L.lib().magnet_edge_mean_bwd_cols_f32(ops._p(dy), ops._p(m.tgt), ops._p(m.rowptr), C.c_long(M), Dp,
+                                                              ops._p(d_rows), Dp, ops._stream()), "edge_mean_bwd_cols")
+            else:
+                d_rows = _pad_cols(dy, Dp)
+            # ---- recompute the chain, activations materialised
+            K0 = len(m.tiles) * 32
+            x0 = torch.empty(max(M, 1), K0, device=dev, dtype=torch.float32)
+            a, keep = ops.mlp_args(M, [[(ops.Term(srcs[si], 32, idx=idx, scale=scale, rdiv=rdiv), col)
+                                        for (si, col, idx, scale, rdiv) in tile] for tile in m.tiles])
+            L.check(L.lib().magnet_mlp_materialize_input_f32(C.byref(a), ops._p(x0), K0, ops._stream()), "materialize_input")
+            X = [x0]
+            for l in range(nl - 1):
+                X.append(_linear(M, X[-1], pk.layers[l], pk.ht, relu=True))
+            grads_par = [None] * m.n_par
+            if pk.ln is not None:
+                zL = _linear(M, X[-1], pk.layers[nl - 1], pk.ot, relu=False)
+                nblk = min(1024, (M + 3) // 4)
+                part = torch.empty(nblk, 2, D, device=dev, dtype=torch.float32)
+                dz = torch.zeros(max(M, 1), Dp, device=dev, dtype=torch.float32)
+                L.check(L.lib().magnet_layernorm_bwd_f32(ops._p(zL), Dp, ops._p(d_rows), Dp, ops._p(pk.ln[0]), C.c_long(M), D,
+                                                         C.c_float(pk.ln[2]), ops._p(dz), Dp, ops._p(part), ops._stream()),
+                        "layernorm_bwd")
+                gb = torch.zeros(2 * D, device=dev, dtype=torch.float32)
+                ops.reduce_partials(part, nblk, 2 * D, gb)
+                grads_par[2 * nl], grads_par[2 * nl + 1] = gb[:D], gb[D:]
+            else:
+                dz = d_rows
+            # ---- walk the Linears back
+            need_dx0 = any(ctx.needs_input_grad[1 + i] for i in range(m.n_src))
+            ws = ops.wgrad_workspace(M, dev)
+            dX0 = None
+            for l in range(nl - 1, -1, -1):
+                W, b = params[2 * l], params[2 * l + 1]
+                n, k = W.shape
+                Np, Kp = dz.shape[1], X[l].shape[1]
+                dWp = torch.zeros(Np, Kp, device=dev, dtype=torch.float32)
+                dbp = torch.zeros(Np, device=dev, dtype=torch.float32)
+                for j, (c0, w) in enumerate(_tiles_of(Kp)):
+                    L.check(L.lib().magnet_wgrad_n_f32(ops._p(dz), Np, Np, ops._p(X[l]), Kp, c0, w, C.c_long(M), ops._p(dWp), Kp, c0,
+                                                       ops._p(dbp if j == 0 else None), ops._p(ws), 1, ops._stream()), "wgrad_n")
+                if l == 0 and m.first_cols is not None:
+                    gW = torch.zeros_like(W)
+                    gW[:, m.first_cols] = dWp[:n][:, m.col_map]
+                elif l == 0 and m.col_map is not None:
+                    gW = dWp[:n][:, m.col_map]
+                else:
+                    gW = dWp[:n, :k]
+                grads_par[2 * l], grads_par[2 * l + 1] = gW.contiguous(), dbp[:n].contiguous()
+                if l == 0 and not need_dx0:
+                    break
+                # dX = dz . W   (transposed packs, column block by column block)
+                dX = torch.empty(max(M, 1), Kp, device=dev, dtype=torch.float32)
+                Wp = _padded_weight(m, l, W, Np, Kp)
+                for (c0, w) in _tiles_of(Kp):
+                    tp = _tpack(pk, l, c0, w, Wp)
+                    ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), [tp], nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE,
+                            y=dX[:, c0:], ldy=Kp, ncols=w)
+                if l > 0:
+                    dzn = torch.empty_like(dX)
+                    L.check(L.lib().magnet_relu_bwd_f32(ops._p(dX), ops._p(X[l]), ops._p(dzn), C.c_long(dX.numel()), ops._stream()),
+                            "relu_bwd")
+                    dz = dzn
+                else:
+                    dX0 = dX
+            # ---- scatter the first-layer input gradient back through the gathers
+            grads_src = [None] * m.n_src
+            if need_dx0:
+                for si, s in enumerate(srcs):
+                    if ctx.needs_input_grad[1 + si]:
+                        grads_src[si] = torch.zeros(s.shape, device=dev, dtype=torch.float32)
+                for (si, col, idx, scale, rdiv, kt0, width) in m.runs:
+                    g = grads_src[si]
+                    if g is None:
+                        continue
+                    g2 = g.view(-1, g.shape[-1])
+                    if idx is None and rdiv == 1 and scale == 1.0:
+                        ops.copy_cols(dX0, kt0 * 32, g2, col, width, accumulate=True)
+                        continue
+                    if idx is None:                                              # dense rows (shared by rdiv consecutive rows)
+                        rowptr = torch.arange(0, M + rdiv, rdiv, dtype=torch.int32, device=dev).clamp_(max=M)
+                        perm = None
+                    elif idx.data_ptr() == (m.tgt.data_ptr() if m.tgt is not None else -1):
+                        rowptr, perm = m.rowptr, None                           # gathered by the CSR's own sorted target
+                    else:
+                        rowptr, perm = _inverse_csr(idx, g2.shape[0], m.inv_cache)
+                    for (c0, w) in _tiles_of(width):
+                        _segment_sum_cols(dX0, kt0 * 32 + c0, rowptr, perm, g2.shape[0], w, scale, g2, col + c0)
+        return (None, *grads_src, *grads_par, *([d_res] if m.has_res else []))
+
+
+def _padded_weight(m, l, W, Np, Kp):
+    n, k = W.shape
+    Wp = torch.zeros(Np, Kp, device=W.device, dtype=torch.float32)
+    if l == 0 and m.first_cols is not None:
+        Wp[:n, m.col_map] = W.detach().float()[:, m.first_cols]
+    elif l == 0 and m.col_map is not None:
+        Wp[:n, m.col_map] = W.detach().float()
+    else:
+        Wp[:n, :k] = W.detach().float()
+    return Wp
+
+
+def _tpack(pk, l, c0, w, Wp):
+    """packed transpose of the padded weight block Wp[:, c0:c0+w] as a Linear [w outputs, Np inputs] (cached on pk)"""
+    cache = pk.__dict__.setdefault("_tpacks", {})
+    key = (l, c0, w)
+    if key not in cache:
+        cache[key] = pack(Wp[:, c0:c0 + w].t().contiguous(), None, BWD_GEMM)
+    return cache[key]
+
+
+def mlp(M, groups, pk, params, *, epi=ops.EPI_STORE, res=None, csr=None, out_rows=None, first_cols=None):
+    """Differentiable fused MLP.  ``groups``: the arguments of ``ops.ktiles`` (Terms or (Term, Term) pairs); ``pk``: the
+    packed namespace of the chain (layers, ln, ht, ot, out_dim, col_map); ``params``: [W0, b0, ..., (ln.weight, ln.bias)]
+    the torch parameters behind ``pk``.  Returns a fresh [out_rows, out_dim] tensor attached to the autograd graph."""
+    srcs, tiles, runs = [], [], []
+    ids = {}
+
+    def src_index(t):
+        key = id(t)
+        if key not in ids:
+            ids[key] = len(srcs)
+            srcs.append(t)
+        return ids[key]
+
+    kt = 0
+    for g in groups:
+        terms = g if isinstance(g, (tuple, list)) else (g,)
+        w = terms[0].width
+        for term in terms:
+            runs.append((src_index(term.t), term.col, term.idx, float(term.scale), int(term.rdiv), kt, w))
+        for k in range(w // 32):
+            tiles.append([(src_index(term.t), term.col + 32 * k, term.idx, float(term.scale), int(term.rdiv)) for term in terms])
+        kt += w // 32
+    meta = types.SimpleNamespace(
+        M=int(M), tiles=tiles, runs=runs, pk=pk, epi=epi, n_src=len(srcs), n_par=len(params), has_res=res is not None,
+        tgt=csr.tgt if csr is not None else None, rowptr=csr.rowptr if csr is not None else None,
+        out_rows=int(out_rows if out_rows is not None else M), first_cols=first_cols, col_map=getattr(pk, "col_map", None),
+        inv_cache={})
+    srcs = [ops._f32(s, "mlp source") for s in srcs]
+    extra = [ops._f32(res, "residual")] if res is not None else []
+    return _Mlp.apply(meta, *srcs, *params, *extra)
+
+
+# ------------------------------------------------------------------------------------------------ small ops
+class _NodeFeatures(torch.autograd.Function):
+    """nf[b*N + n] = [u[b, n, 0:T] | x | t_last | 0-pad]  (magnet_node_features_f32); only u is differentiable"""
+
+    @staticmethod
+    def forward(ctx, u, flat, t_last, B, N, T, d, ld):
+        nf = torch.empty(B * N, ld, device=u.device, dtype=torch.float32)
+        uf = ops._f32(u.reshape(B * N, T))
+        L.check(L.lib().magnet_node_features_f32(ops._p(uf), ops._p(flat), ops._p(ops._f32(t_last)), B, N, T, d, ld, ops._p(nf),
+                                                 ops._stream()), "node_features")
+        ctx.shape = (B, N, T)
+        return nf
+
+    @staticmethod
+    def backward(ctx, dnf):
+        B, N, T = ctx.shape
+        du = torch.empty(B * N, T, device=dnf.device, dtype=torch.float32)
+        ops.copy_cols(dnf.contiguous(), 0, du, 0, T)
+        return du.view(B, N, T), None, None, None, None, None, None, None
+
+
+def node_features(u, flat, t_last, ld):
+    B, N, T = u.shape
+    return _NodeFeatures.apply(u, flat, t_last, B, N, T, flat.shape[1], ld)
+
+
+class _KnnBlend(torch.autograd.Function):
+    """z = blend of the two nearest LR nodes (magnet_inr_knn_blend_f32, models/magnet_gnn.py:254-280); differentiable in
+    ``base``, ``vals`` and the two rank-1 columns (value, time) of the ``proj_head`` weight"""
+
+    @staticmethod
+    def forward(ctx, base, vals, W, meta):
+        m = meta
+        wv, wt = W[:, m.col_v].float().contiguous(), W[:, m.col_t].float().contiguous()
+        z = torch.empty(m.B * m.Nq * m.T, m.C, device=base.device, dtype=torch.float32)
+        L.check(L.lib().magnet_inr_knn_blend_f32(ops._p(base), ops._p(m.w), ops._p(vals), ops._p(m.nn2), ops._p(m.t), m.t.shape[1],
+                                                 ops._p(wv), ops._p(wt), m.B, m.L, m.Nq, m.T, m.C, m.mode, ops._p(z), ops._stream()),
+                "inr_knn_blend")
+        ctx.meta = m
+        ctx.save_for_backward(vals, wv, W)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        m = ctx.meta
+        vals, wv, W = ctx.saved_tensors
+        dev = dz.device
+        nq = m.B * m.Nq
+        dbase = torch.empty(2 * nq, m.C, device=dev, dtype=torch.float32)
+        dvq = torch.empty(2 * nq, m.T, device=dev, dtype=torch.float32)
+        nblk = min(1024, (nq + 3) // 4)
+        part = torch.empty(nblk, 2, m.C, device=dev, dtype=torch.float32)
+        L.check(L.lib().magnet_inr_knn_blend_bwd_f32(ops._p(dz.contiguous()), ops._p(m.w), ops._p(vals), ops._p(m.nn2), ops._p(m.t),
+                                                     m.t.shape[1], ops._p(wv), m.B, m.L, m.Nq, m.T, m.C, m.mode, ops._p(dbase),
+                                                     ops._p(dvq), ops._p(part), ops._stream()), "inr_knn_blend_bwd")
+        g = torch.zeros(2 * m.C, device=dev, dtype=torch.float32)
+        ops.reduce_partials(part, nblk, 2 * m.C, g)
+        dW = torch.zeros_like(W)
+        dW[:, m.col_v], dW[:, m.col_t] = g[:m.C], g[m.C:]
+        # scatter the per-(query, neighbour) value gradients to the LR nodes: pad T to a launchable width
+        Tp = 4
+        while Tp < m.T:
+            Tp *= 2
+        dvp = _pad_cols(dvq, Tp)
+        dvals_p = torch.zeros(vals.shape[0], Tp, device=dev, dtype=torch.float32)
+        rowptr, perm = _inverse_csr(m.nn2, vals.shape[0], m.inv_cache)
+        _segment_sum_cols(dvp, 0, rowptr, perm, vals.shape[0], Tp, 1.0, dvals_p, 0)
+        return dbase, dvals_p[:, :m.T].contiguous(), dW, None
+
+
+def knn_blend(base, vals, W, meta):
+    return _KnnBlend.apply(base, vals, W, meta)
+
+
+class _Euler(torch.autograd.Function):
+    """out[b, k, node] = last + (t[b, T+k] - t[b, T-1]) * ret  (magnet_euler_update_f32, models/magnet_gnn.py:359-369)"""
+
+    @staticmethod
+    def forward(ctx, ret, last, t, B, n, T, T_out):
+        out = torch.empty(B, T_out, n, 1, device=ret.device, dtype=torch.float32)
+        tt = ops._f32(t)
+        L.check(L.lib().magnet_euler_update_f32(ops._p(ret), ret.shape[1], ops._p(ops._f32(last.reshape(-1))), ops._p(tt), tt.shape[1],
+                                                B, n, T, T_out, ops._p(out), ops._stream()), "euler_update")
+        ctx.args = (tt, B, n, T, T_out, ret.shape[1], last.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tt, B, n, T, T_out, ld, lshape = ctx.args
+        dret = torch.zeros(B * n, ld, device=dout.device, dtype=torch.float32)
+        dlast = torch.empty(B * n, device=dout.device, dtype=torch.float32)
+        L.check(L.lib().magnet_euler_update_bwd_f32(ops._p(dout.contiguous()), ops._p(tt), tt.shape[1], B, n, T, T_out, ops._p(dret), ld,
+                                                    ops._p(dlast), ops._stream()), "euler_update_bwd")
+        return dret, dlast.view(lshape), None, None, None, None, None
+
+
+def euler_update(ret, last, t, B, n, T, T_out):
+    return _Euler.apply(ret, last, t, B, n, T, T_out)

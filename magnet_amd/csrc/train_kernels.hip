@@ -113,15 +113,15 @@ __global__ void __launch_bounds__(256) k_segment_sum128(const float* __restrict_
 // the previous slab is consumed; two workgroups per CU.  HBM-bound at the edge level: 2 x 4 B per (row, column).
 #define WG_SLAB 32
 template <int KT>
-__device__ __forceinline__ void wgrad_dma(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, int xcol,
+__device__ __forceinline__ void wgrad_dma(const float* __restrict__ dY, int ldy, int N, const float* __restrict__ X, int ldx, int xcol,
                                           long m0, long M, float* sy, float* sx, int wave, int lane) {
     constexpr int KC = KT * 32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                                      // dY slab: 16 pieces of 2 rows
-        const int pi = wave + 4 * i;
-        long r = m0 + 2 * pi + (lane >> 5);
+    const int npy = N / 8;                                              // dY slab: 32 * N / 256 pieces of 1 KiB
+    for (int pi = wave; pi < npy; pi += 4) {
+        const int f = pi * 256 + lane * 4;
+        long r = m0 + f / N;
         r = r < M ? r : M - 1;                                          // tail rows: valid address, masked at use
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32x4*>(dY + r * ldy + (lane & 31) * 4),
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32x4*>(dY + r * ldy + f % N),
                                          reinterpret_cast<u32x4*>(sy + pi * 256), 16, 0, 0);
     }
 #pragma unroll
@@ -136,39 +136,43 @@ __device__ __forceinline__ void wgrad_dma(const float* __restrict__ dY, int ldy,
 }
 
 template <int KT>
-__global__ void __launch_bounds__(256, 2) k_wgrad_partial(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
-                                                          int ldx, int xcol, long M, float* __restrict__ partial /* [grid][128][KT*32] */,
-                                                          float* __restrict__ bpartial /* [grid][128] or null */) {
+__global__ void __launch_bounds__(256, 2) k_wgrad_partial(const float* __restrict__ dY, int ldy, int N, const float* __restrict__ X,
+                                                          int ldx, int xcol, long M, float* __restrict__ partial /* [grid][N][KT*32] */,
+                                                          float* __restrict__ bpartial /* [grid][N] or null */) {
     constexpr int KC = KT * 32;
     __shared__ __attribute__((aligned(16))) float sy[2][WG_SLAB * 128];
     __shared__ __attribute__((aligned(16))) float sx[2][WG_SLAB * KC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, half = lane >> 5;
+    const bool active = wave * 32 < N;                                  // N = 32, 64 or 128 columns of dY: one n tile per wave
     f32x16 acc[KT];
     zero_tiles<KT>(acc);
     float bsum = 0.f;
     const long nslabs = (M + WG_SLAB - 1) / WG_SLAB;
     long sl = blockIdx.x;
-    if (sl < nslabs) wgrad_dma<KT>(dY, ldy, X, ldx, xcol, sl * WG_SLAB, M, sy[0], sx[0], wave, lane);
+    if (sl < nslabs) wgrad_dma<KT>(dY, ldy, N, X, ldx, xcol, sl * WG_SLAB, M, sy[0], sx[0], wave, lane);
     for (int it = 0; sl < nslabs; sl += gridDim.x, ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // my pieces of slab `it` have landed
         __syncthreads();                                                // everybody's have; stage (it+1)&1 is free again
         const long nxt = sl + gridDim.x;
-        if (nxt < nslabs) wgrad_dma<KT>(dY, ldy, X, ldx, xcol, nxt * WG_SLAB, M, sy[(it + 1) & 1], sx[(it + 1) & 1], wave, lane);
+        if (nxt < nslabs) wgrad_dma<KT>(dY, ldy, N, X, ldx, xcol, nxt * WG_SLAB, M, sy[(it + 1) & 1], sx[(it + 1) & 1], wave, lane);
         const float* cy = sy[it & 1];
         const float* cx = sx[it & 1];
         const long m0 = sl * WG_SLAB;
+        if (active) {
 #pragma unroll 4
-        for (int s = 0; s < WG_SLAB / 2; ++s) {
-            const int m = 2 * s + half;
-            float a = cy[m * 128 + wave * 32 + i];
-            a = (m0 + m < M) ? a : 0.f;
-            bsum += a;
+            for (int s = 0; s < WG_SLAB / 2; ++s) {
+                const int m = 2 * s + half;
+                float a = cy[m * N + wave * 32 + i];
+                a = (m0 + m < M) ? a : 0.f;
+                bsum += a;
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) acc[kt] = mfma32(a, cx[m * KC + kt * 32 + i], acc[kt]);
+                for (int kt = 0; kt < KT; ++kt) acc[kt] = mfma32(a, cx[m * KC + kt * 32 + i], acc[kt]);
+            }
         }
     }
-    float* out = partial + (size_t)blockIdx.x * 128 * KC;
+    if (!active) return;
+    float* out = partial + (size_t)blockIdx.x * N * KC;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -178,7 +182,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_partial(const float* __restric
         }
     if (bpartial) {
         bsum += __shfl_xor(bsum, 32);
-        if (half == 0) bpartial[(size_t)blockIdx.x * 128 + wave * 32 + i] = bsum;
+        if (half == 0) bpartial[(size_t)blockIdx.x * N + wave * 32 + i] = bsum;
     }
 }
 // out[g][j] (+)= scale * sum_b partial[g][b][j]   (fixed summation order: deterministic).  32 consecutive j per
@@ -417,26 +421,34 @@ extern "C" int magnet_segment_sum128_f32(const float* x, const int32_t* rowptr, 
 }
 // dW[128][kc] (+)= dY^T X[:, xcol : xcol+kc], db[128] (+)= column sums of dY (db may be null).
 // workspace: nblk * (128 * kc + 128) + 128 * kc floats, nblk = min(512, ceil(M / 32)).
-extern "C" int magnet_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, int xcol, int kc, long M, float* dW, int ldw,
-                                int wcol, float* db, float* workspace, int accumulate, void* stream) {
+// general form: dY has n_out in {32, 64, 128} columns (weight rows), dW is [n_out][ldw]
+extern "C" int magnet_wgrad_n_f32(const float* dY, int ldy, int n_out, const float* X, int ldx, int xcol, int kc, long M, float* dW,
+                                  int ldw, int wcol, float* db, float* workspace, int accumulate, void* stream) {
     BEGIN();
     if (M <= 0) return 0;
-    if (kc % 32 || kc < 32 || kc > 128) return -2;
+    if (kc % 32 || kc < 32 || kc > 128 || (n_out != 32 && n_out != 64 && n_out != 128)) return -2;
+    const int N = n_out;
     const int nblk = (int)((M + WG_SLAB - 1) / WG_SLAB < 512 ? (M + WG_SLAB - 1) / WG_SLAB : 512);
     float* part = workspace;
-    float* bpart = db ? workspace + (size_t)nblk * 128 * kc : nullptr;
+    float* bpart = db ? workspace + (size_t)nblk * N * kc : nullptr;
     switch (kc / 32) {
-        case 1: hipLaunchKernelGGL(k_wgrad_partial<1>, dim3(nblk), dim3(256), 0, S_, dY, ldy, X, ldx, xcol, M, part, bpart); break;
-        case 2: hipLaunchKernelGGL(k_wgrad_partial<2>, dim3(nblk), dim3(256), 0, S_, dY, ldy, X, ldx, xcol, M, part, bpart); break;
-        case 3: hipLaunchKernelGGL(k_wgrad_partial<3>, dim3(nblk), dim3(256), 0, S_, dY, ldy, X, ldx, xcol, M, part, bpart); break;
-        default: hipLaunchKernelGGL(k_wgrad_partial<4>, dim3(nblk), dim3(256), 0, S_, dY, ldy, X, ldx, xcol, M, part, bpart); break;
+        case 1: hipLaunchKernelGGL(k_wgrad_partial<1>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
+        case 2: hipLaunchKernelGGL(k_wgrad_partial<2>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
+        case 3: hipLaunchKernelGGL(k_wgrad_partial<3>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
+        default: hipLaunchKernelGGL(k_wgrad_partial<4>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
     }
-    // reduce into a scratch tile then scatter into dW[:, wcol:wcol+kc] (ldw) - done column-block wise
+    // reduce into a scratch tile, then place it at dW[:, wcol : wcol+kc]
     float* tile = workspace + (size_t)nblk * (128 * kc + 128);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(nb(128L * kc, 32)), dim3(256), 0, S_, part, nblk, 128L * kc, 1.0f, tile, 0);
-    hipLaunchKernelGGL(k_copy_cols, dim3(nb(128L * kc, 256)), dim3(256), 0, S_, tile, kc, 0, dW, ldw, wcol, kc, 128L, accumulate);
-    if (db) hipLaunchKernelGGL(k_reduce_partials, dim3(4), dim3(256), 0, S_, bpart, nblk, 128L, 1.0f, db, accumulate);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nb((long)N * kc, 32)), dim3(256), 0, S_, part, nblk, (long)N * kc, 1.0f, tile, 0);
+    hipLaunchKernelGGL(k_copy_cols, dim3(nb((long)N * kc, 256)), dim3(256), 0, S_, tile, kc, 0, dW, ldw, wcol, kc, (long)N, accumulate);
+    if (db) hipLaunchKernelGGL(k_reduce_partials, dim3(nb(N, 32)), dim3(256), 0, S_, bpart, nblk, (long)N, 1.0f, db, accumulate);
     END();
+}
+// dW[0:128, wcol:wcol+kc] (+)= dY[M,128]^T X[M, xcol:xcol+kc], db[128] (+)= column sums of dY (db may be null).
+// workspace: nblk * (128 * kc + 128) + 128 * kc floats, nblk = min(512, ceil(M / 32)).
+extern "C" int magnet_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, int xcol, int kc, long M, float* dW, int ldw,
+                                int wcol, float* db, float* workspace, int accumulate, void* stream) {
+    return magnet_wgrad_n_f32(dY, ldy, 128, X, ldx, xcol, kc, M, dW, ldw, wcol, db, workspace, accumulate, stream);
 }
 extern "C" int magnet_reduce_partials_f32(const float* partial, int nblk, long n, float scale, float* out, int accumulate,
                                           void* stream) {

@@ -59,12 +59,14 @@ def pack_mlp_ln(seq, k_pad=None, col_map=None, mode=None):
     mlp, ln = seq[0], seq[1]
     return types.SimpleNamespace(layers=mlp.packed(k_pad=k_pad, col_map=col_map, mode=mode),
                                  ln=(ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps),
-                                 ht=mlp.hidden // 32, ot=pad_to(mlp.out_dim) // 32, out_dim=mlp.out_dim)
+                                 ht=mlp.hidden // 32, ot=pad_to(mlp.out_dim) // 32, out_dim=mlp.out_dim, col_map=col_map,
+                                 params=[p for lin in mlp.linears() for p in (lin.weight, lin.bias)] + [ln.weight, ln.bias])
 
 
 def pack_mlp(mlp, k_pad=None, mode=None):
     return types.SimpleNamespace(layers=mlp.packed(k_pad=k_pad, mode=mode), ln=None, ht=mlp.hidden // 32,
-                                 ot=pad_to(mlp.out_dim) // 32, out_dim=mlp.out_dim)
+                                 ot=pad_to(mlp.out_dim) // 32, out_dim=mlp.out_dim, col_map=None,
+                                 params=[p for lin in mlp.linears() for p in (lin.weight, lin.bias)])
 
 
 def pack_graph_net(enc: Encoder, proc: Processor, ldn: int):
@@ -86,16 +88,20 @@ class MagnetBase(LightningModule):
         self.factor, self.step_size, self.loss = hparams.factor, hparams.step_size, hparams.loss
         self.criterion = {"l1": nn.L1Loss(), "l2": nn.MSELoss(), "smooth_l1": nn.SmoothL1Loss()}[self.loss]
         self.mse_criterion, self.mae_criterion = nn.MSELoss(), nn.L1Loss()
-        self._pack_key, self._pack = None, None
+        self._pack_key, self._pack, self._pack_gen = None, None, 0
         self._topo_cache = {}
+        self.optimizer_kind = getattr(hparams, "optimizer", "fused")     # "fused" (magnet_amd.optim.FusedAdam) | "torch"
 
     # ---- packed-weight cache -------------------------------------------------------------
     def _packed(self):
         params = list(self.parameters())
-        key = (params[0].device, sum(p._version for p in params))
+        key = (params[0].device, sum(p._version for p in params), self._pack_gen)
         if self._pack_key != key:
             self._pack, self._pack_key = self._pack_weights(), key
         return self._pack
+
+    def _weights_changed(self):
+        self._pack_gen += 1
 
     # ---- graph (reference _build_graph, models/magnet_gnn.py:286-310) ---------------------
     def _topology(self, coords: torch.Tensor, key):
@@ -154,6 +160,38 @@ class MagnetBase(LightningModule):
             x, x2 = x2, x
         return x
 
+    # ---- the same two blocks with gradients (training): every op is a magnet_amd.autograd Function, outputs are
+    # fresh tensors (autograd keeps the inputs of every op alive for its backward)
+    def _build_graph_grad(self, u, x, t, key=None):
+        from .. import autograd as AG
+        B, N, T = u.shape
+        topo = self._topology(x, key if key is not None else self._tkey(x))
+        nf = AG.node_features(u.float(), topo.flat, t[:, -1].float(), pad_to(T + x.shape[-1] + 1))
+        return nf, topo
+
+    def _graph_net_grad(self, pk, nf, topo, D):
+        from .. import autograd as AG
+        csr = topo.csr
+        N, E = csr.N, csr.E
+        ldn = nf.shape[1]
+        T_ = ops.Term
+        x = AG.mlp(N, [T_(nf, ldn)], pk.node, pk.node.params)
+        e0 = AG.mlp(E, [(T_(nf, ldn, idx=csr.src, scale=1.0), T_(nf, ldn, idx=csr.tgt, scale=-1.0))], pk.edge, pk.edge.params)
+        for k, hop in enumerate(pk.hops):
+            agg = AG.mlp(E, [T_(x, D, idx=csr.tgt), T_(x, D, idx=csr.src), T_(e0, D, scale=float(2 ** k))], hop.edge,
+                         hop.edge.params, epi=ops.EPI_SEGMEAN, csr=csr, out_rows=N)
+            x = AG.mlp(N, [T_(agg, D), T_(x, D)], hop.node, hop.node.params, epi=ops.EPI_STORE_RES, res=x)
+        return x
+
+    def _interaction_and_update_grad(self, pk, feats, coords, t, T, last, key):
+        from .. import autograd as AG
+        B, n, _ = feats.shape
+        nf, topo = self._build_graph_grad(feats, coords, t[:, :T], key=key)
+        x = self._graph_net_grad(pk.graph2, nf, topo, self.latent_dim)
+        T_out = t.shape[1] - T
+        ret = AG.mlp(B * n, [ops.Term(x, self.latent_dim)], pk.decoder, pk.decoder.params)
+        return AG.euler_update(ret, last, t, B, n, T, T_out)
+
     # ---- second half of every MAgNet forward: joint graph, decoder, Euler update ------------
     def _interaction_and_update(self, pk, feats, coords, t, T, last, key):
         """feats [B, n, T], coords [B, n, d] -> out [B, T_out, n, 1] (models/magnet_gnn.py:351-369)."""
@@ -176,15 +214,23 @@ class MagnetBase(LightningModule):
         return out
 
     def configure_optimizers(self):
-        opt = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        """Adam(lr, weight_decay) + StepLR(step_size, gamma=factor) as in the reference (models/magnet_gnn.py:377-386); on a HIP
+        device the optimizer is magnet_amd.optim.FusedAdam (same update rule, one kernel over a flat parameter buffer)."""
+        if next(self.parameters()).is_cuda and self.optimizer_kind == "fused":
+            from ..optim import FusedAdam
+            opt = FusedAdam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+            opt.on_step = self._weights_changed
+        else:
+            opt = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
         sch = torch.optim.lr_scheduler.StepLR(opt, step_size=self.step_size, gamma=self.factor)
         return {"optimizer": opt, "lr_scheduler": {"scheduler": sch}}
 
     def _no_backward_yet(self):
         if torch.is_grad_enabled():
             raise NotImplementedError(
-                "the HIP backward (SURVEY.md 8(f) rank 2) exists for MPNN / MPNN_2d only so far; the MAgNet models "
-                "ship the forward / rollout kernels, so their training_step cannot produce gradients yet")
+                "the HIP backward exists for MPNN / MPNN_2d and MAgNet[GNN]; the MAgNet[CNN] models ship the forward / "
+                "rollout kernels only (their EDSR and grid-INR backward is not built), so training_step cannot produce "
+                "gradients yet")
 
 
 __all__ = ["Encoder", "InteractionNetwork", "Processor", "Decoder", "MagnetBase", "pack_mlp", "pack_mlp_ln",

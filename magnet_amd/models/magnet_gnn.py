@@ -63,8 +63,53 @@ class MAgNetGNN(MagnetBase):
             proj_wv=W[:, D].float().contiguous(), proj_wt=W[:, D + d + 1].float().contiguous(),
             projector=pack_mlp(self.projector), decoder=pack_mlp(self._decoder.node_fn))
 
-    @torch.no_grad()
     def forward(self, x_lr, lr_coords, hr_coords, t, hr_last):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_grad(x_lr, lr_coords, hr_coords, t, hr_last)
+        with torch.no_grad():
+            return self._forward(x_lr, lr_coords, hr_coords, t, hr_last)
+
+    def _forward_grad(self, x_lr, lr_coords, hr_coords, t, hr_last):
+        """the forward of ``_forward`` built from magnet_amd.autograd Functions (fused HIP forward kernels, HIP backward
+        kernels); torch autograd only chains them and differentiates the cat / permute / reshape glue."""
+        from .. import autograd as AG
+        B, T, C, Lr = x_lr.shape
+        Nq, d, D, Cn = hr_coords.shape[1], self.coord_dim, self.latent_dim, self.n_chan
+        dev = x_lr.device
+        pk = self._packed()
+        t = t.float()
+        lr_coords = lr_coords.reshape(B, Lr, d).float()
+        hr_coords = hr_coords.reshape(B, Nq, d).float()
+        u = x_lr.permute(0, 3, 1, 2).reshape(B, Lr, T * C).float().contiguous()
+        nf, topo = self._build_graph_grad(u, lr_coords, t[:, :T], key=("lr",) + self._tkey(lr_coords))
+        enc = self._graph_net_grad(pk.graph1, nf, topo, D)
+        with torch.no_grad():
+            flr, fhr = topo.flat, ops._f32(hr_coords.reshape(B * Nq, d))
+            nn_idx = ops.knn(flr, ops.graph_ptr(B, Lr, dev), fhr, ops.graph_ptr(B, Nq, dev), self.codec_neighbors)
+            M2 = 2 * B * Nq
+            nn2 = torch.empty(M2, dtype=torch.int32, device=dev)
+            rel = torch.empty(M2, 32, device=dev, dtype=torch.float32)
+            w = torch.empty(M2, device=dev, dtype=torch.float32)
+            L.check(L.lib().magnet_inr_knn_prepare_f32(ops._p(flr), ops._p(fhr), ops._p(nn_idx), self.codec_neighbors, d, B,
+                                                       Lr, Nq, ops._p(nn2), ops._p(rel), ops._p(w), ops._stream()), "inr_knn_prepare")
+        ot = Cn // 32
+        Wp = self.proj_head.weight
+        cols = torch.cat([torch.arange(D), D + 1 + torch.arange(d)]).to(dev)       # enc, rel columns of proj_head
+        cmap = torch.cat([torch.arange(D), D + torch.arange(d)]).to(dev)
+        pb = types.SimpleNamespace(layers=[pk.proj_base], ln=None, ht=ot, ot=ot, out_dim=Cn, col_map=cmap)
+        base = AG.mlp(M2, [ops.Term(enc, D, idx=nn2), ops.Term(rel, 32)], pb, [Wp, self.proj_head.bias], first_cols=cols)
+        meta = types.SimpleNamespace(w=w, nn2=nn2, t=t.contiguous(), B=B, L=Lr, Nq=Nq, T=T, C=Cn, mode=_MODES[self.interpolation],
+                                     col_v=D, col_t=D + d + 1, inv_cache={})
+        z = AG.knn_blend(base, u.reshape(B * Lr, T), Wp, meta)
+        pj = pk.projector
+        hr_points = AG.mlp(B * Nq * T, [ops.Term(z, Cn)], pj, pj.params).reshape(B, Nq, T)
+        feats = torch.cat([u, hr_points], dim=1)
+        coords = torch.cat([lr_coords, hr_coords], dim=1)
+        last = torch.cat([x_lr[:, -1].permute(0, 2, 1).float(), hr_last.float()], dim=1)
+        out = self._interaction_and_update_grad(pk, feats, coords, t, T, last, key=("all",) + self._tkey(lr_coords, hr_coords))
+        return out[:, :, Lr:], out[:, :, :Lr], hr_points.permute(0, 2, 1)[..., None]
+
+    def _forward(self, x_lr, lr_coords, hr_coords, t, hr_last):
         B, T, C, Lr = x_lr.shape
         Nq, d, D, Cn = hr_coords.shape[1], self.coord_dim, self.latent_dim, self.n_chan
         dev = x_lr.device
@@ -122,7 +167,6 @@ class MAgNetGNN(MagnetBase):
         return pred, target, torch.cat(hrs, dim=1), vals
 
     def training_step(self, train_batch, batch_idx):
-        self._no_backward_yet()
         if self.noise:
             raise NotImplementedError("input noise (magnet_gnn.py:402-407) is a training-only feature")
         pred, target, hr_hat, vals = self._rollout(train_batch, self.teacher_forcing)

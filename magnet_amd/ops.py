@@ -58,18 +58,12 @@ def ktiles(*groups):
     return out
 
 
-def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STORE, y=None, ldy=None, ncols=None,
-             res=None, tgt=None, rowptr=None, partials=None, colgroups=1):
-    """Build the argument block of one fused-MLP launch once and return a zero-argument callable that enqueues it on the
-    current stream.  For call sites that repeat the same launch on the same buffers (the EDSR convolution stack: 34
-    launches of up to 36 gathered k tiles each) this removes the per-call descriptor marshalling from the host path."""
+def mlp_args(M, kts):
+    """argument block with the row count and the first-layer k-tile descriptors filled in -> (args, keep-alive list)"""
     a = L.MlpArgs()
     a.M, a.nkt = int(M), len(kts)
-    # colgroups G > 1 (single Linear only): ``layers`` holds G packed column slices of ot*32 outputs each; the launch
-    # gets G workgroup columns - more parallelism when M alone cannot fill the chip (a 64 x 64 EDSR map is 4096 rows)
-    assert 1 <= len(kts) <= L.MAX_KT and len(layers) == nl * colgroups and (colgroups == 1 or nl == 1)
-    a.ncolgroups = int(colgroups)
-    keep = [layers, ln, y, res, tgt, rowptr, partials]
+    assert 1 <= len(kts) <= L.MAX_KT
+    keep = []
     for i, tile in enumerate(kts):
         a.kt[i].n = len(tile)
         for j, (term, col) in enumerate(tile):
@@ -80,6 +74,20 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
             s = a.kt[i].s[j]
             s.p, s.ld, s.col, s.scale, s.rdiv = t.data_ptr(), ld, col, float(term.scale), int(term.rdiv)
             s.idx = term.idx.data_ptr() if term.idx is not None else None
+    return a, keep
+
+
+def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STORE, y=None, ldy=None, ncols=None,
+             res=None, tgt=None, rowptr=None, partials=None, colgroups=1):
+    """Build the argument block of one fused-MLP launch once and return a zero-argument callable that enqueues it on the
+    current stream.  For call sites that repeat the same launch on the same buffers (the EDSR convolution stack: 34
+    launches of up to 36 gathered k tiles each) this removes the per-call descriptor marshalling from the host path."""
+    # colgroups G > 1 (single Linear only): ``layers`` holds G packed column slices of ot*32 outputs each; the launch
+    # gets G workgroup columns - more parallelism when M alone cannot fill the chip (a 64 x 64 EDSR map is 4096 rows)
+    assert len(layers) == nl * colgroups and (colgroups == 1 or nl == 1)
+    a, keep = mlp_args(M, kts)
+    a.ncolgroups = int(colgroups)
+    keep += [layers, ln, y, res, tgt, rowptr, partials]
     for i, (w, b) in enumerate(layers):
         a.layer[i].w, a.layer[i].b = w.data_ptr(), b.data_ptr()
     if ln is not None:

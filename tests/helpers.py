@@ -76,3 +76,30 @@ def load_grads(tag, teacher_forcing):
     names = [k.split(":", 1)[1] for k in d.files if k.startswith(key + "_norm:")]
     return float(d[key + "_loss"]), {n: (float(d[f"{key}_norm:{n}"]), torch.from_numpy(d[f"{key}_sample:{n}"]), stride)
                                      for n in names}
+
+
+def oracle_magnet_gnn_grads(oracle, batch, teacher_forcing, loss_name, dtype=torch.float64):
+    """loss + parameter gradients of the reference's MAgNetGNN.training_step (models/magnet_gnn.py:388-440, noise = 0) by
+    torch autograd through the oracle restatement."""
+    from oracle.models import _criterion
+    o = oracle.to(dtype)
+    b = {k: v.to(dtype) for k, v in batch.items()}
+    t, u, vals, hr_c, lr_c = b["t"], b["lr_frames"], b["hr_points"], b["coords_hr"], b["coords_lr"]
+    T = o.T
+    fut = vals[:, T:]
+    inp, hr_last, outs, hrs = u[:, :T], vals[:, T - 1], [], []
+    for i in range(fut.shape[1] // T):
+        out_hr, out_lr, hr_points = o.forward(inp, lr_c, hr_c, t[:, i * T:(i + 2) * T], hr_last)
+        outs.append(torch.cat([out_hr, out_lr], 2))
+        hrs.append(hr_points)
+        if teacher_forcing:
+            inp, hr_last = u[:, (i + 1) * T:(i + 2) * T], vals[:, (i + 2) * T - 1]
+        else:
+            inp, hr_last = out_lr.permute(0, 1, 3, 2), out_hr[:, -1]
+    pred, hr_hat = torch.cat(outs, 1), torch.cat(hrs, 1)
+    target = torch.cat([fut, u[:, T:].permute(0, 1, 3, 2)], 2)
+    crit = _criterion(loss_name)
+    loss = crit(pred, target) + crit(hr_hat, vals[:, :-T])
+    o.zero_grad()
+    loss.backward()
+    return float(loss.detach()), {n: p.grad.clone() for n, p in o.named_parameters()}

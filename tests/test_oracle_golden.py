@@ -57,3 +57,19 @@ def test_oracle_gradients_match_reference_training_step(tag, teacher_forcing):
         for n, (norm, sample, stride) in gold.items():
             assert abs(float(grads[n].norm()) - norm) < tol * norm, (n, dtype)
             assert rel_l2(grads[n].flatten()[::stride], sample) < tol, (n, dtype)
+
+
+@pytest.mark.parametrize("teacher_forcing", [False, True])
+def test_oracle_magnet_gnn_gradients_match_reference_training_step(teacher_forcing):
+    """same pin for MAgNet[GNN] (models/magnet_gnn.py:388-440): the oracle's autograd gradients vs the reference's own"""
+    from tests.helpers import load_grads, oracle_magnet_gnn_grads
+    name, hp, salt, batch, d = load_case("magnet_gnn_tiny")
+    model = O.build(name, hp)
+    fill_state_dict(model, salt)
+    gold_loss, gold = load_grads("magnet_gnn_tiny", teacher_forcing)
+    loss, grads = oracle_magnet_gnn_grads(model, batch, teacher_forcing, hp.loss, dtype=torch.float32)
+    assert abs(loss - gold_loss) < 1e-5 * max(1.0, abs(gold_loss))
+    assert set(grads) == set(gold)
+    for n, (norm, sample, stride) in gold.items():
+        assert abs(float(grads[n].norm()) - norm) < 2e-4 * max(norm, 1e-12), n
+        assert rel_l2(grads[n].flatten()[::stride], sample) < 2e-4, n
