@@ -226,6 +226,9 @@ int magnet_segment_sum_cols_f32(const float* x, int ldx, int xcol, const int32_t
 int magnet_inr_knn_blend_bwd_f32(const float* dz, const float* w, const float* vals, const int32_t* nn2, const float* t,
                                  int t_ld, const float* wv, int n_graphs, int L, int Nq, int T, int C, int mode, float* dbase,
                                  float* dvq, float* part, void* stream);
+/* backward of magnet_inr_grid_blend_f32: dp [n_rows*nshift*T][C] from dz [n_rows*T][C] (the area weights are constants) */
+int magnet_inr_grid_blend_bwd_f32(const float* dz, const float* area, int n_rows, int T, int C, int nshift, float* dp,
+                                  void* stream);
 int magnet_euler_update_bwd_f32(const float* dout, const float* t, int t_ld, int n_graphs, int nodes_per_graph, int T,
                                 int T_out, float* dret, int ld_ret, float* dlast, void* stream);
 /* backward of InstanceNorm (mpnn.py:63,70) from the kept output yhat and biased variance var [n_graphs][H];

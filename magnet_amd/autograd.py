@@ -86,17 +86,23 @@ class _Mlp(torch.autograd.Function):
             seg = dict(tgt=m.tgt, rowptr=m.rowptr,
                        partials=torch.empty(((m.M + 31) // 32) * 2 * pk.ot * 32 + 1, device=y.device, dtype=torch.float32))
         nl = len(pk.layers)
-        ops.mlp(m.M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU if nl > 1 else ops.ACT_NONE, last_act=False,
-                ln=pk.ln, epi=m.epi, y=y, res=res, ncols=pk.out_dim, **seg)
+        ops.mlp(m.M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU if (nl > 1 or m.final_relu) else ops.ACT_NONE,
+                last_act=m.final_relu, ln=pk.ln, epi=m.epi, y=y, res=res, ncols=pk.out_dim, **seg)
         if m.epi == ops.EPI_SEGMEAN:
             ops.segmean_fixup(m.rowptr, m.out_rows, pk.ot * 32, seg["partials"], y)
         ctx.meta = m
-        ctx.save_for_backward(*tensors)
+        ctx.save_for_backward(*tensors, *([y] if m.final_relu else []))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         m, tensors = ctx.meta, ctx.saved_tensors
+        if m.final_relu:                                                 # y = ReLU(chain): mask the incoming gradient first
+            y_out, tensors = tensors[-1], tensors[:-1]
+            masked = torch.empty_like(y_out)
+            L.check(L.lib().magnet_relu_bwd_f32(ops._p(dy.contiguous().float()), ops._p(y_out), ops._p(masked),
+                                                C.c_long(y_out.numel()), ops._stream()), "relu_bwd")
+            dy = masked
         pk = m.pk
         srcs = tensors[:m.n_src]
         params = tensors[m.n_src:m.n_src + m.n_par]
@@ -220,7 +226,7 @@ def _tpack(pk, l, c0, w, Wp):
     return cache[key]
 
 
-def mlp(M, groups, pk, params, *, epi=ops.EPI_STORE, res=None, csr=None, out_rows=None, first_cols=None):
+def mlp(M, groups, pk, params, *, epi=ops.EPI_STORE, res=None, csr=None, out_rows=None, first_cols=None, final_relu=False):
     """Differentiable fused MLP.  ``groups``: the arguments of ``ops.ktiles`` (Terms or (Term, Term) pairs); ``pk``: the
     packed namespace of the chain (layers, ln, ht, ot, out_dim, col_map); ``params``: [W0, b0, ..., (ln.weight, ln.bias)]
     the torch parameters behind ``pk``.  Returns a fresh [out_rows, out_dim] tensor attached to the autograd graph."""
@@ -247,7 +253,8 @@ def mlp(M, groups, pk, params, *, epi=ops.EPI_STORE, res=None, csr=None, out_row
         M=int(M), tiles=tiles, runs=runs, pk=pk, epi=epi, n_src=len(srcs), n_par=len(params), has_res=res is not None,
         tgt=csr.tgt if csr is not None else None, rowptr=csr.rowptr if csr is not None else None,
         out_rows=int(out_rows if out_rows is not None else M), first_cols=first_cols, col_map=getattr(pk, "col_map", None),
-        inv_cache={})
+        inv_cache={}, final_relu=bool(final_relu))
+    assert not (final_relu and (pk.ln is not None or epi != ops.EPI_STORE))
     srcs = [ops._f32(s, "mlp source") for s in srcs]
     extra = [ops._f32(res, "residual")] if res is not None else []
     return _Mlp.apply(meta, *srcs, *params, *extra)
@@ -351,3 +358,26 @@ class _Euler(torch.autograd.Function):
 
 def euler_update(ret, last, t, B, n, T, T_out):
     return _Euler.apply(ret, last, t, B, n, T, T_out)
+
+
+class _GridBlend(torch.autograd.Function):
+    """z = area blend of the 2^d shifted cell predictions (magnet_inr_grid_blend_f32, models/magnet_cnn_2d.py:285-290)"""
+
+    @staticmethod
+    def forward(ctx, p, area, n_rows, T, C, S):
+        z = torch.empty(n_rows * T, C, device=p.device, dtype=torch.float32)
+        L.check(L.lib().magnet_inr_grid_blend_f32(ops._p(p), ops._p(area), n_rows, T, C, S, ops._p(z), ops._stream()), "inr_grid_blend")
+        ctx.args = (area, n_rows, T, C, S)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        area, n_rows, T, C, S = ctx.args
+        dp = torch.empty(n_rows * S * T, C, device=dz.device, dtype=torch.float32)
+        L.check(L.lib().magnet_inr_grid_blend_bwd_f32(ops._p(dz.contiguous()), ops._p(area), n_rows, T, C, S, ops._p(dp), ops._stream()),
+                "inr_grid_blend_bwd")
+        return dp, None, None, None, None, None
+
+
+def grid_blend(p, area, n_rows, T, C, S):
+    return _GridBlend.apply(p, area, n_rows, T, C, S)

@@ -321,3 +321,35 @@ extern "C" int magnet_euler_update_bwd_f32(const float* dout, const float* t, in
                        dret, ld_ret, dlast);
     END();
 }
+
+// ---- backward of k_inr_grid_blend (magnet_kernels.hip): z = sum_s p_s * om_s with om_s = area[opposite(s)] / sum area
+// (functions of the coordinates only)  ->  dp[((bq*S + s)*T + i)][c] = dz[(bq*T + i)][c] * om_s
+__global__ void k_inr_grid_blend_bwd(const float* __restrict__ dz, const float* __restrict__ area, int T, int C, int S,
+                                     long total /* = n_rows * S * T * C */, float* __restrict__ dp) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int ti = (int)((i / C) % T);
+    const long rs = i / ((long)C * T);                                 // bq*S + s
+    const int s = (int)(rs % S);
+    const long bq = rs / S;
+    float om;
+    if (S == 2) {
+        const float a0 = area[bq * 2], a1 = area[bq * 2 + 1];
+        om = (s == 0 ? a1 : a0) / (a1 + a0);
+    } else {
+        const float a0 = area[bq * 4], a1 = area[bq * 4 + 1], a2 = area[bq * 4 + 2], a3 = area[bq * 4 + 3];
+        const float tot = ((a0 + a1) + a2) + a3;
+        om = (s == 0 ? a3 : s == 1 ? a2 : s == 2 ? a1 : a0) / tot;
+    }
+    dp[i] = dz[(bq * T + ti) * C + c] * om;
+}
+extern "C" int magnet_inr_grid_blend_bwd_f32(const float* dz, const float* area, int n_rows, int T, int C, int nshift, float* dp,
+                                             void* stream) {
+    BEGIN();
+    const long total = (long)n_rows * nshift * T * C;
+    if (total <= 0) return 0;
+    if (nshift != 2 && nshift != 4) return -2;
+    hipLaunchKernelGGL(k_inr_grid_blend_bwd, dim3(nb(total, 256)), dim3(256), 0, S_, dz, area, T, C, nshift, total, dp);
+    END();
+}

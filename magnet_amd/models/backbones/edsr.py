@@ -125,6 +125,44 @@ class EDSR(nn.Module):
             go()
         return out[:P]
 
+    def rows_grad(self, x):
+        """``rows`` with gradients (training): every convolution is a differentiable gathered-tap Linear
+        (magnet_amd.autograd.mlp, HIP forward and backward); the conv weight reaches it as a torch view
+        [Co, taps, Ci] -> [Co, taps * Ci] of the parameter, so its gradient lands in the parameter's own layout."""
+        from ... import autograd as AG
+        import types
+        x = ops._f32(x, "EDSR input")
+        B, cin = x.shape[:2]
+        spatial = x.shape[2:]
+        P = B * int(torch.tensor(spatial).prod())
+        dev, C, ot = x.device, self.n_chan, self.n_chan // 32
+        pk = self.packed()
+        taps = self._tap_table(B, spatial, dev)
+        ntaps = taps.shape[0]
+
+        def as_rows(t_rows):                                   # append the all-zero padding row
+            return torch.cat([t_rows, torch.zeros(1, t_rows.shape[1], device=dev, dtype=torch.float32)], 0)
+
+        def conv(src, width, layer, conv_mod, relu=False, res=None):
+            ci = conv_mod.weight.shape[1]
+            W2 = conv_mod.weight.reshape(conv_mod.weight.shape[0], ci, ntaps).permute(0, 2, 1).reshape(conv_mod.weight.shape[0], -1)
+            cmap = (torch.arange(ntaps, device=dev)[:, None] * width + torch.arange(ci, device=dev)[None, :]).reshape(-1)
+            pkc = types.SimpleNamespace(layers=[layer[0]], ln=None, ht=ot, ot=ot, out_dim=C, col_map=cmap)
+            groups = [ops.Term(src, width, idx=taps[t]) for t in range(ntaps)]
+            return AG.mlp(P, groups, pkc, [W2, conv_mod.bias], epi=ops.EPI_STORE_RES if res is not None else ops.EPI_STORE,
+                          res=res, final_relu=relu)
+
+        cp = pad_to(cin)
+        xin = torch.zeros(P, cp, device=dev, dtype=torch.float32)
+        xin = torch.cat([x.reshape(B, cin, -1).permute(0, 2, 1).reshape(P, cin), xin[:, cin:]], 1) if cp != cin else \
+            x.reshape(B, cin, -1).permute(0, 2, 1).reshape(P, cin)
+        head = conv(as_rows(xin), cp, pk["head"], self.head_conv)
+        cur = head
+        for blk, (c1, c2) in zip(self.res_layers, pk["blocks"]):
+            mid = conv(as_rows(cur), C, c1, blk.conv_1, relu=True)
+            cur = conv(as_rows(mid), C, c2, blk.conv_2, res=cur)
+        return conv(as_rows(cur), C, pk["tail"], self.tail_conv, res=head)
+
     @torch.no_grad()
     def forward(self, x):
         """[B, in_chan, W(, W)] -> [B, n_chan, W(, W)] (the reference's layout; the models consume ``rows`` directly)."""

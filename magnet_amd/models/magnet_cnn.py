@@ -63,8 +63,61 @@ class MAgNetCNN(MagnetBase):
         B, T = x_t.shape[:2]
         return self.encoder(x_t.reshape(B, T * x_t.shape[2], *x_t.shape[3:]))
 
-    @torch.no_grad()
     def forward(self, x_t, coords, cell, t, hr_last, hiddens=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_grad(x_t, coords, cell, t, hr_last)
+        with torch.no_grad():
+            return self._forward(x_t, coords, cell, t, hr_last)
+
+    def _forward_grad(self, x_t, coords, cell, t, hr_last):
+        """``_forward`` built from magnet_amd.autograd Functions (HIP forward and backward kernels); torch autograd chains
+        them and differentiates the layout glue.  The nearest-cell value q_inp, which the inference path copies into column
+        0 of the per-row tail, is gathered here as its own (differentiable) source summed into the same k tile."""
+        from .. import autograd as AG
+        d, C = self.DIM, self.n_chan
+        B, T = x_t.shape[:2]
+        W = x_t.shape[-1]
+        nlr = W ** d
+        Nq = coords.shape[1]
+        S = 2 ** d
+        dev = x_t.device
+        pk = self._packed()
+        t = ops._f32(t)
+        x_t = x_t.float()
+        coords = coords.reshape(B, Nq, d).float()
+        featT = self.encoder.rows_grad(x_t.reshape(B, T * x_t.shape[2], *x_t.shape[3:]))
+        rows = B * Nq * S
+        with torch.no_grad():
+            cell_idx = torch.empty(rows * T, dtype=torch.int32, device=dev)
+            tail = torch.empty(rows * T, 32, device=dev, dtype=torch.float32)
+            area = torch.empty(rows, device=dev, dtype=torch.float32)
+            fco, fce = ops._f32(coords.reshape(B * Nq, d)), ops._f32(cell.reshape(B * Nq, d))
+            L.check(L.lib().magnet_inr_grid_prepare_f32(ops._p(fco), ops._p(fce), ops._p(ops._f32(x_t.detach())), ops._p(t), t.shape[1],
+                                                        B, Nq, T, W, d, ops._p(cell_idx), ops._p(tail), ops._p(area), ops._stream()),
+                    "inr_grid_prepare")
+            tail[:, 0] = 0                                                   # q_inp comes in through its own source below
+            r = torch.arange(rows * T, device=dev)
+            b_of, i_of = (r // T) // (Nq * S), r % T
+            flat = cell_idx.long() - b_of * nlr
+            idx_q = ((b_of * T + i_of) * nlr + flat).int()                     # row of x_t[b, i, cell] in [B*T*cells]
+        xq = torch.cat([x_t.reshape(B * T * nlr, 1), torch.zeros(B * T * nlr, 31, device=dev)], 1)
+        ph = pk.proj_head
+        p = AG.mlp(rows * T, [ops.Term(featT, C, idx=cell_idx), (ops.Term(xq, 32, idx=idx_q), ops.Term(tail, 32))], ph, ph.params)
+        z = AG.grid_blend(p, area, B * Nq, T, C, S)
+        pj = pk.projector
+        hr_points = AG.mlp(B * Nq * T, [ops.Term(z, C)], pj, pj.params).reshape(B, Nq, T)
+        lr_points = x_t[:, :, 0].reshape(B, T, nlr).permute(0, 2, 1)
+        lr_coords = make_coord([W] * d, device=dev)[None].expand(B, -1, -1)
+        feats = torch.cat([lr_points, hr_points], dim=1)
+        allc = torch.cat([lr_coords, coords], dim=1)
+        last = torch.cat([x_t[:, -1, 0].reshape(B, nlr, 1), hr_last.float()], dim=1)
+        out = self._interaction_and_update_grad(pk, feats, allc, t, T, last, key=("all", W) + self._tkey(coords))
+        out_lr = out[:, :, :nlr]
+        if d == 2:
+            out_lr = out_lr.permute(0, 1, 3, 2).reshape(B, -1, 1, W, W)
+        return out[:, :, nlr:], out_lr, hr_points.permute(0, 2, 1)[..., None]
+
+    def _forward(self, x_t, coords, cell, t, hr_last, hiddens=None):
         d, C = self.DIM, self.n_chan
         B, T = x_t.shape[:2]
         W = x_t.shape[-1]
@@ -110,7 +163,6 @@ class MAgNetCNN(MagnetBase):
         return frames.reshape(B, T, 1, -1).permute(0, 1, 3, 2)
 
     def training_step(self, train_batch, batch_idx):
-        self._no_backward_yet()
         t, u = train_batch["t"].float(), train_batch["lr_frames"].float()
         vals, coords, cells = train_batch["hr_points"].float(), train_batch["coords"].float(), train_batch["cells"].float()
         T = self.time_slice

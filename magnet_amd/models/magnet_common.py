@@ -225,13 +225,6 @@ class MagnetBase(LightningModule):
         sch = torch.optim.lr_scheduler.StepLR(opt, step_size=self.step_size, gamma=self.factor)
         return {"optimizer": opt, "lr_scheduler": {"scheduler": sch}}
 
-    def _no_backward_yet(self):
-        if torch.is_grad_enabled():
-            raise NotImplementedError(
-                "the HIP backward exists for MPNN / MPNN_2d and MAgNet[GNN]; the MAgNet[CNN] models ship the forward / "
-                "rollout kernels only (their EDSR and grid-INR backward is not built), so training_step cannot produce "
-                "gradients yet")
-
 
 __all__ = ["Encoder", "InteractionNetwork", "Processor", "Decoder", "MagnetBase", "pack_mlp", "pack_mlp_ln",
            "pack_graph_net", "run_mlp", "pad_vec"]

@@ -103,3 +103,31 @@ def oracle_magnet_gnn_grads(oracle, batch, teacher_forcing, loss_name, dtype=tor
     o.zero_grad()
     loss.backward()
     return float(loss.detach()), {n: p.grad.clone() for n, p in o.named_parameters()}
+
+
+def oracle_magnet_cnn_grads(oracle, batch, teacher_forcing, loss_name, dtype=torch.float64):
+    """loss + parameter gradients of the reference's MAgNetCNN(_2d).training_step (models/magnet_cnn.py:393-437,
+    models/magnet_cnn_2d.py:399-443) by torch autograd through the oracle restatement."""
+    from oracle.models import _criterion
+    o = oracle.to(dtype)
+    b = {k: v.to(dtype) for k, v in batch.items()}
+    t, u, vals, coords, cells = b["t"], b["lr_frames"], b["hr_points"], b["coords"], b["cells"]
+    T, B = o.T, u.shape[0]
+    fut = vals[:, T:]
+    inp, hr_last, outs, hrs = u[:, :T], vals[:, T - 1], [], []
+    as_nodes = lambda f: f.reshape(B, f.shape[1], 1, -1).permute(0, 1, 3, 2)  # noqa: E731
+    for i in range(fut.shape[1] // T):
+        out_hr, out_lr, hr_points = o.forward(inp, coords, cells, t[:, i * T:(i + 2) * T], hr_last)
+        outs.append(torch.cat([out_hr, as_nodes(out_lr) if o.dim == 2 else out_lr], 2))
+        hrs.append(hr_points)
+        if teacher_forcing:
+            inp, hr_last = u[:, (i + 1) * T:(i + 2) * T], vals[:, (i + 2) * T - 1]
+        else:
+            inp, hr_last = (out_lr if o.dim == 2 else out_lr.permute(0, 1, 3, 2)), out_hr[:, -1]
+    pred, hr_hat = torch.cat(outs, 1), torch.cat(hrs, 1)
+    target = torch.cat([fut, as_nodes(u[:, T:])], 2)
+    crit = _criterion(loss_name)
+    loss = crit(pred, target) + crit(hr_hat, vals[:, :-T])
+    o.zero_grad()
+    loss.backward()
+    return float(loss.detach()), {n: p.grad.clone() for n, p in o.named_parameters()}

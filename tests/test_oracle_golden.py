@@ -73,3 +73,20 @@ def test_oracle_magnet_gnn_gradients_match_reference_training_step(teacher_forci
     for n, (norm, sample, stride) in gold.items():
         assert abs(float(grads[n].norm()) - norm) < 2e-4 * max(norm, 1e-12), n
         assert rel_l2(grads[n].flatten()[::stride], sample) < 2e-4, n
+
+
+@pytest.mark.parametrize("teacher_forcing", [False, True])
+@pytest.mark.parametrize("tag", ["magnet_cnn_1d", "magnet_cnn_2d"])
+def test_oracle_magnet_cnn_gradients_match_reference_training_step(tag, teacher_forcing):
+    """and for MAgNet[CNN] 1-D / 2-D (models/magnet_cnn.py:393-437, models/magnet_cnn_2d.py:399-443)"""
+    from tests.helpers import load_grads, oracle_magnet_cnn_grads
+    name, hp, salt, batch, d = load_case(tag)
+    model = O.build(name, hp)
+    fill_state_dict(model, salt)
+    gold_loss, gold = load_grads(tag, teacher_forcing)
+    loss, grads = oracle_magnet_cnn_grads(model, batch, teacher_forcing, hp.loss, dtype=torch.float32)
+    assert abs(loss - gold_loss) < 1e-5 * max(1.0, abs(gold_loss))
+    assert set(grads) == set(gold)
+    for n, (norm, sample, stride) in gold.items():
+        assert abs(float(grads[n].norm()) - norm) < 5e-4 * max(norm, 1e-12), n
+        assert rel_l2(grads[n].flatten()[::stride], sample) < 5e-4, n

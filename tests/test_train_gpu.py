@@ -438,7 +438,7 @@ def test_magnet_gnn_training_step_gradients(teacher_forcing):
     for n, p in model.named_parameters():
         assert p.grad is not None, n
         errs[n] = rel_l2(p.grad, want[n])
-        cos = float((p.grad.double().cpu().flatten() @ want[n].flatten()) / (p.grad.double().norm().cpu() * want[n].norm()).clamp_min(1e-300))
+        cos = float((p.grad.double().cpu().flatten() @ want[n].double().flatten()) / (p.grad.double().norm().cpu() * want[n].double().norm()).clamp_min(1e-300))
         assert errs[n] < 0.1 and cos > 0.995, (n, errs[n], cos)
         norm, sample, stride = gold[n]
         assert abs(float(p.grad.norm()) - norm) < 0.1 * norm, n
@@ -467,3 +467,65 @@ def test_magnet_gnn_optimizer_steps_reduce_the_loss():
     assert losses[-1] < losses[0]
     with torch.no_grad():                                             # inference path sees the updated weights too
         assert torch.isfinite(model.validation_step(cb, 0)).all()
+
+
+def test_differentiable_edsr_matches_torch_autograd():
+    """EDSR.rows_grad: every convolution a differentiable gathered-tap Linear (HIP forward + backward) vs torch conv autograd"""
+    from magnet_amd.models.backbones.edsr import EDSR
+    from oracle.models import EDSR as OracleEDSR
+    torch.manual_seed(12)
+    for mode, shape in (("2d", (2, 5, 9, 7)), ("1d", (2, 5, 21))):
+        ref = OracleEDSR(shape[1], 64, 2, 3, mode).double()
+        net = EDSR(shape[1], 64, 2, 3, 1, mode)
+        net.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+        net = net.cuda()
+        x = torch.randn(*shape)
+        xg = x.cuda().requires_grad_()
+        rows = net.rows_grad(xg)
+        x64 = x.double().requires_grad_()
+        want = ref(x64)
+        want_rows = want.reshape(shape[0], 64, -1).permute(0, 2, 1).reshape(-1, 64)
+        assert rel_l2(rows, want_rows.detach()) < 2e-6
+        g = torch.randn_like(rows) * 1e-5
+        rows.backward(g)
+        want_rows.backward(g.double().cpu())
+        assert rel_l2(xg.grad, x64.grad) < 5e-5
+        refp = dict(ref.named_parameters())
+        for n, p in net.named_parameters():
+            assert rel_l2(p.grad, refp[n].grad) < 5e-5, (mode, n)
+
+
+@pytest.mark.parametrize("teacher_forcing", [False, True])
+@pytest.mark.parametrize("tag", ["magnet_cnn_1d", "magnet_cnn_2d"])
+def test_magnet_cnn_training_step_gradients(tag, teacher_forcing):
+    """MAgNet[CNN] training_step through the HIP autograd Functions (EDSR, grid INR, joint graph, decoder, Euler): equal loss;
+    kink-limited agreement (see test_magnet_gnn_training_step_gradients) with fp64 autograd through the oracle and with the
+    reference's own gradients (tests/golden/magnet_cnn_*_grad.npz)."""
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    from tests.helpers import oracle_magnet_cnn_grads
+    name, hp, salt, batch, d = load_case(tag)
+    hp.teacher_forcing = teacher_forcing
+    oracle = O.build(name, hp)
+    fill_state_dict(oracle, salt)
+    model = FACTORY[name](hp)
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda().train()
+    want_loss, want = oracle_magnet_cnn_grads(oracle, batch, teacher_forcing, hp.loss, dtype=torch.float32)   # the oracle's grid_sample path is fp32
+    cb = {k: v.cuda() for k, v in batch.items()}
+    model.zero_grad()
+    loss = model.training_step(cb, 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - want_loss) < 2e-5 * max(1.0, abs(want_loss))
+    gold_loss, gold = load_grads(tag, teacher_forcing)
+    assert abs(float(loss.detach()) - gold_loss) < 2e-5 * max(1.0, abs(gold_loss))
+    errs = {}
+    for n, p in model.named_parameters():
+        assert p.grad is not None, n
+        errs[n] = rel_l2(p.grad, want[n])
+        cos = float((p.grad.double().cpu().flatten() @ want[n].double().flatten()) / (p.grad.double().norm().cpu() * want[n].double().norm()).clamp_min(1e-300))
+        assert errs[n] < 0.1 and cos > 0.995, (n, errs[n], cos)
+        norm, sample, stride = gold[n]
+        assert abs(float(p.grad.norm()) - norm) < 0.1 * norm, n
+    assert sorted(errs.values())[len(errs) // 2] < 1e-5 and max(errs.values()) < 1e-2       # measured: 6e-7 ... 2e-6, 1.3e-3
