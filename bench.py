@@ -217,6 +217,35 @@ def bench_magnet(args, dev, rank, world, dist, max_over_ranks):
                 "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None, "launch_ms": round(ms, 4), "launches_timed": len(sel), "flops_per_launch": flops,
                 "gemm_mode": mode, "edges": Emax}
+    # ---- training step (autograd Functions with HIP backward kernels, one gradient all-reduce, fused Adam) - unfused,
+    # correctness-first path; reported beside the rollout, never mixed into `value`
+    train = None
+    if args.train_steps > 0:
+        from magnet_amd.sharding import allreduce_gradients
+        tmodel = FACTORY[name](types.SimpleNamespace(**hp)).to(dev).train()
+        opt = tmodel.configure_optimizers()["optimizer"]
+
+        def train_step():
+            opt.zero_grad(set_to_none=True)
+            loss = tmodel.training_step(batch, 0)
+            loss.backward()
+            allreduce_gradients(tmodel.parameters())
+            opt.step()
+            return loss
+
+        first = float(train_step().detach())
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            last = train_step()
+        barrier()
+        t_el = max_over_ranks(time.perf_counter() - t0, dev)
+        train = {"ms_per_step": round(t_el / args.train_steps * 1e3, 3), "steps": args.train_steps, "warmup": 1,
+                 "value": world * B * nodes * pred_steps * args.train_steps / t_el, "unit": "mesh-node-updates/s",
+                 "what": "rollout through autograd Functions (HIP forward + backward kernels, unfused) + one gradient all-reduce + fused Adam",
+                 "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],
+                 "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
+        del tmodel, opt
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -230,7 +259,7 @@ def bench_magnet(args, dev, rank, world, dist, max_over_ranks):
                                    f"time_slice={T} -> {pred_steps} predicted steps, {B} trajectories per GPU",
                        "trajectories_per_gpu": B, "global_trajectories": B * world,
                        "parallelism": f"batch-shard x{world}, no data-path collective"},
-            "roofline": roof, "cpu_baseline": None, "training_step": None}))
+            "roofline": roof, "cpu_baseline": None, "training_step": train}))
 
 
 def main():

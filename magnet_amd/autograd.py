@@ -28,14 +28,22 @@ BWD_GEMM = "bf16x6"
 
 
 # ------------------------------------------------------------------------------------------------ helpers
-def _inverse_csr(idx: torch.Tensor, n_rows: int, cache: dict):
-    """CSR over the *values* of a gather index: rows = gathered-from rows, perm = gathering positions"""
+_INV_CACHE: dict = {}          # (data_ptr, numel, n_rows) -> (idx kept alive, rowptr, perm); gather indices belong to cached topologies
+
+
+def _inverse_csr(idx: torch.Tensor, n_rows: int, cache: dict = None):
+    """CSR over the *values* of a gather index: rows = gathered-from rows, perm = gathering positions.  Built once per
+    index tensor (the sort inside csr_by_target was a third of the first training profile): the cache keeps the index
+    tensor alive, so its address cannot be reused for different contents."""
     key = (idx.data_ptr(), idx.numel(), n_rows)
-    if key not in cache:
+    hit = _INV_CACHE.get(key)
+    if hit is None:
         pos = torch.arange(idx.numel(), dtype=torch.int32, device=idx.device)
         c = ops.csr_by_target(pos, idx, n_rows)
-        cache[key] = (c.rowptr, c.perm)
-    return cache[key]
+        if len(_INV_CACHE) >= 64:
+            _INV_CACHE.pop(next(iter(_INV_CACHE)))
+        hit = _INV_CACHE[key] = (idx, c.rowptr, c.perm)
+    return hit[1], hit[2]
 
 
 def _segment_sum_cols(x, xcol, rowptr, perm, n_rows, width, scale, out, ocol):

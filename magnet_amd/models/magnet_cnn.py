@@ -185,6 +185,7 @@ class MAgNetCNN(MagnetBase):
         self.log("train_interp_loss", self.mae_criterion(hr_hat, vals[:, :-T]), prog_bar=True)
         return loss
 
+    @torch.no_grad()          # validation never differentiates (Lightning runs it under no_grad as well)
     def validation_step(self, val_batch, batch_idx):
         """Free-running rollout; the next LR input is the predicted HR field down-sampled with
         (bi)linear interpolation (magnet_cnn.py:456-461, magnet_cnn_2d.py:466-472)."""

@@ -177,6 +177,7 @@ class MAgNetGNN(MagnetBase):
         self.log("train_interp_loss", self.mae_criterion(hr_hat, vals[:, :-T]), prog_bar=True)
         return loss
 
+    @torch.no_grad()          # validation never differentiates (Lightning runs it under no_grad as well)
     def validation_step(self, val_batch, batch_idx):
         pred, target, _, _ = self._rollout(val_batch)
         self.log("val_loss", self.criterion(pred, target), prog_bar=True)
