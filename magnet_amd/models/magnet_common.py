@@ -101,7 +101,11 @@ class MagnetBase(LightningModule):
         return self._pack
 
     def _weights_changed(self):
+        """FusedAdam writes the parameters behind torch's version counters: drop every packed-weight cache"""
         self._pack_gen += 1
+        for m in self.modules():
+            if m is not self and hasattr(m, "_pack_key"):
+                m._pack_key = None                     # EDSR keeps its own packs / launch plans
 
     # ---- graph (reference _build_graph, models/magnet_gnn.py:286-310) ---------------------
     def _topology(self, coords: torch.Tensor, key):

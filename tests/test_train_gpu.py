@@ -215,13 +215,13 @@ def test_training_step_is_deterministic_and_optimizer_steps():
         grads.append([p.grad.clone() for p in model.parameters()])
     assert all(torch.equal(a, b) for a, b in zip(*grads))
     opt = model.configure_optimizers()["optimizer"]
-    l0 = float(model.training_step(cb, 0))
+    l0 = float(model.training_step(cb, 0).detach())
     for _ in range(5):
         opt.zero_grad()
         loss = model.training_step(cb, 0)
         loss.backward()
         opt.step()
-    assert float(model.training_step(cb, 0)) < l0          # a few Adam steps on one batch reduce its loss
+    assert float(model.training_step(cb, 0).detach()) < l0          # a few Adam steps on one batch reduce its loss
 
 
 def test_fused_adam_matches_torch_adam():
@@ -448,10 +448,11 @@ def test_magnet_gnn_training_step_gradients(teacher_forcing):
     assert len(upstream) > 90 and max(upstream) < 2e-5, max(upstream)
 
 
-def test_magnet_gnn_optimizer_steps_reduce_the_loss():
-    """a few FusedAdam steps of MAgNet[GNN] on one batch: packed-weight caches follow the updates, the loss goes down"""
+@pytest.mark.parametrize("tag", ["magnet_gnn_tiny", "magnet_cnn_2d"])
+def test_magnet_optimizer_steps_reduce_the_loss(tag):
+    """a few FusedAdam steps of a MAgNet model on one batch: packed-weight caches (incl. EDSR's own) follow the updates"""
     from magnet_amd.models.factory import FACTORY
-    name, hp, salt, batch, d = load_case("magnet_gnn_tiny")
+    name, hp, salt, batch, d = load_case(tag)
     torch.manual_seed(0)
     model = FACTORY[name](hp).cuda().train()
     cb = {k: v.cuda() for k, v in batch.items()}
@@ -465,8 +466,11 @@ def test_magnet_gnn_optimizer_steps_reduce_the_loss():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0]
-    with torch.no_grad():                                             # inference path sees the updated weights too
-        assert torch.isfinite(model.validation_step(cb, 0)).all()
+    # the inference path sees the updated weights too: its rollout loss equals a fresh model loaded with the trained weights
+    pred = model.validation_step(cb, 0)
+    fresh = FACTORY[name](hp).cuda().eval()
+    fresh.load_state_dict(model.state_dict())
+    assert torch.isfinite(pred).all() and rel_l2(pred, fresh.validation_step(cb, 0)) < 1e-6
 
 
 def test_differentiable_edsr_matches_torch_autograd():
