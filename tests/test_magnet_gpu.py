@@ -100,3 +100,17 @@ def test_magnet_gnn_1d_configs(L, Nq, irregular):
     pred = model.validation_step({k: v.cuda() for k, v in batch.items()}, 0)
     with torch.no_grad():
         assert rel_l2(pred, oracle.validation_step(batch)) < 5 * OUT_TOL
+
+
+def test_magnet_gnn_1d_training_step():
+    """BASELINE configs 2/3 shapes (1-D coordinates, shipped widths): training_step through the HIP autograd Functions; equal
+    loss, gradients in kink-limited agreement with fp64 autograd through the oracle (tests/test_train_gpu.py explains)."""
+    from tests.helpers import oracle_magnet_gnn_grads
+    hp, batch, oracle, model = _gnn_1d(25, 25, False, seed=25)
+    model.train()
+    want_loss, want = oracle_magnet_gnn_grads(oracle, batch, False, hp.loss)
+    loss = model.training_step({k: v.cuda() for k, v in batch.items()}, 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - want_loss) < 2e-5 * max(1.0, abs(want_loss))
+    errs = sorted(rel_l2(p.grad, want[n]) for n, p in model.named_parameters())
+    assert errs[len(errs) // 2] < 1e-4 and errs[-1] < 0.1, (errs[len(errs) // 2], errs[-1])
