@@ -31,8 +31,8 @@ Extra objects on the JSON line:
   traffic (inside both roofline objects) - HBM bytes per launch from the newest committed PMC measurement of this same
                   command (profiles/r*/traffic_v*.json <- scripts/collect_traffic.py <- two separate rocprofv3 --pmc passes,
                   FETCH_SIZE doubled per the gfx950 correction); null when the workload differs from the recorded one.
-                  Edge kernel 1.58 GB (2.1x its 0.75 GB algorithmic minimum: gathered Bm rows are fetched once per XCD L2),
-                  scatter-mean 4.57 GB = 1.00x algorithmic.
+                  Edge kernel 0.62 GB (0.75 GB algorithmic; 1.58 GB before the XCD-aware tile ranges), scatter-mean 4.57 GB =
+                  1.00x algorithmic.
   training_step - the same workload trained: rollout with tape, HIP backward
                   kernels, ONE flat gradient all-reduce over RCCL, fused Adam; ms per step and the node-updates/s it
                   corresponds to (all ranks), `--train-steps` timed steps after one warm-up.  Never part of `value`.

@@ -18,6 +18,10 @@
 #include "common.cuh"
 #include "edge_tile.cuh"
 
+#ifndef EDGE6_CONTIGUOUS
+#define EDGE6_CONTIGUOUS 1
+#endif
+
 // Swish + segmented inclusive scan of one output register across the 32 edge lanes
 __device__ __forceinline__ float scan_reg(float v, const TileMeta& md) { return seg_scan_sum(act_swish(v), md); }
 
@@ -35,9 +39,22 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, j = lane & 31;
     const int ntiles = (E + 31) / 32;
+#if EDGE6_CONTIGUOUS
+    // XCD-aware contiguous ranges: workgroups are dispatched round-robin over the 8 XCDs (b % 8), each XCD has its own L2;
+    // virtual block vb groups the workgroups of one XCD and every wave walks a contiguous run of tiles, so the A / Bm rows a
+    // wave gathers (edges sorted by target = spatially local) stay in its XCD's L2 instead of being fetched by all eight
+    const int nb8 = gridDim.x / 8;
+    const int vb = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * nb8 + blockIdx.x / 8 : blockIdx.x;
+    const int tpw = (ntiles + gridDim.x * 4 - 1) / (gridDim.x * 4);
+    int tile = (vb * 4 + wave) * tpw;
+    const int tend = min(tile + tpw, ntiles);
+    constexpr int stride = 1;
+#else
     const int stride = gridDim.x * 4;
     int tile = blockIdx.x * 4 + wave;
-    if (tile >= ntiles) return;
+    const int tend = ntiles;
+#endif
+    if (tile >= tend) return;
     f32x16 in[4], out[4], outc[4], prev[4];
     f32x4 la[4], lb[4];                       // one k tile (32 columns) of A[i] / Bm[j] in flight
     {   // prologue: gather + Swish for the first tile
@@ -60,9 +77,9 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__
     }
     TileMeta pmd = tile_meta(tile, E, tgt, rowptr, j);      // placeholder until a real previous tile exists
     bool have_prev = false;
-    for (; tile < ntiles; tile += stride) {
+    for (; tile < tend; tile += stride) {
         const TileMeta md = tile_meta(tile, E, tgt, rowptr, j);
-        const int tn = tile + stride < ntiles ? tile + stride : tile;     // clamped: last iteration prefetches unused data
+        const int tn = tile + stride < tend ? tile + stride : tile;       // clamped: last iteration prefetches unused data
         const int en = min(tn * 32 + j, E - 1);
         const float* pan = A + (size_t)tgt[en] * 128 + 4 * half;
         const float* pbn = Bm + (size_t)src[en] * 128 + 4 * half;
