@@ -124,7 +124,11 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
-    const int tile = blockIdx.x * 4 + wave;
+    // XCD-aware row order: workgroups are dispatched round-robin over the 8 XCDs (each with its own L2); consecutive row
+    // tiles - target-sorted edges gather neighbouring rows - go to the same XCD
+    const int g8 = gridDim.x / 8;
+    const int vbx = (int)blockIdx.x < g8 * 8 ? (int)(blockIdx.x % 8) * g8 + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int tile = vbx * 4 + wave;
     const int row_raw = tile * 32 + (lane & 31);
     const bool row_ok = row_raw < a.M;
     const int row = row_ok ? row_raw : (a.M - 1);
