@@ -18,6 +18,8 @@
 #include "common.cuh"
 #include "edge_tile.cuh"
 
+// EB_INTERLEAVE = 1 moves the s1 / dq stores between the MFMA groups of the two GEMMs (to drain the HBM write queue behind
+// the matrix pipe).  Measured slower: hipcc then spills 147 registers (8.1 ms vs 5.3 ms); kept as a switch.
 #ifndef EB_INTERLEAVE
 #define EB_INTERLEAVE 0
 #endif
@@ -57,9 +59,14 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, j = lane & 31;
     const int ntiles = (E + 31) / 32;
-    const int stride = gridDim.x * 4;
-    int tile = blockIdx.x * 4 + wave;
-    if (tile >= ntiles) return;
+    // XCD-aware contiguous tile ranges, as in k_mpnn_edge6 (workgroups go round-robin over the 8 XCDs and their L2s)
+    const int nb8 = gridDim.x / 8;
+    const int vb = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * nb8 + blockIdx.x / 8 : blockIdx.x;
+    const int tpw = (ntiles + gridDim.x * 4 - 1) / (gridDim.x * 4);
+    int tile = (vb * 4 + wave) * tpw;
+    const int tend = min(tile + tpw, ntiles);
+    constexpr int stride = 1;
+    if (tile >= tend) return;
     // software pipeline over the tiles of this wave: the Bm rows of tile t+1 are requested before GEMM 2 of tile t, its A
     // rows after it, the dagg rows of tile t before its GEMM 1 - with one wave per SIMD nothing else hides the latency.
     f32x16 ga[4], gb[4];
@@ -80,13 +87,13 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
                 }
             }
     }
-    for (; tile < ntiles; tile += stride) {
+    for (; tile < tend; tile += stride) {
         const TileMeta md = tile_meta(tile, E, tgt, rowptr, j);
         const int e = min(tile * 32 + j, E - 1);
         const int ti = md.ti;
         const float inv_deg = 1.0f / (float)(md.re - md.rs);
         const size_t row = (size_t)e * 128 + 4 * half;
-        const int tn = tile + stride < ntiles ? tile + stride : tile;     // clamped: the last iteration prefetches unused rows
+        const int tn = tile + stride < tend ? tile + stride : tile;       // clamped: the last iteration prefetches unused rows
         const int en = min(tn * 32 + j, E - 1);
         const float* pan = A + (size_t)tgt[en] * 128 + 4 * half;
         const float* pbn = Bm + (size_t)src[en] * 128 + 4 * half;
