@@ -87,6 +87,20 @@ class FusedAdam(torch.optim.Optimizer):
             o += k
         return self._scratch_g
 
+    # ---- checkpointing: the moments live in the flat buffers, not in ``self.state``
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["magnet_flat"] = {"exp_avg": self.flat_m.clone(), "exp_avg_sq": self.flat_v.clone(), "step": self.steps}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        flat = state_dict.get("magnet_flat")
+        super().load_state_dict({k: v for k, v in state_dict.items() if k != "magnet_flat"})
+        if flat is not None:
+            self.flat_m.copy_(flat["exp_avg"])
+            self.flat_v.copy_(flat["exp_avg_sq"])
+            self.steps = int(flat["step"])
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

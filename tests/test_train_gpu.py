@@ -533,3 +533,35 @@ def test_magnet_cnn_training_step_gradients(tag, teacher_forcing):
         norm, sample, stride = gold[n]
         assert abs(float(p.grad.norm()) - norm) < 0.1 * norm, n
     assert sorted(errs.values())[len(errs) // 2] < 1e-5 and max(errs.values()) < 1e-2       # measured: 6e-7 ... 2e-6, 1.3e-3
+
+
+def test_fused_adam_checkpoint_resume():
+    """optimizer.state_dict() / load_state_dict() carry the flat moments and the step count: a resumed run continues bitwise"""
+    from magnet_amd.optim import FusedAdam
+    torch.manual_seed(13)
+    def make():
+        torch.manual_seed(13)
+        return [torch.nn.Parameter(torch.randn(64, 33, device="cuda")), torch.nn.Parameter(torch.randn(7, device="cuda"))]
+    grads = [[torch.randn(64, 33, device="cuda"), torch.randn(7, device="cuda")] for _ in range(6)]
+    a = make()
+    oa = FusedAdam(a, lr=1e-2, weight_decay=1e-3)
+    for g in grads[:3]:
+        for p, gg in zip(a, g):
+            p.grad = gg.clone()
+        oa.step()
+    ckpt_params, ckpt_opt = [p.detach().clone() for p in a], oa.state_dict()
+    for g in grads[3:]:
+        for p, gg in zip(a, g):
+            p.grad = gg.clone()
+        oa.step()
+    b = make()
+    ob = FusedAdam(b, lr=1e-2, weight_decay=1e-3)
+    with torch.no_grad():
+        for p, c in zip(b, ckpt_params):
+            p.copy_(c)
+    ob.load_state_dict(ckpt_opt)
+    for g in grads[3:]:
+        for p, gg in zip(b, g):
+            p.grad = gg.clone()
+        ob.step()
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
