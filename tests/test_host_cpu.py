@@ -91,3 +91,23 @@ def test_split_fp16x2_reconstructs_to_fp32_class():
     assert float(((back - x.double()).abs() / x.double().abs().clamp_min(6.1e-5)).max()) < 2.5e-7
     with pytest.raises(ValueError):
         split_fp16x2(torch.tensor([1.0, 7e4]))
+
+
+def test_training_host_logic_on_cpu():
+    """host-side pieces of the training path that need no GPU: flat-gradient detection, the width decomposition of the
+    backward GEMMs, and the loud failure of the fused optimizer / differentiable ops without a HIP device."""
+    import torch
+    from magnet_amd import optim
+    from magnet_amd.autograd import _tiles_of
+    assert _tiles_of(384) == [(0, 128), (128, 128), (256, 128)] and _tiles_of(160) == [(0, 128), (128, 32)]
+    assert _tiles_of(96) == [(0, 64), (64, 32)] and _tiles_of(32) == [(0, 32)]
+    ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5))]
+    fg = optim.FlatGrads(ps)
+    for p, v in zip(ps, fg.views):
+        p.grad = v
+    flat = optim.flat_gradient(ps)
+    assert flat is not None and flat.numel() == 17 and flat.data_ptr() == fg.flat.data_ptr()
+    ps[1].grad = torch.zeros(5)                                   # a gradient from elsewhere: not one buffer any more
+    assert optim.flat_gradient(ps) is None
+    with pytest.raises(RuntimeError, match="HIP device"):
+        optim.FusedAdam(ps)
