@@ -115,7 +115,8 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
     MLP_ABL_INIT
     constexpr int NTMAX = MaxI<HT, OT>::v;
     constexpr int PPN = 2 * Split<MODE>::NP;                              // 1 KiB pieces per output tile and k tile
-    constexpr int DIST = (NL >= 5 && HT >= 4) ? 2 : 1;                   // chunks requested ahead (measured: 2 pays only for the long 128-wide chains)
+    constexpr int DIST = 1;                   // chunks requested ahead.  2 (three-slot ring, counted vmcnt) paid +7 % while the wide
+                                              // 5-Linear chains ran one workgroup per CU; with two per CU it costs 3 % (C5 edge MLP 1.63 vs 1.59 ms)
     constexpr int NBUF = DIST + 1;
     constexpr bool PIPE = (NL >= 5 && HT >= 4);                          // see mma_chunk
     constexpr int CH = NTMAX * PPN * 64;                                   // u32x4 per chunk buffer
