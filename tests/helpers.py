@@ -18,7 +18,7 @@ def load_case(tag):
 
 
 def rel_l2(a, b):
-    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 

@@ -565,3 +565,58 @@ def test_fused_adam_checkpoint_resume():
             p.grad = gg.clone()
         ob.step()
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("tw,dim", [(50, 1), (20, 1), (16, 1)])
+def test_mpnn_training_gradients_other_time_windows(tw, dim):
+    """the other read-out variants of mpnn.py:140-163 (tw = 50 pads node_in to 64 columns: two k tiles in every node-level
+    backward GEMM): training_step gradients vs fp64 autograd through the oracle (smooth net: tight tolerance)."""
+    import types
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    hp = types.SimpleNamespace(lr=1e-3, weight_decay=0.0, factor=0.3, step_size=50, loss="l2", hidden_features=128, hidden_layer=5,
+                               time_window=tw, teacher_forcing=False, neighbors=3)
+    g = torch.Generator().manual_seed(tw)
+    B, N, nt = 2, 40, 3 * tw
+    batch = {"u": torch.randn(B, N, nt, generator=g), "x": torch.linspace(0, 16, N)[None, :, None].repeat(B, 1, 1),
+             "t": torch.linspace(0, 4, nt)[None].repeat(B, 1)}
+    oracle = O.build("mpnn", hp)
+    fill_state_dict(oracle, 40 + tw)
+    model = FACTORY["mpnn"](hp)
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda().train()
+    want_loss, want = oracle_grads(oracle, batch, False, hp.loss)
+    loss = model.training_step({k: v.cuda() for k, v in batch.items()}, 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - want_loss) < 1e-5 * max(1.0, abs(want_loss))
+    bad = {n: rel_l2(p.grad, want[n]) for n, p in model.named_parameters() if not rel_l2(p.grad, want[n]) < GRAD_TOL}
+    assert not bad, bad
+
+
+def test_differentiable_mlp_shared_rows_source():
+    """a dense source shared by ``rdiv`` consecutive rows (row r reads t[r // rdiv]): forward and the fixed-size segment sum
+    of its backward, vs torch autograd"""
+    from magnet_amd import autograd as AG, ops
+    from magnet_amd.models.magnet_common import pack_mlp
+    from magnet_amd.models.backbones.mlp import MLP
+    torch.manual_seed(14)
+    rows, rdiv = 250, 5
+    net = MLP(64, [64] * 4, 32).cuda()
+    pk = pack_mlp(net)
+    a = torch.randn(rows, 32, device="cuda", requires_grad=True)
+    b = torch.randn(rows // rdiv, 32, device="cuda", requires_grad=True)
+    y = AG.mlp(rows, [ops.Term(a, 32), ops.Term(b, 32, rdiv=rdiv)], pk, pk.params)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    net64 = __import__("copy").deepcopy(net).double()
+    a64, b64 = a.detach().double().requires_grad_(), b.detach().double().requires_grad_()
+    h = torch.cat([a64, b64.repeat_interleave(rdiv, 0)], 1)
+    lins = net64.linears()
+    for i, lin in enumerate(lins):
+        h = lin(h)
+        if i < len(lins) - 1:
+            h = torch.relu(h)
+    assert rel_l2(y, h.detach()) < 2e-6
+    h.backward(gy.double())
+    assert rel_l2(a.grad, a64.grad) < 5e-5 and rel_l2(b.grad, b64.grad) < 5e-5
