@@ -114,3 +114,37 @@ def test_magnet_gnn_1d_training_step():
     assert abs(float(loss.detach()) - want_loss) < 2e-5 * max(1.0, abs(want_loss))
     errs = sorted(rel_l2(p.grad, want[n]) for n, p in model.named_parameters())
     assert errs[len(errs) // 2] < 1e-4 and errs[-1] < 0.1, (errs[len(errs) // 2], errs[-1])
+
+
+def test_datamodule_batches_feed_the_models():
+    """items of magnet_amd.datamodule (the reference's HDF5 batch schemas) collated with to_device go
+    straight into validation_step - irregular 2-D implicit-GNN data into magnet_gnn, regular 2-D graph data into mpnn_2d's
+    graph builder - and give the oracle's result on the same batch."""
+    import os
+    import types
+    import numpy as np
+    from magnet_amd import datamodule as DM
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data_items.npz"), allow_pickle=False)
+    tree = {}
+    for k in gold.files:
+        if k.startswith("tree:irr:"):
+            _, _, mode, key = k.split(":")
+            tree.setdefault(mode, {})[key] = gold[k]
+    nt, n = int(gold["cfg_nt"]), int(gold["cfg_n_irr"])
+    ds = DM.HDF5DatasetImplicitGNN_2d(None, nt, n, mode="valid", regular=False, source=tree)
+    items = [ds[0], ds[1]]
+    hp = types.SimpleNamespace(lr=1e-3, weight_decay=0.0, factor=0.3, step_size=50, loss="l1", time_slice=4, latent_dim=32,
+                               num_message_passing_steps=2, mlp_layers=4, mlp_hidden=64, radius=0.6, n_chan=64, teacher_forcing=False,
+                               codec_neighbors=4, noise=0, interpolation="area")
+    oracle = O.build("magnet_gnn", hp).eval()
+    fill_state_dict(oracle, 77)
+    model = FACTORY["magnet_gnn"](hp).eval()
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda()
+    pred = model.validation_step(DM.to_device(items, "cuda"), 0)
+    with torch.no_grad():
+        want = oracle.validation_step(DM.to_device(items, "cpu"))
+    assert pred.shape == want.shape and rel_l2(pred, want) < 5 * OUT_TOL
