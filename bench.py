@@ -57,7 +57,7 @@ HP = dict(lr=1e-3, weight_decay=0.0, factor=0.3, step_size=50, loss="l1", hidden
 NT = 50
 MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_BF16_PEAK_TFLOPS = 2500.0
-SPLIT_PRODUCTS = {"fp16x3": 3, "bf16x6": 6}   # MFMA partial products per fp32 product in k_mpnn_edge6
+SPLIT_PRODUCTS = {"fp16x3": 3, "bf16x6": 6, "bf16": 1}   # MFMA products per multiply in k_mpnn_edge6 (bf16: reduced precision)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -107,6 +107,13 @@ def synthetic_magnet_batch(name, B, Wq, seed, device):
         batch = {"t": t, "lr_frames": torch.randn(B, NT, 1, n_lr, generator=g), "hr_points": hr, "coords_hr": hr_c,
                  "coords_lr": lr_c}
     return {k: v.to(device) for k, v in batch.items()}, n_lr + Wq * Wq
+
+
+DTYPE_NOTE = {"fp16x3": "f32 (GEMMs: exact 2-piece fp16 split on the matrix cores, fp32 accumulate)",
+              "bf16x6": "f32 (GEMMs: exact 3-piece bf16 split on the matrix cores, fp32 accumulate)",
+              "fp32": "f32 (fp32 MFMA)",
+              "bf16": "bf16 - REDUCED precision (inputs and weights rounded to one bf16 piece, fp32 accumulate): not the headline, "
+                      "see deviation_vs_f32_path"}
 
 
 def measured_traffic(kernel):
@@ -185,7 +192,8 @@ def bench_magnet(args, dev, rank, world, dist, max_over_ranks):
     if rank == 0:      # dominant kernel: the InteractionNetwork edge MLP (5 Linears + LayerNorm + CSR mean) of the joint graph
         D, H = hp["latent_dim"], hp["mlp_hidden"]
         mode = __import__("magnet_amd.packing", fromlist=["default_gemm"]).default_gemm()
-        entry = {"fp16x3": "magnet_mlp_fp16x3_f32", "bf16x6": "magnet_mlp_bf16x6_f32", "fp32": "magnet_mlp_f32"}[mode]
+        entry = {"fp16x3": "magnet_mlp_fp16x3_f32", "bf16x6": "magnet_mlp_bf16x6_f32", "fp32": "magnet_mlp_f32",
+                 "bf16": "magnet_mlp_bf16_f32"}[mode]
         orig = getattr(ops.L.lib(), entry)
         ev = []
 
@@ -254,7 +262,7 @@ def bench_magnet(args, dev, rank, world, dist, max_over_ranks):
             "metric": f"mesh-node-updates/s (nodes x steps x batch), {name} 256^2-query rollout", "value": value,
             "unit": "mesh-node-updates/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (GEMMs: exact 2-piece fp16 split on the matrix cores, fp32 accumulate)", "data": "synthetic",
+            "dtype": DTYPE_NOTE[__import__("magnet_amd.packing", fromlist=["default_gemm"]).default_gemm()], "data": "synthetic",
             "config": {"workload": f"{name} free-running rollout, {nodes - Wq * Wq} LR nodes + {Wq}x{Wq} queries, nt={NT}, "
                                    f"time_slice={T} -> {pred_steps} predicted steps, {B} trajectories per GPU",
                        "trajectories_per_gpu": B, "global_trajectories": B * world,
@@ -271,6 +279,9 @@ def main():
     ap.add_argument("--mesh", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=3, help="timed training steps of the extra 'training_step' leg (0: skip)")
+    ap.add_argument("--gemm", default=None, choices=["fp16x3", "bf16x6", "fp32", "bf16"],
+                    help="arithmetic of the Linears; default fp16x3 = fp32-class.  'bf16' is the REDUCED-precision mode BASELINE.json "
+                         "config 2 asks for: reported with its measured deviation from the fp32-class result, never as the headline")
     ap.add_argument("--workload", default="mpnn_2d", choices=["mpnn_2d", "magnet_cnn_2d", "magnet_gnn"],
                     help="mpnn_2d = the headline metric case; the two MAgNet 256^2 cases of SURVEY.md 8(d) (C4b, C5) on request")
     args = ap.parse_args()
@@ -293,6 +304,8 @@ def main():
         else:
             dist.init_process_group(backend)
     W, B, K, Wm = args.mesh, args.traj, args.steps, args.warmup
+    if args.gemm:
+        os.environ["MAGNET_GEMM"] = args.gemm                  # read by packing.default_gemm() when the models are built
     if args.workload != "mpnn_2d":
         return bench_magnet(args, dev, rank, world, dist, max_over_ranks)
 
@@ -417,6 +430,15 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(128)
+    deviation = None
+    if model.edge_gemm == "bf16" and rank == 0:               # reduced precision: measure it against the fp32-class path
+        ref_model = FACTORY["mpnn_2d"](types.SimpleNamespace(**dict(HP, edge_gemm="fp16x3", gemm="fp16x3"))).to(dev).eval()
+        ref_model.load_state_dict(model.state_dict())
+        a, b = model.validation_step(batch, 0), ref_model.validation_step(batch, 0)
+        last = batch["u"][:, :, HP["time_window"] - 1].unsqueeze(1)
+        deviation = {"rollout_rel_l2": float((a - b).norm() / b.norm()),
+                     "increment_rel_l2": float(((a - last) - (b - last)).norm() / (b - last).norm())}
+        del ref_model
 
     if world > 1:
         dist.barrier()
@@ -425,7 +447,7 @@ def main():
         line = {"metric": "mesh-node-updates/s (nodes x steps x batch), 2D Burgers 256^2 rollout",
                 "value": value, "unit": "mesh-node-updates/s", "n_gpus": world, "steps": K, "warmup": Wm,
                 "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32 (GEMMs: exact 2-piece fp16 split on the matrix cores, fp32 accumulate)", "data": "synthetic",
+                "dtype": DTYPE_NOTE[model.edge_gemm], "data": "synthetic", "deviation_vs_f32_path": deviation,
                 "config": {"workload": f"mpnn_2d free-running rollout, {W}x{W} regular mesh (N={W * W}, E={model._topo.csr.E // B} per "
                                        f"trajectory), nt={NT}, time_window={tw} -> {pred_steps} predicted steps, {B} trajectories per GPU, "
                                        "radius graph + CSR rebuilt every step",

@@ -91,6 +91,11 @@ int magnet_mlp_bf16x6_f32(const magnet_mlp_args_t* args, int nl, int ht, int ot,
  * layer[l].w: planes [kt][nt][m][2][64 lanes][8 fp16] (magnet_amd/packing.py:pack_linear_fp16x2). */
 int magnet_mlp_fp16x3_f32(const magnet_mlp_args_t* args, int nl, int ht, int ot, int act, int last_act, int ln, int epi,
                           void* stream);
+/* REDUCED precision, opt-in (BASELINE.json config 2 "bf16"): inputs and weights rounded to ONE bf16 piece (RNE), one MFMA
+ * product, fp32 accumulate; ~1e-2 relative deviation from the fp32 result.  layer[l].w: one bf16 plane
+ * [kt][nt][m][1][64 lanes][8 bf16] (packing.py:pack_linear_bf16x1). */
+int magnet_mlp_bf16_f32(const magnet_mlp_args_t* args, int nl, int ht, int ot, int act, int last_act, int ln, int epi,
+                        void* stream);
 int magnet_segmean_fixup_f32(const int32_t* rowptr, int n_rows, int d, const float* partials, float* agg,
                              void* stream);
 
@@ -119,6 +124,10 @@ int magnet_mpnn_edge_bf16x6_f32(const float* A, const float* Bm, const int32_t* 
 int magnet_mpnn_edge_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
                                 const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2, float* agg,
                                 float* partials, void* stream);
+/* reduced-precision variant of the edge kernel (one bf16 piece, see magnet_mlp_bf16_f32) */
+int magnet_mpnn_edge_bf16_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
+                              const int32_t* rowptr, int n_edges, const void* w2_bf16, const float* b2, float* agg,
+                              float* partials, void* stream);
 /* out[n][k] = u[n][tw-1] + dt*(k+1) * Conv1d(8->1,k2)([Swish](Conv1d(1->8,k1,stride s1)(h[n])))[k];
  * models/mpnn.py:197-201 with the conv specs of :140-163. */
 int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1, int k1,

@@ -255,7 +255,7 @@ __device__ __forceinline__ f32x16 mma_split6(bf16x8 wh, bf16x8 wm, bf16x8 wl, bf
 // post-norm hidden state on this path); bf16x6 has the full fp32 range and remains selectable.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
-enum { GEMM_BF16X6 = 0, GEMM_FP16X3 = 1 };
+enum { GEMM_BF16X6 = 0, GEMM_FP16X3 = 1, GEMM_BF16 = 2 };
 
 template <int MODE>
 struct Split;
@@ -298,6 +298,24 @@ struct Split<GEMM_FP16X3> {
 #pragma unroll
         for (int i = 0; i < 16; ++i) accM[i] = fmaf(accC[i], 1.0f / 2048.0f, accM[i]);
     }
+};
+
+// Reduced precision (opt-in, BASELINE.json config 2): ONE bf16 piece per value, round-to-nearest-even, one MFMA product.
+__device__ __forceinline__ unsigned bf16_rne_pair(float v1, float v0) {          // (bf16(v1) << 16) | bf16(v0)
+    const unsigned a = __float_as_uint(v0), b = __float_as_uint(v1);
+    const unsigned ra = a + 0x7FFFu + ((a >> 16) & 1u), rb = b + 0x7FFFu + ((b >> 16) & 1u);
+    return __builtin_amdgcn_perm(rb, ra, 0x07060302u);
+}
+template <>
+struct Split<GEMM_BF16> {
+    static constexpr int NP = 1;
+    static __device__ __forceinline__ void quarter(const f32x16& tile, int m, int p, u32x4 (&planes)[1]) {
+        planes[0][p] = bf16_rne_pair(tile[8 * m + 2 * p + 1], tile[8 * m + 2 * p]);
+    }
+    static __device__ __forceinline__ void mma(const u32x4 (&w)[1], const u32x4 (&x)[1], f32x16& accM, f32x16&) {
+        accM = mfma_bf16(__builtin_bit_cast(bf16x8, w[0]), __builtin_bit_cast(bf16x8, x[0]), accM);
+    }
+    static __device__ __forceinline__ void fold(f32x16&, const f32x16&) {}
 };
 
 template <int MODE>

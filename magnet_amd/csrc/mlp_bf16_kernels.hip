@@ -305,6 +305,15 @@ extern "C" int magnet_mlp_bf16x6_f32(const MagnetMlpArgs* args, int nl, int ht, 
     return launch_mlp(pick<GEMM_BF16X6>(nl, ht, ot, act, last_act, ln, epi), args, stream);
 }
 
+extern "C" int magnet_mlp_bf16_f32(const MagnetMlpArgs* args, int nl, int ht, int ot, int act, int last_act, int ln,
+                                  int epi, void* stream) {
+    (void)hipGetLastError();
+    if (!args || args->M <= 0) return args && args->M == 0 ? 0 : -1;
+    if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
+    if (args->ncolgroups > 1 && (nl != 1 || args->ncolgroups > MAGNET_MAX_LAYERS)) return -2;
+    return launch_mlp(pick<GEMM_BF16>(nl, ht, ot, act, last_act, ln, epi), args, stream);
+}
+
 extern "C" int magnet_mlp_fp16x3_f32(const MagnetMlpArgs* args, int nl, int ht, int ot, int act, int last_act, int ln,
                                      int epi, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)

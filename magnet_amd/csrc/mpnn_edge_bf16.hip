@@ -183,6 +183,12 @@ extern "C" int magnet_mpnn_edge_bf16x6_f32(const float* A, const float* Bm, cons
     return launch_edge6<GEMM_BF16X6>(A, Bm, src, tgt, rowptr, n_edges, w2_split, b2, agg, partials, stream);
 }
 
+extern "C" int magnet_mpnn_edge_bf16_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
+                                         const int32_t* rowptr, int n_edges, const void* w2_bf16, const float* b2,
+                                         float* agg, float* partials, void* stream) {
+    return launch_edge6<GEMM_BF16>(A, Bm, src, tgt, rowptr, n_edges, w2_bf16, b2, agg, partials, stream);
+}
+
 extern "C" int magnet_mpnn_edge_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
                                            const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2,
                                            float* agg, float* partials, void* stream) {

@@ -99,7 +99,8 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
         a.tgt, a.rowptr, a.partials = tgt.data_ptr(), rowptr.data_ptr(), partials.data_ptr()
     kind = layers[0][0].dtype                                 # float16: fp16x3, int16: bf16x6, float32: fp32 MFMA
     assert all(w.dtype == kind for w, _ in layers)
-    name = {torch.float16: "magnet_mlp_fp16x3_f32", torch.int16: "magnet_mlp_bf16x6_f32", torch.float32: "magnet_mlp_f32"}[kind]
+    name = {torch.float16: "magnet_mlp_fp16x3_f32", torch.int16: "magnet_mlp_bf16x6_f32", torch.float32: "magnet_mlp_f32",
+            torch.bfloat16: "magnet_mlp_bf16_f32"}[kind]
     fn = getattr(L.lib(), name)
     ref = C.byref(a)
     what = f"{name}(nl={nl},ht={ht},ot={ot},act={act},ln={ln is not None},epi={epi})"
@@ -141,7 +142,7 @@ def mpnn_node_input(u, pos, Lvec, tmax, tw, dpos, kin):
 
 
 EDGE_ENTRY = {torch.float16: "magnet_mpnn_edge_fp16x3_f32", torch.int16: "magnet_mpnn_edge_bf16x6_f32",
-              torch.float32: "magnet_mpnn_edge_f32"}
+              torch.float32: "magnet_mpnn_edge_f32", torch.bfloat16: "magnet_mpnn_edge_bf16_f32"}
 
 
 def mpnn_edge(A, Bm, csr, w2, b2, agg, partials):

@@ -116,11 +116,34 @@ def pack_linear_fp16x2(w: torch.Tensor, b: torch.Tensor | None, k_pad: int | Non
     return out.view(-1), bp
 
 
+def pack_linear_bf16x1(w: torch.Tensor, b: torch.Tensor | None, k_pad: int | None = None, n_pad: int | None = None,
+                       col_map: torch.Tensor | None = None):
+    """ONE bf16 plane (round-to-nearest-even) in MFMA fragment order [kt][nt][m][1][lane][8] (bfloat16) + padded fp32 bias:
+    the reduced-precision "bf16" mode (bf16 inputs and weights, fp32 accumulate) BASELINE.json config 2 asks for."""
+    n, k = w.shape
+    kp = k_pad or pad_to(k if col_map is None else int(col_map.max()) + 1)
+    np_ = n_pad or pad_to(n)
+    wp = torch.zeros(np_, kp, dtype=torch.float32, device=w.device)
+    if col_map is None:
+        wp[:n, :k] = w.detach().float()
+    else:
+        wp[:n, col_map.to(w.device)] = w.detach().float()
+    kt, nt = kp // 32, np_ // 32
+    pl = wp.to(torch.bfloat16).view(torch.int16)
+    out = pl.view(nt, 32, kt, 2, 2, 2, 4).permute(2, 0, 3, 5, 1, 4, 6).reshape(kt, nt, 2, 1, 64, 8).contiguous()
+    bp = torch.zeros(np_, dtype=torch.float32, device=w.device)
+    if b is not None:
+        bp[:n] = b.detach().float()
+    return out.view(-1).view(torch.bfloat16), bp
+
+
 # ---- which arithmetic the Linears run on (ops picks the kernel from the dtype of the packed weights):
 #   "fp16x3" (default)  two fp16 pieces, 3 MFMA products, |values| < 65504   -> float16 planes
 #   "bf16x6"            three bf16 pieces, 6 MFMA products, full fp32 range    -> int16 planes
 #   "fp32"              v_mfma_f32_32x32x2_f32                                 -> float32 fragments
-GEMM_MODES = ("fp16x3", "bf16x6", "fp32")
+#   "bf16"              REDUCED precision: one bf16 piece (RNE), 1 MFMA product -> bfloat16 plane.  Opt-in only (BASELINE
+#                       config 2); ~1e-2 deviation from the fp32 result, reported as a deviation, never as parity
+GEMM_MODES = ("fp16x3", "bf16x6", "fp32", "bf16")
 
 
 def default_gemm() -> str:
@@ -135,5 +158,7 @@ def pack(w, b, mode: str, k_pad=None, n_pad=None, col_map=None):
         return pack_linear_fp16x2(w, b, k_pad=k_pad, n_pad=n_pad, col_map=col_map)
     if mode == "bf16x6":
         return pack_linear_bf16x3(w, b, k_pad=k_pad, n_pad=n_pad, col_map=col_map)
+    if mode == "bf16":
+        return pack_linear_bf16x1(w, b, k_pad=k_pad, n_pad=n_pad, col_map=col_map)
     assert mode == "fp32", mode
     return pack_linear(w, b, k_pad=k_pad, n_pad=n_pad, col_map=col_map)

@@ -148,3 +148,23 @@ def test_datamodule_batches_feed_the_models():
     with torch.no_grad():
         want = oracle.validation_step(DM.to_device(items, "cpu"))
     assert pred.shape == want.shape and rel_l2(pred, want) < 5 * OUT_TOL
+
+
+def test_magnet_gnn_bf16_mode_deviation(monkeypatch):
+    """the same opt-in reduced-precision mode for the MAgNet chains (MAGNET_GEMM=bf16): a measured deviation, not parity"""
+    monkeypatch.setenv("MAGNET_GEMM", "bf16")
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    name, hp, salt, batch, d = load_case("magnet_gnn_tiny")
+    oracle = O.build(name, hp).eval()
+    fill_state_dict(oracle, salt)
+    model = FACTORY[name](hp).eval()
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda()
+    args = [a.cuda() for a in forward_args(name, hp, batch)]
+    with torch.no_grad():
+        out = model(*args)
+    dev = rel_l2(out[0], d["fwd_out_hr"])
+    print("bf16 magnet_gnn forward deviation", dev)
+    assert OUT_TOL < dev < 5e-2
