@@ -17,6 +17,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MAGNET_MAX_KT 36      // first-layer K up to 1152 (a 3x3 convolution over 128 channels as 9 gathered taps)
 #define MAGNET_MAX_LAYERS 6

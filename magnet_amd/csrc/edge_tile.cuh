@@ -54,16 +54,18 @@ __device__ __forceinline__ void store_run_results(const f32x16 (&v)[NT], const T
         const int e0 = md.tile * 32;
         const int s = md.rs, en = md.re;
         const bool complete = (s >= e0) && (en <= e0 + 32);
-        const float dn = (MEAN && complete) ? (float)(en - s) : 1.f;
+        // one reciprocal per run instead of 32 * NT IEEE divisions (each a ~10-instruction sequence that every lane of the
+        // wave pays although only the run-end lanes are active): mean = sum * RN(1 / degree), within 1 ulp of sum / degree
+        const float inv = (MEAN && complete) ? 1.f / (float)(en - s) : 1.f;
         float* dst = complete ? out + (size_t)md.ti * D : partials + ((size_t)md.tile * 2 + (s < e0 ? 0 : 1)) * D;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 o = {v[nt][4 * g], v[nt][4 * g + 1], v[nt][4 * g + 2], v[nt][4 * g + 3]};
-                if (MEAN && complete) {
+                if (MEAN) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = o[c] / dn;
+                    for (int c = 0; c < 4; ++c) o[c] *= inv;
                 }
                 *reinterpret_cast<f32x4*>(dst + nt * 32 + 8 * g + 4 * half) = o;
             }

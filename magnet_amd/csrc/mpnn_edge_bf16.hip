@@ -148,6 +148,203 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__
     store_run_results<4, true>(prev, pmd, agg, partials, half);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Generation 7: the same pipeline, but the segmented mean no longer runs as a DPP scan over the 64 output registers
+// of every lane (5 dpp moves + 5 fmas + hazard nops per register: ~1 250 of the ~4 400 instructions a tile cost, and
+// the kernel is instruction-issue bound).  The folded GEMM output of tile t-1 is written once to a per-wave LDS tile
+// (32 edges x 128 features, rows padded to 132 floats: the 16-byte writes of 16 consecutive lanes cover all 64 banks)
+// and read back TRANSPOSED while tile t runs on the matrix cores: in MFMA group e every lane reads features
+// (2 lane, 2 lane + 1) of edge e (one conflict-free ds_read_b64), adds the bias, applies Swish and adds into a
+// two-register running sum; run ends are wave-uniform (a ballot of tgt[e] != tgt[e+1]), so the finished row leaves
+// with one coalesced 512-byte store under a scalar branch.  Same number of Swish evaluations, ~3x fewer instructions.
+// The sum runs in edge order (deterministic); tile-boundary runs go through `partials` exactly as before.
+constexpr int TB_STRIDE = 132;
+
+struct RunMeta {             // per-lane bookkeeping of one tile (lane j <-> edge j), read back with readlane at run ends
+    int tile, ti, rs, re;
+    unsigned ends;           // wave-uniform: bit e set <=> edge e is the last edge of its run inside this tile
+};
+
+__device__ __forceinline__ RunMeta run_meta(int tile, int E, const int32_t* __restrict__ tgt,
+                                            const int32_t* __restrict__ rowptr, int j) {
+    RunMeta md;
+    md.tile = tile;
+    const int e_raw = tile * 32 + j;
+    const bool e_ok = e_raw < E;
+    md.ti = tgt[e_ok ? e_raw : E - 1];
+    const int tnext = (e_raw + 1 < E && j < 31) ? tgt[e_raw + 1] : -2;
+    md.rs = rowptr[md.ti];
+    md.re = rowptr[md.ti + 1];
+    md.ends = (unsigned)__builtin_amdgcn_ballot_w64(e_ok && tnext != md.ti);      // both halves agree: low word
+    return md;
+}
+
+// the run that ends at edge e of tile md.tile: mean (complete run) or tile-boundary partial sum
+__device__ __forceinline__ void emit_run(const f32x2 acc, const RunMeta& md, int e, float* __restrict__ agg,
+                                         float* __restrict__ partials, int lane) {
+    const int ti = __builtin_amdgcn_readlane(md.ti, e);
+    const int rs = __builtin_amdgcn_readlane(md.rs, e), re = __builtin_amdgcn_readlane(md.re, e);
+    const int e0 = md.tile * 32;
+    f32x2 o = acc;
+    float* dst;
+    if (rs >= e0 && re <= e0 + 32) {
+        const float dn = (float)(re - rs);
+        o[0] = o[0] / dn;
+        o[1] = o[1] / dn;
+        dst = agg + (size_t)ti * 128;
+    } else {
+        dst = partials + ((size_t)md.tile * 2 + (rs < e0 ? 0 : 1)) * 128;
+    }
+    *reinterpret_cast<f32x2*>(dst + 2 * lane) = o;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                       const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
+                                                       const int32_t* __restrict__ rowptr, int E,
+                                                       const u32x4* __restrict__ w2s /* [32 slots][NP planes][64] */,
+                                                       const float* __restrict__ b2, float* __restrict__ agg,
+                                                       float* __restrict__ partials) {
+    constexpr int NP = Split<MODE>::NP;
+    static_assert(NP <= 2, "the transposition tiles and three weight planes do not fit the 160 KiB of LDS together");
+    __shared__ __attribute__((aligned(16))) u32x4 wl[32 * NP * 64];          // 64 KiB (fp16x3) / 32 KiB (bf16)
+    __shared__ __attribute__((aligned(16))) float tb[4][32 * TB_STRIDE];     // 66 KiB
+    for (int i = threadIdx.x; i < 32 * NP * 64; i += 256) wl[i] = w2s[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    const int ntiles = (E + 31) / 32;
+    const int nb8 = gridDim.x / 8;         // XCD-aware contiguous ranges, see k_mpnn_edge6
+    const int vb = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * nb8 + blockIdx.x / 8 : blockIdx.x;
+    const int tpw = (ntiles + gridDim.x * 4 - 1) / (gridDim.x * 4);
+    int tile = (vb * 4 + wave) * tpw;
+    const int tend = min(tile + tpw, ntiles);
+    if (tile >= tend) return;
+    float* const tw = tb[wave] + j * TB_STRIDE + 4 * half;          // this lane's row of the tile (write side)
+    const float* const tr = tb[wave] + 2 * lane;                    // this lane's feature pair (read side)
+    const f32x2 bias = *reinterpret_cast<const f32x2*>(b2 + 2 * lane);
+    f32x16 in[4], out[4], outc[4];
+    f32x4 la[4], lb[4];                       // one k tile (32 columns) of A[i] / Bm[j] in flight
+    {   // prologue: gather + Swish for the first tile
+        const int e = min(tile * 32 + j, E - 1);
+        const float* pa = A + (size_t)tgt[e] * 128 + 4 * half;
+        const float* pb = Bm + (size_t)src[e] * 128 + 4 * half;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(pa + kt * 32 + 8 * g);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(pb + kt * 32 + 8 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) in[kt][4 * g + c] = act_swish(a[c] + b[c]);
+            }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {          // k tile 3 stays raw: groups 0-3 of the first iteration turn it into in[3]
+            la[g] = *reinterpret_cast<const f32x4*>(pa + 96 + 8 * g);
+            lb[g] = *reinterpret_cast<const f32x4*>(pb + 96 + 8 * g);
+        }
+    }
+    RunMeta pmd = run_meta(tile, E, tgt, rowptr, j);
+    pmd.ends = 0;                              // no previous tile yet: nothing leaves in the first iteration
+    for (; tile < tend; ++tile) {
+        const RunMeta md = run_meta(tile, E, tgt, rowptr, j);
+        const int tn = tile + 1 < tend ? tile + 1 : tile;       // clamped: last iteration prefetches unused data
+        const int en = min(tn * 32 + j, E - 1);
+        const float* pan = A + (size_t)tgt[en] * 128 + 4 * half;
+        const float* pbn = Bm + (size_t)src[en] * 128 + 4 * half;
+        f32x2 acc = {0.f, 0.f};
+        f32x2 rv = *reinterpret_cast<const f32x2*>(tr);
+        {
+            u32x4 xs[2][NP], wr[2][NP];
+            split_slot<MODE>(in[0], 0, xs[0]);
+            {
+                const u32x4* wp = wl + lane;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) wr[0][q] = wp[64 * q];
+            }
+#pragma unroll
+            for (int gq = 0; gq < 32; ++gq) {     // gq = slot * 4 + nt, slot = kt * 2 + m
+                const int slot = gq >> 2, nt = gq & 3;
+                if (gq + 1 < 32) {
+                    const int s1 = (gq + 1) >> 2, n1 = (gq + 1) & 3;
+                    const u32x4* wp = wl + ((((s1 >> 1) * 4 + n1) * 2 + (s1 & 1)) * NP) * 64 + lane;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) wr[(gq + 1) & 1][q] = wp[64 * q];
+                }
+                if (slot + 1 < 8) Split<MODE>::quarter(in[(slot + 1) >> 1], (slot + 1) & 1, nt, xs[(slot + 1) & 1]);
+                if (slot == 0) {                  // first k slot: the accumulators start from the inline constant 0
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) out[nt][i] = 0.f, outc[nt][i] = 0.f;
+                }
+                Split<MODE>::mma(wr[gq & 1], xs[slot & 1], out[nt], outc[nt]);
+                // edge gq of the previous tile: transposed read, bias, Swish, running sum; a run end leaves here
+                {
+                    const f32x2 cur = rv;
+                    if (gq + 1 < 32) rv = *reinterpret_cast<const f32x2*>(tr + (gq + 1) * TB_STRIDE);
+                    acc[0] += act_swish(cur[0] + bias[0]);
+                    acc[1] += act_swish(cur[1] + bias[1]);
+                    if (pmd.ends & (1u << gq)) {
+                        emit_run(acc, pmd, gq, agg, partials, lane);
+                        acc[0] = 0.f;
+                        acc[1] = 0.f;
+                    }
+                }
+                // rolling gather prefetch for the next tile: the rows of k tile kt are requested in group 8kt+4 (k tile kt
+                // of `in` is dead after group 8kt+3) and become Swish(A + Bm) four values per group in groups 8kt+8 ..
+                // 8kt+11 (k tile 3: groups 0-3 of the next iteration).  The empty asm pins each value to its group: hipcc
+                // otherwise sinks the whole Swish block to the end of the loop, outside every MFMA shadow.
+                if ((gq & 7) < 4) {
+                    const int ktc = ((gq >> 3) + 3) & 3, g = gq & 3;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float v = act_swish(la[g][c] + lb[g][c]);
+                        asm volatile("" : "+v"(v));
+                        in[ktc][4 * g + c] = v;
+                    }
+                }
+                if ((gq & 7) == 4) {
+                    const int kt = gq >> 3;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        la[g] = *reinterpret_cast<const f32x4*>(pan + kt * 32 + 8 * g);
+                        lb[g] = *reinterpret_cast<const f32x4*>(pbn + kt * 32 + 8 * g);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // this tile's raw GEMM output -> the wave's LDS tile (row = edge), consumed during the next iteration
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            Split<MODE>::fold(out[nt], outc[nt]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 o = {out[nt][4 * g], out[nt][4 * g + 1], out[nt][4 * g + 2], out[nt][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(tw + nt * 32 + 8 * g) = o;
+            }
+        }
+        pmd = md;
+    }
+    // the last tile's rows
+    f32x2 acc = {0.f, 0.f};
+    for (int e = 0; e < 32; ++e) {
+        const f32x2 cur = *reinterpret_cast<const f32x2*>(tr + e * TB_STRIDE);
+        acc[0] += act_swish(cur[0] + bias[0]);
+        acc[1] += act_swish(cur[1] + bias[1]);
+        if (pmd.ends & (1u << e)) {
+            const int ti = __shfl(pmd.ti, e), rs = __shfl(pmd.rs, e), re = __shfl(pmd.re, e);
+            const int e0 = pmd.tile * 32;
+            const bool complete = rs >= e0 && re <= e0 + 32;
+            const float dn = complete ? (float)(re - rs) : 1.f;
+            float* dst = complete ? agg + (size_t)ti * 128 : partials + ((size_t)pmd.tile * 2 + (rs < e0 ? 0 : 1)) * 128;
+            const f32x2 o = {acc[0] / dn, acc[1] / dn};
+            *reinterpret_cast<f32x2*>(dst + 2 * lane) = o;
+            acc[0] = 0.f;
+            acc[1] = 0.f;
+        }
+    }
+}
+
 int g_edge6_ablation = 0;
 
 template <int MODE>
@@ -167,6 +364,12 @@ static int launch_edge6(const float* A, const float* Bm, const int32_t* src, con
     const dim3 g(min((tiles + 3) / 4, ncu)), b(256);
     const u32x4* ws = reinterpret_cast<const u32x4*>(w2_split);
     hipStream_t s = (hipStream_t)stream;
+    if constexpr (Split<MODE>::NP <= 2) {
+        if (g_edge6_ablation == 0) {          // 6 = A/B knob: the generation-6 kernel (DPP scan epilogue)
+            hipLaunchKernelGGL((k_mpnn_edge7<MODE>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+            return (int)hipGetLastError();
+        }
+    }
     switch (g_edge6_ablation) {   // development only: ablations produce invalid results
         case 1: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 1>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
         case 2: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 2>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;

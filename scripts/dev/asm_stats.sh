@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: scripts/dev/asm_stats.sh magnet_amd/csrc/file.hip kernel_name_substring  -> register / spill / instruction mix summary
 f=$1; k=$2
-out=$(mktemp /tmp/asmXXXX.s)
+out=$(mktemp /tmp/asmXXXXXX.s)
 hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -S "$f" -o "$out" 2>/dev/null
 python3 - "$out" "$k" <<'PY'
 import re,sys,collections
