@@ -280,11 +280,19 @@ struct Split<GEMM_FP16X3> {
     static constexpr int NP = 2;
     static __device__ __forceinline__ void quarter(const f32x16& tile, int m, int p, u32x4 (&planes)[2]) {
         const float a0 = tile[8 * m + 2 * p], a1 = tile[8 * m + 2 * p + 1];
-        const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(a0, a1);
-        const float r0 = (a0 - (float)h[0]) * 2048.f, r1 = (a1 - (float)h[1]) * 2048.f;
-        const _Float16 l0 = (_Float16)r0, l1 = (_Float16)r1;
-        planes[0][p] = __builtin_bit_cast(unsigned, h);
-        planes[1][p] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a0, a1));
+        // five instructions per value pair (hipcc's own lowering of the C expression takes nine): the remainder a - h is a
+        // mixed-precision fma that reads the fp16 piece in place (exact, no conversion back to fp32), and the two scaled
+        // remainders are rounded (RNE) straight into the low / high half of the plane word
+        float d0, d1;
+        unsigned l;
+        const float k2048 = 2048.f;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(h), "v"(a0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(h), "v"(a1));
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l) : "v"(d0), "s"(k2048));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l) : "v"(d1), "s"(k2048));
+        planes[0][p] = h;
+        planes[1][p] = l;
     }
     static __device__ __forceinline__ void mma(const u32x4 (&w)[2], const u32x4 (&x)[2], f32x16& accM, f32x16& accC) {
         const f16x8 wh = __builtin_bit_cast(f16x8, w[0]), wl = __builtin_bit_cast(f16x8, w[1]);

@@ -165,18 +165,21 @@ struct RunMeta {             // per-lane bookkeeping of one tile (lane j <-> edg
     unsigned ends;           // wave-uniform: bit e set <=> edge e is the last edge of its run inside this tile
 };
 
-__device__ __forceinline__ RunMeta run_meta(int tile, int E, const int32_t* __restrict__ tgt,
-                                            const int32_t* __restrict__ rowptr, int j) {
-    RunMeta md;
-    md.tile = tile;
+// indices of one tile, requested two iterations before the tile is computed (nothing on the path waits for them)
+struct TileIdx {
+    int ti, sj, tnext;       // tgt[e], src[e] (clamped to the last edge), tgt[e + 1] or -2 at the tile / array end
+    bool e_ok;
+};
+__device__ __forceinline__ TileIdx tile_idx(int tile, int E, const int32_t* __restrict__ src,
+                                            const int32_t* __restrict__ tgt, int j) {
+    TileIdx x;
     const int e_raw = tile * 32 + j;
-    const bool e_ok = e_raw < E;
-    md.ti = tgt[e_ok ? e_raw : E - 1];
-    const int tnext = (e_raw + 1 < E && j < 31) ? tgt[e_raw + 1] : -2;
-    md.rs = rowptr[md.ti];
-    md.re = rowptr[md.ti + 1];
-    md.ends = (unsigned)__builtin_amdgcn_ballot_w64(e_ok && tnext != md.ti);      // both halves agree: low word
-    return md;
+    x.e_ok = e_raw < E;
+    const int e = x.e_ok ? e_raw : E - 1;
+    x.ti = tgt[e];
+    x.sj = src[e];
+    x.tnext = (e_raw + 1 < E && j < 31) ? tgt[e_raw + 1] : -2;
+    return x;
 }
 
 // the run that ends at edge e of tile md.tile: mean (complete run) or tile-boundary partial sum
@@ -222,13 +225,19 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
     if (tile >= tend) return;
     float* const tw = tb[wave] + j * TB_STRIDE + 4 * half;          // this lane's row of the tile (write side)
     const float* const tr = tb[wave] + 2 * lane;                    // this lane's feature pair (read side)
-    const f32x2 bias = *reinterpret_cast<const f32x2*>(b2 + 2 * lane);
-    f32x16 in[4], out[4], outc[4];
-    f32x4 la[4], lb[4];                       // one k tile (32 columns) of A[i] / Bm[j] in flight
+    f32x16 in[4], out[4], outc[4], bias[4];
+    init_bias<4>(bias, b2, half);             // loop-invariant C operand of every tile's first main product
+    // Gather staging: two register sets, k tiles alternate between them.  The rows of k tile kt of the NEXT tile are
+    // requested in group 8kt and become Swish(A + Bm) twelve groups (~4 000 cycles) later, in groups 8kt+12 .. 8kt+15
+    // (k tile 3: groups 4-7 of the next iteration) - `in[kt]` of the current tile is dead after group 8kt+3.  With a
+    // single set the distance was four groups and a third of the kernel's cycles were s_waitcnt on these loads
+    // (SQ_WAIT_ANY 32 %; the gathered rows take ~2 000 cycles under load).
+    f32x4 la[2][4], lb[2][4];
+    TileIdx ix = tile_idx(tile, E, src, tgt, j);
+    RunMeta md;
     {   // prologue: gather + Swish for the first tile
-        const int e = min(tile * 32 + j, E - 1);
-        const float* pa = A + (size_t)tgt[e] * 128 + 4 * half;
-        const float* pb = Bm + (size_t)src[e] * 128 + 4 * half;
+        const float* pa = A + (size_t)ix.ti * 128 + 4 * half;
+        const float* pb = Bm + (size_t)ix.sj * 128 + 4 * half;
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
@@ -239,19 +248,28 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
                 for (int c = 0; c < 4; ++c) in[kt][4 * g + c] = act_swish(a[c] + b[c]);
             }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {          // k tile 3 stays raw: groups 0-3 of the first iteration turn it into in[3]
-            la[g] = *reinterpret_cast<const f32x4*>(pa + 96 + 8 * g);
-            lb[g] = *reinterpret_cast<const f32x4*>(pb + 96 + 8 * g);
+        for (int g = 0; g < 4; ++g) {          // k tile 3 stays raw: groups 4-7 of the first iteration turn it into in[3]
+            la[1][g] = *reinterpret_cast<const f32x4*>(pa + 96 + 8 * g);
+            lb[1][g] = *reinterpret_cast<const f32x4*>(pb + 96 + 8 * g);
         }
+        md.tile = tile;
+        md.ti = ix.ti;
+        md.rs = rowptr[ix.ti];
+        md.re = rowptr[ix.ti + 1];
+        md.ends = (unsigned)__builtin_amdgcn_ballot_w64(ix.e_ok && ix.tnext != ix.ti);   // both halves agree: low word
     }
-    RunMeta pmd = run_meta(tile, E, tgt, rowptr, j);
+    RunMeta pmd = md;
     pmd.ends = 0;                              // no previous tile yet: nothing leaves in the first iteration
+    TileIdx ix1 = tile_idx(min(tile + 1, tend - 1), E, src, tgt, j);       // indices one tile ahead ...
     for (; tile < tend; ++tile) {
-        const RunMeta md = run_meta(tile, E, tgt, rowptr, j);
-        const int tn = tile + 1 < tend ? tile + 1 : tile;       // clamped: last iteration prefetches unused data
-        const int en = min(tn * 32 + j, E - 1);
-        const float* pan = A + (size_t)tgt[en] * 128 + 4 * half;
-        const float* pbn = Bm + (size_t)src[en] * 128 + 4 * half;
+        const TileIdx ix2 = tile_idx(min(tile + 2, tend - 1), E, src, tgt, j);   // ... and two: requested here, used next iteration
+        RunMeta md1;                                                      // bookkeeping of tile + 1: its targets arrived long ago
+        md1.tile = min(tile + 1, tend - 1);
+        md1.ti = ix1.ti;
+        md1.rs = rowptr[ix1.ti];
+        md1.re = rowptr[ix1.ti + 1];
+        const float* pan = A + (size_t)ix1.ti * 128 + 4 * half;           // clamped: the last iteration prefetches unused data
+        const float* pbn = Bm + (size_t)ix1.sj * 128 + 4 * half;
         f32x2 acc = {0.f, 0.f};
         f32x2 rv = *reinterpret_cast<const f32x2*>(tr);
         {
@@ -272,42 +290,42 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
                     for (int q = 0; q < NP; ++q) wr[(gq + 1) & 1][q] = wp[64 * q];
                 }
                 if (slot + 1 < 8) Split<MODE>::quarter(in[(slot + 1) >> 1], (slot + 1) & 1, nt, xs[(slot + 1) & 1]);
-                if (slot == 0) {                  // first k slot: the accumulators start from the inline constant 0
+                if (slot == 0) {   // first k slot: the accumulators start from the bias registers / the inline constant 0
+                    out[nt] = bias[nt];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) out[nt][i] = 0.f, outc[nt][i] = 0.f;
+                    for (int i = 0; i < 16; ++i) outc[nt][i] = 0.f;
                 }
                 Split<MODE>::mma(wr[gq & 1], xs[slot & 1], out[nt], outc[nt]);
-                // edge gq of the previous tile: transposed read, bias, Swish, running sum; a run end leaves here
+                // edge gq of the previous tile: transposed read, Swish, running sum; a run end leaves here
                 {
                     const f32x2 cur = rv;
                     if (gq + 1 < 32) rv = *reinterpret_cast<const f32x2*>(tr + (gq + 1) * TB_STRIDE);
-                    acc[0] += act_swish(cur[0] + bias[0]);
-                    acc[1] += act_swish(cur[1] + bias[1]);
+                    acc[0] += act_swish(cur[0]);
+                    acc[1] += act_swish(cur[1]);
                     if (pmd.ends & (1u << gq)) {
                         emit_run(acc, pmd, gq, agg, partials, lane);
                         acc[0] = 0.f;
                         acc[1] = 0.f;
                     }
                 }
-                // rolling gather prefetch for the next tile: the rows of k tile kt are requested in group 8kt+4 (k tile kt
-                // of `in` is dead after group 8kt+3) and become Swish(A + Bm) four values per group in groups 8kt+8 ..
-                // 8kt+11 (k tile 3: groups 0-3 of the next iteration).  The empty asm pins each value to its group: hipcc
-                // otherwise sinks the whole Swish block to the end of the loop, outside every MFMA shadow.
-                if ((gq & 7) < 4) {
-                    const int ktc = ((gq >> 3) + 3) & 3, g = gq & 3;
+                // staged rows -> Swish(A + Bm), four values per group.  The empty asm pins each value to its group: hipcc
+                // otherwise sinks the whole Swish block to the end of the loop.
+                if ((gq & 7) >= 4) {
+                    const int ktc = ((gq >> 3) + 3) & 3, g = gq & 3;      // groups 4-7: k tile 3, 12-15: 0, 20-23: 1, 28-31: 2
+                    const int set = ktc & 1;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        float v = act_swish(la[g][c] + lb[g][c]);
+                        float v = act_swish(la[set][g][c] + lb[set][g][c]);
                         asm volatile("" : "+v"(v));
                         in[ktc][4 * g + c] = v;
                     }
                 }
-                if ((gq & 7) == 4) {
-                    const int kt = gq >> 3;
+                if ((gq & 7) == 0) {
+                    const int kt = gq >> 3, set = kt & 1;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        la[g] = *reinterpret_cast<const f32x4*>(pan + kt * 32 + 8 * g);
-                        lb[g] = *reinterpret_cast<const f32x4*>(pbn + kt * 32 + 8 * g);
+                        la[set][g] = *reinterpret_cast<const f32x4*>(pan + kt * 32 + 8 * g);
+                        lb[set][g] = *reinterpret_cast<const f32x4*>(pbn + kt * 32 + 8 * g);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -324,13 +342,16 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
             }
         }
         pmd = md;
+        md1.ends = (unsigned)__builtin_amdgcn_ballot_w64(ix1.e_ok && ix1.tnext != ix1.ti);
+        md = md1;
+        ix1 = ix2;
     }
     // the last tile's rows
     f32x2 acc = {0.f, 0.f};
     for (int e = 0; e < 32; ++e) {
         const f32x2 cur = *reinterpret_cast<const f32x2*>(tr + e * TB_STRIDE);
-        acc[0] += act_swish(cur[0] + bias[0]);
-        acc[1] += act_swish(cur[1] + bias[1]);
+        acc[0] += act_swish(cur[0]);
+        acc[1] += act_swish(cur[1]);
         if (pmd.ends & (1u << e)) {
             const int ti = __shfl(pmd.ti, e), rs = __shfl(pmd.rs, e), re = __shfl(pmd.re, e);
             const int e0 = pmd.tile * 32;

@@ -380,7 +380,7 @@ def test_magnet_gnn_training_step_gradients(teacher_forcing):
     by 0.6 - 4 %).  The exact check of the backward is therefore made where it is well posed:
       (a) every differentiable op against fp64 autograd (the tests above), and
       (b) here, the decoder chain inside the real training step: its parameter gradients against fp64 autograd of the same
-          chain fed with the inputs / output gradients the HIP run itself produced (branches are then the HIP run's own);
+          chain fed with the inputs / output gradients the HIP run itself produced, on the HIP run's own ReLU branches;
     against the oracle and the reference's own gradients (tests/golden/magnet_gnn_tiny_grad.npz) the test asks for what
     a kink-limited comparison can give: equal loss, the half of the network upstream of the flipped units (LR-mesh graph
     net, INR decoder) to rounding, everything within a few percent and in the same direction."""
@@ -420,12 +420,19 @@ def test_magnet_gnn_training_step_gradients(teacher_forcing):
     # (b) the decoder chain on the run's own inputs and output gradients
     net = copy.deepcopy(model._decoder.node_fn).double()
     lins = net.linears()
+    # ReLU branches of the reference chain = the HIP run's own (the hidden activations its backward recomputes, layer by
+    # layer): with ~1e6 hidden units per call a few pre-activations sit within fp32 rounding of zero, and an fp64 forward
+    # would put them on the other side
+    pk = model._packed().decoder
     for rec in calls:
-        h = rec["x"].double()
+        x32 = rec["x"]
+        xh = AG._pad_cols(x32, (x32.shape[1] + 31) // 32 * 32)
+        h = x32.double()
         for i, lin in enumerate(lins):
             h = lin(h)
             if i < len(lins) - 1:
-                h = torch.relu(h)
+                xh = AG._linear(x32.shape[0], xh, pk.layers[i], pk.ht, relu=True)
+                h = h * (xh[:, :h.shape[1]] > 0).double()
         h.backward(rec["dy"].double())
     assert len(calls) == 2
     for i, lin in enumerate(lins):
