@@ -15,7 +15,7 @@ and already resident in HBM when the clock starts; weights are random-init (torc
 seed 0).  value = nodes x predicted steps x trajectories (all ranks) / max-over-ranks wall time.
 
 Extra objects on the JSON line:
-  roofline      - dominant kernel (k_mpnn_edge6, MFMA bound): algorithmic flops per launch
+  roofline      - dominant kernel (k_mpnn_edge7, MFMA bound): algorithmic flops per launch
                   (2*E*128*128, the message_net_2 GEMM; message_net_1 is factorised per node, see
                   DESIGN.md) / mean launch time measured with HIP events on the launch stream.  The
                   kernel evaluates every fp32 product through an exact split into 16-bit pieces on the
@@ -57,7 +57,7 @@ HP = dict(lr=1e-3, weight_decay=0.0, factor=0.3, step_size=50, loss="l1", hidden
 NT = 50
 MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_BF16_PEAK_TFLOPS = 2500.0
-SPLIT_PRODUCTS = {"fp16x3": 3, "bf16x6": 6, "bf16": 1}   # MFMA products per multiply in k_mpnn_edge6 (bf16: reduced precision)
+SPLIT_PRODUCTS = {"fp16x3": 3, "bf16x6": 6, "bf16": 1}   # MFMA products per multiply in k_mpnn_edge7 / k_mpnn_edge6 (bf16: reduced precision)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -395,7 +395,8 @@ def main():
         mode = model.edge_gemm
         nprod = SPLIT_PRODUCTS.get(mode, 1)
         peak = MFMA_BF16_PEAK_TFLOPS / nprod if mode in SPLIT_PRODUCTS else MFMA_F32_PEAK_TFLOPS
-        roof = {"kernel": "k_mpnn_edge6" if mode in SPLIT_PRODUCTS else "k_mpnn_edge2", "bound": "mfma",
+        kname = {"fp16x3": "k_mpnn_edge7", "bf16": "k_mpnn_edge7", "bf16x6": "k_mpnn_edge6"}.get(mode, "k_mpnn_edge2")
+        roof = {"kernel": kname, "bound": "mfma",
                 "achieved": round(ach, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "launch_ms": round(ms, 4), "launches_timed": len(ev), "flops_per_launch": flops, "gemm_mode": mode,
@@ -405,7 +406,7 @@ def main():
                 "note": "fp32 GEMM evaluated through an exact split into 16-bit pieces on the matrix cores "
                         f"({nprod} MFMA products per fp32 product, fp32 accumulate); peak = 2500 / {nprod}"}
         if W == 256 and B == 4 and mode in SPLIT_PRODUCTS:     # the recorded PMC passes are of this exact workload
-            roof["traffic"], roof["traffic_source"] = measured_traffic("k_mpnn_edge6")
+            roof["traffic"], roof["traffic_source"] = measured_traffic(kname)
         msg = torch.randn(E, H, device=dev)
         out = torch.empty(N, H, device=dev)
         for _ in range(3):

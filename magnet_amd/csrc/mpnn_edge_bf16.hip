@@ -201,7 +201,7 @@ __device__ __forceinline__ void emit_run(const f32x2 acc, const RunMeta& md, int
     *reinterpret_cast<f32x2*>(dst + 2 * lane) = o;
 }
 
-template <int MODE>
+template <int MODE, int ABL = 0>
 __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__ A, const float* __restrict__ Bm,
                                                        const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
                                                        const int32_t* __restrict__ rowptr, int E,
@@ -261,6 +261,9 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
     RunMeta pmd = md;
     pmd.ends = 0;                              // no previous tile yet: nothing leaves in the first iteration
     TileIdx ix1 = tile_idx(min(tile + 1, tend - 1), E, src, tgt, j);       // indices one tile ahead ...
+    // (a use before the loop: otherwise these loads are still pending at the loop header on the entry path, and hipcc's
+    // merged wait state puts an s_waitcnt on everything but the newest three loads at the top of EVERY iteration)
+    asm volatile("" ::"v"(ix1.ti), "v"(ix1.sj), "v"(ix1.tnext), "v"(md.rs), "v"(md.re));
     for (; tile < tend; ++tile) {
         const TileIdx ix2 = tile_idx(min(tile + 2, tend - 1), E, src, tgt, j);   // ... and two: requested here, used next iteration
         RunMeta md1;                                                      // bookkeeping of tile + 1: its targets arrived long ago
@@ -268,8 +271,8 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
         md1.ti = ix1.ti;
         md1.rs = rowptr[ix1.ti];
         md1.re = rowptr[ix1.ti + 1];
-        const float* pan = A + (size_t)ix1.ti * 128 + 4 * half;           // clamped: the last iteration prefetches unused data
-        const float* pbn = Bm + (size_t)ix1.sj * 128 + 4 * half;
+        const float* pan = A + (size_t)(ABL & 8 ? j : ix1.ti) * 128 + 4 * half;   // clamped: the last iteration prefetches unused data
+        const float* pbn = Bm + (size_t)(ABL & 8 ? j : ix1.sj) * 128 + 4 * half;  // (ABL 8, development: rows that stay in L1)
         f32x2 acc = {0.f, 0.f};
         f32x2 rv = *reinterpret_cast<const f32x2*>(tr);
         {
@@ -289,6 +292,10 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
 #pragma unroll
                     for (int q = 0; q < NP; ++q) wr[(gq + 1) & 1][q] = wp[64 * q];
                 }
+                const f32x2 cur = rv;             // edge gq of the previous tile; the next row is requested now as well
+                if (gq + 1 < 32) rv = *reinterpret_cast<const f32x2*>(tr + (gq + 1) * TB_STRIDE);
+                __builtin_amdgcn_sched_barrier(0);    // LDS requests first: hipcc otherwise sinks them behind the second MFMA
+                                                      // and the next group opens with an exposed LDS round trip
                 if (slot + 1 < 8) Split<MODE>::quarter(in[(slot + 1) >> 1], (slot + 1) & 1, nt, xs[(slot + 1) & 1]);
                 if (slot == 0) {   // first k slot: the accumulators start from the bias registers / the inline constant 0
                     out[nt] = bias[nt];
@@ -298,8 +305,6 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
                 Split<MODE>::mma(wr[gq & 1], xs[slot & 1], out[nt], outc[nt]);
                 // edge gq of the previous tile: transposed read, Swish, running sum; a run end leaves here
                 {
-                    const f32x2 cur = rv;
-                    if (gq + 1 < 32) rv = *reinterpret_cast<const f32x2*>(tr + (gq + 1) * TB_STRIDE);
                     acc[0] += act_swish(cur[0]);
                     acc[1] += act_swish(cur[1]);
                     if (pmd.ends & (1u << gq)) {
@@ -388,6 +393,10 @@ static int launch_edge6(const float* A, const float* Bm, const int32_t* src, con
     if constexpr (Split<MODE>::NP <= 2) {
         if (g_edge6_ablation == 0) {          // 6 = A/B knob: the generation-6 kernel (DPP scan epilogue)
             hipLaunchKernelGGL((k_mpnn_edge7<MODE>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+            return (int)hipGetLastError();
+        }
+        if (g_edge6_ablation == 8) {          // development only (invalid results): gather from 32 fixed rows
+            hipLaunchKernelGGL((k_mpnn_edge7<MODE, 8>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
             return (int)hipGetLastError();
         }
     }
