@@ -109,25 +109,28 @@ int magnet_segment_mean_f32(const float* msg, const int32_t* rowptr, int n_rows,
  * models/mpnn_2d.py:179 (the x/Lx, x/Ly quirk).  L and tmax are device scalars/vectors. */
 int magnet_mpnn_node_input_f32(const float* u, const float* pos, int pos_ld, const float* Lvec, const float* tmax,
                                int n, int tw, int dpos, int kin, float* out, void* stream);
-/* agg[i] = mean_{e: tgt(e)=i} Swish(W2 * Swish(A[i] + Bm[src(e)]) + b2); GNN_Layer.message + aggregate,
- * models/mpnn.py:73-79,46, with message_net_1 split per node.  Follow with
- * magnet_segmean_fixup_f32(rowptr, n, 128, partials, agg). */
+/* agg[i] = mean_{e: tgt(e)=i} Swish(W2 * Swish(A[i] + Bm[src(e)]) + b2), 0 for rows without edges; GNN_Layer.message +
+ * aggregate, models/mpnn.py:73-79,46, with message_net_1 split per node.  Edges CSR-sorted by target
+ * (rowptr [n_rows + 1]).  The call enqueues the fused edge kernel and the small kernel that assembles the rows crossing
+ * work-partition boundaries: agg is complete when the stream reaches the end of the call.  partials: scratch,
+ * ceil(n_edges / 32) * 2 * 128 floats. */
 int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
-                         const int32_t* rowptr, int n_edges, const void* w2_packed, const float* b2, float* agg,
-                         float* partials, void* stream);
+                         const int32_t* rowptr, int n_edges, int n_rows, const void* w2_packed, const float* b2,
+                         float* agg, float* partials, void* stream);
 /* Same contract as magnet_mpnn_edge_f32, message_net_2 evaluated on the bf16 matrix cores through the exact
  * hi/mid/lo split (six partial products, fp32-class accuracy).  w2_split: the three bf16 planes of
  * W2 in fragment order [kt][nt][m][plane][64 lanes][8 bf16] (magnet_amd/packing.py:pack_linear_bf16x3). */
 int magnet_mpnn_edge_bf16x6_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
-                                const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2, float* agg,
-                                float* partials, void* stream);
+                                const int32_t* rowptr, int n_edges, int n_rows, const void* w2_split, const float* b2,
+                                float* agg, float* partials, void* stream);
+/* ... through the two-piece fp16 split (three MFMA products; the default, k_mpnn_edge7) */
 int magnet_mpnn_edge_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
-                                const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2, float* agg,
-                                float* partials, void* stream);
+                                const int32_t* rowptr, int n_edges, int n_rows, const void* w2_split, const float* b2,
+                                float* agg, float* partials, void* stream);
 /* reduced-precision variant of the edge kernel (one bf16 piece, see magnet_mlp_bf16_f32) */
 int magnet_mpnn_edge_bf16_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
-                              const int32_t* rowptr, int n_edges, const void* w2_bf16, const float* b2, float* agg,
-                              float* partials, void* stream);
+                              const int32_t* rowptr, int n_edges, int n_rows, const void* w2_bf16, const float* b2,
+                              float* agg, float* partials, void* stream);
 /* out[n][k] = u[n][tw-1] + dt*(k+1) * Conv1d(8->1,k2)([Swish](Conv1d(1->8,k1,stride s1)(h[n])))[k];
  * models/mpnn.py:197-201 with the conv specs of :140-163. */
 int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1, int k1,

@@ -161,42 +161,44 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge6(const float* __restrict__
 constexpr int TB_STRIDE = 132;
 
 struct RunMeta {             // per-lane bookkeeping of one tile (lane j <-> edge j), read back with readlane at run ends
-    int tile, ti, rs, re;
-    unsigned ends;           // wave-uniform: bit e set <=> edge e is the last edge of its run inside this tile
+    int ti, rs, re;
+    unsigned ends;           // wave-uniform: bit e set <=> edge e is the last edge of its run (or of the wave's range)
 };
 
 // indices of one tile, requested two iterations before the tile is computed (nothing on the path waits for them)
 struct TileIdx {
-    int ti, sj, tnext;       // tgt[e], src[e] (clamped to the last edge), tgt[e + 1] or -2 at the tile / array end
+    int ti, sj, tnext;       // tgt[e], src[e] (clamped to the last edge), tgt[e + 1] or -2 at the end of the wave's range
     bool e_ok;
 };
-__device__ __forceinline__ TileIdx tile_idx(int tile, int E, const int32_t* __restrict__ src,
+__device__ __forceinline__ TileIdx tile_idx(int tile, int e_end, const int32_t* __restrict__ src,
                                             const int32_t* __restrict__ tgt, int j) {
     TileIdx x;
     const int e_raw = tile * 32 + j;
-    x.e_ok = e_raw < E;
-    const int e = x.e_ok ? e_raw : E - 1;
+    x.e_ok = e_raw < e_end;
+    const int e = x.e_ok ? e_raw : e_end - 1;
     x.ti = tgt[e];
     x.sj = src[e];
-    x.tnext = (e_raw + 1 < E && j < 31) ? tgt[e_raw + 1] : -2;
+    x.tnext = (e_raw + 1 < e_end) ? tgt[e_raw + 1] : -2;      // runs continue across the tiles of one wave
     return x;
 }
 
-// the run that ends at edge e of tile md.tile: mean (complete run) or tile-boundary partial sum
-__device__ __forceinline__ void emit_run(const f32x2 acc, const RunMeta& md, int e, float* __restrict__ agg,
-                                         float* __restrict__ partials, int lane) {
+// The run that ends at edge e of the current tile.  A wave walks a contiguous range of tiles and its running sum simply
+// continues across tile boundaries, so only the two runs that cross the ends of the wave's RANGE [e_lo, e_hi) leave as
+// partial sums (partials[range][0 = entered from the previous range | 1 = continues into the next][128]); every other row
+// leaves finished, divided by its degree.  k_edge_range_fixup combines the few partials in range order (deterministic).
+__device__ __forceinline__ void emit_run(const f32x2 acc, const RunMeta& md, int e, int e_lo, int e_hi, int range,
+                                         float* __restrict__ agg, float* __restrict__ partials, int lane) {
     const int ti = __builtin_amdgcn_readlane(md.ti, e);
     const int rs = __builtin_amdgcn_readlane(md.rs, e), re = __builtin_amdgcn_readlane(md.re, e);
-    const int e0 = md.tile * 32;
     f32x2 o = acc;
     float* dst;
-    if (rs >= e0 && re <= e0 + 32) {
+    if (rs >= e_lo && re <= e_hi) {
         const float dn = (float)(re - rs);
         o[0] = o[0] / dn;
         o[1] = o[1] / dn;
         dst = agg + (size_t)ti * 128;
     } else {
-        dst = partials + ((size_t)md.tile * 2 + (rs < e0 ? 0 : 1)) * 128;
+        dst = partials + ((size_t)range * 2 + (rs < e_lo ? 0 : 1)) * 128;
     }
     *reinterpret_cast<f32x2*>(dst + 2 * lane) = o;
 }
@@ -220,9 +222,11 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
     const int nb8 = gridDim.x / 8;         // XCD-aware contiguous ranges, see k_mpnn_edge6
     const int vb = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * nb8 + blockIdx.x / 8 : blockIdx.x;
     const int tpw = (ntiles + gridDim.x * 4 - 1) / (gridDim.x * 4);
-    int tile = (vb * 4 + wave) * tpw;
+    const int range = vb * 4 + wave;
+    int tile = range * tpw;
     const int tend = min(tile + tpw, ntiles);
     if (tile >= tend) return;
+    const int e_lo = tile * 32, e_hi = min(tend * 32, E);           // this wave's edges
     float* const tw = tb[wave] + j * TB_STRIDE + 4 * half;          // this lane's row of the tile (write side)
     const float* const tr = tb[wave] + 2 * lane;                    // this lane's feature pair (read side)
     f32x16 in[4], out[4], outc[4], bias[4];
@@ -233,8 +237,13 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
     // single set the distance was four groups and a third of the kernel's cycles were s_waitcnt on these loads
     // (SQ_WAIT_ANY 32 %; the gathered rows take ~2 000 cycles under load).
     f32x4 la[2][4], lb[2][4];
-    TileIdx ix = tile_idx(tile, E, src, tgt, j);
+    TileIdx ix = tile_idx(tile, e_hi, src, tgt, j);
     RunMeta md;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {            // the first iteration reads the LDS tile before any GEMM has filled it: Swish(0) = 0
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(tw + (c >> 2) * 32 + 8 * (c & 3)) = z;
+    }
     {   // prologue: gather + Swish for the first tile
         const float* pa = A + (size_t)ix.ti * 128 + 4 * half;
         const float* pb = Bm + (size_t)ix.sj * 128 + 4 * half;
@@ -252,7 +261,6 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
             la[1][g] = *reinterpret_cast<const f32x4*>(pa + 96 + 8 * g);
             lb[1][g] = *reinterpret_cast<const f32x4*>(pb + 96 + 8 * g);
         }
-        md.tile = tile;
         md.ti = ix.ti;
         md.rs = rowptr[ix.ti];
         md.re = rowptr[ix.ti + 1];
@@ -260,20 +268,19 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
     }
     RunMeta pmd = md;
     pmd.ends = 0;                              // no previous tile yet: nothing leaves in the first iteration
-    TileIdx ix1 = tile_idx(min(tile + 1, tend - 1), E, src, tgt, j);       // indices one tile ahead ...
+    TileIdx ix1 = tile_idx(min(tile + 1, tend - 1), e_hi, src, tgt, j);    // indices one tile ahead ...
     // (a use before the loop: otherwise these loads are still pending at the loop header on the entry path, and hipcc's
     // merged wait state puts an s_waitcnt on everything but the newest three loads at the top of EVERY iteration)
     asm volatile("" ::"v"(ix1.ti), "v"(ix1.sj), "v"(ix1.tnext), "v"(md.rs), "v"(md.re));
+    f32x2 acc = {0.f, 0.f};                   // running sum of the current run; carried across the wave's tiles
     for (; tile < tend; ++tile) {
-        const TileIdx ix2 = tile_idx(min(tile + 2, tend - 1), E, src, tgt, j);   // ... and two: requested here, used next iteration
+        const TileIdx ix2 = tile_idx(min(tile + 2, tend - 1), e_hi, src, tgt, j);   // ... and two: requested here, used next iteration
         RunMeta md1;                                                      // bookkeeping of tile + 1: its targets arrived long ago
-        md1.tile = min(tile + 1, tend - 1);
         md1.ti = ix1.ti;
         md1.rs = rowptr[ix1.ti];
         md1.re = rowptr[ix1.ti + 1];
         const float* pan = A + (size_t)(ABL & 8 ? j : ix1.ti) * 128 + 4 * half;   // clamped: the last iteration prefetches unused data
         const float* pbn = Bm + (size_t)(ABL & 8 ? j : ix1.sj) * 128 + 4 * half;  // (ABL 8, development: rows that stay in L1)
-        f32x2 acc = {0.f, 0.f};
         f32x2 rv = *reinterpret_cast<const f32x2*>(tr);
         {
             u32x4 xs[2][NP], wr[2][NP];
@@ -308,7 +315,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
                     acc[0] += act_swish(cur[0]);
                     acc[1] += act_swish(cur[1]);
                     if (pmd.ends & (1u << gq)) {
-                        emit_run(acc, pmd, gq, agg, partials, lane);
+                        emit_run(acc, pmd, gq, e_lo, e_hi, range, agg, partials, lane);
                         acc[0] = 0.f;
                         acc[1] = 0.f;
                     }
@@ -352,17 +359,15 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
         ix1 = ix2;
     }
     // the last tile's rows
-    f32x2 acc = {0.f, 0.f};
     for (int e = 0; e < 32; ++e) {
         const f32x2 cur = *reinterpret_cast<const f32x2*>(tr + e * TB_STRIDE);
         acc[0] += act_swish(cur[0]);
         acc[1] += act_swish(cur[1]);
         if (pmd.ends & (1u << e)) {
             const int ti = __shfl(pmd.ti, e), rs = __shfl(pmd.rs, e), re = __shfl(pmd.re, e);
-            const int e0 = pmd.tile * 32;
-            const bool complete = rs >= e0 && re <= e0 + 32;
+            const bool complete = rs >= e_lo && re <= e_hi;
             const float dn = complete ? (float)(re - rs) : 1.f;
-            float* dst = complete ? agg + (size_t)ti * 128 : partials + ((size_t)pmd.tile * 2 + (rs < e0 ? 0 : 1)) * 128;
+            float* dst = complete ? agg + (size_t)ti * 128 : partials + ((size_t)range * 2 + (rs < e_lo ? 0 : 1)) * 128;
             const f32x2 o = {acc[0] / dn, acc[1] / dn};
             *reinterpret_cast<f32x2*>(dst + 2 * lane) = o;
             acc[0] = 0.f;
@@ -371,13 +376,47 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
     }
 }
 
+// Completes what k_mpnn_edge7 left open: rows without edges become 0, and the row that crosses the start of range w (if it
+// ends inside range w) is assembled from the partial sums of the ranges it touches, in range order.
+__global__ void __launch_bounds__(256) k_edge_range_fixup(const int32_t* __restrict__ tgt, const int32_t* __restrict__ rowptr,
+                                                          int N, int E, int tpw, int nranges,
+                                                          const float* __restrict__ partials, float* __restrict__ agg) {
+    const int r0 = blockIdx.x * 256 + threadIdx.x;
+    if (r0 < N && rowptr[r0] == rowptr[r0 + 1]) {
+        f32x4* o = reinterpret_cast<f32x4*>(agg + (size_t)r0 * 128);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < 32; ++c) o[c] = z;
+    }
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w < 1 || w >= nranges) return;
+    const long es = (long)w * tpw * 32;
+    if (es >= E) return;
+    const int r = tgt[es];
+    const int s = rowptr[r], e = rowptr[r + 1];
+    if (s >= es) return;                                   // the row starts here: nothing entered from the previous range
+    if (((e - 1) >> 5) / tpw != w) return;                 // the row goes on: the range it ends in assembles it
+    const int wa = (s >> 5) / tpw;
+    f32x2 acc = *reinterpret_cast<const f32x2*>(partials + ((size_t)wa * 2 + 1) * 128 + 2 * lane);
+    for (int t = wa + 1; t <= w; ++t) {
+        const f32x2 p = *reinterpret_cast<const f32x2*>(partials + ((size_t)t * 2 + 0) * 128 + 2 * lane);
+        acc[0] += p[0];
+        acc[1] += p[1];
+    }
+    const float dn = (float)(e - s);
+    const f32x2 o = {acc[0] / dn, acc[1] / dn};
+    *reinterpret_cast<f32x2*>(agg + (size_t)r * 128 + 2 * lane) = o;
+}
+
 int g_edge6_ablation = 0;
+
+extern "C" int magnet_segmean_fixup_f32(const int32_t* rowptr, int n_rows, int d, const float* partials, float* agg, void* stream);
 
 template <int MODE>
 static int launch_edge6(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt, const int32_t* rowptr,
-                        int n_edges, const void* w2_split, const float* b2, float* agg, float* partials, void* stream) {
+                        int n_edges, int n_rows, const void* w2_split, const float* b2, float* agg, float* partials,
+                        void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
-    if (n_edges <= 0) return 0;
+    if (n_edges <= 0) return magnet_segmean_fixup_f32(rowptr, n_rows, 128, partials, agg, stream);   // all rows empty: zeros
     static int ncu = 0;
     if (!ncu) {
         hipDeviceProp_t prop;
@@ -391,12 +430,14 @@ static int launch_edge6(const float* A, const float* Bm, const int32_t* src, con
     const u32x4* ws = reinterpret_cast<const u32x4*>(w2_split);
     hipStream_t s = (hipStream_t)stream;
     if constexpr (Split<MODE>::NP <= 2) {
-        if (g_edge6_ablation == 0) {          // 6 = A/B knob: the generation-6 kernel (DPP scan epilogue)
-            hipLaunchKernelGGL((k_mpnn_edge7<MODE>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
-            return (int)hipGetLastError();
-        }
-        if (g_edge6_ablation == 8) {          // development only (invalid results): gather from 32 fixed rows
-            hipLaunchKernelGGL((k_mpnn_edge7<MODE, 8>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+        if (g_edge6_ablation == 0 || g_edge6_ablation == 8) {      // 6 = A/B knob: the generation-6 kernel (DPP scan epilogue)
+            if (g_edge6_ablation == 0)
+                hipLaunchKernelGGL((k_mpnn_edge7<MODE>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+            else                                                    // development only (invalid results): gather from 32 fixed rows
+                hipLaunchKernelGGL((k_mpnn_edge7<MODE, 8>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+            const int nranges = (int)g.x * 4, tpw = (tiles + nranges - 1) / nranges;      // as computed inside the kernel
+            const int fb = max((n_rows + 255) / 256, (nranges + 3) / 4);
+            hipLaunchKernelGGL(k_edge_range_fixup, dim3(fb), dim3(256), 0, s, tgt, rowptr, n_rows, n_edges, tpw, nranges, partials, agg);
             return (int)hipGetLastError();
         }
     }
@@ -407,23 +448,24 @@ static int launch_edge6(const float* A, const float* Bm, const int32_t* src, con
         case 7: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 7>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
         default: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 0>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
     }
-    return (int)hipGetLastError();
+    const int rc = (int)hipGetLastError();
+    return rc ? rc : magnet_segmean_fixup_f32(rowptr, n_rows, 128, partials, agg, stream);
 }
 
 extern "C" int magnet_mpnn_edge_bf16x6_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
-                                           const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2,
-                                           float* agg, float* partials, void* stream) {
-    return launch_edge6<GEMM_BF16X6>(A, Bm, src, tgt, rowptr, n_edges, w2_split, b2, agg, partials, stream);
+                                           const int32_t* rowptr, int n_edges, int n_rows, const void* w2_split,
+                                           const float* b2, float* agg, float* partials, void* stream) {
+    return launch_edge6<GEMM_BF16X6>(A, Bm, src, tgt, rowptr, n_edges, n_rows, w2_split, b2, agg, partials, stream);
 }
 
 extern "C" int magnet_mpnn_edge_bf16_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
-                                         const int32_t* rowptr, int n_edges, const void* w2_bf16, const float* b2,
-                                         float* agg, float* partials, void* stream) {
-    return launch_edge6<GEMM_BF16>(A, Bm, src, tgt, rowptr, n_edges, w2_bf16, b2, agg, partials, stream);
+                                         const int32_t* rowptr, int n_edges, int n_rows, const void* w2_bf16,
+                                         const float* b2, float* agg, float* partials, void* stream) {
+    return launch_edge6<GEMM_BF16>(A, Bm, src, tgt, rowptr, n_edges, n_rows, w2_bf16, b2, agg, partials, stream);
 }
 
 extern "C" int magnet_mpnn_edge_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
-                                           const int32_t* rowptr, int n_edges, const void* w2_split, const float* b2,
-                                           float* agg, float* partials, void* stream) {
-    return launch_edge6<GEMM_FP16X3>(A, Bm, src, tgt, rowptr, n_edges, w2_split, b2, agg, partials, stream);
+                                           const int32_t* rowptr, int n_edges, int n_rows, const void* w2_split,
+                                           const float* b2, float* agg, float* partials, void* stream) {
+    return launch_edge6<GEMM_FP16X3>(A, Bm, src, tgt, rowptr, n_edges, n_rows, w2_split, b2, agg, partials, stream);
 }

@@ -305,11 +305,13 @@ extern "C" int magnet_mpnn_node_input_f32(const float* u, const float* pos, int 
     LAUNCH_CHECK();
 }
 
+extern "C" int magnet_segmean_fixup_f32(const int32_t* rowptr, int n_rows, int d, const float* partials, float* agg, void* stream);
+
 extern "C" int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
-                                    const int32_t* rowptr, int n_edges, const void* w2_packed, const float* b2,
+                                    const int32_t* rowptr, int n_edges, int n_rows, const void* w2_packed, const float* b2,
                                     float* agg, float* partials, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
-    if (n_edges <= 0) return 0;
+    if (n_edges <= 0) return magnet_segmean_fixup_f32(rowptr, n_rows, 128, partials, agg, stream);   // all rows empty: zeros
     MagnetLayer L{reinterpret_cast<const f32x4*>(w2_packed), b2};
     const int tiles = (n_edges + 31) / 32;
     const dim3 g((tiles + 3) / 4), b(256);
@@ -349,7 +351,8 @@ extern "C" int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32
         case 14: hipLaunchKernelGGL((k_mpnn_edge<0, 4>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
         default: hipLaunchKernelGGL(k_mpnn_edge<0>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
     }
-    LAUNCH_CHECK();
+    const int rc = (int)hipGetLastError();
+    return rc ? rc : magnet_segmean_fixup_f32(rowptr, n_rows, 128, partials, agg, stream);
 }
 
 

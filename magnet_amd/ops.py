@@ -149,9 +149,8 @@ def mpnn_edge(A, Bm, csr, w2, b2, agg, partials):
     """fused MPNN edge kernel; the dtype of the packed message_net_2 weights selects the arithmetic
     (float16 planes: fp16x3 split, int16 planes: bf16x6 split, float32 fragments: fp32 MFMA)."""
     name = EDGE_ENTRY[w2.dtype]
-    L.check(getattr(L.lib(), name)(_p(A), _p(Bm), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.E, _p(w2), _p(b2),
+    L.check(getattr(L.lib(), name)(_p(A), _p(Bm), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.E, csr.N, _p(w2), _p(b2),
                                    _p(agg), _p(partials), _stream()), name)
-    segmean_fixup(csr.rowptr, csr.N, 128, partials, agg)
     return agg
 
 
