@@ -191,6 +191,49 @@ def test_mpnn_edge_kernels_agree_on_ragged_graph():
         assert rel_l2(agg, want) < 1e-6, mode
 
 
+@pytest.mark.parametrize("case", ["no_edges", "under_one_tile", "one_row_owns_everything", "empty_rows_at_both_ends"])
+def test_mpnn_edge_range_partials_corner_cases(case):
+    """k_mpnn_edge7 carries a row's running sum across the tiles of a wave and hands only range-crossing rows to
+    k_edge_range_fixup: a graph without edges, fewer edges than one tile, one row spanning every wave's range, and
+    empty rows before / after the populated ones (all three arithmetic modes against a host evaluation)."""
+    from magnet_amd import ops
+    from magnet_amd.packing import pack
+    from oracle.pyg_semantics import scatter_mean
+    torch.manual_seed(7)
+    H = 128
+    if case == "no_edges":
+        n, deg = 5, [0, 0, 0, 0, 0]
+    elif case == "under_one_tile":
+        n, deg = 6, [3, 0, 7, 1, 0, 2]
+    elif case == "one_row_owns_everything":
+        n, deg = 3, [0, 40000, 0]                      # 1250 tiles > the 1024 waves of a full grid: every range is crossed
+    else:
+        n, deg = 400, [0] * 30 + [int(d) for d in torch.randint(1, 70, (340,))] + [0] * 30
+    rowptr = torch.zeros(n + 1, dtype=torch.int32)
+    rowptr[1:] = torch.tensor(deg).cumsum(0)
+    E = int(rowptr[-1])
+    tgt = torch.repeat_interleave(torch.arange(n), torch.tensor(deg)).int()
+    src = torch.randint(0, n, (E,)).int()
+    A, Bm = torch.randn(n, H), torch.randn(n, H)
+    lin = torch.nn.Linear(H, H)
+    sw = lambda x: x * torch.sigmoid(x)  # noqa: E731
+    with torch.no_grad():
+        m = sw(lin.double()(sw((A[tgt.long()] + Bm[src.long()]).double())))
+    want = scatter_mean(m, tgt.long(), n) if E else torch.zeros(n, H, dtype=torch.float64)
+    csr = ops.CSR(rowptr.cuda(), src.cuda(), tgt.cuda(), n, E)
+    lin = lin.float().cuda()
+    for mode in ("fp16x3", "bf16x6", "fp32"):
+        w, b = pack(lin.weight, lin.bias, mode)
+        agg = torch.full((n, H), float("nan"), device="cuda")
+        partials = torch.zeros(max((E + 31) // 32, 1) * 2 * H, device="cuda")
+        ops.mpnn_edge(A.cuda(), Bm.cuda(), csr, w, b, agg, partials)
+        assert not torch.isnan(agg).any(), mode
+        if E:
+            assert rel_l2(agg, want) < 1e-6, mode
+        else:
+            assert float(agg.abs().max()) == 0.0, mode
+
+
 @pytest.mark.parametrize("dim,loop", [(1, False), (2, False), (2, True)])
 def test_radius_search_ragged_graphs_duplicates_and_isolated_nodes(dim, loop):
     """graphs of different sizes (one of them empty, one a single node), duplicate coordinates, isolated nodes and a
