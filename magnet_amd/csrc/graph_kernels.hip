@@ -124,27 +124,60 @@ __global__ void k_kept(const int32_t* __restrict__ nbr, const int32_t* __restric
     kept[q] = c;
 }
 
-// in-place exclusive scan of n ints by one 1024-thread block (n up to a few million)
+// in-place exclusive scan of n ints by one 1024-thread block: 4096-int chunks, 16 coalesced bytes per thread, the next
+// chunk's load in flight while the current one is scanned (wave scan by __shfl_up, 16 wave totals through LDS)
 __global__ void __launch_bounds__(1024) k_exclusive_scan(int32_t* __restrict__ v, int n) {
-    __shared__ int sums[1024];
-    const int t = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int b = t * per, e = min(n, b + per);
-    int s = 0;
-    for (int i = b; i < e; ++i) s += v[i];
-    sums[t] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int add = t >= off ? sums[t - off] : 0;
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nch = (n + 4095) / 4096;
+    auto load = [&](int ch, int (&x)[4]) {
+        const int b = ch * 4096 + t * 4;
+        if (b + 3 < n) {
+            const int4 q = *reinterpret_cast<const int4*>(v + b);
+            x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = b + c < n ? v[b + c] : 0;
+        }
+    };
+    int x[4], y[4] = {0, 0, 0, 0};
+    int carry = 0;
+    if (nch > 0) load(0, x);
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) load(ch + 1, y);
+        const int s = x[0] + x[1] + x[2] + x[3];
+        int inc = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(inc, off);
+            if (lane >= off) inc += up;
+        }
+        if (lane == 63) wsum[wave] = inc;
         __syncthreads();
-        sums[t] += add;
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int ws = wsum[w];
+            before += w < wave ? ws : 0;
+            total += ws;
+        }
         __syncthreads();
-    }
-    int run = sums[t] - s;
-    for (int i = b; i < e; ++i) {
-        const int x = v[i];
-        v[i] = run;
-        run += x;
+        int run = carry + before + inc - s;
+        const int b = ch * 4096 + t * 4;
+        if (b + 3 < n) {
+            int4 q;
+            q.x = run, q.y = run + x[0], q.z = run + x[0] + x[1], q.w = run + x[0] + x[1] + x[2];
+            *reinterpret_cast<int4*>(v + b) = q;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (b + c < n) v[b + c] = run;
+                run += x[c];
+            }
+        }
+        carry += total;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[c] = y[c];
     }
 }
 
