@@ -69,6 +69,9 @@ typedef struct {
     float* partials;       /* SEGMEAN: scratch [ceil(M/32)][2][ncols] */
     int32_t ncolgroups;    /* nl == 1 only, 0/1 = off: G > 1 launches G workgroup columns; group g multiplies by layer[g]
                             * (the packed slice of its OT*32 output columns) and writes y / reads res at column g*OT*32 */
+    int32_t groups_in_block; /* 0/1: the G groups are workgroup columns (gridDim.y); G: every workgroup runs its rows through
+                              * the G groups one after the other (the input rows are then read from HBM once) */
+    int64_t y_group_stride;  /* floats between the outputs of consecutive groups; 0 = OT*32 (neighbouring columns) */
 } magnet_mlp_args_t;
 
 /* Fused gather/concat -> NL x (Linear [+ activation]) -> [LayerNorm] -> store | +residual | CSR mean.

@@ -65,6 +65,8 @@ struct MagnetMlpArgs {
     const int32_t* rowptr;         // [N+1]
     float* partials;               // [ntiles][2][ncols]
     int32_t ncolgroups;            // NL == 1 only: > 1 splits the output columns over gridDim.y, group g uses layer[g] (own packed slice)
+    int32_t groups_in_block;       // > 1 (= ncolgroups): the groups run one after the other inside each workgroup instead of over gridDim.y
+    int64_t y_group_stride;        // floats between the outputs of consecutive groups; 0 = OT*32 columns of the same rows
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {

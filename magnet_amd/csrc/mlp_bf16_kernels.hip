@@ -138,119 +138,127 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
 
     constexpr int NT0 = (NL == 1) ? OT : HT;
     constexpr int NT1 = (NL == 2) ? OT : HT;            // output tiles of layer 1 (when it exists)
-    const int cg = (NL == 1) ? blockIdx.y : 0;          // column group (single-Linear launches may split their outputs)
-    const MagnetLayer l0 = a.layer[cg];
-    // Chunk c (one k tile of one layer) lives in ring slot c % NBUF and is requested DIST chunks ahead; iteration c:
-    //   wait (DIST 2: counted, chunk c+1 stays in flight) -> barrier (chunk c visible, slot of c-1 free) ->
-    //   request chunk c+DIST -> compute chunk c.
-    int c = 0;                                         // running chunk index (uniform)
-    dma_chunk<NT0 * PPN>(l0.w, wbuf, wave, lane);
-    if (DIST == 2) {
-        if (a.nkt > 1) dma_chunk<NT0 * PPN>(l0.w + (size_t)NT0 * PPN * 64, wbuf + CH, wave, lane);
-        else if (NL > 1) dma_chunk<NT1 * PPN>(a.layer[1].w, wbuf + CH, wave, lane);
-    }
+    // Column groups of a single-Linear launch: over gridDim.y, or - groups_in_block - one after the other inside the
+    // workgroup, so that the second group finds its input rows in L2 instead of HBM (MPNN: the A and Bm halves of
+    // message_net_1 share [h | node_in]).
+    const int gib = (NL == 1 && a.groups_in_block > 1) ? a.groups_in_block : 1;
+    for (int gi = 0; gi < gib; ++gi) {
+        const int cg = (NL == 1) ? (gib > 1 ? gi : (int)blockIdx.y) : 0;
+        if (gi > 0) __syncthreads();                    // every wave is done with the previous group's ring slots
+        const MagnetLayer l0 = a.layer[cg];
+        // Chunk c (one k tile of one layer) lives in ring slot c % NBUF and is requested DIST chunks ahead; iteration c:
+        //   wait (DIST 2: counted, chunk c+1 stays in flight) -> barrier (chunk c visible, slot of c-1 free) ->
+        //   request chunk c+DIST -> compute chunk c.
+        int c = 0;                                         // running chunk index (uniform)
+        dma_chunk<NT0 * PPN>(l0.w, wbuf, wave, lane);
+        if (DIST == 2) {
+            if (a.nkt > 1) dma_chunk<NT0 * PPN>(l0.w + (size_t)NT0 * PPN * 64, wbuf + CH, wave, lane);
+            else if (NL > 1) dma_chunk<NT1 * PPN>(a.layer[1].w, wbuf + CH, wave, lane);
+        }
 
-    f32x16 out[OT];
-    f32x16 h0[HT], h1[HT];
-    // ---------------- layer 0: K streamed from the sources
-    {
-        f32x16 acc[NT0], accc[NT0];
-        init_bias<NT0>(acc, l0.b, half);
-        zero_tiles<NT0>(accc);
-        f32x16 x = load_ktile(a.kt[0], row, half);
-        KRows rn = ktile_rows(a.kt[a.nkt > 1 ? 1 : 0], row);          // indices of k tile 1, requested one iteration early
-        for (int kt = 0; kt < a.nkt; ++kt, ++c) {
-            // outstanding, oldest first: chunk c, x tile kt, indices of kt+1, chunk c+1  ->  leave only chunk c+1 in flight
-            if (DIST == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (kt + 1 < a.nkt) wait_all_but_one_chunk<NT0 * PPN>();
-            else if (NL > 1) wait_all_but_one_chunk<NT1 * PPN>();
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(abl & 8)) __syncthreads();
-            // data of x tile kt+1 (its indices arrived during the previous iteration), indices of x tile kt+2, then
-            // chunk c+2: the next iteration's counted wait then covers both
-            const f32x16 xn = (abl & 16) ? x : ktile_data(a.kt[kt + 1 < a.nkt ? kt + 1 : kt], rn, half);
-            rn = ktile_rows(a.kt[kt + 2 < a.nkt ? kt + 2 : a.nkt - 1], row);
-            if (abl & 2) {
-            } else if (kt + DIST < a.nkt) dma_chunk<NT0 * PPN>(l0.w + (size_t)(kt + DIST) * NT0 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
-            else if (NL > 1 && kt + DIST - a.nkt < HT) dma_chunk<NT1 * PPN>(a.layer[1].w + (size_t)(kt + DIST - a.nkt) * NT1 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
-            if (!(abl & 1)) mma_chunk<NT0, MODE, PIPE>(x, acc, accc, wbuf + (c % NBUF) * CH, lane);
-            x = xn;
-        }
-        fold_tiles<NT0, MODE>(acc, accc);
-        if (NL == 1) {
-#pragma unroll
-            for (int t = 0; t < NT0; ++t) out[t < OT ? t : 0] = acc[t];
-        } else {
-#pragma unroll
-            for (int t = 0; t < NT0; ++t) {
-                apply_act<ACT>(acc[t]);
-                h0[t < HT ? t : 0] = acc[t];
+        f32x16 out[OT];
+        f32x16 h0[HT], h1[HT];
+        // ---------------- layer 0: K streamed from the sources
+        {
+            f32x16 acc[NT0], accc[NT0];
+            init_bias<NT0>(acc, l0.b, half);
+            zero_tiles<NT0>(accc);
+            f32x16 x = load_ktile(a.kt[0], row, half);
+            KRows rn = ktile_rows(a.kt[a.nkt > 1 ? 1 : 0], row);          // indices of k tile 1, requested one iteration early
+            for (int kt = 0; kt < a.nkt; ++kt, ++c) {
+                // outstanding, oldest first: chunk c, x tile kt, indices of kt+1, chunk c+1  ->  leave only chunk c+1 in flight
+                if (DIST == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (kt + 1 < a.nkt) wait_all_but_one_chunk<NT0 * PPN>();
+                else if (NL > 1) wait_all_but_one_chunk<NT1 * PPN>();
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!(abl & 8)) __syncthreads();
+                // data of x tile kt+1 (its indices arrived during the previous iteration), indices of x tile kt+2, then
+                // chunk c+2: the next iteration's counted wait then covers both
+                const f32x16 xn = (abl & 16) ? x : ktile_data(a.kt[kt + 1 < a.nkt ? kt + 1 : kt], rn, half);
+                rn = ktile_rows(a.kt[kt + 2 < a.nkt ? kt + 2 : a.nkt - 1], row);
+                if (abl & 2) {
+                } else if (kt + DIST < a.nkt) dma_chunk<NT0 * PPN>(l0.w + (size_t)(kt + DIST) * NT0 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+                else if (NL > 1 && kt + DIST - a.nkt < HT) dma_chunk<NT1 * PPN>(a.layer[1].w + (size_t)(kt + DIST - a.nkt) * NT1 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+                if (!(abl & 1)) mma_chunk<NT0, MODE, PIPE>(x, acc, accc, wbuf + (c % NBUF) * CH, lane);
+                x = xn;
             }
-        }
-    }
-    // ---------------- layers 1 .. NL-1, activations in registers (fully unrolled: static register indices)
-    // here the only VMEM traffic is the weight DMA, so the waits are counted: chunks c+1 (already requested) stays
-    // in flight while chunk c is consumed.
-#pragma unroll
-    for (int l = 1; l < NL; ++l) {
-        const bool last = (l == NL - 1);
-        const bool src0 = (l & 1);                     // odd layers read h0, even layers read h1
-        f32x16 cc[NTMAX];
-        zero_tiles<NTMAX>(cc);
-        f32x16(&cco)[OT] = reinterpret_cast<f32x16(&)[OT]>(cc);
-        f32x16(&cch)[HT] = reinterpret_cast<f32x16(&)[HT]>(cc);
-        if (last) init_bias<OT>(out, a.layer[l].b, half);
-        else if (src0) init_bias<HT>(h1, a.layer[l].b, half);
-        else init_bias<HT>(h0, a.layer[l].b, half);
-#pragma unroll
-        for (int kt = 0; kt < HT; ++kt, ++c) {
-            // chunk c+1: next k tile of this layer, or the first k tile of the next layer, or nothing (very last chunk)
-            const bool has_next = (kt + 1 < HT) || (l + 1 < NL);
-            const bool next_is_last_layer = (kt + 1 < HT) ? last : (l + 1 == NL - 1);
-            if (!has_next || DIST == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (next_is_last_layer) wait_all_but_one_chunk<OT * PPN>();
-            else wait_all_but_one_chunk<HT * PPN>();
-            if (!(abl & 8)) __syncthreads();
-            // chunk c+2
-            if (!(abl & 2)) {
-                const int k2 = kt + DIST;
-                if (k2 < HT) {
-                    if (last) dma_chunk<OT * PPN>(a.layer[l].w + (size_t)k2 * OT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
-                    else dma_chunk<HT * PPN>(a.layer[l].w + (size_t)k2 * HT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
-                } else if (l + 1 < NL) {
-                    const int k3 = k2 - HT;                               // 0 or 1: k tile of the next layer
-                    if (l + 1 == NL - 1) dma_chunk<OT * PPN>(a.layer[l + 1 < NL ? l + 1 : l].w + (size_t)k3 * OT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
-                    else dma_chunk<HT * PPN>(a.layer[l + 1 < NL ? l + 1 : l].w + (size_t)k3 * HT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+            fold_tiles<NT0, MODE>(acc, accc);
+            if (NL == 1) {
+    #pragma unroll
+                for (int t = 0; t < NT0; ++t) out[t < OT ? t : 0] = acc[t];
+            } else {
+    #pragma unroll
+                for (int t = 0; t < NT0; ++t) {
+                    apply_act<ACT>(acc[t]);
+                    h0[t < HT ? t : 0] = acc[t];
                 }
             }
-            if (abl & 1) {
-            } else if (last) mma_chunk<OT, MODE, PIPE>(src0 ? h0[kt] : h1[kt], out, cco, wbuf + (c % NBUF) * CH, lane);
-            else if (src0) mma_chunk<HT, MODE, PIPE>(h0[kt], h1, cch, wbuf + (c % NBUF) * CH, lane);
-            else mma_chunk<HT, MODE, PIPE>(h1[kt], h0, cch, wbuf + (c % NBUF) * CH, lane);
         }
-        if (last) fold_tiles<OT, MODE>(out, cco);
-        else if (src0) fold_tiles<HT, MODE>(h1, cch);
-        else fold_tiles<HT, MODE>(h0, cch);
-        if (!last) {
-#pragma unroll
-            for (int t = 0; t < HT; ++t) {
-                if (src0) apply_act<ACT>(h1[t]);
-                else apply_act<ACT>(h0[t]);
+        // ---------------- layers 1 .. NL-1, activations in registers (fully unrolled: static register indices)
+        // here the only VMEM traffic is the weight DMA, so the waits are counted: chunks c+1 (already requested) stays
+        // in flight while chunk c is consumed.
+    #pragma unroll
+        for (int l = 1; l < NL; ++l) {
+            const bool last = (l == NL - 1);
+            const bool src0 = (l & 1);                     // odd layers read h0, even layers read h1
+            f32x16 cc[NTMAX];
+            zero_tiles<NTMAX>(cc);
+            f32x16(&cco)[OT] = reinterpret_cast<f32x16(&)[OT]>(cc);
+            f32x16(&cch)[HT] = reinterpret_cast<f32x16(&)[HT]>(cc);
+            if (last) init_bias<OT>(out, a.layer[l].b, half);
+            else if (src0) init_bias<HT>(h1, a.layer[l].b, half);
+            else init_bias<HT>(h0, a.layer[l].b, half);
+    #pragma unroll
+            for (int kt = 0; kt < HT; ++kt, ++c) {
+                // chunk c+1: next k tile of this layer, or the first k tile of the next layer, or nothing (very last chunk)
+                const bool has_next = (kt + 1 < HT) || (l + 1 < NL);
+                const bool next_is_last_layer = (kt + 1 < HT) ? last : (l + 1 == NL - 1);
+                if (!has_next || DIST == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (next_is_last_layer) wait_all_but_one_chunk<OT * PPN>();
+                else wait_all_but_one_chunk<HT * PPN>();
+                if (!(abl & 8)) __syncthreads();
+                // chunk c+2
+                if (!(abl & 2)) {
+                    const int k2 = kt + DIST;
+                    if (k2 < HT) {
+                        if (last) dma_chunk<OT * PPN>(a.layer[l].w + (size_t)k2 * OT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+                        else dma_chunk<HT * PPN>(a.layer[l].w + (size_t)k2 * HT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+                    } else if (l + 1 < NL) {
+                        const int k3 = k2 - HT;                               // 0 or 1: k tile of the next layer
+                        if (l + 1 == NL - 1) dma_chunk<OT * PPN>(a.layer[l + 1 < NL ? l + 1 : l].w + (size_t)k3 * OT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+                        else dma_chunk<HT * PPN>(a.layer[l + 1 < NL ? l + 1 : l].w + (size_t)k3 * HT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+                    }
+                }
+                if (abl & 1) {
+                } else if (last) mma_chunk<OT, MODE, PIPE>(src0 ? h0[kt] : h1[kt], out, cco, wbuf + (c % NBUF) * CH, lane);
+                else if (src0) mma_chunk<HT, MODE, PIPE>(h0[kt], h1, cch, wbuf + (c % NBUF) * CH, lane);
+                else mma_chunk<HT, MODE, PIPE>(h1[kt], h0, cch, wbuf + (c % NBUF) * CH, lane);
+            }
+            if (last) fold_tiles<OT, MODE>(out, cco);
+            else if (src0) fold_tiles<HT, MODE>(h1, cch);
+            else fold_tiles<HT, MODE>(h0, cch);
+            if (!last) {
+    #pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    if (src0) apply_act<ACT>(h1[t]);
+                    else apply_act<ACT>(h0[t]);
+                }
             }
         }
-    }
-    if (LAST_ACT) {
-#pragma unroll
-        for (int t = 0; t < OT; ++t) apply_act<ACT>(out[t]);
-    }
-    if (LN) layer_norm_rows<OT>(out, a.ln_g, a.ln_b, a.ln_eps, half);
+        if (LAST_ACT) {
+    #pragma unroll
+            for (int t = 0; t < OT; ++t) apply_act<ACT>(out[t]);
+        }
+        if (LN) layer_norm_rows<OT>(out, a.ln_g, a.ln_b, a.ln_eps, half);
 
-    if (abl & 4) {
-        if (out[0][0] == 12345.678f) a.y[0] = 1.f;      // keep the computation alive
-    } else if (EPI == EPI_SEGMEAN) {
-        segmean_epilogue_dpp<OT>(out, md, a.M, a.y, a.partials, lane);
-    } else {
-        store_rows<OT, EPI == EPI_STORE_RES>(out, a.y + cg * OT * 32, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
+        if (abl & 4) {
+            if (out[0][0] == 12345.678f) a.y[0] = 1.f;      // keep the computation alive
+        } else if (EPI == EPI_SEGMEAN) {
+            segmean_epilogue_dpp<OT>(out, md, a.M, a.y, a.partials, lane);
+        } else {
+            float* yg = a.y + (a.y_group_stride ? (size_t)cg * a.y_group_stride : (size_t)cg * OT * 32);
+            store_rows<OT, EPI == EPI_STORE_RES>(out, yg, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
+        }
     }
 }
 
@@ -292,7 +300,7 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
 static int launch_mlp(mlp_fn fn, const MagnetMlpArgs* args, void* stream) {
     if (!fn) return -3;
     const int tiles = (args->M + 31) / 32;
-    hipLaunchKernelGGL(fn, dim3((tiles + 3) / 4, args->ncolgroups > 1 ? args->ncolgroups : 1), dim3(256), 0, (hipStream_t)stream, *args);
+    hipLaunchKernelGGL(fn, dim3((tiles + 3) / 4, (args->ncolgroups > 1 && args->groups_in_block <= 1) ? args->ncolgroups : 1), dim3(256), 0, (hipStream_t)stream, *args);
     return (int)hipGetLastError();
 }
 

@@ -70,7 +70,8 @@ __global__ void __launch_bounds__(256) k_mlp(const MagnetMlpArgs a) {
     if (EPI == EPI_SEGMEAN) {
         segmean_epilogue_dpp<OT>(out, md, a.M, a.y, a.partials, lane);
     } else {
-        store_rows<OT, EPI == EPI_STORE_RES>(out, a.y + cg * OT * 32, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
+        float* yg = a.y + (a.y_group_stride ? (size_t)cg * a.y_group_stride : (size_t)cg * OT * 32);   // groups_in_block: always gridDim.y here
+        store_rows<OT, EPI == EPI_STORE_RES>(out, yg, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
     }
 }
 

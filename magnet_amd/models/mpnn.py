@@ -159,7 +159,8 @@ class MPNN(LightningModule):
 
         node_in = ops.mpnn_node_input(u, pos, Lv, tm, tw, self.dpos, kin)
         new = lambda: torch.empty(N, H, device=dev, dtype=torch.float32)  # noqa: E731
-        h, g, A, Bm, agg = new(), new(), new(), new(), new()
+        h, g, agg = new(), new(), new()
+        AB = torch.empty(2, N, H, device=dev, dtype=torch.float32)      # the two per-node halves of message_net_1, one launch
         partials = torch.empty(((csr.E + 31) // 32) * 2 * H, device=dev, dtype=torch.float32)
         T = ops.Term
         ops.mlp(N, ops.ktiles(T(node_in, kin)), P.emb, nl=2, ht=4, ot=4, act=ops.ACT_SWISH, last_act=True, y=h)
@@ -167,10 +168,13 @@ class MPNN(LightningModule):
             tape.topo, tape.node_in, tape.u, tape.dt, tape.layers = topo, node_in, u, dtv, []
         for lyr in P.layers:
             if tape is not None:
-                A, Bm, agg = new(), new(), new()
+                AB, agg = torch.empty(2, N, H, device=dev, dtype=torch.float32), new()
+            A, Bm = AB[0], AB[1]
             pre_in = ops.ktiles(T(h, H), T(node_in, kin))
-            ops.mlp(N, pre_in, [lyr.pre_a], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=A)
-            ops.mlp(N, pre_in, [lyr.pre_b], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=Bm)
+            # A = W1a.[h | node_in] + b1 and Bm = W1b.[h | node_in]: two column groups of one launch, run back to back inside
+            # each workgroup so that the second group reads [h | node_in] from L2 (fp32 kernels: two workgroup columns)
+            ops.mlp(N, pre_in, [lyr.pre_a, lyr.pre_b], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2,
+                    groups_in_block=True, y_group_stride=N * H)
             ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials)
             ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
                     act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g)

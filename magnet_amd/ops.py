@@ -78,7 +78,7 @@ def mlp_args(M, kts):
 
 
 def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STORE, y=None, ldy=None, ncols=None,
-             res=None, tgt=None, rowptr=None, partials=None, colgroups=1):
+             res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0):
     """Build the argument block of one fused-MLP launch once and return a zero-argument callable that enqueues it on the
     current stream.  For call sites that repeat the same launch on the same buffers (the EDSR convolution stack: 34
     launches of up to 36 gathered k tiles each) this removes the per-call descriptor marshalling from the host path."""
@@ -87,6 +87,10 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
     assert len(layers) == nl * colgroups and (colgroups == 1 or nl == 1)
     a, keep = mlp_args(M, kts)
     a.ncolgroups = int(colgroups)
+    # groups_in_block: every workgroup runs its rows through the G groups one after the other (inputs read from HBM once)
+    # instead of G workgroup columns; y_group_stride: floats between the groups' outputs (0: neighbouring column blocks)
+    a.groups_in_block = int(colgroups) if groups_in_block and colgroups > 1 else 0
+    a.y_group_stride = int(y_group_stride)
     keep += [layers, ln, y, res, tgt, rowptr, partials]
     for i, (w, b) in enumerate(layers):
         a.layer[i].w, a.layer[i].b = w.data_ptr(), b.data_ptr()
@@ -112,10 +116,11 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
 
 
 def mlp(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STORE, y=None, ldy=None, ncols=None,
-        res=None, tgt=None, rowptr=None, partials=None):
+        res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0):
     """Run the fused MLP kernel.  ``layers``: list of (packed_w, padded_b).  Returns y."""
     mlp_plan(M, kts, layers, nl=nl, ht=ht, ot=ot, act=act, last_act=last_act, ln=ln, epi=epi, y=y, ldy=ldy, ncols=ncols,
-             res=res, tgt=tgt, rowptr=rowptr, partials=partials)()
+             res=res, tgt=tgt, rowptr=rowptr, partials=partials, colgroups=colgroups, groups_in_block=groups_in_block,
+             y_group_stride=y_group_stride)()
     return y
 
 
