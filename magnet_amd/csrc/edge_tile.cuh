@@ -85,6 +85,43 @@ __device__ __forceinline__ void segmean_epilogue_dpp(f32x16 (&v)[NT], const Tile
     store_run_results<NT, true>(v, md, agg, partials, lane >> 5);
 }
 
+// The same CSR segment mean for a 128-wide tile, through LDS instead of the DPP scan (which costs ten instructions plus
+// hazard nops for each of the 64 registers of every lane): the tile goes to a per-wave LDS buffer 64 columns at a time
+// (rows padded to 68 floats: conflict-free 16-byte writes and 4-byte column reads), every lane then walks ONE column down
+// the 32 rows with a running sum, and run ends - wave-uniform, a ballot - leave under a scalar branch with a coalesced
+// 256-byte store.  Same partials protocol as store_run_results (per tile), sums in edge order.
+// buf: 32 * 68 floats owned by this wave; the caller guarantees nobody else is using that memory any more.
+__device__ __forceinline__ void segmean_epilogue_lds128(const f32x16 (&v)[4], const TileMeta& md, int M, float* __restrict__ agg,
+                                                        float* __restrict__ partials, float* __restrict__ buf, int lane) {
+    if (md.tile * 32 >= M) return;                                // wave-uniform: no rows in this tile
+    const int j = lane & 31, half = lane >> 5;
+    const unsigned ends = (unsigned)__builtin_amdgcn_ballot_w64(md.e_ok && md.tnext != md.ti);   // both halves agree
+    const int e0 = md.tile * 32;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16& t = v[2 * p + q];
+                const f32x4 o = {t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
+                *reinterpret_cast<f32x4*>(buf + j * 68 + q * 32 + 8 * g + 4 * half) = o;
+            }
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            acc += buf[e * 68 + lane];
+            if (ends & (1u << e)) {
+                const int ti = __builtin_amdgcn_readlane(md.ti, e);
+                const int rs = __builtin_amdgcn_readlane(md.rs, e), re = __builtin_amdgcn_readlane(md.re, e);
+                if (rs >= e0 && re <= e0 + 32) agg[(size_t)ti * 128 + p * 64 + lane] = acc / (float)(re - rs);
+                else partials[((size_t)md.tile * 2 + (rs < e0 ? 0 : 1)) * 128 + p * 64 + lane] = acc;
+                acc = 0.f;
+            }
+        }
+    }
+}
+
 // acc[nt] (+ cross accumulators) += W(planes in LDS) * x, x = the wave's [128 x 32] register tile.
 // While the matrix pipe works, x * store_scale is also written to HBM (row `dst`, may be null), one 16-byte chunk every
 // other MFMA group: HBM absorbs ~9 bytes per cycle and CU, so a burst of 16 stores would stall the wave on the full

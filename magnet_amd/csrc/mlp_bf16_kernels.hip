@@ -120,7 +120,10 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
     constexpr int NBUF = DIST + 1;
     constexpr bool PIPE = (NL >= 5 && HT >= 4);                          // see mma_chunk
     constexpr int CH = NTMAX * PPN * 64;                                   // u32x4 per chunk buffer
-    __shared__ __attribute__((aligned(16))) u32x4 smem[NBUF * CH];                    // weight chunk ring
+    // weight chunk ring; a 128-wide CSR-mean epilogue reuses it as four 32 x 68 float transposition tiles (34 KiB)
+    constexpr bool LDS_MEAN = (EPI == EPI_SEGMEAN && OT == 4);
+    constexpr int SMEM_U4 = (LDS_MEAN && NBUF * CH < 4 * 32 * 68 / 4) ? 4 * 32 * 68 / 4 : NBUF * CH;
+    __shared__ __attribute__((aligned(16))) u32x4 smem[SMEM_U4];
     u32x4* wbuf = smem;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -254,7 +257,13 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
         if (abl & 4) {
             if (out[0][0] == 12345.678f) a.y[0] = 1.f;      // keep the computation alive
         } else if (EPI == EPI_SEGMEAN) {
-            segmean_epilogue_dpp<OT>(out, md, a.M, a.y, a.partials, lane);
+            if constexpr (LDS_MEAN) {
+                __syncthreads();                        // every wave is done with the weight ring
+                segmean_epilogue_lds128(reinterpret_cast<const f32x16(&)[4]>(out), md, a.M, a.y, a.partials,
+                                        reinterpret_cast<float*>(smem) + wave * (32 * 68), lane);
+            } else {
+                segmean_epilogue_dpp<OT>(out, md, a.M, a.y, a.partials, lane);
+            }
         } else {
             float* yg = a.y + (a.y_group_stride ? (size_t)cg * a.y_group_stride : (size_t)cg * OT * 32);
             store_rows<OT, EPI == EPI_STORE_RES>(out, yg, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
