@@ -47,7 +47,7 @@ for v3 in (0, 6, 8, 0):
     agg.fill_(float("nan"))
     ms = timeit(lambda: ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials))
     err = float((agg - ref).norm() / ref.norm())
-    print(f"edge bf16x6 [{v3}]: {ms:.3f} ms  {2*E*H*H/ms/1e9:.1f} TFLOP/s-equivalent (incl fixup)  rel-diff vs first {err:.2e} nan={int(torch.isnan(agg).sum())}")
+    print(f"edge kernel, default split mode, knob [{v3}]: {ms:.3f} ms  {2*E*H*H/ms/1e9:.1f} TFLOP/s-equivalent (incl fixup)  rel-diff vs first {err:.2e} nan={int(torch.isnan(agg).sum())}")
 _lib.lib().magnet_debug_set_variant(1, 0)
 h = torch.randn(N, H, device="cuda"); node_in = torch.randn(N, 32, device="cuda"); gbuf = torch.empty_like(h)
 T = ops.Term
