@@ -372,23 +372,28 @@ def main():
         csr = model._topo.csr
         E, N, H = csr.E, csr.N, 128
         ev = []
-        entry = ops.EDGE_ENTRY[model._packed().layers[0].msg2[0].dtype]
-        orig = getattr(ops.L.lib(), entry)
+        wdt = model._packed().layers[0].msg2[0].dtype
+        entries = [e for e in (ops.EDGE_ENTRY[wdt], ops.EDGE_ENTRY_L2E.get(wdt)) if e]   # the model picks one of them
+        origs = {e: getattr(ops.L.lib(), e) for e in entries}
 
-        def timed_edge(*a):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            rc = orig(*a)
-            e.record()
-            ev.append((s, e))
-            return rc
+        def timed(orig):
+            def timed_edge(*a):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                rc = orig(*a)
+                e.record()
+                ev.append((s, e))
+                return rc
+            return timed_edge
 
-        setattr(ops.L._lib, entry, timed_edge)
+        for e_, o_ in origs.items():
+            setattr(ops.L._lib, e_, timed(o_))
         try:
             model.validation_step(batch, 0)
             torch.cuda.synchronize()
         finally:
-            setattr(ops.L._lib, entry, orig)
+            for e_, o_ in origs.items():
+                setattr(ops.L._lib, e_, o_)
         ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
         flops = 2.0 * E * H * H
         ach = flops / (ms * 1e-3) / 1e12

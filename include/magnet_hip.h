@@ -134,6 +134,16 @@ int magnet_mpnn_edge_fp16x3_f32(const float* A, const float* Bm, const int32_t* 
 int magnet_mpnn_edge_bf16_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
                               const int32_t* rowptr, int n_edges, int n_rows, const void* w2_bf16, const float* b2,
                               float* agg, float* partials, void* stream);
+/* The same two kernels for callers that fold log2(e) into the packed per-node halves of message_net_1: A_l2e = log2(e) * A,
+ * Bm_l2e = log2(e) * Bm.  The hardware exponential is base 2, so both Swish evaluations then cost one multiply less; the
+ * factor rides through W2 (linear) and is divided out together with the degree.  agg is the same quantity as above
+ * (models/mpnn.py:73-79,46); w2 / b2 are the unscaled parameters. */
+int magnet_mpnn_edge_fp16x3_l2e_f32(const float* A_l2e, const float* Bm_l2e, const int32_t* src, const int32_t* tgt,
+                                    const int32_t* rowptr, int n_edges, int n_rows, const void* w2_split, const float* b2,
+                                    float* agg, float* partials, void* stream);
+int magnet_mpnn_edge_bf16_l2e_f32(const float* A_l2e, const float* Bm_l2e, const int32_t* src, const int32_t* tgt,
+                                  const int32_t* rowptr, int n_edges, int n_rows, const void* w2_bf16, const float* b2,
+                                  float* agg, float* partials, void* stream);
 /* out[n][k] = u[n][tw-1] + dt*(k+1) * Conv1d(8->1,k2)([Swish](Conv1d(1->8,k1,stride s1)(h[n])))[k];
  * models/mpnn.py:197-201 with the conv specs of :140-163. */
 int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1, int k1,

@@ -78,6 +78,14 @@ __device__ __forceinline__ float act_swish(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
+// Swish of x given xs = log2(e) * x, returned with the same factor: xs * sigmoid(x) = xs / (1 + 2^-xs).  One multiply fewer
+// than act_swish (v_exp_f32 is a base-2 exponential and takes the negation as an operand modifier); the factor is linear,
+// so a GEMM or a mean behind it carries it along until somebody divides it out.
+#define MAGNET_LOG2E 1.44269504088896340736f
+__device__ __forceinline__ float act_swish_l2e(float xs) {
+    return xs * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-xs));
+}
+
 template <int ACT>
 __device__ __forceinline__ void apply_act(f32x16& v) {
     if (ACT == ACT_SWISH) {

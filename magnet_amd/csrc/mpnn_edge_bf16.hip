@@ -187,13 +187,13 @@ __device__ __forceinline__ TileIdx tile_idx(int tile, int e_end, const int32_t* 
 // partial sums (partials[range][0 = entered from the previous range | 1 = continues into the next][128]); every other row
 // leaves finished, divided by its degree.  k_edge_range_fixup combines the few partials in range order (deterministic).
 __device__ __forceinline__ void emit_run(const f32x2 acc, const RunMeta& md, int e, int e_lo, int e_hi, int range,
-                                         float* __restrict__ agg, float* __restrict__ partials, int lane) {
+                                         float deg_scale, float* __restrict__ agg, float* __restrict__ partials, int lane) {
     const int ti = __builtin_amdgcn_readlane(md.ti, e);
     const int rs = __builtin_amdgcn_readlane(md.rs, e), re = __builtin_amdgcn_readlane(md.re, e);
     f32x2 o = acc;
     float* dst;
     if (rs >= e_lo && re <= e_hi) {
-        const float dn = (float)(re - rs);
+        const float dn = (float)(re - rs) * deg_scale;
         o[0] = o[0] / dn;
         o[1] = o[1] / dn;
         dst = agg + (size_t)ti * 128;
@@ -203,7 +203,10 @@ __device__ __forceinline__ void emit_run(const f32x2 acc, const RunMeta& md, int
     *reinterpret_cast<f32x2*>(dst + 2 * lane) = o;
 }
 
-template <int MODE, int ABL = 0>
+// L2E: A and Bm arrive multiplied by log2(e) (folded into the packed message_net_1 halves by the caller).  Swish then costs
+// one multiply less on both sides of the GEMM: Swish(A + Bm) comes out with the factor, W2 passes it on, the bias registers
+// are scaled once per kernel, the second Swish keeps it, and the division by the degree divides it out.
+template <int MODE, int ABL = 0, bool L2E = false>
 __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__ A, const float* __restrict__ Bm,
                                                        const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
                                                        const int32_t* __restrict__ rowptr, int E,
@@ -212,6 +215,8 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
                                                        float* __restrict__ partials) {
     constexpr int NP = Split<MODE>::NP;
     static_assert(NP <= 2, "the transposition tiles and three weight planes do not fit the 160 KiB of LDS together");
+    auto sw = [](float x) { return L2E ? act_swish_l2e(x) : act_swish(x); };
+    constexpr float deg_scale = L2E ? MAGNET_LOG2E : 1.0f;           // folded into the divisor of finished rows
     __shared__ __attribute__((aligned(16))) u32x4 wl[32 * NP * 64];          // 64 KiB (fp16x3) / 32 KiB (bf16)
     __shared__ __attribute__((aligned(16))) float tb[4][32 * TB_STRIDE];     // 66 KiB
     for (int i = threadIdx.x; i < 32 * NP * 64; i += 256) wl[i] = w2s[i];
@@ -231,6 +236,12 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
     const float* const tr = tb[wave] + 2 * lane;                    // this lane's feature pair (read side)
     f32x16 in[4], out[4], outc[4], bias[4];
     init_bias<4>(bias, b2, half);             // loop-invariant C operand of every tile's first main product
+    if (L2E) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bias[nt][i] *= MAGNET_LOG2E;
+    }
     // Gather staging: two register sets, k tiles alternate between them.  The rows of k tile kt of the NEXT tile are
     // requested in group 8kt and become Swish(A + Bm) twelve groups (~4 000 cycles) later, in groups 8kt+12 .. 8kt+15
     // (k tile 3: groups 4-7 of the next iteration) - `in[kt]` of the current tile is dead after group 8kt+3.  With a
@@ -254,7 +265,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
                 const f32x4 a = *reinterpret_cast<const f32x4*>(pa + kt * 32 + 8 * g);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(pb + kt * 32 + 8 * g);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) in[kt][4 * g + c] = act_swish(a[c] + b[c]);
+                for (int c = 0; c < 4; ++c) in[kt][4 * g + c] = sw(a[c] + b[c]);
             }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {          // k tile 3 stays raw: groups 4-7 of the first iteration turn it into in[3]
@@ -312,10 +323,10 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
                 Split<MODE>::mma(wr[gq & 1], xs[slot & 1], out[nt], outc[nt]);
                 // edge gq of the previous tile: transposed read, Swish, running sum; a run end leaves here
                 {
-                    acc[0] += act_swish(cur[0]);
-                    acc[1] += act_swish(cur[1]);
+                    acc[0] += sw(cur[0]);
+                    acc[1] += sw(cur[1]);
                     if (pmd.ends & (1u << gq)) {
-                        emit_run(acc, pmd, gq, e_lo, e_hi, range, agg, partials, lane);
+                        emit_run(acc, pmd, gq, e_lo, e_hi, range, deg_scale, agg, partials, lane);
                         acc[0] = 0.f;
                         acc[1] = 0.f;
                     }
@@ -327,7 +338,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
                     const int set = ktc & 1;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        float v = act_swish(la[set][g][c] + lb[set][g][c]);
+                        float v = sw(la[set][g][c] + lb[set][g][c]);
                         asm volatile("" : "+v"(v));
                         in[ktc][4 * g + c] = v;
                     }
@@ -361,12 +372,12 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
     // the last tile's rows
     for (int e = 0; e < 32; ++e) {
         const f32x2 cur = *reinterpret_cast<const f32x2*>(tr + e * TB_STRIDE);
-        acc[0] += act_swish(cur[0]);
-        acc[1] += act_swish(cur[1]);
+        acc[0] += sw(cur[0]);
+        acc[1] += sw(cur[1]);
         if (pmd.ends & (1u << e)) {
             const int ti = __shfl(pmd.ti, e), rs = __shfl(pmd.rs, e), re = __shfl(pmd.re, e);
             const bool complete = rs >= e_lo && re <= e_hi;
-            const float dn = complete ? (float)(re - rs) : 1.f;
+            const float dn = complete ? (float)(re - rs) * deg_scale : 1.f;
             float* dst = complete ? agg + (size_t)ti * 128 : partials + ((size_t)range * 2 + (rs < e_lo ? 0 : 1)) * 128;
             const f32x2 o = {acc[0] / dn, acc[1] / dn};
             *reinterpret_cast<f32x2*>(dst + 2 * lane) = o;
@@ -379,7 +390,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
 // Completes what k_mpnn_edge7 left open: rows without edges become 0, and the row that crosses the start of range w (if it
 // ends inside range w) is assembled from the partial sums of the ranges it touches, in range order.
 __global__ void __launch_bounds__(256) k_edge_range_fixup(const int32_t* __restrict__ tgt, const int32_t* __restrict__ rowptr,
-                                                          int N, int E, int tpw, int nranges,
+                                                          int N, int E, int tpw, int nranges, float deg_scale,
                                                           const float* __restrict__ partials, float* __restrict__ agg) {
     const int r0 = blockIdx.x * 256 + threadIdx.x;
     if (r0 < N && rowptr[r0] == rowptr[r0 + 1]) {
@@ -402,7 +413,7 @@ __global__ void __launch_bounds__(256) k_edge_range_fixup(const int32_t* __restr
         acc[0] += p[0];
         acc[1] += p[1];
     }
-    const float dn = (float)(e - s);
+    const float dn = (float)(e - s) * deg_scale;
     const f32x2 o = {acc[0] / dn, acc[1] / dn};
     *reinterpret_cast<f32x2*>(agg + (size_t)r * 128 + 2 * lane) = o;
 }
@@ -411,7 +422,7 @@ int g_edge6_ablation = 0;
 
 extern "C" int magnet_segmean_fixup_f32(const int32_t* rowptr, int n_rows, int d, const float* partials, float* agg, void* stream);
 
-template <int MODE>
+template <int MODE, bool L2E = false>
 static int launch_edge6(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt, const int32_t* rowptr,
                         int n_edges, int n_rows, const void* w2_split, const float* b2, float* agg, float* partials,
                         void* stream) {
@@ -432,15 +443,17 @@ static int launch_edge6(const float* A, const float* Bm, const int32_t* src, con
     if constexpr (Split<MODE>::NP <= 2) {
         if (g_edge6_ablation == 0 || g_edge6_ablation == 8) {      // 6 = A/B knob: the generation-6 kernel (DPP scan epilogue)
             if (g_edge6_ablation == 0)
-                hipLaunchKernelGGL((k_mpnn_edge7<MODE>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+                hipLaunchKernelGGL((k_mpnn_edge7<MODE, 0, L2E>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
             else                                                    // development only (invalid results): gather from 32 fixed rows
                 hipLaunchKernelGGL((k_mpnn_edge7<MODE, 8>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
             const int nranges = (int)g.x * 4, tpw = (tiles + nranges - 1) / nranges;      // as computed inside the kernel
             const int fb = max((n_rows + 255) / 256, (nranges + 3) / 4);
-            hipLaunchKernelGGL(k_edge_range_fixup, dim3(fb), dim3(256), 0, s, tgt, rowptr, n_rows, n_edges, tpw, nranges, partials, agg);
+            hipLaunchKernelGGL(k_edge_range_fixup, dim3(fb), dim3(256), 0, s, tgt, rowptr, n_rows, n_edges, tpw, nranges,
+                               L2E ? MAGNET_LOG2E : 1.0f, partials, agg);
             return (int)hipGetLastError();
         }
     }
+    if (L2E) return -2;           // the scaled-input contract exists for the generation-7 kernel only
     switch (g_edge6_ablation) {   // development only: ablations produce invalid results
         case 1: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 1>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
         case 2: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 2>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
@@ -468,4 +481,16 @@ extern "C" int magnet_mpnn_edge_fp16x3_f32(const float* A, const float* Bm, cons
                                            const int32_t* rowptr, int n_edges, int n_rows, const void* w2_split,
                                            const float* b2, float* agg, float* partials, void* stream) {
     return launch_edge6<GEMM_FP16X3>(A, Bm, src, tgt, rowptr, n_edges, n_rows, w2_split, b2, agg, partials, stream);
+}
+
+extern "C" int magnet_mpnn_edge_fp16x3_l2e_f32(const float* A_l2e, const float* Bm_l2e, const int32_t* src, const int32_t* tgt,
+                                               const int32_t* rowptr, int n_edges, int n_rows, const void* w2_split,
+                                               const float* b2, float* agg, float* partials, void* stream) {
+    return launch_edge6<GEMM_FP16X3, true>(A_l2e, Bm_l2e, src, tgt, rowptr, n_edges, n_rows, w2_split, b2, agg, partials, stream);
+}
+
+extern "C" int magnet_mpnn_edge_bf16_l2e_f32(const float* A_l2e, const float* Bm_l2e, const int32_t* src, const int32_t* tgt,
+                                             const int32_t* rowptr, int n_edges, int n_rows, const void* w2_bf16,
+                                             const float* b2, float* agg, float* partials, void* stream) {
+    return launch_edge6<GEMM_BF16, true>(A_l2e, Bm_l2e, src, tgt, rowptr, n_edges, n_rows, w2_bf16, b2, agg, partials, stream);
 }

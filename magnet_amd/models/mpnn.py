@@ -124,6 +124,11 @@ class MPNN(LightningModule):
             L = types.SimpleNamespace()
             L.pre_a = pack(wa, m1.bias, self.gemm, k_pad=H + kin)
             L.pre_b = pack(wb, None, self.gemm, k_pad=H + kin)
+            # inference: the same halves with log2(e) folded in, for the edge kernel's base-2 Swish (ops.mpnn_edge(l2e=True));
+            # the backward recomputes from the tape's plain A / Bm, so training keeps the unscaled packs
+            if self.edge_gemm in ("fp16x3", "bf16"):
+                L.pre_a_l2e = pack(wa * ops.LOG2E, m1.bias.detach() * ops.LOG2E, self.gemm, k_pad=H + kin)
+                L.pre_b_l2e = pack(wb * ops.LOG2E, None, self.gemm, k_pad=H + kin)
             L.msg2 = pack(m2.weight, m2.bias, self.edge_gemm)
             cmap = torch.cat([torch.arange(2 * H), torch.tensor([2 * H + tw + dp])])   # var column inside node_in
             L.upd1 = pack(u1.weight, u1.bias, self.gemm, k_pad=2 * H + kin, col_map=cmap)
@@ -173,9 +178,10 @@ class MPNN(LightningModule):
             pre_in = ops.ktiles(T(h, H), T(node_in, kin))
             # A = W1a.[h | node_in] + b1 and Bm = W1b.[h | node_in]: two column groups of one launch, run back to back inside
             # each workgroup so that the second group reads [h | node_in] from L2 (fp32 kernels: two workgroup columns)
-            ops.mlp(N, pre_in, [lyr.pre_a, lyr.pre_b], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2,
-                    groups_in_block=True, y_group_stride=N * H)
-            ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials)
+            l2e = tape is None and hasattr(lyr, "pre_a_l2e")
+            ops.mlp(N, pre_in, [lyr.pre_a_l2e, lyr.pre_b_l2e] if l2e else [lyr.pre_a, lyr.pre_b], nl=1, ht=4, ot=4,
+                    act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2, groups_in_block=True, y_group_stride=N * H)
+            ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials, l2e=l2e)
             ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
                     act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g)
             if tape is None:

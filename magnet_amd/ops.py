@@ -150,10 +150,15 @@ EDGE_ENTRY = {torch.float16: "magnet_mpnn_edge_fp16x3_f32", torch.int16: "magnet
               torch.float32: "magnet_mpnn_edge_f32", torch.bfloat16: "magnet_mpnn_edge_bf16_f32"}
 
 
-def mpnn_edge(A, Bm, csr, w2, b2, agg, partials):
+EDGE_ENTRY_L2E = {torch.float16: "magnet_mpnn_edge_fp16x3_l2e_f32", torch.bfloat16: "magnet_mpnn_edge_bf16_l2e_f32"}
+LOG2E = 1.4426950408889634
+
+
+def mpnn_edge(A, Bm, csr, w2, b2, agg, partials, l2e=False):
     """fused MPNN edge kernel; the dtype of the packed message_net_2 weights selects the arithmetic
-    (float16 planes: fp16x3 split, int16 planes: bf16x6 split, float32 fragments: fp32 MFMA)."""
-    name = EDGE_ENTRY[w2.dtype]
+    (float16 planes: fp16x3 split, int16 planes: bf16x6 split, float32 fragments: fp32 MFMA).
+    l2e: A and Bm carry the factor log2(e) (EDGE_ENTRY_L2E modes only; see magnet_hip.h)."""
+    name = EDGE_ENTRY_L2E[w2.dtype] if l2e else EDGE_ENTRY[w2.dtype]
     L.check(getattr(L.lib(), name)(_p(A), _p(Bm), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.E, csr.N, _p(w2), _p(b2),
                                    _p(agg), _p(partials), _stream()), name)
     return agg

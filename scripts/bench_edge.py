@@ -49,6 +49,11 @@ for v3 in (0, 6, 8, 0):
     err = float((agg - ref).norm() / ref.norm())
     print(f"edge kernel, default split mode, knob [{v3}]: {ms:.3f} ms  {2*E*H*H/ms/1e9:.1f} TFLOP/s-equivalent (incl fixup)  rel-diff vs first {err:.2e} nan={int(torch.isnan(agg).sum())}")
 _lib.lib().magnet_debug_set_variant(1, 0)
+agg.fill_(float("nan"))
+A2, B2 = A * ops.LOG2E, Bm * ops.LOG2E
+ms = timeit(lambda: ops.mpnn_edge(A2, B2, csr, lyr.msg2[0], lyr.msg2[1], agg, partials, l2e=True))
+print(f"edge kernel, log2(e)-scaled inputs (what the model's inference path runs): {ms:.3f} ms  {2*E*H*H/ms/1e9:.1f} TFLOP/s-equivalent (incl fixup)  "
+      f"rel-diff vs first {float((agg - ref).norm() / ref.norm()):.2e}")
 h = torch.randn(N, H, device="cuda"); node_in = torch.randn(N, 32, device="cuda"); gbuf = torch.empty_like(h)
 T = ops.Term
 ms = timeit(lambda: ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, 32)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4, act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=gbuf))

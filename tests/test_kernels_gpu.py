@@ -191,6 +191,30 @@ def test_mpnn_edge_kernels_agree_on_ragged_graph():
         assert rel_l2(agg, want) < 1e-6, mode
 
 
+def test_mpnn_edge_log2e_scaled_inputs_give_the_same_mean():
+    """magnet_mpnn_edge_*_l2e_f32: A and Bm multiplied by log2(e) (what the model folds into the packed message_net_1
+    halves), unscaled W2 / b2 - the aggregated messages are the same quantity as from the plain entry point."""
+    from magnet_amd import ops
+    from magnet_amd.packing import pack
+    torch.manual_seed(11)
+    n, H = 257, 128
+    rowptr, tgt = _random_csr(n, 40, seed=9, long_rows=2)
+    E = tgt.numel()
+    src = torch.randint(0, n, (E,))
+    A, Bm = torch.randn(n, H).cuda(), torch.randn(n, H).cuda()
+    lin = torch.nn.Linear(H, H).cuda()
+    csr = ops.CSR(rowptr.cuda(), src.int().cuda(), tgt.int().cuda(), n, E)
+    for mode, tol in (("fp16x3", 1e-6), ("bf16", 2e-2)):
+        w, b = pack(lin.weight, lin.bias, mode)
+        ref = torch.full((n, H), float("nan"), device="cuda")
+        got = torch.full((n, H), float("nan"), device="cuda")
+        partials = torch.zeros(((E + 31) // 32) * 2 * H, device="cuda")
+        ops.mpnn_edge(A, Bm, csr, w, b, ref, partials)
+        ops.mpnn_edge(A * ops.LOG2E, Bm * ops.LOG2E, csr, w, b, got, partials, l2e=True)
+        assert not torch.isnan(got).any()
+        assert rel_l2(got, ref) < tol, (mode, rel_l2(got, ref))
+
+
 @pytest.mark.parametrize("case", ["no_edges", "under_one_tile", "one_row_owns_everything", "empty_rows_at_both_ends"])
 def test_mpnn_edge_range_partials_corner_cases(case):
     """k_mpnn_edge7 carries a row's running sum across the tiles of a wave and hands only range-crossing rows to
