@@ -15,6 +15,7 @@ state-dict keys; the arithmetic runs in libmagnet_hip.so:
 """
 from __future__ import annotations
 
+import os
 import types
 
 import torch
@@ -87,6 +88,8 @@ class MPNN(LightningModule):
         # arithmetic of the Linears: "fp16x3" / "bf16x6" = fp32 GEMMs on the fp16 / bf16 matrix cores through an exact
         # split (fp32-class accuracy), "fp32" = fp32 MFMA; optional hparams, not in the reference's config
         self.edge_gemm = getattr(hparams, "edge_gemm", default_gemm())
+        # inference: fold log2(e) into the per-node halves of message_net_1 for the edge kernel's base-2 Swish (A/B knob)
+        self.edge_l2e = bool(int(os.environ.get("MAGNET_EDGE_L2E", "1"))) and bool(getattr(hparams, "edge_l2e", True))
         assert self.edge_gemm in GEMM_MODES
         self.gemm = getattr(hparams, "gemm", self.edge_gemm)     # node-level Linears (same two choices)
         # backward-data GEMMs: gradients of a mean loss are ~1e-7, inside fp16's subnormal range, so the fp16 split is
@@ -126,7 +129,7 @@ class MPNN(LightningModule):
             L.pre_b = pack(wb, None, self.gemm, k_pad=H + kin)
             # inference: the same halves with log2(e) folded in, for the edge kernel's base-2 Swish (ops.mpnn_edge(l2e=True));
             # the backward recomputes from the tape's plain A / Bm, so training keeps the unscaled packs
-            if self.edge_gemm in ("fp16x3", "bf16"):
+            if self.edge_l2e and self.edge_gemm in ("fp16x3", "bf16"):
                 L.pre_a_l2e = pack(wa * ops.LOG2E, m1.bias.detach() * ops.LOG2E, self.gemm, k_pad=H + kin)
                 L.pre_b_l2e = pack(wb * ops.LOG2E, None, self.gemm, k_pad=H + kin)
             L.msg2 = pack(m2.weight, m2.bias, self.edge_gemm)
