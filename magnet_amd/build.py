@@ -19,6 +19,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmagnet_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+# per-source additions: the lane-per-node read-out is one fully unrolled block; below the default pragma-unroll threshold
+# hipcc unrolls it partially, indexes the row registers dynamically and puts them in scratch
+EXTRA_FLAGS = {"readout_kernels.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
 
 
 def sources():
@@ -38,7 +41,7 @@ def _compile(src: str) -> str:
     hdr = max(os.path.getmtime(p) for p in glob.glob(os.path.join(CSRC, "*.cuh")))
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr):
         return obj
-    cmd = ["hipcc", *FLAGS, "-c", src, "-o", obj]
+    cmd = ["hipcc", *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

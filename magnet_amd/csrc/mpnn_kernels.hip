@@ -189,42 +189,6 @@ __global__ void __launch_bounds__(NW * 64, (NW == 12 ? 3 : 2)) k_mpnn_edge2(cons
     }
 }
 
-// ---------------------------------------------------------------------------- read-out + Euler step
-// diff = Conv1d(8->1,k2)( [Swish]( Conv1d(1->8,k1,stride s1)(h[:, None, :]) ) ),
-// out[n, k] = u[n, tw-1] + dt*(k+1) * diff[n, k]        (models/mpnn.py:197-201, conv specs :140-163)
-// One wave per node; conv1 output (8 x L1) lives in LDS.
-__global__ void __launch_bounds__(256) k_mpnn_readout(const float* __restrict__ h, const float* __restrict__ u, int N,
-                                                      int tw, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                      int k1, int s1, const float* __restrict__ w2,
-                                                      const float* __restrict__ b2, int k2, int use_swish,
-                                                      const float* __restrict__ dt, float* __restrict__ out) {
-    __shared__ float sh[4][128];
-    __shared__ float sz[4][8 * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.x * 4 + wave;
-    const int L1 = (128 - k1) / s1 + 1;
-    if (n < N) {
-        sh[wave][lane] = h[(size_t)n * 128 + lane];
-        sh[wave][lane + 64] = h[(size_t)n * 128 + lane + 64];
-    }
-    __syncthreads();
-    if (n < N) {
-        for (int o = lane; o < 8 * L1; o += 64) {
-            const int c = o / L1, p = o % L1;
-            float acc = b1[c];
-            for (int k = 0; k < k1; ++k) acc += w1[c * k1 + k] * sh[wave][p * s1 + k];
-            sz[wave][o] = use_swish ? act_swish(acc) : acc;
-        }
-    }
-    __syncthreads();
-    if (n < N && lane < tw) {
-        float acc = b2[0];
-        for (int c = 0; c < 8; ++c)
-            for (int k = 0; k < k2; ++k) acc += w2[c * k2 + k] * sz[wave][c * L1 + lane + k];
-        out[(size_t)n * tw + lane] = u[(size_t)n * tw + tw - 1] + dt[0] * (float)(lane + 1) * acc;
-    }
-}
-
 // ---------------------------------------------------------------------------- per-graph InstanceNorm
 // y = (x - mean_g) / sqrt(var_g + eps), biased variance per graph and channel, two-pass
 // (PyG InstanceNorm defaults; models/mpnn.py:63,70).  Graphs are contiguous row blocks of
@@ -390,18 +354,6 @@ extern "C" int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32
     return rc ? rc : magnet_segmean_fixup_f32(rowptr, n_rows, 128, partials, agg, stream);
 }
 
-
-extern "C" int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1,
-                                       int k1, int s1, const float* w2, const float* b2, int k2, int use_swish,
-                                       const float* dt, float* out, void* stream) {
-    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
-    if (n <= 0) return 0;
-    const int L1 = (128 - k1) / s1 + 1;
-    if (L1 > 64 || tw > 64 || L1 - k2 + 1 != tw) return -2;
-    hipLaunchKernelGGL(k_mpnn_readout, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, u, n, tw, w1, b1, k1,
-                       s1, w2, b2, k2, use_swish, dt, out);
-    LAUNCH_CHECK();
-}
 
 // workspace: (2 * n_graphs * nchunks + 2 * n_graphs) * H floats, nchunks = ceil(rows_per_graph / 64)
 extern "C" int magnet_instance_norm_f32(const float* x, int n_graphs, int rows_per_graph, int H, float eps, float* y,

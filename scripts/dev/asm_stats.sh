@@ -2,7 +2,7 @@
 # usage: scripts/dev/asm_stats.sh magnet_amd/csrc/file.hip kernel_name_substring  -> register / spill / instruction mix summary
 f=$1; k=$2
 out=$(mktemp /tmp/asmXXXXXX.s)
-hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -S "$f" -o "$out" 2>/dev/null
+hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only $ASM_STATS_FLAGS -S "$f" -o "$out" 2>/dev/null   # ASM_STATS_FLAGS: e.g. "-mllvm -pragma-unroll-threshold=200000" for readout_kernels.hip
 python3 - "$out" "$k" <<'PY'
 import re,sys,collections
 s=open(sys.argv[1]).read(); key=sys.argv[2]
