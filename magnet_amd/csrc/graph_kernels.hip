@@ -182,18 +182,29 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan(int32_t* __restrict__ v
 }
 
 // query-major edge list: found[qptr[q] + k], query[...] = q   (== torch_cluster / PyG edge order)
-__global__ void k_emit_pairs(const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt,
-                             const int32_t* __restrict__ qptr, int N, int cap, int loop, int32_t* __restrict__ found,
-                             int32_t* __restrict__ query) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= N) return;
-    int o = qptr[q];
-    for (int k = 0; k < cnt[q]; ++k) {
-        const int f = nbr[(size_t)q * cap + k];
-        if (!loop && f == q) continue;
-        found[o] = f;
-        query[o] = q;
-        ++o;
+// Half a wave per query: 32 lanes read 32 consecutive candidates (coalesced), the kept ones are ranked with a ballot and
+// written next to each other; a thread per query read and wrote with a stride of `cap` ints (0.31 ms for 8.6 M pairs).
+__global__ void __launch_bounds__(256) k_emit_pairs(const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt,
+                                                    const int32_t* __restrict__ qptr, int N, int cap, int loop,
+                                                    int32_t* __restrict__ found, int32_t* __restrict__ query) {
+    const int lane = threadIdx.x & 63, sub = lane & 31, hi = lane >> 5;
+    const int q = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + hi;
+    const bool q_ok = q < N;
+    const int c = q_ok ? cnt[q] : 0;
+    int o = q_ok ? qptr[q] : 0;
+    const int cmax = max(__shfl(c, 0), __shfl(c, 32));            // both halves run the same number of rounds
+    for (int k0 = 0; k0 < cmax; k0 += 32) {
+        const int k = k0 + sub;
+        const int f = (k < c) ? nbr[(size_t)q * cap + k] : -1;
+        const bool keep = (k < c) && (loop || f != q);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        const unsigned mh = (unsigned)(hi ? (m >> 32) : m);       // this query's 32 lanes
+        if (keep) {
+            const int pos = o + __builtin_popcount(mh & ((1u << sub) - 1u));
+            found[pos] = f;
+            query[pos] = q;
+        }
+        o += __builtin_popcount(mh);
     }
 }
 
@@ -352,7 +363,7 @@ extern "C" int magnet_radius_emit_pairs(const int32_t* nbr, const int32_t* cnt, 
                                         int cap, int loop, int32_t* found, int32_t* query, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (n_nodes <= 0) return 0;
-    hipLaunchKernelGGL(k_emit_pairs, dim3(nb(n_nodes, 256)), dim3(256), 0, S_, nbr, cnt, qptr, n_nodes, cap, loop,
+    hipLaunchKernelGGL(k_emit_pairs, dim3(nb(n_nodes, 8)), dim3(256), 0, S_, nbr, cnt, qptr, n_nodes, cap, loop,
                        found, query);
     LAUNCH_CHECK();
 }
