@@ -374,6 +374,8 @@ def main():
         ev = []
         wdt = model._packed().layers[0].msg2[0].dtype
         entries = [e for e in (ops.EDGE_ENTRY[wdt], ops.EDGE_ENTRY_L2E.get(wdt)) if e]   # the model picks one of them
+        if wdt == torch.float16:
+            entries.append("magnet_mpnn_edge_fp16x3_t16_f32")
         origs = {e: getattr(ops.L.lib(), e) for e in entries}
 
         def timed(orig):
@@ -400,7 +402,8 @@ def main():
         mode = model.edge_gemm
         nprod = SPLIT_PRODUCTS.get(mode, 1)
         peak = MFMA_BF16_PEAK_TFLOPS / nprod if mode in SPLIT_PRODUCTS else MFMA_F32_PEAK_TFLOPS
-        kname = {"fp16x3": "k_mpnn_edge7", "bf16": "k_mpnn_edge7", "bf16x6": "k_mpnn_edge6"}.get(mode, "k_mpnn_edge2")
+        kname = {"fp16x3": "k_mpnn_edge16" if hasattr(model._packed().layers[0], "msg2_t16") else "k_mpnn_edge7",
+                 "bf16": "k_mpnn_edge7", "bf16x6": "k_mpnn_edge6"}.get(mode, "k_mpnn_edge2")
         roof = {"kernel": kname, "bound": "mfma",
                 "achieved": round(ach, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,

@@ -144,6 +144,14 @@ int magnet_mpnn_edge_fp16x3_l2e_f32(const float* A_l2e, const float* Bm_l2e, con
 int magnet_mpnn_edge_bf16_l2e_f32(const float* A_l2e, const float* Bm_l2e, const int32_t* src, const int32_t* tgt,
                                   const int32_t* rowptr, int n_edges, int n_rows, const void* w2_bf16, const float* b2,
                                   float* agg, float* partials, void* stream);
+/* The fp16x3 edge op on 16-edge tiles with two waves per SIMD (k_mpnn_edge16).  Same result contract as
+ * magnet_mpnn_edge_fp16x3_f32; w2_t16: the two fp16 planes of W2 in v_mfma_f32_16x16x32_f16 fragment order
+ * [4 k steps][8 output tiles][2 planes][64 lanes][8 fp16] (magnet_amd/packing.py:pack_edge16_fp16x2);
+ * a_bm_log2e_scaled != 0: A and Bm carry the factor log2(e) as for the _l2e entry points.
+ * partials: scratch, ceil(n_edges / 16) * 2 * 128 floats (twice the 32-edge kernels' bound). */
+int magnet_mpnn_edge_fp16x3_t16_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
+                                    const int32_t* rowptr, int n_edges, int n_rows, const void* w2_t16, const float* b2,
+                                    float* agg, float* partials, int a_bm_log2e_scaled, void* stream);
 /* out[n][k] = u[n][tw-1] + dt*(k+1) * Conv1d(8->1,k2)([Swish](Conv1d(1->8,k1,stride s1)(h[n])))[k];
  * models/mpnn.py:197-201 with the conv specs of :140-163. */
 int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1, int k1,

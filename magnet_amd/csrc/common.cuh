@@ -203,6 +203,7 @@ __device__ __forceinline__ void dense_layer(const f32x16 (&in)[KT], f32x16 (&out
 // of the C/D map, so a layer's output registers are again the next layer's B operands.
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned pack_top16(float v1, float v0) {   // (top16(v1) << 16) | top16(v0)
     return __builtin_amdgcn_perm(__float_as_uint(v1), __float_as_uint(v0), 0x07060302u);
@@ -289,7 +290,12 @@ template <>
 struct Split<GEMM_FP16X3> {
     static constexpr int NP = 2;
     static __device__ __forceinline__ void quarter(const f32x16& tile, int m, int p, u32x4 (&planes)[2]) {
-        const float a0 = tile[8 * m + 2 * p], a1 = tile[8 * m + 2 * p + 1];
+        const u32x2 w = pair(tile[8 * m + 2 * p], tile[8 * m + 2 * p + 1]);
+        planes[0][p] = w[0];
+        planes[1][p] = w[1];
+    }
+    // one word of each plane from two values: {(h1 << 16 | h0), (l1 << 16 | l0)}
+    static __device__ __forceinline__ u32x2 pair(float a0, float a1) {
         const unsigned h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a0, a1));
         // five instructions per value pair (hipcc's own lowering of the C expression takes nine): the remainder a - h is a
         // mixed-precision fma that reads the fp16 piece in place (exact, no conversion back to fp32), and the two scaled
@@ -301,8 +307,8 @@ struct Split<GEMM_FP16X3> {
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(h), "v"(a1));
         asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l) : "v"(d0), "s"(k2048));
         asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l) : "v"(d1), "s"(k2048));
-        planes[0][p] = h;
-        planes[1][p] = l;
+        const u32x2 w = {h, l};
+        return w;
     }
     static __device__ __forceinline__ void mma(const u32x4 (&w)[2], const u32x4 (&x)[2], f32x16& accM, f32x16& accC) {
         const f16x8 wh = __builtin_bit_cast(f16x8, w[0]), wl = __builtin_bit_cast(f16x8, w[1]);

@@ -170,10 +170,11 @@ struct TileIdx {
     int ti, sj, tnext;       // tgt[e], src[e] (clamped to the last edge), tgt[e + 1] or -2 at the end of the wave's range
     bool e_ok;
 };
+template <int TILE = 32>
 __device__ __forceinline__ TileIdx tile_idx(int tile, int e_end, const int32_t* __restrict__ src,
                                             const int32_t* __restrict__ tgt, int j) {
     TileIdx x;
-    const int e_raw = tile * 32 + j;
+    const int e_raw = tile * TILE + j;
     x.e_ok = e_raw < e_end;
     const int e = x.e_ok ? e_raw : e_end - 1;
     x.ti = tgt[e];
@@ -390,7 +391,8 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge7(const float* __restrict__
 // Completes what k_mpnn_edge7 left open: rows without edges become 0, and the row that crosses the start of range w (if it
 // ends inside range w) is assembled from the partial sums of the ranges it touches, in range order.
 __global__ void __launch_bounds__(256) k_edge_range_fixup(const int32_t* __restrict__ tgt, const int32_t* __restrict__ rowptr,
-                                                          int N, int E, int tpw, int nranges, float deg_scale,
+                                                          int N, int E, int tpw, int tshift /* log2(edges per tile) */,
+                                                          int nranges, float deg_scale,
                                                           const float* __restrict__ partials, float* __restrict__ agg) {
     const int r0 = blockIdx.x * 256 + threadIdx.x;
     if (r0 < N && rowptr[r0] == rowptr[r0 + 1]) {
@@ -400,13 +402,13 @@ __global__ void __launch_bounds__(256) k_edge_range_fixup(const int32_t* __restr
     }
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (w < 1 || w >= nranges) return;
-    const long es = (long)w * tpw * 32;
+    const long es = ((long)w * tpw) << tshift;
     if (es >= E) return;
     const int r = tgt[es];
     const int s = rowptr[r], e = rowptr[r + 1];
     if (s >= es) return;                                   // the row starts here: nothing entered from the previous range
-    if (((e - 1) >> 5) / tpw != w) return;                 // the row goes on: the range it ends in assembles it
-    const int wa = (s >> 5) / tpw;
+    if (((e - 1) >> tshift) / tpw != w) return;            // the row goes on: the range it ends in assembles it
+    const int wa = (s >> tshift) / tpw;
     f32x2 acc = *reinterpret_cast<const f32x2*>(partials + ((size_t)wa * 2 + 1) * 128 + 2 * lane);
     for (int t = wa + 1; t <= w; ++t) {
         const f32x2 p = *reinterpret_cast<const f32x2*>(partials + ((size_t)t * 2 + 0) * 128 + 2 * lane);
@@ -416,6 +418,195 @@ __global__ void __launch_bounds__(256) k_edge_range_fixup(const int32_t* __restr
     const float dn = (float)(e - s) * deg_scale;
     const f32x2 o = {acc[0] / dn, acc[1] / dn};
     *reinterpret_cast<f32x2*>(agg + (size_t)r * 128 + 2 * lane) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generation 8: the generation-7 pipeline on 16-EDGE tiles (v_mfma_f32_16x16x32_f16), two waves per SIMD.
+// scripts/dev/issue_probe.cpp: a single wave issues one instruction every ~4.5 cycles and nothing of its MFMA / VALU /
+// transcendental work overlaps; with two waves on a SIMD the transcendentals of one wave hide completely behind the other
+// wave's MFMAs and plain VALU issues at ~2.8 cycles ("3 MFMA + 20 fma + 4 exp + 4 rcp": 111 ns -> 76 ns per group).
+// The 32-edge tile needs 440 registers; halving the tile halves every per-tile array (accumulators 64, inputs 32, staging
+// 32, fragments 32: ~230 registers), so eight waves fit a CU.  Price: every wave still reads all of W2 from LDS per tile,
+// i.e. twice the LDS weight traffic per edge (ds_read_b128 runs at 256 B/clk on gfx950: ~40 % of the LDS pipe).
+// Operand layouts (checked by scripts/dev/mfma16_probe.cpp): A = W2 rows, lane l: row 16t + (l & 15), k = 32s + 8(l >> 4) + 0..7;
+// B = activations, lane l: edge l & 15, the same k; D: lane l: edge l & 15, rows 16t + 4(l >> 4) + 0..3.
+constexpr int T16_STRIDE = 132;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <bool L2E>
+__global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                     const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
+                                                     const int32_t* __restrict__ rowptr, int E,
+                                                     const u32x4* __restrict__ w2t /* [4 s][8 t][2 planes][64] */,
+                                                     const float* __restrict__ b2, float* __restrict__ agg,
+                                                     float* __restrict__ partials) {
+    auto sw = [](float x) { return L2E ? act_swish_l2e(x) : act_swish(x); };
+    constexpr float deg_scale = L2E ? MAGNET_LOG2E : 1.0f;
+    __shared__ __attribute__((aligned(16))) u32x4 wl[4 * 8 * 2 * 64];          // 64 KiB
+    __shared__ __attribute__((aligned(16))) float tb[8][16 * T16_STRIDE];      // 66 KiB
+    for (int i = threadIdx.x; i < 4 * 8 * 2 * 64; i += 512) wl[i] = w2t[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int ntiles = (E + 15) / 16;
+    const int nb8 = gridDim.x / 8;         // XCD-aware contiguous ranges, see k_mpnn_edge6
+    const int vb = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * nb8 + blockIdx.x / 8 : blockIdx.x;
+    const int tpw = (ntiles + gridDim.x * 8 - 1) / (gridDim.x * 8);
+    const int range = vb * 8 + wave;
+    int tile = range * tpw;
+    const int tend = min(tile + tpw, ntiles);
+    if (tile >= tend) return;
+    const int e_lo = tile * 16, e_hi = min(tend * 16, E);           // this wave's edges
+    float* const tw = tb[wave] + j * T16_STRIDE + 4 * q;            // this lane's row of the tile (write side), + 16 t
+    const float* const tr = tb[wave] + 2 * lane;                    // this lane's feature pair (read side), + 132 e
+    f32x4 out[8], outc[8], bias[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {             // loop-invariant C operand of every tile's first main product
+        bias[t] = *reinterpret_cast<const f32x4*>(b2 + 16 * t + 4 * q);
+        if (L2E) bias[t] *= MAGNET_LOG2E;
+    }
+    float in[4][8];
+    f32x4 la[2][2], lb[2][2];                 // gather staging: two sets of one k step (8 columns of A[i], 8 of Bm[j])
+    TileIdx ix = tile_idx<16>(tile, e_hi, src, tgt, j);
+    RunMeta md;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {             // the first iteration reads the LDS tile before any GEMM has filled it: Swish(0) = 0
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(tw + 16 * t) = z;
+    }
+    {   // prologue: gather + Swish for the first tile
+        const float* pa = A + (size_t)ix.ti * 128 + 8 * q;
+        const float* pb = Bm + (size_t)ix.sj * 128 + 8 * q;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(pa + 32 * s + 4 * g);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(pb + 32 * s + 4 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) in[s][4 * g + c] = sw(a[c] + b[c]);
+            }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {          // k step 3 stays raw: groups 4-7 of the first iteration turn it into in[3]
+            la[1][g] = *reinterpret_cast<const f32x4*>(pa + 96 + 4 * g);
+            lb[1][g] = *reinterpret_cast<const f32x4*>(pb + 96 + 4 * g);
+        }
+        md.ti = ix.ti;
+        md.rs = rowptr[ix.ti];
+        md.re = rowptr[ix.ti + 1];
+        md.ends = (unsigned)__builtin_amdgcn_ballot_w64(ix.e_ok && ix.tnext != ix.ti) & 0xFFFFu;   // lanes 0-15
+    }
+    RunMeta pmd = md;
+    pmd.ends = 0;                              // no previous tile yet: nothing leaves in the first iteration
+    TileIdx ix1 = tile_idx<16>(min(tile + 1, tend - 1), e_hi, src, tgt, j);
+    asm volatile("" ::"v"(ix1.ti), "v"(ix1.sj), "v"(ix1.tnext), "v"(md.rs), "v"(md.re));   // see k_mpnn_edge7
+    f32x2 acc = {0.f, 0.f};                   // running sum of the current run; carried across the wave's tiles
+    for (; tile < tend; ++tile) {
+        const TileIdx ix2 = tile_idx<16>(min(tile + 2, tend - 1), e_hi, src, tgt, j);
+        RunMeta md1;
+        md1.ti = ix1.ti;
+        md1.rs = rowptr[ix1.ti];
+        md1.re = rowptr[ix1.ti + 1];
+        const float* pan = A + (size_t)ix1.ti * 128 + 8 * q;             // clamped: the last iteration prefetches unused data
+        const float* pbn = Bm + (size_t)ix1.sj * 128 + 8 * q;
+        f32x2 rv = *reinterpret_cast<const f32x2*>(tr);
+        {
+            u32x4 xs[2][2], wr[2][2];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const u32x2 w = Split<GEMM_FP16X3>::pair(in[0][2 * p], in[0][2 * p + 1]);
+                xs[0][0][p] = w[0];
+                xs[0][1][p] = w[1];
+            }
+            wr[0][0] = wl[lane];
+            wr[0][1] = wl[64 + lane];
+#pragma unroll
+            for (int g = 0; g < 32; ++g) {        // g = s * 8 + t: k step s (32 input features), output tile t (16 features)
+                const int s = g >> 3, t = g & 7;
+                if (g + 1 < 32) {
+                    wr[(g + 1) & 1][0] = wl[((g + 1) * 2 + 0) * 64 + lane];
+                    wr[(g + 1) & 1][1] = wl[((g + 1) * 2 + 1) * 64 + lane];
+                }
+                f32x2 cur = rv;                   // even groups: edge g / 2 of the previous tile; the next row is requested now
+                if (!(g & 1) && g + 2 < 32) rv = *reinterpret_cast<const f32x2*>(tr + (g / 2 + 1) * T16_STRIDE);
+                __builtin_amdgcn_sched_barrier(0);    // LDS requests first (see k_mpnn_edge7)
+                if (s + 1 < 4 && !(g & 1)) {
+                    const int p = t >> 1;
+                    const u32x2 w = Split<GEMM_FP16X3>::pair(in[s + 1][2 * p], in[s + 1][2 * p + 1]);
+                    xs[(s + 1) & 1][0][p] = w[0];
+                    xs[(s + 1) & 1][1][p] = w[1];
+                }
+                if (s == 0) {   // first k step: the accumulators start from the bias registers / the inline constant 0
+                    out[t] = bias[t];
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    outc[t] = z;
+                }
+                outc[t] = mfma16(wr[g & 1][1], xs[s & 1][0], outc[t]);
+                out[t] = mfma16(wr[g & 1][0], xs[s & 1][0], out[t]);
+                outc[t] = mfma16(wr[g & 1][0], xs[s & 1][1], outc[t]);
+                if (!(g & 1)) {                   // transposed read of one edge of the previous tile, Swish, running sum
+                    acc[0] += sw(cur[0]);
+                    acc[1] += sw(cur[1]);
+                    if (pmd.ends & (1u << (g / 2))) {
+                        emit_run(acc, pmd, g / 2, e_lo, e_hi, range, deg_scale, agg, partials, lane);
+                        acc[0] = 0.f;
+                        acc[1] = 0.f;
+                    }
+                }
+                // staged rows -> Swish(A + Bm), two values per group, pinned to their group (see k_mpnn_edge7)
+                if ((g & 7) >= 4) {
+                    const int sc = ((g >> 3) + 3) & 3, idx = g & 3, set = sc & 1;   // groups 4-7: k step 3, 12-15: 0, 20-23: 1, 28-31: 2
+#pragma unroll
+                    for (int c = 2 * idx; c < 2 * idx + 2; ++c) {
+                        float v = sw(la[set][c >> 2][c & 3] + lb[set][c >> 2][c & 3]);
+                        asm volatile("" : "+v"(v));
+                        in[sc][c] = v;
+                    }
+                }
+                if ((g & 7) == 0) {
+                    const int set = s & 1;
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        la[set][h2] = *reinterpret_cast<const f32x4*>(pan + 32 * s + 4 * h2);
+                        lb[set][h2] = *reinterpret_cast<const f32x4*>(pbn + 32 * s + 4 * h2);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // this tile's raw GEMM output -> the wave's LDS tile (row = edge), consumed during the next iteration
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = fmaf(outc[t][r], 1.0f / 2048.0f, out[t][r]);
+            *reinterpret_cast<f32x4*>(tw + 16 * t) = o;
+        }
+        pmd = md;
+        md1.ends = (unsigned)__builtin_amdgcn_ballot_w64(ix1.e_ok && ix1.tnext != ix1.ti) & 0xFFFFu;
+        md = md1;
+        ix1 = ix2;
+    }
+    // the last tile's rows
+    for (int e = 0; e < 16; ++e) {
+        const f32x2 cur = *reinterpret_cast<const f32x2*>(tr + e * T16_STRIDE);
+        acc[0] += sw(cur[0]);
+        acc[1] += sw(cur[1]);
+        if (pmd.ends & (1u << e)) {
+            const int ti = __shfl(pmd.ti, e), rs = __shfl(pmd.rs, e), re = __shfl(pmd.re, e);
+            const bool complete = rs >= e_lo && re <= e_hi;
+            const float dn = complete ? (float)(re - rs) * deg_scale : 1.f;
+            float* dst = complete ? agg + (size_t)ti * 128 : partials + ((size_t)range * 2 + (rs < e_lo ? 0 : 1)) * 128;
+            const f32x2 o = {acc[0] / dn, acc[1] / dn};
+            *reinterpret_cast<f32x2*>(dst + 2 * lane) = o;
+            acc[0] = 0.f;
+            acc[1] = 0.f;
+        }
+    }
 }
 
 int g_edge6_ablation = 0;
@@ -448,7 +639,7 @@ static int launch_edge6(const float* A, const float* Bm, const int32_t* src, con
                 hipLaunchKernelGGL((k_mpnn_edge7<MODE, 8>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
             const int nranges = (int)g.x * 4, tpw = (tiles + nranges - 1) / nranges;      // as computed inside the kernel
             const int fb = max((n_rows + 255) / 256, (nranges + 3) / 4);
-            hipLaunchKernelGGL(k_edge_range_fixup, dim3(fb), dim3(256), 0, s, tgt, rowptr, n_rows, n_edges, tpw, nranges,
+            hipLaunchKernelGGL(k_edge_range_fixup, dim3(fb), dim3(256), 0, s, tgt, rowptr, n_rows, n_edges, tpw, 5, nranges,
                                L2E ? MAGNET_LOG2E : 1.0f, partials, agg);
             return (int)hipGetLastError();
         }
@@ -493,4 +684,33 @@ extern "C" int magnet_mpnn_edge_bf16_l2e_f32(const float* A_l2e, const float* Bm
                                              const int32_t* rowptr, int n_edges, int n_rows, const void* w2_bf16,
                                              const float* b2, float* agg, float* partials, void* stream) {
     return launch_edge6<GEMM_BF16, true>(A_l2e, Bm_l2e, src, tgt, rowptr, n_edges, n_rows, w2_bf16, b2, agg, partials, stream);
+}
+
+// 16-edge tiles, two waves per SIMD (k_mpnn_edge16).  w2_t16: fp16 planes of W2 in the 16x16x32 fragment order
+// [4 k steps][8 output tiles][2 planes][64 lanes][8 fp16] (magnet_amd/packing.py:pack_edge16_fp16x2).
+extern "C" int magnet_mpnn_edge_fp16x3_t16_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
+                                               const int32_t* rowptr, int n_edges, int n_rows, const void* w2_t16,
+                                               const float* b2, float* agg, float* partials, int a_bm_log2e_scaled,
+                                               void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
+    if (n_edges <= 0) return magnet_segmean_fixup_f32(rowptr, n_rows, 128, partials, agg, stream);   // all rows empty: zeros
+    static int ncu = 0;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        int dev;
+        hipGetDevice(&dev);
+        hipGetDeviceProperties(&prop, dev);
+        ncu = prop.multiProcessorCount;
+    }
+    const int tiles = (n_edges + 15) / 16;
+    const dim3 g(min((tiles + 7) / 8, ncu)), b(512);
+    const u32x4* ws = reinterpret_cast<const u32x4*>(w2_t16);
+    hipStream_t s = (hipStream_t)stream;
+    if (a_bm_log2e_scaled) hipLaunchKernelGGL(k_mpnn_edge16<true>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+    else hipLaunchKernelGGL(k_mpnn_edge16<false>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+    const int nranges = (int)g.x * 8, tpw = (tiles + nranges - 1) / nranges;      // as computed inside the kernel
+    const int fb = max((n_rows + 255) / 256, (nranges + 3) / 4);
+    hipLaunchKernelGGL(k_edge_range_fixup, dim3(fb), dim3(256), 0, s, tgt, rowptr, n_rows, n_edges, tpw, 4, nranges,
+                       a_bm_log2e_scaled ? MAGNET_LOG2E : 1.0f, partials, agg);
+    return (int)hipGetLastError();
 }

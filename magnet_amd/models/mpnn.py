@@ -23,7 +23,7 @@ from torch import nn
 
 from .. import ops
 from ..lightning_compat import LightningModule
-from ..packing import GEMM_MODES, default_gemm, pack, pad_to
+from ..packing import GEMM_MODES, default_gemm, pack, pack_edge16_fp16x2, pad_to
 
 _READOUT = {10: (16, 6, 10), 16: (16, 5, 8), 20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}  # mpnn.py:140-163
 
@@ -90,6 +90,8 @@ class MPNN(LightningModule):
         self.edge_gemm = getattr(hparams, "edge_gemm", default_gemm())
         # inference: fold log2(e) into the per-node halves of message_net_1 for the edge kernel's base-2 Swish (A/B knob)
         self.edge_l2e = bool(int(os.environ.get("MAGNET_EDGE_L2E", "1"))) and bool(getattr(hparams, "edge_l2e", True))
+        # inference, fp16x3: 16-edge tiles with two waves per SIMD (k_mpnn_edge16) instead of 32-edge tiles (A/B knob)
+        self.edge_t16 = bool(int(os.environ.get("MAGNET_EDGE_T16", "1"))) and bool(getattr(hparams, "edge_t16", True))
         assert self.edge_gemm in GEMM_MODES
         self.gemm = getattr(hparams, "gemm", self.edge_gemm)     # node-level Linears (same two choices)
         # backward-data GEMMs: gradients of a mean loss are ~1e-7, inside fp16's subnormal range, so the fp16 split is
@@ -133,6 +135,8 @@ class MPNN(LightningModule):
                 L.pre_a_l2e = pack(wa * ops.LOG2E, m1.bias.detach() * ops.LOG2E, self.gemm, k_pad=H + kin)
                 L.pre_b_l2e = pack(wb * ops.LOG2E, None, self.gemm, k_pad=H + kin)
             L.msg2 = pack(m2.weight, m2.bias, self.edge_gemm)
+            if self.edge_t16 and self.edge_gemm == "fp16x3":
+                L.msg2_t16 = pack_edge16_fp16x2(m2.weight, m2.bias)
             cmap = torch.cat([torch.arange(2 * H), torch.tensor([2 * H + tw + dp])])   # var column inside node_in
             L.upd1 = pack(u1.weight, u1.bias, self.gemm, k_pad=2 * H + kin, col_map=cmap)
             L.upd2 = pack(u2.weight, u2.bias, self.gemm)
@@ -169,7 +173,7 @@ class MPNN(LightningModule):
         new = lambda: torch.empty(N, H, device=dev, dtype=torch.float32)  # noqa: E731
         h, g, agg = new(), new(), new()
         AB = torch.empty(2, N, H, device=dev, dtype=torch.float32)      # the two per-node halves of message_net_1, one launch
-        partials = torch.empty(((csr.E + 31) // 32) * 2 * H, device=dev, dtype=torch.float32)
+        partials = torch.empty(ops.edge_scratch_floats(csr.E), device=dev, dtype=torch.float32)
         T = ops.Term
         ops.mlp(N, ops.ktiles(T(node_in, kin)), P.emb, nl=2, ht=4, ot=4, act=ops.ACT_SWISH, last_act=True, y=h)
         if tape is not None:
@@ -184,7 +188,10 @@ class MPNN(LightningModule):
             l2e = tape is None and hasattr(lyr, "pre_a_l2e")
             ops.mlp(N, pre_in, [lyr.pre_a_l2e, lyr.pre_b_l2e] if l2e else [lyr.pre_a, lyr.pre_b], nl=1, ht=4, ot=4,
                     act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2, groups_in_block=True, y_group_stride=N * H)
-            ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials, l2e=l2e)
+            if tape is None and hasattr(lyr, "msg2_t16"):
+                ops.mpnn_edge16(A, Bm, csr, lyr.msg2_t16[0], lyr.msg2_t16[1], agg, partials, l2e=l2e)
+            else:
+                ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials, l2e=l2e)
             ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
                     act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g)
             if tape is None:

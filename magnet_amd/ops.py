@@ -164,6 +164,22 @@ def mpnn_edge(A, Bm, csr, w2, b2, agg, partials, l2e=False):
     return agg
 
 
+def edge_scratch_floats(n_edges: int) -> int:
+    """size of the ``partials`` scratch of the fused edge kernels (the 16-edge-tile kernel needs two 128-float rows per
+    16 edges at most; the 32-edge ones half of that)"""
+    return max((int(n_edges) + 15) // 16, 1) * 2 * 128
+
+
+def mpnn_edge16(A, Bm, csr, w2_t16, b2, agg, partials, l2e=False):
+    """the same op on 16-edge tiles with two waves per SIMD (k_mpnn_edge16, fp16x3 only); w2_t16 from
+    packing.pack_edge16_fp16x2 - the fragment order differs from the 32-edge kernels' packs"""
+    assert w2_t16.dtype == torch.float16 and partials.numel() >= edge_scratch_floats(csr.E)
+    L.check(L.lib().magnet_mpnn_edge_fp16x3_t16_f32(_p(A), _p(Bm), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.E, csr.N,
+                                                    _p(w2_t16), _p(b2), _p(agg), _p(partials), int(l2e), _stream()),
+            "mpnn_edge_fp16x3_t16")
+    return agg
+
+
 mpnn_edge_bf16x6 = mpnn_edge     # kept for scripts: the weights' dtype decides
 
 

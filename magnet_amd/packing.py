@@ -116,6 +116,19 @@ def pack_linear_fp16x2(w: torch.Tensor, b: torch.Tensor | None, k_pad: int | Non
     return out.view(-1), bp
 
 
+def pack_edge16_fp16x2(w: torch.Tensor, b: torch.Tensor | None):
+    """message_net_2 (128 x 128) for the 16-edge-tile edge kernel (k_mpnn_edge16): the two fp16 planes in the
+    v_mfma_f32_16x16x32_f16 A-operand order [4 k steps][8 output tiles][2 planes][64 lanes][8 fp16] - lane l of (s, t)
+    holds W[16 t + (l & 15)][32 s + 8 (l >> 4) + 0..7] - plus the fp32 bias."""
+    assert tuple(w.shape) == (128, 128), w.shape
+    planes = [pl.view(8, 16, 4, 4, 8).permute(2, 0, 3, 1, 4).reshape(4, 8, 64, 8) for pl in split_fp16x2(w)]
+    out = torch.stack(planes, dim=2).contiguous()            # [s, t, plane, lane, 8]
+    bp = torch.zeros(128, dtype=torch.float32, device=w.device)
+    if b is not None:
+        bp[:] = b.detach().float()
+    return out.view(-1), bp
+
+
 def pack_linear_bf16x1(w: torch.Tensor, b: torch.Tensor | None, k_pad: int | None = None, n_pad: int | None = None,
                        col_map: torch.Tensor | None = None):
     """ONE bf16 plane (round-to-nearest-even) in MFMA fragment order [kt][nt][m][1][lane][8] (bfloat16) + padded fp32 bias:

@@ -19,7 +19,7 @@ csr = topo.csr
 N, E, H = csr.N, csr.E, 128
 P = m._packed()
 A, Bm, agg = (torch.randn(N, H, device="cuda") for _ in range(3))
-partials = torch.empty(((E + 31) // 32) * 2 * H, device="cuda")
+partials = torch.empty(ops.edge_scratch_floats(E), device="cuda")
 lyr = P.layers[0]
 
 def timeit(fn, reps=10):
@@ -54,6 +54,14 @@ A2, B2 = A * ops.LOG2E, Bm * ops.LOG2E
 ms = timeit(lambda: ops.mpnn_edge(A2, B2, csr, lyr.msg2[0], lyr.msg2[1], agg, partials, l2e=True))
 print(f"edge kernel, log2(e)-scaled inputs (what the model's inference path runs): {ms:.3f} ms  {2*E*H*H/ms/1e9:.1f} TFLOP/s-equivalent (incl fixup)  "
       f"rel-diff vs first {float((agg - ref).norm() / ref.norm()):.2e}")
+from magnet_amd.packing import pack_edge16_fp16x2
+w16 = pack_edge16_fp16x2(_m2.weight, _m2.bias)
+for l2e in (False, True):
+    agg.fill_(float("nan"))
+    Ax, Bx = (A2, B2) if l2e else (A, Bm)
+    ms = timeit(lambda: ops.mpnn_edge16(Ax, Bx, csr, w16[0], w16[1], agg, partials, l2e=l2e))
+    print(f"edge kernel, 16-edge tiles, 2 waves/SIMD, l2e={l2e}: {ms:.3f} ms  {2*E*H*H/ms/1e9:.1f} TFLOP/s-equivalent (incl fixup)  "
+          f"rel-diff vs first {float((agg - ref).norm() / ref.norm()):.2e} nan={int(torch.isnan(agg).sum())}")
 h = torch.randn(N, H, device="cuda"); node_in = torch.randn(N, 32, device="cuda"); gbuf = torch.empty_like(h)
 T = ops.Term
 ms = timeit(lambda: ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, 32)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4, act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=gbuf))

@@ -13,7 +13,7 @@ import glob
 import json
 import sys
 
-KERNELS = {"k_mpnn_edge7": "k_mpnn_edge7", "k_mpnn_edge6": "k_mpnn_edge6", "k_segment_mean<128>": "k_segment_mean<128>"}
+KERNELS = {"k_mpnn_edge16": "k_mpnn_edge16", "k_mpnn_edge7": "k_mpnn_edge7", "k_mpnn_edge6": "k_mpnn_edge6", "k_segment_mean<128>": "k_segment_mean<128>"}
 
 
 def mean_per_launch(d, counter):

@@ -2,6 +2,7 @@
 // every wave does the same work: if the time stays the same when the waves double, throughput doubled.
 //   kind 0: independent v_fma_f32            kind 1: v_exp_f32 (+ mul)          kind 2: Swish  x * rcp(1 + exp(-x))
 //   kind 3: MFMA 32x32x16 f16 + 8 fma per MFMA (one instruction stream)        kind 4: MFMA only
+//   kind 5: one MFMA group of the edge kernel: 3 MFMA + 20 fma + 4 exp + 4 rcp, interleaved
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -27,6 +28,20 @@ __global__ void __launch_bounds__(TPB) k(float* out, int iters) {
 #pragma unroll
                 for (int q = 8; q < 16; ++q) v[q] = fmaf(v[q], b, a);
             }
+        } else if (KIND == 5) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c0, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) v[q] = fmaf(v[q], b, a);
+            v[12] = __builtin_amdgcn_exp2f(-v[12]) * 0.5f; v[13] = __builtin_amdgcn_exp2f(-v[13]) * 0.5f;
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c1, 0, 0, 0);
+#pragma unroll
+            for (int q = 7; q < 12; ++q) v[q] = fmaf(v[q], b, a);
+            v[12] = __builtin_amdgcn_rcpf(1.0f + v[12]); v[13] = __builtin_amdgcn_rcpf(1.0f + v[13]);
+            v[14] = __builtin_amdgcn_exp2f(-v[14]) * 0.5f; v[15] = __builtin_amdgcn_exp2f(-v[15]) * 0.5f;
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, c0, 0, 0, 0);
+            v[14] = __builtin_amdgcn_rcpf(1.0f + v[14]); v[15] = __builtin_amdgcn_rcpf(1.0f + v[15]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaf(v[q + 4], b, v[q]);
         } else {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -58,5 +73,6 @@ int main() {
     ROW(2, "16 x swish (+fma): 2 trans + 4 valu")
     ROW(3, "2 MFMA f16 32x32x16 + 16 fma")
     ROW(4, "2 MFMA only")
+    ROW(5, "edge group: 3 MFMA + 20 fma + 4 exp + 4 rcp")
     return 0;
 }

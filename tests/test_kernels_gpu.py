@@ -215,6 +215,47 @@ def test_mpnn_edge_log2e_scaled_inputs_give_the_same_mean():
         assert rel_l2(got, ref) < tol, (mode, rel_l2(got, ref))
 
 
+@pytest.mark.parametrize("case", ["ragged", "no_edges", "under_one_tile", "one_row_owns_everything"])
+@pytest.mark.parametrize("l2e", [False, True])
+def test_mpnn_edge16_matches_host_evaluation(case, l2e):
+    """k_mpnn_edge16 (16-edge tiles, v_mfma_f32_16x16x32_f16, two waves per SIMD, its own weight fragment order) against a
+    host evaluation on a ragged graph (empty rows, rows across many tiles, E % 16 != 0) and the range-partials corner cases."""
+    from magnet_amd import ops
+    from magnet_amd.packing import pack_edge16_fp16x2
+    from oracle.pyg_semantics import scatter_mean
+    torch.manual_seed(3)
+    H = 128
+    if case == "ragged":
+        n = 301
+        rowptr, tgt = _random_csr(n, 45, seed=5, long_rows=3)
+    else:
+        n, deg = {"no_edges": (5, [0] * 5), "under_one_tile": (6, [3, 0, 7, 1, 0, 2]),
+                  "one_row_owns_everything": (3, [0, 40001, 0])}[case]
+        rowptr = torch.zeros(n + 1, dtype=torch.int32)
+        rowptr[1:] = torch.tensor(deg).cumsum(0)
+        tgt = torch.repeat_interleave(torch.arange(n), torch.tensor(deg))
+    E = tgt.numel()
+    src = torch.randint(0, n, (E,))
+    A, Bm = torch.randn(n, H), torch.randn(n, H)
+    lin = torch.nn.Linear(H, H)
+    sw = lambda x: x * torch.sigmoid(x)  # noqa: E731
+    with torch.no_grad():
+        m = sw(lin.double()(sw((A[tgt.long()] + Bm[src.long()]).double())))
+    want = scatter_mean(m, tgt.long(), n) if E else torch.zeros(n, H, dtype=torch.float64)
+    csr = ops.CSR(rowptr.int().cuda(), src.int().cuda(), tgt.int().cuda(), n, E)
+    w, b = pack_edge16_fp16x2(lin.weight.cuda(), lin.bias.cuda())
+    agg = torch.full((n, H), float("nan"), device="cuda")
+    partials = torch.zeros(ops.edge_scratch_floats(E), device="cuda")
+    scale = ops.LOG2E if l2e else 1.0
+    ops.mpnn_edge16(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e)
+    assert not torch.isnan(agg).any()
+    if E:
+        # a 40 001-term fp32 running sum (one row owning every edge) carries ~1e-6 of rounding by itself
+        assert rel_l2(agg, want) < (3e-6 if case == "one_row_owns_everything" else 1e-6), rel_l2(agg, want)
+    else:
+        assert float(agg.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("case", ["no_edges", "under_one_tile", "one_row_owns_everything", "empty_rows_at_both_ends"])
 def test_mpnn_edge_range_partials_corner_cases(case):
     """k_mpnn_edge7 carries a row's running sum across the tiles of a wave and hands only range-crossing rows to
