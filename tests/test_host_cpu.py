@@ -93,6 +93,24 @@ def test_split_fp16x2_reconstructs_to_fp32_class():
         split_fp16x2(torch.tensor([1.0, 7e4]))
 
 
+def test_pack_edge16_fragment_order():
+    """pack_edge16_fp16x2: lane l of (k step s, output tile t) holds W[16 t + (l & 15)][32 s + 8 (l >> 4) + 0..7] of each
+    fp16 plane - the A-operand order of v_mfma_f32_16x16x32_f16 the 16-edge-tile edge kernel reads from LDS."""
+    from magnet_amd.packing import pack_edge16_fp16x2, split_fp16x2
+    torch.manual_seed(0)
+    w, b = torch.randn(128, 128) * 0.1, torch.randn(128)
+    flat, bias = pack_edge16_fp16x2(w, b)
+    assert flat.dtype == torch.float16 and flat.numel() == 4 * 8 * 2 * 64 * 8 and torch.equal(bias, b)
+    frag = flat.view(4, 8, 2, 64, 8)
+    h, lo = split_fp16x2(w)
+    for s_, t, lane in ((0, 0, 0), (1, 3, 17), (3, 7, 63), (2, 5, 40)):
+        row, k0 = 16 * t + (lane & 15), 32 * s_ + 8 * (lane >> 4)
+        assert torch.equal(frag[s_, t, 0, lane], h[row, k0:k0 + 8])
+        assert torch.equal(frag[s_, t, 1, lane], lo[row, k0:k0 + 8])
+    # the two planes reconstruct the weight to fp32 rounding
+    assert float(((h.float() + lo.float() / 2048.0) - w).abs().max()) < 1e-7
+
+
 def test_training_host_logic_on_cpu():
     """host-side pieces of the training path that need no GPU: flat-gradient detection, the width decomposition of the
     backward GEMMs, and the loud failure of the fused optimizer / differentiable ops without a HIP device."""
