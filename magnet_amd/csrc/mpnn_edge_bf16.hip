@@ -515,59 +515,72 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
         const float* pbn = Bm + (size_t)ix1.sj * 128 + 8 * q;
         f32x2 rv = *reinterpret_cast<const f32x2*>(tr);
         {
-            u32x4 xs[2][2], wr[2][2];
+            u32x4 xs[2][2], wr[2][2][2];          // weight fragments: [buffer][tile of the pair][plane]
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const u32x2 w = Split<GEMM_FP16X3>::pair(in[0][2 * p], in[0][2 * p + 1]);
                 xs[0][0][p] = w[0];
                 xs[0][1][p] = w[1];
             }
-            wr[0][0] = wl[lane];
-            wr[0][1] = wl[64 + lane];
 #pragma unroll
-            for (int g = 0; g < 32; ++g) {        // g = s * 8 + t: k step s (32 input features), output tile t (16 features)
-                const int s = g >> 3, t = g & 7;
-                if (g + 1 < 32) {
-                    wr[(g + 1) & 1][0] = wl[((g + 1) * 2 + 0) * 64 + lane];
-                    wr[(g + 1) & 1][1] = wl[((g + 1) * 2 + 1) * 64 + lane];
+            for (int u = 0; u < 2; ++u) {
+                wr[0][u][0] = wl[(u * 2 + 0) * 64 + lane];
+                wr[0][u][1] = wl[(u * 2 + 1) * 64 + lane];
+            }
+            // 16 double groups: dg = s * 4 + tp handles k step s for the output tiles 2 tp and 2 tp + 1.  The six MFMAs
+            // alternate between the two tiles, so an accumulator is read again only two MFMAs after it was written
+            // (back to back, the dependent cross product stalled the issue for an MFMA latency).  One edge of the
+            // previous tile per double group.
+#pragma unroll
+            for (int dg = 0; dg < 16; ++dg) {
+                const int s = dg >> 2, tp = dg & 3, t0 = 2 * tp, t1 = 2 * tp + 1;
+                if (dg + 1 < 16) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        wr[(dg + 1) & 1][u][0] = wl[(((dg + 1) * 2 + u) * 2 + 0) * 64 + lane];
+                        wr[(dg + 1) & 1][u][1] = wl[(((dg + 1) * 2 + u) * 2 + 1) * 64 + lane];
+                    }
                 }
-                f32x2 cur = rv;                   // even groups: edge g / 2 of the previous tile; the next row is requested now
-                if (!(g & 1) && g + 2 < 32) rv = *reinterpret_cast<const f32x2*>(tr + (g / 2 + 1) * T16_STRIDE);
+                const f32x2 cur = rv;             // edge dg of the previous tile; the next row is requested now
+                if (dg + 1 < 16) rv = *reinterpret_cast<const f32x2*>(tr + (dg + 1) * T16_STRIDE);
                 if (VAR != 1) __builtin_amdgcn_sched_barrier(0);    // LDS requests first (see k_mpnn_edge7)
-                if (s + 1 < 4 && !(g & 1)) {
-                    const int p = t >> 1;
-                    const u32x2 w = Split<GEMM_FP16X3>::pair(in[s + 1][2 * p], in[s + 1][2 * p + 1]);
-                    xs[(s + 1) & 1][0][p] = w[0];
-                    xs[(s + 1) & 1][1][p] = w[1];
+                if (s + 1 < 4) {
+                    const u32x2 w = Split<GEMM_FP16X3>::pair(in[s + 1][2 * tp], in[s + 1][2 * tp + 1]);
+                    xs[(s + 1) & 1][0][tp] = w[0];
+                    xs[(s + 1) & 1][1][tp] = w[1];
                 }
                 if (s == 0) {   // first k step: the accumulators start from the bias registers / the inline constant 0
-                    out[t] = bias[t];
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    outc[t] = z;
+                    out[t0] = bias[t0], out[t1] = bias[t1];
+                    outc[t0] = z, outc[t1] = z;
                 }
-                outc[t] = mfma16(wr[g & 1][1], xs[s & 1][0], outc[t]);
-                out[t] = mfma16(wr[g & 1][0], xs[s & 1][0], out[t]);
-                outc[t] = mfma16(wr[g & 1][0], xs[s & 1][1], outc[t]);
-                if (!(g & 1)) {                   // transposed read of one edge of the previous tile, Swish, running sum
+                const int bsel = dg & 1;
+                outc[t0] = mfma16(wr[bsel][0][1], xs[s & 1][0], outc[t0]);
+                outc[t1] = mfma16(wr[bsel][1][1], xs[s & 1][0], outc[t1]);
+                out[t0] = mfma16(wr[bsel][0][0], xs[s & 1][0], out[t0]);
+                out[t1] = mfma16(wr[bsel][1][0], xs[s & 1][0], out[t1]);
+                outc[t0] = mfma16(wr[bsel][0][0], xs[s & 1][1], outc[t0]);
+                outc[t1] = mfma16(wr[bsel][1][0], xs[s & 1][1], outc[t1]);
+                {                                 // transposed read of one edge of the previous tile, Swish, running sum
                     acc[0] += sw(cur[0]);
                     acc[1] += sw(cur[1]);
-                    if (pmd.ends & (1u << (g / 2))) {
-                        emit_run(acc, pmd, g / 2, e_lo, e_hi, range, deg_scale, agg, partials, lane);
+                    if (pmd.ends & (1u << dg)) {
+                        emit_run(acc, pmd, dg, e_lo, e_hi, range, deg_scale, agg, partials, lane);
                         acc[0] = 0.f;
                         acc[1] = 0.f;
                     }
                 }
-                // staged rows -> Swish(A + Bm), two values per group, pinned to their group (see k_mpnn_edge7)
-                if ((g & 7) >= 4) {
-                    const int sc = ((g >> 3) + 3) & 3, idx = g & 3, set = sc & 1;   // groups 4-7: k step 3, 12-15: 0, 20-23: 1, 28-31: 2
+                // staged rows -> Swish(A + Bm), four values per double group, pinned to it (see k_mpnn_edge7)
+                if ((dg & 3) >= 2) {
+                    const int sc = ((dg >> 2) + 3) & 3, idx = dg & 1, set = sc & 1;   // dg 2-3: k step 3, 6-7: 0, 10-11: 1, 14-15: 2
 #pragma unroll
-                    for (int c = 2 * idx; c < 2 * idx + 2; ++c) {
-                        float v = sw(la[set][c >> 2][c & 3] + lb[set][c >> 2][c & 3]);
+                    for (int c = 0; c < 4; ++c) {
+                        float v = sw(la[set][idx][c] + lb[set][idx][c]);
                         asm volatile("" : "+v"(v));
-                        in[sc][c] = v;
+                        in[sc][4 * idx + c] = v;
                     }
                 }
-                if ((g & 7) == 0) {
+                if ((dg & 3) == 0) {
                     const int set = s & 1;
 #pragma unroll
                     for (int h2 = 0; h2 < 2; ++h2) {
