@@ -194,31 +194,46 @@ __global__ void __launch_bounds__(NW * 64, (NW == 12 ? 3 : 2)) k_mpnn_edge2(cons
 // (PyG InstanceNorm defaults; models/mpnn.py:63,70).  Graphs are contiguous row blocks of
 // `rows_per_graph` rows.  Deterministic: chunk partials are combined in a fixed order.
 #define NORM_CHUNK 64
+#define NORM_SUB 4                                                  // 64-row chunks per partial
 // One pass over x for the InstanceNorm statistics: a thread holds its column of a 64-row chunk in registers (64
 // independent loads in flight) and emits the chunk's column sum and its sum of squares CENTRED ON THE CHUNK'S OWN MEAN;
 // k_colstat_final merges the chunks with the pairwise-variance identity  M2 = sum_c [ M2_c + n_c (mean_c - mean)^2 ]
 // - as free of cancellation as the two-pass algorithm, at half its HBM traffic and three launches instead of five.
 __global__ void __launch_bounds__(128) k_colstat_partial(const float* __restrict__ x, int rows_per_graph, int H,
                                                          float* __restrict__ part_sum, float* __restrict__ part_m2) {
-    const int g = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
-    const int r0 = chunk * NORM_CHUNK, cnt = min(rows_per_graph - r0, NORM_CHUNK);
+    // one workgroup = NORM_SUB consecutive 64-row chunks, merged on the fly with the same pairwise identity: four times
+    // fewer partials for k_colstat_final (which runs on n_graphs x H/32 workgroups only)
+    const int g = blockIdx.y, sup = blockIdx.x, nsup = gridDim.x;
     for (int c = threadIdx.x; c < H; c += blockDim.x) {
-        const float* col = x + ((size_t)g * rows_per_graph + r0) * H + c;
-        float v[NORM_CHUNK];
+        float n_a = 0.f, s_a = 0.f, m2_a = 0.f;
+        for (int sub = 0; sub < NORM_SUB; ++sub) {
+            const int r0 = (sup * NORM_SUB + sub) * NORM_CHUNK, cnt = min(rows_per_graph - r0, NORM_CHUNK);
+            if (cnt <= 0) break;
+            const float* col = x + ((size_t)g * rows_per_graph + r0) * H + c;
+            float v[NORM_CHUNK];
 #pragma unroll
-        for (int r = 0; r < NORM_CHUNK; ++r) v[r] = r < cnt ? col[(size_t)r * H] : 0.f;
-        float s = 0.f;
+            for (int r = 0; r < NORM_CHUNK; ++r) v[r] = r < cnt ? col[(size_t)r * H] : 0.f;
+            float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < NORM_CHUNK; ++r) s += v[r];
-        const float m = s / (float)cnt;
-        float m2 = 0.f;
+            for (int r = 0; r < NORM_CHUNK; ++r) s += v[r];
+            const float n_b = (float)cnt, m = s / n_b;
+            float m2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < NORM_CHUNK; ++r) {
-            const float d = r < cnt ? v[r] - m : 0.f;
-            m2 += d * d;
+            for (int r = 0; r < NORM_CHUNK; ++r) {
+                const float d = r < cnt ? v[r] - m : 0.f;
+                m2 += d * d;
+            }
+            if (sub == 0) {
+                n_a = n_b, s_a = s, m2_a = m2;
+            } else {
+                const float delta = m - s_a / n_a, n = n_a + n_b;
+                m2_a += m2 + delta * delta * (n_a * n_b / n);
+                s_a += s;
+                n_a = n;
+            }
         }
-        part_sum[((size_t)g * nchunks + chunk) * H + c] = s;
-        part_m2[((size_t)g * nchunks + chunk) * H + c] = m2;
+        part_sum[((size_t)g * nsup + sup) * H + c] = s_a;
+        part_m2[((size_t)g * nsup + sup) * H + c] = m2_a;
     }
 }
 // One workgroup per (graph, 32-channel window): 32 groups of 32 lanes each sum a strided subset of the chunk
@@ -248,7 +263,7 @@ __global__ void __launch_bounds__(1024) k_colstat_final(const float* __restrict_
     acc = 0.f;
     if (c < H)
         for (int k = grp; k < nchunks; k += 32) {
-            const float nc = (float)min(NORM_CHUNK, rows_per_graph - k * NORM_CHUNK);
+            const float nc = (float)min(NORM_CHUNK * NORM_SUB, rows_per_graph - k * NORM_CHUNK * NORM_SUB);
             const float d = part_sum[((size_t)g * nchunks + k) * H + c] / nc - m;
             acc += part_m2[((size_t)g * nchunks + k) * H + c] + nc * d * d;
         }
@@ -367,8 +382,9 @@ extern "C" int magnet_instance_norm_f32(const float* x, int n_graphs, int rows_p
     float* var = mean + (size_t)n_graphs * H;
     hipStream_t s = (hipStream_t)stream;
     float* part_m2 = var + (size_t)n_graphs * H;
-    hipLaunchKernelGGL(k_colstat_partial, dim3(nchunks, n_graphs), dim3(128), 0, s, x, rows_per_graph, H, part, part_m2);
-    hipLaunchKernelGGL(k_colstat_final, dim3(n_graphs, (H + 31) / 32), dim3(1024), 0, s, part, part_m2, nchunks,
+    const int nsup = (nchunks + NORM_SUB - 1) / NORM_SUB;     // the workspace keeps its documented per-64-row layout; fewer slots are used
+    hipLaunchKernelGGL(k_colstat_partial, dim3(nsup, n_graphs), dim3(128), 0, s, x, rows_per_graph, H, part, part_m2);
+    hipLaunchKernelGGL(k_colstat_final, dim3(n_graphs, (H + 31) / 32), dim3(1024), 0, s, part, part_m2, nsup,
                        rows_per_graph, H, mean, var);
     const long total = (long)n_graphs * rows_per_graph * H;
     hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, x, mean, var,
