@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 12 ? 3 : 2)) k_mpnn_edge2(cons
 }
 
 // ---------------------------------------------------------------------------- per-graph InstanceNorm
-// y = (x - mean_g) / sqrt(var_g + eps), biased variance per graph and channel, two-pass
+// y = (x - mean_g) / sqrt(var_g + eps), biased variance per graph and channel, one pass over x
 // (PyG InstanceNorm defaults; models/mpnn.py:63,70).  Graphs are contiguous row blocks of
 // `rows_per_graph` rows.  Deterministic: chunk partials are combined in a fixed order.
 #define NORM_CHUNK 64
