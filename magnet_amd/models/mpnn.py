@@ -188,7 +188,7 @@ class MPNN(LightningModule):
             l2e = tape is None and hasattr(lyr, "pre_a_l2e")
             ops.mlp(N, pre_in, [lyr.pre_a_l2e, lyr.pre_b_l2e] if l2e else [lyr.pre_a, lyr.pre_b], nl=1, ht=4, ot=4,
                     act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2, groups_in_block=True, y_group_stride=N * H)
-            if tape is None and hasattr(lyr, "msg2_t16"):
+            if hasattr(lyr, "msg2_t16"):          # training forward too (plain halves: l2e is False with a tape)
                 ops.mpnn_edge16(A, Bm, csr, lyr.msg2_t16[0], lyr.msg2_t16[1], agg, partials, l2e=l2e)
             else:
                 ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials, l2e=l2e)
