@@ -437,7 +437,7 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f3
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <bool L2E, int VAR = 0>
+template <bool L2E>
 __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A, const float* __restrict__ Bm,
                                                      const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
                                                      const int32_t* __restrict__ rowptr, int E,
@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
                 }
                 const f32x2 cur = rv;             // edge dg of the previous tile; the next row is requested now
                 if (dg + 1 < 16) rv = *reinterpret_cast<const f32x2*>(tr + (dg + 1) * T16_STRIDE);
-                if (VAR != 1) __builtin_amdgcn_sched_barrier(0);    // LDS requests first (see k_mpnn_edge7)
+                __builtin_amdgcn_sched_barrier(0);    // LDS requests first (see k_mpnn_edge7)
                 if (s + 1 < 4) {
                     const u32x2 w = Split<GEMM_FP16X3>::pair(in[s + 1][2 * tp], in[s + 1][2 * tp + 1]);
                     xs[(s + 1) & 1][0][tp] = w[0];
@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
                         lb[set][h2] = *reinterpret_cast<const f32x4*>(pbn + 32 * s + 4 * h2);
                     }
                 }
-                if (VAR != 1) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // this tile's raw GEMM output -> the wave's LDS tile (row = edge), consumed during the next iteration
@@ -699,7 +699,6 @@ extern "C" int magnet_mpnn_edge_bf16_l2e_f32(const float* A_l2e, const float* Bm
     return launch_edge6<GEMM_BF16, true>(A_l2e, Bm_l2e, src, tgt, rowptr, n_edges, n_rows, w2_bf16, b2, agg, partials, stream);
 }
 
-extern int g_edge6_ablation;
 // 16-edge tiles, two waves per SIMD (k_mpnn_edge16).  w2_t16: fp16 planes of W2 in the 16x16x32 fragment order
 // [4 k steps][8 output tiles][2 planes][64 lanes][8 fp16] (magnet_amd/packing.py:pack_edge16_fp16x2).
 extern "C" int magnet_mpnn_edge_fp16x3_t16_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
@@ -720,8 +719,7 @@ extern "C" int magnet_mpnn_edge_fp16x3_t16_f32(const float* A, const float* Bm, 
     const dim3 g(min((tiles + 7) / 8, ncu)), b(512);
     const u32x4* ws = reinterpret_cast<const u32x4*>(w2_t16);
     hipStream_t s = (hipStream_t)stream;
-    if (a_bm_log2e_scaled && g_edge6_ablation == 21) hipLaunchKernelGGL((k_mpnn_edge16<true, 1>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
-    else if (a_bm_log2e_scaled) hipLaunchKernelGGL(k_mpnn_edge16<true>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+    if (a_bm_log2e_scaled) hipLaunchKernelGGL(k_mpnn_edge16<true>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
     else hipLaunchKernelGGL(k_mpnn_edge16<false>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
     const int nranges = (int)g.x * 8, tpw = (tiles + nranges - 1) / nranges;      // as computed inside the kernel
     const int fb = max((n_rows + 255) / 256, (nranges + 3) / 4);

@@ -62,11 +62,6 @@ for l2e in (False, True):
     ms = timeit(lambda: ops.mpnn_edge16(Ax, Bx, csr, w16[0], w16[1], agg, partials, l2e=l2e))
     print(f"edge kernel, 16-edge tiles, 2 waves/SIMD, l2e={l2e}: {ms:.3f} ms  {2*E*H*H/ms/1e9:.1f} TFLOP/s-equivalent (incl fixup)  "
           f"rel-diff vs first {float((agg - ref).norm() / ref.norm()):.2e} nan={int(torch.isnan(agg).sum())}")
-for knob in (21, 0, 21, 0):
-    _lib.lib().magnet_debug_set_variant(1, knob)
-    ms = timeit(lambda: ops.mpnn_edge16(A2, B2, csr, w16[0], w16[1], agg, partials, l2e=True))
-    print(f"edge16 l2e knob {knob}: {ms:.3f} ms  rel-diff {float((agg - ref).norm() / ref.norm()):.2e}")
-_lib.lib().magnet_debug_set_variant(1, 0)
 h = torch.randn(N, H, device="cuda"); node_in = torch.randn(N, 32, device="cuda"); gbuf = torch.empty_like(h)
 T = ops.Term
 ms = timeit(lambda: ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, 32)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4, act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=gbuf))
