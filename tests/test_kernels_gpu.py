@@ -162,6 +162,31 @@ def test_mlp_gather_difference_and_segmean_epilogue(mode):
     assert rel_l2(agg, want) < 2e-6
 
 
+@pytest.mark.parametrize("mode", ["fp16x3", "bf16x6", "fp32"])
+def test_mlp_column_groups_in_block_equal_separate_launches(mode):
+    """groups_in_block / y_group_stride of magnet_mlp_args_t: two Linears sharing their input rows as the column groups of
+    one launch (what MPNN does for the per-node halves of message_net_1) write exactly what two launches write - rows that
+    are not a multiple of the tile, outputs a full buffer apart."""
+    from magnet_amd import ops
+    from magnet_amd.packing import pack
+    torch.manual_seed(4)
+    n, k = 1000, 160
+    x = torch.randn(n, k, device="cuda")
+    la, lb = torch.nn.Linear(k, 128).cuda(), torch.nn.Linear(k, 128, bias=False).cuda()
+    pa, pb = pack(la.weight, la.bias, mode), pack(lb.weight, None, mode)
+    kts = ops.ktiles(ops.Term(x, k))
+    want = torch.empty(2, n, 128, device="cuda")
+    ops.mlp(n, kts, [pa], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=want[0])
+    ops.mlp(n, kts, [pb], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=want[1])
+    got = torch.full((2, n, 128), float("nan"), device="cuda")
+    ops.mlp(n, kts, [pa, pb], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=got, ldy=128, colgroups=2, groups_in_block=True,
+            y_group_stride=n * 128)
+    assert torch.equal(got, want)
+    with torch.no_grad():
+        ref = torch.stack([la.double()(x.double()), lb.double()(x.double())])
+    assert rel_l2(got, ref) < 1e-6
+
+
 def test_mpnn_edge_kernels_agree_on_ragged_graph():
     """fp32-MFMA and bf16-split edge kernels vs a host evaluation, on a graph with empty rows, rows longer
     than several tiles and an edge count that is not a multiple of 32."""
