@@ -220,7 +220,9 @@ __global__ void k_fill_tgt(const int32_t* __restrict__ tgt, int E, const int32_t
     const int t = tgt[e];
     eid_unsorted[rowptr[t] + atomicAdd(&cursor[t], 1)] = e;
 }
-// one wave per row: rank-sort the row's edge ids ascending, then emit (perm, src, tgt) in CSR order
+// one wave per row: rank-sort the row's edge ids ascending, then emit (perm, src, tgt) in CSR order.  The rank sort is
+// O(d^2) per row: rows longer than SORT_BIG_ROW are left to k_sort_big_rows.
+#define SORT_BIG_ROW 1024
 __global__ void __launch_bounds__(256) k_sort_rows(const int32_t* __restrict__ rowptr, int N,
                                                    const int32_t* __restrict__ eid_unsorted,
                                                    const int32_t* __restrict__ src_in, int32_t* __restrict__ perm,
@@ -229,6 +231,7 @@ __global__ void __launch_bounds__(256) k_sort_rows(const int32_t* __restrict__ r
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= N) return;
     const int s = rowptr[r], d = rowptr[r + 1] - s;
+    if (d > SORT_BIG_ROW) return;
     for (int i = lane; i < d; i += 64) {
         const int v = eid_unsorted[s + i];
         int rank = 0;
@@ -236,6 +239,69 @@ __global__ void __launch_bounds__(256) k_sort_rows(const int32_t* __restrict__ r
         perm[s + rank] = v;
         src_out[s + rank] = src_in[v];
         tgt_out[s + rank] = r;
+    }
+}
+// Long rows (the inverse CSR of a gather index can have rows of 10^4..10^5 entries: every query of an INR decoder that
+// reads one coarse node; the rank sort then ran for 16 ms on one wave): one workgroup per row, least-significant-bit-first
+// binary radix sort of the edge ids - per bit a stable block-wide partition (count the zeros, then ordered 256-element
+// chunks ranked with ballots), ping-ponging between the row's segments of eid_unsorted and perm.  O(d log E).
+__global__ void __launch_bounds__(256) k_sort_big_rows(const int32_t* __restrict__ rowptr, int N, int nbits,
+                                                       int32_t* __restrict__ eid_unsorted,
+                                                       const int32_t* __restrict__ src_in, int32_t* __restrict__ perm,
+                                                       int32_t* __restrict__ src_out, int32_t* __restrict__ tgt_out) {
+    __shared__ int wz[4];
+    __shared__ int ztotal;
+    const int r = blockIdx.x;
+    const int s = rowptr[r], d = rowptr[r + 1] - s;
+    if (d <= SORT_BIG_ROW) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t* a = eid_unsorted + s;
+    int32_t* b = perm + s;
+    for (int bit = 0; bit < nbits; ++bit) {
+        int z = 0;
+        for (int i = tid; i < d; i += 256) z += !((a[i] >> bit) & 1);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off);
+        if (lane == 0) wz[wave] = z;
+        __syncthreads();
+        if (tid == 0) ztotal = wz[0] + wz[1] + wz[2] + wz[3];
+        __syncthreads();
+        const int Z = ztotal;
+        int zrun = 0, orun = 0;
+        for (int c0 = 0; c0 < d; c0 += 256) {
+            const int i = c0 + tid, nvalid = min(256, d - c0);
+            const bool valid = i < d;
+            const int v = valid ? a[i] : 0;
+            const bool isz = valid && !((v >> bit) & 1);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(isz);
+            const int zpre_w = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            __syncthreads();                                  // wz of the previous chunk has been read by everybody
+            if (lane == 0) wz[wave] = __builtin_popcountll(m);
+            __syncthreads();
+            int zbefore = zpre_w, zchunk = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                zbefore += w < wave ? wz[w] : 0;
+                zchunk += wz[w];
+            }
+            if (valid) {
+                if (isz) b[zrun + zbefore] = v;
+                else b[Z + orun + (tid - zbefore)] = v;      // valid lanes are 0 .. nvalid-1: ones before me = tid - zeros before me
+            }
+            zrun += zchunk;
+            orun += nvalid - zchunk;
+        }
+        __syncthreads();
+        int32_t* t = a;
+        a = b;
+        b = t;
+    }
+    // `a` holds the sorted ids (either buffer); emit in place / across
+    for (int i = tid; i < d; i += 256) {
+        const int v = a[i];                                   // in place when `a` is the row's perm segment: one thread per index
+        perm[s + i] = v;
+        src_out[s + i] = src_in[v];
+        tgt_out[s + i] = r;
     }
 }
 
@@ -380,6 +446,10 @@ extern "C" int magnet_csr_by_target(const int32_t* src, const int32_t* tgt, int 
         hipLaunchKernelGGL(k_fill_tgt, dim3(nb(n_edges, 256)), dim3(256), 0, S_, tgt, n_edges, rowptr, cursor,
                            eid_scratch);
         hipLaunchKernelGGL(k_sort_rows, dim3(nb(n_nodes, 4)), dim3(256), 0, S_, rowptr, n_nodes, eid_scratch, src, perm,
+                           src_out, tgt_out);
+        int nbits = 1;
+        while (nbits < 31 && (1 << nbits) < n_edges) ++nbits;
+        hipLaunchKernelGGL(k_sort_big_rows, dim3(n_nodes), dim3(256), 0, S_, rowptr, n_nodes, nbits, eid_scratch, src, perm,
                            src_out, tgt_out);
     }
     LAUNCH_CHECK();

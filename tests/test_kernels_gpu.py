@@ -81,6 +81,25 @@ def test_csr_by_target_is_stable_transpose():
     assert torch.equal(csr.rowptr.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(torch.bincount(tgt.long(), minlength=n), 0)]))
 
 
+def test_csr_by_target_long_rows_take_the_radix_path():
+    """rows beyond 1024 entries (the inverse CSR of an INR gather index has rows of 10^4..10^5) are sorted by the per-row
+    binary radix kernel instead of the O(d^2) rank sort: same stable transpose, including a row that owns half the edges,
+    one exactly at the threshold and an edge count that is not a power of two"""
+    from magnet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n, E = 60, 70001
+    tgt = torch.randint(0, n, (E,), generator=g)
+    tgt[torch.rand(E, generator=g) < 0.5] = 7                      # one row owns ~half of the edges
+    tgt[:1024] = 11                                                # ... and row 11 gets at least the threshold
+    tgt = tgt[torch.randperm(E, generator=g)].int()
+    src = torch.randint(0, n, (E,), generator=g).int()
+    csr = ops.csr_by_target(src.cuda(), tgt.cuda(), n)
+    order = torch.sort(tgt.long(), stable=True).indices
+    assert int(torch.bincount(tgt.long()).max()) > 30000
+    assert torch.equal(csr.perm.cpu().long(), order)
+    assert torch.equal(csr.src.cpu(), src[order]) and torch.equal(csr.tgt.cpu(), tgt[order])
+
+
 def test_knn_matches_restatement():
     from magnet_amd import ops
     from oracle.pyg_semantics import knn
