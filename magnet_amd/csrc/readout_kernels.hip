@@ -95,7 +95,10 @@ extern "C" int magnet_mpnn_readout_f32(const float* h, const float* u, int n, in
                                 (hipStream_t)stream, h, u, n, w1, b1, w2, b2, dt, out);                                    \
         LAUNCH_CHECK();                                                                                                   \
     }
-    READOUT_CASE(16, 6, 10, 10)     // the 2D configuration (models/mpnn_2d.py:140-163, tw = 10); other windows: generic kernel
+    READOUT_CASE(16, 6, 10, 10)     // models/mpnn.py:140-163 / mpnn_2d.py:140-163; tw = 50 (59 x 8 hidden values) stays generic
+    READOUT_CASE(16, 5, 8, 16)
+    READOUT_CASE(15, 4, 10, 20)
+    READOUT_CASE(16, 3, 14, 25)
 #undef READOUT_CASE
     hipLaunchKernelGGL(k_mpnn_readout, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, u, n, tw, w1, b1, k1,
                        s1, w2, b2, k2, use_swish, dt, out);
