@@ -18,8 +18,8 @@ Extra objects on the JSON line:
   roofline      - dominant kernel (k_mpnn_edge7, MFMA bound): algorithmic flops per launch
                   (2*E*128*128, the message_net_2 GEMM; message_net_1 is factorised per node, see
                   DESIGN.md) / mean launch time measured with HIP events on the launch stream.  The
-                  kernel evaluates every fp32 product through an exact split into 16-bit pieces on the
-                  matrix cores (default fp16x3: 3 fp16 MFMA products per fp32 product; bf16x6: 6), so its
+                  kernel evaluates every fp32 product through a split into 16-bit pieces on the matrix cores
+                  (default fp16x3: 2 pieces, 3 fp16 MFMA products, ~2^-22 relative; bf16x6: 3 pieces, 6 products), so its
                   ceiling is the dense 16-bit MFMA peak / 3 = 833 TFLOP/s of fp32-equivalent work (`peak`);
                   `executed_mfma_tflops` / 2500 is the same fraction.
   roofline_scatter - the standalone CSR segment-mean ("scatter mean") kernel on the same graph's
@@ -40,6 +40,7 @@ Extra objects on the JSON line:
 from __future__ import annotations
 
 import argparse
+import copy
 import json
 import os
 import sys
@@ -109,8 +110,9 @@ def synthetic_magnet_batch(name, B, Wq, seed, device):
     return {k: v.to(device) for k, v in batch.items()}, n_lr + Wq * Wq
 
 
-DTYPE_NOTE = {"fp16x3": "f32 (GEMMs: exact 2-piece fp16 split on the matrix cores, fp32 accumulate)",
-              "bf16x6": "f32 (GEMMs: exact 3-piece bf16 split on the matrix cores, fp32 accumulate)",
+DTYPE_NOTE = {"fp16x3": "f32-class (GEMM operands as 2 fp16 pieces, 3 MFMA products, ~2^-22 relative, fp32 accumulate; |values| < 65504, "
+                        "guarded at run time)",
+              "bf16x6": "f32-class (GEMM operands as 3 bf16 pieces, 6 MFMA products, ~2^-24 relative, fp32 accumulate; full fp32 range)",
               "fp32": "f32 (fp32 MFMA)",
               "bf16": "bf16 - REDUCED precision (inputs and weights rounded to one bf16 piece, fp32 accumulate): not the headline, "
                       "see deviation_vs_f32_path"}
@@ -134,8 +136,20 @@ def measured_traffic(kernel):
     return (k["traffic"], os.path.relpath(files[-1], ROOT)) if k else (None, None)
 
 
-def cpu_baseline(W=128):
-    """oracle rollout of ONE trajectory on a W x W mesh on the host cores (forward time only)."""
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(W=128, timed=3):
+    """the oracle's free-running rollout of ONE trajectory on a W x W mesh on the host cores, fp32,
+    no_grad, 1 warm-up rollout + ``timed`` timed rollouts, median; the radius-graph build is timed separately (the oracle
+    builds it by brute force) and excluded from the rollout time, as the reference's own CPU numbers in BASELINE.md are."""
     from oracle import models as O
     torch.manual_seed(0)
     hp = types.SimpleNamespace(**HP)
@@ -145,28 +159,40 @@ def cpu_baseline(W=128):
     x, t = batch["x"], batch["t"]
     tw = hp.time_window
     t0 = time.perf_counter()
-    graph = model._build_graph(u[:, :tw], t, x, [tw - 1])
+    graph0 = model._build_graph(u[:, :tw], t, x, [tw - 1])
     t_graph = time.perf_counter() - t0
-    t_fwd, n_calls = 0.0, (NT - tw) // tw
-    with torch.no_grad():
-        for i in range(n_calls):
-            t0 = time.perf_counter()
-            y = model(graph, x[0, -1], t[0, -1], t[0][1] - t[0][0])
-            t_fwd += time.perf_counter() - t0
-            graph.x = y                                                   # same mesh: reuse the edge list
-            graph.pos = torch.cat([torch.full((W * W, 1), float(t[0, (i + 2) * tw - 1])), graph.pos[:, 1:]], 1)
-    return {"value": W * W * tw * n_calls / t_fwd, "unit": "mesh-node-updates/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"oracle mpnn_2d, {W}x{W} mesh, 1 trajectory, 1 free-running rollout = {n_calls} forward calls "
-                      f"({t_fwd:.1f} s; radius-graph build {t_graph:.1f} s excluded), fp32, torch {torch.__version__} CPU"}
+    n_calls = (NT - tw) // tw
+
+    def rollout():
+        g = copy.copy(graph0)                                             # same edge list, fresh x / pos per rollout
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for i in range(n_calls):
+                y = model(g, x[0, -1], t[0, -1], t[0][1] - t[0][0])
+                g.x = y                                                   # same mesh: reuse the edge list
+                g.pos = torch.cat([torch.full((W * W, 1), float(t[0, (i + 2) * tw - 1])), g.pos[:, 1:]], 1)
+        return time.perf_counter() - t0
+
+    times = []
+    for k in range(1 + timed):
+        dt = rollout()
+        if k > 0:
+            times.append(dt)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": W * W * tw * n_calls / med, "unit": "mesh-node-updates/s", "cores": torch.get_num_threads(),
+            "cpu_model": cpu_model_string(), "kind": "port", "rollouts_s": [round(v, 2) for v in times], "graph_build_s": round(t_graph, 2),
+            "sample": f"oracle mpnn_2d, {W}x{W} mesh, 1 trajectory, 1 warm-up + {timed} timed free-running rollouts of {n_calls} forward "
+                      f"calls each, median {med:.1f} s (radius-graph build {t_graph:.1f} s timed separately, excluded), fp32, no_grad, "
+                      f"torch {torch.__version__} CPU, {torch.get_num_threads()} threads"}
 
 
-def bench_magnet(args, dev, rank, world, dist, max_over_ranks):
+def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_over_ranks):
     """C4b (magnet_cnn_2d, 64^2 LR grid -> 256^2 queries) / C5 (magnet_gnn, 256 LR nodes -> 256^2 queries): free-running
-    validation_step rollout (4 forwards = 40 predicted steps), nodes = LR nodes + queries; same JSON contract."""
+    validation_step rollout (4 forwards = 40 predicted steps), nodes = LR nodes + queries; same JSON contract.
+    Returns the JSON object on rank 0 (None elsewhere); every rank takes part in the barriers."""
     from magnet_amd import ops
     from magnet_amd.models.factory import FACTORY
-    name, B, K, Wm, Wq = args.workload, args.traj, args.steps, args.warmup, args.mesh
     torch.manual_seed(0)
     hp = MAGNET_HP[name]
     model = FACTORY[name](types.SimpleNamespace(**hp)).to(dev).eval()
@@ -225,10 +251,12 @@ def bench_magnet(args, dev, rank, world, dist, max_over_ranks):
                 "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None, "launch_ms": round(ms, 4), "launches_timed": len(sel), "flops_per_launch": flops,
                 "gemm_mode": mode, "edges": Emax}
+        if Wq == 256 and B == 1 and mode in SPLIT_PRODUCTS:      # the recorded PMC passes are of this exact workload
+            roof["traffic"], roof["traffic_source"] = measured_traffic(f"{name}:edge_mlp")
     # ---- training step (autograd Functions with HIP backward kernels, one gradient all-reduce, fused Adam) - unfused,
     # correctness-first path; reported beside the rollout, never mixed into `value`
     train = None
-    if args.train_steps > 0:
+    if train_steps > 0:
         from magnet_amd.sharding import allreduce_gradients
         tmodel = FACTORY[name](types.SimpleNamespace(**hp)).to(dev).train()
         opt = tmodel.configure_optimizers()["optimizer"]
@@ -244,30 +272,51 @@ def bench_magnet(args, dev, rank, world, dist, max_over_ranks):
         first = float(train_step().detach())
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.train_steps):
+        for _ in range(train_steps):
             last = train_step()
         barrier()
         t_el = max_over_ranks(time.perf_counter() - t0, dev)
-        train = {"ms_per_step": round(t_el / args.train_steps * 1e3, 3), "steps": args.train_steps, "warmup": 1,
-                 "value": world * B * nodes * pred_steps * args.train_steps / t_el, "unit": "mesh-node-updates/s",
+        train = {"ms_per_step": round(t_el / train_steps * 1e3, 3), "steps": train_steps, "warmup": 1,
+                 "value": world * B * nodes * pred_steps * train_steps / t_el, "unit": "mesh-node-updates/s",
                  "what": "rollout through autograd Functions (HIP forward + backward kernels, unfused) + one gradient all-reduce + fused Adam",
                  "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],
                  "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
         del tmodel, opt
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps({
-            "metric": f"mesh-node-updates/s (nodes x steps x batch), {name} 256^2-query rollout", "value": value,
-            "unit": "mesh-node-updates/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE_NOTE[__import__("magnet_amd.packing", fromlist=["default_gemm"]).default_gemm()], "data": "synthetic",
-            "config": {"workload": f"{name} free-running rollout, {nodes - Wq * Wq} LR nodes + {Wq}x{Wq} queries, nt={NT}, "
-                                   f"time_slice={T} -> {pred_steps} predicted steps, {B} trajectories per GPU",
-                       "trajectories_per_gpu": B, "global_trajectories": B * world,
-                       "parallelism": f"batch-shard x{world}, no data-path collective"},
-            "roofline": roof, "cpu_baseline": None, "training_step": train}))
+    del model, batch
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    return {
+        "metric": f"mesh-node-updates/s (nodes x steps x batch), {name} 256^2-query rollout", "value": value,
+        "unit": "mesh-node-updates/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": DTYPE_NOTE[__import__("magnet_amd.packing", fromlist=["default_gemm"]).default_gemm()], "data": "synthetic",
+        "config": {"workload": f"{name} free-running rollout, {nodes - Wq * Wq} LR nodes + {Wq}x{Wq} queries, nt={NT}, "
+                               f"time_slice={T} -> {pred_steps} predicted steps, {B} trajectories per GPU",
+                   "trajectories_per_gpu": B, "global_trajectories": B * world,
+                   "parallelism": f"batch-shard x{world}, no data-path collective"},
+        "roofline": roof, "cpu_baseline": None, "training_step": train}
+
+
+def free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """``python bench.py --gpus N`` without a torch.distributed.run environment: start the N ranks as FRESH child processes
+    (one per GPU, what the reference's `trainer.gpus=N trainer.strategy=ddp` does, README.md:124-125) before this process
+    has made any GPU call - a process that has initialised HIP must never exec or fork GPU work - and forward the exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    if os.environ.get("MAGNET_BENCH_LAUNCH_DRY") == "1":       # test hook: show the command instead of running it
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -283,8 +332,13 @@ def main():
                     help="arithmetic of the Linears; default fp16x3 = fp32-class.  'bf16' is the REDUCED-precision mode BASELINE.json "
                          "config 2 asks for: reported with its measured deviation from the fp32-class result, never as the headline")
     ap.add_argument("--workload", default="mpnn_2d", choices=["mpnn_2d", "magnet_cnn_2d", "magnet_gnn"],
-                    help="mpnn_2d = the headline metric case; the two MAgNet 256^2 cases of SURVEY.md 8(d) (C4b, C5) on request")
+                    help="mpnn_2d = the headline metric case (its line also carries the two MAgNet 256^2 cases of SURVEY.md 8(d) as "
+                         "the objects `c4b` / `c5`); magnet_cnn_2d / magnet_gnn make one of those the headline of the line")
+    ap.add_argument("--no-extra-cases", action="store_true", help="skip the c4b / c5 / c1 objects of the default line")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:       # N ranks as fresh children, before any GPU call here
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch.distributed as dist
     from magnet_amd import ops
@@ -292,6 +346,9 @@ def main():
     from magnet_amd.sharding import env_world, max_over_ranks
 
     rank, local_rank, world = env_world()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); start it as "
+                         f"`python bench.py --gpus N` or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     # one process per GPU over RCCL ("nccl" on ROCm).  MAGNET_DIST_BACKEND=gloo is a test hook: it lets several ranks
     # share one GPU (RCCL refuses that) so that the N > 1 control flow can be exercised on a 1-GPU box.
     backend = os.environ.get("MAGNET_DIST_BACKEND", "nccl")
@@ -307,14 +364,20 @@ def main():
     if args.gemm:
         os.environ["MAGNET_GEMM"] = args.gemm                  # read by packing.default_gemm() when the models are built
     if args.workload != "mpnn_2d":
-        return bench_magnet(args, dev, rank, world, dist, max_over_ranks)
+        line = bench_magnet(args.workload, args.traj, K, Wm, W, args.train_steps, dev, rank, world, dist, max_over_ranks)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(line))
+        return
 
     torch.manual_seed(0)
     model = FACTORY["mpnn_2d"](types.SimpleNamespace(**HP)).to(dev).eval()
     batch = synthetic_batch(W, B, 1000 + rank, dev)          # every rank owns B different trajectories
 
     def step():
-        model._topo_key = None                                # rebuild radius graph + CSR every step
+        model.drop_topology_cache()                              # rebuild radius graph + CSR every step
         return model.validation_step(batch, 0)
 
     def barrier():
@@ -411,7 +474,7 @@ def main():
                 "algorithmic_hbm_bytes": 3 * N * H * 4 + 2 * E * 4 + 4 * (N + 1),
                 "executed_mfma_tflops": round(ach * nprod, 1), "mfma_16bit_dense_peak": MFMA_BF16_PEAK_TFLOPS,
                 "fp32_mfma_peak_for_reference": MFMA_F32_PEAK_TFLOPS,
-                "note": "fp32 GEMM evaluated through an exact split into 16-bit pieces on the matrix cores "
+                "note": "fp32-class GEMM: operands split into 16-bit pieces on the matrix cores "
                         f"({nprod} MFMA products per fp32 product, fp32 accumulate); peak = 2500 / {nprod}"}
         if W == 256 and B == 4 and mode in SPLIT_PRODUCTS:     # the recorded PMC passes are of this exact workload
             roof["traffic"], roof["traffic_source"] = measured_traffic(kname)
@@ -449,6 +512,14 @@ def main():
                      "increment_rel_l2": float(((a - last) - (b - last)).norm() / (b - last).norm())}
         del ref_model
 
+    # ---- the other two 256^2 cases of SURVEY.md 8(d) (C4b magnet_cnn_2d, C5 magnet_gnn; 1 trajectory per GPU), each a
+    # complete object of the same contract (value, ms_per_step, roofline, training_step) beside the headline
+    extras = {}
+    if not args.no_extra_cases and W == 256:
+        for key, name in (("c4b", "magnet_cnn_2d"), ("c5", "magnet_gnn")):
+            extras[key] = bench_magnet(name, 1, max(1, min(K, 10)), max(1, min(Wm, 2)), 256, min(args.train_steps, 2), dev, rank, world,
+                                       dist, max_over_ranks)
+
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -461,7 +532,7 @@ def main():
                                        f"trajectory), nt={NT}, time_window={tw} -> {pred_steps} predicted steps, {B} trajectories per GPU, "
                                        "radius graph + CSR rebuilt every step",
                            "trajectories_per_gpu": B, "global_trajectories": B * world, "parallelism": f"batch-shard x{world}, no data-path collective"},
-                "roofline": roof, "roofline_scatter": roof_sc, "cpu_baseline": cpu, "training_step": train}
+                "roofline": roof, "roofline_scatter": roof_sc, "cpu_baseline": cpu, "training_step": train, **extras}
         print(json.dumps(line))
 
 

@@ -107,6 +107,14 @@ int magnet_segmean_fixup_f32(const int32_t* rowptr, int n_rows, int d, const flo
  * (models/mpnn.py:46, models/magnet_gnn.py:54) for CSR-sorted messages. */
 int magnet_segment_mean_f32(const float* msg, const int32_t* rowptr, int n_rows, int h, float* out, void* stream);
 
+/* Range guard of the fp16x3 GEMM mode (no reference counterpart: the reference computes in fp32 throughout, configs/
+ * trainer/default.yaml:5).  *status |= range_bit if some limit <= |x[i]| < inf, |= nonfinite_bit if some x[i] is inf or NaN
+ * (the latter only while *status does not carry unless_bit: a non-finite prediction fed back as an input is not bad data);
+ * sticky, never cleared by the library.  The models check the arrays entering the GEMM chains against 65504 (the two-piece
+ * fp16 split overflows there) and the predicted window for non-finite values, and raise on the host (magnet_amd/models). */
+int magnet_status_check_f32(const float* x, long n, float limit, int range_bit, int nonfinite_bit, int unless_bit, int* status,
+                            void* stream);
+
 /* ---- MPNN / MPNN_2d (hidden width 128) ---- */
 /* node_in[n] = [u[n,0:tw] | pos[n,1]/L[0..dpos) | pos[n,0]/tmax | 0-pad to kin]; models/mpnn.py:180-191,
  * models/mpnn_2d.py:179 (the x/Lx, x/Ly quirk).  L and tmax are device scalars/vectors. */
@@ -289,9 +297,6 @@ int magnet_mpnn_edge_bwd_f32(const float* A, const float* Bm, const float* dagg,
                              const int32_t* rowptr, int n_nodes, int n_edges, const void* w2_f16, const void* w2t_f16,
                              const float* b2, float* s1, float* dq, float* dp, float* dA, float* partials, void* stream);
 
-/* development knob (kernel variant selection for A/B measurements); not part of the data path */
-int magnet_debug_set_variant(int which, int value);
-int magnet_debug_set_mlp_ablation(int value); /* development: run-time ablation flags of the split-GEMM MLP kernel */
 
 #ifdef __cplusplus
 }

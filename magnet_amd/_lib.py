@@ -12,7 +12,10 @@ import re
 import torch  # noqa: F401  (must come first: the library has to bind to the HIP runtime torch has loaded, not a second copy)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libmagnet_hip.so")
+# MAGNET_DEV_LIB=1 (development scripts only): the library built by `python -m magnet_amd.build --dev`, which additionally
+# exports the run-time variant / ablation knobs of include/magnet_hip_dev.h
+DEV = os.environ.get("MAGNET_DEV_LIB", "0") == "1"
+LIB_PATH = os.path.join(HERE, "csrc", "libmagnet_hip_dev.so" if DEV else "libmagnet_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "magnet_hip.h")
 
 MAX_KT, MAX_LAYERS = 36, 6
@@ -63,6 +66,9 @@ def lib() -> C.CDLL:
         for name in declared_symbols():
             fn = getattr(_lib, name)          # AttributeError if the .so does not export it
             fn.restype = C.c_int
+        if DEV:
+            for name in ("magnet_debug_set_variant", "magnet_debug_set_mlp_ablation"):
+                getattr(_lib, name).restype = C.c_int
     return _lib
 
 

@@ -2,6 +2,9 @@
 
     python -m magnet_amd.build            # rebuild if sources are newer than the library
     python -m magnet_amd.build --force
+    python -m magnet_amd.build --dev      # development library libmagnet_hip_dev.so: earlier kernel generations and run-time
+                                          # ablations selectable through include/magnet_hip_dev.h (MAGNET_DEV_LIB=1 loads it);
+                                          # the product library contains none of that
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the .so travels to the
 GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
@@ -28,45 +31,50 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def needs_build(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.cuh"))
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def _compile(src: str) -> str:
-    obj = os.path.splitext(src)[0] + ".o"
+DEV_LIB = os.path.join(CSRC, "libmagnet_hip_dev.so")
+
+
+def _compile(src: str, dev: bool = False) -> str:
+    obj = os.path.splitext(src)[0] + (".dev.o" if dev else ".o")
     hdr = max(os.path.getmtime(p) for p in glob.glob(os.path.join(CSRC, "*.cuh")))
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr):
         return obj
-    cmd = ["hipcc", *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+    cmd = ["hipcc", *FLAGS, *(["-DMAGNET_DEV_VARIANTS"] if dev else []), *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src,
+           "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
     return obj
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
-        return LIB
+def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
+    lib = DEV_LIB if dev else LIB
+    if not force and not needs_build(lib):
+        return lib
     srcs = sources()
     if force:
         for s in srcs:
-            o = os.path.splitext(s)[0] + ".o"
+            o = os.path.splitext(s)[0] + (".dev.o" if dev else ".o")
             if os.path.exists(o):
                 os.remove(o)
     with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        objs = list(ex.map(_compile, srcs))
-    r = subprocess.run(["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB],
+        objs = list(ex.map(lambda s_: _compile(s_, dev), srcs))
+    r = subprocess.run(["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)
     if verbose:
-        print(f"[magnet_amd.build] built {LIB} from {len(srcs)} sources", file=sys.stderr)
-    return LIB
+        print(f"[magnet_amd.build] built {lib} from {len(srcs)} sources", file=sys.stderr)
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, dev="--dev" in sys.argv)

@@ -100,10 +100,10 @@ __device__ __forceinline__ void fold_tiles(f32x16 (&accM)[NT], f32x16 (&accC)[NT
 }
 
 // development ablation flags (results invalid): 1 = no MFMA/LDS-read work, 2 = no weight DMA after the prologue, 4 = no epilogue,
-// 8 = no workgroup barriers, 16 = no gathered x loads after the first k tile.  Compiled in only with -DMAGNET_MLP_ABLATION:
+// 8 = no workgroup barriers, 16 = no gathered x loads after the first k tile.  Compiled in only with -DMAGNET_DEV_VARIANTS:
 // even as never-taken run-time branches they cost the product kernel 20 % (the conditional loads break hipcc's software
 // pipelining of the gathers).
-#ifdef MAGNET_MLP_ABLATION
+#ifdef MAGNET_DEV_VARIANTS
 __device__ int g_mlp_abl = 0;
 #define MLP_ABL_INIT const int abl = __builtin_amdgcn_readfirstlane(g_mlp_abl);
 #else
@@ -340,10 +340,8 @@ extern "C" int magnet_mlp_fp16x3_f32(const MagnetMlpArgs* args, int nl, int ht, 
     return launch_mlp(pick<GEMM_FP16X3>(nl, ht, ot, act, last_act, ln, epi), args, stream);
 }
 
+#ifdef MAGNET_DEV_VARIANTS
 extern "C" int magnet_debug_set_mlp_ablation(int value) {
-#ifdef MAGNET_MLP_ABLATION
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_abl), &value, sizeof(int));
-#else
-    return value == 0 ? 0 : -2;      // ablations are not compiled into the product library
-#endif
 }
+#endif

@@ -622,7 +622,11 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
     }
 }
 
-int g_edge6_ablation = 0;
+#ifdef MAGNET_DEV_VARIANTS
+int g_edge6_ablation = 0;          // development builds only (see mpnn_kernels.hip): 6 = generation-6 kernel, others = ablations
+#else
+static constexpr int g_edge6_ablation = 0;
+#endif
 
 extern "C" int magnet_segmean_fixup_f32(const int32_t* rowptr, int n_rows, int d, const float* partials, float* agg, void* stream);
 
@@ -646,10 +650,12 @@ static int launch_edge6(const float* A, const float* Bm, const int32_t* src, con
     hipStream_t s = (hipStream_t)stream;
     if constexpr (Split<MODE>::NP <= 2) {
         if (g_edge6_ablation == 0 || g_edge6_ablation == 8) {      // 6 = A/B knob: the generation-6 kernel (DPP scan epilogue)
-            if (g_edge6_ablation == 0)
-                hipLaunchKernelGGL((k_mpnn_edge7<MODE, 0, L2E>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
-            else                                                    // development only (invalid results): gather from 32 fixed rows
+#ifdef MAGNET_DEV_VARIANTS
+            if (g_edge6_ablation == 8)                              // development only (invalid results): gather from 32 fixed rows
                 hipLaunchKernelGGL((k_mpnn_edge7<MODE, 8>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+            else
+#endif
+                hipLaunchKernelGGL((k_mpnn_edge7<MODE, 0, L2E>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
             const int nranges = (int)g.x * 4, tpw = (tiles + nranges - 1) / nranges;      // as computed inside the kernel
             const int fb = max((n_rows + 255) / 256, (nranges + 3) / 4);
             hipLaunchKernelGGL(k_edge_range_fixup, dim3(fb), dim3(256), 0, s, tgt, rowptr, n_rows, n_edges, tpw, 5, nranges,
@@ -658,6 +664,7 @@ static int launch_edge6(const float* A, const float* Bm, const int32_t* src, con
         }
     }
     if (L2E) return -2;           // the scaled-input contract exists for the generation-7 kernel only
+#ifdef MAGNET_DEV_VARIANTS
     switch (g_edge6_ablation) {   // development only: ablations produce invalid results
         case 1: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 1>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
         case 2: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 2>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
@@ -665,6 +672,9 @@ static int launch_edge6(const float* A, const float* Bm, const int32_t* src, con
         case 7: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 7>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
         default: hipLaunchKernelGGL((k_mpnn_edge6<MODE, 0>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
     }
+#else
+    hipLaunchKernelGGL((k_mpnn_edge6<MODE, 0>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+#endif
     const int rc = (int)hipGetLastError();
     return rc ? rc : magnet_segmean_fixup_f32(rowptr, n_rows, 128, partials, agg, stream);
 }

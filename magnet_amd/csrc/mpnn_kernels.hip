@@ -19,6 +19,25 @@ __global__ void k_mpnn_node_input(const float* __restrict__ u, const float* __re
     out[i] = v;
 }
 
+// ---------------------------------------------------------------------------- range / finiteness status
+// The fp16x3 GEMM mode represents every fp32 value with two fp16 pieces, so a value of magnitude >= 65504 silently becomes
+// inf (common.cuh).  The models run this check on the arrays that enter the GEMM chains (node features) and on the arrays
+// that leave a forward (the predicted window): status |= range_bit where limit <= |x| < inf, |= nonfinite_bit where x is
+// inf / NaN - unless the word already carries `unless_bit` (stream order: a free-running rollout feeds a non-finite
+// prediction back as the next input, which must not be mistaken for non-finite data).  Sticky (atomicOr), read by the host
+// once per rollout.
+__global__ void k_status_check(const float* __restrict__ x, long n, float limit, int range_bit, int nonfinite_bit,
+                               int unless_bit, int* __restrict__ status) {
+    if (unless_bit && (__builtin_nontemporal_load(status) & unless_bit)) nonfinite_bit = 0;
+    int flag = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float a = fabsf(x[i]);
+        if (!(a < limit)) flag |= (a <= 3.402823466e+38f) ? range_bit : nonfinite_bit;      // NaN fails both compares
+    }
+    if (__ballot(flag != 0) == 0) return;
+    if (flag) atomicOr(status, flag);
+}
+
 // ---------------------------------------------------------------------------- fused edge kernel
 // For every CSR edge e = (i <- j):  m_e = Swish(W2 * Swish(A[i] + Bm[j]) + b2), then the mean of
 // m_e over each target row.  A / Bm are the per-node halves of message_net_1 (exact algebra:
@@ -296,16 +315,20 @@ __global__ void k_norm_apply(const float* __restrict__ x, const float* __restric
 // ------------------------------------------------------------------------------------ C entry points
 #define LAUNCH_CHECK() return (int)hipGetLastError()
 
+// Development builds (-DMAGNET_DEV_VARIANTS, `python -m magnet_amd.build --dev`) keep the earlier kernel generations and
+// their ablations (which produce INVALID results) selectable at run time for A/B measurements through
+// magnet_debug_set_variant (include/magnet_hip_dev.h).  The product library contains none of it: no knob, no symbol.
+#ifdef MAGNET_DEV_VARIANTS
 extern int g_edge6_ablation;
 static int g_edge_variant = 102;   // persistent v2 kernel, 8 waves / workgroup
-// development knob for A/B measurements: 102 = k_mpnn_edge2<8> (default), 0 = first-generation k_mpnn_edge,
-// 1x/11x = ablations (results invalid)
+// 102 = k_mpnn_edge2<8> (default), 0 = first-generation k_mpnn_edge, 1x/11x = ablations (results invalid)
 extern "C" int magnet_debug_set_variant(int which, int value) {
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (which == 0) g_edge_variant = value;
     if (which == 1) g_edge6_ablation = value;
     return 0;
 }
+#endif
 
 extern "C" int magnet_mpnn_node_input_f32(const float* u, const float* pos, int pos_ld, const float* Lvec,
                                           const float* tmax, int n, int tw, int dpos, int kin, float* out,
@@ -316,6 +339,16 @@ extern "C" int magnet_mpnn_node_input_f32(const float* u, const float* pos, int 
     const long total = (long)n * kin;
     hipLaunchKernelGGL(k_mpnn_node_input, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u,
                        pos, pos_ld, Lvec, tmax, n, tw, dpos, kin, out);
+    LAUNCH_CHECK();
+}
+
+extern "C" int magnet_status_check_f32(const float* x, long n, float limit, int range_bit, int nonfinite_bit, int unless_bit,
+                                       int* status, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
+    if (n <= 0) return 0;
+    const long blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(k_status_check, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, x,
+                       n, limit, range_bit, nonfinite_bit, unless_bit, status);
     LAUNCH_CHECK();
 }
 
@@ -330,6 +363,7 @@ extern "C" int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32
     const int tiles = (n_edges + 31) / 32;
     const dim3 g((tiles + 3) / 4), b(256);
     hipStream_t s = (hipStream_t)stream;
+#ifdef MAGNET_DEV_VARIANTS
     switch (g_edge_variant) {
         case 1: hipLaunchKernelGGL(k_mpnn_edge<1>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
         case 2: hipLaunchKernelGGL(k_mpnn_edge<2>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
@@ -365,6 +399,15 @@ extern "C" int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32
         case 14: hipLaunchKernelGGL((k_mpnn_edge<0, 4>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
         default: hipLaunchKernelGGL(k_mpnn_edge<0>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials); break;
     }
+#else
+    {   // persistent k_mpnn_edge2: 2 workgroups of 8 waves per CU (64 KiB LDS each)
+        (void)g; (void)b;
+        static int ncu = 0;
+        if (!ncu) { hipDeviceProp_t prop; int dev; hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev); ncu = prop.multiProcessorCount; }
+        const int nw = 8;
+        hipLaunchKernelGGL(k_mpnn_edge2<8>, dim3(min((tiles + nw - 1) / nw, 2 * ncu)), dim3(nw * 64), 0, s, A, Bm, src, tgt, rowptr, n_edges, L, agg, partials);
+    }
+#endif
     const int rc = (int)hipGetLastError();
     return rc ? rc : magnet_segmean_fixup_f32(rowptr, n_rows, 128, partials, agg, stream);
 }

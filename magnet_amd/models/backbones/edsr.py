@@ -48,13 +48,16 @@ class EDSR(nn.Module):
             raise NotImplementedError("the convolution kernels are instantiated for n_chan = 64 or 128")
         if (kernel_size ** self.dim) * (n_chan // 32) > 36 or not kernel_size & 1:
             raise NotImplementedError("odd kernel sizes with k^d * n_chan / 32 <= 36 k tiles are supported")
-        self._pack_key, self._pack, self._taps = None, None, {}
+        self._pack_key, self._pack, self._pack_gen, self._taps = None, None, 0, {}
+        self._plan_key, self._plan_val = None, None
 
     # ------------------------------------------------------------------ packed weights / tap tables (cached)
     def packed(self, mode=None):
         mode = mode or default_gemm()
         params = list(self.parameters())
-        key = (params[0].device, sum(p._version for p in params), mode)
+        # _pack_gen: bumped by the owning model when an optimizer wrote the parameters behind torch's version counters
+        # (FusedAdam); it is part of the key so that the launch plans built on the old packs (_plan) go stale with them
+        key = (params[0].device, sum(p._version for p in params), mode, self._pack_gen)
         if self._pack_key != key:
             cin = pad_to(self.in_chan)
 
@@ -77,12 +80,17 @@ class EDSR(nn.Module):
             self._taps[key] = ops.conv_tap_index(B, H, W, self.kernel_size, self.dim, device)
         return self._taps[key]
 
+    def weights_changed(self):
+        """parameters were rewritten in place without a version bump: drop the packs and every launch plan built on them"""
+        self._pack_gen += 1
+        self._pack_key = self._plan_key = self._plan_val = None
+
     # ------------------------------------------------------------------ forward
     def _plan(self, B, cin, spatial, dev):
         """buffers + the 2 * res_layers + 2 prebuilt launches for one input geometry (cached with the packed weights)"""
         pk = self.packed()
         key = (B, cin, tuple(spatial), str(dev), self._pack_key)
-        if getattr(self, "_plan_key", None) == key:
+        if self._plan_key == key:
             return self._plan_val
         P = B * int(torch.tensor(spatial).prod())
         C, ot = self.n_chan, self.n_chan // 32

@@ -111,7 +111,7 @@ class MAgNetCNN(MagnetBase):
         feats = torch.cat([lr_points, hr_points], dim=1)
         allc = torch.cat([lr_coords, coords], dim=1)
         last = torch.cat([x_t[:, -1, 0].reshape(B, nlr, 1), hr_last.float()], dim=1)
-        out = self._interaction_and_update_grad(pk, feats, allc, t, T, last, key=("all", W) + self._tkey(coords))
+        out = self._interaction_and_update_grad(pk, feats, allc, t, T, last, key=self._tkey(("all", W), coords))
         out_lr = out[:, :, :nlr]
         if d == 2:
             out_lr = out_lr.permute(0, 1, 3, 2).reshape(B, -1, 1, W, W)
@@ -151,7 +151,7 @@ class MAgNetCNN(MagnetBase):
         feats = torch.cat([lr_points, hr_points], dim=1)
         allc = torch.cat([lr_coords, coords], dim=1)
         last = torch.cat([x_t[:, -1, 0].reshape(B, nlr, 1), hr_last.float()], dim=1)
-        out = self._interaction_and_update(pk, feats, allc, t, T, last, key=("all", W) + self._tkey(coords))
+        out = self._interaction_and_update(pk, feats, allc, t, T, last, key=self._tkey(("all", W), coords))
         out_lr = out[:, :, :nlr]
         if d == 2:
             out_lr = out_lr.permute(0, 1, 3, 2).reshape(B, -1, 1, W, W)
@@ -179,6 +179,7 @@ class MAgNetCNN(MagnetBase):
                 hr_last = out_hr[:, -1]
         pred, hr_hat = torch.cat(outs, dim=1), torch.cat(hrs, dim=1)
         target = torch.cat([fut, self._lr_as_nodes(u[:, T:])], dim=2)
+        self._guard.raise_if_set(f"{type(self).__name__} training rollout")
         loss = self.criterion(pred, target) + self.criterion(hr_hat, vals[:, :-T])
         self.log("train_loss", loss, prog_bar=True)
         self.log("train_mae_loss", self.mae_criterion(pred, target), prog_bar=True)
@@ -205,6 +206,7 @@ class MAgNetCNN(MagnetBase):
                 inp = ops.resize_linear(img.reshape(-1, img.shape[-1]), (W,), 1).reshape(B, -1, 1, W)
             hr_last = y[:, -1]
         pred = torch.cat(outs, dim=1)
+        self._guard.raise_if_set(f"{type(self).__name__} rollout")
         self.log("val_loss", self.criterion(pred, fut), prog_bar=True)
         self.log("val_mae_loss", self.mae_criterion(pred, fut), prog_bar=True)
         return pred

@@ -19,6 +19,7 @@ from .. import _lib as L
 from .. import ops
 from ..lightning_compat import LightningModule
 from ..packing import pad_to, pad_vec
+from ..topo_cache import TopologyCache
 from .backbones.mlp import MLP
 
 
@@ -89,7 +90,10 @@ class MagnetBase(LightningModule):
         self.criterion = {"l1": nn.L1Loss(), "l2": nn.MSELoss(), "smooth_l1": nn.SmoothL1Loss()}[self.loss]
         self.mse_criterion, self.mae_criterion = nn.MSELoss(), nn.L1Loss()
         self._pack_key, self._pack, self._pack_gen = None, None, 0
-        self._topo_cache = {}
+        self._topo_cache = TopologyCache()
+        # fp16x3 only: sticky device-side range / finiteness status, read once per rollout (ops.RangeGuard)
+        from ..packing import default_gemm
+        self._guard = ops.RangeGuard(default_gemm() == "fp16x3" and bool(getattr(hparams, "range_check", True)))
         self.optimizer_kind = getattr(hparams, "optimizer", "fused")     # "fused" (magnet_amd.optim.FusedAdam) | "torch"
 
     # ---- packed-weight cache -------------------------------------------------------------
@@ -104,43 +108,47 @@ class MagnetBase(LightningModule):
         """FusedAdam writes the parameters behind torch's version counters: drop every packed-weight cache"""
         self._pack_gen += 1
         for m in self.modules():
-            if m is not self and hasattr(m, "_pack_key"):
-                m._pack_key = None                     # EDSR keeps its own packs / launch plans
+            if m is not self and hasattr(m, "weights_changed"):
+                m.weights_changed()                    # EDSR keeps its own packs and prebuilt launch plans
 
     # ---- graph (reference _build_graph, models/magnet_gnn.py:286-310) ---------------------
     def _topology(self, coords: torch.Tensor, key):
         """radius_graph(loop=True, cap 32) on [B, N, d] coords, swapped (senders = query, receivers =
-        found neighbour) and sorted by receiver; cached while the coordinate tensors are unchanged."""
-        hit = self._topo_cache.get(key)
-        if hit is not None:
-            return hit
-        B, N, d = coords.shape
-        flat = coords.reshape(B * N, d).float().contiguous()
-        gptr = ops.graph_ptr(B, N, flat.device)
-        found, query, _, E = ops.radius_pairs(flat, self.radius, gptr, loop=True)
-        csr = ops.csr_by_target(query, found, B * N)      # src = senders (query), tgt = receivers (found)
-        topo = types.SimpleNamespace(csr=csr, n_graphs=B, nodes_per_graph=N, flat=flat)
-        if len(self._topo_cache) > 8:
-            self._topo_cache.clear()
-        self._topo_cache[key] = topo
-        return topo
+        found neighbour) and sorted by receiver; cached while the coordinate tensors are unchanged.
+        ``key`` = (tag, tensors): the tensors ``coords`` was assembled from - the cache entry keeps them alive
+        and recognises them by identity, or by content after a miss (magnet_amd/topo_cache.py)."""
+        tag, tensors = key
+
+        def build():
+            B, N, d = coords.shape
+            flat = coords.reshape(B * N, d).float().contiguous()
+            gptr = ops.graph_ptr(B, N, flat.device)
+            found, query, _, E = ops.radius_pairs(flat, self.radius, gptr, loop=True)
+            csr = ops.csr_by_target(query, found, B * N)      # src = senders (query), tgt = receivers (found)
+            return types.SimpleNamespace(csr=csr, n_graphs=B, nodes_per_graph=N, flat=flat)
+
+        return self._topo_cache.get((tag, float(self.radius)), tensors, build)
 
     @staticmethod
-    def _tkey(*tensors):
-        return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    def _tkey(tag, *tensors):
+        return (tag, tensors)
+
+    def drop_topology_cache(self):
+        self._topo_cache.clear()
 
     def _build_graph(self, u, x, t, key=None):
         """u [B, N, T], x [B, N, d], t [B, T] -> (node_features [B*N, ld], topology).  Edge features
         (u_s - u_r, x_s - x_r) are formed inside the edge-encoder kernel from node_features."""
         B, N, T = u.shape
         d = x.shape[-1]
-        topo = self._topology(x, key if key is not None else self._tkey(x))
+        topo = self._topology(x, key if key is not None else self._tkey("x", x))
         ld = pad_to(T + d + 1)
         nf = torch.empty(B * N, ld, device=u.device, dtype=torch.float32)
         uf = ops._f32(u.reshape(B * N, T))
         t_last = ops._f32(t[:, -1])
         L.check(L.lib().magnet_node_features_f32(ops._p(uf), ops._p(topo.flat), ops._p(t_last), B, N, T, d, ld,
                                                  ops._p(nf), ops._stream()), "node_features")
+        self._guard.inputs(nf)
         return nf, topo
 
     # ---- Encoder + Processor (models/magnet_gnn.py:38-42, 70-117) --------------------------
@@ -169,8 +177,9 @@ class MagnetBase(LightningModule):
     def _build_graph_grad(self, u, x, t, key=None):
         from .. import autograd as AG
         B, N, T = u.shape
-        topo = self._topology(x, key if key is not None else self._tkey(x))
+        topo = self._topology(x, key if key is not None else self._tkey("x", x))
         nf = AG.node_features(u.float(), topo.flat, t[:, -1].float(), pad_to(T + x.shape[-1] + 1))
+        self._guard.inputs(nf.detach())
         return nf, topo
 
     def _graph_net_grad(self, pk, nf, topo, D):
@@ -194,7 +203,9 @@ class MagnetBase(LightningModule):
         x = self._graph_net_grad(pk.graph2, nf, topo, self.latent_dim)
         T_out = t.shape[1] - T
         ret = AG.mlp(B * n, [ops.Term(x, self.latent_dim)], pk.decoder, pk.decoder.params)
-        return AG.euler_update(ret, last, t, B, n, T, T_out)
+        out = AG.euler_update(ret, last, t, B, n, T, T_out)
+        self._guard.outputs(out.detach())
+        return out
 
     # ---- second half of every MAgNet forward: joint graph, decoder, Euler update ------------
     def _interaction_and_update(self, pk, feats, coords, t, T, last, key):
@@ -209,6 +220,7 @@ class MagnetBase(LightningModule):
         tt = ops._f32(t)
         L.check(L.lib().magnet_euler_update_f32(ops._p(ret), ret.shape[1], ops._p(ops._f32(last.reshape(-1))), ops._p(tt),
                                                 tt.shape[1], B, n, T, T_out, ops._p(out), ops._stream()), "euler_update")
+        self._guard.outputs(out)
         return out
 
     def _projector(self, pk, z, rows):

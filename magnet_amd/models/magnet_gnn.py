@@ -81,7 +81,7 @@ class MAgNetGNN(MagnetBase):
         lr_coords = lr_coords.reshape(B, Lr, d).float()
         hr_coords = hr_coords.reshape(B, Nq, d).float()
         u = x_lr.permute(0, 3, 1, 2).reshape(B, Lr, T * C).float().contiguous()
-        nf, topo = self._build_graph_grad(u, lr_coords, t[:, :T], key=("lr",) + self._tkey(lr_coords))
+        nf, topo = self._build_graph_grad(u, lr_coords, t[:, :T], key=self._tkey("lr", lr_coords))
         enc = self._graph_net_grad(pk.graph1, nf, topo, D)
         with torch.no_grad():
             flr, fhr = topo.flat, ops._f32(hr_coords.reshape(B * Nq, d))
@@ -106,7 +106,7 @@ class MAgNetGNN(MagnetBase):
         feats = torch.cat([u, hr_points], dim=1)
         coords = torch.cat([lr_coords, hr_coords], dim=1)
         last = torch.cat([x_lr[:, -1].permute(0, 2, 1).float(), hr_last.float()], dim=1)
-        out = self._interaction_and_update_grad(pk, feats, coords, t, T, last, key=("all",) + self._tkey(lr_coords, hr_coords))
+        out = self._interaction_and_update_grad(pk, feats, coords, t, T, last, key=self._tkey("all", lr_coords, hr_coords))
         return out[:, :, Lr:], out[:, :, :Lr], hr_points.permute(0, 2, 1)[..., None]
 
     def _forward(self, x_lr, lr_coords, hr_coords, t, hr_last):
@@ -119,7 +119,7 @@ class MAgNetGNN(MagnetBase):
         hr_coords = hr_coords.reshape(B, Nq, d).float()
         u = x_lr.permute(0, 3, 1, 2).reshape(B, Lr, T * C).float().contiguous()      # magnet_gnn.py:331-332
         # encode-process the LR mesh
-        nf, topo = self._build_graph(u, lr_coords, t[:, :T], key=("lr",) + self._tkey(lr_coords))
+        nf, topo = self._build_graph(u, lr_coords, t[:, :T], key=self._tkey("lr", lr_coords))
         enc = self._graph_net(pk.graph1, nf, topo, D)
         # INR decoder (continuous_decoder, magnet_gnn.py:224-283)
         flr, fhr = topo.flat, ops._f32(hr_coords.reshape(B * Nq, d))
@@ -144,16 +144,27 @@ class MAgNetGNN(MagnetBase):
         feats = torch.cat([u, hr_points], dim=1)
         coords = torch.cat([lr_coords, hr_coords], dim=1)
         last = torch.cat([x_lr[:, -1].permute(0, 2, 1).float(), hr_last.float()], dim=1)
-        out = self._interaction_and_update(pk, feats, coords, t, T, last, key=("all",) + self._tkey(lr_coords, hr_coords))
+        out = self._interaction_and_update(pk, feats, coords, t, T, last, key=self._tkey("all", lr_coords, hr_coords))
         return out[:, :, Lr:], out[:, :, :Lr], hr_points.permute(0, 2, 1)[..., None]
 
-    def _rollout(self, batch, teacher_forcing=False):
+    def _noisy(self, x, on):
+        """training-time input noise, magnet_gnn.py:402-407 / :424-428: ``noise * torch.randn(shape)`` drawn from torch's
+        default HOST generator (as the reference does - same seed, same call order, same numbers), added on the device.
+        The reference draws even when ``noise`` is 0; the shipped config (configs/model/magnet_gnn.yaml:13) has 0 and the
+        draw is skipped then."""
+        if not on or not self.noise:
+            return x
+        return x + (self.noise * torch.randn(x.shape)).to(x.device)
+
+    def _rollout(self, batch, teacher_forcing=False, noise=False):
         t, u = batch["t"].float(), batch["lr_frames"].float()
         vals = batch["hr_points"].float()
         hr_c, lr_c = batch["coords_hr"].float(), batch["coords_lr"].float()
         T = self.time_slice
         fut = vals[:, T:]
-        inp, hr_last, outs, hrs = u[:, :T], vals[:, T - 1], [], []
+        outs, hrs = [], []
+        inp = self._noisy(u[:, :T], noise)                     # reference order: input noise first, then hr_last
+        hr_last = self._noisy(vals[:, T - 1], noise)
         for i in range(fut.shape[1] // T):
             out_hr, out_lr, hr_points = self.forward(inp, lr_c, hr_c, t[:, i * T:(i + 2) * T], hr_last)
             outs.append(torch.cat([out_hr, out_lr], dim=2))
@@ -162,14 +173,15 @@ class MAgNetGNN(MagnetBase):
                 inp, hr_last = u[:, (i + 1) * T:(i + 2) * T], vals[:, (i + 2) * T - 1]
             else:
                 inp, hr_last = out_lr.permute(0, 1, 3, 2), out_hr[:, -1]
+            inp = self._noisy(inp, noise)
+            hr_last = self._noisy(hr_last, noise)
         pred = torch.cat(outs, dim=1)
         target = torch.cat([fut, u[:, T:].permute(0, 1, 3, 2)], dim=2)
+        self._guard.raise_if_set("MAgNetGNN rollout")
         return pred, target, torch.cat(hrs, dim=1), vals
 
     def training_step(self, train_batch, batch_idx):
-        if self.noise:
-            raise NotImplementedError("input noise (magnet_gnn.py:402-407) is a training-only feature")
-        pred, target, hr_hat, vals = self._rollout(train_batch, self.teacher_forcing)
+        pred, target, hr_hat, vals = self._rollout(train_batch, self.teacher_forcing, noise=True)
         T = self.time_slice
         loss = self.criterion(pred, target) + self.criterion(hr_hat, vals[:, :-T])
         self.log("train_loss", loss, prog_bar=True)

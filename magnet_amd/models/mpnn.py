@@ -24,6 +24,7 @@ from torch import nn
 from .. import ops
 from ..lightning_compat import LightningModule
 from ..packing import GEMM_MODES, default_gemm, pack, pack_edge16_fp16x2, pad_to
+from ..topo_cache import TopologyCache
 
 _READOUT = {10: (16, 6, 10), 16: (16, 5, 8), 20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}  # mpnn.py:140-163
 
@@ -102,8 +103,10 @@ class MPNN(LightningModule):
         self.optimizer_kind = getattr(hparams, "optimizer", "fused")     # "fused" (magnet_amd.optim.FusedAdam) | "torch"
         self.edge_bwd = getattr(hparams, "edge_bwd", "fused")
         assert self.edge_bwd in ("fused", "unfused")
+        # fp16x3 only: sticky device-side range / finiteness status, read once per rollout (ops.RangeGuard)
+        self._guard = ops.RangeGuard("fp16x3" in (self.gemm, self.edge_gemm) and bool(getattr(hparams, "range_check", True)))
         self._pack_key, self._pack, self._pack_gen = None, None, 0
-        self._topo_key, self._topo = None, None
+        self._topo_cache, self._topo = TopologyCache(4), None       # _topo: the topology of the latest _build_graph
         self.hip_graph = bool(getattr(hparams, "hip_graph", False))
         self._fwd_graphs = {}
 
@@ -170,6 +173,7 @@ class MPNN(LightningModule):
             Lv = Lv.expand(self.dpos).contiguous()
 
         node_in = ops.mpnn_node_input(u, pos, Lv, tm, tw, self.dpos, kin)
+        self._guard.inputs(node_in)
         new = lambda: torch.empty(N, H, device=dev, dtype=torch.float32)  # noqa: E731
         h, g, agg = new(), new(), new()
         AB = torch.empty(2, N, H, device=dev, dtype=torch.float32)      # the two per-node halves of message_net_1, one launch
@@ -203,7 +207,9 @@ class MPNN(LightningModule):
         if tape is not None:
             tape.h = h
         k1, s1, k2 = _READOUT[tw]
-        return ops.mpnn_readout(h, u, tw, P.conv[0], P.conv[1], k1, s1, P.conv[2], P.conv[3], k2, self.readout_swish, dtv)
+        out = ops.mpnn_readout(h, u, tw, P.conv[0], P.conv[1], k1, s1, P.conv[2], P.conv[3], k2, self.readout_swish, dtv)
+        self._guard.outputs(out)
+        return out
 
     # ------------------------------------------------------------------ hipGraph replay of the forward
     def _graphed_forward(self, data, L, tmax, dt):
@@ -257,10 +263,9 @@ class MPNN(LightningModule):
         """data [B, tw, N], t [B, T], x [B, N(, 2)], steps [B] -> MeshGraph (Data-like)."""
         B, tw, Ns = data.shape
         x0 = x[0]
-        key = (x0.data_ptr(), x0._version, tuple(x0.shape), B, str(x0.device))
-        if self._topo_key != key:
-            self._topo, self._topo_key = self._build_topology(x0, B), key
-        topo = self._topo
+        # cached while sample 0's mesh (Q8) is unchanged; the entry keeps x0 alive and recognises it by identity, or by
+        # content after a miss (magnet_amd/topo_cache.py) - irregular meshes change from batch to batch
+        topo = self._topo = self._topo_cache.get(("mesh", B, self.n), (x0,), lambda: self._build_topology(x0, B))
         u = data.permute(0, 2, 1).reshape(B * Ns, tw).contiguous()
         if len(set(int(s_) for s_ in steps)) == 1:          # every reference caller passes one step for all samples
             t_sel = t[:, int(steps[0])]
@@ -271,6 +276,10 @@ class MPNN(LightningModule):
             topo.batch = torch.arange(B, device=u.device).repeat_interleave(Ns)
         batch = topo.batch
         return MeshGraph(u, pos, batch, topo)
+
+    def drop_topology_cache(self):
+        self._topo_cache.clear()
+        self._topo = None
 
     def _topology_of(self, data, N):
         topo = getattr(data, "topo", None)
@@ -337,6 +346,8 @@ class MPNN(LightningModule):
             u_hat.append(y_hat)
             nxt = u[:, (i + 1) * tw:(i + 2) * tw] if teacher_forcing else y_hat
             graph = self._build_graph(nxt, t, x, [self._next_step(i)] * B)
+        if tapes is None:                                      # with tapes: rollout_with_grad checks after its own bookkeeping
+            self._guard.raise_if_set(f"{type(self).__name__} rollout")
         return torch.cat(u_hat, dim=1), target
 
     def training_step(self, train_batch, batch_idx):

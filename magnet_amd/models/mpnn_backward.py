@@ -216,6 +216,7 @@ class _Rollout(torch.autograd.Function):
             u_hat, target = m.rollout(batch, teacher_forcing, tapes=tapes)
         ctx.m, ctx.tapes, ctx.tf = m, tapes, teacher_forcing
         m._last_target = target
+        m._guard.raise_if_set(f"{type(m).__name__} training rollout")
         return u_hat.contiguous()
 
     @staticmethod

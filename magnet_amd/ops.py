@@ -15,9 +15,19 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _same_device(t: torch.Tensor, name: str) -> None:
+    """kernels are enqueued on the current stream of the CURRENT device (one process per GPU, torch.cuda.set_device(local_rank)
+    first - what Lightning's ddp strategy does for the reference): a tensor of another device would be dereferenced from the
+    wrong GPU's stream, so refuse it loudly"""
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"magnet_amd: {name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "call torch.cuda.set_device(...) (or wrap the call in torch.cuda.device(...)) first")
+
+
 def _f32(t: torch.Tensor, name="tensor") -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"magnet_amd: {name} must live on a HIP device (got {t.device}); there is no CPU path")
+    _same_device(t, name)
     if t.dtype != torch.float32 or not t.is_contiguous():
         t = t.float().contiguous()
     return t
@@ -26,6 +36,7 @@ def _f32(t: torch.Tensor, name="tensor") -> torch.Tensor:
 def _i32(t: torch.Tensor, name="index") -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"magnet_amd: {name} must live on a HIP device")
+    _same_device(t, name)
     assert t.dtype == torch.int32 and t.is_contiguous()
     return t
 
@@ -134,6 +145,54 @@ def segment_mean(msg: torch.Tensor, rowptr: torch.Tensor, n_rows: int, out: torc
     out = torch.empty(n_rows, h, device=msg.device, dtype=torch.float32) if out is None else out
     L.check(L.lib().magnet_segment_mean_f32(_p(msg), _p(_i32(rowptr)), n_rows, h, _p(out), _stream()), "segment_mean")
     return out
+
+
+# ------------------------------------------------------------------------------------ fp16x3 range guard
+FP16_LIMIT = 65504.0
+ST_IN_RANGE, ST_IN_NONFINITE, ST_OUT_NONFINITE = 1, 2, 4
+
+
+class RangeGuard:
+    """Sticky device-side status word for the fp16x3 GEMM mode (two fp16 pieces per value: magnitudes >= 65504 overflow to
+    inf silently).  ``inputs(x)`` flags out-of-range / non-finite entries of an array that enters a GEMM chain,
+    ``outputs(y)`` non-finite entries of a result; ``raise_if_set()`` reads the word once (one host sync - the models call
+    it once per rollout) and raises, pointing to the full-range ``bf16x6`` mode.  Inactive (no launches, no sync) in the
+    other GEMM modes."""
+
+    def __init__(self, active: bool):
+        self.active, self._status = bool(active), None
+
+    def _word(self, dev):
+        if self._status is None or self._status.device != dev:
+            self._status = torch.zeros(1, dtype=torch.int32, device=dev)
+        return self._status
+
+    def inputs(self, x):
+        if self.active:
+            L.check(L.lib().magnet_status_check_f32(_p(x), C.c_long(x.numel()), C.c_float(FP16_LIMIT), ST_IN_RANGE,
+                                                    ST_IN_NONFINITE, ST_OUT_NONFINITE, _p(self._word(x.device)), _stream()),
+                    "status_check")
+
+    def outputs(self, y):
+        if self.active:
+            L.check(L.lib().magnet_status_check_f32(_p(y), C.c_long(y.numel()), C.c_float(float("inf")), ST_OUT_NONFINITE,
+                                                    ST_OUT_NONFINITE, 0, _p(self._word(y.device)), _stream()), "status_check")
+
+    def raise_if_set(self, what: str):
+        if not self.active or self._status is None:
+            return
+        st = int(self._status.item())
+        if st == 0:
+            return
+        self._status.zero_()
+        hint = ('select the full-range split with hparams.gemm = hparams.edge_gemm = "bf16x6" (or MAGNET_GEMM=bf16x6); '
+                "fp16x3 represents values with two fp16 pieces and needs |value| < 65504")
+        if st & ST_IN_RANGE:
+            raise OverflowError(f"magnet_amd {what}: an input of the fp16x3 GEMM chain has magnitude >= 65504 - {hint}")
+        if st & ST_OUT_NONFINITE and not st & ST_IN_NONFINITE:
+            raise OverflowError(f"magnet_amd {what}: non-finite prediction from finite inputs in fp16x3 mode - an intermediate "
+                                f"left the fp16 range (or the data contain a 0/0, e.g. duplicate LR nodes in the INR blend, "
+                                f"which the reference turns into NaN as well; hparams.range_check = False disables this guard) - {hint}")
 
 
 # ------------------------------------------------------------------------------------ MPNN pieces

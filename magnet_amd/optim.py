@@ -87,19 +87,54 @@ class FusedAdam(torch.optim.Optimizer):
             o += k
         return self._scratch_g
 
-    # ---- checkpointing: the moments live in the flat buffers, not in ``self.state``
+    # ---- checkpointing: the moments live in the flat buffers, the checkpoint is torch.optim.Adam's format
     def state_dict(self):
+        """The layout ``torch.optim.Adam.state_dict()`` writes (what the reference's Lightning checkpoints hold,
+        configure_optimizers models/mpnn.py:206-214): per parameter index ``step`` / ``exp_avg`` / ``exp_avg_sq`` in the
+        parameter's own shape, so a checkpoint written here resumes under torch.optim.Adam and vice versa."""
         sd = super().state_dict()
-        sd["magnet_flat"] = {"exp_avg": self.flat_m.clone(), "exp_avg_sq": self.flat_v.clone(), "step": self.steps}
+        state, o = {}, 0
+        if self.steps > 0:
+            for i, p in enumerate(self._params):
+                k = p.numel()
+                state[i] = {"step": torch.tensor(float(self.steps)),
+                            "exp_avg": self.flat_m[o:o + k].view(p.shape).clone(),
+                            "exp_avg_sq": self.flat_v[o:o + k].view(p.shape).clone()}
+                o += k
+        sd["state"] = state
         return sd
 
     def load_state_dict(self, state_dict):
-        flat = state_dict.get("magnet_flat")
-        super().load_state_dict({k: v for k, v in state_dict.items() if k != "magnet_flat"})
+        flat = state_dict.get("magnet_flat")              # round-1 checkpoints of this class
+        per_param = state_dict.get("state", {})
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
         if flat is not None:
             self.flat_m.copy_(flat["exp_avg"])
             self.flat_v.copy_(flat["exp_avg_sq"])
             self.steps = int(flat["step"])
+            return
+        if not per_param:
+            self.flat_m.zero_()
+            self.flat_v.zero_()
+            self.steps = 0
+            return
+        if sorted(per_param.keys()) != list(range(len(self._params))):
+            raise ValueError("FusedAdam.load_state_dict: optimizer state covers parameters "
+                             f"{sorted(per_param.keys())[:4]}... but the model has {len(self._params)}")
+        steps, o = set(), 0
+        for i, p in enumerate(self._params):
+            st, k = per_param[i], p.numel()
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"FusedAdam.load_state_dict: moment shape {tuple(st['exp_avg'].shape)} of parameter {i} "
+                                 f"does not match {tuple(p.shape)}")
+            self.flat_m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+            self.flat_v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+            o += k
+        if len(steps) != 1:
+            raise ValueError(f"FusedAdam.load_state_dict: parameters carry different step counts {sorted(steps)}; "
+                             "one bias correction per step is applied to the whole flat buffer")
+        self.steps = steps.pop()
 
     @torch.no_grad()
     def step(self, closure=None):

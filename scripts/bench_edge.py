@@ -1,4 +1,5 @@
 """Dev microbench: time the MPNN hop kernels in isolation on the 256^2 graph (B trajectories)."""
+__import__("os").environ.setdefault("MAGNET_DEV_LIB", "1")   # needs the development library: python -m magnet_amd.build --dev
 import sys, types
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch

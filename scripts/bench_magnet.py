@@ -35,7 +35,7 @@ if which in ("cnn", "both"):
     hr_last = torch.randn(B, Wq * Wq, 1, device=dev)
     dt = timeit(lambda: m(x_t, coords, cell, t, hr_last))
     n = W * W + Wq * Wq
-    topo = list(m._topo_cache.values())[0]
+    topo = m._topo_cache.topologies()[0][1]
     deg = (topo.csr.rowptr[1:] - topo.csr.rowptr[:-1]).float()
     print(f"magnet_cnn_2d C4b B={B}: forward {dt*1e3:.1f} ms, nodes {n}, E {topo.csr.E}, in-degree min/mean/max {deg.min():.0f}/{deg.mean():.1f}/{deg.max():.0f}"
           f" -> {B*n*T/dt:.3e} node-updates/s (per forward of {T} steps), peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB")
@@ -55,7 +55,7 @@ if which in ("gnn", "both"):
     hr_last = torch.randn(B, Wq * Wq, 1, device=dev)
     dt = timeit(lambda: m(x_lr, lr_c, hr_c, t, hr_last))
     n = L + Wq * Wq
-    topo = [v for k, v in m._topo_cache.items() if k[0] == "all"][0]
+    topo = [v for k, v in m._topo_cache.topologies() if k[0] == "all"][0]
     deg = (topo.csr.rowptr[1:] - topo.csr.rowptr[:-1]).float()
     print(f"magnet_gnn C5 B={B}: forward {dt*1e3:.1f} ms, nodes {n}, E {topo.csr.E}, in-degree min/mean/max {deg.min():.0f}/{deg.mean():.1f}/{deg.max():.0f}"
           f" -> {B*n*T/dt:.3e} node-updates/s (per forward of {T} steps), peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB")

@@ -1,4 +1,5 @@
 """Dev microbench: run-time ablations of the 5-Linear InteractionNetwork edge kernel (C5 joint graph shape)."""
+__import__("os").environ.setdefault("MAGNET_DEV_LIB", "1")   # needs the development library: python -m magnet_amd.build --dev
 import sys
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch

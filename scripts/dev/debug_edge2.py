@@ -1,4 +1,5 @@
 import sys, types
+__import__("os").environ.setdefault("MAGNET_DEV_LIB", "1")   # needs the development library: python -m magnet_amd.build --dev
 sys.path.insert(0, ".")
 import torch
 from magnet_amd import ops, _lib

@@ -28,7 +28,7 @@ for _ in range(K):
 torch.cuda.synchronize(); dt = (time.time() - t0) / K
 print(f"W={W} B={B}: rollout {dt*1e3:.2f} ms -> {B*W*W*40/dt:.3e} node-updates/s")
 # graph build alone
-m._topo_key = None
+m.drop_topology_cache()
 torch.cuda.synchronize(); t0 = time.time()
 m._build_graph(u.permute(0, 2, 1)[:, :10], t, x, [9] * B); torch.cuda.synchronize()
 print("graph build", time.time() - t0)

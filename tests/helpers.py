@@ -7,7 +7,9 @@ import numpy as np
 import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["mpnn_1d", "mpnn_2d", "magnet_gnn_full", "magnet_gnn_tiny", "magnet_cnn_1d", "magnet_cnn_2d"]
+CASES = ["mpnn_1d", "mpnn_2d", "magnet_gnn_full", "magnet_gnn_tiny", "magnet_cnn_1d", "magnet_cnn_2d",
+         # round 2: shipped hyper-parameters on reduced grids (tests/golden/make_golden.py round2)
+         "magnet_cnn_1d_shipped", "magnet_cnn_2d_shipped", "magnet_gnn_c5_reduced"]
 
 
 def load_case(tag):
@@ -78,16 +80,18 @@ def load_grads(tag, teacher_forcing):
                                      for n in names}
 
 
-def oracle_magnet_gnn_grads(oracle, batch, teacher_forcing, loss_name, dtype=torch.float64):
-    """loss + parameter gradients of the reference's MAgNetGNN.training_step (models/magnet_gnn.py:388-440, noise = 0) by
-    torch autograd through the oracle restatement."""
+def oracle_magnet_gnn_grads(oracle, batch, teacher_forcing, loss_name, dtype=torch.float64, noise=0.0):
+    """loss + parameter gradients of the reference's MAgNetGNN.training_step (models/magnet_gnn.py:388-440) by
+    torch autograd through the oracle restatement; ``noise`` > 0 draws the reference's host-side randn in its order."""
     from oracle.models import _criterion
     o = oracle.to(dtype)
     b = {k: v.to(dtype) for k, v in batch.items()}
     t, u, vals, hr_c, lr_c = b["t"], b["lr_frames"], b["hr_points"], b["coords_hr"], b["coords_lr"]
     T = o.T
     fut = vals[:, T:]
-    inp, hr_last, outs, hrs = u[:, :T], vals[:, T - 1], [], []
+    noisy = (lambda x: x + (noise * torch.randn(x.shape)).to(dtype)) if noise else (lambda x: x)   # magnet_gnn.py:402-407
+    inp, outs, hrs = noisy(u[:, :T]), [], []
+    hr_last = noisy(vals[:, T - 1])
     for i in range(fut.shape[1] // T):
         out_hr, out_lr, hr_points = o.forward(inp, lr_c, hr_c, t[:, i * T:(i + 2) * T], hr_last)
         outs.append(torch.cat([out_hr, out_lr], 2))
@@ -96,6 +100,8 @@ def oracle_magnet_gnn_grads(oracle, batch, teacher_forcing, loss_name, dtype=tor
             inp, hr_last = u[:, (i + 1) * T:(i + 2) * T], vals[:, (i + 2) * T - 1]
         else:
             inp, hr_last = out_lr.permute(0, 1, 3, 2), out_hr[:, -1]
+        inp = noisy(inp)
+        hr_last = noisy(hr_last)
     pred, hr_hat = torch.cat(outs, 1), torch.cat(hrs, 1)
     target = torch.cat([fut, u[:, T:].permute(0, 1, 3, 2)], 2)
     crit = _criterion(loss_name)

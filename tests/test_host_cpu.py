@@ -129,3 +129,99 @@ def test_training_host_logic_on_cpu():
     assert optim.flat_gradient(ps) is None
     with pytest.raises(RuntimeError, match="HIP device"):
         optim.FusedAdam(ps)
+
+
+# ---- topology cache (magnet_amd/topo_cache.py): identity with keep-alive, content re-key, in-place writes
+def test_topology_cache_follows_the_coordinates_not_the_address():
+    from magnet_amd.topo_cache import TopologyCache
+    cache, built = TopologyCache(4), []
+
+    def get(x, tag="g"):
+        return cache.get(tag, (x,), lambda: built.append(len(built)) or ("topo", len(built)))
+
+    a = torch.arange(12.0).reshape(6, 2)
+    t1 = get(a)
+    assert get(a) is t1 and get(a[:]) is t1 and len(built) == 1          # the same storage through another view object
+    a2 = a.clone()
+    assert get(a2) is t1 and len(built) == 1                            # equal content in a new tensor: re-keyed, not rebuilt
+    assert get(a2) is t1
+    b = a + 1.0                                                         # same shape, different coordinates
+    t2 = get(b)
+    assert t2 is not t1 and len(built) == 2
+    b.add_(1.0)                                                         # in-place write bumps the version counter
+    t3 = get(b)
+    assert t3 is not t2 and len(built) == 3
+    assert get(a2, tag="other") is not t1 and len(built) == 4           # the tag is part of the key
+    # the entry keeps its key tensor alive, so a freed-and-recycled address cannot alias it
+    ptr = b.data_ptr()
+    del b
+    c = torch.full((6, 2), 7.0)
+    assert c.data_ptr() != ptr or get(c) is not t3
+
+
+def test_topology_cache_is_bounded():
+    from magnet_amd.topo_cache import TopologyCache
+    cache = TopologyCache(3)
+    keep = [torch.full((2, 2), float(i)) for i in range(5)]
+    for i, x in enumerate(keep):
+        cache.get("g", (x,), lambda i=i: i)
+    assert len(cache) == 3 and [t for _, t in cache.topologies()] == [2, 3, 4]
+
+
+# ---- bench.py multi-rank launcher (`--gpus N` must be real)
+def _bench(*argv, **env_over):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_over)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_gpus_n_starts_n_fresh_ranks():
+    import json
+    r = _bench("--gpus", "4", "--steps", "3", MAGNET_BENCH_LAUNCH_DRY="1")
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+
+
+def test_bench_refuses_a_rank_count_mismatch():
+    r = _bench("--gpus", "4", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    assert r.returncode != 0 and "--gpus 4" in r.stderr and "2 rank" in r.stderr
+
+
+def test_launcher_runs_two_gloo_ranks_end_to_end(tmp_path):
+    """the same torch.distributed.run invocation bench.py builds, on a CPU script: two ranks rendezvous on 127.0.0.1 over gloo"""
+    import os
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    script = tmp_path / "echo_rank.py"
+    script.write_text("import os, torch, torch.distributed as dist\n"
+                      "dist.init_process_group('gloo')\n"
+                      "t = torch.tensor([float(dist.get_rank() + 1)])\n"
+                      "dist.all_reduce(t)\n"
+                      "print('SUM', int(t.item()), 'WORLD', dist.get_world_size()) if dist.get_rank() == 0 else None\n"
+                      "dist.destroy_process_group()\n")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(bench.free_port()), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "SUM 3 WORLD 2" in r.stdout
+
+
+def test_product_library_has_no_development_knobs():
+    """kernel-variant / ablation selection exists only in the -DMAGNET_DEV_VARIANTS build (include/magnet_hip_dev.h)"""
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    assert not hasattr(lib, "magnet_debug_set_variant") and not hasattr(lib, "magnet_debug_set_mlp_ablation")
+    assert all("debug" not in n for n in _lib.declared_symbols())
+
+
+def test_factory_lists_all_five_models():
+    from magnet_amd.models.factory import FACTORY
+    assert sorted(FACTORY) == ["magnet_cnn", "magnet_cnn_2d", "magnet_gnn", "mpnn", "mpnn_2d"]

@@ -9,7 +9,10 @@ pytestmark = pytest.mark.gpu
 
 OUT_TOL = 1e-5
 INC_TOL = 2e-4      # increment (out - last) is ~1e-2 of the output norm; fp32 roundoff through 5-10 hops + norms
-TAGS = ["magnet_gnn_full", "magnet_gnn_tiny", "magnet_cnn_1d", "magnet_cnn_2d"]
+TAGS = ["magnet_gnn_full", "magnet_gnn_tiny", "magnet_cnn_1d", "magnet_cnn_2d",
+        # shipped hyper-parameters (K = 10 hops, 16 / 4 ResBlocks, n_chan 128; magnet_gnn: shipped widths, 256 irregular LR nodes)
+        # on reduced query grids - fixtures from the imported reference
+        "magnet_cnn_1d_shipped", "magnet_cnn_2d_shipped", "magnet_gnn_c5_reduced"]
 
 
 def _models(tag):
@@ -168,3 +171,165 @@ def test_magnet_gnn_bf16_mode_deviation(monkeypatch):
     dev = rel_l2(out[0], d["fwd_out_hr"])
     print("bf16 magnet_gnn forward deviation", dev)
     assert OUT_TOL < dev < 5e-2
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs exactly as written / at full size (VERDICT r1 "configs_untested")
+def _c2_batch(samples, seed):
+    """BASELINE configs[1]: magnet_gnn, 1-D E1, 50-node mesh -> LR = every second node (25), `samples` = 16 sorted random
+    queries among the 25 odd nodes (datamodule/dataset.py:85-113, mode='train'), nt = 250, time_slice = 25 -> 9 forward
+    calls in the free-running rollout."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    B, L, nt = 2, 50, 250
+    x = np.linspace(0.0, 16.0, L)
+    x = 2 * (x - x.min()) / (x.max() - x.min()) - 1                      # dataset.py:85
+    tgrid = np.linspace(0.0, 4.0, nt)
+    u = np.stack([np.sin(3 * x[None, :] + 4 * tgrid[:, None] + rng.uniform(0, 6)) + 0.3 * np.cos(5 * x[None, :] - tgrid[:, None])
+                  for _ in range(B)])                                     # [B, nt, L]
+    odd = np.arange(1, L, 2)
+    batch = {"t": [], "lr_frames": [], "hr_points": [], "coords_hr": [], "coords_lr": []}
+    for b in range(B):
+        sel = np.sort(rng.choice(odd, samples, replace=False))
+        batch["t"].append(tgrid)
+        batch["lr_frames"].append(u[b][:, None, ::2])
+        batch["hr_points"].append(u[b][:, sel][..., None])
+        batch["coords_hr"].append(x[sel][:, None])
+        batch["coords_lr"].append(x[::2][:, None])
+    return {k: torch.from_numpy(np.stack(v)).float() for k, v in batch.items()}
+
+
+def _c2_models(gemm=None):
+    import types
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    hp = types.SimpleNamespace(lr=1e-3, weight_decay=0.0, factor=0.3, step_size=50, loss="l1", time_slice=25, latent_dim=128,
+                               num_message_passing_steps=5, mlp_layers=4, mlp_hidden=128, radius=0.08, n_chan=128,
+                               teacher_forcing=False, codec_neighbors=4, noise=0, interpolation="area", coord_dim=1)
+    oracle = O.build("magnet_gnn", hp).eval()
+    fill_state_dict(oracle, 22)
+    model = FACTORY["magnet_gnn"](hp).eval()
+    model.load_state_dict(oracle.state_dict())
+    return hp, oracle, model.cuda()
+
+
+def test_config2_exactly_16_queries_250_steps():
+    """configs[1] as stated: 25 LR nodes + 16 INR queries, nt = 250, T = 25 -> 9 forward calls.  The LR graph has only self
+    loops (spacing 2/24 > r = 0.08); fp32-class path against the oracle (the reference class cannot take 1-D
+    coordinates)."""
+    hp, oracle, model = _c2_models()
+    batch = _c2_batch(16, seed=2)
+    assert batch["coords_hr"].shape == (2, 16, 1) and batch["lr_frames"].shape == (2, 250, 1, 25)
+    calls = []
+    orig = model.forward
+    model.forward = lambda *a: (calls.append(1) or orig(*a))
+    pred = model.validation_step({k: v.cuda() for k, v in batch.items()}, 0)
+    assert len(calls) == 9 and pred.shape == (2, 225, 16 + 25, 1)
+    with torch.no_grad():
+        want = oracle.validation_step(batch)
+    assert rel_l2(pred, want) < 5 * OUT_TOL, rel_l2(pred, want)
+    assert abs(float(model.logged["val_mae_loss"]) - float(oracle.logged["val_mae_loss"])) < 2e-5
+
+
+def test_config2_bf16_deviation(monkeypatch):
+    """configs[1] asks for bf16: the opt-in reduced-precision mode on that exact 1-D case, reported as a measured deviation
+    from the fp32-class result, bounded between the parity bar and 5e-2 - never parity."""
+    hp, oracle, ref_model = _c2_models()
+    batch = _c2_batch(16, seed=2)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    ref = ref_model.validation_step(cb, 0)
+    monkeypatch.setenv("MAGNET_GEMM", "bf16")
+    hp2, _, model = _c2_models()
+    pred = model.validation_step(cb, 0)
+    dev = rel_l2(pred, ref)
+    print("config 2 bf16 rollout deviation vs fp32-class path:", dev)
+    assert OUT_TOL < dev < 5e-2
+
+
+def _full_size_checks(model, batch, n_lr, Wq, radius):
+    """size-independent properties of a full-size MAgNet rollout (the CPU oracle would need minutes): graph against a
+    brute-force restatement on a sub-block, bitwise determinism, independence of a trajectory from its batch mates,
+    dt-linearity of the Euler update, finite outputs, the in-degree spread of the swapped capped graph (Q3 / Q11)."""
+    from oracle import pyg_semantics as S
+    pred = model.validation_step(batch, 0)
+    assert torch.isfinite(pred).all()
+    assert torch.equal(pred, model.validation_step(batch, 0))                         # bitwise deterministic
+    topo = [t for (tag, _), t in model._topo_cache.topologies() if (tag[0] if isinstance(tag, tuple) else tag) == "all"][-1]
+    csr = topo.csr
+    B = topo.n_graphs
+    n = n_lr + Wq * Wq
+    assert csr.N == B * n
+    deg = (csr.rowptr[1:] - csr.rowptr[:-1]).cpu()
+    src, tgt = csr.src.long().cpu(), csr.tgt.long().cpu()
+    assert bool((src // n == tgt // n).all())                                          # no edge crosses trajectories
+    out_deg = torch.bincount(src, minlength=B * n)
+    assert int(out_deg.max()) == 32                                                    # the cap of Q3 is active ...
+    assert int(deg.min()) == 0 and int(deg.max()) > 300                               # ... so the swapped graph is skewed (Q11)
+    # found-neighbour lists of a sample of queries of trajectory 0 (LR nodes, first / middle / last INR queries) against the
+    # restated torch_cluster rule (oracle/pyg_semantics.radius: ascending index, strict d^2 < r^2, first 32 kept)
+    flat = topo.flat[:n].cpu()
+    g = torch.Generator().manual_seed(1)
+    sel = torch.unique(torch.cat([torch.arange(0, 8), torch.tensor([n_lr - 1, n_lr, n_lr + 1, n - 1]),
+                                  torch.randint(0, n_lr, (60,), generator=g), torch.randint(n_lr, n, (180,), generator=g)]))
+    zeros = lambda k: torch.zeros(k, dtype=torch.long)  # noqa: E731
+    qf = S.radius(flat, flat[sel], radius, zeros(n), zeros(sel.numel()), 32)
+    in0 = src < n                                                                      # edges of trajectory 0 (src = the query)
+    src0, tgt0 = src[in0], tgt[in0]
+    for k, q in enumerate(sel.tolist()):
+        want = qf[1][qf[0] == k]
+        got = torch.sort(tgt0[src0 == q]).values
+        assert torch.equal(got, want), (q, got[:5], want[:5])
+    return pred
+
+
+def test_config5_full_size_properties():
+    """configs[4]: magnet_gnn, 256 LR nodes of a 512-node concentrated irregular mesh -> 256 x 256 INR queries, shipped widths"""
+    import types
+    import bench
+    from magnet_amd.models.factory import FACTORY
+    torch.manual_seed(0)
+    model = FACTORY["magnet_gnn"](types.SimpleNamespace(**bench.MAGNET_HP["magnet_gnn"])).cuda().eval()
+    batch, nodes = bench.synthetic_magnet_batch("magnet_gnn", 2, 256, 5, "cuda")
+    assert nodes == 256 + 65536
+    pred = _full_size_checks(model, batch, 256, 256, 0.08)
+    alone = model.validation_step({k: v[1:2] for k, v in batch.items()}, 0)
+    assert rel_l2(alone, pred[1:2]) < 1e-6
+    # Euler update (magnet_gnn.py:359-369): out - last is linear in (t[T + k] - t[T - 1]) for fixed network input
+    T = 10
+    args = [batch["lr_frames"][:1, :T], batch["coords_lr"][:1], batch["coords_hr"][:1], batch["t"][:1, :2 * T], batch["hr_points"][:1, T - 1]]
+    o1 = model(*args)[0] - args[4][:, None]
+    t2 = args[3].clone()
+    t2[:, T:] = t2[:, T - 1:T] + 2 * (t2[:, T:] - t2[:, T - 1:T])
+    o2 = model(args[0], args[1], args[2], t2, args[4])[0] - args[4][:, None]
+    assert rel_l2(o2, 2 * o1) < 1e-5
+
+
+def test_config4b_full_size_shipped_hparams_properties():
+    """configs[3], magnet_cnn_2d half: 64 x 64 LR grid -> 256 x 256 queries at the shipped hyper-parameters (K = 10 hops,
+    16 ResBlocks, n_chan 128, latent 32, radius 0.1)"""
+    import types
+    import bench
+    from magnet_amd.models.factory import FACTORY
+    torch.manual_seed(0)
+    hp = bench.MAGNET_HP["magnet_cnn_2d"]
+    assert hp["num_message_passing_steps"] == 10 and hp["res_layers"] == 16 and hp["n_chan"] == 128
+    model = FACTORY["magnet_cnn_2d"](types.SimpleNamespace(**hp)).cuda().eval()
+    batch, nodes = bench.synthetic_magnet_batch("magnet_cnn_2d", 2, 256, 6, "cuda")
+    assert nodes == 64 * 64 + 65536
+    pred = _full_size_checks(model, batch, 64 * 64, 256, 0.1)
+    alone = model.validation_step({k: v[1:2] for k, v in batch.items()}, 0)
+    assert rel_l2(alone, pred[1:2]) < 1e-6
+    # the EDSR feature map against torch's own convolutions at this size
+    T = 10
+    x_t = batch["lr_frames"][:1, :T]
+    feat = model.encoder(x_t.reshape(1, T, 64, 64))
+    enc = model.encoder
+    with torch.no_grad():
+        h0 = torch.nn.functional.conv2d(x_t.reshape(1, T, 64, 64), enc.head_conv.weight, enc.head_conv.bias, padding=1)
+        h = h0
+        for blk in enc.res_layers:
+            h = h + torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(h, blk.conv_1.weight, blk.conv_1.bias, padding=1)),
+                                               blk.conv_2.weight, blk.conv_2.bias, padding=1)
+        want = torch.nn.functional.conv2d(h, enc.tail_conv.weight, enc.tail_conv.bias, padding=1) + h0
+    assert rel_l2(feat, want) < 2e-5       # torch's MIOpen convolutions are themselves only fp32-roundoff accurate

@@ -1,0 +1,269 @@
+"""GPU regression tests for the round-1 review findings: stale topology / launch-plan caches, optimizer checkpoint
+interchange with torch.optim.Adam, the fp16x3 range guard, training-time input noise, the 'knn' / 'sph' INR blends and
+the multi-rank launcher of bench.py."""
+import json
+import os
+import subprocess
+import sys
+import types
+
+import pytest
+import torch
+
+from tests.helpers import forward_args, load_case, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pair(tag, **over):
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    name, hp, salt, batch, d = load_case(tag)
+    for k, v in over.items():
+        setattr(hp, k, v)
+    oracle = O.build(name, hp).eval()
+    fill_state_dict(oracle, salt)
+    model = FACTORY[name](hp).eval()
+    model.load_state_dict(oracle.state_dict())
+    return name, hp, batch, d, oracle, model.cuda()
+
+
+# ------------------------------------------------------------------------------------------- topology cache
+def test_new_query_coordinates_rebuild_the_graph():
+    """MAgNet training draws new query coordinates every step (reference datamodule/dataset.py:95, dataset_2d.py:111).  In
+    round 1 the cache key was (address, version, shape): the previous step's tensor was freed, the caching allocator handed
+    its address to the next one and the stale joint graph / k-NN table was used.  Now an entry keeps its key tensor alive
+    (so the address cannot come back) - same-shape new coordinates, fresh or written in place, must give the oracle's
+    result of THOSE coordinates."""
+    name, hp, batch, d, oracle, model = _pair("magnet_gnn_tiny")
+    T = hp.time_slice
+    g = torch.Generator().manual_seed(5)
+    outs, wants, ptrs = [], [], []
+    for step in range(3):
+        b = dict(batch)
+        b["coords_hr"] = (torch.rand(batch["coords_hr"].shape, generator=g) * 2 - 1)
+        args = forward_args(name, hp, b)
+        dev_args = [a.cuda() for a in args]           # fresh device tensors; the previous step's are freed here
+        ptrs.append(dev_args[2].data_ptr())
+        outs.append([o.cpu() for o in model(*dev_args)])
+        with torch.no_grad():
+            wants.append(oracle(*args))
+        del dev_args
+    for got, want in zip(outs, wants):
+        for g_, w_ in zip(got, want):
+            assert rel_l2(g_, w_) < 1e-5
+    # the same storage rewritten in place (same address, new version)
+    args = [a.cuda() for a in forward_args(name, hp, batch)]
+    model(*args)
+    new_hr = torch.rand(batch["coords_hr"].shape, generator=g) * 2 - 1
+    args[2].copy_(new_hr)
+    got = model(*args)
+    b = dict(batch, coords_hr=new_hr)
+    with torch.no_grad():
+        want = oracle(*forward_args(name, hp, b))
+    for g_, w_ in zip(got, want):
+        assert rel_l2(g_, w_) < 1e-5
+
+
+def test_mpnn_mesh_change_rebuilds_the_graph():
+    """irregular MPNN meshes change from batch to batch (datamodule/dataset_2d.py:38-59)"""
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    name, hp, salt, batch, d = load_case("mpnn_1d")
+    oracle = O.build(name, hp).eval()
+    fill_state_dict(oracle, salt)
+    model = FACTORY[name](hp).eval()
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda()
+    ptrs = []
+    for scale in (1.0, 0.7, 1.3):
+        b = {k: v.clone() for k, v in batch.items()}
+        b["x"] = batch["x"] * scale                                    # same shape, different spacing -> different radius graph
+        cb = {k: v.cuda() for k, v in b.items()}
+        ptrs.append(cb["x"].data_ptr())
+        pred = model.validation_step(cb, 0).cpu()
+        del cb
+        with torch.no_grad():
+            want = oracle.validation_step(b)
+        assert rel_l2(pred, want) < 5e-5, scale
+
+
+def test_equal_coordinates_in_a_new_tensor_reuse_the_graph():
+    name, hp, batch, d, oracle, model = _pair("magnet_gnn_tiny")
+    args = forward_args(name, hp, batch)
+    a1 = [a.cuda() for a in args]
+    a2 = [a.cuda() for a in args]                                      # equal content, different storage (both alive)
+    o1 = model(*a1)
+    topo_before = [t for _, t in model._topo_cache.topologies()]
+    o2 = model(*a2)
+    topo_after = [t for _, t in model._topo_cache.topologies()]
+    assert len(topo_before) == len(topo_after) and all(any(x is y for y in topo_before) for x in topo_after)
+    assert all(torch.equal(x, y) for x, y in zip(o1, o2))
+
+
+# ------------------------------------------------------------------------------------------- EDSR launch plans
+@pytest.mark.parametrize("tag", ["magnet_cnn_1d", "magnet_cnn_2d"])
+def test_validation_after_fused_adam_steps_uses_the_new_weights(tag):
+    """Lightning's order: sanity validation -> train -> validation.  The EDSR launch plans built by the first validation
+    hold pointers to the packed weights; FusedAdam rewrites the parameters behind torch's version counters."""
+    from magnet_amd.models.factory import FACTORY
+    name, hp, batch, d, oracle, model = _pair(tag)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    before = model.validation_step(cb, 0).clone()
+    model.train()
+    opt = model.configure_optimizers()["optimizer"]
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        model.training_step(cb, 0).backward()
+        opt.step()
+    model.eval()
+    after = model.validation_step(cb, 0)
+    fresh = FACTORY[name](hp).eval()
+    fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    want = fresh.cuda().validation_step(cb, 0)
+    assert rel_l2(after, before) > 1e-4, "three Adam steps at lr 1e-3 must move the prediction"
+    assert torch.equal(after, want)
+
+
+# ------------------------------------------------------------------------------------------- optimizer checkpoints
+def test_fused_adam_and_torch_adam_exchange_checkpoints():
+    """state_dict() is torch.optim.Adam's layout (what the reference's Lightning checkpoints hold): a FusedAdam checkpoint
+    resumes under torch.optim.Adam and the other way round, and both continue like an uninterrupted torch.optim.Adam."""
+    from magnet_amd.optim import FusedAdam
+    shapes = [(64, 33), (7,), (5, 3, 2)]
+
+    def make():
+        torch.manual_seed(3)
+        return [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+
+    grads = [[torch.randn(*s, device="cuda") for s in shapes] for _ in range(6)]
+
+    def run(opt, params, gs):
+        for g in gs:
+            for p, gg in zip(params, g):
+                p.grad = gg.clone()
+            opt.step()
+
+    ref = make()
+    oref = torch.optim.Adam(ref, lr=1e-2, weight_decay=1e-3)
+    run(oref, ref, grads)
+    for first, second in ((FusedAdam, torch.optim.Adam), (torch.optim.Adam, FusedAdam)):
+        a = make()
+        oa = first(a, lr=1e-2, weight_decay=1e-3)
+        run(oa, a, grads[:3])
+        sd = oa.state_dict()
+        assert sorted(sd["state"].keys()) == [0, 1, 2] and set(sd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"}
+        assert "magnet_flat" not in sd
+        b = make()
+        with torch.no_grad():
+            for p, q in zip(b, a):
+                p.copy_(q)
+        ob = second(b, lr=1e-2, weight_decay=1e-3)
+        ob.load_state_dict(sd)
+        run(ob, b, grads[3:])
+        for p, q in zip(b, ref):
+            assert rel_l2(p, q) < 1e-6, (first.__name__, second.__name__)
+    # a state that does not cover the parameters is refused, not silently dropped
+    c = make()
+    oc = FusedAdam(c, lr=1e-2)
+    bad = oref.state_dict()
+    bad["state"] = {0: bad["state"][0]}
+    with pytest.raises(ValueError):
+        oc.load_state_dict(bad)
+
+
+# ------------------------------------------------------------------------------------------- fp16x3 range guard
+def test_large_magnitude_input_fails_loudly_in_fp16x3_and_passes_in_bf16x6():
+    """fp16x3 holds every GEMM operand as two fp16 pieces: |value| >= 65504 would become inf silently.  The guard turns
+    that into an OverflowError naming the full-range mode; bf16x6 on the same input meets the parity bar."""
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    name, hp, salt, batch, d = load_case("mpnn_2d")
+    big = {k: v.clone() for k, v in batch.items()}
+    big["u"] = batch["u"] * 1.0e5                                       # |u| ~ 2e5
+    oracle = O.build(name, hp).eval()
+    fill_state_dict(oracle, salt)
+    with torch.no_grad():
+        want = oracle.validation_step(big)
+    for mode in ("fp16x3", "bf16x6"):
+        hp_m = types.SimpleNamespace(**vars(hp), gemm=mode, edge_gemm=mode)
+        model = FACTORY[name](hp_m).eval()
+        model.load_state_dict(oracle.state_dict())
+        model = model.cuda()
+        cb = {k: v.cuda() for k, v in big.items()}
+        if mode == "fp16x3":
+            with pytest.raises(OverflowError, match="bf16x6"):
+                model.validation_step(cb, 0)
+            ok = model.validation_step({k: v.cuda() for k, v in batch.items()}, 0)     # the status word was cleared
+            assert torch.isfinite(ok).all()
+        else:
+            pred = model.validation_step(cb, 0)
+            assert rel_l2(pred, want) < 5e-5
+
+
+def test_overflow_inside_the_chain_is_caught_at_the_output():
+    """inputs below 65504 whose hidden activations leave the fp16 range: the prediction is non-finite from finite inputs"""
+    from magnet_amd.models.factory import FACTORY
+    from oracle.weightgen import fill_state_dict
+    name, hp, salt, batch, d = load_case("mpnn_1d")
+    model = FACTORY[name](hp).eval()
+    fill_state_dict(model, salt)
+    with torch.no_grad():
+        for p in model.embedding_mlp.parameters():
+            p.mul_(1000.0)                                             # node_in ~ 1 -> embedding output ~ 1e6 after two Linears
+    model = model.cuda()
+    cb = {k: v.cuda() for k, v in batch.items()}
+    assert float(cb["u"].abs().max()) < 100
+    with pytest.raises(OverflowError, match="non-finite"):
+        model.validation_step(cb, 0)
+
+
+# ------------------------------------------------------------------------------------------- noise, interpolation modes
+def test_training_noise_matches_the_reference_draw_order():
+    """magnet_gnn.py:402-407, 424-428: noise * torch.randn(shape) from the host generator, input first, then hr_last, again
+    after every forward call.  Same seed -> same loss as the oracle's restatement of that loop."""
+    from tests.helpers import oracle_magnet_gnn_grads
+    name, hp, batch, d, oracle, model = _pair("magnet_gnn_tiny", noise=0.05)
+    model.train()
+    torch.manual_seed(77)
+    want_loss, _ = oracle_magnet_gnn_grads(oracle, batch, hp.teacher_forcing, hp.loss, dtype=torch.float32, noise=hp.noise)
+    torch.manual_seed(77)
+    loss = model.training_step({k: v.cuda() for k, v in batch.items()}, 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - want_loss) < 2e-5 * max(1.0, abs(want_loss))
+    torch.manual_seed(78)
+    other = model.training_step({k: v.cuda() for k, v in batch.items()}, 0)
+    assert abs(float(other.detach()) - want_loss) > 1e-5                 # the noise really enters
+
+
+@pytest.mark.parametrize("interp", ["knn", "sph"])
+def test_inr_interpolation_modes_match_the_oracle(interp):
+    """magnet_gnn.py:269-272, 279: 'knn' (inverse squared distance) and 'sph' ((1 - L d^2)^3) weights of the two nearest"""
+    name, hp, batch, d, oracle, model = _pair("magnet_gnn_tiny", interpolation=interp)
+    args = forward_args(name, hp, batch)
+    with torch.no_grad():
+        want = oracle(*args)
+    got = model(*[a.cuda() for a in args])
+    for g_, w_, key in zip(got, want, ("out_hr", "out_lr", "hr_points")):
+        assert rel_l2(g_, w_) < 1e-5, (interp, key, rel_l2(g_, w_))
+
+
+# ------------------------------------------------------------------------------------------- bench.py launcher
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed.run environment starts two fresh ranks itself; gloo lets them
+    share this box's single GPU.  The line must say n_gpus = 2."""
+    env = dict(os.environ, MAGNET_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mesh", "64", "--traj", "1", "--steps", "2",
+                        "--warmup", "1", "--train-steps", "1", "--no-cpu-baseline", "--no-extra-cases"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_trajectories"] == 2 and line["value"] > 0
+    assert line["training_step"]["ms_per_step"] > 0
