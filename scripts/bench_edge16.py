@@ -1,0 +1,56 @@
+"""Dev microbench: the fused MPNN edge kernel k_mpnn_edge16 (16-edge tiles, fp16x3) on the 256^2 bench graph, against the
+fp32-MFMA kernel's result.  usage: python scripts/bench_edge16.py [W] [B]"""
+import os, sys, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from magnet_amd import ops
+from magnet_amd.models.factory import FACTORY
+from magnet_amd.packing import pack, pack_edge16_fp16x2
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+hp = types.SimpleNamespace(lr=1e-3, weight_decay=0, factor=0.3, step_size=50, loss="l1", hidden_features=128,
+                           hidden_layer=5, time_window=10, teacher_forcing=False, neighbors=4)
+torch.manual_seed(0)
+m = FACTORY["mpnn_2d"](hp).cuda().eval()
+g = torch.linspace(0, 1, W)
+x0 = torch.stack(torch.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2).cuda()
+csr = m._build_topology(x0, B).csr
+N, E, H = csr.N, csr.E, 128
+A, Bm, agg = (torch.randn(N, H, device="cuda") for _ in range(3))
+partials = torch.empty(ops.edge_scratch_floats(E), device="cuda")
+m2 = m.gnn_layers[0].message_net_2[0]
+w32, w16 = pack(m2.weight, m2.bias, "fp32"), pack_edge16_fp16x2(m2.weight, m2.bias)
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+ops.mpnn_edge(A, Bm, csr, w32[0], w32[1], agg, partials)
+ref = agg.clone()
+A2, B2 = A * ops.LOG2E, Bm * ops.LOG2E
+for l2e in (False, True):
+    agg.fill_(float("nan"))
+    Ax, Bx = (A2, B2) if l2e else (A, Bm)
+    ms = min(timeit(lambda: ops.mpnn_edge16(Ax, Bx, csr, w16[0], w16[1], agg, partials, l2e=l2e)) for _ in range(3))
+    print(f"k_mpnn_edge16 l2e={l2e} : {ms:.4f} ms  {2 * E * H * H / ms / 1e9:.1f} TFLOP/s-eq "
+          f"(incl. fix-up), frac of 833 = {2 * E * H * H / ms / 1e9 / 833.3:.3f}, rel-diff vs fp32 kernel {float((agg - ref).norm() / ref.norm()):.2e} "
+          f"nan={int(torch.isnan(agg).sum())}")
+
+from magnet_amd.packing import pack as _pack
+w7 = _pack(m2.weight, m2.bias, "fp16x3")
+for l2e in (False, True):
+    agg.fill_(float("nan"))
+    Ax, Bx = (A2, B2) if l2e else (A, Bm)
+    ms = min(timeit(lambda: ops.mpnn_edge(Ax, Bx, csr, w7[0], w7[1], agg, partials, l2e=l2e)) for _ in range(3))
+    print(f"k_mpnn_edge7 (32-edge tiles, 1 wave/SIMD) l2e={l2e} : {ms:.4f} ms  frac of 833 = "
+          f"{2 * E * H * H / ms / 1e9 / 833.3:.3f}, rel-diff vs fp32 kernel {float((agg - ref).norm() / ref.norm()):.2e} nan={int(torch.isnan(agg).sum())}")
