@@ -243,14 +243,19 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
         Emax = max(m for _, _, m in ev)
         sel = [(s_, e_) for s_, e_, m in ev if m == Emax]           # the joint-graph launches (the LR-only graph is tiny)
         ms = sum(s_.elapsed_time(e_) for s_, e_ in sel) / len(sel)
-        flops = 2.0 * Emax * (3 * D * H + 3 * H * H + H * D)
+        # flops of the formulation EXECUTED: with hidden <= latent the first Linear is factored per node (its x_i / x_j thirds
+        # run once per node, magnet_amd/models/magnet_common.py:pack_interaction_edge), so the per-edge chain has K0 = D
+        factored = H <= D
+        flops = 2.0 * Emax * ((1 if factored else 3) * D * H + 3 * H * H + H * D)
+        flops_reference = 2.0 * Emax * (3 * D * H + 3 * H * H + H * D)
         ach = flops / (ms * 1e-3) / 1e12
         nprod = SPLIT_PRODUCTS.get(mode, 1)
         peak = MFMA_BF16_PEAK_TFLOPS / nprod if mode in SPLIT_PRODUCTS else MFMA_F32_PEAK_TFLOPS
         roof = {"kernel": f"k_mlp_bf16<5 Linears, hidden {H}, LayerNorm, CSR-mean epilogue>", "bound": "mfma",
                 "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None, "launch_ms": round(ms, 4), "launches_timed": len(sel), "flops_per_launch": flops,
-                "gemm_mode": mode, "edges": Emax}
+                "gemm_mode": mode, "edges": Emax, "first_layer_factored_per_node": factored,
+                "flops_per_launch_reference_formulation": flops_reference}
         if Wq == 256 and B == 1 and mode in SPLIT_PRODUCTS:      # the recorded PMC passes are of this exact workload
             roof["traffic"], roof["traffic_source"] = measured_traffic(f"{name}:edge_mlp")
     # ---- training step (autograd Functions with HIP backward kernels, one gradient all-reduce, fused Adam) - unfused,
@@ -296,6 +301,37 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
                    "trajectories_per_gpu": B, "global_trajectories": B * world,
                    "parallelism": f"batch-shard x{world}, no data-path collective"},
         "roofline": roof, "cpu_baseline": None, "training_step": train}
+
+
+def bench_c1(dev, reps=50):
+    """BASELINE.json configs[0] on the GPU (the launch-bound regime): mpnn 1-D, N = 50, B = 2, tw = 25, nt = 250 - a 9-forward
+    free-running rollout (validation_step), replayed from ONE hipGraph (the default for small graphs, magnet_amd/graphs.py) and,
+    for comparison, enqueued kernel by kernel (hip_graph = False).  Host wall time per rollout, graph topology cached."""
+    from magnet_amd.models.factory import FACTORY
+    hp = dict(lr=1e-3, weight_decay=0.0, factor=0.3, step_size=50, loss="l1", hidden_features=128, hidden_layer=5, time_window=25,
+              teacher_forcing=False, neighbors=3)
+    B, N, nt = 2, 50, 250
+    batch = {"u": torch.randn(B, N, nt, generator=torch.Generator().manual_seed(0)), "x": torch.linspace(0, 16, N)[None, :, None].repeat(B, 1, 1),
+             "t": torch.linspace(0, 4, nt)[None].repeat(B, 1)}
+    cb = {k: v.to(dev) for k, v in batch.items()}
+    out = {}
+    for mode, flag in (("graph", True), ("eager", False)):
+        torch.manual_seed(0)                               # the same weights in both models
+        m = FACTORY["mpnn"](types.SimpleNamespace(**hp, hip_graph=flag)).to(dev).eval()
+        for _ in range(3):
+            ref = m.validation_step(cb, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.validation_step(cb, 0)
+        torch.cuda.synchronize()
+        out[mode] = ((time.perf_counter() - t0) / reps, ref)
+    same = bool(torch.equal(out["graph"][1], out["eager"][1]))
+    steps = (nt - 25) // 25 * 25
+    return {"workload": "mpnn 1-D, 50-node mesh, B = 2, time_window = 25, nt = 250: 9-forward free-running rollout",
+            "ms_per_rollout": round(out["graph"][0] * 1e3, 3), "ms_per_rollout_eager": round(out["eager"][0] * 1e3, 3),
+            "value": B * N * steps / out["graph"][0], "unit": "mesh-node-updates/s", "graph_replay_equals_eager_bitwise": same,
+            "how": "whole rollout replayed from one hipGraph (default when B*N <= 4096 rows)"}
 
 
 def free_port():
@@ -373,7 +409,9 @@ def main():
         return
 
     torch.manual_seed(0)
-    model = FACTORY["mpnn_2d"](types.SimpleNamespace(**HP)).to(dev).eval()
+    # hip_graph = False: every timed step rebuilds the radius graph + CSR (a host-visible edge count), which a replayed hipGraph
+    # would skip; at the metric size the default "auto" is eager anyway, the flag only matters for small --mesh runs
+    model = FACTORY["mpnn_2d"](types.SimpleNamespace(**HP, hip_graph=False)).to(dev).eval()
     batch = synthetic_batch(W, B, 1000 + rank, dev)          # every rank owns B different trajectories
 
     def step():
@@ -519,6 +557,8 @@ def main():
         for key, name in (("c4b", "magnet_cnn_2d"), ("c5", "magnet_gnn")):
             extras[key] = bench_magnet(name, 1, max(1, min(K, 10)), max(1, min(Wm, 2)), 256, min(args.train_steps, 2), dev, rank, world,
                                        dist, max_over_ranks)
+        if rank == 0:
+            extras["c1"] = bench_c1(dev)
 
     if world > 1:
         dist.barrier()

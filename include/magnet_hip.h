@@ -72,6 +72,11 @@ typedef struct {
     int32_t groups_in_block; /* 0/1: the G groups are workgroup columns (gridDim.y); G: every workgroup runs its rows through
                               * the G groups one after the other (the input rows are then read from HBM once) */
     int64_t y_group_stride;  /* floats between the outputs of consecutive groups; 0 = OT*32 (neighbouring columns) */
+    magnet_src_t pre[2];     /* nl > 1 only, p == NULL = off: rows added to the first
+                              * Linear's pre-activation, pre[s].p[(idx ? idx[row] : row) * ld + 0 .. first-layer width).  This is
+                              * how a Linear over torch.cat([x_i, x_j, e]) (InteractionNetwork.message, models/magnet_gnn.py:79-83)
+                              * runs with K = width(e) only: W [x_i, x_j, e] + b = (Wa x)[i] + (Wb x)[j] + Wc e + b, the two
+                              * per-node products computed once per node instead of once per edge (col / scale / rdiv unused) */
 } magnet_mlp_args_t;
 
 /* Fused gather/concat -> NL x (Linear [+ activation]) -> [LayerNorm] -> store | +residual | CSR mean.

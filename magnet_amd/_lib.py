@@ -42,7 +42,7 @@ class MlpArgs(C.Structure):
                 ("y", C.c_void_p), ("ldy", C.c_int32), ("ncols", C.c_int32),
                 ("res", C.c_void_p), ("ldres", C.c_int32),
                 ("tgt", C.c_void_p), ("rowptr", C.c_void_p), ("partials", C.c_void_p), ("ncolgroups", C.c_int32),
-                ("groups_in_block", C.c_int32), ("y_group_stride", C.c_int64)]
+                ("groups_in_block", C.c_int32), ("y_group_stride", C.c_int64), ("pre", Src * 2)]
 
 
 def declared_symbols() -> list[str]:

@@ -67,6 +67,7 @@ struct MagnetMlpArgs {
     int32_t ncolgroups;            // NL == 1 only: > 1 splits the output columns over gridDim.y, group g uses layer[g] (own packed slice)
     int32_t groups_in_block;       // > 1 (= ncolgroups): the groups run one after the other inside each workgroup instead of over gridDim.y
     int64_t y_group_stride;        // floats between the outputs of consecutive groups; 0 = OT*32 columns of the same rows
+    MagnetSrc pre[2];              // gathered rows added to the first Linear's pre-activation (split-GEMM kernels), p == nullptr: off
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -109,6 +110,24 @@ __device__ __forceinline__ void init_bias(f32x16 (&out)[NT], const float* __rest
             out[nt][4 * g + 1] = t[1];
             out[nt][4 * g + 2] = t[2];
             out[nt][4 * g + 3] = t[3];
+        }
+    }
+}
+
+// out[nt] += src.p[(idx ? idx[row] : row) * ld + the lane's columns of tile nt]: a gathered row in the accumulator layout
+template <int NT>
+__device__ __forceinline__ void add_rows(f32x16 (&out)[NT], const MagnetSrc& src, int row, int half) {
+    const int r = src.idx ? src.idx[row] : row;
+    const float* p = src.p + (size_t)r * src.ld + 4 * half;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p + nt * 32 + 8 * g);
+            out[nt][4 * g + 0] += t[0];
+            out[nt][4 * g + 1] += t[1];
+            out[nt][4 * g + 2] += t[2];
+            out[nt][4 * g + 3] += t[3];
         }
     }
 }

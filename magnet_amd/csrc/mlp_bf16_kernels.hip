@@ -186,6 +186,10 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                 x = xn;
             }
             fold_tiles<NT0, MODE>(acc, accc);
+            if (NL > 1) {                                  // per-node products of a factored first layer (magnet_hip.h: pre)
+                if (a.pre[0].p) add_rows<NT0>(acc, a.pre[0], row, half);
+                if (a.pre[1].p) add_rows<NT0>(acc, a.pre[1], row, half);
+            }
             if (NL == 1) {
     #pragma unroll
                 for (int t = 0; t < NT0; ++t) out[t < OT ? t : 0] = acc[t];

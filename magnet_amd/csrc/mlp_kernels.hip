@@ -43,6 +43,8 @@ __global__ void __launch_bounds__(256) k_mlp(const MagnetMlpArgs a) {
     } else {
         f32x16 h0[HT], h1[HT];
         stream_layer<HT>(a, a.layer[0], h0, row, lane);
+        if (a.pre[0].p) add_rows<HT>(h0, a.pre[0], row, half);       // per-node products of a factored first layer (magnet_hip.h: pre)
+        if (a.pre[1].p) add_rows<HT>(h0, a.pre[1], row, half);
 #pragma unroll
         for (int t = 0; t < HT; ++t) apply_act<ACT>(h0[t]);
         // middle layers, ping-pong h0 <-> h1 (fully unrolled so register arrays stay static)

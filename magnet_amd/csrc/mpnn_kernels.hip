@@ -296,6 +296,57 @@ __global__ void __launch_bounds__(1024) k_colstat_final(const float* __restrict_
         var[(size_t)g * H + c] = tot / n_rows;
     }
 }
+// Small graphs (rows_per_graph <= NORM_SMALL_ROWS, the launch-bound 1-D configs): statistics AND normalisation in ONE launch.
+// One workgroup per (graph, 32-channel window), 32 row groups x 32 channels; two passes over the graph's rows (the second
+// one hits L1/L2): mean, then the centred second moment - fixed summation order, deterministic.
+#define NORM_SMALL_ROWS 2048
+__global__ void __launch_bounds__(1024) k_instance_norm_small(const float* __restrict__ x, int rows_per_graph, int H, float eps,
+                                                              float* __restrict__ y, float* __restrict__ mean,
+                                                              float* __restrict__ var) {
+    __shared__ float sm[32][33];
+    __shared__ float stat[2][32];
+    const int g = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, grp = threadIdx.x >> 5;
+    const float n_rows = (float)rows_per_graph;
+    const float* xg = x + (size_t)g * rows_per_graph * H;
+    float acc = 0.f;
+    if (c < H)
+        for (int r = grp; r < rows_per_graph; r += 32) acc += xg[(size_t)r * H + c];
+    sm[grp][cl] = acc;
+    __syncthreads();
+    if (grp == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) tot += sm[q][cl];
+        stat[0][cl] = tot / n_rows;
+    }
+    __syncthreads();
+    const float m = stat[0][cl];
+    acc = 0.f;
+    if (c < H)
+        for (int r = grp; r < rows_per_graph; r += 32) {
+            const float d = xg[(size_t)r * H + c] - m;
+            acc += d * d;
+        }
+    __syncthreads();
+    sm[grp][cl] = acc;
+    __syncthreads();
+    if (grp == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) tot += sm[q][cl];
+        stat[1][cl] = tot / n_rows;
+        if (c < H) {
+            mean[(size_t)g * H + c] = m;
+            var[(size_t)g * H + c] = stat[1][cl];
+        }
+    }
+    __syncthreads();
+    if (c < H) {
+        const float v = stat[1][cl];
+        float* yg = y + (size_t)g * rows_per_graph * H;
+        for (int r = grp; r < rows_per_graph; r += 32) yg[(size_t)r * H + c] = (xg[(size_t)r * H + c] - m) / sqrtf(v + eps);
+    }
+}
 __global__ void k_norm_apply(const float* __restrict__ x, const float* __restrict__ mean,
                              const float* __restrict__ var, int rows_per_graph, int H, float eps, long total,
                              float* __restrict__ y) {
@@ -424,6 +475,11 @@ extern "C" int magnet_instance_norm_f32(const float* x, int n_graphs, int rows_p
     float* mean = part + (size_t)n_graphs * nchunks * H;
     float* var = mean + (size_t)n_graphs * H;
     hipStream_t s = (hipStream_t)stream;
+    if (rows_per_graph <= NORM_SMALL_ROWS) {
+        hipLaunchKernelGGL(k_instance_norm_small, dim3(n_graphs, (H + 31) / 32), dim3(1024), 0, s, x, rows_per_graph, H, eps, y, mean,
+                           var);
+        LAUNCH_CHECK();
+    }
     float* part_m2 = var + (size_t)n_graphs * H;
     const int nsup = (nchunks + NORM_SUB - 1) / NORM_SUB;     // the workspace keeps its documented per-64-row layout; fewer slots are used
     hipLaunchKernelGGL(k_colstat_partial, dim3(nsup, n_graphs), dim3(128), 0, s, x, rows_per_graph, H, part, part_m2);

@@ -87,8 +87,10 @@ extern "C" int magnet_mpnn_readout_f32(const float* h, const float* u, int n, in
     if (n <= 0) return 0;
     const int L1 = (128 - k1) / s1 + 1;
     if (L1 > 64 || tw > 64 || L1 - k2 + 1 != tw) return -2;
+    // lane-per-node kernels: one long serial block per lane - right when there are nodes enough to fill the chip; below that
+    // (the launch-bound 1-D configs) the wave-per-node kernel finishes sooner (n = 100: 46 us vs the time of a few waves)
 #define READOUT_CASE(K1_, S1_, K2_, TW_)                                                                                  \
-    if (k1 == K1_ && s1 == S1_ && k2 == K2_ && tw == TW_) {                                                               \
+    if (n >= 8192 && k1 == K1_ && s1 == S1_ && k2 == K2_ && tw == TW_) {                                                               \
         if (use_swish) hipLaunchKernelGGL((k_mpnn_readout_rows<K1_, S1_, K2_, TW_, true>), dim3((n + 255) / 256), dim3(256), 0, \
                                           (hipStream_t)stream, h, u, n, w1, b1, w2, b2, dt, out);                          \
         else hipLaunchKernelGGL((k_mpnn_readout_rows<K1_, S1_, K2_, TW_, false>), dim3((n + 255) / 256), dim3(256), 0,    \

@@ -1,0 +1,95 @@
+"""hipGraph replay of a whole free-running rollout (SURVEY.md 8(f) rank 1 context: the launch-bound regime).
+
+The small BASELINE configs (C1: 2 x 50 nodes, C2 / C3: tens to hundreds of nodes) are launch bound: a rollout is several
+hundred kernels of a few microseconds each plus the host glue between the forward calls, and the host cannot enqueue
+them as fast as the GPU retires them.  ``RolloutGraph`` captures one complete rollout - every forward call and the
+feedback glue between them - into ONE hipGraph (``torch.cuda.CUDAGraph`` is hipGraph on ROCm) and replays it:
+
+* the batch is copied into static input buffers, the graph is replayed, the outputs are cloned out of the graph's pool;
+* a capture is keyed on the batch's shapes / dtypes and on the model's packed-weight generation (an optimizer step
+  re-packs the weights into new buffers, so the old graph's pointers are stale);
+* the radius graph / k-NN topology is baked into the capture (its build needs the edge count on the host).  The
+  coordinate tensors of every call are therefore compared with the captured ones - by identity when the caller passes the
+  same tensors again, else by content (one ``torch.equal`` = one host sync per rollout) - and a mismatch re-captures;
+* nothing inside the captured region may synchronise: the models skip their range-guard read while capturing and
+  ``RolloutGraph`` reads it after the replay.
+
+Used by default when a rollout's graph has at most ``AUTO_MAX_ROWS`` node rows (``hip_graph`` hparam: True / False / "auto").
+"""
+from __future__ import annotations
+
+import torch
+
+AUTO_MAX_ROWS = 4096
+
+
+def capturing() -> bool:
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def _ident(t: torch.Tensor):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version)
+
+
+class RolloutGraph:
+    def __init__(self, topology_keys, max_entries: int = 4):
+        """``topology_keys``: the batch entries that determine the graph topology (coordinates)."""
+        self.topology_keys, self.max_entries = tuple(topology_keys), max_entries
+        self._entries = {}
+
+    def clear(self):
+        self._entries.clear()
+
+    def __deepcopy__(self, memo):                      # captured graphs belong to one model instance: a copy starts empty
+        return RolloutGraph(self.topology_keys, self.max_entries)
+
+    def __getstate__(self):
+        return {"topology_keys": self.topology_keys, "max_entries": self.max_entries, "_entries": {}}
+
+    def __call__(self, fn, batch: dict, generation):
+        """``fn(batch: dict) -> tuple of tensors`` runs one rollout with no host synchronisation once its caches are warm"""
+        key = (generation,) + tuple((k, tuple(v.shape), v.dtype, str(v.device)) for k, v in sorted(batch.items()))
+        e = self._entries.get(key)
+        if e is not None:
+            for k in self.topology_keys:                      # same coordinates as the capture?
+                if e["seen"].get(k) == _ident(batch[k]):
+                    continue
+                if not bool(torch.equal(e["static"][k], batch[k].to(e["static"][k].dtype))):
+                    e = None
+                    break
+                e["seen"][k] = _ident(batch[k])
+        if e is None:
+            e = self._capture(fn, batch)
+            if len(self._entries) >= self.max_entries:
+                self._entries.pop(next(iter(self._entries)))
+            self._entries[key] = e                             # its static buffers already hold this batch
+        else:
+            for k, v in batch.items():
+                if k not in self.topology_keys:                # topology inputs are known to be equal: leave them (and
+                    e["static"][k].copy_(v)                    # their version counters) alone
+        e["graph"].replay()
+        return tuple(o.clone() for o in e["out"])
+
+    def _capture(self, fn, batch: dict):
+        # floating inputs are kept as fp32 (what every model converts to first): `.float()` inside the rollout is then a view
+        # of the static buffer and the topology caches recognise it by identity in the capture pass
+        static = {k: (v.float().clone() if v.is_floating_point() else v.clone()) for k, v in batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                                 # builds topology / packed weights / lazy buffers (may sync)
+                fn(static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = fn(static)
+        out = tuple(out) if isinstance(out, (tuple, list)) else (out,)
+        return {"graph": graph, "static": static, "out": out, "seen": {k: _ident(batch[k]) for k in self.topology_keys}}
+
+
+def wants_graph(setting, rows: int) -> bool:
+    """``hip_graph`` hparam: True / False / "auto" (default: replay when the rollout's graph has few rows)"""
+    if setting in (True, False):
+        return bool(setting)
+    return rows <= AUTO_MAX_ROWS

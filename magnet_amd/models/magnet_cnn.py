@@ -27,6 +27,7 @@ from .magnet_common import (Decoder, Encoder, MagnetBase, Processor, _mlp_ln, pa
 
 class MAgNetCNN(MagnetBase):
     DIM = 1
+    TOPOLOGY_KEYS = ("coords",)
 
     def __init__(self, hparams):
         super().__init__()
@@ -186,10 +187,9 @@ class MAgNetCNN(MagnetBase):
         self.log("train_interp_loss", self.mae_criterion(hr_hat, vals[:, :-T]), prog_bar=True)
         return loss
 
-    @torch.no_grad()          # validation never differentiates (Lightning runs it under no_grad as well)
-    def validation_step(self, val_batch, batch_idx):
+    def _inference_rollout(self, val_batch):
         """Free-running rollout; the next LR input is the predicted HR field down-sampled with
-        (bi)linear interpolation (magnet_cnn.py:456-461, magnet_cnn_2d.py:466-472)."""
+        (bi)linear interpolation (magnet_cnn.py:456-461, magnet_cnn_2d.py:466-472).  -> (pred, fut)"""
         t, u = val_batch["t"].float(), val_batch["lr_frames"].float()
         vals, coords, cells = val_batch["hr_points"].float(), val_batch["coords"].float(), val_batch["cells"].float()
         T, W, B = self.time_slice, u.shape[-1], u.shape[0]
@@ -205,8 +205,14 @@ class MAgNetCNN(MagnetBase):
             else:
                 inp = ops.resize_linear(img.reshape(-1, img.shape[-1]), (W,), 1).reshape(B, -1, 1, W)
             hr_last = y[:, -1]
-        pred = torch.cat(outs, dim=1)
-        self._guard.raise_if_set(f"{type(self).__name__} rollout")
+        return torch.cat(outs, dim=1), fut
+
+    @torch.no_grad()          # validation never differentiates (Lightning runs it under no_grad as well)
+    def validation_step(self, val_batch, batch_idx):
+        keys = ("t", "lr_frames", "hr_points", "coords", "cells")
+        u = val_batch["lr_frames"]
+        rows = u.shape[0] * (u.shape[-1] ** self.DIM + val_batch["coords"].shape[1])
+        pred, fut = self._graphed(self._inference_rollout, val_batch, keys, rows)
         self.log("val_loss", self.criterion(pred, fut), prog_bar=True)
         self.log("val_mae_loss", self.mae_criterion(pred, fut), prog_bar=True)
         return pred

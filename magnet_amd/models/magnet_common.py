@@ -18,6 +18,7 @@ from torch import nn
 from .. import _lib as L
 from .. import ops
 from ..lightning_compat import LightningModule
+from ..graphs import RolloutGraph, capturing, wants_graph  # noqa: F401
 from ..packing import pad_to, pad_vec
 from ..topo_cache import TopologyCache
 from .backbones.mlp import MLP
@@ -70,10 +71,32 @@ def pack_mlp(mlp, k_pad=None, mode=None):
                                  params=[p for lin in mlp.linears() for p in (lin.weight, lin.bias)])
 
 
+def pack_interaction_edge(seq, D):
+    """InteractionNetwork.edge_fn (models/magnet_gnn.py:79-83) with its first Linear factored per node:
+        W0 [x_i, x_j, e] + b0 = (W0a x)[i] + (W0b x)[j] + W0c e + b0          (exact algebra; summation order changes)
+    -> (chain pack whose first layer is W0c only (K = D instead of 3 D), packed W0a, packed W0b).  The two per-node products
+    are computed once per NODE by a single-Linear launch and gathered into the chain's first pre-activation (magnet_hip.h:
+    magnet_mlp_args_t.pre): the first layer of the edge chain does a third of its flops and reads D instead of 3 D columns
+    per edge - the factorisation SURVEY.md 7 (step 4) names, as for MPNN's message_net_1."""
+    from ..packing import default_gemm, pack
+    mlp, ln = seq[0], seq[1]
+    lins = mlp.linears()
+    mode = default_gemm()
+    W0 = lins[0].weight.detach()
+    assert W0.shape[1] == 3 * D and D % 32 == 0
+    layers = [pack(W0[:, 2 * D:], lins[0].bias, mode)] + [pack(l.weight, l.bias, mode) for l in lins[1:]]
+    chain = types.SimpleNamespace(layers=layers, ln=(ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps),
+                                  ht=mlp.hidden // 32, ot=pad_to(mlp.out_dim) // 32, out_dim=mlp.out_dim, col_map=None)
+    return chain, pack(W0[:, :D], None, mode), pack(W0[:, D:2 * D], None, mode)
+
+
 def pack_graph_net(enc: Encoder, proc: Processor, ldn: int):
-    return types.SimpleNamespace(
-        node=pack_mlp_ln(enc.node_fn, k_pad=ldn), edge=pack_mlp_ln(enc.edge_fn, k_pad=ldn),
-        hops=[types.SimpleNamespace(edge=pack_mlp_ln(g.edge_fn), node=pack_mlp_ln(g.node_fn)) for g in proc.gnn_stacks])
+    hops = []
+    for g in proc.gnn_stacks:
+        D = g.node_fn[0].out_dim
+        chain, pre_i, pre_j = pack_interaction_edge(g.edge_fn, D)
+        hops.append(types.SimpleNamespace(edge=pack_mlp_ln(g.edge_fn), node=pack_mlp_ln(g.node_fn), edge_f=chain, pre_i=pre_i, pre_j=pre_j))
+    return types.SimpleNamespace(node=pack_mlp_ln(enc.node_fn, k_pad=ldn), edge=pack_mlp_ln(enc.edge_fn, k_pad=ldn), hops=hops)
 
 
 def run_mlp(M, kts, pk, y, *, epi=ops.EPI_STORE, res=None, ncols=None, ldy=None, **seg):
@@ -83,6 +106,18 @@ def run_mlp(M, kts, pk, y, *, epi=ops.EPI_STORE, res=None, ncols=None, ldy=None,
 
 class MagnetBase(LightningModule):
     """Graph building + encode-process on HIP, shared by the three MAgNet models."""
+    TOPOLOGY_KEYS = ()          # batch entries that determine the graph topology (set by the models)
+
+    def _graphed(self, fn, batch, keys, rows):
+        """run ``fn(batch)`` (an inference rollout returning a tuple of tensors) - replayed from one hipGraph when the graph
+        is small (launch bound), else directly"""
+        if next(iter(batch.values())).is_cuda and wants_graph(self.hip_graph, rows):
+            self._packed()
+            out = self._rollout_graph(fn, {k: batch[k] for k in keys}, generation=self._pack_key)
+        else:
+            out = fn(batch)
+        self._guard.raise_if_set(f"{type(self).__name__} rollout")
+        return out
 
     def _init_common(self, hparams):
         self.lr, self.weight_decay = hparams.lr, hparams.weight_decay
@@ -95,6 +130,9 @@ class MagnetBase(LightningModule):
         from ..packing import default_gemm
         self._guard = ops.RangeGuard(default_gemm() == "fp16x3" and bool(getattr(hparams, "range_check", True)))
         self.optimizer_kind = getattr(hparams, "optimizer", "fused")     # "fused" (magnet_amd.optim.FusedAdam) | "torch"
+        # hipGraph replay of whole inference rollouts (magnet_amd/graphs.py): True / False / "auto" = when the graph is small
+        self.hip_graph = getattr(hparams, "hip_graph", "auto")
+        self._rollout_graph = RolloutGraph(topology_keys=self.TOPOLOGY_KEYS)
 
     # ---- packed-weight cache -------------------------------------------------------------
     def _packed(self):
@@ -135,6 +173,7 @@ class MagnetBase(LightningModule):
 
     def drop_topology_cache(self):
         self._topo_cache.clear()
+        self._rollout_graph.clear()           # captured rollouts have their topology baked in
 
     def _build_graph(self, u, x, t, key=None):
         """u [B, N, T], x [B, N, d], t [B, T] -> (node_features [B*N, ld], topology).  Edge features
@@ -164,9 +203,24 @@ class MagnetBase(LightningModule):
         partials = torch.empty(((E + 31) // 32) * 2 * D + 1, device=dev, dtype=torch.float32)
         run_mlp(N, ops.ktiles(T_(nf, ldn)), pk.node, x)
         run_mlp(E, ops.ktiles((T_(nf, ldn, idx=csr.src, scale=1.0), T_(nf, ldn, idx=csr.tgt, scale=-1.0))), pk.edge, e0)
+        # edge_fn([x_i, x_j, e]) with the first Linear factored per node (pack_interaction_edge) when that does not widen the
+        # gathered rows (hidden <= latent: MAgNet[GNN] 128 / 128; the CNN models' 64-wide chains over 32-wide latents keep the
+        # concatenated form - measured: C5 edge chain 1.55 -> 1.21 ms, C4b 0.38 -> 0.39 ms)
+        Hm = pk.hops[0].edge_f.ht * 32 if pk.hops else 0
+        factored = 0 < Hm <= D
+        if factored:
+            PQ = torch.empty(2, N, Hm, device=dev, dtype=torch.float32)   # per-node halves of the edge chains' first Linear
         for k, hop in enumerate(pk.hops):
-            kts = ops.ktiles(T_(x, D, idx=csr.tgt), T_(x, D, idx=csr.src), T_(e0, D, scale=float(2 ** k)))
-            run_mlp(E, kts, hop.edge, agg, epi=ops.EPI_SEGMEAN, tgt=csr.tgt, rowptr=csr.rowptr, partials=partials)
+            if factored:
+                # P = W0a x, Q = W0b x in one launch (two column groups run back to back inside each workgroup), then the
+                # chain over e_k = 2^k e_0 (Q2) alone
+                ops.mlp(N, ops.ktiles(T_(x, D)), [hop.pre_i, hop.pre_j], nl=1, ht=Hm // 32, ot=Hm // 32, act=ops.ACT_NONE, y=PQ, ldy=Hm,
+                        colgroups=2, groups_in_block=True, y_group_stride=N * Hm)
+                run_mlp(E, ops.ktiles(T_(e0, D, scale=float(2 ** k))), hop.edge_f, agg, epi=ops.EPI_SEGMEAN, tgt=csr.tgt,
+                        rowptr=csr.rowptr, partials=partials, pre=[(PQ[0], csr.tgt), (PQ[1], csr.src)])
+            else:
+                kts = ops.ktiles(T_(x, D, idx=csr.tgt), T_(x, D, idx=csr.src), T_(e0, D, scale=float(2 ** k)))
+                run_mlp(E, kts, hop.edge, agg, epi=ops.EPI_SEGMEAN, tgt=csr.tgt, rowptr=csr.rowptr, partials=partials)
             ops.segmean_fixup(csr.rowptr, N, D, partials, agg)
             run_mlp(N, ops.ktiles(T_(agg, D), T_(x, D)), hop.node, x2, epi=ops.EPI_STORE_RES, res=x)
             x, x2 = x2, x

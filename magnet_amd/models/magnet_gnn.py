@@ -20,6 +20,7 @@ from torch import nn
 
 from .. import _lib as L
 from .. import ops
+from ..graphs import capturing
 from ..packing import default_gemm, pack, pad_to
 from .backbones.mlp import MLP
 from .magnet_common import (Decoder, Encoder, MagnetBase, Processor, pack_graph_net, pack_mlp)
@@ -28,6 +29,8 @@ _MODES = {"area": 0, "knn": 1, "sph": 2}
 
 
 class MAgNetGNN(MagnetBase):
+    TOPOLOGY_KEYS = ("coords_hr", "coords_lr")
+
     def __init__(self, hparams):
         super().__init__()
         self.save_hyperparameters()
@@ -177,7 +180,8 @@ class MAgNetGNN(MagnetBase):
             hr_last = self._noisy(hr_last, noise)
         pred = torch.cat(outs, dim=1)
         target = torch.cat([fut, u[:, T:].permute(0, 1, 3, 2)], dim=2)
-        self._guard.raise_if_set("MAgNetGNN rollout")
+        if not capturing():
+            self._guard.raise_if_set("MAgNetGNN rollout")
         return pred, target, torch.cat(hrs, dim=1), vals
 
     def training_step(self, train_batch, batch_idx):
@@ -191,7 +195,9 @@ class MAgNetGNN(MagnetBase):
 
     @torch.no_grad()          # validation never differentiates (Lightning runs it under no_grad as well)
     def validation_step(self, val_batch, batch_idx):
-        pred, target, _, _ = self._rollout(val_batch)
+        keys = ("t", "lr_frames", "hr_points", "coords_hr", "coords_lr")
+        rows = val_batch["lr_frames"].shape[0] * (val_batch["lr_frames"].shape[-1] + val_batch["coords_hr"].shape[1])
+        pred, target = self._graphed(lambda b: self._rollout(b)[:2], val_batch, keys, rows)
         self.log("val_loss", self.criterion(pred, target), prog_bar=True)
         self.log("val_mae_loss", self.mae_criterion(pred, target), prog_bar=True)
         return pred

@@ -24,6 +24,7 @@ from torch import nn
 from .. import ops
 from ..lightning_compat import LightningModule
 from ..packing import GEMM_MODES, default_gemm, pack, pack_edge16_fp16x2, pad_to
+from ..graphs import RolloutGraph, capturing, wants_graph
 from ..topo_cache import TopologyCache
 
 _READOUT = {10: (16, 6, 10), 16: (16, 5, 8), 20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}  # mpnn.py:140-163
@@ -107,8 +108,9 @@ class MPNN(LightningModule):
         self._guard = ops.RangeGuard("fp16x3" in (self.gemm, self.edge_gemm) and bool(getattr(hparams, "range_check", True)))
         self._pack_key, self._pack, self._pack_gen = None, None, 0
         self._topo_cache, self._topo = TopologyCache(4), None       # _topo: the topology of the latest _build_graph
-        self.hip_graph = bool(getattr(hparams, "hip_graph", False))
-        self._fwd_graphs = {}
+        # hipGraph replay of whole inference rollouts (magnet_amd/graphs.py): True / False / "auto" = when the graph is small
+        self.hip_graph = getattr(hparams, "hip_graph", "auto")
+        self._rollout_graph = RolloutGraph(topology_keys=("x",))
 
     # ------------------------------------------------------------------ packed weights (cached)
     def _packed(self):
@@ -211,37 +213,6 @@ class MPNN(LightningModule):
         self._guard.outputs(out)
         return out
 
-    # ------------------------------------------------------------------ hipGraph replay of the forward
-    def _graphed_forward(self, data, L, tmax, dt):
-        """Capture ``forward`` for this topology once (torch.cuda.CUDAGraph = hipGraph on ROCm) and replay it.
-        Worth it in the launch-bound regime (N ~ 100: ~45 kernels of a few microseconds per forward); opt-in through
-        the optional ``hip_graph`` hparam.  Inputs are copied into static buffers; the output buffer is reused."""
-        dev = data.x.device
-        key = (id(data.topo), tuple(data.x.shape), tuple(data.pos.shape), self._packed() is not None and self._pack_key)
-        fg = self._fwd_graphs.get(key)
-        if fg is None:
-            as_t = lambda v: (v.to(dev).float().reshape(-1) if torch.is_tensor(v) else torch.tensor([float(v)], device=dev)).clone()  # noqa: E731
-            st = types.SimpleNamespace(u=data.x.clone(), pos=data.pos.clone(), L=as_t(L), tmax=as_t(tmax), dt=as_t(dt))
-            st.data = MeshGraph(st.u, st.pos, data.batch, data.topo)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    self.forward(st.data, st.L, st.tmax, st.dt)
-            torch.cuda.current_stream().wait_stream(side)
-            st.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(st.graph):
-                st.out = self.forward(st.data, st.L, st.tmax, st.dt)
-            if len(self._fwd_graphs) > 4:
-                self._fwd_graphs.clear()
-            self._fwd_graphs[key] = fg = st
-        fg.u.copy_(data.x)
-        fg.pos.copy_(data.pos)
-        for dst, v in ((fg.L, L), (fg.tmax, tmax), (fg.dt, dt)):
-            dst.copy_(v.reshape(-1) if torch.is_tensor(v) else torch.tensor([float(v)]))
-        fg.graph.replay()
-        return fg.out.clone()
-
     # ------------------------------------------------------------------ graph (mpnn.py:216-251)
     def _radius(self, x0, nx):
         if self.DIM == 1:
@@ -279,6 +250,7 @@ class MPNN(LightningModule):
 
     def drop_topology_cache(self):
         self._topo_cache.clear()
+        self._rollout_graph.clear()           # captured rollouts have their topology baked in
         self._topo = None
 
     def _topology_of(self, data, N):
@@ -340,13 +312,12 @@ class MPNN(LightningModule):
                 tapes.append(types.SimpleNamespace())
                 y = self._forward(graph, x[0, -1], t[0, -1], dt, tapes[-1])
             else:
-                fwd = self._graphed_forward if self.hip_graph else self.forward
-                y = fwd(graph, x[0, -1], t[0, -1], dt)
+                y = self.forward(graph, x[0, -1], t[0, -1], dt)
             y_hat = y.reshape(B, N, -1).permute(0, 2, 1)
             u_hat.append(y_hat)
             nxt = u[:, (i + 1) * tw:(i + 2) * tw] if teacher_forcing else y_hat
             graph = self._build_graph(nxt, t, x, [self._next_step(i)] * B)
-        if tapes is None:                                      # with tapes: rollout_with_grad checks after its own bookkeeping
+        if tapes is None and not capturing():                  # with tapes: rollout_with_grad checks after its own bookkeeping
             self._guard.raise_if_set(f"{type(self).__name__} rollout")
         return torch.cat(u_hat, dim=1), target
 
@@ -363,8 +334,18 @@ class MPNN(LightningModule):
         self.log("train_mae_loss", self.mae_criterion(u_hat.detach(), target), prog_bar=True)
         return loss
 
+    def _inference_rollout(self, batch):
+        """the free-running rollout of validation_step; replayed from one hipGraph when the graph is small (launch bound)"""
+        u = batch["u"]
+        if u.is_cuda and wants_graph(self.hip_graph, u.shape[0] * u.shape[1]):
+            self._packed()
+            out = self._rollout_graph(self.rollout, {k: batch[k] for k in ("u", "x", "t")}, generation=self._pack_key)
+            self._guard.raise_if_set(f"{type(self).__name__} rollout")
+            return out
+        return self.rollout(batch)
+
     def validation_step(self, val_batch, batch_idx):
-        u_hat, target = self.rollout(val_batch)
+        u_hat, target = self._inference_rollout(val_batch)
         self.log("val_loss", self.criterion(u_hat, target), prog_bar=True)
         self.log("val_mae_loss", self.mae_criterion(u_hat, target), prog_bar=True)
         return u_hat

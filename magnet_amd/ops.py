@@ -89,7 +89,7 @@ def mlp_args(M, kts):
 
 
 def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STORE, y=None, ldy=None, ncols=None,
-             res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0):
+             res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0, pre=None):
     """Build the argument block of one fused-MLP launch once and return a zero-argument callable that enqueues it on the
     current stream.  For call sites that repeat the same launch on the same buffers (the EDSR convolution stack: 34
     launches of up to 36 gathered k tiles each) this removes the per-call descriptor marshalling from the host path."""
@@ -102,7 +102,13 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
     # instead of G workgroup columns; y_group_stride: floats between the groups' outputs (0: neighbouring column blocks)
     a.groups_in_block = int(colgroups) if groups_in_block and colgroups > 1 else 0
     a.y_group_stride = int(y_group_stride)
-    keep += [layers, ln, y, res, tgt, rowptr, partials]
+    keep += [layers, ln, y, res, tgt, rowptr, partials, pre]
+    # pre: up to two (rows [n, ld >= first-layer width] fp32, idx int32 or None): gathered rows added to the first Linear's
+    # pre-activation (the per-node products of a factored first layer, see magnet_hip.h)
+    for i, (t, idx) in enumerate(pre or ()):
+        assert nl > 1 and i < 2 and t.dtype == torch.float32 and t.is_contiguous() and t.shape[-1] % 4 == 0 and t.shape[-1] >= ht * 32
+        a.pre[i].p, a.pre[i].ld = t.data_ptr(), t.shape[-1]
+        a.pre[i].idx = idx.data_ptr() if idx is not None else None
     for i, (w, b) in enumerate(layers):
         a.layer[i].w, a.layer[i].b = w.data_ptr(), b.data_ptr()
     if ln is not None:
@@ -127,11 +133,11 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
 
 
 def mlp(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STORE, y=None, ldy=None, ncols=None,
-        res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0):
+        res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0, pre=None):
     """Run the fused MLP kernel.  ``layers``: list of (packed_w, padded_b).  Returns y."""
     mlp_plan(M, kts, layers, nl=nl, ht=ht, ot=ot, act=act, last_act=last_act, ln=ln, epi=epi, y=y, ldy=ldy, ncols=ncols,
              res=res, tgt=tgt, rowptr=rowptr, partials=partials, colgroups=colgroups, groups_in_block=groups_in_block,
-             y_group_stride=y_group_stride)()
+             y_group_stride=y_group_stride, pre=pre)()
     return y
 
 

@@ -11,6 +11,7 @@ hp = types.SimpleNamespace(lr=1e-3, weight_decay=0, factor=0.3, step_size=50, lo
 torch.manual_seed(0)
 B, N, nt = 2, 50, 250
 batch = {"u": torch.randn(B, N, nt), "x": torch.linspace(0, 16, N)[None, :, None].repeat(B, 1, 1), "t": torch.linspace(0, 4, nt)[None].repeat(B, 1)}
+hp.hip_graph = False
 m = FACTORY["mpnn"](hp).eval().cuda()
 cb = {k: v.cuda() for k, v in batch.items()}
 for _ in range(3): m.validation_step(cb, 0)

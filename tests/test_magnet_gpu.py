@@ -221,11 +221,15 @@ def test_config2_exactly_16_queries_250_steps():
     hp, oracle, model = _c2_models()
     batch = _c2_batch(16, seed=2)
     assert batch["coords_hr"].shape == (2, 16, 1) and batch["lr_frames"].shape == (2, 250, 1, 25)
+    cb = {k: v.cuda() for k, v in batch.items()}
     calls = []
     orig = model.forward
     model.forward = lambda *a: (calls.append(1) or orig(*a))
-    pred = model.validation_step({k: v.cuda() for k, v in batch.items()}, 0)
+    model.hip_graph = False                                  # kernel by kernel: count the forward calls of one rollout
+    pred = model.validation_step(cb, 0)
     assert len(calls) == 9 and pred.shape == (2, 225, 16 + 25, 1)
+    model.hip_graph = "auto"                                 # the default for a graph this small: one hipGraph replay
+    assert torch.equal(model.validation_step(cb, 0), pred) and torch.equal(model.validation_step(cb, 0), pred)
     with torch.no_grad():
         want = oracle.validation_step(batch)
     assert rel_l2(pred, want) < 5 * OUT_TOL, rel_l2(pred, want)
