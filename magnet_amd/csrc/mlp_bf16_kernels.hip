@@ -110,15 +110,18 @@ __device__ int g_mlp_abl = 0;
 #define MLP_ABL_INIT constexpr int abl = 0;
 #endif
 
-template <int MODE, int NL, int HT, int OT, int ACT, bool LAST_ACT, bool LN, int EPI>
+// DIST: chunks requested ahead.  1 for full grids: 2 (three-slot ring, counted vmcnt) paid +7 % while the wide 5-Linear chains ran
+// one workgroup per CU and still costs 3 % with two per CU (C5 edge MLP 1.63 vs 1.59 ms).  2 for launches of at most one
+// workgroup per CU (the launch-bound 1-D configs: 100 rows = one workgroup): nothing else on the CU hides the L2 -> LDS latency of
+// a chunk (~1.8 us per k tile exposed), so the extra chunk of lead pays.
+template <int MODE, int NL, int HT, int OT, int ACT, bool LAST_ACT, bool LN, int EPI, int DIST = 1>
 __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
     MLP_ABL_INIT
     constexpr int NTMAX = MaxI<HT, OT>::v;
     constexpr int PPN = 2 * Split<MODE>::NP;                              // 1 KiB pieces per output tile and k tile
-    constexpr int DIST = 1;                   // chunks requested ahead.  2 (three-slot ring, counted vmcnt) paid +7 % while the wide
-                                              // 5-Linear chains ran one workgroup per CU; with two per CU it costs 3 % (C5 edge MLP 1.63 vs 1.59 ms)
     constexpr int NBUF = DIST + 1;
-    constexpr bool PIPE = (NL >= 5 && HT >= 4);                          // see mma_chunk
+    constexpr bool PIPE = (NL >= 5 && HT >= 4) || DIST == 2;             // see mma_chunk; the one-workgroup-per-CU variants too:
+                                                                         // nobody else on the SIMD hides the LDS latency of a group
     constexpr int CH = NTMAX * PPN * 64;                                   // u32x4 per chunk buffer
     // weight chunk ring; a 128-wide CSR-mean epilogue reuses it as four 32 x 68 float transposition tiles (34 KiB)
     constexpr bool LDS_MEAN = (EPI == EPI_SEGMEAN && OT == 4);
@@ -281,9 +284,13 @@ typedef void (*mlp_fn)(const MagnetMlpArgs);
 #define MLP_CASE(NL_, HT_, OT_, ACT_, LA_, LN_, EPI_)                                              \
     if (nl == NL_ && ht == HT_ && ot == OT_ && act == ACT_ && last_act == LA_ && ln == LN_ && epi == EPI_) \
         fn = k_mlp_bf16<MODE, NL_, HT_, OT_, ACT_, LA_, LN_, EPI_>;
+// the same with two chunks of lead, for launches of at most one workgroup per CU (MPNN node-level kernels of the small configs)
+#define MLP_CASE_SMALL(NL_, HT_, OT_, ACT_, LA_, LN_, EPI_)                                        \
+    if (small && nl == NL_ && ht == HT_ && ot == OT_ && act == ACT_ && last_act == LA_ && ln == LN_ && epi == EPI_) \
+        fn = k_mlp_bf16<MODE, NL_, HT_, OT_, ACT_, LA_, LN_, EPI_, 2>;
 
 template <int MODE>
-static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int epi) {
+static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int epi, bool small = false) {
     mlp_fn fn = nullptr;
     MLP_CASE(2, 4, 4, ACT_SWISH, true, false, EPI_STORE)
     MLP_CASE(2, 4, 4, ACT_SWISH, true, false, EPI_STORE_RES)
@@ -307,9 +314,13 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
     MLP_CASE(5, 2, 1, ACT_RELU, false, false, EPI_STORE)
     MLP_CASE(5, 2, 2, ACT_RELU, false, true, EPI_STORE)
     MLP_CASE(5, 2, 4, ACT_RELU, false, true, EPI_STORE)
+    MLP_CASE_SMALL(2, 4, 4, ACT_SWISH, true, false, EPI_STORE)
+    MLP_CASE_SMALL(2, 4, 4, ACT_SWISH, true, false, EPI_STORE_RES)
+    MLP_CASE_SMALL(1, 4, 4, ACT_NONE, false, false, EPI_STORE)
     return fn;
 }
 
+constexpr int SMALL_M = 128 * 256;      // rows of at most one workgroup per CU
 static int launch_mlp(mlp_fn fn, const MagnetMlpArgs* args, void* stream) {
     if (!fn) return -3;
     const int tiles = (args->M + 31) / 32;
@@ -323,7 +334,7 @@ extern "C" int magnet_mlp_bf16x6_f32(const MagnetMlpArgs* args, int nl, int ht, 
     if (!args || args->M <= 0) return args && args->M == 0 ? 0 : -1;
     if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
     if (args->ncolgroups > 1 && (nl != 1 || args->ncolgroups > MAGNET_MAX_LAYERS)) return -2;
-    return launch_mlp(pick<GEMM_BF16X6>(nl, ht, ot, act, last_act, ln, epi), args, stream);
+    return launch_mlp(pick<GEMM_BF16X6>(nl, ht, ot, act, last_act, ln, epi, args->M <= SMALL_M), args, stream);
 }
 
 extern "C" int magnet_mlp_bf16_f32(const MagnetMlpArgs* args, int nl, int ht, int ot, int act, int last_act, int ln,
@@ -332,7 +343,7 @@ extern "C" int magnet_mlp_bf16_f32(const MagnetMlpArgs* args, int nl, int ht, in
     if (!args || args->M <= 0) return args && args->M == 0 ? 0 : -1;
     if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
     if (args->ncolgroups > 1 && (nl != 1 || args->ncolgroups > MAGNET_MAX_LAYERS)) return -2;
-    return launch_mlp(pick<GEMM_BF16>(nl, ht, ot, act, last_act, ln, epi), args, stream);
+    return launch_mlp(pick<GEMM_BF16>(nl, ht, ot, act, last_act, ln, epi, args->M <= SMALL_M), args, stream);
 }
 
 extern "C" int magnet_mlp_fp16x3_f32(const MagnetMlpArgs* args, int nl, int ht, int ot, int act, int last_act, int ln,
@@ -341,7 +352,7 @@ extern "C" int magnet_mlp_fp16x3_f32(const MagnetMlpArgs* args, int nl, int ht, 
     if (!args || args->M <= 0) return args && args->M == 0 ? 0 : -1;
     if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
     if (args->ncolgroups > 1 && (nl != 1 || args->ncolgroups > MAGNET_MAX_LAYERS)) return -2;
-    return launch_mlp(pick<GEMM_FP16X3>(nl, ht, ot, act, last_act, ln, epi), args, stream);
+    return launch_mlp(pick<GEMM_FP16X3>(nl, ht, ot, act, last_act, ln, epi, args->M <= SMALL_M), args, stream);
 }
 
 #ifdef MAGNET_DEV_VARIANTS
