@@ -31,7 +31,8 @@ extern "C" {
 #define MAGNET_MAX_KT 36
 #define MAGNET_MAX_LAYERS 6
 enum { MAGNET_ACT_NONE = 0, MAGNET_ACT_SWISH = 1, MAGNET_ACT_RELU = 2 };
-enum { MAGNET_EPI_STORE = 0, MAGNET_EPI_STORE_RES = 1, MAGNET_EPI_SEGMEAN = 2 };
+enum { MAGNET_EPI_STORE = 0, MAGNET_EPI_STORE_RES = 1, MAGNET_EPI_SEGMEAN = 2,
+       MAGNET_EPI_STORE_MASK = 3 /* nl == 1: y = res > 0 ? x W^T : 0 - a backward-data GEMM with the ReLU mask of the layer below */ };
 
 /* One source feeding a 32-wide k tile of the first Linear's input:
  *   value[row][k] = scale * p[(idx ? idx[row] : row / rdiv) * ld + col + k],  k = 0..31
@@ -77,6 +78,10 @@ typedef struct {
                               * how a Linear over torch.cat([x_i, x_j, e]) (InteractionNetwork.message, models/magnet_gnn.py:79-83)
                               * runs with K = width(e) only: W [x_i, x_j, e] + b = (Wa x)[i] + (Wb x)[j] + Wc e + b, the two
                               * per-node products computed once per node instead of once per edge (col / scale / rdiv unused) */
+    float* x0_out;           /* optional (NULL = off) tape outputs for a training backward (no reference counterpart: torch autograd
+                              * keeps these tensors alive instead): the first Linear's assembled input rows [M][nkt*32], */
+    float* hid[MAGNET_MAX_LAYERS]; /* ... hid[l], l < nl-1: layer l's output after its activation [M][ht*32]; hid[nl-1]: the last
+                              * Linear's raw output before last_act / LayerNorm [M][ot*32] */
 } magnet_mlp_args_t;
 
 /* Fused gather/concat -> NL x (Linear [+ activation]) -> [LayerNorm] -> store | +residual | CSR mean.

@@ -20,7 +20,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "magnet_hip.h")
 
 MAX_KT, MAX_LAYERS = 36, 6
 ACT_NONE, ACT_SWISH, ACT_RELU = 0, 1, 2
-EPI_STORE, EPI_STORE_RES, EPI_SEGMEAN = 0, 1, 2
+EPI_STORE, EPI_STORE_RES, EPI_SEGMEAN, EPI_STORE_MASK = 0, 1, 2, 3
 
 
 class Src(C.Structure):
@@ -42,7 +42,8 @@ class MlpArgs(C.Structure):
                 ("y", C.c_void_p), ("ldy", C.c_int32), ("ncols", C.c_int32),
                 ("res", C.c_void_p), ("ldres", C.c_int32),
                 ("tgt", C.c_void_p), ("rowptr", C.c_void_p), ("partials", C.c_void_p), ("ncolgroups", C.c_int32),
-                ("groups_in_block", C.c_int32), ("y_group_stride", C.c_int64), ("pre", Src * 2)]
+                ("groups_in_block", C.c_int32), ("y_group_stride", C.c_int64), ("pre", Src * 2),
+                ("x0_out", C.c_void_p), ("hid", C.c_void_p * MAX_LAYERS)]
 
 
 def declared_symbols() -> list[str]:

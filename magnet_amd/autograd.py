@@ -68,6 +68,21 @@ def _linear(rows, x, layer, out_tiles, relu):
     return y
 
 
+def _tape_variant_ok(nl, pk):
+    """is there a store-epilogue instantiation of the fused kernel for this chain without LayerNorm? (nl, ht, ot, ReLU, no
+    last_act, no LN, STORE): the projector / decoder shapes (5, 4, 1), (5, 2, 1) exist; the LayerNorm chains use their own
+    (5, ht, ot, LN) variants with the LayerNorm switched on and its output discarded."""
+    return bool(L.lib().magnet_mlp_supported(nl, pk.ht, pk.ot, ops.ACT_RELU, 0, 0, ops.EPI_STORE))
+
+
+def _recompute_by_layers(M, kts, pk, nl, x0, X, zL):
+    """fallback: the same tape with the LayerNorm variant of the chain kernel (its normalised output goes to a scratch array)"""
+    dev = x0.device
+    scratch = torch.empty(max(M, 1), pk.ot * 32, device=dev, dtype=torch.float32)
+    ops.mlp(M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU, last_act=False, ln=pk.ln, epi=ops.EPI_STORE, y=scratch,
+            ncols=pk.ot * 32, x0_out=x0, hid=X[1:] + [zL if zL is not None else None])
+
+
 def _tiles_of(width):
     """decompose a padded width into launchable output widths (128 / 64 / 32 columns)"""
     out, c = [], 0
@@ -127,18 +142,30 @@ class _Mlp(torch.autograd.Function):
                                                               ops._p(d_rows), Dp, ops._stream()), "edge_mean_bwd_cols")
             else:
                 d_rows = _pad_cols(dy, Dp)
-            # ---- recompute the chain, activations materialised
+            # ---- recompute the chain in ONE launch of the forward kernel with its tape outputs switched on: the assembled
+            # first-layer input x0, every layer's activated output and the last Linear's raw output z_L (before LayerNorm) come
+            # out of the registers the chain runs in (round 1: a materialisation pass + one single-Linear launch per layer, each
+            # re-reading and re-writing an [M, width] array).  Multi-layer chains only; a single Linear needs x0 alone.
             K0 = len(m.tiles) * 32
             x0 = torch.empty(max(M, 1), K0, device=dev, dtype=torch.float32)
-            a, keep = ops.mlp_args(M, [[(ops.Term(srcs[si], 32, idx=idx, scale=scale, rdiv=rdiv), col)
-                                        for (si, col, idx, scale, rdiv) in tile] for tile in m.tiles])
-            L.check(L.lib().magnet_mlp_materialize_input_f32(C.byref(a), ops._p(x0), K0, ops._stream()), "materialize_input")
-            X = [x0]
-            for l in range(nl - 1):
-                X.append(_linear(M, X[-1], pk.layers[l], pk.ht, relu=True))
+            kts = [[(ops.Term(srcs[si], 32, idx=idx, scale=scale, rdiv=rdiv), col) for (si, col, idx, scale, rdiv) in tile]
+                   for tile in m.tiles]
             grads_par = [None] * m.n_par
+            zL = None
+            if nl > 1:
+                X = [x0] + [torch.empty(max(M, 1), pk.ht * 32, device=dev, dtype=torch.float32) for _ in range(nl - 1)]
+                zL = torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32) if pk.ln is not None else None
+                scratch = torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32)      # the chain's own output is not needed
+                ops.mlp(M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU, last_act=False, ln=None, epi=ops.EPI_STORE,
+                        y=scratch, ncols=Dp, x0_out=x0, hid=X[1:] + [zL]) if _tape_variant_ok(nl, pk) else _recompute_by_layers(
+                            M, kts, pk, nl, x0, X, zL)
+            else:
+                a, keep = ops.mlp_args(M, kts)
+                L.check(L.lib().magnet_mlp_materialize_input_f32(C.byref(a), ops._p(x0), K0, ops._stream()), "materialize_input")
+                X = [x0]
+                if pk.ln is not None:
+                    zL = _linear(M, X[-1], pk.layers[nl - 1], pk.ot, relu=False)
             if pk.ln is not None:
-                zL = _linear(M, X[-1], pk.layers[nl - 1], pk.ot, relu=False)
                 nblk = min(1024, (M + 3) // 4)
                 part = torch.empty(nblk, 2, D, device=dev, dtype=torch.float32)
                 dz = torch.zeros(max(M, 1), Dp, device=dev, dtype=torch.float32)
@@ -178,13 +205,14 @@ class _Mlp(torch.autograd.Function):
                 Wp = _padded_weight(m, l, W, Np, Kp)
                 for (c0, w) in _tiles_of(Kp):
                     tp = _tpack(pk, l, c0, w, Wp)
-                    ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), [tp], nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE,
-                            y=dX[:, c0:], ldy=Kp, ncols=w)
+                    if l > 0:      # ... with the ReLU mask of the layer below as the epilogue: dz_{l-1} = (X[l] > 0) ? dX : 0
+                        ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), [tp], nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE,
+                                epi=ops.EPI_STORE_MASK, res=X[l][:, c0:], y=dX[:, c0:], ldy=Kp, ncols=w)
+                    else:
+                        ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), [tp], nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE,
+                                y=dX[:, c0:], ldy=Kp, ncols=w)
                 if l > 0:
-                    dzn = torch.empty_like(dX)
-                    L.check(L.lib().magnet_relu_bwd_f32(ops._p(dX), ops._p(X[l]), ops._p(dzn), C.c_long(dX.numel()), ops._stream()),
-                            "relu_bwd")
-                    dz = dzn
+                    dz = dX
                 else:
                     dX0 = dX
             # ---- scatter the first-layer input gradient back through the gathers

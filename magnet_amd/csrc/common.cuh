@@ -26,7 +26,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
-enum { EPI_STORE = 0, EPI_STORE_RES = 1, EPI_SEGMEAN = 2 };
+enum { EPI_STORE = 0, EPI_STORE_RES = 1, EPI_SEGMEAN = 2, EPI_STORE_MASK = 3 };   // MASK: y = res > 0 ? mlp(x) : 0 (ReLU backward)
 
 // one source of a first-layer k tile: value = scale * p[(idx ? idx[row] : row / rdiv) * ld + col + k]
 struct MagnetSrc {
@@ -68,6 +68,8 @@ struct MagnetMlpArgs {
     int32_t groups_in_block;       // > 1 (= ncolgroups): the groups run one after the other inside each workgroup instead of over gridDim.y
     int64_t y_group_stride;        // floats between the outputs of consecutive groups; 0 = OT*32 columns of the same rows
     MagnetSrc pre[2];              // gathered rows added to the first Linear's pre-activation (split-GEMM kernels), p == nullptr: off
+    float* x0_out;                 // tape outputs (training backward), nullptr = off: assembled first-layer input rows [M][nkt*32]
+    float* hid[MAGNET_MAX_LAYERS]; // hid[l]: layer l's activated output [M][HT*32]; hid[NL-1]: raw output of the last Linear [M][OT*32]
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -454,8 +456,19 @@ __device__ __forceinline__ void layer_norm_rows(f32x16 (&v)[NT], const float* __
         }
 }
 
-// rows -> global memory (optionally + residual); ragged widths handled per element
-template <int NT, bool RES>
+// one 32-column tile of a row block -> global memory (tape of the first layer's assembled input)
+__device__ __forceinline__ void store_ktile(const f32x16& x, float* __restrict__ y, int ldy, int col0, int row, bool row_ok, int half) {
+    if (!row_ok) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 t = {x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(y + (size_t)row * ldy + col0 + 8 * g + 4 * half) = t;
+    }
+}
+
+// rows -> global memory; RES = 1: + residual; RES = 2: kept where res > 0, else 0 (the ReLU mask of a backward-data GEMM: res is the
+// layer's post-ReLU activation); ragged widths handled per element
+template <int NT, int RES>
 __device__ __forceinline__ void store_rows(const f32x16 (&v)[NT], float* __restrict__ y, int ldy, int ncols,
                                             const float* __restrict__ res, int ldres, int row, bool row_ok,
                                             int half) {
@@ -469,14 +482,20 @@ __device__ __forceinline__ void store_rows(const f32x16 (&v)[NT], float* __restr
             if (n0 >= ncols) continue;
             f32x4 t = {v[nt][4 * g], v[nt][4 * g + 1], v[nt][4 * g + 2], v[nt][4 * g + 3]};
             if (vec && n0 + 3 < ncols) {
-                if (RES) t += *reinterpret_cast<const f32x4*>(res + (size_t)row * ldres + n0);
+                if (RES == 1) t += *reinterpret_cast<const f32x4*>(res + (size_t)row * ldres + n0);
+                if (RES == 2) {
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(res + (size_t)row * ldres + n0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t[c] = r[c] > 0.f ? t[c] : 0.f;
+                }
                 *reinterpret_cast<f32x4*>(y + (size_t)row * ldy + n0) = t;
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (n0 + c < ncols) {
                         float x = t[c];
-                        if (RES) x += res[(size_t)row * ldres + n0 + c];
+                        if (RES == 1) x += res[(size_t)row * ldres + n0 + c];
+                        if (RES == 2) x = res[(size_t)row * ldres + n0 + c] > 0.f ? x : 0.f;
                         y[(size_t)row * ldy + n0 + c] = x;
                     }
             }

@@ -186,6 +186,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                 } else if (kt + DIST < a.nkt) dma_chunk<NT0 * PPN>(l0.w + (size_t)(kt + DIST) * NT0 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
                 else if (NL > 1 && kt + DIST - a.nkt < HT) dma_chunk<NT1 * PPN>(a.layer[1].w + (size_t)(kt + DIST - a.nkt) * NT1 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
                 if (!(abl & 1)) mma_chunk<NT0, MODE, PIPE>(x, acc, accc, wbuf + (c % NBUF) * CH, lane);
+                if (a.x0_out && gi == 0) store_ktile(x, a.x0_out, a.nkt * 32, kt * 32, row, row_ok, half);
                 x = xn;
             }
             fold_tiles<NT0, MODE>(acc, accc);
@@ -202,6 +203,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                     apply_act<ACT>(acc[t]);
                     h0[t < HT ? t : 0] = acc[t];
                 }
+                if (a.hid[0]) store_rows<HT, 0>(h0, a.hid[0], HT * 32, HT * 32, nullptr, 0, row, row_ok, half);
             }
         }
         // ---------------- layers 1 .. NL-1, activations in registers (fully unrolled: static register indices)
@@ -253,8 +255,13 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                     if (src0) apply_act<ACT>(h1[t]);
                     else apply_act<ACT>(h0[t]);
                 }
+                if (a.hid[l]) {
+                    if (src0) store_rows<HT, 0>(h1, a.hid[l], HT * 32, HT * 32, nullptr, 0, row, row_ok, half);
+                    else store_rows<HT, 0>(h0, a.hid[l], HT * 32, HT * 32, nullptr, 0, row, row_ok, half);
+                }
             }
         }
+        if (NL > 1 && a.hid[NL - 1]) store_rows<OT, 0>(out, a.hid[NL - 1], OT * 32, OT * 32, nullptr, 0, row, row_ok, half);
         if (LAST_ACT) {
     #pragma unroll
             for (int t = 0; t < OT; ++t) apply_act<ACT>(out[t]);
@@ -273,7 +280,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
             }
         } else {
             float* yg = a.y + (a.y_group_stride ? (size_t)cg * a.y_group_stride : (size_t)cg * OT * 32);
-            store_rows<OT, EPI == EPI_STORE_RES>(out, yg, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
+            store_rows<OT, EPI == EPI_STORE_MASK ? 2 : (EPI == EPI_STORE_RES ? 1 : 0)>(out, yg, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
         }
     }
 }
@@ -304,6 +311,10 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
     MLP_CASE(1, 1, 1, ACT_NONE, false, false, EPI_STORE)
     MLP_CASE(1, 1, 1, ACT_RELU, true, false, EPI_STORE)
     MLP_CASE(1, 1, 1, ACT_NONE, false, false, EPI_STORE_RES)
+    // backward-data GEMMs with the ReLU mask of the layer below as the epilogue (magnet_amd/autograd.py)
+    MLP_CASE(1, 4, 4, ACT_NONE, false, false, EPI_STORE_MASK)
+    MLP_CASE(1, 2, 2, ACT_NONE, false, false, EPI_STORE_MASK)
+    MLP_CASE(1, 1, 1, ACT_NONE, false, false, EPI_STORE_MASK)
     MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_STORE)
     MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_STORE_RES)
     MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_SEGMEAN)

@@ -16,12 +16,13 @@
 // layer 0: K streamed tile by tile from the gathered sources (hipcc schedules the loads; a hand
 // pipelined version with sched_barriers measured 20-30 % slower, see DESIGN.md "what did not work")
 template <int NT>
-__device__ __forceinline__ void stream_layer(const MagnetMlpArgs& a, const MagnetLayer l0, f32x16 (&out)[NT], int row, int lane) {
+__device__ __forceinline__ void stream_layer(const MagnetMlpArgs& a, const MagnetLayer l0, f32x16 (&out)[NT], int row, int lane, bool row_ok = false) {
     const int half = lane >> 5;
     init_bias<NT>(out, l0.b, half);
     for (int kt = 0; kt < a.nkt; ++kt) {
         const f32x16 x = load_ktile(a.kt[kt], row, half);
         mma_ktile<NT>(x, out, l0.w, kt, lane);
+        if (a.x0_out && row_ok) store_ktile(x, a.x0_out, a.nkt * 32, kt * 32, row, true, half);
     }
 }
 
@@ -42,11 +43,12 @@ __global__ void __launch_bounds__(256) k_mlp(const MagnetMlpArgs a) {
         stream_layer<OT>(a, a.layer[cg], out, row, lane);
     } else {
         f32x16 h0[HT], h1[HT];
-        stream_layer<HT>(a, a.layer[0], h0, row, lane);
+        stream_layer<HT>(a, a.layer[0], h0, row, lane, row_ok);
         if (a.pre[0].p) add_rows<HT>(h0, a.pre[0], row, half);       // per-node products of a factored first layer (magnet_hip.h: pre)
         if (a.pre[1].p) add_rows<HT>(h0, a.pre[1], row, half);
 #pragma unroll
         for (int t = 0; t < HT; ++t) apply_act<ACT>(h0[t]);
+        if (a.hid[0]) store_rows<HT, 0>(h0, a.hid[0], HT * 32, HT * 32, nullptr, 0, row, row_ok, half);
         // middle layers, ping-pong h0 <-> h1 (fully unrolled so register arrays stay static)
 #pragma unroll
         for (int l = 1; l < NL - 1; ++l) {
@@ -54,14 +56,17 @@ __global__ void __launch_bounds__(256) k_mlp(const MagnetMlpArgs a) {
                 dense_layer<HT, HT>(h0, h1, a.layer[l], lane);
 #pragma unroll
                 for (int t = 0; t < HT; ++t) apply_act<ACT>(h1[t]);
+                if (a.hid[l]) store_rows<HT, 0>(h1, a.hid[l], HT * 32, HT * 32, nullptr, 0, row, row_ok, half);
             } else {
                 dense_layer<HT, HT>(h1, h0, a.layer[l], lane);
 #pragma unroll
                 for (int t = 0; t < HT; ++t) apply_act<ACT>(h0[t]);
+                if (a.hid[l]) store_rows<HT, 0>(h0, a.hid[l], HT * 32, HT * 32, nullptr, 0, row, row_ok, half);
             }
         }
         if ((NL - 1) & 1) dense_layer<HT, OT>(h0, out, a.layer[NL - 1], lane);
         else dense_layer<HT, OT>(h1, out, a.layer[NL - 1], lane);
+        if (a.hid[NL - 1]) store_rows<OT, 0>(out, a.hid[NL - 1], OT * 32, OT * 32, nullptr, 0, row, row_ok, half);
     }
     if (LAST_ACT) {
 #pragma unroll
@@ -73,7 +78,7 @@ __global__ void __launch_bounds__(256) k_mlp(const MagnetMlpArgs a) {
         segmean_epilogue_dpp<OT>(out, md, a.M, a.y, a.partials, lane);
     } else {
         float* yg = a.y + (a.y_group_stride ? (size_t)cg * a.y_group_stride : (size_t)cg * OT * 32);   // groups_in_block: always gridDim.y here
-        store_rows<OT, EPI == EPI_STORE_RES>(out, yg, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
+        store_rows<OT, EPI == EPI_STORE_MASK ? 2 : (EPI == EPI_STORE_RES ? 1 : 0)>(out, yg, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
     }
 }
 
@@ -119,6 +124,10 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
     MLP_CASE(1, 1, 1, ACT_NONE, false, false, EPI_STORE)
     MLP_CASE(1, 1, 1, ACT_RELU, true, false, EPI_STORE)
     MLP_CASE(1, 1, 1, ACT_NONE, false, false, EPI_STORE_RES)
+    // backward-data GEMMs with the ReLU mask of the layer below as the epilogue (magnet_amd/autograd.py)
+    MLP_CASE(1, 4, 4, ACT_NONE, false, false, EPI_STORE_MASK)
+    MLP_CASE(1, 2, 2, ACT_NONE, false, false, EPI_STORE_MASK)
+    MLP_CASE(1, 1, 1, ACT_NONE, false, false, EPI_STORE_MASK)
     // MAgNet 5-Linear ReLU MLPs: hidden 128 (HT 4) or 64 (HT 2)
     MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_STORE)
     MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_STORE_RES)

@@ -8,7 +8,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib as L
-from ._lib import ACT_NONE, ACT_RELU, ACT_SWISH, EPI_SEGMEAN, EPI_STORE, EPI_STORE_RES  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, ACT_SWISH, EPI_SEGMEAN, EPI_STORE, EPI_STORE_MASK, EPI_STORE_RES  # noqa: F401
 
 
 def _stream() -> C.c_void_p:
@@ -89,7 +89,8 @@ def mlp_args(M, kts):
 
 
 def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STORE, y=None, ldy=None, ncols=None,
-             res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0, pre=None):
+             res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0, pre=None,
+             x0_out=None, hid=None):
     """Build the argument block of one fused-MLP launch once and return a zero-argument callable that enqueues it on the
     current stream.  For call sites that repeat the same launch on the same buffers (the EDSR convolution stack: 34
     launches of up to 36 gathered k tiles each) this removes the per-call descriptor marshalling from the host path."""
@@ -102,7 +103,16 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
     # instead of G workgroup columns; y_group_stride: floats between the groups' outputs (0: neighbouring column blocks)
     a.groups_in_block = int(colgroups) if groups_in_block and colgroups > 1 else 0
     a.y_group_stride = int(y_group_stride)
-    keep += [layers, ln, y, res, tgt, rowptr, partials, pre]
+    keep += [layers, ln, y, res, tgt, rowptr, partials, pre, x0_out, hid]
+    # tape outputs for a training backward (magnet_hip.h): assembled first-layer input, every layer's activated output, the last
+    # Linear's raw output - one recomputing launch instead of a materialisation pass plus one launch per layer
+    if x0_out is not None:
+        assert x0_out.is_contiguous() and x0_out.shape[1] == len(kts) * 32
+        a.x0_out = x0_out.data_ptr()
+    for i, t in enumerate(hid or ()):
+        if t is not None:
+            assert nl > 1 and t.is_contiguous() and t.shape[1] == (ot if i == nl - 1 else ht) * 32
+            a.hid[i] = t.data_ptr()
     # pre: up to two (rows [n, ld >= first-layer width] fp32, idx int32 or None): gathered rows added to the first Linear's
     # pre-activation (the per-node products of a factored first layer, see magnet_hip.h)
     for i, (t, idx) in enumerate(pre or ()):
@@ -115,7 +125,7 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
         a.ln_g, a.ln_b, a.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
     a.y, a.ldy, a.ncols = y.data_ptr(), int(ldy if ldy is not None else y.shape[-1]), int(ncols if ncols is not None else ot * 32)
     if res is not None:
-        a.res, a.ldres = res.data_ptr(), res.shape[-1]
+        a.res, a.ldres = res.data_ptr(), (res.stride(0) if res.dim() == 2 else res.shape[-1])
     if epi == EPI_SEGMEAN:
         a.tgt, a.rowptr, a.partials = tgt.data_ptr(), rowptr.data_ptr(), partials.data_ptr()
     kind = layers[0][0].dtype                                 # float16: fp16x3, int16: bf16x6, float32: fp32 MFMA
@@ -133,11 +143,12 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
 
 
 def mlp(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STORE, y=None, ldy=None, ncols=None,
-        res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0, pre=None):
+        res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0, pre=None,
+        x0_out=None, hid=None):
     """Run the fused MLP kernel.  ``layers``: list of (packed_w, padded_b).  Returns y."""
     mlp_plan(M, kts, layers, nl=nl, ht=ht, ot=ot, act=act, last_act=last_act, ln=ln, epi=epi, y=y, ldy=ldy, ncols=ncols,
              res=res, tgt=tgt, rowptr=rowptr, partials=partials, colgroups=colgroups, groups_in_block=groups_in_block,
-             y_group_stride=y_group_stride, pre=pre)()
+             y_group_stride=y_group_stride, pre=pre, x0_out=x0_out, hid=hid)()
     return y
 
 
