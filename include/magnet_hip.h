@@ -247,7 +247,7 @@ int magnet_edge_mean_bwd_f32(const float* dagg, const int32_t* tgt, const int32_
 int magnet_segment_sum128_f32(const float* x, const int32_t* rowptr, const int32_t* perm, int n_rows, float* out,
                               void* stream);
 /* dW[0:128, wcol:wcol+kc] (+)= dY[M,128]^T X[M, xcol:xcol+kc]; db[128] (+)= column sums of dY (db may be null);
- * kc in {32,64,96,128}; workspace: nblk*(128*kc+128) + 128*kc floats, nblk = min(512, ceil(M/32)) */
+ * kc in {32,64,96,128}; workspace: nblk*(128*kc+128) + 128*kc floats, nblk = min(768, ceil(M/32)) */
 int magnet_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, int xcol, int kc, long M, float* dW, int ldw,
                      int wcol, float* db, float* workspace, int accumulate, void* stream);
 /* general form: dY has n_out in {32, 64, 128} columns, dW is [n_out][ldw] (same workspace formula) */

@@ -1,6 +1,7 @@
 // Backward-pass building blocks for the MPNN training step (reference autograd through
 // models/mpnn.py:175-203 and the rollout of :254-297).  First generation: correct and deterministic, tensors at
 // edge granularity are materialised (the fused forward kernels stay in use for the forward half of the step).
+#include <cstdlib>
 #include "common.cuh"
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -185,6 +186,102 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_partial(const float* __restric
         if (half == 0) bpartial[(size_t)blockIdx.x * N + wave * 32 + i] = bsum;
     }
 }
+// ---- the same weight gradient on the bf16 matrix cores through the exact three-piece split (common.cuh "bf16x6": six partial
+// products, fp32-class accuracy, full fp32 exponent range - gradients of a mean loss are ~1e-7).  The fp32-MFMA kernel above needs
+// 256 x 64 = 16 384 matrix-pipe cycles per 32-row slab and wave (the E-level launches were matrix-pipe bound: 2.06 of their 2.8 ms);
+// here a slab costs KT x 2 x 6 = 48 MFMA 32x32x16 = 1 536 cycles.  The contraction runs over ROWS m, so both operands must hold 8
+// consecutive rows of one column per lane (A[i = n][k = m], B[k = m][j = column of X]):
+//   * A (this wave's 32 columns of dY) never leaves the wave: lane (n, h) loads dY[m0 + 16 ks + 8 h + c][n0 + n] (c = 0..7, ks = 0, 1:
+//     16 dword loads, 128-byte coalesced per row), splits them into the three pieces in registers;
+//   * B (the X slab) is shared by the four waves: wave w loads and splits the 32 columns of k tile w the same way and writes the
+//     pieces to LDS in fragment order [stage][ks][piece][h][column][8 rows] (16-byte writes and reads, conflict-free); one barrier
+//     per slab, two stages;
+//   * the loads of slab s + 1 are issued before the MFMAs of slab s (32 staging registers).
+template <int KT>
+__global__ void __launch_bounds__(256, 3) k_wgrad_split(const float* __restrict__ dY, int ldy, int N, const float* __restrict__ X,
+                                                        int ldx, int xcol, long M, float* __restrict__ partial /* [grid][N][KT*32] */,
+                                                        float* __restrict__ bpartial /* [grid][N] or null */) {
+    constexpr int KC = KT * 32;
+    __shared__ __attribute__((aligned(16))) u32x4 pb[2][2 * 3 * 2 * KC];        // [stage][ks][piece][h][column]: 12 KiB per k tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    const bool active = wave * 32 < N;                                  // one 32-column n tile of dY per wave
+    const bool conv = wave < KT;                                        // ... and one k tile of X to convert
+    f32x16 acc[KT];
+    zero_tiles<KT>(acc);
+    float bsum = 0.f;
+    const long nslabs = (M + WG_SLAB - 1) / WG_SLAB;
+    float ra[16], rb[16];                                               // raw values of the slab about to be consumed
+    auto load = [&](long sl) {
+        const long m0 = sl * WG_SLAB;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const long m = m0 + 16 * (q >> 3) + 8 * half + (q & 7);
+            const long mc = m < M ? m : M - 1;
+            const float va = active ? dY[mc * ldy + wave * 32 + i] : 0.f;
+            const float vb = conv ? X[mc * ldx + xcol + wave * 32 + i] : 0.f;
+            ra[q] = m < M ? va : 0.f;
+            rb[q] = m < M ? vb : 0.f;
+        }
+    };
+    long sl = blockIdx.x;
+    if (sl < nslabs) load(sl);
+    for (int it = 0; sl < nslabs; sl += gridDim.x, ++it) {
+        // ---- split this slab's values; B pieces -> LDS stage it & 1, A pieces stay in registers
+        bf16x8 ah[2], am[2], al[2];
+        u32x4* st = pb[it & 1];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                v[c] = ra[8 * ks + c];
+                bsum += v[c];
+            }
+            split_bf16x3(v, ah[ks], am[ks], al[ks]);
+            if (conv) {
+                bf16x8 h_, m_, l_;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = rb[8 * ks + c];
+                split_bf16x3(v, h_, m_, l_);
+                u32x4* d = st + ((ks * 3) * 2 + half) * KC + wave * 32 + i;
+                d[0] = __builtin_bit_cast(u32x4, h_);
+                d[2 * KC] = __builtin_bit_cast(u32x4, m_);
+                d[4 * KC] = __builtin_bit_cast(u32x4, l_);
+            }
+        }
+        __syncthreads();                                                // every k tile's pieces of this slab are in LDS; the other
+                                                                        // stage is free (all waves finished the previous slab)
+        const long nxt = sl + gridDim.x;
+        if (nxt < nslabs) load(nxt);                                    // in flight during the MFMAs below
+        if (active) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const u32x4* f = st + ((ks * 3) * 2 + half) * KC + kt * 32 + i;
+                    const bf16x8 xh = __builtin_bit_cast(bf16x8, f[0]);
+                    const bf16x8 xm = __builtin_bit_cast(bf16x8, f[2 * KC]);
+                    const bf16x8 xl = __builtin_bit_cast(bf16x8, f[4 * KC]);
+                    acc[kt] = mma_split6(ah[ks], am[ks], al[ks], xh, xm, xl, acc[kt]);
+                }
+        }
+    }
+    if (!active) return;
+    float* out = partial + (size_t)blockIdx.x * N * KC;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // C/D row = A's i = n
+            out[(size_t)n * KC + kt * 32 + i] = acc[kt][r];                    // C/D col = B's j = k
+        }
+    if (bpartial) {
+        bsum += __shfl_xor(bsum, 32);
+        if (half == 0) bpartial[(size_t)blockIdx.x * N + wave * 32 + i] = bsum;
+    }
+}
+
 // out[g][j] (+)= scale * sum_b partial[g][b][j]   (fixed summation order: deterministic).  32 consecutive j per
 // workgroup (coalesced), 8 interleaved sub-sums per j combined through LDS.
 __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ partial, int nblk, long n, float scale,
@@ -420,7 +517,7 @@ extern "C" int magnet_segment_sum128_f32(const float* x, const int32_t* rowptr, 
     END();
 }
 // dW[128][kc] (+)= dY^T X[:, xcol : xcol+kc], db[128] (+)= column sums of dY (db may be null).
-// workspace: nblk * (128 * kc + 128) + 128 * kc floats, nblk = min(512, ceil(M / 32)).
+// workspace: nblk * (128 * kc + 128) + 128 * kc floats, nblk = min(768, ceil(M / 32)).
 // general form: dY has n_out in {32, 64, 128} columns (weight rows), dW is [n_out][ldw]
 extern "C" int magnet_wgrad_n_f32(const float* dY, int ldy, int n_out, const float* X, int ldx, int xcol, int kc, long M, float* dW,
                                   int ldw, int wcol, float* db, float* workspace, int accumulate, void* stream) {
@@ -428,14 +525,25 @@ extern "C" int magnet_wgrad_n_f32(const float* dY, int ldy, int n_out, const flo
     if (M <= 0) return 0;
     if (kc % 32 || kc < 32 || kc > 128 || (n_out != 32 && n_out != 64 && n_out != 128)) return -2;
     const int N = n_out;
-    const int nblk = (int)((M + WG_SLAB - 1) / WG_SLAB < 512 ? (M + WG_SLAB - 1) / WG_SLAB : 512);
+    const int nblk = (int)((M + WG_SLAB - 1) / WG_SLAB < 768 ? (M + WG_SLAB - 1) / WG_SLAB : 768);
     float* part = workspace;
     float* bpart = db ? workspace + (size_t)nblk * N * kc : nullptr;
-    switch (kc / 32) {
-        case 1: hipLaunchKernelGGL(k_wgrad_partial<1>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
-        case 2: hipLaunchKernelGGL(k_wgrad_partial<2>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
-        case 3: hipLaunchKernelGGL(k_wgrad_partial<3>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
-        default: hipLaunchKernelGGL(k_wgrad_partial<4>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
+    static int use_fp32 = -1;        // MAGNET_WGRAD=fp32 keeps the fp32-MFMA kernel (A/B knob; the split kernel is the default)
+    if (use_fp32 < 0) { const char* e = getenv("MAGNET_WGRAD"); use_fp32 = (e && e[0] == 'f') ? 1 : 0; }
+    if (use_fp32) {
+        switch (kc / 32) {
+            case 1: hipLaunchKernelGGL(k_wgrad_partial<1>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
+            case 2: hipLaunchKernelGGL(k_wgrad_partial<2>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
+            case 3: hipLaunchKernelGGL(k_wgrad_partial<3>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
+            default: hipLaunchKernelGGL(k_wgrad_partial<4>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
+        }
+    } else {
+        switch (kc / 32) {
+            case 1: hipLaunchKernelGGL(k_wgrad_split<1>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
+            case 2: hipLaunchKernelGGL(k_wgrad_split<2>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
+            case 3: hipLaunchKernelGGL(k_wgrad_split<3>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
+            default: hipLaunchKernelGGL(k_wgrad_split<4>, dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart); break;
+        }
     }
     // reduce into a scratch tile, then place it at dW[:, wcol : wcol+kc]
     float* tile = workspace + (size_t)nblk * (128 * kc + 128);
@@ -445,7 +553,7 @@ extern "C" int magnet_wgrad_n_f32(const float* dY, int ldy, int n_out, const flo
     END();
 }
 // dW[0:128, wcol:wcol+kc] (+)= dY[M,128]^T X[M, xcol:xcol+kc], db[128] (+)= column sums of dY (db may be null).
-// workspace: nblk * (128 * kc + 128) + 128 * kc floats, nblk = min(512, ceil(M / 32)).
+// workspace: nblk * (128 * kc + 128) + 128 * kc floats, nblk = min(768, ceil(M / 32)).
 extern "C" int magnet_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, int xcol, int kc, long M, float* dW, int ldw,
                                 int wcol, float* db, float* workspace, int accumulate, void* stream) {
     return magnet_wgrad_n_f32(dY, ldy, 128, X, ldx, xcol, kc, M, dW, ldw, wcol, db, workspace, accumulate, stream);

@@ -357,7 +357,7 @@ def segment_sum128(x, rowptr, n_rows, perm=None, out=None):
 
 
 def wgrad_workspace(M, device):
-    nblk = min(512, (M + 31) // 32)
+    nblk = min(768, (M + 31) // 32)
     return torch.empty(nblk * (128 * 128 + 128) + 128 * 128, device=device, dtype=torch.float32)
 
 
