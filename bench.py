@@ -33,6 +33,11 @@ Extra objects on the JSON line:
                   FETCH_SIZE doubled per the gfx950 correction); null when the workload differs from the recorded one.
                   Edge kernel 0.62 GB (0.75 GB algorithmic; 1.58 GB before the XCD-aware tile ranges), scatter-mean 4.57 GB =
                   1.00x algorithmic.
+  c4b, c5       - the other two 256^2 cases of SURVEY.md 8(d) as complete objects of the same contract (value, ms_per_step, roofline of
+                  their dominant kernel - the InteractionNetwork edge chain of the joint graph -, training_step): `magnet_cnn_2d` 64^2 LR
+                  grid -> 256^2 queries and `magnet_gnn` 256 irregular LR nodes -> 256^2 queries, one trajectory per GPU.
+  c1            - BASELINE.json configs[0] on the GPU: `mpnn` 1-D, 2 x 50 nodes, 9-forward rollout replayed from one hipGraph (ms per
+                  rollout, and the kernel-by-kernel time beside it); rank 0 only.
   training_step - the same workload trained: rollout with tape, HIP backward
                   kernels, ONE flat gradient all-reduce over RCCL, fused Adam; ms per step and the node-updates/s it
                   corresponds to (all ranks), `--train-steps` timed steps after one warm-up.  Never part of `value`.

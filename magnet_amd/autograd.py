@@ -185,11 +185,13 @@ class _Mlp(torch.autograd.Function):
                 W, b = params[2 * l], params[2 * l + 1]
                 n, k = W.shape
                 Np, Kp = dz.shape[1], X[l].shape[1]
-                dWp = torch.zeros(Np, Kp, device=dev, dtype=torch.float32)
-                dbp = torch.zeros(Np, device=dev, dtype=torch.float32)
+                # the column tiles cover all Kp columns and all Np rows: written, not accumulated - no zero fill needed
+                alloc = torch.empty if M > 0 else torch.zeros           # (no rows: the kernel returns without writing)
+                dWp = alloc(Np, Kp, device=dev, dtype=torch.float32)
+                dbp = alloc(Np, device=dev, dtype=torch.float32)
                 for j, (c0, w) in enumerate(_tiles_of(Kp)):
                     L.check(L.lib().magnet_wgrad_n_f32(ops._p(dz), Np, Np, ops._p(X[l]), Kp, c0, w, C.c_long(M), ops._p(dWp), Kp, c0,
-                                                       ops._p(dbp if j == 0 else None), ops._p(ws), 1, ops._stream()), "wgrad_n")
+                                                       ops._p(dbp if j == 0 else None), ops._p(ws), 0, ops._stream()), "wgrad_n")
                 if l == 0 and m.first_cols is not None:
                     gW = torch.zeros_like(W)
                     gW[:, m.first_cols] = dWp[:n][:, m.col_map]
