@@ -110,3 +110,52 @@ def test_instance_norm_vs_functional():
         assert torch.allclose(got[o:o + n], want, atol=2e-6)
         o += n
     assert not math.isnan(float(got.sum()))
+
+
+# ---- cross-checks against INDEPENDENT library implementations that exist in this image (scipy's cKDTree, torch's own
+# scatter_reduce): they do not pin the cap-32 selection rule or the k-NN tie order (torch_cluster itself cannot be installed), but
+# they do pin the in-radius neighbour SETS, the edge direction, the strictness of the comparison and the mean's empty-row rule to
+# code this repository did not write.
+def test_radius_neighbour_sets_match_scipy_ckdtree_when_the_cap_is_inactive():
+    from scipy.spatial import cKDTree
+    g = torch.Generator().manual_seed(21)
+    sizes = [90, 57]
+    x = torch.cat([torch.rand(n, 2, generator=g) for n in sizes])
+    batch = torch.cat([torch.full((n,), b, dtype=torch.long) for b, n in enumerate(sizes)])
+    r = 0.11                                                       # ~3.4 in-radius points on average: far below the cap
+    ei = S.radius_graph(x, r, batch, loop=False)
+    assert int(torch.bincount(ei[1], minlength=x.shape[0]).max()) < 32
+    got = {(int(j), int(i)) for j, i in ei.t().tolist()}           # (found neighbour j, query i)
+    want, o = set(), 0
+    for n in sizes:
+        pts = x[o:o + n].double().numpy()
+        tree = cKDTree(pts)
+        for i, nb in enumerate(tree.query_ball_point(pts, r)):
+            for j in nb:
+                d2 = float(((x[o + i] - x[o + j]) ** 2).sum())
+                if j != i and abs(d2 - r * r) > 1e-9:              # the strict '<' is tested by the naive-loop test; skip exact ties
+                    want.add((o + j, o + i))
+        o += n
+    assert got == want
+    assert bool((ei[1][1:] >= ei[1][:-1]).all())                   # grouped by query (= PyG target), ascending
+
+
+def test_knn_matches_scipy_ckdtree_without_ties():
+    from scipy.spatial import cKDTree
+    g = torch.Generator().manual_seed(22)
+    x, y = torch.rand(70, 2, generator=g), torch.rand(40, 2, generator=g)
+    zx, zy = torch.zeros(70, dtype=torch.long), torch.zeros(40, dtype=torch.long)
+    got = S.knn(x, y, 4, zx, zy)
+    _, idx = cKDTree(x.double().numpy()).query(y.double().numpy(), k=4)
+    assert torch.equal(got[1].view(40, 4), torch.from_numpy(idx))
+    assert torch.equal(got[0].view(40, 4), torch.arange(40)[:, None].expand(40, 4))
+
+
+def test_scatter_mean_matches_torch_scatter_reduce():
+    g = torch.Generator().manual_seed(23)
+    src = torch.randn(300, 5, generator=g)
+    idx = torch.randint(0, 40, (300,), generator=g)
+    idx[idx == 7] = 8                                              # an empty row
+    got = S.scatter_mean(src, idx, 45)
+    want = torch.zeros(45, 5).scatter_reduce(0, idx[:, None].expand(-1, 5), src, reduce="mean", include_self=False)
+    assert torch.allclose(got, want, atol=1e-6) and float(got[7].abs().sum()) == 0.0
