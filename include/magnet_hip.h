@@ -76,7 +76,8 @@ typedef struct {
     magnet_src_t pre[2];     /* nl > 1 only, p == NULL = off: rows added to the first
                               * Linear's pre-activation, pre[s].p[(idx ? idx[row] : row) * ld + 0 .. first-layer width).  This is
                               * how a Linear over torch.cat([x_i, x_j, e]) (InteractionNetwork.message, models/magnet_gnn.py:79-83)
-                              * runs with K = width(e) only: W [x_i, x_j, e] + b = (Wa x)[i] + (Wb x)[j] + Wc e + b, the two
+                              * runs with K = width(e) only: W [x_i, x_j, e] + b = ((Wa x)[i] + b) + (Wb x)[j] + Wc e (pre[0] carries the bias: with both
+                              * sources set the fp16x3 kernel starts its accumulators from the gathered rows), the two
                               * per-node products computed once per node instead of once per edge (col / scale / rdiv unused) */
     float* x0_out;           /* optional (NULL = off) tape outputs for a training backward (no reference counterpart: torch autograd
                               * keeps these tensors alive instead): the first Linear's assembled input rows [M][nkt*32], */

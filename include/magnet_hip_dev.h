@@ -11,6 +11,8 @@ extern "C" {
 int magnet_debug_set_variant(int which, int value);
 /* run-time ablation flags of the split-GEMM MLP kernel */
 int magnet_debug_set_mlp_ablation(int value);
+/* cycle trace (s_memtime stamps + phase tags) of wave 0 of workgroup `wg` of the split-GEMM MLP kernel into buf[1000] (uint64) */
+int magnet_debug_set_mlp_trace(void* buf, int wg);
 #ifdef __cplusplus
 }
 #endif

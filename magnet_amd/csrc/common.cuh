@@ -422,6 +422,56 @@ __device__ __forceinline__ f32x16 ktile_data(const MagnetKTile& d, const KRows& 
 __device__ __forceinline__ f32x16 load_ktile(const MagnetKTile& d, int row, int half) {
     return ktile_data(d, ktile_rows(d, row), half);
 }
+// The same fetch in two steps: ktile_raw only ISSUES the loads (the loaded registers are not touched), ktile_finish applies the
+// scales / the sum of the two sources.  A kernel that requests k tile kt+1 while it works on k tile kt must not do arithmetic on
+// the loaded values in the issuing phase - the multiply by `scale` in ktile_data makes the wave wait for the data right there (cycle
+// trace of the C5 edge chain: 3 300 cycles per first-layer iteration between the barrier and the MFMAs, a full memory round trip).
+struct KRaw {
+    f32x4 a[4];
+};
+__device__ __forceinline__ KRaw ktile_raw(const MagnetKTile& d, const KRows& r, int half) {
+    KRaw v;
+    const float* p = d.s[0].p + r.r0 * d.s[0].ld + d.s[0].col + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) v.a[g] = *reinterpret_cast<const f32x4*>(p + 8 * g);
+    if (d.n > 1) {             // two summed sources (the edge encoders' u_s - u_r): combined here as before - staging both raw
+                               // costs 16 more registers and the 64-wide chains a wave per SIMD (138 -> 170 registers, measured)
+        const float* q = d.s[1].p + r.r1 * d.s[1].ld + d.s[1].col + 4 * half;
+        const float s0 = d.s[0].scale, s1 = d.s[1].scale;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(q + 8 * g);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v.a[g][c] = v.a[g][c] * s0 + t[c] * s1;
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ f32x16 ktile_finish(const MagnetKTile& d, const KRaw& v) {
+    f32x16 x;
+    const float s0 = d.n > 1 ? 1.0f : d.s[0].scale;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[4 * g + c] = v.a[g][c] * s0;
+    return x;
+}
+// accumulator tiles <- gathered rows (pure loads: nothing touches the registers until their first use)
+template <int NT>
+__device__ __forceinline__ void load_rows(f32x16 (&out)[NT], const MagnetSrc& src, int row, int half) {
+    const int r = src.idx ? src.idx[row] : row;
+    const float* p = src.p + (size_t)r * src.ld + 4 * half;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p + nt * 32 + 8 * g);
+            out[nt][4 * g + 0] = t[0];
+            out[nt][4 * g + 1] = t[1];
+            out[nt][4 * g + 2] = t[2];
+            out[nt][4 * g + 3] = t[3];
+        }
+}
 
 // LayerNorm over the NT*32 columns of each row (row split across lanes l and l^32)
 template <int NT>

@@ -106,8 +106,15 @@ __device__ __forceinline__ void fold_tiles(f32x16 (&accM)[NT], f32x16 (&accC)[NT
 #ifdef MAGNET_DEV_VARIANTS
 __device__ int g_mlp_abl = 0;
 #define MLP_ABL_INIT const int abl = __builtin_amdgcn_readfirstlane(g_mlp_abl);
+// cycle trace (development builds): wave 0 of workgroup g_mlp_trace_wg writes s_memtime stamps with a phase tag
+__device__ unsigned long long* g_mlp_trace = nullptr;
+__device__ int g_mlp_trace_wg = 0;
+#define TRACE_INIT int tr_n = 0; const bool tr_on = g_mlp_trace && (int)blockIdx.x == g_mlp_trace_wg && threadIdx.x == 0;
+#define TRACE(tag) if (tr_on && tr_n < 500) { g_mlp_trace[2 * tr_n] = __builtin_readcyclecounter(); g_mlp_trace[2 * tr_n + 1] = (tag); ++tr_n; }
 #else
 #define MLP_ABL_INIT constexpr int abl = 0;
+#define TRACE_INIT
+#define TRACE(tag)
 #endif
 
 // DIST: chunks requested ahead.  1 for full grids: 2 (three-slot ring, counted vmcnt) paid +7 % while the wide 5-Linear chains ran
@@ -117,6 +124,8 @@ __device__ int g_mlp_abl = 0;
 template <int MODE, int NL, int HT, int OT, int ACT, bool LAST_ACT, bool LN, int EPI, int DIST = 1>
 __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
     MLP_ABL_INIT
+    TRACE_INIT
+    TRACE(1)
     constexpr int NTMAX = MaxI<HT, OT>::v;
     constexpr int PPN = 2 * Split<MODE>::NP;                              // 1 KiB pieces per output tile and k tile
     constexpr int NBUF = DIST + 1;
@@ -167,30 +176,51 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
         // ---------------- layer 0: K streamed from the sources
         {
             f32x16 acc[NT0], accc[NT0];
-            init_bias<NT0>(acc, l0.b, half);
-            zero_tiles<NT0>(accc);
-            f32x16 x = load_ktile(a.kt[0], row, half);
+            // per-node products of a factored first layer (magnet_hip.h: pre): pre[0] (which already contains the bias) IS the
+            // accumulator's initial value and pre[1] the cross accumulator's (scaled by 2^11 after it has landed: the fold divides it
+            // out again) - pure loads issued here, first touched after the first barrier, instead of 2 x 16 gathered loads that the
+            // wave waited for between the first layer and its activation
+            const bool pre_init = NL > 1 && MODE == GEMM_FP16X3 && a.pre[0].p && a.pre[1].p;
+            if (pre_init) {
+                load_rows<NT0>(acc, a.pre[0], row, half);
+                load_rows<NT0>(accc, a.pre[1], row, half);
+            } else {
+                init_bias<NT0>(acc, l0.b, half);
+                zero_tiles<NT0>(accc);
+            }
+            KRaw xr = ktile_raw(a.kt[0], ktile_rows(a.kt[0], row), half);
             KRows rn = ktile_rows(a.kt[a.nkt > 1 ? 1 : 0], row);          // indices of k tile 1, requested one iteration early
             for (int kt = 0; kt < a.nkt; ++kt, ++c) {
                 // outstanding, oldest first: chunk c, x tile kt, indices of kt+1, chunk c+1  ->  leave only chunk c+1 in flight
+                TRACE(10)
                 if (DIST == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (kt + 1 < a.nkt) wait_all_but_one_chunk<NT0 * PPN>();
                 else if (NL > 1) wait_all_but_one_chunk<NT1 * PPN>();
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                TRACE(11)
                 if (!(abl & 8)) __syncthreads();
-                // data of x tile kt+1 (its indices arrived during the previous iteration), indices of x tile kt+2, then
+                TRACE(12)
+                const f32x16 x = ktile_finish(a.kt[kt], xr);               // x tile kt has landed: scales / sum of the sources now
+                if (pre_init && kt == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT0; ++t)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) accc[t][q] *= 2048.0f;
+                }
+                // raw loads of x tile kt+1 (its indices arrived during the previous iteration), indices of x tile kt+2, then
                 // chunk c+2: the next iteration's counted wait then covers both
-                const f32x16 xn = (abl & 16) ? x : ktile_data(a.kt[kt + 1 < a.nkt ? kt + 1 : kt], rn, half);
+                if (!(abl & 16)) xr = ktile_raw(a.kt[kt + 1 < a.nkt ? kt + 1 : kt], rn, half);
                 rn = ktile_rows(a.kt[kt + 2 < a.nkt ? kt + 2 : a.nkt - 1], row);
                 if (abl & 2) {
                 } else if (kt + DIST < a.nkt) dma_chunk<NT0 * PPN>(l0.w + (size_t)(kt + DIST) * NT0 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
                 else if (NL > 1 && kt + DIST - a.nkt < HT) dma_chunk<NT1 * PPN>(a.layer[1].w + (size_t)(kt + DIST - a.nkt) * NT1 * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
+                TRACE(13)
                 if (!(abl & 1)) mma_chunk<NT0, MODE, PIPE>(x, acc, accc, wbuf + (c % NBUF) * CH, lane);
+                TRACE(14)
                 if (a.x0_out && gi == 0) store_ktile(x, a.x0_out, a.nkt * 32, kt * 32, row, row_ok, half);
-                x = xn;
             }
             fold_tiles<NT0, MODE>(acc, accc);
-            if (NL > 1) {                                  // per-node products of a factored first layer (magnet_hip.h: pre)
+            if (NL > 1 && !pre_init) {                     // (other GEMM modes: added after the first layer)
                 if (a.pre[0].p) add_rows<NT0>(acc, a.pre[0], row, half);
                 if (a.pre[1].p) add_rows<NT0>(acc, a.pre[1], row, half);
             }
@@ -225,10 +255,13 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                 // chunk c+1: next k tile of this layer, or the first k tile of the next layer, or nothing (very last chunk)
                 const bool has_next = (kt + 1 < HT) || (l + 1 < NL);
                 const bool next_is_last_layer = (kt + 1 < HT) ? last : (l + 1 == NL - 1);
+                TRACE(20)
                 if (!has_next || DIST == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (next_is_last_layer) wait_all_but_one_chunk<OT * PPN>();
                 else wait_all_but_one_chunk<HT * PPN>();
+                TRACE(21)
                 if (!(abl & 8)) __syncthreads();
+                TRACE(22)
                 // chunk c+2
                 if (!(abl & 2)) {
                     const int k2 = kt + DIST;
@@ -241,10 +274,12 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                         else dma_chunk<HT * PPN>(a.layer[l + 1 < NL ? l + 1 : l].w + (size_t)k3 * HT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
                     }
                 }
+                TRACE(23)
                 if (abl & 1) {
                 } else if (last) mma_chunk<OT, MODE, PIPE>(src0 ? h0[kt] : h1[kt], out, cco, wbuf + (c % NBUF) * CH, lane);
                 else if (src0) mma_chunk<HT, MODE, PIPE>(h0[kt], h1, cch, wbuf + (c % NBUF) * CH, lane);
                 else mma_chunk<HT, MODE, PIPE>(h1[kt], h0, cch, wbuf + (c % NBUF) * CH, lane);
+                TRACE(24)
             }
             if (last) fold_tiles<OT, MODE>(out, cco);
             else if (src0) fold_tiles<HT, MODE>(h1, cch);
@@ -266,7 +301,9 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
     #pragma unroll
             for (int t = 0; t < OT; ++t) apply_act<ACT>(out[t]);
         }
+        TRACE(30)
         if (LN) layer_norm_rows<OT>(out, a.ln_g, a.ln_b, a.ln_eps, half);
+        TRACE(31)
 
         if (abl & 4) {
             if (out[0][0] == 12345.678f) a.y[0] = 1.f;      // keep the computation alive
@@ -282,6 +319,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
             float* yg = a.y + (a.y_group_stride ? (size_t)cg * a.y_group_stride : (size_t)cg * OT * 32);
             store_rows<OT, EPI == EPI_STORE_MASK ? 2 : (EPI == EPI_STORE_RES ? 1 : 0)>(out, yg, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
         }
+        TRACE(32)
     }
 }
 
@@ -369,5 +407,10 @@ extern "C" int magnet_mlp_fp16x3_f32(const MagnetMlpArgs* args, int nl, int ht, 
 #ifdef MAGNET_DEV_VARIANTS
 extern "C" int magnet_debug_set_mlp_ablation(int value) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_abl), &value, sizeof(int));
+}
+// cycle trace of one wave: buf = device buffer of 1000 uint64 (stamp, tag pairs), wg = the workgroup whose wave 0 writes it
+extern "C" int magnet_debug_set_mlp_trace(void* buf, int wg) {
+    int rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_trace), &buf, sizeof(void*));
+    return rc ? rc : (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_trace_wg), &wg, sizeof(int));
 }
 #endif

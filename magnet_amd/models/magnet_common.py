@@ -84,18 +84,23 @@ def pack_interaction_edge(seq, D):
     mode = default_gemm()
     W0 = lins[0].weight.detach()
     assert W0.shape[1] == 3 * D and D % 32 == 0
-    layers = [pack(W0[:, 2 * D:], lins[0].bias, mode)] + [pack(l.weight, l.bias, mode) for l in lins[1:]]
-    chain = types.SimpleNamespace(layers=layers, ln=(ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps),
-                                  ht=mlp.hidden // 32, ot=pad_to(mlp.out_dim) // 32, out_dim=mlp.out_dim, col_map=None)
-    return chain, pack(W0[:, :D], None, mode), pack(W0[:, D:2 * D], None, mode)
+    # b0 travels with the receiver's product (the chain kernel starts its first accumulator FROM the gathered row, magnet_hip.h: pre);
+    # `e_scale` = 2^k of hop k (Q2: e_k = 2^k e_0) is folded into W0c - a power of two, exact - so that the kernel loads e_0 unscaled
+    def chain_for(e_scale):
+        layers = [pack(W0[:, 2 * D:] * float(e_scale), None, mode)] + [pack(l.weight, l.bias, mode) for l in lins[1:]]
+        return types.SimpleNamespace(layers=layers, ln=(ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps),
+                                     ht=mlp.hidden // 32, ot=pad_to(mlp.out_dim) // 32, out_dim=mlp.out_dim, col_map=None)
+    return chain_for, pack(W0[:, :D], lins[0].bias, mode), pack(W0[:, D:2 * D], None, mode)
 
 
 def pack_graph_net(enc: Encoder, proc: Processor, ldn: int):
     hops = []
-    for g in proc.gnn_stacks:
+    for k, g in enumerate(proc.gnn_stacks):
         D = g.node_fn[0].out_dim
-        chain, pre_i, pre_j = pack_interaction_edge(g.edge_fn, D)
-        hops.append(types.SimpleNamespace(edge=pack_mlp_ln(g.edge_fn), node=pack_mlp_ln(g.node_fn), edge_f=chain, pre_i=pre_i, pre_j=pre_j))
+        chain_for, pre_i, pre_j = pack_interaction_edge(g.edge_fn, D)
+        factored = g.edge_fn[0].hidden <= D                        # see MagnetBase._graph_net
+        hops.append(types.SimpleNamespace(edge=pack_mlp_ln(g.edge_fn), node=pack_mlp_ln(g.node_fn),
+                                          edge_f=chain_for(2 ** k) if factored else None, pre_i=pre_i, pre_j=pre_j))
     return types.SimpleNamespace(node=pack_mlp_ln(enc.node_fn, k_pad=ldn), edge=pack_mlp_ln(enc.edge_fn, k_pad=ldn), hops=hops)
 
 
@@ -206,7 +211,7 @@ class MagnetBase(LightningModule):
         # edge_fn([x_i, x_j, e]) with the first Linear factored per node (pack_interaction_edge) when that does not widen the
         # gathered rows (hidden <= latent: MAgNet[GNN] 128 / 128; the CNN models' 64-wide chains over 32-wide latents keep the
         # concatenated form - measured: C5 edge chain 1.55 -> 1.21 ms, C4b 0.38 -> 0.39 ms)
-        Hm = pk.hops[0].edge_f.ht * 32 if pk.hops else 0
+        Hm = pk.hops[0].edge.ht * 32 if pk.hops else 0
         factored = 0 < Hm <= D
         if factored:
             PQ = torch.empty(2, N, Hm, device=dev, dtype=torch.float32)   # per-node halves of the edge chains' first Linear
@@ -216,7 +221,7 @@ class MagnetBase(LightningModule):
                 # chain over e_k = 2^k e_0 (Q2) alone
                 ops.mlp(N, ops.ktiles(T_(x, D)), [hop.pre_i, hop.pre_j], nl=1, ht=Hm // 32, ot=Hm // 32, act=ops.ACT_NONE, y=PQ, ldy=Hm,
                         colgroups=2, groups_in_block=True, y_group_stride=N * Hm)
-                run_mlp(E, ops.ktiles(T_(e0, D, scale=float(2 ** k))), hop.edge_f, agg, epi=ops.EPI_SEGMEAN, tgt=csr.tgt,
+                run_mlp(E, ops.ktiles(T_(e0, D)), hop.edge_f, agg, epi=ops.EPI_SEGMEAN, tgt=csr.tgt,
                         rowptr=csr.rowptr, partials=partials, pre=[(PQ[0], csr.tgt), (PQ[1], csr.src)])
             else:
                 kts = ops.ktiles(T_(x, D, idx=csr.tgt), T_(x, D, idx=csr.src), T_(e0, D, scale=float(2 ** k)))
