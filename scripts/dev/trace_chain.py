@@ -22,7 +22,8 @@ rowptr = torch.arange(0, E + 1, deg, device="cuda", dtype=torch.int32)
 agg = torch.empty(N, D, device="cuda"); partials = torch.empty(((E + 31) // 32) * 2 * D + 1, device="cuda")
 T_ = ops.Term
 if fact:
-    chain, pi, pj = pack_interaction_edge(net, D)
+    chain_for, pi, pj = pack_interaction_edge(net, D)
+    chain = chain_for(1)
     PQ = torch.randn(2, N, H, device="cuda")
     run = lambda: run_mlp(E, ops.ktiles(T_(e0, D)), chain, agg, epi=ops.EPI_SEGMEAN, tgt=tgt, rowptr=rowptr, partials=partials, pre=[(PQ[0], tgt), (PQ[1], src)])
 else:
