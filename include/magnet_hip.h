@@ -180,6 +180,21 @@ int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const
  * workspace: (2*n_graphs*ceil(rows_per_graph/64) + 2*n_graphs) * H floats. */
 int magnet_instance_norm_f32(const float* x, int n_graphs, int rows_per_graph, int H, float eps, float* y,
                              float* workspace, void* stream);
+/* The same InstanceNorm in two steps, for callers that fuse the normalisation into the next consumer's loads:
+ * statistics only - mean [n_graphs][H] at workspace + n_graphs*ceil(rows_per_graph/64)*H, biased variance right behind it
+ * (same workspace size as above). */
+int magnet_instance_norm_stats_f32(const float* x, int n_graphs, int rows_per_graph, int H, float* workspace, void* stream);
+/* One MPNN hop's per-node halves of message_net_1 (models/mpnn.py:73-79: the Linear over cat(x_i, x_j, u_i - u_j, pos_i - pos_j,
+ * variables) splits into a target half A and a source half Bm, evaluated once per NODE) fused with the InstanceNorm apply of the
+ * previous hop (models/mpnn.py:70 `x = self.norm(x, batch)`):
+ *   hn = mean ? (h - mean[g]) / sqrt(var[g] + eps) : h      (g = row / rows_per_graph)
+ *   A  = Wa [hn | node_in] + ba,   Bm = Wb [hn | node_in] + bb,   h_norm = hn (if mean and h_norm)
+ * h [n][128], node_in [n][kin], kin in {32, 64}; wa / wb: fp16x3 planes of the two [128][128 + kin] weight halves in the layout
+ * magnet_mlp_fp16x3_f32 takes (magnet_amd/packing.py:pack_linear_fp16x2).  Returns -2 for an unsupported shape (kin, more than
+ * 8 graphs, rows_per_graph not a multiple of 32): the caller then uses magnet_instance_norm_f32 + magnet_mlp_fp16x3_f32. */
+int magnet_mpnn_node_halves_f32(const float* h, const float* node_in, int kin, long n_rows, const float* mean, const float* var,
+                                float eps, int n_graphs, int rows_per_graph, const void* wa_f16, const float* ba,
+                                const void* wb_f16, const float* bb, float* A, float* Bm, float* h_norm, void* stream);
 
 /* ---- neighbour search / CSR (torch_cluster radius_graph / knn call sites: models/mpnn.py:245,
  *      models/magnet_gnn.py:247,293) ---- */

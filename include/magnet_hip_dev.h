@@ -13,6 +13,8 @@ int magnet_debug_set_variant(int which, int value);
 int magnet_debug_set_mlp_ablation(int value);
 /* cycle trace (s_memtime stamps + phase tags) of wave 0 of workgroup `wg` of the split-GEMM MLP kernel into buf[1000] (uint64) */
 int magnet_debug_set_mlp_trace(void* buf, int wg);
+/* run-time ablation flags of the fused MPNN edge backward kernel (csrc/mpnn_edge_bwd.hip) */
+int magnet_debug_set_edge_bwd_ablation(int value);
 #ifdef __cplusplus
 }
 #endif

@@ -68,7 +68,8 @@ def lib() -> C.CDLL:
             fn = getattr(_lib, name)          # AttributeError if the .so does not export it
             fn.restype = C.c_int
         if DEV:
-            for name in ("magnet_debug_set_variant", "magnet_debug_set_mlp_ablation", "magnet_debug_set_mlp_trace"):
+            for name in ("magnet_debug_set_variant", "magnet_debug_set_mlp_ablation", "magnet_debug_set_mlp_trace",
+                         "magnet_debug_set_edge_bwd_ablation"):
                 getattr(_lib, name).restype = C.c_int
     return _lib
 

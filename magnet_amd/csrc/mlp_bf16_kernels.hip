@@ -377,6 +377,195 @@ static int launch_mlp(mlp_fn fn, const MagnetMlpArgs* args, void* stream) {
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------- MPNN per-node halves, weights resident
+// A = W1a [h | node_in] + b1 and Bm = W1b [h | node_in] (the per-node factorisation of message_net_1, models/mpnn.py:73-79 /
+// models/mpnn_2d.py:73-79) for one hop, fused with the InstanceNorm APPLY of the previous hop (GNN_Layer.forward, mpnn_2d.py:69:
+// `x = self.norm(x, batch)`): the kernel reads the un-normalised update output, normalises it on load with the per-(graph, channel)
+// mean / variance, and - besides A and Bm - writes the normalised h that the next update reads.  One launch instead of
+// k_norm_apply + the generic one-Linear kernel, and no pass over h in between.
+//
+// The generic kernel streams weight chunks through an LDS ring with a barrier per k tile and two workgroups per CU; at 1 Linear
+// that structure is all overhead (measured at 4 x 256^2 rows, scripts/bench_node_abl.py: 166 us of which 42 us is the empty
+// skeleton, 44 us exposed source loads, 46 us the epilogue; 2.6 TB/s).  Here one workgroup of 8 waves per CU keeps ONE column
+// group's planes (NKT x 16 KiB) in LDS for its lifetime, waves are independent (no barrier after the prologue), every wave walks
+// 32-row tiles and the loads of its next tile are requested k tile by k tile as the current tile's registers are consumed.
+// Workgroups b and b + 8 (same XCD, same L2) hold the two column groups and walk the same rows at the same time, so the second
+// read of [h | node_in] is an L2 hit.  Same split arithmetic and accumulation order as k_mlp_bf16<GEMM_FP16X3, 1, 4, 4>.
+struct NodeHalvesArgs {
+    const float* h;            // [n][128] update output (un-normalised when mean != nullptr)
+    const float* node_in;      // [n][kin]
+    const float* mean;         // [n_graphs][128] or nullptr
+    const float* var;          // [n_graphs][128] biased variance
+    const f32x4* w[2];         // fp16 planes [NKT][4][2][2][64] x 16 B of the two column groups
+    const float* b[2];         // padded biases
+    float* y[2];               // A, Bm [n][128]
+    float* h_norm;             // [n][128] or nullptr
+    long n;
+    int rows_per_graph, n_graphs, kin;
+    float eps;
+};
+#define NH_MAX_GRAPHS 8
+#ifndef NH_PIPE
+#define NH_PIPE true
+#endif
+#define NH_TS 36                                                    // row stride (floats) of a wave's 32 x 32 transposition tile
+// One 32-row x 32-column tile from the accumulator layout (lane = row, 16 B pieces at a 512 B stride: 32 quarter lines per store
+// instruction) through a wave-private LDS tile to whole 128-byte lines (lane l -> row 8 it + l / 8, 16 B piece l % 8)
+__device__ __forceinline__ void store_tile_lines(const f32x16& v, float* __restrict__ tl, float* __restrict__ y, int col0, long row0,
+                                                 long n, int lane) {
+    const int j = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 t = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(tl + j * NH_TS + 8 * g + 4 * half) = t;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = 8 * it + (lane >> 3);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tl + r * NH_TS + 4 * (lane & 7));
+        if (row0 + r < n) *reinterpret_cast<f32x4*>(y + (row0 + r) * 128 + col0 + 4 * (lane & 7)) = t;
+    }
+}
+#ifndef NH_WAVES
+#define NH_WAVES 4
+#endif
+template <int NKT>
+__global__ void __launch_bounds__(NH_WAVES * 64, 1) k_node_halves(NodeHalvesArgs a) {
+    constexpr int MODE = GEMM_FP16X3;
+    MLP_ABL_INIT
+    TRACE_INIT
+    TRACE(40)
+    __shared__ __attribute__((aligned(16))) u32x4 wl[NKT * 1024];
+    __shared__ __attribute__((aligned(16))) float st[2][NH_MAX_GRAPHS][128];          // mean, 1 / sqrt(var + eps)
+    __shared__ __attribute__((aligned(16))) float tls[NH_WAVES][32 * NH_TS];                 // per-wave transposition tile
+    __shared__ __attribute__((aligned(16))) float bl[128];      // bias: re-read per tile from LDS - a global load here would be the
+                                                                // youngest VMEM operation of the wave and waiting for it (in-order
+                                                                // vmcnt) drains the prefetched rows AND the previous tile's stores
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    float* tl = tls[wave];
+    // blockIdx -> (XCD, slot); slot parity = column group, so that the two groups of a row range share an L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int grp = slot & 1;
+    const int wi = (slot >> 1) * 8 + xcd, nwg = gridDim.x >> 1;
+    {
+        // all NKT * 2 loads of a thread in flight at once (a load -> LDS-write loop pays one memory round trip per iteration)
+        const u32x4* g = reinterpret_cast<const u32x4*>(a.w[grp]);
+        constexpr int NQ = NKT * 1024 / (NH_WAVES * 64);
+        u32x4 wv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) wv[q] = g[q * (NH_WAVES * 64) + threadIdx.x];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) wl[q * (NH_WAVES * 64) + threadIdx.x] = wv[q];
+        if (threadIdx.x < 128) bl[threadIdx.x] = a.b[grp][threadIdx.x];
+        if (a.mean)
+            for (int i = threadIdx.x; i < a.n_graphs * 128; i += NH_WAVES * 64) {
+                st[0][i >> 7][i & 127] = a.mean[i];
+                st[1][i >> 7][i & 127] = 1.0f / sqrtf(a.var[i] + a.eps);
+            }
+    }
+    __syncthreads();
+    TRACE(41)
+    const bool norm = a.mean != nullptr;
+    const bool write_h = norm && grp == 0 && a.h_norm;
+    const long ntiles = (a.n + 31) / 32;
+    const long stride = (long)nwg * NH_WAVES;
+    long t = (long)wi * NH_WAVES + wave;
+    if (t >= ntiles) return;
+    // two tiles of raw rows in flight per wave (the wave is alone on its SIMD: nothing else covers the ~2 us of a load)
+    f32x4 xa[NKT][4], xb[NKT][4];
+    auto request = [&](f32x4 (&xr)[NKT][4], long tile, int kt) {
+        const long r = min(min(tile, ntiles - 1) * 32 + j, a.n - 1);      // clamped: the last iterations prefetch rows they drop
+        const float* p = kt < 4 ? a.h + r * 128 + kt * 32 + 4 * half : a.node_in + r * a.kin + (kt - 4) * 32 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xr[kt][g] = *reinterpret_cast<const f32x4*>(p + 8 * g);
+    };
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) request(xa, t, kt);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) request(xb, t + stride, kt);
+    const float* bias = bl;
+    float* y = a.y[grp];
+    auto do_tile = [&](f32x4 (&xr)[NKT][4], long tt) {
+        const long row = tt * 32 + j;
+        const int gid = norm ? (int)(min(row, a.n - 1) / a.rows_per_graph) : 0;
+        f32x16 acc[4], accc[4];
+        TRACE(42)
+        init_bias<4>(acc, bias, half);
+        zero_tiles<4>(accc);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x16 x;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[4 * g + c] = xr[kt][g][c];
+            if (kt < 4 && norm) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 m = *reinterpret_cast<const f32x4*>(&st[0][gid][kt * 32 + 8 * g + 4 * half]);
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(&st[1][gid][kt * 32 + 8 * g + 4 * half]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[4 * g + c] = (x[4 * g + c] - m[c]) * r[c];
+                }
+            }
+#ifdef MAGNET_DEV_VARIANTS
+            asm volatile("" ::"v"(x[0]), "v"(x[15]));
+#endif
+            TRACE(43)
+            if (write_h && kt < 4 && !(abl & 4)) store_tile_lines(x, tl, a.h_norm, kt * 32, tt * 32, a.n, lane);
+            if (!(abl & 1)) mma_chunk<4, MODE, NH_PIPE>(x, acc, accc, wl + kt * 1024, lane);
+            TRACE(44)
+            if (!(abl & 16)) request(xr, tt + 2 * stride, kt);            // into the registers this k tile has just released
+        }
+        fold_tiles<4, MODE>(acc, accc);
+        TRACE(45)
+        if (!(abl & 4)) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) store_tile_lines(acc[nt], tl, y, nt * 32, tt * 32, a.n, lane);
+        } else if (acc[0][0] == 12345.678f) y[row] = acc[1][1] + acc[2][2] + acc[3][3];      // keep the values live
+        TRACE(46)
+    };
+    for (; t < ntiles; t += 2 * stride) {
+        do_tile(xa, t);
+        if (t + stride < ntiles) do_tile(xb, t + stride);
+    }
+}
+
+// A, Bm: [n_rows][128].  mean == NULL: h is used as it is and h_norm is not written.  Returns -2 for shapes this kernel does
+// not cover (the caller then runs magnet_instance_norm_f32 + magnet_mlp_fp16x3_f32): kin not 32 or 64, more than 8 graphs,
+// graph boundaries inside a 32-row tile.
+extern "C" int magnet_mpnn_node_halves_f32(const float* h, const float* node_in, int kin, long n_rows, const float* mean,
+                                           const float* var, float eps, int n_graphs, int rows_per_graph, const void* wa_f16,
+                                           const float* ba, const void* wb_f16, const float* bb, float* A, float* Bm,
+                                           float* h_norm, void* stream) {
+    (void)hipGetLastError();
+    if (n_rows <= 0) return 0;
+    if (kin != 32 && kin != 64) return -2;
+    if (mean && (n_graphs > NH_MAX_GRAPHS || n_graphs < 1 || rows_per_graph % 32 || !var)) return -2;
+    NodeHalvesArgs a;
+    a.h = h, a.node_in = node_in, a.mean = mean, a.var = var;
+    a.w[0] = reinterpret_cast<const f32x4*>(wa_f16), a.w[1] = reinterpret_cast<const f32x4*>(wb_f16);
+    a.b[0] = ba, a.b[1] = bb, a.y[0] = A, a.y[1] = Bm, a.h_norm = h_norm;
+    a.n = n_rows, a.rows_per_graph = rows_per_graph, a.n_graphs = n_graphs, a.kin = kin, a.eps = eps;
+    static int ncu = 0;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        int dev;
+        hipGetDevice(&dev);
+        hipGetDeviceProperties(&prop, dev);
+        ncu = prop.multiProcessorCount;
+    }
+    const long ntiles = (n_rows + 31) / 32;
+    long pairs = (ntiles + NH_WAVES - 1) / NH_WAVES;                 // workgroup pairs that have at least one tile per wave
+    int grid = (int)(pairs * 2 < ncu ? pairs * 2 : ncu);
+    grid = (grid + 15) / 16 * 16;                                    // whole (XCD, slot pair) blocks
+    hipStream_t s = (hipStream_t)stream;
+    if (kin == 32) hipLaunchKernelGGL(k_node_halves<5>, dim3(grid), dim3(NH_WAVES * 64), 0, s, a);
+    else hipLaunchKernelGGL(k_node_halves<6>, dim3(grid), dim3(NH_WAVES * 64), 0, s, a);
+    return (int)hipGetLastError();
+}
+
 extern "C" int magnet_mlp_bf16x6_f32(const MagnetMlpArgs* args, int nl, int ht, int ot, int act, int last_act, int ln,
                                      int epi, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)

@@ -30,13 +30,23 @@ __device__ __forceinline__ float dswish(float x) {
     return s * (1.0f + x * (1.0f - s));
 }
 
-__device__ __forceinline__ void store_tile(float* __restrict__ dst_row /* row e, + 4*half */, const f32x16 (&v)[4]) {
+#ifdef MAGNET_DEV_VARIANTS
+// development ablations (results invalid): 1 = no s1 / dq stores, 2 = no dp store, 4 = every store instruction writes 1 KiB of
+// consecutive addresses (what an LDS-transposed, row-contiguous store would cost), instead of 64 pieces of 16 B in 32 rows
+__device__ int g_ebwd_abl = 0;
+#define EBWD_ABL_INIT const int abl = __builtin_amdgcn_readfirstlane(g_ebwd_abl);
+extern "C" int magnet_debug_set_edge_bwd_ablation(int value) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ebwd_abl), &value, sizeof(int)); }
+#else
+#define EBWD_ABL_INIT constexpr int abl = 0;
+#endif
+
+__device__ __forceinline__ void store_tile(float* __restrict__ dst_row /* row e, + 4*half */, const f32x16 (&v)[4], int so = 1) {
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 o = {v[nt][4 * g], v[nt][4 * g + 1], v[nt][4 * g + 2], v[nt][4 * g + 3]};
-            *reinterpret_cast<f32x4*>(dst_row + nt * 32 + 8 * g) = o;
+            *reinterpret_cast<f32x4*>(dst_row + (nt * 32 + 8 * g) * so) = o;
         }
 }
 
@@ -56,6 +66,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
         wt[i] = w2ts[i];
     }
     __syncthreads();
+    EBWD_ABL_INIT
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, j = lane & 31;
     const int ntiles = (E + 31) / 32;
@@ -92,7 +103,8 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
         const int e = min(tile * 32 + j, E - 1);
         const int ti = md.ti;
         const float inv_deg = 1.0f / (float)(md.re - md.rs);
-        const size_t row = (size_t)e * 128 + 4 * half;
+        const int so = (abl & 4) ? 32 : 1;
+        const size_t row = (abl & 4) ? (size_t)tile * 4096 + lane * 4 : (size_t)e * 128 + 4 * half;
         const int tn = tile + stride < tend ? tile + stride : tile;       // clamped: the last iteration prefetches unused rows
         const int en = min(tn * 32 + j, E - 1);
         const float* pan = A + (size_t)tgt[en] * 128 + 4 * half;
@@ -124,7 +136,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
 #if EB_INTERLEAVE
         gemm128<MODE>(wl, x, acc, accc, lane, md.e_ok ? s1_out + row : nullptr, 1.0f);
 #else
-        if (md.e_ok) store_tile(s1_out + row, x);
+        if (md.e_ok && !(abl & 1)) store_tile(s1_out + row, x, so);
         gemm128<MODE>(wl, x, acc, accc, lane, nullptr, 1.0f);
 #endif
         // ---- dq = dagg[i] / deg * Swish'(q)   (into x), per-edge power-of-two scale for the fp16 split
@@ -142,7 +154,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
         const float sc = __uint_as_float((254u - eb) << 23);                   // 2^(127-eb): scaled max in [1, 2)
         const float usc = __uint_as_float(eb << 23);                           // 2^(eb-127)  (0 for an all-zero row)
 #if !EB_INTERLEAVE
-        if (md.e_ok) store_tile(dq_out + row, x);
+        if (md.e_ok && !(abl & 1)) store_tile(dq_out + row, x, so);
 #endif
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -185,9 +197,9 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
         for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                if (md.e_ok) {
+                if (md.e_ok && !(abl & 2)) {
                     const f32x4 o = {acc[kt][4 * g], acc[kt][4 * g + 1], acc[kt][4 * g + 2], acc[kt][4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(dp_out + row + kt * 32 + 8 * g) = o;
+                    *reinterpret_cast<f32x4*>(dp_out + row + (kt * 32 + 8 * g) * so) = o;
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[kt][4 * g + c] = seg_scan_sum(acc[kt][4 * g + c], md);

@@ -464,6 +464,25 @@ extern "C" int magnet_mpnn_edge_f32(const float* A, const float* Bm, const int32
 }
 
 
+// statistics only: mean at workspace + n_graphs * nchunks * H, biased variance right behind it ([n_graphs][H] each); the apply
+// step is fused into the consumer (magnet_mpnn_node_halves_f32).  Same workspace layout as magnet_instance_norm_f32.
+extern "C" int magnet_instance_norm_stats_f32(const float* x, int n_graphs, int rows_per_graph, int H, float* workspace,
+                                              void* stream) {
+    (void)hipGetLastError();
+    if (n_graphs <= 0 || rows_per_graph <= 0) return 0;
+    if (H % 4) return -2;
+    const int nchunks = (rows_per_graph + NORM_CHUNK - 1) / NORM_CHUNK;
+    float* part = workspace;
+    float* mean = part + (size_t)n_graphs * nchunks * H;
+    float* var = mean + (size_t)n_graphs * H;
+    float* part_m2 = var + (size_t)n_graphs * H;
+    hipStream_t s = (hipStream_t)stream;
+    const int nsup = (nchunks + NORM_SUB - 1) / NORM_SUB;
+    hipLaunchKernelGGL(k_colstat_partial, dim3(nsup, n_graphs), dim3(128), 0, s, x, rows_per_graph, H, part, part_m2);
+    hipLaunchKernelGGL(k_colstat_final, dim3(n_graphs, (H + 31) / 32), dim3(1024), 0, s, part, part_m2, nsup,
+                       rows_per_graph, H, mean, var);
+    LAUNCH_CHECK();
+}
 // workspace: (2 * n_graphs * nchunks + 2 * n_graphs) * H floats, nchunks = ceil(rows_per_graph / 64)
 extern "C" int magnet_instance_norm_f32(const float* x, int n_graphs, int rows_per_graph, int H, float eps, float* y,
                                         float* workspace, void* stream) {

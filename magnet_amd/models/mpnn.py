@@ -110,6 +110,8 @@ class MPNN(LightningModule):
         self._topo_cache, self._topo = TopologyCache(4), None       # _topo: the topology of the latest _build_graph
         # hipGraph replay of whole inference rollouts (magnet_amd/graphs.py): True / False / "auto" = when the graph is small
         self.hip_graph = getattr(hparams, "hip_graph", "auto")
+        # A/B knob (default on): InstanceNorm apply fused into the next hop's per-node-halves kernel on large graphs
+        self.fused_node_halves = bool(getattr(hparams, "fused_node_halves", os.environ.get("MAGNET_FUSED_HALVES", "1") != "0"))
         self._rollout_graph = RolloutGraph(topology_keys=("x",))
 
     # ------------------------------------------------------------------ packed weights (cached)
@@ -184,23 +186,34 @@ class MPNN(LightningModule):
         ops.mlp(N, ops.ktiles(T(node_in, kin)), P.emb, nl=2, ht=4, ot=4, act=ops.ACT_SWISH, last_act=True, y=h)
         if tape is not None:
             tape.topo, tape.node_in, tape.u, tape.dt, tape.layers = topo, node_in, u, dtv, []
-        for lyr in P.layers:
+        # large graphs, inference: the InstanceNorm of hop l is applied by hop l+1's per-node-halves kernel while it loads
+        # (ops.mpnn_node_halves: weights resident in LDS, writes the normalised h next to A / Bm) - no separate apply pass
+        fused_halves = (tape is None and self.gemm == "fp16x3" and Ns > ops.NORM_SMALL_ROWS
+                        and ops.node_halves_supported(kin, B, Ns, H) and self.fused_node_halves)
+        stats = None                                                        # (mean, var) of g, not applied yet
+        for li, lyr in enumerate(P.layers):
             if tape is not None:
                 AB, agg = torch.empty(2, N, H, device=dev, dtype=torch.float32), new()
             A, Bm = AB[0], AB[1]
-            pre_in = ops.ktiles(T(h, H), T(node_in, kin))
             # A = W1a.[h | node_in] + b1 and Bm = W1b.[h | node_in]: two column groups of one launch, run back to back inside
             # each workgroup so that the second group reads [h | node_in] from L2 (fp32 kernels: two workgroup columns)
             l2e = tape is None and hasattr(lyr, "pre_a_l2e")
-            ops.mlp(N, pre_in, [lyr.pre_a_l2e, lyr.pre_b_l2e] if l2e else [lyr.pre_a, lyr.pre_b], nl=1, ht=4, ot=4,
-                    act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2, groups_in_block=True, y_group_stride=N * H)
+            pa, pb = (lyr.pre_a_l2e, lyr.pre_b_l2e) if l2e else (lyr.pre_a, lyr.pre_b)
+            if fused_halves:
+                ops.mpnn_node_halves(g if stats is not None else h, node_in, pa, pb, A, Bm, stats=stats, rows_per_graph=Ns,
+                                     h_norm=h if stats is not None else None)
+            else:
+                ops.mlp(N, ops.ktiles(T(h, H), T(node_in, kin)), [pa, pb], nl=1, ht=4, ot=4,
+                        act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2, groups_in_block=True, y_group_stride=N * H)
             if hasattr(lyr, "msg2_t16"):          # training forward too (plain halves: l2e is False with a tape)
                 ops.mpnn_edge16(A, Bm, csr, lyr.msg2_t16[0], lyr.msg2_t16[1], agg, partials, l2e=l2e)
             else:
                 ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials, l2e=l2e)
             ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
                     act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g)
-            if tape is None:
+            if fused_halves and li + 1 < len(P.layers):
+                stats = ops.instance_norm_stats(g, B, Ns)                  # applied by the next hop's halves kernel
+            elif tape is None:
                 ops.instance_norm(g, B, Ns, out=h)
             else:
                 h_in = h

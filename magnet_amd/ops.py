@@ -281,6 +281,35 @@ def instance_norm(x, n_graphs, rows_per_graph, eps=1e-5, out=None, return_var=Fa
     return out
 
 
+NORM_SMALL_ROWS = 2048          # csrc/mpnn_kernels.hip: graphs up to this size are normalised by ONE launch
+
+
+def instance_norm_stats(x, n_graphs, rows_per_graph):
+    """-> (mean, var) [n_graphs, H] views of a fresh workspace: the statistics of ``instance_norm`` without the apply pass"""
+    x = _f32(x, "x")
+    h = x.shape[1]
+    nchunks = (rows_per_graph + 63) // 64
+    ws = torch.empty((2 * n_graphs * nchunks + 2 * n_graphs) * h, device=x.device, dtype=torch.float32)
+    L.check(L.lib().magnet_instance_norm_stats_f32(_p(x), n_graphs, rows_per_graph, h, _p(ws), _stream()), "instance_norm_stats")
+    o = n_graphs * nchunks * h
+    return ws[o:o + n_graphs * h].view(n_graphs, h), ws[o + n_graphs * h:o + 2 * n_graphs * h].view(n_graphs, h)
+
+
+def node_halves_supported(kin, n_graphs, rows_per_graph, h=128):
+    return h == 128 and kin in (32, 64) and 1 <= n_graphs <= 8 and rows_per_graph % 32 == 0
+
+
+def mpnn_node_halves(h, node_in, pre_a, pre_b, A, Bm, stats=None, rows_per_graph=0, eps=1e-5, h_norm=None):
+    """A = Wa [hn | node_in] + ba, Bm = Wb [hn | node_in] (+ bb) with hn = InstanceNorm-applied h when ``stats`` = (mean, var)
+    is given (then hn is also written to ``h_norm``).  pre_a / pre_b: (fp16x3 planes, padded bias) of ``packing.pack``."""
+    n, kin = h.shape[0], node_in.shape[1]
+    mean, var = stats if stats is not None else (None, None)
+    ng = mean.shape[0] if mean is not None else 0
+    L.check(L.lib().magnet_mpnn_node_halves_f32(_p(h), _p(node_in), kin, C.c_long(n), _p(mean), _p(var), C.c_float(float(eps)), ng,
+                                                int(rows_per_graph), _p(pre_a[0]), _p(pre_a[1]), _p(pre_b[0]), _p(pre_b[1]),
+                                                _p(A), _p(Bm), _p(h_norm), _stream()), "mpnn_node_halves")
+
+
 def resize_linear(x, out_hw, d):
     """x [n, Hi, Wi] (d = 2) or [n, Wi] (d = 1) -> [n, Ho, Wo] / [n, Wo], F.interpolate(..., align_corners=False)"""
     x = _f32(x, "resize source")

@@ -8,7 +8,7 @@ from magnet_amd.packing import pack
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-abls = [0]
+abls = [0, 1, 2, 3, 4] if _lib.DEV else [0]   # MAGNET_DEV_LIB=1: store ablations (include/magnet_hip_dev.h)
 hp = types.SimpleNamespace(lr=1e-3, weight_decay=0, factor=0.3, step_size=50, loss="l1", hidden_features=128,
                            hidden_layer=5, time_window=10, teacher_forcing=False, neighbors=4)
 torch.manual_seed(0)
@@ -38,6 +38,8 @@ def timeit(fn, reps=5):
 
 
 for a in abls:
+    if _lib.DEV:
+        _lib.lib().magnet_debug_set_edge_bwd_ablation(a)
     ms = timeit(lambda: ops.mpnn_edge_bwd(A, Bm, dagg, csr, w2[0], w2t[0], w2[1], s1, dq, dp, dA, partials))
     print(f"edge_bwd ablation {a:2d}: {ms:.3f} ms   ({4*E*H*H/ms/1e9:.1f} TFLOP/s fp32-equivalent, {3*E*H*4/ms/1e6:.0f} GB/s written)")
 ws = ops.wgrad_workspace(E, "cuda")

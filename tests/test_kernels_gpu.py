@@ -405,3 +405,54 @@ def test_resize_linear_matches_interpolate(d, shape, out):
     got = ops.resize_linear(x, out, d)
     assert got.shape == want.shape
     assert rel_l2(got, want) < 1e-6
+
+
+@pytest.mark.parametrize("kin,n_graphs,rows,with_norm", [(32, 4, 4096, True), (64, 2, 2144, True), (32, 1, 1013, False),
+                                                          (32, 8, 32, True)])
+def test_node_halves_resident_kernel_matches_norm_plus_generic_mlp(kin, n_graphs, rows, with_norm):
+    """magnet_mpnn_node_halves_f32 (InstanceNorm apply on load + both per-node halves + normalised h, weights resident in LDS)
+    == magnet_instance_norm_f32 followed by the generic one-Linear launch, and both against fp64 on the host."""
+    from magnet_amd import ops
+    from magnet_amd.packing import pack
+    g = torch.Generator().manual_seed(3)
+    H, n = 128, n_graphs * rows
+    wa, wb = torch.randn(H, H + kin, generator=g) * 0.1, torch.randn(H, H + kin, generator=g) * 0.1
+    ba = torch.randn(H, generator=g)
+    h_raw = (torch.randn(n, H, generator=g) * 2 + 1).cuda()
+    node_in = torch.randn(n, kin, generator=g).cuda()
+    pa, pb = pack(wa.cuda(), ba.cuda(), "fp16x3", k_pad=H + kin), pack(wb.cuda(), None, "fp16x3", k_pad=H + kin)
+    A, Bm, hn = (torch.full((n, H), float("nan"), device="cuda") for _ in range(3))
+    assert ops.node_halves_supported(kin, n_graphs, rows) or not with_norm
+    if with_norm:
+        stats = ops.instance_norm_stats(h_raw, n_graphs, rows)
+        ops.mpnn_node_halves(h_raw, node_in, pa, pb, A, Bm, stats=stats, rows_per_graph=rows, h_norm=hn)
+        h_ref = ops.instance_norm(h_raw, n_graphs, rows)
+        assert rel_l2(hn, h_ref) < 2e-7
+        x64 = h_raw.double().view(n_graphs, rows, H)
+        h64 = ((x64 - x64.mean(1, keepdim=True)) / (x64.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt()).view(n, H)
+        assert rel_l2(hn, h64) < 1e-6
+    else:
+        ops.mpnn_node_halves(h_raw, node_in, pa, pb, A, Bm)
+        h_ref, h64 = h_raw, h_raw.double()
+    AB = torch.empty(2, n, H, device="cuda")
+    T = ops.Term
+    ops.mlp(n, ops.ktiles(T(h_ref, H), T(node_in, kin)), [pa, pb], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2,
+            groups_in_block=True, y_group_stride=n * H)
+    assert rel_l2(A, AB[0]) < 5e-7 and rel_l2(Bm, AB[1]) < 5e-7
+    x64 = torch.cat([h64, node_in.double()], 1)
+    assert rel_l2(A, x64 @ wa.double().cuda().t() + ba.double().cuda()) < 2e-6
+    assert rel_l2(Bm, x64 @ wb.double().cuda().t()) < 2e-6
+
+
+def test_mpnn_2d_rollout_with_fused_node_halves_equals_the_unfused_path():
+    import types
+    import bench
+    from magnet_amd.models.factory import FACTORY
+    outs = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        m = FACTORY["mpnn_2d"](types.SimpleNamespace(**dict(bench.HP, fused_node_halves=fused, hip_graph=False))).cuda().eval()
+        batch = bench.synthetic_batch(64, 2, 1234, "cuda")
+        outs.append(m.validation_step(batch, 0))
+    assert torch.isfinite(outs[0]).all()
+    assert rel_l2(outs[0], outs[1]) < 1e-6

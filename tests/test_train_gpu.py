@@ -95,6 +95,9 @@ def test_edge_gather_scatter_kernels():
 
 @pytest.mark.parametrize("tw,dim", [(10, 1), (10, 2), (25, 1), (50, 1)])
 def test_readout_backward(tw, dim):
+    """reference: torch autograd through the two Conv1d of the read-out, evaluated on the HOST in fp64 (a Conv1d backward on the
+    device goes through MIOpen, which is not part of this framework - and which aborted the whole pytest process when this test ran
+    late in the full -m gpu session)"""
     from magnet_amd import ops
     from magnet_amd.models.mpnn import _READOUT
     torch.manual_seed(4)
@@ -103,18 +106,21 @@ def test_readout_backward(tw, dim):
     n = 1037
     h = torch.randn(n, 128, device="cuda")
     dout = torch.randn(n, tw, device="cuda")
-    c1 = torch.nn.Conv1d(1, 8, k1, stride=s1).cuda()
-    c2 = torch.nn.Conv1d(8, 1, k2).cuda()
+    c1 = torch.nn.Conv1d(1, 8, k1, stride=s1)
+    c2 = torch.nn.Conv1d(8, 1, k2)
     dt = torch.tensor([0.37], device="cuda")
-    u_last = torch.randn(n, device="cuda", requires_grad=True)
-    hh = h.clone().requires_grad_()
-    z = c1(hh[:, None])
+    u_last = torch.randn(n, dtype=torch.float64, requires_grad=True)
+    hh = h.cpu().double().requires_grad_()
+    c1d, c2d = c1.double(), c2.double()
+    z = c1d(hh[:, None])
     if use_swish:
         z = z * torch.sigmoid(z)
-    out = u_last[:, None] + dt * torch.arange(1, tw + 1, device="cuda") * c2(z).squeeze(1)
-    out.backward(dout)
-    dh, du, gp = ops.mpnn_readout_bwd(h, dout, tw, c1.weight.detach().reshape(-1).contiguous(), c1.bias.detach(), k1, s1,
-                                      c2.weight.detach().reshape(-1).contiguous(), k2, use_swish, dt)
+    out = u_last[:, None] + dt.cpu().double() * torch.arange(1, tw + 1, dtype=torch.float64) * c2d(z).squeeze(1)
+    out.backward(dout.cpu().double())
+    c1, c2 = c1d, c2d
+    f32 = lambda t: t.detach().float().cuda()  # noqa: E731
+    dh, du, gp = ops.mpnn_readout_bwd(h, dout, tw, f32(c1.weight).reshape(-1).contiguous(), f32(c1.bias), k1, s1,
+                                      f32(c2.weight).reshape(-1).contiguous(), k2, use_swish, dt)
     g = torch.zeros(gp.shape[1], device="cuda")
     ops.reduce_partials(gp, gp.shape[0], gp.shape[1], g)
     assert rel_l2(dh, hh.grad) < 1e-5
