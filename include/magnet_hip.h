@@ -192,6 +192,16 @@ int magnet_instance_norm_stats_f32(const float* x, int n_graphs, int rows_per_gr
  * h [n][128], node_in [n][kin], kin in {32, 64}; wa / wb: fp16x3 planes of the two [128][128 + kin] weight halves in the layout
  * magnet_mlp_fp16x3_f32 takes (magnet_amd/packing.py:pack_linear_fp16x2).  Returns -2 for an unsupported shape (kin, more than
  * 8 graphs, rows_per_graph not a multiple of 32): the caller then uses magnet_instance_norm_f32 + magnet_mlp_fp16x3_f32. */
+/* GNN_Layer.update (models/mpnn.py:81-90), residual branch, as ONE persistent launch for large graphs, optionally fused with the
+ * InstanceNorm apply of the previous hop (models/mpnn.py:70) on its h input:
+ *   hn = mean ? (h - mean[g]) / sqrt(var[g] + eps) : h          (g = row / rows_per_graph)
+ *   y  = hn + Swish(W2 Swish(W1 [hn | agg | node_in] + b1) + b2)
+ * h, agg, y [n][128] (y must not alias h), node_in [n][kin], kin in {32, 64}, at most 8 graphs (else -2: use
+ * magnet_mlp_fp16x3_f32); w1 / w2: fp16x3 planes of update_net_1 ([128][256 + kin]) / update_net_2 ([128][128]) as
+ * packing.pack_linear_fp16x2 lays them out. */
+int magnet_mpnn_node_update_f32(const float* h, const float* agg, const float* node_in, int kin, long n_rows, const float* mean,
+                                const float* var, float eps, int n_graphs, int rows_per_graph, const void* w1_f16,
+                                const float* b1, const void* w2_f16, const float* b2, float* y, void* stream);
 int magnet_mpnn_node_halves_f32(const float* h, const float* node_in, int kin, long n_rows, const float* mean, const float* var,
                                 float eps, int n_graphs, int rows_per_graph, const void* wa_f16, const float* ba,
                                 const void* wb_f16, const float* bb, float* A, float* Bm, float* h_norm, void* stream);

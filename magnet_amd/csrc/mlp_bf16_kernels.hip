@@ -566,6 +566,203 @@ extern "C" int magnet_mpnn_node_halves_f32(const float* h, const float* node_in,
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------- MPNN node update, persistent
+// g = h + Swish(W2 Swish(W1 [h | agg | node_in] + b1) + b2)   (GNN_Layer.update, models/mpnn.py:81-90 / mpnn_2d.py:81-91, residual
+// branch in_features == out_features) for the large-graph inference path.  Same lessons as k_node_halves, for a chain whose
+// planes (147 + 64 KiB) do not fit in LDS together:
+//   * one workgroup of 4 waves per CU, persistent over 128-row tiles; W2 (64 KiB) resident; the W1 chunks (16 KiB per k tile) pass
+//     through a two-slot LDS buffer, fetched by plain loads into registers D chunks ahead and written to LDS one step before use -
+//     compiler-tracked waits, one barrier per first-layer step, and the chunk stream runs on across tile boundaries;
+//   * every wave keeps one whole tile of source rows in flight ahead of itself; the first layer takes the agg / node_in k tiles first
+//     and the h k tiles last, so the h registers are still intact at the epilogue (they ARE the residual) and are re-requested for
+//     the next tile only then, five steps before their next use;
+//   * no global load is consumed soon after it is issued (vmcnt retires in order: such a load would wait for every store of the
+//     previous tile): biases come from LDS;
+//   * results leave through a wave-private LDS tile as whole 128-byte lines.
+struct NodeUpdateArgs {
+    const float* h;            // [n][128] (normalised) node features: input and residual
+    const float* agg;          // [n][128] mean-aggregated messages
+    const float* node_in;      // [n][kin]
+    const f32x4* w1;           // fp16 planes of update_net_1 [NKT][4][2][2][64] x 16 B, columns [h | agg | node_in]
+    const f32x4* w2;           // fp16 planes of update_net_2 [4][4][2][2][64] x 16 B
+    const float* b1;
+    const float* b2;
+    float* y;                  // [n][128]
+    const float* mean;         // [n_graphs][128] or nullptr: h is then normalised on load, (h - mean) / sqrt(var + eps)
+    const float* var;
+    long n;
+    int kin, rows_per_graph, n_graphs;
+    float eps;
+};
+template <int NKT, bool NORM>
+__global__ void __launch_bounds__(256, 1) k_node_update(NodeUpdateArgs a) {
+    constexpr int MODE = GEMM_FP16X3;
+    constexpr int D = (NKT % 3 == 0) ? 3 : 2;                        // W1 chunks in flight in registers (NKT % D == 0: static ring index)
+    TRACE_INIT
+    TRACE(50)
+    static_assert(NKT % D == 0, "ring depth");
+    __shared__ __attribute__((aligned(16))) u32x4 w2l[4 * 1024];
+    __shared__ __attribute__((aligned(16))) u32x4 w1s[2][1024];
+    __shared__ __attribute__((aligned(16))) float tls[4][32 * NH_TS];
+    __shared__ __attribute__((aligned(16))) float bl[2][128];
+    __shared__ __attribute__((aligned(16))) float st[2][NH_MAX_GRAPHS][128];          // mean, 1 / sqrt(var + eps)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    float* tl = tls[wave];
+    constexpr bool norm = NORM;
+    if (norm)
+        for (int i = threadIdx.x; i < a.n_graphs * 128; i += 256) {
+            st[0][i >> 7][i & 127] = a.mean[i];
+            st[1][i >> 7][i & 127] = 1.0f / sqrtf(a.var[i] + a.eps);
+        }
+    const u32x4* g1 = reinterpret_cast<const u32x4*>(a.w1);
+    // first-layer step i takes k tile KSEQ(i): agg and node_in first, h last
+    auto kseq = [](int i) { return i < NKT - 4 ? i + 4 : i - (NKT - 4); };
+    {
+        const u32x4* g2 = reinterpret_cast<const u32x4*>(a.w2);
+        u32x4 wv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wv[q] = g2[q * 256 + threadIdx.x];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w2l[q * 256 + threadIdx.x] = wv[q];
+        if (threadIdx.x < 128) bl[0][threadIdx.x] = a.b1[threadIdx.x];
+        else bl[1][threadIdx.x - 128] = a.b2[threadIdx.x - 128];
+    }
+    const long ntiles = (a.n + 127) / 128;
+    long tile = blockIdx.x;
+    if (tile >= ntiles) return;                                       // (whole workgroup: uniform)
+    // W1 chunk stream: wr[r] holds this thread's 4 pieces of a chunk on its way to LDS
+    u32x4 wr[D][4];
+    auto wload = [&](int r, int kt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wr[r][q] = g1[kt * 1024 + q * 256 + threadIdx.x];
+    };
+    auto wstore = [&](int r, int slot) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w1s[slot][q * 256 + threadIdx.x] = wr[r][q];
+    };
+    // prologue: chunk of step 0 straight to slot 0, chunks of steps 1 .. D in flight
+    wload(0, kseq(0));
+    wstore(0, 0);
+#pragma unroll
+    for (int i = 1; i <= D; ++i) wload(i % D, kseq(i % NKT));
+    f32x4 xr[NKT][4];
+    auto request = [&](long tl_, int kt) {
+        const long r = min(min(tl_, ntiles - 1) * 128 + wave * 32 + j, a.n - 1);   // clamped: rows past the end are dropped later
+        const float* p = kt < 4 ? a.h + r * 128 + kt * 32 + 4 * half
+                       : kt < 8 ? a.agg + r * 128 + (kt - 4) * 32 + 4 * half
+                                : a.node_in + r * a.kin + (kt - 8) * 32 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xr[kt][g] = *reinterpret_cast<const f32x4*>(p + 8 * g);
+    };
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) request(tile, kseq(i));
+    int par = 0;                                                      // LDS slot of the chunk of first-layer step 0 of this tile
+    for (; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * 128 + wave * 32;
+        const int gid = norm ? (int)(min(row0 + j, a.n - 1) / a.rows_per_graph) : 0;
+        f32x16 acc[4], accc[4];
+        init_bias<4>(acc, bl[0], half);
+        zero_tiles<4>(accc);
+#pragma unroll
+        for (int i = 0; i < NKT; ++i) {
+            const int kt = kseq(i);
+            const int slot = (par + i) & 1;
+            TRACE(51)
+            __syncthreads();                                          // chunk of step i complete in `slot`; the other slot is free
+            TRACE(52)
+            // chunk of step i+1 (this tile's or, at the end, the next tile's first) -> the free slot; then its ring place is
+            // refilled with the chunk of step i+1+D
+            wstore((i + 1) % D, slot ^ 1);
+            wload((i + 1) % D, kseq((i + 1 + D) % NKT));
+            f32x16 x;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[4 * g + c] = xr[kt][g][c];
+            if (kt < 4 && norm) {                                      // normalise on load; the residual is the normalised h too
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 m = *reinterpret_cast<const f32x4*>(&st[0][gid][kt * 32 + 8 * g + 4 * half]);
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(&st[1][gid][kt * 32 + 8 * g + 4 * half]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        x[4 * g + c] = (x[4 * g + c] - m[c]) * r[c];
+                        xr[kt][g][c] = x[4 * g + c];
+                    }
+                }
+            }
+#ifdef MAGNET_DEV_VARIANTS
+            asm volatile("" ::"v"(x[0]), "v"(x[15]));
+#endif
+            TRACE(53)
+            mma_chunk<4, MODE, false>(x, acc, accc, w1s[slot], lane);
+            TRACE(54)
+            if (kt >= 4) request(tile + gridDim.x, kt);                // h tiles stay: they are the residual
+        }
+        par = (par + NKT) & 1;
+        fold_tiles<4, MODE>(acc, accc);
+        TRACE(55)
+        f32x16 h0[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            apply_act<ACT_SWISH>(acc[t]);
+            h0[t] = acc[t];
+        }
+        init_bias<4>(acc, bl[1], half);
+        zero_tiles<4>(accc);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) mma_chunk<4, MODE, false>(h0[kt], acc, accc, w2l + kt * 1024, lane);
+        fold_tiles<4, MODE>(acc, accc);
+        TRACE(56)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            apply_act<ACT_SWISH>(acc[t]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[t][4 * g + c] += xr[t][g][c];
+            store_tile_lines(acc[t], tl, a.y, t * 32, row0, a.n, lane);
+        }
+        TRACE(57)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) request(tile + gridDim.x, kt);
+    }
+}
+
+// y [n_rows][128] = hn + Swish(W2 Swish(W1 [hn | agg | node_in] + b1) + b2), hn = mean ? (h - mean[g]) / sqrt(var[g] + eps) : h;
+// w1 / w2: fp16x3 planes as magnet_mlp_fp16x3_f32 takes them.  Returns -2 for kin not in {32, 64} or more than 8 graphs (the
+// caller then uses the generic chain).  y must not alias h.
+extern "C" int magnet_mpnn_node_update_f32(const float* h, const float* agg, const float* node_in, int kin, long n_rows,
+                                           const float* mean, const float* var, float eps, int n_graphs, int rows_per_graph,
+                                           const void* w1_f16, const float* b1, const void* w2_f16, const float* b2, float* y,
+                                           void* stream) {
+    (void)hipGetLastError();
+    if (n_rows <= 0) return 0;
+    if (kin != 32 && kin != 64) return -2;
+    if (mean && (n_graphs > NH_MAX_GRAPHS || n_graphs < 1 || rows_per_graph < 1 || !var)) return -2;
+    NodeUpdateArgs a;
+    a.mean = mean, a.var = var, a.eps = eps, a.n_graphs = n_graphs, a.rows_per_graph = rows_per_graph;
+    a.h = h, a.agg = agg, a.node_in = node_in, a.kin = kin, a.n = n_rows, a.y = y, a.b1 = b1, a.b2 = b2;
+    a.w1 = reinterpret_cast<const f32x4*>(w1_f16), a.w2 = reinterpret_cast<const f32x4*>(w2_f16);
+    static int ncu = 0;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        int dev;
+        hipGetDevice(&dev);
+        hipGetDeviceProperties(&prop, dev);
+        ncu = prop.multiProcessorCount;
+    }
+    const long ntiles = (n_rows + 127) / 128;
+    const int grid = (int)(ntiles < ncu ? ntiles : ncu);
+    hipStream_t s = (hipStream_t)stream;
+    if (kin == 32 && mean) hipLaunchKernelGGL((k_node_update<9, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (kin == 32) hipLaunchKernelGGL((k_node_update<9, false>), dim3(grid), dim3(256), 0, s, a);
+    else if (mean) hipLaunchKernelGGL((k_node_update<10, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_node_update<10, false>), dim3(grid), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
 extern "C" int magnet_mlp_bf16x6_f32(const MagnetMlpArgs* args, int nl, int ht, int ot, int act, int last_act, int ln,
                                      int epi, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)

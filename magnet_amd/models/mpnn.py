@@ -186,11 +186,13 @@ class MPNN(LightningModule):
         ops.mlp(N, ops.ktiles(T(node_in, kin)), P.emb, nl=2, ht=4, ot=4, act=ops.ACT_SWISH, last_act=True, y=h)
         if tape is not None:
             tape.topo, tape.node_in, tape.u, tape.dt, tape.layers = topo, node_in, u, dtv, []
-        # large graphs, inference: the InstanceNorm of hop l is applied by hop l+1's per-node-halves kernel while it loads
-        # (ops.mpnn_node_halves: weights resident in LDS, writes the normalised h next to A / Bm) - no separate apply pass
-        fused_halves = (tape is None and self.gemm == "fp16x3" and Ns > ops.NORM_SMALL_ROWS
-                        and ops.node_halves_supported(kin, B, Ns, H) and self.fused_node_halves)
-        stats = None                                                        # (mean, var) of g, not applied yet
+        # large graphs, inference: the InstanceNorm of hop l is never applied as a pass of its own - hop l+1's per-node-halves
+        # kernel and its update kernel normalise the raw update output while they load it (ops.mpnn_node_halves: weights resident
+        # in LDS; ops.mpnn_node_update: persistent, W2 resident); only the statistics are computed in between, and the last hop's
+        # output is normalised once for the read-out
+        fused_nodes = (tape is None and self.gemm == "fp16x3" and Ns > ops.NORM_SMALL_ROWS
+                       and ops.node_halves_supported(kin, B, Ns, H) and self.fused_node_halves)
+        stats = None                                                        # (mean, var) of h when h is still un-normalised
         for li, lyr in enumerate(P.layers):
             if tape is not None:
                 AB, agg = torch.empty(2, N, H, device=dev, dtype=torch.float32), new()
@@ -199,9 +201,8 @@ class MPNN(LightningModule):
             # each workgroup so that the second group reads [h | node_in] from L2 (fp32 kernels: two workgroup columns)
             l2e = tape is None and hasattr(lyr, "pre_a_l2e")
             pa, pb = (lyr.pre_a_l2e, lyr.pre_b_l2e) if l2e else (lyr.pre_a, lyr.pre_b)
-            if fused_halves:
-                ops.mpnn_node_halves(g if stats is not None else h, node_in, pa, pb, A, Bm, stats=stats, rows_per_graph=Ns,
-                                     h_norm=h if stats is not None else None)
+            if fused_nodes:
+                ops.mpnn_node_halves(h, node_in, pa, pb, A, Bm, stats=stats, rows_per_graph=Ns)
             else:
                 ops.mlp(N, ops.ktiles(T(h, H), T(node_in, kin)), [pa, pb], nl=1, ht=4, ot=4,
                         act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2, groups_in_block=True, y_group_stride=N * H)
@@ -209,11 +210,17 @@ class MPNN(LightningModule):
                 ops.mpnn_edge16(A, Bm, csr, lyr.msg2_t16[0], lyr.msg2_t16[1], agg, partials, l2e=l2e)
             else:
                 ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials, l2e=l2e)
+            if fused_nodes:
+                ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g, stats=stats, rows_per_graph=Ns)
+                if li + 1 < len(P.layers):
+                    stats = ops.instance_norm_stats(g, B, Ns)
+                    h, g = g, h                                             # h: raw update output + its statistics
+                else:
+                    ops.instance_norm(g, B, Ns, out=h)
+                continue
             ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
                     act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g)
-            if fused_halves and li + 1 < len(P.layers):
-                stats = ops.instance_norm_stats(g, B, Ns)                  # applied by the next hop's halves kernel
-            elif tape is None:
+            if tape is None:
                 ops.instance_norm(g, B, Ns, out=h)
             else:
                 h_in = h

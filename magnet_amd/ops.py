@@ -310,6 +310,18 @@ def mpnn_node_halves(h, node_in, pre_a, pre_b, A, Bm, stats=None, rows_per_graph
                                                 _p(A), _p(Bm), _p(h_norm), _stream()), "mpnn_node_halves")
 
 
+def mpnn_node_update(h, agg, node_in, upd1, upd2, y, stats=None, rows_per_graph=0, eps=1e-5):
+    """y = hn + Swish(W2 Swish(W1 [hn | agg | node_in] + b1) + b2), hn = InstanceNorm-applied h when ``stats`` = (mean, var);
+    upd1 / upd2: (fp16x3 planes, padded bias)"""
+    assert y.data_ptr() != h.data_ptr()
+    mean, var = stats if stats is not None else (None, None)
+    ng = mean.shape[0] if mean is not None else 0
+    L.check(L.lib().magnet_mpnn_node_update_f32(_p(h), _p(agg), _p(node_in), node_in.shape[1], C.c_long(h.shape[0]), _p(mean), _p(var),
+                                                C.c_float(float(eps)), ng, int(rows_per_graph), _p(upd1[0]), _p(upd1[1]),
+                                                _p(upd2[0]), _p(upd2[1]), _p(y), _stream()), "mpnn_node_update")
+    return y
+
+
 def resize_linear(x, out_hw, d):
     """x [n, Hi, Wi] (d = 2) or [n, Wi] (d = 1) -> [n, Ho, Wo] / [n, Wo], F.interpolate(..., align_corners=False)"""
     x = _f32(x, "resize source")

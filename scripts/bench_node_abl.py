@@ -57,6 +57,10 @@ def halves_resident_only():
 
 
 print(f"N={N} kin={kin}")
+st0 = ops.instance_norm_stats(h, 4, N // 4)
+print(f"persistent update kernel: {timeit(lambda: ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g))*1e3:.1f} us;  with norm on load: "
+      f"{timeit(lambda: ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g, stats=st0, rows_per_graph=N // 4))*1e3:.1f} us;  generic update: {timeit(update)*1e3:.1f} us")
+print(f"resident halves with norm on load, no h_norm: {timeit(lambda: ops.mpnn_node_halves(h, node_in, lyr.pre_a_l2e, lyr.pre_b_l2e, AB[0], AB[1], stats=st0, rows_per_graph=N // 4))*1e3:.1f} us")
 for abl in [0, 1, 4, 16, 5, 17, 20, 21]:
     _lib.lib().magnet_debug_set_mlp_ablation(abl)
     print(f"resident halves abl {abl:2d}: {timeit(halves_resident_only)*1e3:7.1f} us    with norm + h_norm: {timeit(halves_fused)*1e3:7.1f} us (incl. stats)")

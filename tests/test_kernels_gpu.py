@@ -425,7 +425,10 @@ def test_node_halves_resident_kernel_matches_norm_plus_generic_mlp(kin, n_graphs
     assert ops.node_halves_supported(kin, n_graphs, rows) or not with_norm
     if with_norm:
         stats = ops.instance_norm_stats(h_raw, n_graphs, rows)
+        ops.mpnn_node_halves(h_raw, node_in, pa, pb, A, Bm, stats=stats, rows_per_graph=rows)       # without the h_norm output
+        A1 = A.clone()
         ops.mpnn_node_halves(h_raw, node_in, pa, pb, A, Bm, stats=stats, rows_per_graph=rows, h_norm=hn)
+        assert torch.equal(A, A1)
         h_ref = ops.instance_norm(h_raw, n_graphs, rows)
         assert rel_l2(hn, h_ref) < 2e-7
         x64 = h_raw.double().view(n_graphs, rows, H)
@@ -456,3 +459,39 @@ def test_mpnn_2d_rollout_with_fused_node_halves_equals_the_unfused_path():
         outs.append(m.validation_step(batch, 0))
     assert torch.isfinite(outs[0]).all()
     assert rel_l2(outs[0], outs[1]) < 1e-6
+
+
+@pytest.mark.parametrize("kin,n", [(32, 4 * 4096), (32, 1000 + 13), (64, 2 * 640 + 5), (32, 70)])
+def test_node_update_persistent_kernel_matches_generic_chain(kin, n):
+    """magnet_mpnn_node_update_f32 (persistent, W2 resident, W1 streamed, h k tiles last) == the generic two-Linear launch with
+    the residual epilogue, and both against fp64 on the host."""
+    from magnet_amd import ops
+    from magnet_amd.packing import pack
+    g = torch.Generator().manual_seed(5)
+    H = 128
+    w1, w2 = torch.randn(H, 2 * H + kin, generator=g) * 0.08, torch.randn(H, H, generator=g) * 0.1
+    b1, b2 = torch.randn(H, generator=g) * 0.3, torch.randn(H, generator=g) * 0.3
+    h, agg = torch.randn(n, H, generator=g).cuda(), torch.randn(n, H, generator=g).cuda()
+    node_in = torch.randn(n, kin, generator=g).cuda()
+    u1, u2 = pack(w1.cuda(), b1.cuda(), "fp16x3", k_pad=2 * H + kin), pack(w2.cuda(), b2.cuda(), "fp16x3")
+    y = torch.full((n, H), float("nan"), device="cuda")
+    ops.mpnn_node_update(h, agg, node_in, u1, u2, y)
+    ref = torch.empty(n, H, device="cuda")
+    T = ops.Term
+    ops.mlp(n, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [u1, u2], nl=2, ht=4, ot=4, act=ops.ACT_SWISH, last_act=True,
+            epi=ops.EPI_STORE_RES, res=h, y=ref)
+    assert rel_l2(y, ref) < 5e-7
+    sw = lambda v: v * torch.sigmoid(v)  # noqa: E731
+
+    def host(hh):
+        x64 = torch.cat([hh, agg.double().cpu(), node_in.double().cpu()], 1)
+        return hh + sw(sw(x64 @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
+    assert rel_l2(y, host(h.double().cpu())) < 2e-6
+    if n % 4 == 0:            # InstanceNorm of the h input applied on load (4 graphs): == normalising first
+        raw = h * 2 + 1
+        stats = ops.instance_norm_stats(raw, 4, n // 4)
+        ops.mpnn_node_update(raw, agg, node_in, u1, u2, y, stats=stats, rows_per_graph=n // 4)
+        ops.mpnn_node_update(ops.instance_norm(raw, 4, n // 4), agg, node_in, u1, u2, ref)
+        assert rel_l2(y, ref) < 5e-7
+        x = raw.double().cpu().view(4, n // 4, H)
+        assert rel_l2(y, host(((x - x.mean(1, keepdim=True)) / (x.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt()).view(n, H))) < 2e-6
