@@ -495,3 +495,46 @@ def test_node_update_persistent_kernel_matches_generic_chain(kin, n):
         assert rel_l2(y, ref) < 5e-7
         x = raw.double().cpu().view(4, n // 4, H)
         assert rel_l2(y, host(((x - x.mean(1, keepdim=True)) / (x.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt()).view(n, H))) < 2e-6
+
+
+@pytest.mark.parametrize("hidden,out,k_in", [(64, 64, 40), (128, 128, 45), (64, 32, 96)])
+def test_chain_kernel_is_bitwise_deterministic_over_launches(hidden, out, k_in):
+    """The LDS weight ring is fed by LDS-DMA and hand-placed waits: a missing wait shows up as an intermittent error in single
+    32-row wave tiles (an experiment of round 2 did exactly that, profiles/r2/chain_sq_counters.txt).  60 launches, all bitwise
+    equal to the first."""
+    from magnet_amd import ops
+    from magnet_amd.models.backbones.mlp import MLP
+    from magnet_amd.models.magnet_common import pack_mlp_ln, run_mlp
+    from magnet_amd.packing import pad_to
+    torch.manual_seed(0)
+    seq = torch.nn.Sequential(MLP(k_in, [hidden] * 4, out), torch.nn.LayerNorm(out)).cuda()
+    M, kp = 1013, pad_to(k_in)
+    x = torch.zeros(M, kp, device="cuda")
+    x[:, :k_in] = torch.randn(M, k_in, device="cuda")
+    pk = pack_mlp_ln(seq, k_pad=kp, mode="fp16x3")
+    kts = ops.ktiles(ops.Term(x, kp))
+    first = run_mlp(M, kts, pk, torch.empty(M, out, device="cuda")).clone()
+    for _ in range(60):
+        assert torch.equal(run_mlp(M, kts, pk, torch.empty(M, out, device="cuda")), first)
+
+
+def test_node_kernels_are_bitwise_deterministic_over_launches():
+    import types
+    import bench
+    from magnet_amd import ops
+    from magnet_amd.models.factory import FACTORY
+    torch.manual_seed(0)
+    m = FACTORY["mpnn_2d"](types.SimpleNamespace(**bench.HP)).cuda().eval()
+    lyr = m._packed().layers[0]
+    N, H, kin = 4 * 2048, 128, m.kin
+    h, agg = torch.randn(N, H, device="cuda") * 2 + 1, torch.randn(N, H, device="cuda")
+    node_in = torch.randn(N, kin, device="cuda")
+    st = ops.instance_norm_stats(h, 4, N // 4)
+    A, B, g = (torch.empty(N, H, device="cuda") for _ in range(3))
+    ops.mpnn_node_halves(h, node_in, lyr.pre_a_l2e, lyr.pre_b_l2e, A, B, stats=st, rows_per_graph=N // 4)
+    ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g, stats=st, rows_per_graph=N // 4)
+    ref = (A.clone(), B.clone(), g.clone())
+    for _ in range(40):
+        ops.mpnn_node_halves(h, node_in, lyr.pre_a_l2e, lyr.pre_b_l2e, A, B, stats=st, rows_per_graph=N // 4)
+        ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g, stats=st, rows_per_graph=N // 4)
+        assert torch.equal(A, ref[0]) and torch.equal(B, ref[1]) and torch.equal(g, ref[2])
