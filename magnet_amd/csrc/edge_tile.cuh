@@ -10,16 +10,16 @@ struct TileMeta {            // what the epilogue of a tile needs, carried one i
     float m1, m2, m4, m8, mb;
 };
 
-__device__ __forceinline__ TileMeta tile_meta(int tile, int E, const int32_t* __restrict__ tgt,
-                                              const int32_t* __restrict__ rowptr, int j) {
+// the part of tile_meta that does not load anything: ti = tgt[min(e, E-1)], tnext = tgt[e+1] or -2, rs / re = rowptr[ti], rowptr[ti+1]
+__device__ __forceinline__ TileMeta tile_meta_from(int tile, int E, int j, int ti, int tnext, int rs, int re) {
     TileMeta md;
     md.tile = tile;
     const int e_raw = tile * 32 + j;
     md.e_ok = e_raw < E;
-    md.ti = tgt[md.e_ok ? e_raw : E - 1];
-    md.tnext = (e_raw + 1 < E && j < 31) ? tgt[e_raw + 1] : -2;
-    md.rs = rowptr[md.ti];
-    md.re = rowptr[md.ti + 1];
+    md.ti = ti;
+    md.tnext = tnext;
+    md.rs = rs;
+    md.re = re;
     const int t = md.e_ok ? md.ti : (-16 - j);
     const int jr = j & 15;
     const int t1 = dpp_i<DPP_SHR1, 0xF>(t), t2 = dpp_i<DPP_SHR2, 0xF>(t), t4 = dpp_i<DPP_SHR4, 0xF>(t);
@@ -30,6 +30,13 @@ __device__ __forceinline__ TileMeta tile_meta(int tile, int E, const int32_t* __
     md.m8 = ((jr >= 8) & (t8 == t)) ? 1.f : 0.f;
     md.mb = ((j >= 16) & (tb == t)) ? 1.f : 0.f;
     return md;
+}
+__device__ __forceinline__ TileMeta tile_meta(int tile, int E, const int32_t* __restrict__ tgt,
+                                              const int32_t* __restrict__ rowptr, int j) {
+    const int e_raw = tile * 32 + j;
+    const int ti = tgt[e_raw < E ? e_raw : E - 1];
+    const int tnext = (e_raw + 1 < E && j < 31) ? tgt[e_raw + 1] : -2;
+    return tile_meta_from(tile, E, j, ti, tnext, rowptr[ti], rowptr[ti + 1]);
 }
 
 

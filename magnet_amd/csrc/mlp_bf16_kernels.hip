@@ -408,24 +408,6 @@ struct NodeHalvesArgs {
 #ifndef NH_PIPE
 #define NH_PIPE true
 #endif
-#define NH_TS 36                                                    // row stride (floats) of a wave's 32 x 32 transposition tile
-// One 32-row x 32-column tile from the accumulator layout (lane = row, 16 B pieces at a 512 B stride: 32 quarter lines per store
-// instruction) through a wave-private LDS tile to whole 128-byte lines (lane l -> row 8 it + l / 8, 16 B piece l % 8)
-__device__ __forceinline__ void store_tile_lines(const f32x16& v, float* __restrict__ tl, float* __restrict__ y, int col0, long row0,
-                                                 long n, int lane) {
-    const int j = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 t = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-        *reinterpret_cast<f32x4*>(tl + j * NH_TS + 8 * g + 4 * half) = t;
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int r = 8 * it + (lane >> 3);
-        const f32x4 t = *reinterpret_cast<const f32x4*>(tl + r * NH_TS + 4 * (lane & 7));
-        if (row0 + r < n) *reinterpret_cast<f32x4*>(y + (row0 + r) * 128 + col0 + 4 * (lane & 7)) = t;
-    }
-}
 #ifndef NH_WAVES
 #define NH_WAVES 4
 #endif

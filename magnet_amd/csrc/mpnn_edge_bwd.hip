@@ -23,6 +23,9 @@
 #ifndef EB_INTERLEAVE
 #define EB_INTERLEAVE 0
 #endif
+#ifndef EB_LINE_STORES
+#define EB_LINE_STORES 0        // A/B: 1 = s1 / dq / dp through the LDS tile as whole lines (4.23 vs 4.51 ms alone, but 12 spilled VGPRs: the training step is 1 % slower)
+#endif
 
 __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float dswish(float x) {
@@ -50,6 +53,17 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst_row /* row e,
         }
 }
 
+// one [32 edges][128] block of a per-edge array: through the LDS tile as whole lines (so == 1), or the ablation's fake layout
+__device__ __forceinline__ void store_lines(float* __restrict__ out, const f32x16 (&v)[4], float* __restrict__ tl, int tile, int E,
+                                            int lane, bool e_ok, size_t row, int so) {
+    if (so != 1 || !EB_LINE_STORES) {
+        if (e_ok) store_tile(out + row, v, so);
+        return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) store_tile_lines(v[nt], tl, out, nt * 32, (long)tile * 32, (long)E, lane);
+}
+
 __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restrict__ A, const float* __restrict__ Bm,
                                                           const float* __restrict__ dagg, const int32_t* __restrict__ src,
                                                           const int32_t* __restrict__ tgt, const int32_t* __restrict__ rowptr,
@@ -61,14 +75,29 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
     constexpr int NP = Split<MODE>::NP;
     __shared__ __attribute__((aligned(16))) u32x4 wl[32 * NP * 64];          // W2   planes, 64 KiB
     __shared__ __attribute__((aligned(16))) u32x4 wt[32 * NP * 64];          // W2^T planes, 64 KiB
+    // b2 in LDS, re-read per tile at an offset the compiler cannot see through: read from global memory the 64 bias registers are loop
+    // invariant, hipcc hoists them out of the tile loop and then SPILLS them (they were 56 of the kernel's 70 spilled VGPRs) - and every
+    // scratch reload is a VMEM load consumed at once, which (in-order vmcnt) waits for all the stores and prefetches issued before it
+    __shared__ __attribute__((aligned(16))) float bl[128];
+    // s1 / dq / dp leave through a wave-private 32 x 36-float LDS tile as whole 128-byte lines (store_tile_lines): the accumulator
+    // layout (lane = edge) stores 16 B pieces at a 512 B stride - 32 quarter lines per instruction, measured 0.85 ms of the kernel
+#if EB_LINE_STORES
+    __shared__ __attribute__((aligned(16))) float tls[4][32 * NH_TS];
+#endif
     for (int i = threadIdx.x; i < 32 * NP * 64; i += 256) {
         wl[i] = w2s[i];
         wt[i] = w2ts[i];
     }
+    if (threadIdx.x < 128) bl[threadIdx.x] = b2[threadIdx.x];
     __syncthreads();
     EBWD_ABL_INIT
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, j = lane & 31;
+#if EB_LINE_STORES
+    float* tl = tls[wave];
+#else
+    float* tl = nullptr;
+#endif
     const int ntiles = (E + 31) / 32;
     // XCD-aware contiguous tile ranges, as in k_mpnn_edge6 (workgroups go round-robin over the 8 XCDs and their L2s)
     const int nb8 = gridDim.x / 8;
@@ -98,8 +127,18 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
                 }
             }
     }
+    // the tile's CSR bookkeeping (target, next target, row bounds) is loaded one tile ahead as well: read at the top of its own tile it
+    // would be the wave's youngest load, and waiting for it (in-order vmcnt) waits for the previous tile's dp stores
+    int m_ti, m_tnext, m_rs, m_re;
+    {
+        const int e_raw = tile * 32 + j;
+        m_ti = tgt[e_raw < E ? e_raw : E - 1];
+        m_tnext = (e_raw + 1 < E && j < 31) ? tgt[e_raw + 1] : -2;
+        m_rs = rowptr[m_ti];
+        m_re = rowptr[m_ti + 1];
+    }
     for (; tile < tend; tile += stride) {
-        const TileMeta md = tile_meta(tile, E, tgt, rowptr, j);
+        const TileMeta md = tile_meta_from(tile, E, j, m_ti, m_tnext, m_rs, m_re);
         const int e = min(tile * 32 + j, E - 1);
         const int ti = md.ti;
         const float inv_deg = 1.0f / (float)(md.re - md.rs);
@@ -107,7 +146,9 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
         const size_t row = (abl & 4) ? (size_t)tile * 4096 + lane * 4 : (size_t)e * 128 + 4 * half;
         const int tn = tile + stride < tend ? tile + stride : tile;       // clamped: the last iteration prefetches unused rows
         const int en = min(tn * 32 + j, E - 1);
-        const float* pan = A + (size_t)tgt[en] * 128 + 4 * half;
+        const int tin = tgt[en];                                           // next tile's target / next target: consumed mid-tile
+        const int tnn = (tn * 32 + j + 1 < E && j < 31) ? tgt[tn * 32 + j + 1] : -2;
+        const float* pan = A + (size_t)tin * 128 + 4 * half;
         const float* pbn = Bm + (size_t)src[en] * 128 + 4 * half;
         f32x16 p[4], x[4], acc[4], accc[4], gd[4];
         {   // dagg rows (consumed after GEMM 1)
@@ -131,12 +172,16 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
                 x[kt][i] = act_swish(v);
             }
         // ---- GEMM 1: q = W2 s1 + b2
-        init_bias<4>(acc, b2, half);
+        {
+            int boff = 0;
+            asm volatile("" : "+v"(boff));                        // loop-variant as far as the compiler knows: no hoisting
+            init_bias<4>(acc, bl + boff, half);
+        }
         zero_tiles<4>(accc);
 #if EB_INTERLEAVE
         gemm128<MODE>(wl, x, acc, accc, lane, md.e_ok ? s1_out + row : nullptr, 1.0f);
 #else
-        if (md.e_ok && !(abl & 1)) store_tile(s1_out + row, x, so);
+        if (!(abl & 1)) store_lines(s1_out, x, tl, tile, E, lane, md.e_ok, row, so);
         gemm128<MODE>(wl, x, acc, accc, lane, nullptr, 1.0f);
 #endif
         // ---- dq = dagg[i] / deg * Swish'(q)   (into x), per-edge power-of-two scale for the fp16 split
@@ -154,7 +199,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
         const float sc = __uint_as_float((254u - eb) << 23);                   // 2^(127-eb): scaled max in [1, 2)
         const float usc = __uint_as_float(eb << 23);                           // 2^(eb-127)  (0 for an all-zero row)
 #if !EB_INTERLEAVE
-        if (md.e_ok && !(abl & 1)) store_tile(dq_out + row, x, so);
+        if (!(abl & 1)) store_lines(dq_out, x, tl, tile, E, lane, md.e_ok, row, so);
 #endif
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -169,6 +214,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
 #pragma unroll
                 for (int c = 0; c < 4; ++c) gb[kt][4 * g + c] = b[c];
             }
+        const int rsn = rowptr[tin], ren = rowptr[tin + 1];                 // next tile's row bounds, consumed at the next tile's top
         // ---- GEMM 2: ds1 = W2^T dq
         zero_tiles<4>(acc);
         zero_tiles<4>(accc);
@@ -195,9 +241,12 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
         // ---- store dp and form dA[i] = sum over the edges of target i, k tile by k tile (stores spread between the scans)
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
+#if EB_LINE_STORES
+            if (!(abl & 2) && so == 1) store_tile_lines(acc[kt], tl, dp_out, kt * 32, (long)tile * 32, (long)E, lane);
+#endif
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                if (md.e_ok && !(abl & 2)) {
+                if (md.e_ok && !(abl & 2) && !(EB_LINE_STORES && so == 1)) {
                     const f32x4 o = {acc[kt][4 * g], acc[kt][4 * g + 1], acc[kt][4 * g + 2], acc[kt][4 * g + 3]};
                     *reinterpret_cast<f32x4*>(dp_out + row + (kt * 32 + 8 * g) * so) = o;
                 }
@@ -206,6 +255,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
             }
         }
         store_run_results<4, false>(acc, md, dA, partials, half);
+        m_ti = tin, m_tnext = tnn, m_rs = rsn, m_re = ren;
     }
 }
 
