@@ -176,6 +176,13 @@ int magnet_mpnn_edge_fp16x3_t16_f32(const float* A, const float* Bm, const int32
 int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1, int k1,
                             int s1, const float* w2, const float* b2, int k2, int use_swish, const float* dt,
                             float* out, void* stream);
+/* The same read-out fused with the InstanceNorm apply of the last hop (models/mpnn.py:70 followed by :197-201): h is the raw update
+ * output, normalised with mean / var [n_graphs][128] (magnet_instance_norm_stats_f32) while it is loaded; mean == NULL: h as it is.
+ * Lane-per-node kernels for the conv specs of models/mpnn.py:140-163 only, n >= 8192, at most 8 graphs; otherwise -2 (normalise with
+ * magnet_instance_norm_f32 and call magnet_mpnn_readout_f32). */
+int magnet_mpnn_readout_norm_f32(const float* h, const float* mean, const float* var, float eps, int n_graphs, int rows_per_graph,
+                                 const float* u, int n, int tw, const float* w1, const float* b1, int k1, int s1, const float* w2,
+                                 const float* b2, int k2, int use_swish, const float* dt, float* out, void* stream);
 /* PyG InstanceNorm(x, batch) with batch = contiguous blocks of rows_per_graph rows (models/mpnn.py:63,70).
  * workspace: (2*n_graphs*ceil(rows_per_graph/64) + 2*n_graphs) * H floats. */
 int magnet_instance_norm_f32(const float* x, int n_graphs, int rows_per_graph, int H, float eps, float* y,

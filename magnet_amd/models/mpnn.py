@@ -212,11 +212,8 @@ class MPNN(LightningModule):
                 ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials, l2e=l2e)
             if fused_nodes:
                 ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g, stats=stats, rows_per_graph=Ns)
-                if li + 1 < len(P.layers):
-                    stats = ops.instance_norm_stats(g, B, Ns)
-                    h, g = g, h                                             # h: raw update output + its statistics
-                else:
-                    ops.instance_norm(g, B, Ns, out=h)
+                stats = ops.instance_norm_stats(g, B, Ns)
+                h, g = g, h                                                 # h: raw update output + its statistics
                 continue
             ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
                     act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g)
@@ -229,7 +226,15 @@ class MPNN(LightningModule):
         if tape is not None:
             tape.h = h
         k1, s1, k2 = _READOUT[tw]
-        out = ops.mpnn_readout(h, u, tw, P.conv[0], P.conv[1], k1, s1, P.conv[2], P.conv[3], k2, self.readout_swish, dtv)
+        out = None
+        if fused_nodes and stats is not None:               # the last hop's InstanceNorm is applied by the read-out while it loads
+            out = ops.mpnn_readout(h, u, tw, P.conv[0], P.conv[1], k1, s1, P.conv[2], P.conv[3], k2, self.readout_swish, dtv,
+                                   stats=stats, rows_per_graph=Ns)
+            if out is None:
+                ops.instance_norm(h, B, Ns, out=g)
+                h = g
+        if out is None:
+            out = ops.mpnn_readout(h, u, tw, P.conv[0], P.conv[1], k1, s1, P.conv[2], P.conv[3], k2, self.readout_swish, dtv)
         self._guard.outputs(out)
         return out
 

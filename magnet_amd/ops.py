@@ -259,9 +259,19 @@ def mpnn_edge16(A, Bm, csr, w2_t16, b2, agg, partials, l2e=False):
 mpnn_edge_bf16x6 = mpnn_edge     # kept for scripts: the weights' dtype decides
 
 
-def mpnn_readout(h, u, tw, w1, b1, k1, s1, w2, b2, k2, use_swish, dt):
+def mpnn_readout(h, u, tw, w1, b1, k1, s1, w2, b2, k2, use_swish, dt, stats=None, rows_per_graph=0, eps=1e-5):
+    """``stats`` = (mean, var): h is the raw output of the last hop and is normalised while it is loaded (returns None when no fused
+    kernel covers the shape: normalise first, then call without ``stats``)"""
     n = h.shape[0]
     out = torch.empty(n, tw, device=h.device, dtype=torch.float32)
+    if stats is not None:
+        rc = L.lib().magnet_mpnn_readout_norm_f32(_p(h), _p(stats[0]), _p(stats[1]), C.c_float(float(eps)), stats[0].shape[0],
+                                                  int(rows_per_graph), _p(u), n, tw, _p(w1), _p(b1), k1, s1, _p(w2), _p(b2), k2,
+                                                  int(use_swish), _p(_f32(dt)), _p(out), _stream())
+        if rc == -2:
+            return None
+        L.check(rc, "mpnn_readout_norm")
+        return out
     L.check(L.lib().magnet_mpnn_readout_f32(_p(h), _p(u), n, tw, _p(w1), _p(b1), k1, s1, _p(w2), _p(b2), k2,
                                             int(use_swish), _p(_f32(dt)), _p(out), _stream()), "mpnn_readout")
     return out

@@ -538,3 +538,40 @@ def test_node_kernels_are_bitwise_deterministic_over_launches():
         ops.mpnn_node_halves(h, node_in, lyr.pre_a_l2e, lyr.pre_b_l2e, A, B, stats=st, rows_per_graph=N // 4)
         ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g, stats=st, rows_per_graph=N // 4)
         assert torch.equal(A, ref[0]) and torch.equal(B, ref[1]) and torch.equal(g, ref[2])
+
+
+@pytest.mark.parametrize("tw,dim,n,n_graphs", [(10, 2, 4 * 4096, 4), (10, 1, 8192 + 37, 0), (25, 1, 2 * 4160, 2), (20, 1, 8200, 0),
+                                               (16, 1, 8192, 1)])
+def test_readout_line_kernel_with_instance_norm_on_load(tw, dim, n, n_graphs):
+    """magnet_mpnn_readout_norm_f32 / the large-n path of magnet_mpnn_readout_f32 (rows through LDS as whole lines, optional InstanceNorm
+    on load) vs the two Conv1d of models/mpnn.py:140-163,197-201 in fp64 on the host, and vs the wave-per-node kernel on a small slice."""
+    from magnet_amd import ops
+    from magnet_amd.models.mpnn import _READOUT
+    torch.manual_seed(7)
+    k1, s1, k2 = _READOUT[tw]
+    use_swish = not (dim == 1 and tw == 10)
+    c1, c2 = torch.nn.Conv1d(1, 8, k1, stride=s1).double(), torch.nn.Conv1d(8, 1, k2).double()
+    h_raw = torch.randn(n, 128) * 1.7 + 0.4
+    u = torch.randn(n, tw)
+    dt = torch.tensor([0.37])
+    hx = h_raw.double()
+    if n_graphs:
+        x = hx.view(n_graphs, n // n_graphs, 128)
+        hx = ((x - x.mean(1, keepdim=True)) / (x.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt()).view(n, 128)
+    with torch.no_grad():
+        z = c1(hx[:, None])
+        if use_swish:
+            z = z * torch.sigmoid(z)
+        want = u[:, -1:].double() + 0.37 * torch.arange(1, tw + 1, dtype=torch.float64) * c2(z).squeeze(1)
+    f32 = lambda t: t.detach().float().cuda().contiguous()  # noqa: E731
+    args = (f32(c1.weight).reshape(-1), f32(c1.bias), k1, s1, f32(c2.weight).reshape(-1), f32(c2.bias), k2, use_swish, dt.cuda())
+    hc, uc = h_raw.cuda(), u.cuda()
+    if n_graphs:
+        stats = ops.instance_norm_stats(hc, n_graphs, n // n_graphs)
+        got = ops.mpnn_readout(hc, uc, tw, *args, stats=stats, rows_per_graph=n // n_graphs)
+        assert got is not None
+    else:
+        got = ops.mpnn_readout(hc, uc, tw, *args)
+    assert rel_l2(got, want) < 2e-6
+    small = ops.mpnn_readout(hx.float().cuda()[:100].contiguous(), uc[:100].contiguous(), tw, *args)     # n < 8192: wave-per-node kernel
+    assert rel_l2(small, want[:100]) < 2e-6
