@@ -205,10 +205,18 @@ int magnet_instance_norm_stats_f32(const float* x, int n_graphs, int rows_per_gr
  *   y  = hn + Swish(W2 Swish(W1 [hn | agg | node_in] + b1) + b2)
  * h, agg, y [n][128] (y must not alias h), node_in [n][kin], kin in {32, 64}, at most 8 graphs (else -2: use
  * magnet_mlp_fp16x3_f32); w1 / w2: fp16x3 planes of update_net_1 ([128][256 + kin]) / update_net_2 ([128][128]) as
- * packing.pack_linear_fp16x2 lays them out. */
+ * packing.pack_linear_fp16x2 lays them out.
+ * part_sum / part_m2 (both or neither; [n_rows / 128][128], n_rows % 128 == 0): per 128-row tile the column sums of y and the
+ * squares centred on the tile's own column means - the InstanceNorm statistics of y (models/mpnn.py:70) without another pass over
+ * it; magnet_colstat_final_f32 turns them into mean / variance. */
 int magnet_mpnn_node_update_f32(const float* h, const float* agg, const float* node_in, int kin, long n_rows, const float* mean,
                                 const float* var, float eps, int n_graphs, int rows_per_graph, const void* w1_f16,
-                                const float* b1, const void* w2_f16, const float* b2, float* y, void* stream);
+                                const float* b1, const void* w2_f16, const float* b2, float* y, float* part_sum, float* part_m2,
+                                void* stream);
+/* mean / biased variance [n_graphs][H] from per-chunk partials of chunk_rows rows (rows_per_graph % chunk_rows == 0; the chunks of a
+ * graph consecutive): the merge step of PyG InstanceNorm's statistics (pairwise-variance identity, fixed order). */
+int magnet_colstat_final_f32(const float* part_sum, const float* part_m2, int n_graphs, int rows_per_graph, int chunk_rows, int H,
+                             float* mean, float* var, void* stream);
 int magnet_mpnn_node_halves_f32(const float* h, const float* node_in, int kin, long n_rows, const float* mean, const float* var,
                                 float eps, int n_graphs, int rows_per_graph, const void* wa_f16, const float* ba,
                                 const void* wb_f16, const float* bb, float* A, float* Bm, float* h_norm, void* stream);

@@ -572,6 +572,8 @@ struct NodeUpdateArgs {
     float* y;                  // [n][128]
     const float* mean;         // [n_graphs][128] or nullptr: h is then normalised on load, (h - mean) / sqrt(var + eps)
     const float* var;
+    float* part_sum;           // [n / 128][128] or nullptr: per 128-row tile the column sums of y ...
+    float* part_m2;            // ... and the sums of squares centred on the tile's own column means (for k_colstat_final)
     long n;
     int kin, rows_per_graph, n_graphs;
     float eps;
@@ -588,6 +590,7 @@ __global__ void __launch_bounds__(256, 1) k_node_update(NodeUpdateArgs a) {
     __shared__ __attribute__((aligned(16))) float tls[4][32 * NH_TS];
     __shared__ __attribute__((aligned(16))) float bl[2][128];
     __shared__ __attribute__((aligned(16))) float st[2][NH_MAX_GRAPHS][128];          // mean, 1 / sqrt(var + eps)
+    __shared__ __attribute__((aligned(16))) float ws[4][2][128];                      // per wave: column sums / centred squares of a tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, j = lane & 31;
     float* tl = tls[wave];
@@ -705,6 +708,51 @@ __global__ void __launch_bounds__(256, 1) k_node_update(NodeUpdateArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[t][4 * g + c] += xr[t][g][c];
             store_tile_lines(acc[t], tl, a.y, t * 32, row0, a.n, lane);
+            if (a.part_sum) {
+                // InstanceNorm statistics of the output without another pass over it: the tile is still in the wave's LDS tile; lane
+                // (column j, half) walks 16 of its 32 rows, the halves are combined, the squares are centred on the wave's own column
+                // mean (the pairwise scheme of k_colstat_partial, 32-row chunks)
+                float vcol[16], sm = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    vcol[r] = tl[(16 * half + r) * NH_TS + j];
+                    sm += vcol[r];
+                }
+                sm += __shfl_xor(sm, 32);
+                const float mu = sm * (1.0f / 32.0f);
+                float q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) q = fmaf(vcol[r] - mu, vcol[r] - mu, q);
+                q += __shfl_xor(q, 32);
+                if (half == 0) {
+                    ws[wave][0][t * 32 + j] = sm;
+                    ws[wave][1][t * 32 + j] = q;
+                }
+            }
+        }
+        if (a.part_sum) {
+            __syncthreads();
+            if (wave == 0) {                             // merge the four 32-row chunks of this 128-row tile (fixed order)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const int col = lane + 64 * cc;
+                    float s4[4], tot = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        s4[w] = ws[w][0][col];
+                        tot += s4[w];
+                    }
+                    const float mu = tot * (1.0f / 128.0f);
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float d = s4[w] * (1.0f / 32.0f) - mu;
+                        m2 += ws[w][1][col] + 32.0f * d * d;
+                    }
+                    a.part_sum[tile * 128 + col] = tot;
+                    a.part_m2[tile * 128 + col] = m2;
+                }
+            }
         }
         TRACE(57)
 #pragma unroll
@@ -714,16 +762,19 @@ __global__ void __launch_bounds__(256, 1) k_node_update(NodeUpdateArgs a) {
 
 // y [n_rows][128] = hn + Swish(W2 Swish(W1 [hn | agg | node_in] + b1) + b2), hn = mean ? (h - mean[g]) / sqrt(var[g] + eps) : h;
 // w1 / w2: fp16x3 planes as magnet_mlp_fp16x3_f32 takes them.  Returns -2 for kin not in {32, 64} or more than 8 graphs (the
-// caller then uses the generic chain).  y must not alias h.
+// caller then uses the generic chain).  y must not alias h.  part_sum / part_m2 ([n_rows / 128][128] each, n_rows % 128 == 0): per
+// 128-row tile the column sums of y and the squares centred on the tile's column means - input of magnet_colstat_final_f32.
 extern "C" int magnet_mpnn_node_update_f32(const float* h, const float* agg, const float* node_in, int kin, long n_rows,
                                            const float* mean, const float* var, float eps, int n_graphs, int rows_per_graph,
                                            const void* w1_f16, const float* b1, const void* w2_f16, const float* b2, float* y,
-                                           void* stream) {
+                                           float* part_sum, float* part_m2, void* stream) {
     (void)hipGetLastError();
     if (n_rows <= 0) return 0;
     if (kin != 32 && kin != 64) return -2;
     if (mean && (n_graphs > NH_MAX_GRAPHS || n_graphs < 1 || rows_per_graph < 1 || !var)) return -2;
+    if (part_sum && (n_rows % 128 || !part_m2)) return -2;        // (tiles must be whole: every row of a tile enters its statistics)
     NodeUpdateArgs a;
+    a.part_sum = part_sum, a.part_m2 = part_m2;
     a.mean = mean, a.var = var, a.eps = eps, a.n_graphs = n_graphs, a.rows_per_graph = rows_per_graph;
     a.h = h, a.agg = agg, a.node_in = node_in, a.kin = kin, a.n = n_rows, a.y = y, a.b1 = b1, a.b2 = b2;
     a.w1 = reinterpret_cast<const f32x4*>(w1_f16), a.w2 = reinterpret_cast<const f32x4*>(w2_f16);

@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(128) k_colstat_partial(const float* __restrict
 // mean first, then the merged centred second moment (biased variance).
 __global__ void __launch_bounds__(1024) k_colstat_final(const float* __restrict__ part_sum, const float* __restrict__ part_m2,
                                                         int nchunks, int rows_per_graph, int H, float* __restrict__ mean,
-                                                        float* __restrict__ var) {
+                                                        float* __restrict__ var, int chunk_rows = NORM_CHUNK * NORM_SUB) {
     __shared__ float sm[32][33];
     __shared__ float mu[32];
     const int g = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, grp = threadIdx.x >> 5;
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(1024) k_colstat_final(const float* __restrict_
     acc = 0.f;
     if (c < H)
         for (int k = grp; k < nchunks; k += 32) {
-            const float nc = (float)min(NORM_CHUNK * NORM_SUB, rows_per_graph - k * NORM_CHUNK * NORM_SUB);
+            const float nc = (float)min(chunk_rows, rows_per_graph - k * chunk_rows);
             const float d = part_sum[((size_t)g * nchunks + k) * H + c] / nc - m;
             acc += part_m2[((size_t)g * nchunks + k) * H + c] + nc * d * d;
         }
@@ -481,6 +481,18 @@ extern "C" int magnet_instance_norm_stats_f32(const float* x, int n_graphs, int 
     hipLaunchKernelGGL(k_colstat_partial, dim3(nsup, n_graphs), dim3(128), 0, s, x, rows_per_graph, H, part, part_m2);
     hipLaunchKernelGGL(k_colstat_final, dim3(n_graphs, (H + 31) / 32), dim3(1024), 0, s, part, part_m2, nsup,
                        rows_per_graph, H, mean, var);
+    LAUNCH_CHECK();
+}
+// mean / biased variance [n_graphs][H] from per-chunk partials (column sums and squares centred on the chunk's own column means,
+// chunk_rows rows each, chunks of a graph consecutive: part[(g * nchunks + k) * H + c]) - the merge step of the InstanceNorm statistics
+// for a producer that emits the partials itself (magnet_mpnn_node_update_f32)
+extern "C" int magnet_colstat_final_f32(const float* part_sum, const float* part_m2, int n_graphs, int rows_per_graph, int chunk_rows,
+                                        int H, float* mean, float* var, void* stream) {
+    (void)hipGetLastError();
+    if (n_graphs <= 0 || rows_per_graph <= 0) return 0;
+    if (chunk_rows <= 0 || rows_per_graph % chunk_rows) return -2;
+    hipLaunchKernelGGL(k_colstat_final, dim3(n_graphs, (H + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part_sum, part_m2,
+                       rows_per_graph / chunk_rows, rows_per_graph, H, mean, var, chunk_rows);
     LAUNCH_CHECK();
 }
 // workspace: (2 * n_graphs * nchunks + 2 * n_graphs) * H floats, nchunks = ceil(rows_per_graph / 64)

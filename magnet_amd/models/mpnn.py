@@ -112,6 +112,9 @@ class MPNN(LightningModule):
         self.hip_graph = getattr(hparams, "hip_graph", "auto")
         # A/B knob (default on): InstanceNorm apply fused into the next hop's per-node-halves kernel on large graphs
         self.fused_node_halves = bool(getattr(hparams, "fused_node_halves", os.environ.get("MAGNET_FUSED_HALVES", "1") != "0"))
+        # the update kernel can emit the partials of its output's InstanceNorm statistics itself (no k_colstat_partial pass): measured
+        # neutral to slightly negative end to end (the 0.5 ms it saves per rollout come back as a slower edge kernel: DESIGN.md 9.9) - off
+        self.fused_node_stats = bool(getattr(hparams, "fused_node_stats", os.environ.get("MAGNET_FUSED_STATS", "0") != "0"))
         self._rollout_graph = RolloutGraph(topology_keys=("x",))
 
     # ------------------------------------------------------------------ packed weights (cached)
@@ -211,8 +214,12 @@ class MPNN(LightningModule):
             else:
                 ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials, l2e=l2e)
             if fused_nodes:
-                ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g, stats=stats, rows_per_graph=Ns)
-                stats = ops.instance_norm_stats(g, B, Ns)
+                if Ns % 128 == 0 and self.fused_node_stats:   # the update kernel emits the partials of the output's InstanceNorm statistics itself
+                    stats = ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g, stats=stats, rows_per_graph=Ns,
+                                                 stats_out_graphs=B)
+                else:
+                    ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g, stats=stats, rows_per_graph=Ns)
+                    stats = ops.instance_norm_stats(g, B, Ns)
                 h, g = g, h                                                 # h: raw update output + its statistics
                 continue
             ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,

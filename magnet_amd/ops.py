@@ -320,16 +320,28 @@ def mpnn_node_halves(h, node_in, pre_a, pre_b, A, Bm, stats=None, rows_per_graph
                                                 _p(A), _p(Bm), _p(h_norm), _stream()), "mpnn_node_halves")
 
 
-def mpnn_node_update(h, agg, node_in, upd1, upd2, y, stats=None, rows_per_graph=0, eps=1e-5):
+def mpnn_node_update(h, agg, node_in, upd1, upd2, y, stats=None, rows_per_graph=0, eps=1e-5, stats_out_graphs=0):
     """y = hn + Swish(W2 Swish(W1 [hn | agg | node_in] + b1) + b2), hn = InstanceNorm-applied h when ``stats`` = (mean, var);
-    upd1 / upd2: (fp16x3 planes, padded bias)"""
+    upd1 / upd2: (fp16x3 planes, padded bias).  ``stats_out_graphs`` = n_graphs > 0: also returns (mean, var) of y per graph of
+    ``rows_per_graph`` rows (multiple of 128), computed from partials the kernel emits - no further pass over y."""
     assert y.data_ptr() != h.data_ptr()
+    n = h.shape[0]
     mean, var = stats if stats is not None else (None, None)
     ng = mean.shape[0] if mean is not None else 0
-    L.check(L.lib().magnet_mpnn_node_update_f32(_p(h), _p(agg), _p(node_in), node_in.shape[1], C.c_long(h.shape[0]), _p(mean), _p(var),
+    ps = pm = None
+    if stats_out_graphs:
+        assert rows_per_graph % 128 == 0 and n == stats_out_graphs * rows_per_graph
+        part = torch.empty(2, n // 128, 128, device=h.device, dtype=torch.float32)
+        ps, pm = part[0], part[1]
+    L.check(L.lib().magnet_mpnn_node_update_f32(_p(h), _p(agg), _p(node_in), node_in.shape[1], C.c_long(n), _p(mean), _p(var),
                                                 C.c_float(float(eps)), ng, int(rows_per_graph), _p(upd1[0]), _p(upd1[1]),
-                                                _p(upd2[0]), _p(upd2[1]), _p(y), _stream()), "mpnn_node_update")
-    return y
+                                                _p(upd2[0]), _p(upd2[1]), _p(y), _p(ps), _p(pm), _stream()), "mpnn_node_update")
+    if not stats_out_graphs:
+        return y
+    mv = torch.empty(2, stats_out_graphs, 128, device=h.device, dtype=torch.float32)
+    L.check(L.lib().magnet_colstat_final_f32(_p(ps), _p(pm), stats_out_graphs, int(rows_per_graph), 128, 128, _p(mv[0]), _p(mv[1]),
+                                             _stream()), "colstat_final")
+    return mv[0], mv[1]
 
 
 def resize_linear(x, out_hw, d):

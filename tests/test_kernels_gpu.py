@@ -487,6 +487,13 @@ def test_node_update_persistent_kernel_matches_generic_chain(kin, n):
         x64 = torch.cat([hh, agg.double().cpu(), node_in.double().cpu()], 1)
         return hh + sw(sw(x64 @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
     assert rel_l2(y, host(h.double().cpu())) < 2e-6
+    if n % 512 == 0:          # the statistics of the output from the kernel's own partials == a separate pass over y
+        mean, var = ops.mpnn_node_update(h, agg, node_in, u1, u2, y, rows_per_graph=n // 4, stats_out_graphs=4)
+        m2, v2 = ops.instance_norm_stats(y, 4, n // 4)
+        y64 = y.double().cpu().view(4, n // 4, H)
+        assert rel_l2(mean, y64.mean(1)) < 1e-6 and rel_l2(var, y64.var(1, unbiased=False)) < 1e-6
+        assert rel_l2(mean, m2) < 1e-6 and rel_l2(var, v2) < 1e-6
+        assert rel_l2(y, ref) < 5e-7
     if n % 4 == 0:            # InstanceNorm of the h input applied on load (4 graphs): == normalising first
         raw = h * 2 + 1
         stats = ops.instance_norm_stats(raw, 4, n // 4)
