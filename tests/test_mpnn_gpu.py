@@ -158,3 +158,25 @@ def test_bf16_mode_is_a_measured_deviation_not_parity():
     last = cb["u"].permute(0, 2, 1)[:, hp.time_window - 1:hp.time_window].cpu()       # increments are the honest measure
     print("bf16 rollout deviation", dev)
     assert OUT_TOL < dev < 5e-2
+
+
+@pytest.mark.gpu
+def test_large_graph_node_kernels_match_the_oracle_rollout():
+    """graphs above 2048 nodes run k_node_halves / k_node_update / k_mpnn_readout_lines (InstanceNorm applied on load): a 48 x 48,
+    two-trajectory free-running rollout against the CPU oracle (the golden fixtures are smaller graphs and take the generic launches)"""
+    import types
+    import bench
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    hp = types.SimpleNamespace(**bench.HP)
+    oracle = O.build("mpnn_2d", hp).eval()
+    fill_state_dict(oracle, 13)
+    model = FACTORY["mpnn_2d"](hp).eval()
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda()
+    batch = bench.synthetic_batch(48, 2, 9, "cpu")
+    pred = model.validation_step({k: v.cuda() for k, v in batch.items()}, 0)
+    with torch.no_grad():
+        want = oracle.validation_step(batch)
+    assert rel_l2(pred, want) < 1e-5
