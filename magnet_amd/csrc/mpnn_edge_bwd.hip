@@ -53,6 +53,22 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst_row /* row e,
         }
 }
 
+// store_tile_lines with the tile's base pointer wave-uniform (SGPR pair) and 32-bit lane offsets: no per-lane 64-bit pointers to keep
+__device__ __forceinline__ void store_tile_lines_u(const f32x16& v, float* __restrict__ tl, float* __restrict__ ytile /* uniform */,
+                                                   int col0, int rows_valid /* uniform */, int lane) {
+    const int j = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 t = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(tl + j * NH_TS + 8 * g + 4 * half) = t;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = 8 * it + (lane >> 3);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tl + r * NH_TS + 4 * (lane & 7));
+        if (r < rows_valid) *reinterpret_cast<f32x4*>(ytile + (r * 128 + col0 + 4 * (lane & 7))) = t;
+    }
+}
 // one [32 edges][128] block of a per-edge array: through the LDS tile as whole lines (so == 1), or the ablation's fake layout
 __device__ __forceinline__ void store_lines(float* __restrict__ out, const f32x16 (&v)[4], float* __restrict__ tl, int tile, int E,
                                             int lane, bool e_ok, size_t row, int so) {
@@ -60,8 +76,10 @@ __device__ __forceinline__ void store_lines(float* __restrict__ out, const f32x1
         if (e_ok) store_tile(out + row, v, so);
         return;
     }
+    float* yt = out + (size_t)__builtin_amdgcn_readfirstlane(tile) * 4096;
+    const int rv = min(32, E - __builtin_amdgcn_readfirstlane(tile) * 32);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) store_tile_lines(v[nt], tl, out, nt * 32, (long)tile * 32, (long)E, lane);
+    for (int nt = 0; nt < 4; ++nt) store_tile_lines_u(v[nt], tl, yt, nt * 32, rv, lane);
 }
 
 __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restrict__ A, const float* __restrict__ Bm,
@@ -242,7 +260,9 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
 #if EB_LINE_STORES
-            if (!(abl & 2) && so == 1) store_tile_lines(acc[kt], tl, dp_out, kt * 32, (long)tile * 32, (long)E, lane);
+            if (!(abl & 2) && so == 1)
+                store_tile_lines_u(acc[kt], tl, dp_out + (size_t)__builtin_amdgcn_readfirstlane(tile) * 4096, kt * 32,
+                                   min(32, E - __builtin_amdgcn_readfirstlane(tile) * 32), lane);
 #endif
 #pragma unroll
             for (int g = 0; g < 4; ++g) {

@@ -255,15 +255,41 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_split(const float* __restrict_
         const long nxt = sl + gridDim.x;
         if (nxt < nslabs) load(nxt);                                    // in flight during the MFMAs below
         if (active) {
+            // the six products of a k step alternate between TWO accumulators: consecutive MFMAs never write the same one (a dependent
+            // accumulate right behind its producer stalls the matrix pipe); all KT at once would need 36 more registers and spill at
+            // three workgroups per CU
+            constexpr int G = KT >= 2 ? 2 : 1;
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const u32x4* f = st + ((ks * 3) * 2 + half) * KC + kt * 32 + i;
-                    const bf16x8 xh = __builtin_bit_cast(bf16x8, f[0]);
-                    const bf16x8 xm = __builtin_bit_cast(bf16x8, f[2 * KC]);
-                    const bf16x8 xl = __builtin_bit_cast(bf16x8, f[4 * KC]);
-                    acc[kt] = mma_split6(ah[ks], am[ks], al[ks], xh, xm, xl, acc[kt]);
+                for (int k0 = 0; k0 < KT; k0 += G) {
+                    bf16x8 xh[G], xm[G], xl[G];
+#pragma unroll
+                    for (int q = 0; q < G; ++q) {
+                        if (k0 + q >= KT) continue;                       // (odd KT: the last group has one member)
+                        const u32x4* f = st + ((ks * 3) * 2 + half) * KC + (k0 + q) * 32 + i;
+                        xh[q] = __builtin_bit_cast(bf16x8, f[0]);
+                        xm[q] = __builtin_bit_cast(bf16x8, f[2 * KC]);
+                        xl[q] = __builtin_bit_cast(bf16x8, f[4 * KC]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < G; ++q)
+                        if (k0 + q < KT) acc[k0 + q] = mfma_bf16(am[ks], xm[q], acc[k0 + q]);
+#pragma unroll
+                    for (int q = 0; q < G; ++q)
+                        if (k0 + q < KT) acc[k0 + q] = mfma_bf16(al[ks], xh[q], acc[k0 + q]);
+#pragma unroll
+                    for (int q = 0; q < G; ++q)
+                        if (k0 + q < KT) acc[k0 + q] = mfma_bf16(ah[ks], xl[q], acc[k0 + q]);
+#pragma unroll
+                    for (int q = 0; q < G; ++q)
+                        if (k0 + q < KT) acc[k0 + q] = mfma_bf16(am[ks], xh[q], acc[k0 + q]);
+#pragma unroll
+                    for (int q = 0; q < G; ++q)
+                        if (k0 + q < KT) acc[k0 + q] = mfma_bf16(ah[ks], xm[q], acc[k0 + q]);
+#pragma unroll
+                    for (int q = 0; q < G; ++q)
+                        if (k0 + q < KT) acc[k0 + q] = mfma_bf16(ah[ks], xh[q], acc[k0 + q]);
                 }
         }
     }
