@@ -195,6 +195,11 @@ class MPNN(LightningModule):
         # output is normalised once for the read-out
         fused_nodes = (tape is None and self.gemm == "fp16x3" and Ns > ops.NORM_SMALL_ROWS
                        and ops.node_halves_supported(kin, B, Ns, H) and self.fused_node_halves)
+        # small graphs (the launch-bound 1-D configs): the same two kernels without the statistics plumbing - a 100-row launch of the
+        # generic chain streams its weight chunks one after the other through ONE workgroup (20 / 22 us per launch, all latency), the
+        # persistent kernels fetch theirs in one burst; InstanceNorm stays the one-launch small-graph kernel
+        small_nodes = (tape is None and self.gemm == "fp16x3" and Ns <= ops.NORM_SMALL_ROWS and kin in (32, 64) and H == 128
+                       and self.fused_node_halves)
         stats = None                                                        # (mean, var) of h when h is still un-normalised
         for li, lyr in enumerate(P.layers):
             if tape is not None:
@@ -204,7 +209,7 @@ class MPNN(LightningModule):
             # each workgroup so that the second group reads [h | node_in] from L2 (fp32 kernels: two workgroup columns)
             l2e = tape is None and hasattr(lyr, "pre_a_l2e")
             pa, pb = (lyr.pre_a_l2e, lyr.pre_b_l2e) if l2e else (lyr.pre_a, lyr.pre_b)
-            if fused_nodes:
+            if fused_nodes or small_nodes:
                 ops.mpnn_node_halves(h, node_in, pa, pb, A, Bm, stats=stats, rows_per_graph=Ns)
             else:
                 ops.mlp(N, ops.ktiles(T(h, H), T(node_in, kin)), [pa, pb], nl=1, ht=4, ot=4,
@@ -222,8 +227,11 @@ class MPNN(LightningModule):
                     stats = ops.instance_norm_stats(g, B, Ns)
                 h, g = g, h                                                 # h: raw update output + its statistics
                 continue
-            ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
-                    act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g)
+            if small_nodes:
+                ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g)
+            else:
+                ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
+                        act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g)
             if tape is None:
                 ops.instance_norm(g, B, Ns, out=h)
             else:
