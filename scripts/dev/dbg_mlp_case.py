@@ -22,7 +22,7 @@ with torch.no_grad():
     pre = r_
     ref = norm.double().cpu()(r_)
 print("pre-LN row std: min", float(pre.std(1).min()), "median", float(pre.std(1).median()), " |mean|/std max", float((pre.mean(1).abs() / pre.std(1)).max()))
-for rep in range(100):
+for rep in range(200):
     y = torch.full((M, out), float("nan"), device="cuda")
     run_mlp(M, ops.ktiles(ops.Term(x.cuda(), kp)), pk, y)
     err = (y.double().cpu() - ref)
