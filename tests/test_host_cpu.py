@@ -225,3 +225,14 @@ def test_product_library_has_no_development_knobs():
 def test_factory_lists_all_five_models():
     from magnet_amd.models.factory import FACTORY
     assert sorted(FACTORY) == ["magnet_cnn", "magnet_cnn_2d", "magnet_gnn", "mpnn", "mpnn_2d"]
+
+
+def test_large_graph_node_kernel_gate():
+    """host-side gate of the persistent node kernels (models/mpnn.py `fused_nodes`): shapes outside it take the generic launches"""
+    from magnet_amd import ops
+    assert ops.node_halves_supported(32, 4, 65536) and ops.node_halves_supported(64, 8, 2304)
+    assert not ops.node_halves_supported(96, 4, 65536)          # kin: only 32 / 64 have resident-weight kernels
+    assert not ops.node_halves_supported(32, 9, 65536)          # statistics of at most 8 graphs fit the kernels' LDS table
+    assert not ops.node_halves_supported(32, 4, 2050)           # graph boundaries must fall on 32-row tiles
+    assert not ops.node_halves_supported(32, 4, 65536, h=64)
+    assert ops.NORM_SMALL_ROWS == 2048
