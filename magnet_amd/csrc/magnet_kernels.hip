@@ -92,13 +92,20 @@ __device__ __forceinline__ int nearest_cell(float c, int W) {
     u = fminf((float)(W - 1), fmaxf(u, 0.f));
     return (int)rintf(u);                                         // round half to even == nearbyint
 }
+// Rows written 16 bytes per lane, lanes along the row: thread = (row (r, i), column quad); the per-(query, shift) values are recomputed by
+// the 8 T threads that share them (a few flops) - one thread per (query, shift) writing T x 128 contiguous bytes at a 128-byte lane stride
+// (64 partially written lines per store instruction) took 238 us at 256^2 queries.
 __global__ void k_inr_grid_prepare(const float* __restrict__ coords, const float* __restrict__ cell,
                                    const float* __restrict__ x_t, const float* __restrict__ t, int t_ld, int B,
                                    int Nq, int T, int W, int d, int32_t* __restrict__ cell_idx,
                                    float* __restrict__ tail, float* __restrict__ area) {
     const int S = d == 2 ? 4 : 2;
-    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;   // r = (b*Nq + q)*S + s
-    if (r >= (long)B * Nq * S) return;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;  // gid = ((r * T) + i) * 8 + quad, r = (b*Nq + q)*S + s
+    const int quad = (int)(gid & 7);
+    const long row = gid >> 3;
+    if (row >= (long)B * Nq * S * T) return;
+    const int i = (int)(row % T);
+    const long r = row / T;
     const int s = (int)(r % S);
     const long bq = r / S;
     const int b = (int)(bq / Nq);
@@ -118,16 +125,20 @@ __global__ void k_inr_grid_prepare(const float* __restrict__ coords, const float
         cw[a] = cell[bq * d + a] * (float)W;
     }
     const long flat = d == 2 ? (long)idx[0] * W + idx[1] : idx[0];
-    area[r] = d == 2 ? fabsf(rel[0] * rel[1]) + 1e-9f : fabsf(rel[0]);
-    for (int i = 0; i < T; ++i) {
-        const long row = r * T + i;
-        cell_idx[row] = (int32_t)((long)b * cells + flat);
-        float* o = tail + row * 32;
-        o[0] = x_t[((size_t)b * T + i) * cells + flat];
-        for (int a = 0; a < d; ++a) { o[1 + a] = rel[a]; o[1 + d + a] = cw[a]; }
-        o[1 + 2 * d] = t[(size_t)b * t_ld + i];
-        for (int c = 2 + 2 * d; c < 32; ++c) o[c] = 0.f;
+    if (quad == 0 && i == 0) area[r] = d == 2 ? fabsf(rel[0] * rel[1]) + 1e-9f : fabsf(rel[0]);
+    if (quad == 0) cell_idx[row] = (int32_t)((long)b * cells + flat);
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * quad + k;
+        float v = 0.f;
+        if (c == 0) v = x_t[((size_t)b * T + i) * cells + flat];
+        else if (c <= d) v = rel[c - 1];
+        else if (c <= 2 * d) v = cw[c - 1 - d];
+        else if (c == 1 + 2 * d) v = t[(size_t)b * t_ld + i];
+        o[k] = v;
     }
+    *reinterpret_cast<f32x4*>(tail + row * 32 + 4 * quad) = o;
 }
 
 // z[(bq, i)][c] = sum_s p[((bq*S + s)*T + i)][c] * area[bq*S + opposite(s)] / sum_s area   (2D)
@@ -153,6 +164,33 @@ __global__ void k_inr_grid_blend(const float* __restrict__ p, const float* __res
         r = r + p[((bq * 4 + 3) * T + ti) * C + c] * (a0 / tot);
         z[i] = r;
     }
+}
+// the 2-D blend with C % 4 == 0: one thread per (query, time step, 4 channels) - the four weights (one division each) are computed
+// once per thread instead of once per element, 16-byte loads and stores; the arithmetic per element is the expression above, bit for bit
+__global__ void k_inr_grid_blend4(const float* __restrict__ p, const float* __restrict__ area, int T, int C4, long total4,
+                                  float* __restrict__ z) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const int c = (int)(i % C4);
+    const int ti = (int)((i / C4) % T);
+    const long bq = i / ((long)C4 * T);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(area + bq * 4);
+    const float tot = ((a[0] + a[1]) + a[2]) + a[3];
+    const float w0 = a[3] / tot, w1 = a[2] / tot, w2 = a[1] / tot, w3 = a[0] / tot;
+    const f32x4* pp = reinterpret_cast<const f32x4*>(p);
+    const f32x4 p0 = pp[((bq * 4 + 0) * T + ti) * C4 + c], p1 = pp[((bq * 4 + 1) * T + ti) * C4 + c];
+    const f32x4 p2 = pp[((bq * 4 + 2) * T + ti) * C4 + c], p3 = pp[((bq * 4 + 3) * T + ti) * C4 + c];
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = 0.f;
+        v = v + p0[k] * w0;
+        v = v + p1[k] * w1;
+        v = v + p2[k] * w2;
+        v = v + p3[k] * w3;
+        r[k] = v;
+    }
+    reinterpret_cast<f32x4*>(z)[i] = r;
 }
 
 // ------------------------------------------------------------------------------------ C entry points
@@ -212,7 +250,7 @@ extern "C" int magnet_inr_grid_prepare_f32(const float* coords, const float* cel
     if (d != 1 && d != 2) return -2;
     const long rows = (long)n_graphs * Nq * (d == 2 ? 4 : 2);
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(k_inr_grid_prepare, dim3(nb(rows, 256)), dim3(256), 0, S_, coords, cell, x_t, t, t_ld, n_graphs,
+    hipLaunchKernelGGL(k_inr_grid_prepare, dim3(nb(rows * T * 8, 256)), dim3(256), 0, S_, coords, cell, x_t, t, t_ld, n_graphs,
                        Nq, T, W, d, cell_idx, tail, area);
     LAUNCH_CHECK();
 }
@@ -223,7 +261,10 @@ extern "C" int magnet_inr_grid_blend_f32(const float* p, const float* area, int 
     const long total = (long)n_rows * T * C;
     if (total <= 0) return 0;
     if (nshift != 2 && nshift != 4) return -2;
-    hipLaunchKernelGGL(k_inr_grid_blend, dim3(nb(total, 256)), dim3(256), 0, S_, p, area, T, C, nshift, total, z);
+    if (nshift == 4 && C % 4 == 0)
+        hipLaunchKernelGGL(k_inr_grid_blend4, dim3(nb(total / 4, 256)), dim3(256), 0, S_, p, area, T, C / 4, total / 4, z);
+    else
+        hipLaunchKernelGGL(k_inr_grid_blend, dim3(nb(total, 256)), dim3(256), 0, S_, p, area, T, C, nshift, total, z);
     LAUNCH_CHECK();
 }
 
