@@ -84,6 +84,36 @@ __global__ void k_inr_knn_blend(const float* __restrict__ base, const float* __r
     z[i] = r;
 }
 
+// the same with C % 4 == 0: one thread per (query, time step, 4 channels), 16-byte loads and stores, the per-(query, step) scalars once per
+// thread; every element goes through the expression above, bit for bit (335 MB written per call at 256^2 queries: 307 -> see DESIGN.md 9.9)
+__global__ void k_inr_knn_blend4(const float* __restrict__ base, const float* __restrict__ w,
+                                 const float* __restrict__ vals, const int32_t* __restrict__ nn2,
+                                 const float* __restrict__ t, int t_ld, const float* __restrict__ wv,
+                                 const float* __restrict__ wt, int L, int Nq, int T, int C4, int mode, long total4,
+                                 float* __restrict__ z) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const int c = (int)(i % C4);
+    const int ti = (int)((i / C4) % T);
+    const long q = i / ((long)C4 * T);
+    const int b = (int)(q / Nq);
+    const float tt = t[(size_t)b * t_ld + ti];
+    const float v0 = vals[(size_t)nn2[2 * q] * T + ti], v1 = vals[(size_t)nn2[2 * q + 1] * T + ti];
+    const f32x4 b0 = reinterpret_cast<const f32x4*>(base)[(2 * q) * C4 + c], b1 = reinterpret_cast<const f32x4*>(base)[(2 * q + 1) * C4 + c];
+    const f32x4 wv4 = reinterpret_cast<const f32x4*>(wv)[c], wt4 = reinterpret_cast<const f32x4*>(wt)[c];
+    float w0 = w[2 * q], w1 = w[2 * q + 1];
+    if (mode == 1) { w0 = 1.f / w0; w1 = 1.f / w1; }
+    else if (mode == 2) { const float a = 1.f - L * w0, bb = 1.f - L * w1; w0 = a * a * a; w1 = bb * bb * bb; }
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float l0 = b0[k] + wv4[k] * v0 + wt4[k] * tt;
+        const float l1 = b1[k] + wv4[k] * v1 + wt4[k] * tt;
+        r[k] = mode == 0 ? (l0 * w1 + l1 * w0) / (w1 + w0) : (l0 * w0 + l1 * w1) / (w1 + w0);
+    }
+    reinterpret_cast<f32x4*>(z)[i] = r;
+}
+
 // ---- grid INR (models/magnet_cnn.py:249-276, models/magnet_cnn_2d.py:248-283): per query and
 // shift: nearest cell (grid_sample nearest / border / align_corners=False), rel, cell*W, area,
 // and per input step the tail [q_inp_i | rel | cell*W | t_i | 0-pad] + the gather row index.
@@ -238,8 +268,12 @@ extern "C" int magnet_inr_knn_blend_f32(const float* base, const float* w, const
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     const long total = (long)n_graphs * Nq * T * C;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_inr_knn_blend, dim3(nb(total, 256)), dim3(256), 0, S_, base, w, vals, nn2, t, t_ld, wv, wt, L,
-                       Nq, T, C, mode, total, z);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL(k_inr_knn_blend4, dim3(nb(total / 4, 256)), dim3(256), 0, S_, base, w, vals, nn2, t, t_ld, wv, wt, L,
+                           Nq, T, C / 4, mode, total / 4, z);
+    else
+        hipLaunchKernelGGL(k_inr_knn_blend, dim3(nb(total, 256)), dim3(256), 0, S_, base, w, vals, nn2, t, t_ld, wv, wt, L,
+                           Nq, T, C, mode, total, z);
     LAUNCH_CHECK();
 }
 
