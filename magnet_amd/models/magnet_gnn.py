@@ -125,14 +125,23 @@ class MAgNetGNN(MagnetBase):
         nf, topo = self._build_graph(u, lr_coords, t[:, :T], key=self._tkey("lr", lr_coords))
         enc = self._graph_net(pk.graph1, nf, topo, D)
         # INR decoder (continuous_decoder, magnet_gnn.py:224-283)
-        flr, fhr = topo.flat, ops._f32(hr_coords.reshape(B * Nq, d))
-        nn_idx = ops.knn(flr, ops.graph_ptr(B, Lr, dev), fhr, ops.graph_ptr(B, Nq, dev), self.codec_neighbors)
         M2 = 2 * B * Nq
-        nn2 = torch.empty(M2, dtype=torch.int32, device=dev)
-        rel = torch.empty(M2, 32, device=dev, dtype=torch.float32)
-        w = torch.empty(M2, device=dev, dtype=torch.float32)
-        L.check(L.lib().magnet_inr_knn_prepare_f32(ops._p(flr), ops._p(fhr), ops._p(nn_idx), self.codec_neighbors, d, B,
-                                                   Lr, Nq, ops._p(nn2), ops._p(rel), ops._p(w), ops._stream()), "inr_knn_prepare")
+
+        def build_inr():
+            # k nearest LR nodes of every query + their relative coordinates and blend weights: a function of the coordinates alone
+            flr, fhr = topo.flat, ops._f32(hr_coords.reshape(B * Nq, d))
+            nn_idx = ops.knn(flr, ops.graph_ptr(B, Lr, dev), fhr, ops.graph_ptr(B, Nq, dev), self.codec_neighbors)
+            nn2_ = torch.empty(M2, dtype=torch.int32, device=dev)
+            rel_ = torch.empty(M2, 32, device=dev, dtype=torch.float32)
+            w_ = torch.empty(M2, device=dev, dtype=torch.float32)
+            L.check(L.lib().magnet_inr_knn_prepare_f32(ops._p(flr), ops._p(fhr), ops._p(nn_idx), self.codec_neighbors, d, B,
+                                                       Lr, Nq, ops._p(nn2_), ops._p(rel_), ops._p(w_), ops._stream()), "inr_knn_prepare")
+            return types.SimpleNamespace(nn2=nn2_, rel=rel_, w=w_)
+
+        # cached with the topology (same cache, same identity / content rules): a free-running rollout decodes at the same queries in
+        # every one of its forward calls
+        inr = self._topo_cache.get(("inr", (self.codec_neighbors, B, Lr, Nq)), (lr_coords, hr_coords), build_inr)
+        nn2, rel, w = inr.nn2, inr.rel, inr.w
         base = torch.empty(M2, Cn, device=dev, dtype=torch.float32)
         ot = Cn // 32
         ops.mlp(M2, ops.ktiles(ops.Term(enc, D, idx=nn2), ops.Term(rel, 32)), [pk.proj_base], nl=1, ht=ot, ot=ot,
