@@ -796,6 +796,109 @@ extern "C" int magnet_mpnn_node_update_f32(const float* h, const float* agg, con
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------- EDSR convolution on a small grid, weights resident
+// y[p][cg*32 ..] = act(sum_taps W_tap . fmap[tap_idx[tap][p]] + b) (+ res[p]) for one 32-column group of a k x k "same" convolution
+// over a channels-last map (models/backbones/edsr.py:32-60; the gathered-tap GEMM of magnet_conv_tap_index).  On the LR grid of the
+// MAgNet[CNN] configs (64 x 64 pixels) the generic launch is 128 workgroups that each stream 36 weight chunks behind a barrier with one
+// k tile of gathered-source lead: 37 us per convolution, all latency, 150 convolutions per C4b rollout.  Here a workgroup of two waves
+// (64 pixels) keeps its column group's planes (K x 32 columns: 144 KiB at K = 1152) in LDS after ONE burst, the waves are independent,
+// and each keeps RING k tiles of gathered rows in flight.
+struct ConvResidentArgs {
+    const float* fmap;         // [P + 1][width] channels-last rows, row P all zero (padding)
+    const int32_t* tap;        // [ntaps][P] neighbour row of every pixel per tap
+    const f32x4* w[4];         // per column group: fp16 planes [nkt][1][2][2][64] x 16 B
+    const float* b[4];
+    const float* res;          // [P + 1][ldy] or nullptr
+    float* y;                  // [P + 1][ldy]
+    int P, width, ntaps, ldy, relu;
+};
+template <int NKT, int TPT /* k tiles per tap = width / 32 */>
+__global__ void __launch_bounds__(128, 1) k_conv_resident(ConvResidentArgs a) {
+    constexpr int MODE = GEMM_FP16X3;
+    constexpr int RING = 9;                                           // k tiles of gathered rows in flight per wave (NKT % RING == 0)
+    static_assert(NKT % RING == 0, "ring");
+    __shared__ __attribute__((aligned(16))) u32x4 wl[NKT * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    const int cg = blockIdx.y;
+    const int row = (blockIdx.x * 2 + wave) * 32 + j;
+    const int rowc = row < a.P ? row : a.P - 1;
+    // this lane's gathered row per tap (requested first: the addresses of everything below depend on them)
+    int trow[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) trow[t] = t < a.ntaps ? a.tap[(size_t)t * a.P + rowc] : a.P;
+    {
+        const u32x4* g = reinterpret_cast<const u32x4*>(a.w[cg]);
+        constexpr int NQ = NKT * 256 / 128;                            // 16-byte pieces per thread
+        constexpr int BATCH = NQ < 72 ? NQ : 72;
+#pragma unroll
+        for (int q0 = 0; q0 < NQ; q0 += BATCH) {
+            u32x4 wv[BATCH];
+#pragma unroll
+            for (int q = 0; q < BATCH; ++q) wv[q] = g[(q0 + q) * 128 + threadIdx.x];
+#pragma unroll
+            for (int q = 0; q < BATCH; ++q) wl[(q0 + q) * 128 + threadIdx.x] = wv[q];
+        }
+    }
+    f32x4 xr[RING][4];
+    auto request = [&](int kt, int slot) {                            // (kt is a compile-time value at every call: static tap index)
+        const int t = kt / TPT, cb = kt - t * TPT;
+        const float* p = a.fmap + (size_t)trow[t] * (TPT * 32) + cb * 32 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xr[slot][g] = *reinterpret_cast<const f32x4*>(p + 8 * g);
+    };
+#pragma unroll
+    for (int s = 0; s < RING; ++s) request(s, s);
+    f32x16 acc[1], accc[1];
+    init_bias<1>(acc, a.b[cg], half);
+    zero_tiles<1>(accc);
+    __syncthreads();                                                  // the planes are in LDS
+#pragma unroll
+    for (int k0 = 0; k0 < NKT; k0 += RING) {
+#pragma unroll
+        for (int s = 0; s < RING; ++s) {
+            f32x16 x;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[4 * g + c] = xr[s][g][c];
+            mma_chunk<1, MODE, false>(x, acc, accc, wl + (k0 + s) * 256, lane);
+            if (k0 + s + RING < NKT) request(k0 + s + RING, s);
+        }
+    }
+    fold_tiles<1, MODE>(acc, accc);
+    if (a.relu) apply_act<ACT_RELU>(acc[0]);
+    if (row < a.P) {
+        float* yo = a.y + (size_t)row * a.ldy + cg * 32 + 4 * half;
+        const float* ro = a.res ? a.res + (size_t)row * a.ldy + cg * 32 + 4 * half : nullptr;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o = {acc[0][4 * g], acc[0][4 * g + 1], acc[0][4 * g + 2], acc[0][4 * g + 3]};
+            if (ro) o += *reinterpret_cast<const f32x4*>(ro + 8 * g);
+            *reinterpret_cast<f32x4*>(yo + 8 * g) = o;
+        }
+    }
+}
+
+// One k x k convolution (ntaps <= 9 gathered taps of `width` in {32, 128} channels each) into ncg <= 4 column groups of 32 output
+// channels: y[:, 32 g .. 32 g + 32) for g < ncg.  w[g] / b[g]: the per-column-group fp16x3 packs the generic launch takes
+// (magnet_amd/models/backbones/edsr.py).  Returns -2 for shapes outside this kernel (the caller then uses magnet_mlp_fp16x3_f32).
+extern "C" int magnet_conv_resident_f32(const float* fmap, int width, const int32_t* tap, int ntaps, int P, const void* const* w,
+                                        const float* const* b, int ncg, int relu, const float* res, float* y, int ldy, void* stream) {
+    (void)hipGetLastError();
+    if (P <= 0) return 0;
+    const int nkt = ntaps * (width / 32);
+    if ((width != 32 && width != 128) || ntaps < 1 || ntaps > 9 || ncg < 1 || ncg > 4 || (nkt != 9 && nkt != 36)) return -2;
+    ConvResidentArgs a;
+    a.fmap = fmap, a.tap = tap, a.res = res, a.y = y, a.P = P, a.width = width, a.ntaps = ntaps, a.ldy = ldy, a.relu = relu;
+    for (int g = 0; g < ncg; ++g) a.w[g] = reinterpret_cast<const f32x4*>(w[g]), a.b[g] = b[g];
+    const dim3 grid((P + 63) / 64, ncg), block(128);
+    if (ntaps != 9) return -2;                                        // (3 x 3 only: the tap index of a k tile is compile-time)
+    if (width == 32) hipLaunchKernelGGL((k_conv_resident<9, 1>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_conv_resident<36, 4>), grid, block, 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
 extern "C" int magnet_mlp_bf16x6_f32(const MagnetMlpArgs* args, int nl, int ht, int ot, int act, int last_act, int ln,
                                      int epi, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)

@@ -49,6 +49,7 @@ class EDSR(nn.Module):
         if (kernel_size ** self.dim) * (n_chan // 32) > 36 or not kernel_size & 1:
             raise NotImplementedError("odd kernel sizes with k^d * n_chan / 32 <= 36 k tiles are supported")
         self._pack_key, self._pack, self._pack_gen, self._taps = None, None, 0, {}
+        self.resident_conv = __import__("os").environ.get("MAGNET_RESIDENT_CONV", "1") != "0"      # A/B knob
         self._plan_key, self._plan_val = None, None
 
     # ------------------------------------------------------------------ packed weights / tap tables (cached)
@@ -107,7 +108,10 @@ class EDSR(nn.Module):
             kts = ops.ktiles(*[ops.Term(src, width, idx=taps[t]) for t in range(taps.shape[0])])
             kw = dict(nl=1, act=ops.ACT_RELU if relu else ops.ACT_NONE, last_act=relu,
                       epi=ops.EPI_STORE_RES if res is not None else ops.EPI_STORE, res=res, y=dst, ldy=C)
-            if split:
+            fast = ops.conv_resident_plan(src, width, taps, layer[1], relu, res, dst, C) if split and self.resident_conv else None
+            if fast is not None:               # small map, 3 x 3, fp16x3: the column group's planes resident in LDS
+                launches.append(fast)
+            elif split:
                 launches.append(ops.mlp_plan(P, kts, layer[1], ht=1, ot=1, ncols=32, colgroups=ot, **kw))
             else:
                 launches.append(ops.mlp_plan(P, kts, [layer[0]], ht=ot, ot=ot, **kw))

@@ -344,6 +344,23 @@ def mpnn_node_update(h, agg, node_in, upd1, upd2, y, stats=None, rows_per_graph=
     return mv[0], mv[1]
 
 
+def conv_resident_plan(fmap, width, taps, packs, relu, res, y, ldy):
+    """prebuilt launch of magnet_conv_resident_f32 (EDSR 3 x 3 convolution on a small map, weights resident in LDS) or None when the
+    shape is outside that kernel; ``packs``: per 32-column group (fp16x3 planes, bias)"""
+    ncg, ntaps, P = len(packs), taps.shape[0], taps.shape[1]
+    if width not in (32, 128) or ntaps != 9 or not 1 <= ncg <= 4 or packs[0][0].dtype != torch.float16:
+        return None
+    wp = (C.c_void_p * ncg)(*[w.data_ptr() for w, _ in packs])
+    bp = (C.c_void_p * ncg)(*[b.data_ptr() for _, b in packs])
+    keep = (fmap, taps, packs, res, y)
+    fn = L.lib().magnet_conv_resident_f32
+    args = (_p(fmap), int(width), _p(taps), int(ntaps), int(P), wp, bp, ncg, int(bool(relu)), _p(res), _p(y), int(ldy))
+
+    def go(_keep=keep):
+        L.check(fn(*args, _stream()), "conv_resident")
+    return go
+
+
 def resize_linear(x, out_hw, d):
     """x [n, Hi, Wi] (d = 2) or [n, Wi] (d = 1) -> [n, Ho, Wo] / [n, Wo], F.interpolate(..., align_corners=False)"""
     x = _f32(x, "resize source")

@@ -582,3 +582,22 @@ def test_readout_line_kernel_with_instance_norm_on_load(tw, dim, n, n_graphs):
     assert rel_l2(got, want) < 2e-6
     small = ops.mpnn_readout(hx.float().cuda()[:100].contiguous(), uc[:100].contiguous(), tw, *args)     # n < 8192: wave-per-node kernel
     assert rel_l2(small, want[:100]) < 2e-6
+
+
+def test_resident_convolution_equals_the_streamed_launch_and_is_deterministic(monkeypatch):
+    """magnet_conv_resident_f32 (3 x 3 EDSR convolution on a small map, the column group's planes resident in LDS) against the generic
+    gathered-tap launch on the same packs (MAGNET_RESIDENT_CONV=0) and against itself over 30 launches, ragged pixel count included"""
+    from magnet_amd.models.backbones.edsr import EDSR
+    torch.manual_seed(3)
+    x = torch.randn(2, 5, 37, 29).cuda()                          # 2 x 1 073 pixels: not a multiple of 64
+    outs = []
+    for knob in ("1", "0"):
+        monkeypatch.setenv("MAGNET_RESIDENT_CONV", knob)
+        torch.manual_seed(4)
+        net = EDSR(5, 128, 3, 3, 1, "2d").cuda()
+        assert net.resident_conv == (knob == "1")
+        outs.append(net.rows(x).clone())
+        if knob == "1":
+            for _ in range(30):
+                assert torch.equal(net.rows(x), outs[0])
+    assert rel_l2(outs[0], outs[1]) < 5e-7
