@@ -183,7 +183,7 @@ int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const
 int magnet_mpnn_readout_norm_f32(const float* h, const float* mean, const float* var, float eps, int n_graphs, int rows_per_graph,
                                  const float* u, int n, int tw, const float* w1, const float* b1, int k1, int s1, const float* w2,
                                  const float* b2, int k2, int use_swish, const float* dt, float* out, void* stream);
-/* One 3 x 3 "same" convolution of EDSR (models/backbones/edsr.py:32-60: nn.Conv2d + ReLU / + skip) on a SMALL channels-last map as a
+/* One 3 x 3 (tap [9][P]) or k = 3 (tap [3][P]) "same" convolution of EDSR (models/backbones/edsr.py:32-60: conv + ReLU / + skip) on a SMALL channels-last map as a
  * gathered-tap GEMM with the weights resident in LDS: y[p][32 g .. 32 g + 32) = act(sum_t W_t fmap[tap[t][p]] + b) (+ res[p]) for the
  * ncg <= 4 column groups g.  fmap [P + 1][width] (row P all zero: the padding), width in {32, 128}, tap [9][P] from
  * magnet_conv_tap_index, w[g] / b[g] the fp16x3 packs of rows 32 g .. 32 g + 32 of the [Co][9 * width] weight

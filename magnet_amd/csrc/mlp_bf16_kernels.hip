@@ -812,10 +812,9 @@ struct ConvResidentArgs {
     float* y;                  // [P + 1][ldy]
     int P, width, ntaps, ldy, relu;
 };
-template <int NKT, int TPT /* k tiles per tap = width / 32 */>
+template <int NKT, int TPT /* k tiles per tap = width / 32 */, int RING /* k tiles of gathered rows in flight per wave */>
 __global__ void __launch_bounds__(128, 1) k_conv_resident(ConvResidentArgs a) {
     constexpr int MODE = GEMM_FP16X3;
-    constexpr int RING = 9;                                           // k tiles of gathered rows in flight per wave (NKT % RING == 0)
     static_assert(NKT % RING == 0, "ring");
     __shared__ __attribute__((aligned(16))) u32x4 wl[NKT * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -887,15 +886,17 @@ extern "C" int magnet_conv_resident_f32(const float* fmap, int width, const int3
                                         const float* const* b, int ncg, int relu, const float* res, float* y, int ldy, void* stream) {
     (void)hipGetLastError();
     if (P <= 0) return 0;
-    const int nkt = ntaps * (width / 32);
-    if ((width != 32 && width != 128) || ntaps < 1 || ntaps > 9 || ncg < 1 || ncg > 4 || (nkt != 9 && nkt != 36)) return -2;
+    if ((width != 32 && width != 128) || (ntaps != 9 && ntaps != 3) || ncg < 1 || ncg > 4) return -2;
     ConvResidentArgs a;
     a.fmap = fmap, a.tap = tap, a.res = res, a.y = y, a.P = P, a.width = width, a.ntaps = ntaps, a.ldy = ldy, a.relu = relu;
     for (int g = 0; g < ncg; ++g) a.w[g] = reinterpret_cast<const f32x4*>(w[g]), a.b[g] = b[g];
     const dim3 grid((P + 63) / 64, ncg), block(128);
-    if (ntaps != 9) return -2;                                        // (3 x 3 only: the tap index of a k tile is compile-time)
-    if (width == 32) hipLaunchKernelGGL((k_conv_resident<9, 1>), grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_conv_resident<36, 4>), grid, block, 0, (hipStream_t)stream, a);
+    // (the tap index of a k tile is compile-time: 3 x 3 in 2-D, k = 3 in 1-D)
+    if (ntaps == 9 && width == 32) hipLaunchKernelGGL((k_conv_resident<9, 1, 9>), grid, block, 0, (hipStream_t)stream, a);
+    else if (ntaps == 9) hipLaunchKernelGGL((k_conv_resident<36, 4, 9>), grid, block, 0, (hipStream_t)stream, a);
+    else if (ntaps == 3 && width == 32) hipLaunchKernelGGL((k_conv_resident<3, 1, 3>), grid, block, 0, (hipStream_t)stream, a);
+    else if (ntaps == 3) hipLaunchKernelGGL((k_conv_resident<12, 4, 6>), grid, block, 0, (hipStream_t)stream, a);
+    else return -2;
     return (int)hipGetLastError();
 }
 

@@ -348,7 +348,7 @@ def conv_resident_plan(fmap, width, taps, packs, relu, res, y, ldy):
     """prebuilt launch of magnet_conv_resident_f32 (EDSR 3 x 3 convolution on a small map, weights resident in LDS) or None when the
     shape is outside that kernel; ``packs``: per 32-column group (fp16x3 planes, bias)"""
     ncg, ntaps, P = len(packs), taps.shape[0], taps.shape[1]
-    if width not in (32, 128) or ntaps != 9 or not 1 <= ncg <= 4 or packs[0][0].dtype != torch.float16:
+    if width not in (32, 128) or ntaps not in (3, 9) or not 1 <= ncg <= 4 or packs[0][0].dtype != torch.float16:
         return None
     wp = (C.c_void_p * ncg)(*[w.data_ptr() for w, _ in packs])
     bp = (C.c_void_p * ncg)(*[b.data_ptr() for _, b in packs])
