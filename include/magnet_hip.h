@@ -203,7 +203,8 @@ int magnet_instance_norm_stats_f32(const float* x, int n_graphs, int rows_per_gr
  * previous hop (models/mpnn.py:70 `x = self.norm(x, batch)`):
  *   hn = mean ? (h - mean[g]) / sqrt(var[g] + eps) : h      (g = row / rows_per_graph)
  *   A  = Wa [hn | node_in] + ba,   Bm = Wb [hn | node_in] + bb,   h_norm = hn (if mean and h_norm)
- * h [n][128], node_in [n][kin], kin in {32, 64}; wa / wb: fp16x3 planes of the two [128][128 + kin] weight halves in the layout
+ * h [n][128], node_in [n][kin], kin in {0, 32, 64} (0: no node_in, the halves are Linears over h alone - MAgNet's InteractionNetwork,
+ * models/magnet_gnn.py:76-90 factored per node); wa / wb: fp16x3 planes of the two [128][128 + kin] weight halves in the layout
  * magnet_mlp_fp16x3_f32 takes (magnet_amd/packing.py:pack_linear_fp16x2).  Returns -2 for an unsupported shape (kin, more than
  * 8 graphs, rows_per_graph not a multiple of 32): the caller then uses magnet_instance_norm_f32 + magnet_mlp_fp16x3_f32. */
 /* GNN_Layer.update (models/mpnn.py:81-90), residual branch, as ONE persistent launch for large graphs, optionally fused with the

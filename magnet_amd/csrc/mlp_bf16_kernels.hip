@@ -523,7 +523,7 @@ extern "C" int magnet_mpnn_node_halves_f32(const float* h, const float* node_in,
                                            float* h_norm, void* stream) {
     (void)hipGetLastError();
     if (n_rows <= 0) return 0;
-    if (kin != 32 && kin != 64) return -2;
+    if (kin != 0 && kin != 32 && kin != 64) return -2;              // kin = 0: x = h alone (MAgNet InteractionNetwork's per-node halves)
     if (mean && (n_graphs > NH_MAX_GRAPHS || n_graphs < 1 || rows_per_graph % 32 || !var)) return -2;
     NodeHalvesArgs a;
     a.h = h, a.node_in = node_in, a.mean = mean, a.var = var;
@@ -543,7 +543,8 @@ extern "C" int magnet_mpnn_node_halves_f32(const float* h, const float* node_in,
     int grid = (int)(pairs * 2 < ncu ? pairs * 2 : ncu);
     grid = (grid + 15) / 16 * 16;                                    // whole (XCD, slot pair) blocks
     hipStream_t s = (hipStream_t)stream;
-    if (kin == 32) hipLaunchKernelGGL(k_node_halves<5>, dim3(grid), dim3(NH_WAVES * 64), 0, s, a);
+    if (kin == 0) hipLaunchKernelGGL(k_node_halves<4>, dim3(grid), dim3(NH_WAVES * 64), 0, s, a);
+    else if (kin == 32) hipLaunchKernelGGL(k_node_halves<5>, dim3(grid), dim3(NH_WAVES * 64), 0, s, a);
     else hipLaunchKernelGGL(k_node_halves<6>, dim3(grid), dim3(NH_WAVES * 64), 0, s, a);
     return (int)hipGetLastError();
 }

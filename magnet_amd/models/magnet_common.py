@@ -10,6 +10,7 @@ found neighbour, not at the query (Q3, Q11); node k gets the time of sample k mo
 """
 from __future__ import annotations
 
+import os
 import types
 
 import torch
@@ -213,14 +214,19 @@ class MagnetBase(LightningModule):
         # concatenated form - measured: C5 edge chain 1.55 -> 1.21 ms, C4b 0.38 -> 0.39 ms)
         Hm = pk.hops[0].edge.ht * 32 if pk.hops else 0
         factored = 0 < Hm <= D
+        resident_halves = (factored and D == 128 and Hm == 128 and pk.hops[0].pre_i[0].dtype == torch.float16       # (fp16x3 planes)
+                           and os.environ.get("MAGNET_FUSED_HALVES", "1") != "0")
         if factored:
             PQ = torch.empty(2, N, Hm, device=dev, dtype=torch.float32)   # per-node halves of the edge chains' first Linear
         for k, hop in enumerate(pk.hops):
             if factored:
                 # P = W0a x, Q = W0b x in one launch (two column groups run back to back inside each workgroup), then the
                 # chain over e_k = 2^k e_0 (Q2) alone
-                ops.mlp(N, ops.ktiles(T_(x, D)), [hop.pre_i, hop.pre_j], nl=1, ht=Hm // 32, ot=Hm // 32, act=ops.ACT_NONE, y=PQ, ldy=Hm,
-                        colgroups=2, groups_in_block=True, y_group_stride=N * Hm)
+                if resident_halves:        # 128 -> 128 + 128, fp16x3: the MPNN per-node-halves kernel (weights resident in LDS), kin = 0
+                    ops.mpnn_node_halves(x, None, hop.pre_i, hop.pre_j, PQ[0], PQ[1])
+                else:
+                    ops.mlp(N, ops.ktiles(T_(x, D)), [hop.pre_i, hop.pre_j], nl=1, ht=Hm // 32, ot=Hm // 32, act=ops.ACT_NONE, y=PQ,
+                            ldy=Hm, colgroups=2, groups_in_block=True, y_group_stride=N * Hm)
                 run_mlp(E, ops.ktiles(T_(e0, D)), hop.edge_f, agg, epi=ops.EPI_SEGMEAN, tgt=csr.tgt,
                         rowptr=csr.rowptr, partials=partials, pre=[(PQ[0], csr.tgt), (PQ[1], csr.src)])
             else:

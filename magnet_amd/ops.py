@@ -312,7 +312,7 @@ def node_halves_supported(kin, n_graphs, rows_per_graph, h=128):
 def mpnn_node_halves(h, node_in, pre_a, pre_b, A, Bm, stats=None, rows_per_graph=0, eps=1e-5, h_norm=None):
     """A = Wa [hn | node_in] + ba, Bm = Wb [hn | node_in] (+ bb) with hn = InstanceNorm-applied h when ``stats`` = (mean, var)
     is given (then hn is also written to ``h_norm``).  pre_a / pre_b: (fp16x3 planes, padded bias) of ``packing.pack``."""
-    n, kin = h.shape[0], node_in.shape[1]
+    n, kin = h.shape[0], (node_in.shape[1] if node_in is not None else 0)
     mean, var = stats if stats is not None else (None, None)
     ng = mean.shape[0] if mean is not None else 0
     L.check(L.lib().magnet_mpnn_node_halves_f32(_p(h), _p(node_in), kin, C.c_long(n), _p(mean), _p(var), C.c_float(float(eps)), ng,
