@@ -32,7 +32,9 @@ extern "C" {
 #define MAGNET_MAX_LAYERS 6
 enum { MAGNET_ACT_NONE = 0, MAGNET_ACT_SWISH = 1, MAGNET_ACT_RELU = 2 };
 enum { MAGNET_EPI_STORE = 0, MAGNET_EPI_STORE_RES = 1, MAGNET_EPI_SEGMEAN = 2,
-       MAGNET_EPI_STORE_MASK = 3 /* nl == 1: y = res > 0 ? x W^T : 0 - a backward-data GEMM with the ReLU mask of the layer below */ };
+       MAGNET_EPI_STORE_MASK = 3 /* nl == 1: y = res > 0 ? x W^T : 0 - a backward-data GEMM with the ReLU mask of the layer below */,
+       MAGNET_EPI_QUADBLEND = 4 /* y[r / 4] = sum of res[row] * mlp(x)[row] over the rows 4 (r / 4) .. + 3 (res: [M] weights, M % 4 == 0):
+                                   the area blend of the 2-D grid INR decoder, models/magnet_cnn_2d.py:285-290; split-GEMM kernels only */ };
 
 /* One source feeding a 32-wide k tile of the first Linear's input:
  *   value[row][k] = scale * p[(idx ? idx[row] : row / rdiv) * ld + col + k],  k = 0..31
@@ -251,6 +253,11 @@ int magnet_pairs_to_edge_index(const int32_t* row0, const int32_t* row1, int n_e
 int magnet_knn_f32(const float* x, const int32_t* x_ptr, const float* y, const int32_t* y_ptr, int n_graphs, int dim,
                    int n_queries, int k, int32_t* out, void* stream);
 
+/* magnet_inr_grid_prepare_f32 for d = 2 in the row order the fused blend epilogue needs (MAGNET_EPI_QUADBLEND): the four shifts of a
+ * (query, step) are consecutive rows, row = ((b Nq + q) T + i) 4 + s; blend_w[row] = area[opposite shift] / (sum of the four areas)
+ * (models/magnet_cnn_2d.py:248-290).  cell_idx / blend_w [B Nq T 4], tail [B Nq T 4][32]. */
+int magnet_inr_grid_prepare_blend_f32(const float* coords, const float* cell, const float* x_t, const float* t, int t_ld, int n_graphs,
+                                      int Nq, int T, int W, int32_t* cell_idx, float* tail, float* blend_w, void* stream);
 /* ---- MAgNet feature builders / INR decoders (magnet_kernels.hip) ---- */
 int magnet_node_features_f32(const float* u, const float* x, const float* t_last, int n_graphs, int nodes_per_graph,
                              int T, int d, int ld, float* out, void* stream);

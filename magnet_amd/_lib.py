@@ -20,7 +20,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "magnet_hip.h")
 
 MAX_KT, MAX_LAYERS = 36, 6
 ACT_NONE, ACT_SWISH, ACT_RELU = 0, 1, 2
-EPI_STORE, EPI_STORE_RES, EPI_SEGMEAN, EPI_STORE_MASK = 0, 1, 2, 3
+EPI_STORE, EPI_STORE_RES, EPI_SEGMEAN, EPI_STORE_MASK, EPI_QUADBLEND = 0, 1, 2, 3, 4
 
 
 class Src(C.Structure):

@@ -26,7 +26,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
-enum { EPI_STORE = 0, EPI_STORE_RES = 1, EPI_SEGMEAN = 2, EPI_STORE_MASK = 3 };   // MASK: y = res > 0 ? mlp(x) : 0 (ReLU backward)
+enum { EPI_STORE = 0, EPI_STORE_RES = 1, EPI_SEGMEAN = 2, EPI_STORE_MASK = 3,   // MASK: y = res > 0 ? mlp(x) : 0 (ReLU backward)
+       EPI_QUADBLEND = 4 };   // y[r / 4] = sum over the 4 consecutive rows 4 (r / 4) .. + 3 of res[row] * mlp(x)[row]  (res: [M] weights)
 
 // one source of a first-layer k tile: value = scale * p[(idx ? idx[row] : row / rdiv) * ld + col + k]
 struct MagnetSrc {

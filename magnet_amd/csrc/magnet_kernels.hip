@@ -171,6 +171,65 @@ __global__ void k_inr_grid_prepare(const float* __restrict__ coords, const float
     *reinterpret_cast<f32x4*>(tail + row * 32 + 4 * quad) = o;
 }
 
+// The 2-D prepare for the decoder whose epilogue does the area blend itself (EPI_QUADBLEND): the four shifts of a (query, step) are
+// CONSECUTIVE rows - row = ((b Nq + q) T + i) 4 + s - and every row carries its blend weight area[opposite shift] / sum of the four areas
+// (models/magnet_cnn_2d.py:285-290).  Same per-row values as k_inr_grid_prepare.
+__global__ void k_inr_grid_prepare_blend(const float* __restrict__ coords, const float* __restrict__ cell,
+                                         const float* __restrict__ x_t, const float* __restrict__ t, int t_ld, int B, int Nq,
+                                         int T, int W, int32_t* __restrict__ cell_idx, float* __restrict__ tail,
+                                         float* __restrict__ blend_w) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;  // gid = row * 8 + quad
+    const int quad = (int)(gid & 7);
+    const long row = gid >> 3;
+    if (row >= (long)B * Nq * T * 4) return;
+    const int s = (int)(row & 3);
+    const int i = (int)((row >> 2) % T);
+    const long bq = (row >> 2) / T;
+    const int b = (int)(bq / Nq);
+    const float lo = (float)(-1.0 + 1e-6), hi = (float)(1.0 - 1e-6);
+    const float c0 = (float)(-1.0 + 1.0 / (double)W), c1 = (float)(2.0 / (double)W);
+    const long cells = (long)W * W;
+    const float co[2] = {coords[bq * 2], coords[bq * 2 + 1]};
+    float ar[4], rel_s[2] = {0.f, 0.f};
+    long flat_s = 0;
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) {
+        int idx[2];
+        float rel[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int v = a == 0 ? (ss >> 1) * 2 - 1 : (ss & 1) * 2 - 1;
+            const float off = (float)((double)v / (double)W + 1e-6);
+            const float c = fminf(hi, fmaxf(lo, co[a] + off));
+            idx[a] = nearest_cell(c, W);
+            const float qc = __fadd_rn(c0, __fmul_rn(c1, (float)idx[a]));
+            rel[a] = (co[a] - qc) * (float)W;
+        }
+        ar[ss] = fabsf(rel[0] * rel[1]) + 1e-9f;
+        if (ss == s) {
+            rel_s[0] = rel[0], rel_s[1] = rel[1];
+            flat_s = (long)idx[0] * W + idx[1];
+        }
+    }
+    if (quad == 0) {
+        const float tot = ((ar[0] + ar[1]) + ar[2]) + ar[3];
+        blend_w[row] = ar[3 - s] / tot;
+        cell_idx[row] = (int32_t)((long)b * cells + flat_s);
+    }
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * quad + k;
+        float v = 0.f;
+        if (c == 0) v = x_t[((size_t)b * T + i) * cells + flat_s];
+        else if (c <= 2) v = rel_s[c - 1];
+        else if (c <= 4) v = cell[bq * 2 + (c - 3)] * (float)W;
+        else if (c == 5) v = t[(size_t)b * t_ld + i];
+        o[k] = v;
+    }
+    *reinterpret_cast<f32x4*>(tail + row * 32 + 4 * quad) = o;
+}
+
 // z[(bq, i)][c] = sum_s p[((bq*S + s)*T + i)][c] * area[bq*S + opposite(s)] / sum_s area   (2D)
 //               = (p0*a1 + p1*a0) / (a1 + a0)                                               (1D)
 __global__ void k_inr_grid_blend(const float* __restrict__ p, const float* __restrict__ area, int T, int C, int S,
@@ -286,6 +345,17 @@ extern "C" int magnet_inr_grid_prepare_f32(const float* coords, const float* cel
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(k_inr_grid_prepare, dim3(nb(rows * T * 8, 256)), dim3(256), 0, S_, coords, cell, x_t, t, t_ld, n_graphs,
                        Nq, T, W, d, cell_idx, tail, area);
+    LAUNCH_CHECK();
+}
+
+extern "C" int magnet_inr_grid_prepare_blend_f32(const float* coords, const float* cell, const float* x_t, const float* t, int t_ld,
+                                                 int n_graphs, int Nq, int T, int W, int32_t* cell_idx, float* tail, float* blend_w,
+                                                 void* stream) {
+    (void)hipGetLastError();
+    const long rows = (long)n_graphs * Nq * T * 4;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_inr_grid_prepare_blend, dim3(nb(rows * 8, 256)), dim3(256), 0, S_, coords, cell, x_t, t, t_ld, n_graphs, Nq, T,
+                       W, cell_idx, tail, blend_w);
     LAUNCH_CHECK();
 }
 

@@ -315,6 +315,22 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
             } else {
                 segmean_epilogue_dpp<OT>(out, md, a.M, a.y, a.partials, lane);
             }
+        } else if (EPI == EPI_QUADBLEND) {
+            // the LIIF area blend of the grid INR decoder (models/magnet_cnn_2d.py:285-290) in the epilogue: the four shifted predictions
+            // of a (query, step) are four CONSECUTIVE rows (magnet_inr_grid_prepare_blend_f32 orders them so), i.e. four adjacent lanes
+            // of the accumulator layout: weight each row, add across the quad with two DPP quad permutes, lane 0 of the quad stores -
+            // the [4 M'][C] predictions are never written (1.34 GB per call at 256^2 queries) nor read back by a blend kernel
+            const float wr = a.res[row];
+#pragma unroll
+            for (int t = 0; t < OT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = out[t][i] * wr;
+                    v += dpp_f<0xB1, 0xF>(v);                   // quad_perm [1, 0, 3, 2]
+                    v += dpp_f<0x4E, 0xF>(v);                   // quad_perm [2, 3, 0, 1]
+                    out[t][i] = v;
+                }
+            store_rows<OT, 0>(out, a.y, a.ldy, a.ncols, nullptr, 0, row >> 2, row_ok && (lane & 3) == 0, half);
         } else {
             float* yg = a.y + (a.y_group_stride ? (size_t)cg * a.y_group_stride : (size_t)cg * OT * 32);
             store_rows<OT, EPI == EPI_STORE_MASK ? 2 : (EPI == EPI_STORE_RES ? 1 : 0)>(out, yg, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
@@ -363,6 +379,7 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
     MLP_CASE(5, 2, 1, ACT_RELU, false, false, EPI_STORE)
     MLP_CASE(5, 2, 2, ACT_RELU, false, true, EPI_STORE)
     MLP_CASE(5, 2, 4, ACT_RELU, false, true, EPI_STORE)
+    MLP_CASE(5, 2, 4, ACT_RELU, false, true, EPI_QUADBLEND)
     MLP_CASE_SMALL(2, 4, 4, ACT_SWISH, true, false, EPI_STORE)
     MLP_CASE_SMALL(2, 4, 4, ACT_SWISH, true, false, EPI_STORE_RES)
     MLP_CASE_SMALL(1, 4, 4, ACT_NONE, false, false, EPI_STORE)

@@ -40,6 +40,8 @@ class MAgNetCNN(MagnetBase):
         self.scales, self.res_layers, self.n_chan = hparams.scales, hparams.res_layers, hparams.n_chan
         self.kernel_size, self.res_scale = hparams.kernel_size, hparams.res_scale
         self.interpolation, self.radius, self.teacher_forcing = hparams.interpolation, hparams.radius, hparams.teacher_forcing
+        # A/B knob: the 2-D area blend inside the decoder chain's epilogue (EPI_QUADBLEND) instead of a blend pass over materialised predictions
+        self.fused_blend = bool(getattr(hparams, "fused_blend", __import__("os").environ.get("MAGNET_FUSED_BLEND", "1") != "0"))
         if self.mlp_layers != 4:
             raise NotImplementedError("the HIP MLP kernel is instantiated for mlp_layers == 4 (5 Linears)")
         T, D, Lm, Hm, C, K = self.time_slice, self.latent_dim, self.mlp_layers, self.mlp_hidden, self.n_chan, self.num_message_passing_steps
@@ -135,8 +137,20 @@ class MAgNetCNN(MagnetBase):
         rows = B * Nq * S
         cell_idx = torch.empty(rows * T, dtype=torch.int32, device=dev)
         tail = torch.empty(rows * T, 32, device=dev, dtype=torch.float32)
-        area = torch.empty(rows, device=dev, dtype=torch.float32)
         fco, fce = ops._f32(coords.reshape(B * Nq, d)), ops._f32(cell.reshape(B * Nq, d))
+        ph = pk.proj_head
+        if (d == 2 and self.fused_blend and len(ph.layers) == 5 and ph.ht == 2 and ph.ot == 4 and ph.ln is not None
+                and ph.layers[0][0].dtype != torch.float32):
+            # the area blend in the decoder chain's epilogue (EPI_QUADBLEND): the 4 shifted predictions of a (query, step) are adjacent
+            # rows, weighted and summed across the quad before anything is stored - p [4 rows][C] is neither written nor re-read
+            bw = torch.empty(rows * T, device=dev, dtype=torch.float32)
+            L.check(L.lib().magnet_inr_grid_prepare_blend_f32(ops._p(fco), ops._p(fce), ops._p(x_t), ops._p(t), t.shape[1], B, Nq, T, W,
+                                                              ops._p(cell_idx), ops._p(tail), ops._p(bw), ops._stream()),
+                    "inr_grid_prepare_blend")
+            z = torch.empty(B * Nq * T, C, device=dev, dtype=torch.float32)
+            run_mlp(rows * T, ops.ktiles(ops.Term(featT, C, idx=cell_idx), ops.Term(tail, 32)), ph, z, epi=ops.EPI_QUADBLEND, res=bw)
+            return self._finish_forward(pk, z, x_t, coords, t, T, hr_last, B, Nq, W, nlr, d, dev)
+        area = torch.empty(rows, device=dev, dtype=torch.float32)
         L.check(L.lib().magnet_inr_grid_prepare_f32(ops._p(fco), ops._p(fce), ops._p(x_t), ops._p(t), t.shape[1], B, Nq, T, W,
                                                     d, ops._p(cell_idx), ops._p(tail), ops._p(area), ops._stream()),
                 "inr_grid_prepare")
@@ -145,6 +159,10 @@ class MAgNetCNN(MagnetBase):
         z = torch.empty(B * Nq * T, C, device=dev, dtype=torch.float32)
         L.check(L.lib().magnet_inr_grid_blend_f32(ops._p(p), ops._p(area), B * Nq, T, C, S, ops._p(z), ops._stream()),
                 "inr_grid_blend")
+        return self._finish_forward(pk, z, x_t, coords, t, T, hr_last, B, Nq, W, nlr, d, dev)
+
+    def _finish_forward(self, pk, z, x_t, coords, t, T, hr_last, B, Nq, W, nlr, d, dev):
+        """projector + joint graph of LR grid nodes and queries (the part of ``_forward`` after the INR blend)"""
         hr_points = self._projector(pk, z, B * Nq * T).reshape(B, Nq, T)
         # joint graph: LR grid nodes (cell centres, row-major) + queries
         lr_points = x_t[:, :, 0].reshape(B, T, nlr).permute(0, 2, 1)

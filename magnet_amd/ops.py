@@ -8,7 +8,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib as L
-from ._lib import ACT_NONE, ACT_RELU, ACT_SWISH, EPI_SEGMEAN, EPI_STORE, EPI_STORE_MASK, EPI_STORE_RES  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, ACT_SWISH, EPI_QUADBLEND, EPI_SEGMEAN, EPI_STORE, EPI_STORE_MASK, EPI_STORE_RES  # noqa: F401
 
 
 def _stream() -> C.c_void_p:

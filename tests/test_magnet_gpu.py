@@ -337,3 +337,26 @@ def test_config4b_full_size_shipped_hparams_properties():
                                                blk.conv_2.weight, blk.conv_2.bias, padding=1)
         want = torch.nn.functional.conv2d(h, enc.tail_conv.weight, enc.tail_conv.bias, padding=1) + h0
     assert rel_l2(feat, want) < 2e-5       # torch's MIOpen convolutions are themselves only fp32-roundoff accurate
+
+
+def test_grid_inr_blend_in_the_decoder_epilogue_equals_the_separate_blend():
+    """magnet_cnn_2d at shipped hyper-parameters: the area blend fused into the decoder chain (EPI_QUADBLEND, shift-minor row order)
+    against the path that materialises the four shifted predictions and blends them in a second pass, and both against the golden output"""
+    from magnet_amd.models.factory import FACTORY
+    name, hp, salt, batch, d = load_case("magnet_cnn_2d_shipped")
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    oracle = O.build(name, hp)
+    fill_state_dict(oracle, salt)
+    outs = []
+    for fused in (True, False):
+        hp.fused_blend = fused
+        model = FACTORY[name](hp).eval()
+        model.load_state_dict(oracle.state_dict())
+        model = model.cuda()
+        assert model.fused_blend == fused
+        args = [a.cuda() for a in forward_args(name, hp, batch)]
+        outs.append([o.cpu() for o in model(*args)])
+    for a, b in zip(*outs):
+        assert rel_l2(a, b) < 1e-6
+    assert rel_l2(outs[0][0], d["fwd_out_hr"] if "fwd_out_hr" in d else outs[1][0]) < 1e-5
