@@ -1,3 +1,6 @@
+"""Dev: repeats the (5 Linears, hidden 64, out 64, K 40, LayerNorm, 1 013 rows) launch of the chain kernel and reports the 32-row
+wave tiles whose result deviates - the reproducer of the intermittent failure of the biases-from-LDS experiments
+(profiles/r2/chain_sq_counters.txt).  With the shipped kernel it prints nothing."""
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from magnet_amd import ops
