@@ -75,12 +75,32 @@ def _tape_variant_ok(nl, pk):
     return bool(L.lib().magnet_mlp_supported(nl, pk.ht, pk.ot, ops.ACT_RELU, 0, 0, ops.EPI_STORE))
 
 
-def _recompute_by_layers(M, kts, pk, nl, x0, X, zL):
-    """fallback: the same tape with the LayerNorm variant of the chain kernel (its normalised output goes to a scratch array)"""
+def _recompute_tape(M, kts, pk, nl, x0, X, zL, K0):
+    """fill the backward's tape - x0 (assembled first-layer input), X[1:] (activated output of every hidden layer) and zL (the
+    last Linear's raw output, LayerNorm chains only) - by re-running the forward:
+
+    1. ONE launch of the chain kernel's plain store variant with its tape outputs switched on, when that instantiation exists;
+    2. else, for a LayerNorm chain, ONE launch of its own (nl, ht, ot, LN) variant (the normalised output goes to a scratch array);
+    3. else layer by layer: a materialisation pass for x0, then one single-Linear launch per layer (any shape the library can
+       run forward can be recomputed this way)."""
     dev = x0.device
-    scratch = torch.empty(max(M, 1), pk.ot * 32, device=dev, dtype=torch.float32)
-    ops.mlp(M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU, last_act=False, ln=pk.ln, epi=ops.EPI_STORE, y=scratch,
-            ncols=pk.ot * 32, x0_out=x0, hid=X[1:] + [zL if zL is not None else None])
+    Dp = pk.ot * 32
+    lnflag = 1 if pk.ln is not None else 0
+    if _tape_variant_ok(nl, pk):
+        scratch = torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32)      # the chain's own output is not needed
+        ops.mlp(M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU, last_act=False, ln=None, epi=ops.EPI_STORE,
+                y=scratch, ncols=Dp, x0_out=x0, hid=X[1:] + [zL])
+    elif lnflag and L.lib().magnet_mlp_supported(nl, pk.ht, pk.ot, ops.ACT_RELU, 0, 1, ops.EPI_STORE):
+        scratch = torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32)
+        ops.mlp(M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU, last_act=False, ln=pk.ln, epi=ops.EPI_STORE,
+                y=scratch, ncols=Dp, x0_out=x0, hid=X[1:] + [zL])
+    else:
+        a, keep = ops.mlp_args(M, kts)
+        L.check(L.lib().magnet_mlp_materialize_input_f32(C.byref(a), ops._p(x0), K0, ops._stream()), "materialize_input")
+        for l in range(nl - 1):
+            X[l + 1].copy_(_linear(M, X[l], pk.layers[l], pk.ht, relu=True))
+        if zL is not None:
+            zL.copy_(_linear(M, X[nl - 1], pk.layers[nl - 1], pk.ot, relu=False))
 
 
 def _tiles_of(width):
@@ -155,10 +175,7 @@ class _Mlp(torch.autograd.Function):
             if nl > 1:
                 X = [x0] + [torch.empty(max(M, 1), pk.ht * 32, device=dev, dtype=torch.float32) for _ in range(nl - 1)]
                 zL = torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32) if pk.ln is not None else None
-                scratch = torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32)      # the chain's own output is not needed
-                ops.mlp(M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU, last_act=False, ln=None, epi=ops.EPI_STORE,
-                        y=scratch, ncols=Dp, x0_out=x0, hid=X[1:] + [zL]) if _tape_variant_ok(nl, pk) else _recompute_by_layers(
-                            M, kts, pk, nl, x0, X, zL)
+                _recompute_tape(M, kts, pk, nl, x0, X, zL, K0)
             else:
                 a, keep = ops.mlp_args(M, kts)
                 L.check(L.lib().magnet_mlp_materialize_input_f32(C.byref(a), ops._p(x0), K0, ops._stream()), "materialize_input")

@@ -10,7 +10,14 @@ feedback glue between them - into ONE hipGraph (``torch.cuda.CUDAGraph`` is hipG
   re-packs the weights into new buffers, so the old graph's pointers are stale);
 * the radius graph / k-NN topology is baked into the capture (its build needs the edge count on the host).  The
   coordinate tensors of every call are therefore compared with the captured ones - by identity when the caller passes the
-  same tensors again, else by content (one ``torch.equal`` = one host sync per rollout) - and a mismatch re-captures;
+  same tensors again, else by content (one ``torch.equal`` = one host sync per rollout) - and a mismatch re-captures.
+  "Identity" is only meaningful while the tensor it was taken from is alive (a freed block comes back from the caching
+  allocator at the same address with version 0), so an entry KEEPS the caller's topology tensors, as
+  ``magnet_amd.topo_cache.TopologyCache`` does;
+* a capture bakes in pointers to buffers that model-side caches own (radius graphs / CSR arrays in a ``TopologyCache``,
+  EDSR launch plans with their feature maps and zero-padding rows, packed weights).  Those caches evict and replace
+  entries on their own schedule, so everything a capture touched is registered with ``hold()`` while it runs and the
+  entry keeps it alive for as long as the graph can be replayed;
 * nothing inside the captured region may synchronise: the models skip their range-guard read while capturing and
   ``RolloutGraph`` reads it after the replay.
 
@@ -29,6 +36,17 @@ def capturing() -> bool:
 
 def _ident(t: torch.Tensor):
     return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version)
+
+
+_holders = []          # stack of keep-alive lists: one per capture in progress (captures do not nest in practice)
+
+
+def hold(*objs) -> None:
+    """called by the model-side caches (TopologyCache.get, EDSR._plan, the packed-weight caches) with the objects whose
+    device buffers the kernels about to be enqueued will read or write: while a rollout is being captured they are added
+    to the capture's keep-alive list, otherwise this is a no-op"""
+    if _holders:
+        _holders[-1].extend(objs)
 
 
 class RolloutGraph:
@@ -52,12 +70,13 @@ class RolloutGraph:
         e = self._entries.get(key)
         if e is not None:
             for k in self.topology_keys:                      # same coordinates as the capture?
-                if e["seen"].get(k) == _ident(batch[k]):
+                seen = e["seen"].get(k)                       # (tensor kept alive, its identity when it was compared)
+                if seen is not None and seen[0] is batch[k] and seen[1] == _ident(batch[k]):
                     continue
                 if not bool(torch.equal(e["static"][k], batch[k].to(e["static"][k].dtype))):
                     e = None
                     break
-                e["seen"][k] = _ident(batch[k])
+                e["seen"][k] = (batch[k], _ident(batch[k]))
         if e is None:
             e = self._capture(fn, batch)
             if len(self._entries) >= self.max_entries:
@@ -74,18 +93,24 @@ class RolloutGraph:
         # floating inputs are kept as fp32 (what every model converts to first): `.float()` inside the rollout is then a view
         # of the static buffer and the topology caches recognise it by identity in the capture pass
         static = {k: (v.float().clone() if v.is_floating_point() else v.clone()) for k, v in batch.items()}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):                                 # builds topology / packed weights / lazy buffers (may sync)
-                fn(static)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = fn(static)
+        keep = []
+        _holders.append(keep)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):                             # builds topology / packed weights / lazy buffers (may sync)
+                    fn(static)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = fn(static)
+        finally:
+            _holders.pop()
         out = tuple(out) if isinstance(out, (tuple, list)) else (out,)
-        return {"graph": graph, "static": static, "out": out, "seen": {k: _ident(batch[k]) for k in self.topology_keys}}
+        return {"graph": graph, "static": static, "out": out, "keep": keep,
+                "seen": {k: (batch[k], _ident(batch[k])) for k in self.topology_keys}}
 
 
 def wants_graph(setting, rows: int) -> bool:

@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from ... import ops
+from ...graphs import hold
 from ...packing import default_gemm, pack, pad_to
 
 
@@ -132,6 +133,9 @@ class EDSR(nn.Module):
         x = ops._f32(x, "EDSR input")
         B, cin = x.shape[:2]
         xin, out, launches, P = self._plan(B, cin, x.shape[2:], x.device)
+        # a hipGraph capture in progress bakes in this plan's buffers (feature maps with their zero-padding rows, tap tables,
+        # packed weights): the capture keeps them alive although `_plan` holds one geometry at a time (magnet_amd/graphs.py)
+        hold(self._plan_val, self._pack, self._taps.get((B, tuple(x.shape[2:]), str(x.device))))
         xin[:P, :cin] = x.reshape(B, cin, -1).permute(0, 2, 1).reshape(P, cin)
         for go in launches:
             go()

@@ -19,7 +19,7 @@ from torch import nn
 from .. import _lib as L
 from .. import ops
 from ..lightning_compat import LightningModule
-from ..graphs import RolloutGraph, capturing, wants_graph  # noqa: F401
+from ..graphs import RolloutGraph, capturing, hold, wants_graph  # noqa: F401
 from ..packing import pad_to, pad_vec
 from ..topo_cache import TopologyCache
 from .backbones.mlp import MLP
@@ -146,6 +146,7 @@ class MagnetBase(LightningModule):
         key = (params[0].device, sum(p._version for p in params), self._pack_gen)
         if self._pack_key != key:
             self._pack, self._pack_key = self._pack_weights(), key
+        hold(self._pack)                    # a capture in progress keeps the packs its launches point into (magnet_amd/graphs.py)
         return self._pack
 
     def _weights_changed(self):

@@ -162,11 +162,15 @@ class MAgNetGNN(MagnetBase):
     def _noisy(self, x, on):
         """training-time input noise, magnet_gnn.py:402-407 / :424-428: ``noise * torch.randn(shape)`` drawn from torch's
         default HOST generator (as the reference does - same seed, same call order, same numbers), added on the device.
-        The reference draws even when ``noise`` is 0; the shipped config (configs/model/magnet_gnn.yaml:13) has 0 and the
-        draw is skipped then."""
-        if not on or not self.noise:
+        The reference draws even when ``noise`` is 0 (the shipped config, configs/model/magnet_gnn.yaml:13): the numbers are
+        then drawn and discarded here too, so that everything that reads the host generator after a training step
+        (DataLoader shuffle seeds, later initialisations) sees the stream the reference would have left."""
+        if not on:
             return x
-        return x + (self.noise * torch.randn(x.shape)).to(x.device)
+        draw = torch.randn(x.shape)
+        if not self.noise:
+            return x
+        return x + (self.noise * draw).to(x.device)
 
     def _rollout(self, batch, teacher_forcing=False, noise=False):
         t, u = batch["t"].float(), batch["lr_frames"].float()

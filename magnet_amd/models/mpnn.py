@@ -24,7 +24,7 @@ from torch import nn
 from .. import ops
 from ..lightning_compat import LightningModule
 from ..packing import GEMM_MODES, default_gemm, pack, pack_edge16_fp16x2, pad_to
-from ..graphs import RolloutGraph, capturing, wants_graph
+from ..graphs import RolloutGraph, capturing, hold, wants_graph
 from ..topo_cache import TopologyCache
 
 _READOUT = {10: (16, 6, 10), 16: (16, 5, 8), 20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}  # mpnn.py:140-163
@@ -122,6 +122,7 @@ class MPNN(LightningModule):
         params = list(self.parameters())
         key = (params[0].device, sum(p._version for p in params), self._pack_gen)
         if self._pack_key == key:
+            hold(self._pack)                # a capture in progress keeps the packs its launches point into (magnet_amd/graphs.py)
             return self._pack
         H, tw, dp, kin = self.hidden_features, self.time_window, self.dpos, self.kin
         nin = tw + dp + 1
@@ -156,6 +157,7 @@ class MPNN(LightningModule):
                   c2.weight.detach().reshape(-1).contiguous(), c2.bias.detach().contiguous())
         assert nin <= kin
         self._pack_key, self._pack = key, P
+        hold(P)
         return P
 
     # ------------------------------------------------------------------ forward (mpnn.py:175-203)

@@ -51,7 +51,12 @@ def flat_gradient(params):
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        params = [p for p in params if p.requires_grad]
+        every = list(params)
+        # the reference builds Adam(self.parameters()) (models/mpnn.py:206-214): its checkpoints index ALL parameters, frozen ones
+        # included; `_index[i]` is the position of our i-th (trainable) parameter in that list
+        self._index = [i for i, p in enumerate(every) if p.requires_grad]
+        self._n_all = len(every)
+        params = [every[i] for i in self._index]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._params = params
         if not params[0].is_cuda:
@@ -91,11 +96,14 @@ class FusedAdam(torch.optim.Optimizer):
     def state_dict(self):
         """The layout ``torch.optim.Adam.state_dict()`` writes (what the reference's Lightning checkpoints hold,
         configure_optimizers models/mpnn.py:206-214): per parameter index ``step`` / ``exp_avg`` / ``exp_avg_sq`` in the
-        parameter's own shape, so a checkpoint written here resumes under torch.optim.Adam and vice versa."""
+        parameter's own shape, so a checkpoint written here resumes under torch.optim.Adam and vice versa.  Indices count
+        every parameter the optimizer was constructed with (as ``Adam(model.parameters())`` does); frozen parameters have
+        no state entry, exactly like parameters torch's Adam never saw a gradient for."""
         sd = super().state_dict()
+        sd["param_groups"][0]["params"] = list(range(self._n_all))
         state, o = {}, 0
         if self.steps > 0:
-            for i, p in enumerate(self._params):
+            for i, p in zip(self._index, self._params):
                 k = p.numel()
                 state[i] = {"step": torch.tensor(float(self.steps)),
                             "exp_avg": self.flat_m[o:o + k].view(p.shape).clone(),
@@ -105,36 +113,51 @@ class FusedAdam(torch.optim.Optimizer):
         return sd
 
     def load_state_dict(self, state_dict):
+        """accepts torch.optim.Adam's layout over ALL parameters (the reference's checkpoints: no entry for a parameter that
+        never received a gradient, frozen parameters counted in the indices), the same layout over the trainable parameters
+        only, and round-1 ``magnet_flat`` checkpoints.  Missing entries start from zero moments at the common step count."""
         flat = state_dict.get("magnet_flat")              # round-1 checkpoints of this class
         per_param = state_dict.get("state", {})
-        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        groups = state_dict["param_groups"]
+        if len(groups) != 1:
+            raise ValueError(f"FusedAdam.load_state_dict: {len(groups)} parameter groups in the checkpoint, one here")
+        for k, v in groups[0].items():                    # lr, betas, eps, weight_decay, the scheduler's initial_lr ...
+            if k != "params":
+                self.param_groups[0][k] = v
         if flat is not None:
             self.flat_m.copy_(flat["exp_avg"])
             self.flat_v.copy_(flat["exp_avg_sq"])
             self.steps = int(flat["step"])
             return
-        if not per_param:
-            self.flat_m.zero_()
-            self.flat_v.zero_()
-            self.steps = 0
-            return
-        if sorted(per_param.keys()) != list(range(len(self._params))):
-            raise ValueError("FusedAdam.load_state_dict: optimizer state covers parameters "
-                             f"{sorted(per_param.keys())[:4]}... but the model has {len(self._params)}")
+        saved = list(groups[0]["params"])
+        if len(saved) == self._n_all:
+            ids = [saved[i] for i in self._index]         # checkpoint id of our i-th trainable parameter
+        elif len(saved) == len(self._params):
+            ids = saved
+        else:
+            raise ValueError(f"FusedAdam.load_state_dict: the checkpoint's group has {len(saved)} parameters; this optimizer "
+                             f"was built over {self._n_all} ({len(self._params)} trainable)")
+        stray = set(per_param) - set(ids)
+        if stray:
+            raise ValueError(f"FusedAdam.load_state_dict: optimizer state for frozen / unknown parameters {sorted(stray)[:4]}")
+        self.flat_m.zero_()
+        self.flat_v.zero_()
         steps, o = set(), 0
-        for i, p in enumerate(self._params):
-            st, k = per_param[i], p.numel()
-            if tuple(st["exp_avg"].shape) != tuple(p.shape):
-                raise ValueError(f"FusedAdam.load_state_dict: moment shape {tuple(st['exp_avg'].shape)} of parameter {i} "
-                                 f"does not match {tuple(p.shape)}")
-            self.flat_m[o:o + k].copy_(st["exp_avg"].reshape(-1))
-            self.flat_v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
-            steps.add(int(float(st["step"])))
+        for cid, p in zip(ids, self._params):
+            k = p.numel()
+            st = per_param.get(cid)
+            if st is not None:
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"FusedAdam.load_state_dict: moment shape {tuple(st['exp_avg'].shape)} of parameter {cid} "
+                                     f"does not match {tuple(p.shape)}")
+                self.flat_m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+                self.flat_v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
             o += k
-        if len(steps) != 1:
+        if len(steps) > 1:
             raise ValueError(f"FusedAdam.load_state_dict: parameters carry different step counts {sorted(steps)}; "
                              "one bias correction per step is applied to the whole flat buffer")
-        self.steps = steps.pop()
+        self.steps = steps.pop() if steps else 0
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -20,6 +20,8 @@ from __future__ import annotations
 
 import torch
 
+from .graphs import hold
+
 
 def _ident(t: torch.Tensor):
     return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, t.dtype, str(t.device))
@@ -43,7 +45,11 @@ class TopologyCache:
     def get(self, tag, tensors, build):
         """topology for ``tensors`` (a tuple of coordinate tensors) under ``tag`` (hashable: everything else the
         topology depends on - batch size, radius, loop flag ...); ``build()`` makes it on a miss."""
-        tensors = tuple(tensors)
+        topo = self._get(tag, tuple(tensors), build)
+        hold(topo)          # a hipGraph capture in progress bakes this topology's buffers in: it outlives an eviction here
+        return topo
+
+    def _get(self, tag, tensors, build):
         idents = tuple(_ident(t) for t in tensors)
         for k, e in enumerate(self._entries):
             if e[0] == tag and e[2] == idents:

@@ -105,6 +105,57 @@ def test_equal_coordinates_in_a_new_tensor_reuse_the_graph():
     assert all(torch.equal(x, y) for x, y in zip(o1, o2))
 
 
+# ------------------------------------------------------------------------------------------- captured rollouts (round-2 review)
+def test_rollout_graph_keeps_the_topology_tensors_it_compares_by_identity():
+    """RolloutGraph skips the content compare of the coordinates when the caller passes "the same tensor" again.  Round 2 stored
+    only (address, shape, strides, version): a validation loop that frees batch k before batch k + 1 arrives gets the same
+    address back with version 0, the compare is skipped and the graph replays the OLD mesh.  The entry now keeps the tensor
+    (the address cannot be recycled while it can still match) - every batch must give the oracle's result for ITS mesh."""
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    name, hp, salt, batch, d = load_case("mpnn_1d")
+    oracle = O.build(name, hp).eval()
+    fill_state_dict(oracle, salt)
+    model = FACTORY[name](types.SimpleNamespace(**vars(hp), hip_graph=True)).eval()
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda()
+    for scale in (1.0, 0.7, 0.7, 1.3, 1.0):
+        b = {k: v.clone() for k, v in batch.items()}
+        b["x"] = batch["x"] * scale                                    # same shape, different spacing -> different radius graph
+        cb = {k: v.cuda() for k, v in b.items()}
+        pred = model.validation_step(cb, 0).cpu()
+        kept = [e["seen"]["x"][0] for e in model._rollout_graph._entries.values()]
+        assert any(k is cb["x"] for k in kept), "the entry must hold the tensor whose identity it trusts"
+        del cb, kept                                                   # the only other reference is the entry's
+        with torch.no_grad():
+            want = oracle.validation_step(b)
+        assert rel_l2(pred, want) < 5e-5, scale
+
+
+@pytest.mark.parametrize("tag", ["magnet_cnn_1d", "magnet_cnn_2d", "magnet_gnn_tiny"])
+def test_captured_rollouts_outlive_the_caches_they_were_built_from(tag):
+    """A captured rollout bakes in pointers to buffers owned by model-side caches: EDSR keeps ONE launch plan (feature maps with
+    their zero-padding rows), TopologyCache evicts its oldest CSR arrays.  Validate geometry A, then others (the caches move
+    on), let other tensors take over whatever was freed, validate A again: the replay of A's graph must still be exact."""
+    name, hp, batch, d, oracle, model = _pair(tag, hip_graph=True)
+    A = {k: v.cuda() for k, v in batch.items()}
+    first = model.validation_step(A, 0).clone()
+    assert len(model._rollout_graph._entries) == 1
+    for sl in (slice(0, 1), slice(1, 2)):                              # other geometries: new EDSR plan, new topologies
+        model.validation_step({k: v[sl].contiguous() for k, v in A.items()}, 0)
+    model._topo_cache.clear()                                          # ... and every cached topology evicted
+    junk = [torch.full((n,), float("nan"), device="cuda") for n in (64, 257, 1024, 4096, 16385, 65536, 300000) for _ in range(6)]
+    torch.cuda.synchronize()
+    again = model.validation_step(A, 0)
+    assert len(model._rollout_graph._entries) == 3                     # A was replayed, not re-captured
+    assert torch.equal(first, again)
+    del junk
+    with torch.no_grad():
+        want = oracle.validation_step(batch)
+    assert rel_l2(again, want) < 5e-5
+
+
 # ------------------------------------------------------------------------------------------- EDSR launch plans
 @pytest.mark.parametrize("tag", ["magnet_cnn_1d", "magnet_cnn_2d"])
 def test_validation_after_fused_adam_steps_uses_the_new_weights(tag):
@@ -167,13 +218,60 @@ def test_fused_adam_and_torch_adam_exchange_checkpoints():
         run(ob, b, grads[3:])
         for p, q in zip(b, ref):
             assert rel_l2(p, q) < 1e-6, (first.__name__, second.__name__)
-    # a state that does not cover the parameters is refused, not silently dropped
+    # state for a parameter this optimizer does not train is refused, not silently dropped
     c = make()
     oc = FusedAdam(c, lr=1e-2)
     bad = oref.state_dict()
-    bad["state"] = {0: bad["state"][0]}
+    bad["state"] = dict(bad["state"], **{7: bad["state"][0]})
     with pytest.raises(ValueError):
         oc.load_state_dict(bad)
+
+
+def test_fused_adam_loads_reference_checkpoints_with_frozen_and_unused_parameters():
+    """The reference builds Adam(self.parameters()) (models/mpnn.py:206-214): its checkpoint indexes EVERY parameter, has no
+    state entry for a parameter that never received a gradient, and counts frozen parameters.  FusedAdam trains only the
+    requires_grad ones, so the indices have to be mapped, and a missing entry means zero moments at the common step."""
+    from magnet_amd.optim import FusedAdam
+    shapes = [(16, 9), (5,), (4, 3), (6,)]
+    FROZEN, UNUSED = 1, 2
+
+    def make():
+        torch.manual_seed(11)
+        ps = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+        ps[FROZEN].requires_grad_(False)
+        return ps
+
+    grads = [[torch.randn(*s, device="cuda") for s in shapes] for _ in range(5)]
+
+    def run(opt, params, gs, skip=()):
+        for g in gs:
+            for i, (p, gg) in enumerate(zip(params, g)):
+                p.grad = None if (i in skip or not p.requires_grad) else gg.clone()
+            opt.step()
+
+    # uninterrupted torch run: parameter UNUSED gets no gradient in the first three steps, then gradients
+    ref = make()
+    oref = torch.optim.Adam(ref, lr=1e-2)
+    run(oref, ref, grads[:3], skip=(UNUSED,))
+    sd = oref.state_dict()
+    assert sorted(sd["state"].keys()) == [0, 3] and sd["param_groups"][0]["params"] == [0, 1, 2, 3]
+    # ... resumed under FusedAdam (which sees zero gradients where torch saw None: Adam's update of a zero-moment parameter is zero)
+    b = make()
+    with torch.no_grad():
+        for p, q in zip(b, ref):
+            p.copy_(q)
+    ob = FusedAdam(b, lr=1e-2)
+    ob.load_state_dict(sd)
+    assert ob.steps == 3
+    run(ob, b, grads[3:], skip=(UNUSED,))
+    run(oref, ref, grads[3:], skip=(UNUSED,))
+    for i, (p, q) in enumerate(zip(b, ref)):
+        assert rel_l2(p, q) < 1e-6, i
+    # and back: FusedAdam's checkpoint counts all four parameters, no entry for the frozen one, and torch.optim.Adam loads it
+    sd2 = ob.state_dict()
+    assert sd2["param_groups"][0]["params"] == [0, 1, 2, 3] and FROZEN not in sd2["state"] and 0 in sd2["state"]
+    c = make()
+    torch.optim.Adam(c, lr=1e-2).load_state_dict(sd2)
 
 
 # ------------------------------------------------------------------------------------------- fp16x3 range guard
