@@ -15,19 +15,32 @@ and already resident in HBM when the clock starts; weights are random-init (torc
 seed 0).  value = nodes x predicted steps x trajectories (all ranks) / max-over-ranks wall time.
 
 Extra objects on the JSON line:
-  roofline      - dominant kernel (k_mpnn_edge7, MFMA bound): algorithmic flops per launch
-                  (2*E*128*128, the message_net_2 GEMM; message_net_1 is factorised per node, see
-                  DESIGN.md) / mean launch time measured with HIP events on the launch stream.  The
+  roofline      - dominant kernel (the fused MPNN edge kernel; `roofline.kernel` names the generation that ran): algorithmic
+                  flops per launch (2*E*128*128, the message_net_2 GEMM; message_net_1 is factorised per node, see
+                  DESIGN.md) / mean launch time measured with HIP events on the launch stream, in an untimed pass that runs
+                  BEFORE the training leg.  `clock_mhz` = the shader clock sampled by a one-wave probe kernel on a second
+                  stream while that pass runs (the part is power limited: ~2.1 GHz, not the 2.4 GHz `peak` assumes);
+                  `peak_at_clock` / `frac_at_clock` rescale to it.  `limiter`: what really bounds the kernel ("issue": it
+                  runs at the sum of its matrix-pipe, VALU and transcendental time; `mfma_share` = matrix-pipe
+                  cycles / kernel cycles = the roofline fraction).  The
                   kernel evaluates every fp32 product through a split into 16-bit pieces on the matrix cores
                   (default fp16x3: 2 pieces, 3 fp16 MFMA products, ~2^-22 relative; bf16x6: 3 pieces, 6 products), so its
                   ceiling is the dense 16-bit MFMA peak / 3 = 833 TFLOP/s of fp32-equivalent work (`peak`);
                   `executed_mfma_tflops` / 2500 is the same fraction.
-  roofline_scatter - the standalone CSR segment-mean ("scatter mean") kernel on the same graph's
+  roofline_scatter - the STAND-ALONE CSR segment-mean ("scatter mean") kernel on the same graph's
                   [E,128] messages: algorithmic bytes E*H*4 + N*H*4 + 4*(N+1) per launch / mean
-                  launch time, against the 8 TB/s HBM3E peak.
+                  launch time, against the 8 TB/s HBM3E peak.  No model calls it on the rollout path (the mean is fused
+                  into the edge kernels); it is the drop-in for torch_scatter when messages are materialised.
+  precision_modes - the same workload and weights in the other GEMM modes (N = 1 only): ms_per_step of `bf16x6`
+                  (three bf16 pieces, exact 24-bit operands, full fp32 range) and `fp32` (fp32 MFMA), and every mode's rollout
+                  relative L2 against the oracle on a 48 x 48 mesh.  The reference computes in fp32
+                  (configs/trainer/default.yaml:5); the headline mode fp16x3 holds ~22-bit operands.
   cpu_baseline  - the oracle (torch-CPU restatement of the reference op sequence) timed on this
-                  box's host cores on a bounded sample (one rollout of one 128 x 128 trajectory;
-                  forward calls only, graph construction excluded), rank 0, N = 1 only.
+                  box's host cores on a bounded sample (rollouts of one 128 x 128 trajectory;
+                  forward calls only, graph construction excluded), rank 0, N = 1 only; the thread count is the best of
+                  {physical cores / 2, physical cores, logical CPUs} by a one-forward sweep (all three reported).
+  dist          - what the process group saw: backend, world size, per-rank ms_per_step; `training_step.allreduce_ms` =
+                  the gradient all-reduce of one step (HIP events).
   traffic (inside both roofline objects) - HBM bytes per launch from the newest committed PMC measurement of this same
                   command (profiles/r*/traffic_v*.json <- scripts/collect_traffic.py <- two separate rocprofv3 --pmc passes,
                   FETCH_SIZE doubled per the gfx950 correction); null when the workload differs from the recorded one.
@@ -65,6 +78,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 SPLIT_PRODUCTS = {"fp16x3": 3, "bf16x6": 6, "bf16": 1}   # MFMA products per multiply in k_mpnn_edge7 / k_mpnn_edge6 (bf16: reduced precision)
 HBM_PEAK_GBS = 8000.0
+PEAK_CLOCK_MHZ = 2400.0                                     # the clock the 2.5 PFLOP/s dense peak is quoted at
 
 
 def synthetic_batch(W, B, seed, device):
@@ -151,10 +165,32 @@ def cpu_model_string():
     return "unknown"
 
 
+def physical_cores():
+    """distinct (physical id, core id) pairs in /proc/cpuinfo, restricted to this process's affinity mask"""
+    try:
+        allowed = os.sched_getaffinity(0)
+        seen, cur = set(), {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                if int(cur.get("processor", -1)) in allowed:
+                    seen.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+        if cur and int(cur.get("processor", -1)) in allowed:
+            seen.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+        return max(1, len(seen))
+    except Exception:  # noqa: BLE001
+        return max(1, (os.cpu_count() or 2) // 2)
+
+
 def cpu_baseline(W=128, timed=3):
     """the oracle's free-running rollout of ONE trajectory on a W x W mesh on the host cores, fp32,
     no_grad, 1 warm-up rollout + ``timed`` timed rollouts, median; the radius-graph build is timed separately (the oracle
-    builds it by brute force) and excluded from the rollout time, as the reference's own CPU numbers in BASELINE.md are."""
+    builds it by brute force) and excluded from the rollout time, as the reference's own CPU numbers in BASELINE.md are.
+    Thread count: the fastest of {physical / 2, physical, logical} on one forward call (torch's default = logical CPUs
+    oversubscribes an SMT part); `cores` is the count the timed rollouts used."""
     from oracle import models as O
     torch.manual_seed(0)
     hp = types.SimpleNamespace(**HP)
@@ -168,28 +204,241 @@ def cpu_baseline(W=128, timed=3):
     t_graph = time.perf_counter() - t0
     n_calls = (NT - tw) // tw
 
-    def rollout():
+    def rollout(calls=n_calls):
         g = copy.copy(graph0)                                             # same edge list, fresh x / pos per rollout
         t0 = time.perf_counter()
         with torch.no_grad():
-            for i in range(n_calls):
+            for i in range(calls):
                 y = model(g, x[0, -1], t[0, -1], t[0][1] - t[0][0])
                 g.x = y                                                   # same mesh: reuse the edge list
                 g.pos = torch.cat([torch.full((W * W, 1), float(t[0, (i + 2) * tw - 1])), g.pos[:, 1:]], 1)
         return time.perf_counter() - t0
 
+    logical, phys = len(os.sched_getaffinity(0)), physical_cores()
+    default_threads = torch.get_num_threads()
+    sweep = {}
+    for n in sorted({max(1, phys // 2), phys, logical}):
+        torch.set_num_threads(n)
+        rollout(1)                                                        # thread pool / allocator warm-up at this size
+        sweep[n] = round(rollout(1), 2)                                   # one forward call
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
     times = []
     for k in range(1 + timed):
         dt = rollout()
         if k > 0:
             times.append(dt)
+    torch.set_num_threads(default_threads)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": W * W * tw * n_calls / med, "unit": "mesh-node-updates/s", "cores": torch.get_num_threads(),
+    return {"value": W * W * tw * n_calls / med, "unit": "mesh-node-updates/s", "cores": best, "physical_cores": phys,
+            "logical_cpus": logical, "one_forward_s_by_threads": {str(k): v for k, v in sweep.items()},
             "cpu_model": cpu_model_string(), "kind": "port", "rollouts_s": [round(v, 2) for v in times], "graph_build_s": round(t_graph, 2),
             "sample": f"oracle mpnn_2d, {W}x{W} mesh, 1 trajectory, 1 warm-up + {timed} timed free-running rollouts of {n_calls} forward "
                       f"calls each, median {med:.1f} s (radius-graph build {t_graph:.1f} s timed separately, excluded), fp32, no_grad, "
-                      f"torch {torch.__version__} CPU, {torch.get_num_threads()} threads"}
+                      f"torch {torch.__version__} CPU, {best} threads (best of {sorted(sweep)} on one forward call; {phys} physical "
+                      f"cores, {logical} logical CPUs)"}
+
+
+class ClockProbe:
+    """Shader clock under load: a one-wave kernel on a side stream reads the shader-clock counter and the constant-rate wall
+    clock for ``wall_us`` microseconds while the main stream runs the workload (magnet_clock_probe, include/magnet_hip.h).
+    Beside it, best effort, the driver's own figure (the starred level of sysfs pp_dpm_sclk), sampled by a host thread."""
+
+    def __init__(self, dev):
+        import ctypes as C
+        self.C, self.dev = C, dev
+        self.out = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.khz = C.c_int(0)
+        self.samples, self.sysfs = [], []
+        self._stop = None
+
+    @staticmethod
+    def _sysfs_mhz():
+        import glob
+        import re
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+            try:
+                for line in open(f):
+                    if "*" in line:
+                        m = re.search(r"(\d+)\s*[Mm][Hh]z", line)
+                        if m:
+                            return int(m.group(1))
+            except OSError:
+                continue
+        return None
+
+    def __enter__(self):
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                v = self._sysfs_mhz()
+                if v:
+                    self.sysfs.append(v)
+                self._stop.wait(0.004)
+
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join()
+
+    def sample(self, wall_us):
+        """enqueue one probe now (call right before the work it should overlap); read it with ``collect`` after a sync"""
+        from magnet_amd import ops
+        self.stream.wait_stream(torch.cuda.current_stream())
+        rc = ops.L.lib().magnet_clock_probe(self.C.c_void_p(self.out.data_ptr()), int(wall_us), self.C.byref(self.khz),
+                                            self.C.c_void_p(self.stream.cuda_stream))
+        return rc == 0
+
+    def collect(self):
+        torch.cuda.synchronize()
+        c, w = (int(v) for v in self.out.tolist())
+        if w > 0 and self.khz.value > 0:
+            mhz = c / w * self.khz.value / 1e3
+            if 300.0 < mhz < 4000.0:                       # a counter that is not the shader clock would read as the wall clock rate
+                self.samples.append(mhz)
+
+    def result(self):
+        probe = sum(self.samples) / len(self.samples) if self.samples else None
+        sysfs = sorted(self.sysfs)[len(self.sysfs) // 2] if self.sysfs else None
+        return probe, sysfs
+
+
+def edge_roofline(model, batch, dev, W, B, passes=3):
+    """HIP-event time of every launch of the fused MPNN edge kernel over ``passes`` untimed rollouts (events are recorded on the
+    stream the kernel is launched on: the C entry points take torch's current stream), with the shader clock sampled
+    alongside.  Returns the `roofline` object."""
+    from magnet_amd import ops
+    csr = model._topo.csr
+    E, N, H = csr.E, csr.N, 128
+    ev = []
+    lyr0 = model._packed().layers[0]
+    wdt = lyr0.msg2[0].dtype
+    entries = [e for e in (ops.EDGE_ENTRY[wdt], ops.EDGE_ENTRY_L2E.get(wdt)) if e]   # the model picks one of them
+    entries += [e for e in ops.EDGE_ENTRY_EXTRA if hasattr(ops.L.lib(), e)] if wdt == torch.float16 else []
+    origs = {e: getattr(ops.L.lib(), e) for e in entries}
+    used = set()
+
+    def timed(name, orig):
+        def timed_edge(*a):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = orig(*a)
+            e.record()
+            ev.append((s, e))
+            used.add(name)
+            return rc
+        return timed_edge
+
+    for e_, o_ in origs.items():
+        setattr(ops.L._lib, e_, timed(e_, o_))
+    probe = ClockProbe(dev)
+    try:
+        with probe:
+            for _ in range(passes):
+                probe.sample(20000)                     # ~20 ms of the ~25 ms rollout
+                model.validation_step(batch, 0)
+                probe.collect()
+    finally:
+        for e_, o_ in origs.items():
+            setattr(ops.L._lib, e_, o_)
+    ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
+    flops = 2.0 * E * H * H
+    ach = flops / (ms * 1e-3) / 1e12
+    mode = model.edge_gemm
+    nprod = SPLIT_PRODUCTS.get(mode, 1)
+    peak = MFMA_BF16_PEAK_TFLOPS / nprod if mode in SPLIT_PRODUCTS else MFMA_F32_PEAK_TFLOPS
+    kname = ops.EDGE_KERNEL_OF_ENTRY.get(next(iter(used)) if len(used) == 1 else None, "k_mpnn_edge?")
+    clk, clk_sysfs = probe.result()
+    roof = {"kernel": kname, "bound": "mfma", "limiter": "issue",
+            "achieved": round(ach, 2), "peak": round(peak, 1),
+            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "launch_ms": round(ms, 4), "launches_timed": len(ev), "flops_per_launch": flops, "gemm_mode": mode,
+            "algorithmic_hbm_bytes": 3 * N * H * 4 + 2 * E * 4 + 4 * (N + 1),
+            "executed_mfma_tflops": round(ach * nprod, 1), "mfma_16bit_dense_peak": MFMA_BF16_PEAK_TFLOPS,
+            "fp32_mfma_peak_for_reference": MFMA_F32_PEAK_TFLOPS,
+            "clock_mhz": round(clk, 1) if clk else None, "clock_mhz_sysfs": clk_sysfs, "peak_clock_mhz": PEAK_CLOCK_MHZ,
+            "mfma_share": round(ach / peak, 4),
+            "note": "fp32-class GEMM: operands split into 16-bit pieces on the matrix cores "
+                    f"({nprod} MFMA products per fp32 product, fp32 accumulate); peak = 2500 / {nprod}.  limiter 'issue': the kernel runs at "
+                    "the SUM of its matrix-pipe, VALU and transcendental time (two Swish per edge-feature), so the matrix-pipe share "
+                    "of its cycles (mfma_share) IS the fraction; measured before the training leg"}
+    if clk:
+        roof["peak_at_clock"] = round(peak * clk / PEAK_CLOCK_MHZ, 1)
+        roof["frac_at_clock"] = round(ach / (peak * clk / PEAK_CLOCK_MHZ), 4)
+    if W == 256 and B == 4 and mode in SPLIT_PRODUCTS:     # the recorded PMC passes are of this exact workload
+        roof["traffic"], roof["traffic_source"] = measured_traffic(kname)
+    return roof
+
+
+def scatter_roofline(model, dev, W, B):
+    from magnet_amd import ops
+    csr = model._topo.csr
+    E, N, H = csr.E, csr.N, 128
+    msg = torch.randn(E, H, device=dev)
+    out = torch.empty(N, H, device=dev)
+    for _ in range(3):
+        ops.segment_mean(msg, csr.rowptr, N, out)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    s.record()
+    for _ in range(reps):
+        ops.segment_mean(msg, csr.rowptr, N, out)
+    e.record()
+    torch.cuda.synchronize()
+    ms_sc = s.elapsed_time(e) / reps
+    nbytes = E * H * 4 + N * H * 4 + 4 * (N + 1)
+    gbs = nbytes / (ms_sc * 1e-3) / 1e9
+    roof_sc = {"kernel": "k_segment_mean<128>", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+               "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(ms_sc, 4),
+               "bytes_per_launch": nbytes,
+               "note": "stand-alone op (magnet_segment_mean_f32, the drop-in for torch_scatter's scatter-mean on materialised messages); "
+                       "not on the rollout path - there the mean is fused into the edge kernels"}
+    if W == 256 and B == 4:
+        roof_sc["traffic"], roof_sc["traffic_source"] = measured_traffic("k_segment_mean<128>")
+    return roof_sc
+
+
+def precision_modes(model, batch, headline_ms, dev, steps=3):
+    """the same workload and weights in every full-precision GEMM mode: ms per rollout (graph rebuilt every step, as the headline)
+    and the rollout's relative L2 against the oracle on a 48 x 48 mesh (one trajectory, same weights)"""
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    oracle = O.build("mpnn_2d", types.SimpleNamespace(**HP)).eval()
+    oracle.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    small = synthetic_batch(48, 1, 5, "cpu")
+    with torch.no_grad():
+        want = oracle.validation_step(small)
+    small_dev = {k: v.to(dev) for k, v in small.items()}
+    out = {}
+    for mode in ("fp16x3", "bf16x6", "fp32"):
+        if mode == model.edge_gemm:
+            m, ms = model, headline_ms
+        else:
+            m = FACTORY["mpnn_2d"](types.SimpleNamespace(**dict(HP, edge_gemm=mode, gemm=mode), hip_graph=False)).to(dev).eval()
+            m.load_state_dict(model.state_dict())
+            m.validation_step(batch, 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                m.drop_topology_cache()
+                m.validation_step(batch, 0)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+        got = m.validation_step(small_dev, 0).cpu()
+        m.drop_topology_cache()
+        out[mode] = {"ms_per_step": round(ms, 3), "dtype": DTYPE_NOTE[mode],
+                     "rollout_rel_l2_vs_oracle_48x48": float((got.double() - want.double()).norm() / want.double().norm())}
+        if m is not model:
+            del m
+            torch.cuda.empty_cache()
+    return out
 
 
 def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_over_ranks):
@@ -376,6 +625,7 @@ def main():
                     help="mpnn_2d = the headline metric case (its line also carries the two MAgNet 256^2 cases of SURVEY.md 8(d) as "
                          "the objects `c4b` / `c5`); magnet_cnn_2d / magnet_gnn make one of those the headline of the line")
     ap.add_argument("--no-extra-cases", action="store_true", help="skip the c4b / c5 / c1 objects of the default line")
+    ap.add_argument("--no-precision-modes", action="store_true", help="skip the bf16x6 / fp32 timings and the 48 x 48 oracle check")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:       # N ranks as fresh children, before any GPU call here
@@ -435,10 +685,35 @@ def main():
     for _ in range(K):
         step()
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+    my_elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(my_elapsed, dev)
     tw = HP["time_window"]
     pred_steps = (NT - tw) // tw * tw
     value = world * B * W * W * pred_steps * K / elapsed
+    # what the process group saw (the first multi-GPU lease should yield a curve, not a debugging session)
+    def gather_f64(v):
+        if world == 1:
+            return [float(v)]
+        mine_ = torch.tensor([float(v)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        parts_ = [torch.empty_like(mine_) for _ in range(world)]
+        dist.all_gather(parts_, mine_)
+        return [float(p_.item()) for p_ in parts_]
+
+    per_rank_ms = gather_f64(my_elapsed / K * 1e3)
+    dist_info = {"backend": dist.get_backend() if world > 1 else None, "world_size_seen": dist.get_world_size() if world > 1 else 1,
+                 "ms_per_step_by_rank": [round(v, 3) for v in per_rank_ms],
+                 "trajectory_seed_by_rank": [int(v) for v in gather_f64(1000 + rank)],
+                 "input_checksum_by_rank": gather_f64(float(batch["u"].double().sum()))}
+
+    # ---- per-kernel rooflines, measured live with HIP events on the launch stream (untimed extra passes) BEFORE the training
+    # leg: the part is power limited and runs cooler / faster before 25 GB of training traffic have gone through it
+    roof = roof_sc = None
+    if rank == 0:
+        roof = edge_roofline(model, batch, dev, W, B)
+        roof_sc = scatter_roofline(model, dev, W, B)
+    modes = None
+    if rank == 0 and world == 1 and not args.no_precision_modes and model.edge_gemm in ("fp16x3", "bf16x6", "fp32"):
+        modes = precision_modes(model, batch, elapsed / K * 1e3, dev)
 
     # ---- training step on the same workload ("plus training-step throughput with the all-reduce"):
     # rollout with tape -> HIP backward -> ONE flat gradient all-reduce (RCCL) -> fused Adam.  Reported beside the
@@ -446,101 +721,44 @@ def main():
     train = None
     if args.train_steps > 0:
         from magnet_amd.sharding import allreduce_gradients
+        barrier()
         tmodel = FACTORY["mpnn_2d"](types.SimpleNamespace(**HP)).to(dev).train()
         opt = tmodel.configure_optimizers()["optimizer"]
+        ar_events = []
 
         def train_step():
             opt.zero_grad(set_to_none=True)
             loss = tmodel.training_step(batch, 0)
             loss.backward()
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
             allreduce_gradients(tmodel.parameters())
+            e_.record()
+            ar_events.append((s_, e_))
             opt.step()
             return loss
 
         first = float(train_step().detach())
         barrier()
+        ar_events.clear()
         t0 = time.perf_counter()
         for _ in range(args.train_steps):
             last = train_step()
         barrier()
         t_el = max_over_ranks(time.perf_counter() - t0, dev)
+        n_grad = sum(p_.numel() for p_ in tmodel.parameters())
+        # DDP invariant: identical parameters on every rank after the steps (same init, same averaged gradient, same Adam)
+        psum = float(sum(p_.detach().double().abs().sum() for p_ in tmodel.parameters()))
+        dist_info["param_abs_sum_by_rank_after_training"] = gather_f64(psum)
         train = {"ms_per_step": round(t_el / args.train_steps * 1e3, 3), "steps": args.train_steps, "warmup": 1,
                  "value": world * B * W * W * pred_steps * args.train_steps / t_el, "unit": "mesh-node-updates/s",
                  "what": "free-running rollout with tape + HIP backward + one flat RCCL gradient all-reduce + fused Adam",
+                 "allreduce_ms": round(sum(s_.elapsed_time(e_) for s_, e_ in ar_events) / len(ar_events), 4),
+                 "allreduce_bytes": 4 * n_grad,
                  "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],
                  "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
         del tmodel, opt
         torch.cuda.empty_cache()
-
-    # ---- per-kernel roofline, measured live with HIP events on the launch stream (untimed extra pass)
-    roof = roof_sc = None
-    if rank == 0:
-        csr = model._topo.csr
-        E, N, H = csr.E, csr.N, 128
-        ev = []
-        wdt = model._packed().layers[0].msg2[0].dtype
-        entries = [e for e in (ops.EDGE_ENTRY[wdt], ops.EDGE_ENTRY_L2E.get(wdt)) if e]   # the model picks one of them
-        if wdt == torch.float16:
-            entries.append("magnet_mpnn_edge_fp16x3_t16_f32")
-        origs = {e: getattr(ops.L.lib(), e) for e in entries}
-
-        def timed(orig):
-            def timed_edge(*a):
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                rc = orig(*a)
-                e.record()
-                ev.append((s, e))
-                return rc
-            return timed_edge
-
-        for e_, o_ in origs.items():
-            setattr(ops.L._lib, e_, timed(o_))
-        try:
-            model.validation_step(batch, 0)
-            torch.cuda.synchronize()
-        finally:
-            for e_, o_ in origs.items():
-                setattr(ops.L._lib, e_, o_)
-        ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
-        flops = 2.0 * E * H * H
-        ach = flops / (ms * 1e-3) / 1e12
-        mode = model.edge_gemm
-        nprod = SPLIT_PRODUCTS.get(mode, 1)
-        peak = MFMA_BF16_PEAK_TFLOPS / nprod if mode in SPLIT_PRODUCTS else MFMA_F32_PEAK_TFLOPS
-        kname = {"fp16x3": "k_mpnn_edge16" if hasattr(model._packed().layers[0], "msg2_t16") else "k_mpnn_edge7",
-                 "bf16": "k_mpnn_edge7", "bf16x6": "k_mpnn_edge6"}.get(mode, "k_mpnn_edge2")
-        roof = {"kernel": kname, "bound": "mfma",
-                "achieved": round(ach, 2), "peak": round(peak, 1),
-                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                "launch_ms": round(ms, 4), "launches_timed": len(ev), "flops_per_launch": flops, "gemm_mode": mode,
-                "algorithmic_hbm_bytes": 3 * N * H * 4 + 2 * E * 4 + 4 * (N + 1),
-                "executed_mfma_tflops": round(ach * nprod, 1), "mfma_16bit_dense_peak": MFMA_BF16_PEAK_TFLOPS,
-                "fp32_mfma_peak_for_reference": MFMA_F32_PEAK_TFLOPS,
-                "note": "fp32-class GEMM: operands split into 16-bit pieces on the matrix cores "
-                        f"({nprod} MFMA products per fp32 product, fp32 accumulate); peak = 2500 / {nprod}"}
-        if W == 256 and B == 4 and mode in SPLIT_PRODUCTS:     # the recorded PMC passes are of this exact workload
-            roof["traffic"], roof["traffic_source"] = measured_traffic(kname)
-        msg = torch.randn(E, H, device=dev)
-        out = torch.empty(N, H, device=dev)
-        for _ in range(3):
-            ops.segment_mean(msg, csr.rowptr, N, out)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
-        s.record()
-        for _ in range(reps):
-            ops.segment_mean(msg, csr.rowptr, N, out)
-        e.record()
-        torch.cuda.synchronize()
-        ms_sc = s.elapsed_time(e) / reps
-        nbytes = E * H * 4 + N * H * 4 + 4 * (N + 1)
-        gbs = nbytes / (ms_sc * 1e-3) / 1e9
-        roof_sc = {"kernel": "k_segment_mean<128>", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                   "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(ms_sc, 4),
-                   "bytes_per_launch": nbytes}
-        if W == 256 and B == 4:
-            roof_sc["traffic"], roof_sc["traffic_source"] = measured_traffic("k_segment_mean<128>")
-        del msg, out
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -577,7 +795,8 @@ def main():
                                        f"trajectory), nt={NT}, time_window={tw} -> {pred_steps} predicted steps, {B} trajectories per GPU, "
                                        "radius graph + CSR rebuilt every step",
                            "trajectories_per_gpu": B, "global_trajectories": B * world, "parallelism": f"batch-shard x{world}, no data-path collective"},
-                "roofline": roof, "roofline_scatter": roof_sc, "cpu_baseline": cpu, "training_step": train, **extras}
+                "roofline": roof, "roofline_scatter": roof_sc, "cpu_baseline": cpu, "precision_modes": modes, "dist": dist_info,
+                "training_step": train, **extras}
         print(json.dumps(line))
 
 

@@ -363,6 +363,10 @@ int magnet_mpnn_edge_bwd_f32(const float* A, const float* Bm, const float* dagg,
                              const int32_t* rowptr, int n_nodes, int n_edges, const void* w2_f16, const void* w2t_f16,
                              const float* b2, float* s1, float* dq, float* dp, float* dA, float* partials, void* stream);
 
+/* Measurement utility for bench.py (no reference counterpart): one wave on `stream` samples the shader clock for ~wall_us
+ * microseconds while other streams run the workload.  out[0] = shader-clock ticks, out[1] = constant-rate ticks of the
+ * wall clock whose rate (kHz) is returned through *wall_khz (host pointer): MHz = out[0] / out[1] * wall_khz / 1000. */
+int magnet_clock_probe(long long* out, int wall_us, int* wall_khz, void* stream);
 
 #ifdef __cplusplus
 }

@@ -493,3 +493,32 @@ extern "C" int magnet_segment_mean_f32(const float* msg, const int32_t* rowptr, 
     }
     LAUNCH_CHECK();
 }
+
+// Measurement utility (bench.py `roofline.clock_mhz`, no reference counterpart): ONE wave samples the shader clock for
+// ~wall_us microseconds on `stream` while other streams run the workload; out[0] = shader-clock ticks (s_memtime),
+// out[1] = constant-rate ticks (s_memrealtime).  MHz = out[0] / out[1] * wall_khz / 1000.
+__global__ void __launch_bounds__(64) k_clock_probe(long long* __restrict__ out, long long wall_ticks) {
+    const long long w0 = wall_clock64();
+    const long long c0 = clock64();
+    long long w;
+    do {
+        __builtin_amdgcn_s_sleep(64);
+        w = wall_clock64();
+    } while (w - w0 < wall_ticks);
+    const long long c1 = clock64();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = w - w0;
+    }
+}
+
+extern "C" int magnet_clock_probe(long long* out, int wall_us, int* wall_khz, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
+    int dev = 0, khz = 0;
+    hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) return -2;
+    if (wall_khz) *wall_khz = khz;
+    if (wall_us <= 0 || wall_us > 2000000) return -2;
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, S_, out, (long long)khz * wall_us / 1000);
+    LAUNCH_CHECK();
+}

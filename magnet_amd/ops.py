@@ -227,6 +227,12 @@ EDGE_ENTRY = {torch.float16: "magnet_mpnn_edge_fp16x3_f32", torch.int16: "magnet
 
 
 EDGE_ENTRY_L2E = {torch.float16: "magnet_mpnn_edge_fp16x3_l2e_f32", torch.bfloat16: "magnet_mpnn_edge_bf16_l2e_f32"}
+# fp16x3 entry points with their own weight packs (ops.mpnn_edge16 ...), and the kernel behind every entry (bench.py names it)
+EDGE_ENTRY_EXTRA = ("magnet_mpnn_edge_fp16x3_t16_f32",)
+EDGE_KERNEL_OF_ENTRY = {"magnet_mpnn_edge_fp16x3_t16_f32": "k_mpnn_edge16", "magnet_mpnn_edge_fp16x3_f32": "k_mpnn_edge7",
+                        "magnet_mpnn_edge_fp16x3_l2e_f32": "k_mpnn_edge7", "magnet_mpnn_edge_bf16_f32": "k_mpnn_edge7",
+                        "magnet_mpnn_edge_bf16_l2e_f32": "k_mpnn_edge7", "magnet_mpnn_edge_bf16x6_f32": "k_mpnn_edge6",
+                        "magnet_mpnn_edge_f32": "k_mpnn_edge2"}
 LOG2E = 1.4426950408889634
 
 

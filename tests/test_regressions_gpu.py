@@ -365,3 +365,28 @@ def test_bench_launches_its_own_ranks():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_trajectories"] == 2 and line["value"] > 0
     assert line["training_step"]["ms_per_step"] > 0
+
+
+def test_bench_eight_ranks_on_one_gpu_over_gloo():
+    """Multi-GPU readiness without the hardware (README.md:124-125 `trainer.gpus=N trainer.strategy=ddp`): the complete
+    `--gpus 8` control flow - eight fresh ranks, rendezvous, batch sharding, barriers, max-over-ranks timing, the flat gradient
+    all-reduce, fused Adam - on this box's single GPU over gloo.  Every rank must own different trajectories, the process group
+    must have seen 8 ranks, and after two training steps all ranks must hold identical parameters (DDP's invariant)."""
+    env = dict(os.environ, MAGNET_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--mesh", "64", "--traj", "1", "--steps", "2",
+                        "--warmup", "1", "--train-steps", "2", "--no-cpu-baseline", "--no-extra-cases", "--no-precision-modes"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["global_trajectories"] == 8 and line["value"] > 0
+    d = line["dist"]
+    assert d["backend"] == "gloo" and d["world_size_seen"] == 8 and len(d["ms_per_step_by_rank"]) == 8
+    assert sorted(d["trajectory_seed_by_rank"]) == list(range(1000, 1008))
+    assert len(set(d["input_checksum_by_rank"])) == 8                  # eight different sets of trajectories
+    ps = d["param_abs_sum_by_rank_after_training"]
+    assert len(ps) == 8 and all(p == ps[0] for p in ps), ps            # bitwise identical parameters on every rank
+    t = line["training_step"]
+    assert t["ms_per_step"] > 0 and t["allreduce_ms"] > 0 and t["allreduce_bytes"] > 2_000_000
+    assert t["loss_first_last"][1] != t["loss_first_last"][0]
