@@ -687,6 +687,7 @@ def main():
     barrier()
     my_elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(my_elapsed, dev)
+    edges_per_traj = model._topo.csr.E // B
     tw = HP["time_window"]
     pred_steps = (NT - tw) // tw * tw
     value = world * B * W * W * pred_steps * K / elapsed
@@ -791,7 +792,7 @@ def main():
                 "value": value, "unit": "mesh-node-updates/s", "n_gpus": world, "steps": K, "warmup": Wm,
                 "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": DTYPE_NOTE[model.edge_gemm], "data": "synthetic", "deviation_vs_f32_path": deviation,
-                "config": {"workload": f"mpnn_2d free-running rollout, {W}x{W} regular mesh (N={W * W}, E={model._topo.csr.E // B} per "
+                "config": {"workload": f"mpnn_2d free-running rollout, {W}x{W} regular mesh (N={W * W}, E={edges_per_traj} per "
                                        f"trajectory), nt={NT}, time_window={tw} -> {pred_steps} predicted steps, {B} trajectories per GPU, "
                                        "radius graph + CSR rebuilt every step",
                            "trajectories_per_gpu": B, "global_trajectories": B * world, "parallelism": f"batch-shard x{world}, no data-path collective"},

@@ -173,6 +173,15 @@ int magnet_mpnn_edge_bf16_l2e_f32(const float* A_l2e, const float* Bm_l2e, const
 int magnet_mpnn_edge_fp16x3_t16_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
                                     const int32_t* rowptr, int n_edges, int n_rows, const void* w2_t16, const float* b2,
                                     float* agg, float* partials, int a_bm_log2e_scaled, void* stream);
+/* The fp16x3 edge op by the TRANSPOSED 32-edge-tile kernel (k_mpnn_edge32t, generation 9): the tile's edges are
+ * the rows of the 32x32x16 MFMA, a lane owns an output feature, the per-target mean is a running sum over accumulator registers
+ * (no LDS transposition), and the three products of the split share ONE accumulator.  Same result contract as
+ * magnet_mpnn_edge_fp16x3_f32.  w2_t32: fp16 planes [8 k slots][4 output blocks][2 planes][64 lanes][8 fp16], both pre-scaled by
+ * 2^11 (magnet_amd/packing.py:pack_edge32t_fp16x2; needs |w| < 31.98); b2 the plain bias; a_bm_log2e_scaled as for _t16.
+ * partials: scratch, ceil(n_edges / 32) * 2 * 128 floats (two rows per wave range, at most one range per tile). */
+int magnet_mpnn_edge_fp16x3_t32_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
+                                    const int32_t* rowptr, int n_edges, int n_rows, const void* w2_t32, const float* b2,
+                                    float* agg, float* partials, int a_bm_log2e_scaled, void* stream);
 /* out[n][k] = u[n][tw-1] + dt*(k+1) * Conv1d(8->1,k2)([Swish](Conv1d(1->8,k1,stride s1)(h[n])))[k];
  * models/mpnn.py:197-201 with the conv specs of :140-163. */
 int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1, int k1,

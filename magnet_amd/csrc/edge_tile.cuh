@@ -164,3 +164,55 @@ __device__ __forceinline__ void gemm128(const u32x4* __restrict__ wl, const f32x
     for (int nt = 0; nt < 4; ++nt) Split<MODE>::fold(acc[nt], accc[nt]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bookkeeping of the edge kernels that carry their running sums across the tiles of a wave (generations 7-9:
+// mpnn_edge_bf16.hip, mpnn_edge32t.hip)
+struct RunMeta {             // per-lane bookkeeping of one tile (lane j <-> edge j), read back with readlane at run ends
+    int ti, rs, re;
+    unsigned ends;           // wave-uniform: bit e set <=> edge e is the last edge of its run (or of the wave's range)
+};
+
+// indices of one tile, requested two iterations before the tile is computed (nothing on the path waits for them)
+struct TileIdx {
+    int ti, sj, tnext;       // tgt[e], src[e] (clamped to the last edge), tgt[e + 1] or -2 at the end of the wave's range
+    bool e_ok;
+};
+template <int TILE = 32>
+__device__ __forceinline__ TileIdx tile_idx(int tile, int e_end, const int32_t* __restrict__ src,
+                                            const int32_t* __restrict__ tgt, int j) {
+    TileIdx x;
+    const int e_raw = tile * TILE + j;
+    x.e_ok = e_raw < e_end;
+    const int e = x.e_ok ? e_raw : e_end - 1;
+    x.ti = tgt[e];
+    x.sj = src[e];
+    x.tnext = (e_raw + 1 < e_end) ? tgt[e_raw + 1] : -2;      // runs continue across the tiles of one wave
+    return x;
+}
+
+// The run that ends at edge e of the current tile.  A wave walks a contiguous range of tiles and its running sum simply
+// continues across tile boundaries, so only the two runs that cross the ends of the wave's RANGE [e_lo, e_hi) leave as
+// partial sums (partials[range][0 = entered from the previous range | 1 = continues into the next][128]); every other row
+// leaves finished, divided by its degree.  k_edge_range_fixup combines the few partials in range order (deterministic).
+__device__ __forceinline__ void emit_run(const f32x2 acc, const RunMeta& md, int e, int e_lo, int e_hi, int range,
+                                         float deg_scale, float* __restrict__ agg, float* __restrict__ partials, int lane) {
+    const int ti = __builtin_amdgcn_readlane(md.ti, e);
+    const int rs = __builtin_amdgcn_readlane(md.rs, e), re = __builtin_amdgcn_readlane(md.re, e);
+    f32x2 o = acc;
+    float* dst;
+    if (rs >= e_lo && re <= e_hi) {
+        const float dn = (float)(re - rs) * deg_scale;
+        o[0] = o[0] / dn;
+        o[1] = o[1] / dn;
+        dst = agg + (size_t)ti * 128;
+    } else {
+        dst = partials + ((size_t)range * 2 + (rs < e_lo ? 0 : 1)) * 128;
+    }
+    *reinterpret_cast<f32x2*>(dst + 2 * lane) = o;
+}
+
+
+// k_edge_range_fixup (mpnn_edge_bf16.hip): rows without edges become 0, the rows crossing range boundaries are assembled from
+// `partials`.  tshift = log2(edges per tile), tpw / nranges exactly as the edge kernel computed them.
+int magnet_launch_edge_range_fixup(const int32_t* tgt, const int32_t* rowptr, int n_rows, int n_edges, int tpw, int tshift,
+                                   int nranges, float deg_scale, const float* partials, float* agg, void* stream);

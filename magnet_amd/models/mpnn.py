@@ -23,7 +23,7 @@ from torch import nn
 
 from .. import ops
 from ..lightning_compat import LightningModule
-from ..packing import GEMM_MODES, default_gemm, pack, pack_edge16_fp16x2, pad_to
+from ..packing import GEMM_MODES, default_gemm, pack, pack_edge16_fp16x2, pack_edge32t_fp16x2, pad_to
 from ..graphs import RolloutGraph, capturing, hold, wants_graph
 from ..topo_cache import TopologyCache
 
@@ -94,6 +94,8 @@ class MPNN(LightningModule):
         self.edge_l2e = bool(int(os.environ.get("MAGNET_EDGE_L2E", "1"))) and bool(getattr(hparams, "edge_l2e", True))
         # inference, fp16x3: 16-edge tiles with two waves per SIMD (k_mpnn_edge16) instead of 32-edge tiles (A/B knob)
         self.edge_t16 = bool(int(os.environ.get("MAGNET_EDGE_T16", "1"))) and bool(getattr(hparams, "edge_t16", True))
+        # fp16x3: the transposed 32-edge-tile kernel (k_mpnn_edge32t, generation 9) instead of k_mpnn_edge16 (A/B knob)
+        self.edge_t32 = bool(int(os.environ.get("MAGNET_EDGE_T32", "0"))) and bool(getattr(hparams, "edge_t32", True))
         assert self.edge_gemm in GEMM_MODES
         self.gemm = getattr(hparams, "gemm", self.edge_gemm)     # node-level Linears (same two choices)
         # backward-data GEMMs: gradients of a mean loss are ~1e-7, inside fp16's subnormal range, so the fp16 split is
@@ -148,6 +150,11 @@ class MPNN(LightningModule):
             L.msg2 = pack(m2.weight, m2.bias, self.edge_gemm)
             if self.edge_t16 and self.edge_gemm == "fp16x3":
                 L.msg2_t16 = pack_edge16_fp16x2(m2.weight, m2.bias)
+            if self.edge_t32 and self.edge_gemm == "fp16x3":
+                try:
+                    L.msg2_t32 = pack_edge32t_fp16x2(m2.weight, m2.bias)
+                except ValueError:              # |w| >= 31.98: the pre-scaled high plane would overflow; this layer keeps the 16-edge kernel
+                    pass
             cmap = torch.cat([torch.arange(2 * H), torch.tensor([2 * H + tw + dp])])   # var column inside node_in
             L.upd1 = pack(u1.weight, u1.bias, self.gemm, k_pad=2 * H + kin, col_map=cmap)
             L.upd2 = pack(u2.weight, u2.bias, self.gemm)
@@ -216,7 +223,9 @@ class MPNN(LightningModule):
             else:
                 ops.mlp(N, ops.ktiles(T(h, H), T(node_in, kin)), [pa, pb], nl=1, ht=4, ot=4,
                         act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2, groups_in_block=True, y_group_stride=N * H)
-            if hasattr(lyr, "msg2_t16"):          # training forward too (plain halves: l2e is False with a tape)
+            if hasattr(lyr, "msg2_t32"):          # training forward too (plain halves: l2e is False with a tape)
+                ops.mpnn_edge32t(A, Bm, csr, lyr.msg2_t32[0], lyr.msg2_t32[1], agg, partials, l2e=l2e)
+            elif hasattr(lyr, "msg2_t16"):
                 ops.mpnn_edge16(A, Bm, csr, lyr.msg2_t16[0], lyr.msg2_t16[1], agg, partials, l2e=l2e)
             else:
                 ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials, l2e=l2e)

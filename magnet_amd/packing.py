@@ -129,6 +129,26 @@ def pack_edge16_fp16x2(w: torch.Tensor, b: torch.Tensor | None):
     return out.view(-1), bp
 
 
+def pack_edge32t_fp16x2(w: torch.Tensor, b: torch.Tensor | None):
+    """message_net_2 (128 x 128) for the transposed 32-edge-tile edge kernel (k_mpnn_edge32t, magnet_amd/csrc/mpnn_edge32t.hip):
+    fp16 planes in the v_mfma_f32_32x32x16_f16 B-operand order [8 k slots][4 output blocks][2 planes][64 lanes][8 fp16] - lane l
+    of (s, nt) holds W[32 nt + (l & 31)][16 s + 8 (l >> 5) + 0..7].  Both planes carry the factor 2^11: plane 0 = 2^11 fp16(w),
+    plane 1 = 2^11 (w - fp16(w)), so that all three products of the fp16x3 split (h.hw, h.lw, l.hw with the activation's low
+    piece l UNSCALED) land in one accumulator on a common scale.  Raises ValueError when 2^11 |w| leaves the fp16 range
+    (|w| >= 31.98): the caller keeps the 16-edge kernel then."""
+    assert tuple(w.shape) == (128, 128), w.shape
+    h, lo = split_fp16x2(w)
+    if float(h.float().abs().max()) * 2048.0 >= 65504.0:
+        raise ValueError("pack_edge32t_fp16x2: |w| >= 31.98 does not survive the 2^11 pre-scaling of the high plane")
+    hs = (h.float() * 2048.0).half()                      # exact: a power-of-two scaling inside the fp16 range
+    planes = [pl.view(4, 32, 8, 2, 8).permute(2, 0, 3, 1, 4).reshape(8, 4, 64, 8) for pl in (hs, lo)]
+    out = torch.stack(planes, dim=2).contiguous()            # [s, nt, plane, lane, 8]
+    bp = torch.zeros(128, dtype=torch.float32, device=w.device)
+    if b is not None:
+        bp[:] = b.detach().float()
+    return out.view(-1), bp
+
+
 def pack_linear_bf16x1(w: torch.Tensor, b: torch.Tensor | None, k_pad: int | None = None, n_pad: int | None = None,
                        col_map: torch.Tensor | None = None):
     """ONE bf16 plane (round-to-nearest-even) in MFMA fragment order [kt][nt][m][1][lane][8] (bfloat16) + padded fp32 bias:

@@ -54,3 +54,12 @@ for l2e in (False, True):
     ms = min(timeit(lambda: ops.mpnn_edge(Ax, Bx, csr, w7[0], w7[1], agg, partials, l2e=l2e)) for _ in range(3))
     print(f"k_mpnn_edge7 (32-edge tiles, 1 wave/SIMD) l2e={l2e} : {ms:.4f} ms  frac of 833 = "
           f"{2 * E * H * H / ms / 1e9 / 833.3:.3f}, rel-diff vs fp32 kernel {float((agg - ref).norm() / ref.norm()):.2e} nan={int(torch.isnan(agg).sum())}")
+
+from magnet_amd.packing import pack_edge32t_fp16x2
+w32t = pack_edge32t_fp16x2(m2.weight, m2.bias)
+for l2e in (False, True):
+    agg.fill_(float("nan"))
+    Ax, Bx = (A2, B2) if l2e else (A, Bm)
+    ms = min(timeit(lambda: ops.mpnn_edge32t(Ax, Bx, csr, w32t[0], w32t[1], agg, partials, l2e=l2e)) for _ in range(3))
+    print(f"k_mpnn_edge32t (generation 9: transposed 32-edge tiles, 1 wave/SIMD) l2e={l2e} : {ms:.4f} ms  frac of 833 = "
+          f"{2 * E * H * H / ms / 1e9 / 833.3:.3f}, rel-diff vs fp32 kernel {float((agg - ref).norm() / ref.norm()):.2e} nan={int(torch.isnan(agg).sum())}")

@@ -259,39 +259,49 @@ def test_mpnn_edge_log2e_scaled_inputs_give_the_same_mean():
         assert rel_l2(got, ref) < tol, (mode, rel_l2(got, ref))
 
 
-@pytest.mark.parametrize("case", ["ragged", "no_edges", "under_one_tile", "one_row_owns_everything"])
+@pytest.mark.parametrize("case", ["ragged", "no_edges", "under_one_tile", "one_row_owns_everything", "every_row_one_edge",
+                                  "small_values"])
 @pytest.mark.parametrize("l2e", [False, True])
-def test_mpnn_edge16_matches_host_evaluation(case, l2e):
-    """k_mpnn_edge16 (16-edge tiles, v_mfma_f32_16x16x32_f16, two waves per SIMD, its own weight fragment order) against a
-    host evaluation on a ragged graph (empty rows, rows across many tiles, E % 16 != 0) and the range-partials corner cases."""
+@pytest.mark.parametrize("kernel", ["edge16", "edge32t"])
+def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
+    """k_mpnn_edge16 (16-edge tiles, v_mfma_f32_16x16x32_f16, two waves per SIMD, its own weight fragment order) and k_mpnn_edge32t
+    (generation 9: transposed 32-edge tiles, lane = output feature, one accumulator, unscaled fp16-subnormal low pieces) against a
+    host evaluation on a ragged graph (empty rows, rows across many tiles, E % 16 != 0), the range-partials corner cases, a
+    graph whose every tile is full of run ends, and inputs small enough that every low piece is an fp16 subnormal."""
     from magnet_amd import ops
-    from magnet_amd.packing import pack_edge16_fp16x2
+    from magnet_amd.packing import pack_edge16_fp16x2, pack_edge32t_fp16x2
     from oracle.pyg_semantics import scatter_mean
     torch.manual_seed(3)
     H = 128
-    if case == "ragged":
+    if case in ("ragged", "small_values"):
         n = 301
         rowptr, tgt = _random_csr(n, 45, seed=5, long_rows=3)
     else:
         n, deg = {"no_edges": (5, [0] * 5), "under_one_tile": (6, [3, 0, 7, 1, 0, 2]),
-                  "one_row_owns_everything": (3, [0, 40001, 0])}[case]
+                  "one_row_owns_everything": (3, [0, 40001, 0]), "every_row_one_edge": (3001, [1, 2] * 1500 + [1])}[case]
         rowptr = torch.zeros(n + 1, dtype=torch.int32)
         rowptr[1:] = torch.tensor(deg).cumsum(0)
         tgt = torch.repeat_interleave(torch.arange(n), torch.tensor(deg))
     E = tgt.numel()
     src = torch.randint(0, n, (E,))
     A, Bm = torch.randn(n, H), torch.randn(n, H)
+    if case == "small_values":                 # Swish(A + Bm) ~ 1e-3: the low pieces of the activations are fp16 subnormals
+        A, Bm = A * 2e-3, Bm * 2e-3
     lin = torch.nn.Linear(H, H)
     sw = lambda x: x * torch.sigmoid(x)  # noqa: E731
     with torch.no_grad():
         m = sw(lin.double()(sw((A[tgt.long()] + Bm[src.long()]).double())))
     want = scatter_mean(m, tgt.long(), n) if E else torch.zeros(n, H, dtype=torch.float64)
     csr = ops.CSR(rowptr.int().cuda(), src.int().cuda(), tgt.int().cuda(), n, E)
-    w, b = pack_edge16_fp16x2(lin.weight.cuda(), lin.bias.cuda())
     agg = torch.full((n, H), float("nan"), device="cuda")
     partials = torch.zeros(ops.edge_scratch_floats(E), device="cuda")
     scale = ops.LOG2E if l2e else 1.0
-    ops.mpnn_edge16(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e)
+    if kernel == "edge16":
+        w, b = pack_edge16_fp16x2(lin.weight.cuda(), lin.bias.cuda())
+        ops.mpnn_edge16(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e)
+    else:
+        w, b = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
+        ops.mpnn_edge32t(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e)
     assert not torch.isnan(agg).any()
     if E:
         # a 40 001-term fp32 running sum (one row owning every edge) carries ~1e-6 of rounding by itself

@@ -148,7 +148,7 @@ def test_captured_rollouts_outlive_the_caches_they_were_built_from(tag):
     junk = [torch.full((n,), float("nan"), device="cuda") for n in (64, 257, 1024, 4096, 16385, 65536, 300000) for _ in range(6)]
     torch.cuda.synchronize()
     again = model.validation_step(A, 0)
-    assert len(model._rollout_graph._entries) == 3                     # A was replayed, not re-captured
+    assert len(model._rollout_graph._entries) == 2                     # A was replayed, not re-captured (the two slices share a key)
     assert torch.equal(first, again)
     del junk
     with torch.no_grad():
