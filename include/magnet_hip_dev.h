@@ -7,7 +7,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* which = 0: kernel behind magnet_mpnn_edge_f32 (102 = product); which = 1: generation / ablation of the split-GEMM edge kernels */
+/* which = 0: kernel behind magnet_mpnn_edge_f32 (102 = product); which = 1: generation / ablation of the split-GEMM edge kernels;
+ * which = 2: ablation flags of k_mpnn_edge32t (1 no MFMA, 2 no epilogue transcendentals, 4 no input Swish / split, 8 L1-resident
+ * gathers, 16 no LDS weight reads; only the combinations instantiated in mpnn_edge32t.hip) */
 int magnet_debug_set_variant(int which, int value);
 /* run-time ablation flags of the split-GEMM MLP kernel */
 int magnet_debug_set_mlp_ablation(int value);

@@ -37,6 +37,9 @@ typedef unsigned int u32;
 namespace {
 
 constexpr float E9_SCALE = 2048.0f;        // every MFMA product carries 2^11 (host-scaled weight planes)
+#ifndef E9_VALU_PER_MFMA
+#define E9_VALU_PER_MFMA 8               // VALU instructions hipcc places behind every MFMA of a double group (sched_group_barrier)
+#endif
 
 __device__ __forceinline__ f32x16 mfma_xw(const u32x4& x, const u32x4& w, const f32x16& c) {
     // A operand = activations (row = edge = lane & 31), B operand = weights (column = feature = lane & 31)
@@ -86,7 +89,20 @@ __device__ __forceinline__ void e9_settle(f32x16 (&t)[4]) {
     else asm volatile("" : "+a"(t[0]), "+a"(t[1]), "+a"(t[2]), "+a"(t[3]));
 }
 
-// one output value of the previous tile -> running sum:  x = acc / 2^11 + b,  sum += x / (1 + 2^-x')
+template <bool WAIT>
+__device__ __forceinline__ void e9_settle2(f32x16 (&t)[2]) {
+    if (WAIT) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+a"(t[0]), "+a"(t[1]));
+    else asm volatile("" : "+a"(t[0]), "+a"(t[1]));
+}
+
+// one output value of the previous tile: x = acc / 2^11 + b and r = 1 / (1 + 2^-x'); Swish = x r
+template <bool L2E>
+__device__ __forceinline__ void swish_parts(float a, float bias, float& x, float& r) {
+    x = fmaf(a, 1.0f / E9_SCALE, bias);
+    r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(L2E ? -x : -x * MAGNET_LOG2E));
+}
+
+// ... -> running sum:  sum += x / (1 + 2^-x')
 template <bool L2E>
 __device__ __forceinline__ void swish_accumulate(float a, float bias, float& sum) {
     const float x = fmaf(a, 1.0f / E9_SCALE, bias);
@@ -113,12 +129,29 @@ __device__ __forceinline__ void emit_run64(float s0, float s1, const RunMeta& md
     dst[64 + lane] = s1;
 }
 
+// emit_run64 for ONE feature half (k_mpnn_edge32p: the two halves of a row leave half a tile apart); fcol = 64 p + lane
+__device__ __forceinline__ void emit_run_half(float sv, const RunMeta& md, int e, int e_lo, int e_hi, int range, float deg_scale,
+                                              float* __restrict__ agg, float* __restrict__ partials, int fcol) {
+    const int ti = __builtin_amdgcn_readlane(md.ti, e);
+    const int rs = __builtin_amdgcn_readlane(md.rs, e), re = __builtin_amdgcn_readlane(md.re, e);
+    float* dst;
+    if (rs >= e_lo && re <= e_hi) {
+        sv = sv / ((float)(re - rs) * deg_scale);
+        dst = agg + (size_t)ti * 128;
+    } else {
+        dst = partials + ((size_t)range * 2 + (rs < e_lo ? 0 : 1)) * 128;
+    }
+    dst[fcol] = sv;
+}
+
 // register of edge e inside the swapped accumulator pair: e = 8 g + w -> index 4 g + (w & 3), first (w < 4) or second block
 __device__ __forceinline__ constexpr int e9_reg(int e) { return 4 * (e >> 3) + (e & 3); }
 
 }  // namespace
 
-template <bool L2E>
+// ABL (development builds only, results INVALID): 1 no MFMAs, 2 no epilogue transcendentals, 4 no input Swish / split, 8 gathers from
+// L1-resident rows, 16 no LDS weight reads - to attribute the kernel's time (scripts/bench_edge9_abl.py)
+template <bool L2E, int ABL = 0>
 __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict__ A, const float* __restrict__ Bm,
                                                          const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
                                                          const int32_t* __restrict__ rowptr, int E,
@@ -159,8 +192,13 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
     auto consume = [&](int entry, int slot, int hf) {
         u32 h0, l0, h1, l1;
         const f32x4 a = la[entry][hf], b = lb[entry][hf];
-        swish_split_pair<L2E>(a[0] + b[0], a[1] + b[1], h0, l0);
-        swish_split_pair<L2E>(a[2] + b[2], a[3] + b[3], h1, l1);
+        if (ABL & 4) {
+            h0 = __builtin_bit_cast(u32, a[0] + b[0]), l0 = __builtin_bit_cast(u32, a[1] + b[1]);
+            h1 = __builtin_bit_cast(u32, a[2] + b[2]), l1 = __builtin_bit_cast(u32, a[3] + b[3]);
+        } else {
+            swish_split_pair<L2E>(a[0] + b[0], a[1] + b[1], h0, l0);
+            swish_split_pair<L2E>(a[2] + b[2], a[3] + b[3], h1, l1);
+        }
         asm volatile("" : "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1));      // pinned to its double group (see k_mpnn_edge7)
         xh[slot][2 * hf] = h0, xh[slot][2 * hf + 1] = h1;
         xl[slot][2 * hf] = l0, xl[slot][2 * hf + 1] = l1;
@@ -204,8 +242,8 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
         md1.ti = ix1.ti;
         md1.rs = rowptr[ix1.ti];
         md1.re = rowptr[ix1.ti + 1];
-        const float* pan = A + (size_t)ix1.ti * 128 + 8 * half;       // clamped: the last iteration prefetches unused data
-        const float* pbn = Bm + (size_t)ix1.sj * 128 + 8 * half;
+        const float* pan = A + (size_t)((ABL & 8) ? j : ix1.ti) * 128 + 8 * half;       // clamped: the last iteration prefetches unused data
+        const float* pbn = Bm + (size_t)((ABL & 8) ? j : ix1.sj) * 128 + 8 * half;
         u32x4 wr[2][2][2];                    // weight fragments: [buffer][block of the pair][plane]
         float late0[4], late1[4];             // second halves of the swapped registers of the current group of eight edges
 #pragma unroll
@@ -222,12 +260,23 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
                 const int s1 = (dg + 1) >> 1, q1 = (dg + 1) & 1;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
+                    if (ABL & 16) continue;
                     wr[(dg + 1) & 1][u][0] = wlane[(((s1 * 4 + 2 * q1 + u) * 2) + 0) * 64];
                     wr[(dg + 1) & 1][u][1] = wlane[(((s1 * 4 + 2 * q1 + u) * 2) + 1) * 64];
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);    // LDS requests first (see k_mpnn_edge7)
-            if (s == 0) {                         // first k slot: the accumulators start from the inline constant 0
+            if (ABL & 1) {                        // no MFMAs: the operands still have to exist
+                if (s == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        cur[n0][i] = __builtin_bit_cast(float, xh[s][i] ^ wr[bsel][0][0][i] ^ wr[bsel][0][1][i]);
+                        cur[n1][i] = __builtin_bit_cast(float, xl[s][i] ^ wr[bsel][1][0][i] ^ wr[bsel][1][1][i]);
+                    }
+                } else {
+                    cur[n0][s] = __builtin_bit_cast(float, xh[s][0] ^ wr[bsel][0][0][1] ^ wr[bsel][0][1][2]);
+                    cur[n1][s] = __builtin_bit_cast(float, xl[s][1] ^ wr[bsel][1][0][3] ^ wr[bsel][1][1][0]);
+                }
+            } else if (s == 0) {                  // first k slot: the accumulators start from the inline constant 0
                 const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 cur[n0] = mfma_xw(xh[s], wr[bsel][0][1], z);
                 cur[n1] = mfma_xw(xh[s], wr[bsel][1][1], z);
@@ -235,11 +284,16 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
                 cur[n0] = mfma_xw(xh[s], wr[bsel][0][1], cur[n0]);
                 cur[n1] = mfma_xw(xh[s], wr[bsel][1][1], cur[n1]);
             }
-            cur[n0] = mfma_xw(xh[s], wr[bsel][0][0], cur[n0]);
-            cur[n1] = mfma_xw(xh[s], wr[bsel][1][0], cur[n1]);
-            cur[n0] = mfma_xw(xl[s], wr[bsel][0][0], cur[n0]);
-            cur[n1] = mfma_xw(xl[s], wr[bsel][1][0], cur[n1]);
-            // ---- epilogue of the previous tile, edges 2 dg and 2 dg + 1
+            if (!(ABL & 1)) {
+                cur[n0] = mfma_xw(xh[s], wr[bsel][0][0], cur[n0]);
+                cur[n1] = mfma_xw(xh[s], wr[bsel][1][0], cur[n1]);
+                cur[n0] = mfma_xw(xl[s], wr[bsel][0][0], cur[n0]);
+                cur[n1] = mfma_xw(xl[s], wr[bsel][1][0], cur[n1]);
+            }
+            // ---- epilogue of the previous tile, edges 2 dg and 2 dg + 1, up to the reciprocal: x = acc / 2^11 + b, r = 1 / (1 + 2^-x);
+            // the accumulation sum += x r sits behind ONE run-end branch per double group (below), so that everything else of the
+            // double group is a single basic block in which the MFMAs and the VALU work can be interleaved
+            float xv[2][2], rv[2][2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int e = 2 * dg + c, r = e9_reg(e), w = e & 7;
@@ -251,12 +305,11 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
                     v0 = late0[w - 4];
                     v1 = late1[w - 4];
                 }
-                swish_accumulate<L2E>(v0, bias0, sum0);
-                swish_accumulate<L2E>(v1, bias1, sum1);
-                if (pmd.ends & (1u << e)) {
-                    emit_run64(sum0, sum1, pmd, e, e_lo, e_hi, range, deg_scale, agg, partials, lane);
-                    sum0 = 0.f;
-                    sum1 = 0.f;
+                if (ABL & 2) {
+                    xv[c][0] = v0, rv[c][0] = bias0, xv[c][1] = v1, rv[c][1] = bias1;
+                } else {
+                    swish_parts<L2E>(v0, bias0, xv[c][0], rv[c][0]);
+                    swish_parts<L2E>(v1, bias1, xv[c][1], rv[c][1]);
                 }
             }
             // ---- inputs: slot 7 of THIS tile in double groups 0 / 1, slots 0-6 of the next tile in double groups 2-15
@@ -270,12 +323,38 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
                 if (sr < 8) {
                     request(sr & 3, sr, pan, pbn);
                 } else {                          // slots 0 / 1 of tile + 2
-                    const float* pa2 = A + (size_t)ix2.ti * 128 + 8 * half;
-                    const float* pb2 = Bm + (size_t)ix2.sj * 128 + 8 * half;
+                    const float* pa2 = A + (size_t)((ABL & 8) ? j : ix2.ti) * 128 + 8 * half;
+                    const float* pb2 = Bm + (size_t)((ABL & 8) ? j : ix2.sj) * 128 + 8 * half;
                     request(sr & 3, sr - 8, pa2, pb2);
                 }
             }
+            // ---- the order hipcc has to emit this block in: the LDS requests of the next double group first, then every MFMA
+            // followed by its share of the ~50 VALU / transcendental instructions (a wave issues in order: MFMAs back to back
+            // stall the issue for 32 cycles each, VALU issued right behind an MFMA runs in its shadow)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, E9_VALU_PER_MFMA, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
+            // ---- running sums and run ends (wave-uniform): one branch per double group, the emitting path is rare
+            const unsigned m2 = (pmd.ends >> (2 * dg)) & 3u;
+            if (m2 == 0) {
+                sum0 = fmaf(xv[1][0], rv[1][0], fmaf(xv[0][0], rv[0][0], sum0));
+                sum1 = fmaf(xv[1][1], rv[1][1], fmaf(xv[0][1], rv[0][1], sum1));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    sum0 = fmaf(xv[c][0], rv[c][0], sum0);
+                    sum1 = fmaf(xv[c][1], rv[c][1], sum1);
+                    if (m2 & (1u << c)) {
+                        emit_run64(sum0, sum1, pmd, 2 * dg + c, e_lo, e_hi, range, deg_scale, agg, partials, lane);
+                        sum0 = 0.f;
+                        sum1 = 0.f;
+                    }
+                }
+            }
         }
         pmd = md;
         md1.ends = (unsigned)__builtin_amdgcn_ballot_w64(ix1.e_ok && ix1.tnext != ix1.ti);
@@ -322,6 +401,211 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
     else tail(accB);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same tile, TWO waves per SIMD (512-thread workgroups): k_mpnn_edge32p.  k_mpnn_edge32t keeps two full sets of
+// accumulators (this tile's and the previous tile's, 128 registers) and ~390 registers in all; one wave per SIMD then has nobody to
+// fill its s_waitcnt and dependency stalls (SQ counters: 27 % of the wave cycles).  Here the tile is computed as two PAIRS of
+// 32-feature blocks, one after the other (double group dg = 8 np + s: pair np, k slot s), so that only two pairs of accumulators
+// are alive at any time (64 registers): while pair 0 of tile t accumulates (dg 0-7) the epilogue of pair 1 of tile t-1 runs in the
+// MFMA shadows, and while pair 1 accumulates (dg 8-15) the epilogue of pair 0 of THIS tile runs.  The activations of the
+// tile serve both passes, so the inputs of tile t+1 can only replace them during the second pass (slot sc in double group
+// 9 + sc, slot 7 in double group 0 of the next tile); their gathered rows are requested E9P_LEAD double groups earlier into a
+// ring of E9P_LEAD register sets - a short lead (the loads take ~2 000 cycles under load), but the partner wave runs meanwhile.
+#ifndef E9P_LEAD
+#define E9P_LEAD 2
+#endif
+template <bool L2E>
+__global__ void __launch_bounds__(512, 2) k_mpnn_edge32p(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                         const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
+                                                         const int32_t* __restrict__ rowptr, int E,
+                                                         const u32x4* __restrict__ w2p /* [8 s][4 nt][2 planes][64] */,
+                                                         const float* __restrict__ b2, float* __restrict__ agg,
+                                                         float* __restrict__ partials) {
+    constexpr float deg_scale = L2E ? MAGNET_LOG2E : 1.0f;
+    constexpr int NR = E9P_LEAD;                                       // ring entries
+    __shared__ __attribute__((aligned(16))) u32x4 wl[8 * 4 * 2 * 64];  // 64 KiB
+    for (int i = threadIdx.x; i < 8 * 4 * 2 * 64; i += 512) wl[i] = w2p[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    const int ntiles = (E + 31) / 32;
+    const int nb8 = gridDim.x / 8;         // XCD-aware contiguous ranges, see k_mpnn_edge6
+    const int vb = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * nb8 + blockIdx.x / 8 : blockIdx.x;
+    const int tpw = (ntiles + gridDim.x * 8 - 1) / (gridDim.x * 8);
+    const int range = vb * 8 + wave;
+    int tile = range * tpw;
+    const int tend = min(tile + tpw, ntiles);
+    if (tile >= tend) return;
+    const int e_lo = tile * 32, e_hi = min(tend * 32, E);           // this wave's edges
+    const float bias0 = b2[lane] * deg_scale, bias1 = b2[64 + lane] * deg_scale;
+    const u32x4* const wlane = wl + lane;
+
+    u32x4 xh[8], xl[8];                       // fp16 pieces of the current tile's activations, one k slot each
+    f32x4 la[NR][2], lb[NR][2];               // gather ring
+    f32x16 P0[2], P1[2];                      // accumulators of pair 0 (features 0-63) and pair 1 (features 64-127)
+    float sum0 = 0.f, sum1 = 0.f;             // running sums of the two feature halves (they run half a tile apart)
+
+    auto request = [&](int entry, int slot, const float* pa, const float* pb) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            la[entry][g] = *reinterpret_cast<const f32x4*>(pa + 16 * slot + 4 * g);
+            lb[entry][g] = *reinterpret_cast<const f32x4*>(pb + 16 * slot + 4 * g);
+        }
+    };
+    auto consume = [&](int entry, int slot) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            u32 h0, l0, h1, l1;
+            const f32x4 a = la[entry][hf], b = lb[entry][hf];
+            swish_split_pair<L2E>(a[0] + b[0], a[1] + b[1], h0, l0);
+            swish_split_pair<L2E>(a[2] + b[2], a[3] + b[3], h1, l1);
+            xh[slot][2 * hf] = h0, xh[slot][2 * hf + 1] = h1;
+            xl[slot][2 * hf] = l0, xl[slot][2 * hf + 1] = l1;
+        }
+    };
+
+    TileIdx ix = tile_idx<32>(tile, e_hi, src, tgt, j);
+    RunMeta md;
+    {   // prologue: the first tile's eight slots
+        const float* pa = A + (size_t)ix.ti * 128 + 8 * half;
+        const float* pb = Bm + (size_t)ix.sj * 128 + 8 * half;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            request(s % NR, s, pa, pb);
+            consume(s % NR, s);
+        }
+        md.ti = ix.ti;
+        md.rs = rowptr[ix.ti];
+        md.re = rowptr[ix.ti + 1];
+        md.ends = (unsigned)__builtin_amdgcn_ballot_w64(ix.e_ok && ix.tnext != ix.ti);   // both halves agree: low word
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) P1[u][i] = 0.f;               // "previous tile" of the first iteration (its sum is dropped)
+    }
+    RunMeta pmd = md;
+    pmd.ends = 0;                              // no previous tile yet: nothing leaves in the first half of the first iteration
+
+    // four edges of one accumulator pair -> x and r of their Swish (lane = feature of the pair)
+    auto pair_edges = [&](f32x16 (&P)[2], int g4 /* 0..7: edges 4 g4 .. 4 g4 + 3 */, float bias, float (&late)[4], float (&xv)[4],
+                          float (&rv)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int e = 4 * g4 + c, r = e9_reg(e), w = e & 7;
+            float v;
+            if (w < 4) lane_half_swap(P[0][r], P[1][r], v, late[w]);
+            else v = late[w - 4];
+            swish_parts<L2E>(v, bias, xv[c], rv[c]);
+        }
+    };
+    auto accumulate = [&](const float (&xv)[4], const float (&rv)[4], unsigned m4, int e0, float& sum, const RunMeta& meta,
+                          int foff) __attribute__((always_inline)) {
+        if (m4 == 0) {
+            sum = fmaf(xv[3], rv[3], fmaf(xv[2], rv[2], fmaf(xv[1], rv[1], fmaf(xv[0], rv[0], sum))));
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                sum = fmaf(xv[c], rv[c], sum);
+                if (m4 & (1u << c)) {
+                    emit_run_half(sum, meta, e0 + c, e_lo, e_hi, range, deg_scale, agg, partials, foff + lane);
+                    sum = 0.f;
+                }
+            }
+        }
+    };
+
+    bool first = true;
+    for (; tile < tend; ++tile) {
+        const TileIdx ixn = tile_idx<32>(min(tile + 1, tend - 1), e_hi, src, tgt, j);   // used from double group 9 - LEAD on
+        RunMeta md1;
+        u32x4 wr[2][2][2];                    // weight fragments: [buffer][block of the pair][plane]
+        float late[4];
+        e9_settle2<false>(P1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            wr[0][u][0] = wlane[(u * 2 + 0) * 64];
+            wr[0][u][1] = wlane[(u * 2 + 1) * 64];
+        }
+        const float* pan = nullptr;
+        const float* pbn = nullptr;
+#pragma unroll
+        for (int dg = 0; dg < 16; ++dg) {
+            const int np = dg >> 3, s = dg & 7, bsel = dg & 1;
+            f32x16(&cur)[2] = np ? P1 : P0;
+            if (dg + 1 < 16) {
+                const int np1 = (dg + 1) >> 3, s1 = (dg + 1) & 7;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    wr[(dg + 1) & 1][u][0] = wlane[(((s1 * 4 + 2 * np1 + u) * 2) + 0) * 64];
+                    wr[(dg + 1) & 1][u][1] = wlane[(((s1 * 4 + 2 * np1 + u) * 2) + 1) * 64];
+                }
+            }
+            // ---- epilogue: pair 1 of the previous tile while pair 0 accumulates, pair 0 of this tile while pair 1 accumulates.
+            // The accumulator reads come BEFORE this double group's MFMAs in program order when they read the pair that is about to
+            // be restarted (dg 8 reads P1 of the previous tile?  no: dg 0-7 read P1, which restarts at dg 8; dg 8-15 read P0, which
+            // restarts at dg 0 of the next tile) - every register is read in an earlier double group than the MFMA that overwrites it.
+            float xv[4], rv[4];
+            if (np == 0) pair_edges(P1, s, bias1, late, xv, rv);
+            else pair_edges(P0, s, bias0, late, xv, rv);
+            if (s == 0) {                         // first k slot: the accumulators start from the inline constant 0
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                cur[0] = mfma_xw(xh[s], wr[bsel][0][1], z);
+                cur[1] = mfma_xw(xh[s], wr[bsel][1][1], z);
+            } else {
+                cur[0] = mfma_xw(xh[s], wr[bsel][0][1], cur[0]);
+                cur[1] = mfma_xw(xh[s], wr[bsel][1][1], cur[1]);
+            }
+            cur[0] = mfma_xw(xh[s], wr[bsel][0][0], cur[0]);
+            cur[1] = mfma_xw(xh[s], wr[bsel][1][0], cur[1]);
+            cur[0] = mfma_xw(xl[s], wr[bsel][0][0], cur[0]);
+            cur[1] = mfma_xw(xl[s], wr[bsel][1][0], cur[1]);
+            // ---- inputs of the next tile: slot sc replaces this tile's slot sc once both passes have used it
+            if (dg >= 9) consume((dg - 9) % NR, dg - 9);
+            if (dg == 0 && !first) consume(7 % NR, 7);                 // (slot 7 of THIS tile, requested by the previous iteration)
+            // ---- gather requests E9P_LEAD double groups ahead (slot sc is consumed in double group 9 + sc; 7 -> dg 0 of the next tile)
+            if (dg == 9 - NR) {
+                pan = A + (size_t)ixn.ti * 128 + 8 * half;             // clamped: the last iteration prefetches unused data
+                pbn = Bm + (size_t)ixn.sj * 128 + 8 * half;
+                md1.ti = ixn.ti;
+                md1.rs = rowptr[ixn.ti];
+                md1.re = rowptr[ixn.ti + 1];
+            }
+            if (dg >= 9 - NR && dg - (9 - NR) < 8) request((dg - (9 - NR)) % NR, dg - (9 - NR), pan, pbn);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, E9_VALU_PER_MFMA, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- running sums and run ends (wave-uniform): one branch per double group
+            if (np == 0) accumulate(xv, rv, (pmd.ends >> (4 * s)) & 15u, 4 * s, sum1, pmd, 64);
+            else accumulate(xv, rv, (md.ends >> (4 * s)) & 15u, 4 * s, sum0, md, 0);
+            if (dg == 7 && first) sum1 = 0.f;    // the first iteration summed the zero "previous tile": drop it
+        }
+        first = false;
+        pmd = md;
+        md1.ends = (unsigned)__builtin_amdgcn_ballot_w64(ixn.e_ok && ixn.tnext != ixn.ti);
+        md = md1;
+    }
+    // pair 1 of the last tile
+    {
+        float late[4];
+        e9_settle2<true>(P1);
+#pragma unroll
+        for (int g4 = 0; g4 < 8; ++g4) {
+            float xv[4], rv[4];
+            pair_edges(P1, g4, bias1, late, xv, rv);
+            accumulate(xv, rv, (pmd.ends >> (4 * g4)) & 15u, 4 * g4, sum1, pmd, 64);
+        }
+    }
+}
+
+#ifdef MAGNET_DEV_VARIANTS
+int g_edge9_ablation = 0;          // development builds only: magnet_debug_set_variant(2, flags), see k_mpnn_edge32t
+#endif
+
 // message_net_2 as fp16 planes [8 k slots][4 output blocks][2 planes][64 lanes][8 fp16], plane 0 = 2^11 fp16(w), plane 1 =
 // 2^11 (w - fp16(w)) (magnet_amd/packing.py:pack_edge32t_fp16x2); b2 the plain fp32 bias.
 extern "C" int magnet_mpnn_edge_fp16x3_t32_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
@@ -339,14 +623,31 @@ extern "C" int magnet_mpnn_edge_fp16x3_t32_f32(const float* A, const float* Bm, 
     }
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (n_edges + 31) / 32;
-    const int nblocks = tiles > 0 ? min((tiles + 3) / 4, ncu) : 0;
+    const bool l2e = (a_bm_log2e_scaled & 1) != 0, paired = (a_bm_log2e_scaled & 2) != 0;     // bit 1: k_mpnn_edge32p (two waves per SIMD)
+    const int wpb = paired ? 8 : 4;
+    const int nblocks = tiles > 0 ? min((tiles + wpb - 1) / wpb, ncu) : 0;
     if (nblocks > 0) {
-        const dim3 g(nblocks), b(256);
+        const dim3 g(nblocks), b(64 * wpb);
         const u32x4* ws = reinterpret_cast<const u32x4*>(w2_t32);
-        if (a_bm_log2e_scaled) hipLaunchKernelGGL(k_mpnn_edge32t<true>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
-        else hipLaunchKernelGGL(k_mpnn_edge32t<false>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+        if (paired) {
+            if (l2e) hipLaunchKernelGGL(k_mpnn_edge32p<true>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+            else hipLaunchKernelGGL(k_mpnn_edge32p<false>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+        } else {
+#ifdef MAGNET_DEV_VARIANTS
+#define E9_ABL_CASE(v) case v: hipLaunchKernelGGL((k_mpnn_edge32t<true, v>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials); break;
+            if (g_edge9_ablation && l2e) {
+                switch (g_edge9_ablation) {
+                    E9_ABL_CASE(1) E9_ABL_CASE(2) E9_ABL_CASE(4) E9_ABL_CASE(6) E9_ABL_CASE(7) E9_ABL_CASE(8) E9_ABL_CASE(16) E9_ABL_CASE(17)
+                    E9_ABL_CASE(31) E9_ABL_CASE(30) E9_ABL_CASE(24)
+                    default: return -2;
+                }
+            } else
+#endif
+            if (l2e) hipLaunchKernelGGL(k_mpnn_edge32t<true>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+            else hipLaunchKernelGGL(k_mpnn_edge32t<false>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+        }
     }
-    const int nranges = nblocks * 4, tpw = nranges ? (tiles + nranges - 1) / nranges : 1;      // as computed inside the kernel
-    return magnet_launch_edge_range_fixup(tgt, rowptr, n_rows, n_edges, tpw, 5, nranges, a_bm_log2e_scaled ? MAGNET_LOG2E : 1.0f,
+    const int nranges = nblocks * wpb, tpw = nranges ? (tiles + nranges - 1) / nranges : 1;      // as computed inside the kernel
+    return magnet_launch_edge_range_fixup(tgt, rowptr, n_rows, n_edges, tpw, 5, nranges, l2e ? MAGNET_LOG2E : 1.0f,
                                           partials, agg, stream);
 }

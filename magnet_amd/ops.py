@@ -262,13 +262,14 @@ def mpnn_edge16(A, Bm, csr, w2_t16, b2, agg, partials, l2e=False):
     return agg
 
 
-def mpnn_edge32t(A, Bm, csr, w2_t32, b2, agg, partials, l2e=False):
+def mpnn_edge32t(A, Bm, csr, w2_t32, b2, agg, partials, l2e=False, paired=False):
     """the same op by the transposed 32-edge-tile kernel (k_mpnn_edge32t, generation 9, fp16x3 only: a lane owns an output
     feature, the mean is a running sum over accumulator registers, one accumulator per output block); w2_t32 from
-    packing.pack_edge32t_fp16x2"""
+    packing.pack_edge32t_fp16x2.  paired: the two-waves-per-SIMD variant k_mpnn_edge32p (the tile as two pairs of 32-feature blocks)"""
     assert w2_t32.dtype == torch.float16 and partials.numel() >= edge_scratch_floats(csr.E)
     L.check(L.lib().magnet_mpnn_edge_fp16x3_t32_f32(_p(A), _p(Bm), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.E, csr.N,
-                                                    _p(w2_t32), _p(b2), _p(agg), _p(partials), int(l2e), _stream()),
+                                                    _p(w2_t32), _p(b2), _p(agg), _p(partials), int(l2e) | (2 if paired else 0),
+                                                    _stream()),
             "mpnn_edge_fp16x3_t32")
     return agg
 

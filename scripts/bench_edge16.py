@@ -57,9 +57,74 @@ for l2e in (False, True):
 
 from magnet_amd.packing import pack_edge32t_fp16x2
 w32t = pack_edge32t_fp16x2(m2.weight, m2.bias)
-for l2e in (False, True):
+for l2e, paired in ((False, False), (True, False), (False, True), (True, True)):
     agg.fill_(float("nan"))
     Ax, Bx = (A2, B2) if l2e else (A, Bm)
-    ms = min(timeit(lambda: ops.mpnn_edge32t(Ax, Bx, csr, w32t[0], w32t[1], agg, partials, l2e=l2e)) for _ in range(3))
-    print(f"k_mpnn_edge32t (generation 9: transposed 32-edge tiles, 1 wave/SIMD) l2e={l2e} : {ms:.4f} ms  frac of 833 = "
+    ms = min(timeit(lambda: ops.mpnn_edge32t(Ax, Bx, csr, w32t[0], w32t[1], agg, partials, l2e=l2e, paired=paired)) for _ in range(3))
+    print(f"k_mpnn_edge32{'p (pairs, 2 waves/SIMD)' if paired else 't (generation 9, 1 wave/SIMD)'} l2e={l2e} : {ms:.4f} ms  frac of 833 = "
           f"{2 * E * H * H / ms / 1e9 / 833.3:.3f}, rel-diff vs fp32 kernel {float((agg - ref).norm() / ref.norm()):.2e} nan={int(torch.isnan(agg).sum())}")
+
+# ---- clock / power under a sustained loop of each kernel (is the part power-limited? DESIGN.md 10.2)
+if os.environ.get("EDGE_CLOCKS", "1") == "1":
+    import ctypes as C, glob, re, subprocess, threading, time
+
+    def sysfs_mhz():
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+            try:
+                for line in open(f):
+                    if "*" in line:
+                        return int(re.search(r"(\d+)\s*[Mm][Hh]z", line).group(1))
+            except Exception:
+                pass
+        return None
+
+    def power_w():
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")) + \
+                sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")):
+            try:
+                return int(open(f).read()) / 1e6
+            except Exception:
+                pass
+        return None
+
+    side = torch.cuda.Stream()
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    khz = C.c_int(0)
+    kernels = {"edge16": lambda: ops.mpnn_edge16(A2, B2, csr, w16[0], w16[1], agg, partials, l2e=True),
+               "edge7": lambda: ops.mpnn_edge(A2, B2, csr, w7[0], w7[1], agg, partials, l2e=True),
+               "edge32t": lambda: ops.mpnn_edge32t(A2, B2, csr, w32t[0], w32t[1], agg, partials, l2e=True),
+               "edge32p": lambda: ops.mpnn_edge32t(A2, B2, csr, w32t[0], w32t[1], agg, partials, l2e=True, paired=True)}
+    print("pp_dpm_sclk:", [open(f).read().replace("\n", " | ") for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")][:1])
+    for name, fn in kernels.items():
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize()
+        samples, pw, stop = [], [], threading.Event()
+
+        def loop():
+            while not stop.is_set():
+                v, p_ = sysfs_mhz(), power_w()
+                if v:
+                    samples.append(v)
+                if p_:
+                    pw.append(p_)
+                stop.wait(0.01)
+
+        th = threading.Thread(target=loop)
+        th.start()
+        t0 = time.perf_counter()
+        side.wait_stream(torch.cuda.current_stream())
+        n = 400
+        for i in range(n):
+            if i == 100:
+                ops.L.lib().magnet_clock_probe(C.c_void_p(out.data_ptr()), 200000, C.byref(khz), C.c_void_p(side.cuda_stream))
+            fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        stop.set()
+        th.join()
+        c, w = (int(v) for v in out.tolist())
+        probe = c / w * khz.value / 1e3 if w else None
+        print(f"{name}: {dt / n * 1e3:.4f} ms per launch sustained, clock probe {probe and round(probe)} MHz, sysfs sclk median "
+              f"{samples and sorted(samples)[len(samples) // 2]} (min {samples and min(samples)}, max {samples and max(samples)}), "
+              f"power median {pw and round(sorted(pw)[len(pw) // 2])} W")

@@ -1,5 +1,5 @@
 # SQ counters of the three fp16x3 edge kernels (scripts/bench_edge16.py launches each ~140 times); summary per kernel
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_edge_r2; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_edge_r3; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/scripts/bench_edge16.py"
 timeout -k 5 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/a -- $CMD > $O/a.log 2>&1

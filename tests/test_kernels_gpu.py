@@ -262,7 +262,7 @@ def test_mpnn_edge_log2e_scaled_inputs_give_the_same_mean():
 @pytest.mark.parametrize("case", ["ragged", "no_edges", "under_one_tile", "one_row_owns_everything", "every_row_one_edge",
                                   "small_values"])
 @pytest.mark.parametrize("l2e", [False, True])
-@pytest.mark.parametrize("kernel", ["edge16", "edge32t"])
+@pytest.mark.parametrize("kernel", ["edge16", "edge32t", "edge32p"])
 def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
     """k_mpnn_edge16 (16-edge tiles, v_mfma_f32_16x16x32_f16, two waves per SIMD, its own weight fragment order) and k_mpnn_edge32t
     (generation 9: transposed 32-edge tiles, lane = output feature, one accumulator, unscaled fp16-subnormal low pieces) against a
@@ -301,7 +301,7 @@ def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
         ops.mpnn_edge16(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e)
     else:
         w, b = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
-        ops.mpnn_edge32t(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e)
+        ops.mpnn_edge32t(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e, paired=kernel == "edge32p")
     assert not torch.isnan(agg).any()
     if E:
         # a 40 001-term fp32 running sum (one row owning every edge) carries ~1e-6 of rounding by itself
