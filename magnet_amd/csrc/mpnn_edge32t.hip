@@ -31,6 +31,7 @@
 //     through a ring of four register sets; tile indices two tiles ahead.
 #include "common.cuh"
 #include "edge_tile.cuh"
+#include <type_traits>
 
 typedef unsigned int u32;
 
@@ -56,6 +57,17 @@ __device__ __forceinline__ void swish_split_pair(float v0, float v1, u32& hw, u3
     asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(v0), "v"(r0));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(v1), "v"(r1));
     // remainder against the fp16 piece read in place: low half for value 0, high half for value 1
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v0), "v"(r0), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v1), "v"(r1), "v"(h));
+    hw = h;
+    lw = l;
+}
+
+// the two fp16 pieces of v0 r0 and v1 r1 (stage 3 of the pipelined Swish: r = 1 / (1 + 2^-v) was computed a double group earlier)
+__device__ __forceinline__ void split_pair_vr(float v0, float r0, float v1, float r1, u32& hw, u32& lw) {
+    u32 h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(v0), "v"(r0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(v1), "v"(r1));
     asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v0), "v"(r0), "v"(h));
     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v1), "v"(r1), "v"(h));
     hw = h;
@@ -150,7 +162,14 @@ __device__ __forceinline__ constexpr int e9_reg(int e) { return 4 * (e >> 3) + (
 }  // namespace
 
 // ABL (development builds only, results INVALID): 1 no MFMAs, 2 no epilogue transcendentals, 4 no input Swish / split, 8 gathers from
-// L1-resident rows, 16 no LDS weight reads - to attribute the kernel's time (scripts/bench_edge9_abl.py)
+// L1-resident rows, 16 no LDS weight reads, 32 no gather loads at all - to attribute the kernel's time (scripts/bench_edge9_abl.py).
+//
+// What the ablations showed (profiles/r3/edge9_ablations.txt): removing the 96 MFMAs of a tile changes NOTHING (1.11 ms either way) -
+// the matrix pipe runs entirely in the shadow of the other ~990 instructions, and those take ~9.5 cycles each although a wave can
+// issue one every ~4.5: a wave issues in order, so every instruction that needs the result of a transcendental (or of another VALU
+// instruction) a few slots earlier stalls the whole stream.  Hence the Swish evaluations are software-pipelined ACROSS double
+// groups: stage 1 (A + Bm / bias fma, 2^-x) in double group k, stage 2 (1 + e, reciprocal) in k + 1, stage 3 (the fp16 pieces /
+// the running sum) in k + 2 - inside one double group no instruction depends on another one of the same group.
 template <bool L2E, int ABL = 0>
 __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict__ A, const float* __restrict__ Bm,
                                                          const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
@@ -180,6 +199,10 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
     f32x4 la[4][2], lb[4][2];                 // gather ring: A[i] / Bm[j] columns 16 s + 8 half + 0..7 of one slot per entry
     f32x16 accA[4], accB[4];                  // GEMM outputs of tile t / tile t - 1 (roles alternate)
     float sum0 = 0.f, sum1 = 0.f;             // running sums of the current run, features lane and 64 + lane
+    // Swish pipelines, four buffers of four values each (three in flight; 16 double groups per tile = a multiple of four, so the
+    // buffer of double group dg is dg & 3 in every tile): inputs iv = A + Bm, iq = 2^-v then 1 / (1 + 2^-v);
+    // outputs ex = acc / 2^11 + b, eq likewise
+    float iv[4][4], iq[4][4], ex[4][4], eq[4][4];
 
     auto request = [&](int entry, int slot, const float* pa, const float* pb) {
 #pragma unroll
@@ -188,18 +211,38 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
             lb[entry][g] = *reinterpret_cast<const f32x4*>(pb + 16 * slot + 4 * g);
         }
     };
-    // half of a slot (four values): ring entry -> two words of each plane
+    auto ex2 = [](float x) { return __builtin_amdgcn_exp2f(L2E ? -x : -x * MAGNET_LOG2E); };
+    // half of a slot (four values), all three stages at once (prologue only)
     auto consume = [&](int entry, int slot, int hf) {
         u32 h0, l0, h1, l1;
         const f32x4 a = la[entry][hf], b = lb[entry][hf];
-        if (ABL & 4) {
-            h0 = __builtin_bit_cast(u32, a[0] + b[0]), l0 = __builtin_bit_cast(u32, a[1] + b[1]);
-            h1 = __builtin_bit_cast(u32, a[2] + b[2]), l1 = __builtin_bit_cast(u32, a[3] + b[3]);
-        } else {
-            swish_split_pair<L2E>(a[0] + b[0], a[1] + b[1], h0, l0);
-            swish_split_pair<L2E>(a[2] + b[2], a[3] + b[3], h1, l1);
+        swish_split_pair<L2E>(a[0] + b[0], a[1] + b[1], h0, l0);
+        swish_split_pair<L2E>(a[2] + b[2], a[3] + b[3], h1, l1);
+        xh[slot][2 * hf] = h0, xh[slot][2 * hf + 1] = h1;
+        xl[slot][2 * hf] = l0, xl[slot][2 * hf + 1] = l1;
+    };
+    // ---- the three stages of the input pipeline (buffer b; stage 3 writes half hf of slot `slot`)
+    auto in1 = [&](int b, int entry, int hf) {
+        const f32x4 a = la[entry][hf], c = lb[entry][hf];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            iv[b][i] = a[i] + c[i];
+            iq[b][i] = (ABL & 4) ? iv[b][i] : ex2(iv[b][i]);
         }
-        asm volatile("" : "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1));      // pinned to its double group (see k_mpnn_edge7)
+    };
+    auto in2 = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) iq[b][i] = (ABL & 4) ? iq[b][i] : __builtin_amdgcn_rcpf(1.0f + iq[b][i]);
+    };
+    auto in3 = [&](int b, int slot, int hf) {
+        u32 h0, l0, h1, l1;
+        if (ABL & 4) {
+            h0 = __builtin_bit_cast(u32, iv[b][0]), l0 = __builtin_bit_cast(u32, iq[b][1]);
+            h1 = __builtin_bit_cast(u32, iv[b][2]), l1 = __builtin_bit_cast(u32, iq[b][3]);
+        } else {
+            split_pair_vr(iv[b][0], iq[b][0], iv[b][1], iq[b][1], h0, l0);
+            split_pair_vr(iv[b][2], iq[b][2], iv[b][3], iq[b][3], h1, l1);
+        }
         xh[slot][2 * hf] = h0, xh[slot][2 * hf + 1] = h1;
         xl[slot][2 * hf] = l0, xl[slot][2 * hf + 1] = l1;
     };
@@ -229,13 +272,39 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) accB[nt][i] = 0.f;            // "previous tile" of the first iteration (its sums are dropped)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) iv[b][i] = iq[b][i] = ex[b][i] = eq[b][i] = 0.f;
     }
-    RunMeta pmd = md;
-    pmd.ends = 0;                              // no previous tile yet: nothing leaves in the first iteration
+    RunMeta pmd = md, ppmd = md;               // meta of the previous tile / of the one before (its last four edges finish two
+    pmd.ends = 0, ppmd.ends = 0;               // double groups into the next tile); no previous tile yet: nothing leaves
+    bool fresh = true;                         // no real tile has been summed yet
     asm volatile("" ::"v"(ix1.ti), "v"(ix1.sj), "v"(ix1.tnext), "v"(md.rs), "v"(md.re));   // see k_mpnn_edge7
 
+    // stage 3 of the output pipeline: sum += x r for the two edges e0, e0 + 1 (both feature halves), run ends leave
+    auto out3 = [&](int b, int e0, const RunMeta& meta) __attribute__((always_inline)) {
+        const unsigned m2 = (meta.ends >> e0) & 3u;
+        if (m2 == 0) {
+            sum0 = fmaf(ex[b][2], eq[b][2], fmaf(ex[b][0], eq[b][0], sum0));
+            sum1 = fmaf(ex[b][3], eq[b][3], fmaf(ex[b][1], eq[b][1], sum1));
+        } else {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                sum0 = fmaf(ex[b][2 * c], eq[b][2 * c], sum0);
+                sum1 = fmaf(ex[b][2 * c + 1], eq[b][2 * c + 1], sum1);
+                if (m2 & (1u << c)) {
+                    emit_run64(sum0, sum1, meta, e0 + c, e_lo, e_hi, range, deg_scale, agg, partials, lane);
+                    sum0 = 0.f;
+                    sum1 = 0.f;
+                }
+            }
+        }
+    };
+
     // one tile: GEMM of `tile` into cur, epilogue of the previous tile from prev, inputs of tile + 1 into xh / xl
-    auto body = [&](f32x16 (&cur)[4], f32x16 (&prev)[4]) __attribute__((always_inline)) {
+    auto body = [&](f32x16 (&cur)[4], f32x16 (&prev)[4], auto first_tag) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         e9_settle<false>(prev);
         const TileIdx ix2 = tile_idx<32>(min(tile + 2, tend - 1), e_hi, src, tgt, j);   // used from double group 12 on
         RunMeta md1;
@@ -252,10 +321,12 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
             wr[0][u][1] = wlane[(u * 2 + 1) * 64];
         }
         // double group dg = 2 s + q: k slot s, output blocks nt = 2 q and 2 q + 1; the six MFMAs alternate between the two
-        // accumulators.  Epilogue: edges 2 dg and 2 dg + 1 of the previous tile.  Inputs: half of slot (s + 7) & 7.
+        // accumulators.  Stage 1 of: edges 2 dg, 2 dg + 1 of the previous tile and half of slot (s + 7) & 7 of the inputs;
+        // stage 2 of what double group dg - 1 started, stage 3 of what dg - 2 started.
 #pragma unroll
         for (int dg = 0; dg < 16; ++dg) {
             const int s = dg >> 1, q = dg & 1, n0 = 2 * q, n1 = 2 * q + 1, bsel = dg & 1;
+            const int b1 = dg & 3, b2 = (dg + 3) & 3, b3 = (dg + 2) & 3, dg3 = (dg + 14) & 15;   // dg3: the double group stage 3 finishes
             if (dg + 1 < 16) {
                 const int s1 = (dg + 1) >> 1, q1 = (dg + 1) & 1;
 #pragma unroll
@@ -290,10 +361,9 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
                 cur[n0] = mfma_xw(xl[s], wr[bsel][0][0], cur[n0]);
                 cur[n1] = mfma_xw(xl[s], wr[bsel][1][0], cur[n1]);
             }
-            // ---- epilogue of the previous tile, edges 2 dg and 2 dg + 1, up to the reciprocal: x = acc / 2^11 + b, r = 1 / (1 + 2^-x);
-            // the accumulation sum += x r sits behind ONE run-end branch per double group (below), so that everything else of the
-            // double group is a single basic block in which the MFMAs and the VALU work can be interleaved
-            float xv[2][2], rv[2][2];
+            // ---- outputs, stage 2 (started by dg - 1) and stage 1 (edges 2 dg, 2 dg + 1 of the previous tile)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) eq[b2][i] = (ABL & 2) ? eq[b2][i] : __builtin_amdgcn_rcpf(1.0f + eq[b2][i]);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int e = 2 * dg + c, r = e9_reg(e), w = e & 7;
@@ -305,20 +375,21 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
                     v0 = late0[w - 4];
                     v1 = late1[w - 4];
                 }
-                if (ABL & 2) {
-                    xv[c][0] = v0, rv[c][0] = bias0, xv[c][1] = v1, rv[c][1] = bias1;
-                } else {
-                    swish_parts<L2E>(v0, bias0, xv[c][0], rv[c][0]);
-                    swish_parts<L2E>(v1, bias1, xv[c][1], rv[c][1]);
-                }
+                ex[b1][2 * c] = fmaf(v0, 1.0f / E9_SCALE, bias0);
+                ex[b1][2 * c + 1] = fmaf(v1, 1.0f / E9_SCALE, bias1);
+                eq[b1][2 * c] = (ABL & 2) ? bias0 : ex2(ex[b1][2 * c]);
+                eq[b1][2 * c + 1] = (ABL & 2) ? bias1 : ex2(ex[b1][2 * c + 1]);
             }
-            // ---- inputs: slot 7 of THIS tile in double groups 0 / 1, slots 0-6 of the next tile in double groups 2-15
+            // ---- inputs: stage 3 (started by dg - 2), stage 2 (dg - 1), stage 1: slot 7 of THIS tile in double groups 0 / 1,
+            // slots 0-6 of the next tile in double groups 2-15
+            if (!FIRST || dg >= 2) in3(b3, ((dg3 >> 1) + 7) & 7, dg3 & 1);
+            if (!FIRST || dg >= 1) in2(b2);
             {
                 const int sc = (s + 7) & 7;
-                consume(sc & 3, sc, dg & 1);
+                in1(b1, sc & 3, dg & 1);
             }
             // ---- gather requests, 6 double groups ahead of their consumption (ring entry = slot & 3)
-            if ((dg & 1) == 0) {
+            if ((dg & 1) == 0 && !(ABL & 32)) {
                 const int sr = (dg >> 1) + 2;     // 2 .. 9
                 if (sr < 8) {
                     request(sr & 3, sr, pan, pbn);
@@ -338,24 +409,16 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
                 __builtin_amdgcn_sched_group_barrier(0x002, E9_VALU_PER_MFMA, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // ---- running sums and run ends (wave-uniform): one branch per double group, the emitting path is rare
-            const unsigned m2 = (pmd.ends >> (2 * dg)) & 3u;
-            if (m2 == 0) {
-                sum0 = fmaf(xv[1][0], rv[1][0], fmaf(xv[0][0], rv[0][0], sum0));
-                sum1 = fmaf(xv[1][1], rv[1][1], fmaf(xv[0][1], rv[0][1], sum1));
-            } else {
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    sum0 = fmaf(xv[c][0], rv[c][0], sum0);
-                    sum1 = fmaf(xv[c][1], rv[c][1], sum1);
-                    if (m2 & (1u << c)) {
-                        emit_run64(sum0, sum1, pmd, 2 * dg + c, e_lo, e_hi, range, deg_scale, agg, partials, lane);
-                        sum0 = 0.f;
-                        sum1 = 0.f;
-                    }
-                }
+            // ---- outputs, stage 3 (started by dg - 2): running sums and run ends, one branch per double group.  Double groups 0 / 1
+            // finish edges 28-31 of the tile BEFORE the previous one
+            if (dg < 2) out3(b3, 2 * dg3, ppmd);
+            else out3(b3, 2 * dg3, pmd);
+            if (!FIRST && dg == 1 && fresh) {      // everything summed so far belonged to the zero tile in front of the first real one
+                sum0 = 0.f, sum1 = 0.f;
+                fresh = false;
             }
         }
+        ppmd = pmd;
         pmd = md;
         md1.ends = (unsigned)__builtin_amdgcn_ballot_w64(ix1.e_ok && ix1.tnext != ix1.ti);
         md = md1;
@@ -363,19 +426,26 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge32t(const float* __restrict
     };
 
     bool last_in_A = true;
-    body(accA, accB);
-    sum0 = 0.f, sum1 = 0.f;                    // the first iteration summed the zero "previous tile": drop it
+    body(accA, accB, std::true_type{});
     ++tile;
     for (; tile < tend; ++tile) {
-        body(accB, accA);
+        body(accB, accA, std::false_type{});
         last_in_A = false;
         if (++tile >= tend) break;
-        body(accA, accB);
+        body(accA, accB, std::false_type{});
         last_in_A = true;
     }
-    // the last tile's rows
+    // the pipeline's last two double groups (edges 28-31 of the tile before the last one), then the last tile's rows
     auto tail = [&](f32x16 (&prev)[4]) __attribute__((always_inline)) {
         float late0[4], late1[4];
+        if (fresh) {                           // a single tile: only the zero tile has been through the pipeline
+            sum0 = 0.f, sum1 = 0.f;
+        } else {
+            out3(2, 28, ppmd);                 // double group 14: x and r are complete
+#pragma unroll
+            for (int i = 0; i < 4; ++i) eq[3][i] = (ABL & 2) ? eq[3][i] : __builtin_amdgcn_rcpf(1.0f + eq[3][i]);
+            out3(3, 30, ppmd);                 // double group 15: stage 2 was still due
+        }
         e9_settle<true>(prev);
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
@@ -638,7 +708,7 @@ extern "C" int magnet_mpnn_edge_fp16x3_t32_f32(const float* A, const float* Bm, 
             if (g_edge9_ablation && l2e) {
                 switch (g_edge9_ablation) {
                     E9_ABL_CASE(1) E9_ABL_CASE(2) E9_ABL_CASE(4) E9_ABL_CASE(6) E9_ABL_CASE(7) E9_ABL_CASE(8) E9_ABL_CASE(16) E9_ABL_CASE(17)
-                    E9_ABL_CASE(31) E9_ABL_CASE(30) E9_ABL_CASE(24)
+                    E9_ABL_CASE(31) E9_ABL_CASE(30) E9_ABL_CASE(24) E9_ABL_CASE(32) E9_ABL_CASE(63) E9_ABL_CASE(33) E9_ABL_CASE(48)
                     default: return -2;
                 }
             } else

@@ -65,7 +65,7 @@ for l2e, paired in ((False, False), (True, False), (False, True), (True, True)):
           f"{2 * E * H * H / ms / 1e9 / 833.3:.3f}, rel-diff vs fp32 kernel {float((agg - ref).norm() / ref.norm()):.2e} nan={int(torch.isnan(agg).sum())}")
 
 # ---- clock / power under a sustained loop of each kernel (is the part power-limited? DESIGN.md 10.2)
-if os.environ.get("EDGE_CLOCKS", "1") == "1":
+if os.environ.get("EDGE_CLOCKS", "0") == "1":
     import ctypes as C, glob, re, subprocess, threading, time
 
     def sysfs_mhz():

@@ -37,7 +37,8 @@ def timeit(fn, reps=30):
 
 names = {0: "as shipped", 1: "no MFMA", 2: "no epilogue exp/rcp", 4: "no input Swish + split", 6: "no Swish at all (2+4)",
          7: "no MFMA, no Swish (1+2+4)", 8: "L1-resident gathers", 16: "no LDS weight reads", 17: "no MFMA, no LDS reads",
-         24: "L1 gathers + no LDS reads", 30: "everything but the MFMAs removed (2+4+8+16)", 31: "skeleton (all removed)"}
+         24: "L1 gathers + no LDS reads", 32: "no gather loads at all", 33: "no gathers, no MFMA", 48: "no gathers, no LDS reads",
+         63: "skeleton without gathers", 30: "everything but the MFMAs removed (2+4+8+16)", 31: "skeleton (all removed)"}
 for abl, name in names.items():
     ops.L.lib().magnet_debug_set_variant(2, abl)
     ms = min(timeit(lambda: ops.mpnn_edge32t(A, Bm, csr, w[0], w[1], agg, partials, l2e=True)) for _ in range(3))
