@@ -205,6 +205,11 @@ int magnet_conv_resident_f32(const float* fmap, int width, const int32_t* tap, i
  * workspace: (2*n_graphs*ceil(rows_per_graph/64) + 2*n_graphs) * H floats. */
 int magnet_instance_norm_f32(const float* x, int n_graphs, int rows_per_graph, int H, float eps, float* y,
                              float* workspace, void* stream);
+/* The same normalisation for graphs of UNEQUAL size (PyG InstanceNorm(x, batch) with an arbitrary sorted batch vector,
+ * models/mpnn.py:63,70): graph g owns rows gptr[g] .. gptr[g+1]; mean / var [n_graphs][H] are outputs.  One workgroup per
+ * (graph, 32 channels): the generality path, not the fast one. */
+int magnet_instance_norm_ragged_f32(const float* x, const int32_t* gptr, int n_graphs, int H, float eps, float* y, float* mean,
+                                    float* var, void* stream);
 /* The same InstanceNorm in two steps, for callers that fuse the normalisation into the next consumer's loads:
  * statistics only - mean [n_graphs][H] at workspace + n_graphs*ceil(rows_per_graph/64)*H, biased variance right behind it
  * (same workspace size as above). */

@@ -347,6 +347,61 @@ __global__ void __launch_bounds__(1024) k_instance_norm_small(const float* __res
         for (int r = grp; r < rows_per_graph; r += 32) yg[(size_t)r * H + c] = (xg[(size_t)r * H + c] - m) / sqrtf(v + eps);
     }
 }
+// Graphs of UNEQUAL size in one batch (PyG's InstanceNorm(x, batch) takes any batch vector, models/mpnn.py:63,70; every caller of
+// the reference builds equal graphs, so this is the generality path, not the fast one): the one-launch kernel above with the
+// graph's rows taken from gptr[g] .. gptr[g + 1].  An empty graph writes nothing (its mean / var rows are set to 0 / 0).
+__global__ void __launch_bounds__(1024) k_instance_norm_ragged(const float* __restrict__ x, const int32_t* __restrict__ gptr, int H,
+                                                               float eps, float* __restrict__ y, float* __restrict__ mean,
+                                                               float* __restrict__ var) {
+    __shared__ float sm[32][33];
+    __shared__ float stat[2][32];
+    const int g = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, grp = threadIdx.x >> 5;
+    const int r0 = gptr[g], nr = gptr[g + 1] - r0;
+    if (nr <= 0) {
+        if (grp == 0 && c < H) mean[(size_t)g * H + c] = 0.f, var[(size_t)g * H + c] = 0.f;
+        return;
+    }
+    const float n_rows = (float)nr;
+    const float* xg = x + (size_t)r0 * H;
+    float acc = 0.f;
+    if (c < H)
+        for (int r = grp; r < nr; r += 32) acc += xg[(size_t)r * H + c];
+    sm[grp][cl] = acc;
+    __syncthreads();
+    if (grp == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) tot += sm[q][cl];
+        stat[0][cl] = tot / n_rows;
+    }
+    __syncthreads();
+    const float m = stat[0][cl];
+    acc = 0.f;
+    if (c < H)
+        for (int r = grp; r < nr; r += 32) {
+            const float d = xg[(size_t)r * H + c] - m;
+            acc += d * d;
+        }
+    __syncthreads();
+    sm[grp][cl] = acc;
+    __syncthreads();
+    if (grp == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) tot += sm[q][cl];
+        stat[1][cl] = tot / n_rows;
+        if (c < H) {
+            mean[(size_t)g * H + c] = m;
+            var[(size_t)g * H + c] = stat[1][cl];
+        }
+    }
+    __syncthreads();
+    if (c < H) {
+        const float v = stat[1][cl];
+        float* yg = y + (size_t)r0 * H;
+        for (int r = grp; r < nr; r += 32) yg[(size_t)r * H + c] = (xg[(size_t)r * H + c] - m) / sqrtf(v + eps);
+    }
+}
 __global__ void k_norm_apply(const float* __restrict__ x, const float* __restrict__ mean,
                              const float* __restrict__ var, int rows_per_graph, int H, float eps, long total,
                              float* __restrict__ y) {
@@ -497,6 +552,15 @@ extern "C" int magnet_colstat_final_f32(const float* part_sum, const float* part
                        rows_per_graph / chunk_rows, rows_per_graph, H, mean, var, chunk_rows);
     LAUNCH_CHECK();
 }
+extern "C" int magnet_instance_norm_ragged_f32(const float* x, const int32_t* gptr, int n_graphs, int H, float eps, float* y,
+                                               float* mean, float* var, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
+    if (n_graphs <= 0) return 0;
+    hipLaunchKernelGGL(k_instance_norm_ragged, dim3(n_graphs, (H + 31) / 32), dim3(1024), 0, (hipStream_t)stream, x, gptr, H, eps, y,
+                       mean, var);
+    LAUNCH_CHECK();
+}
+
 // workspace: (2 * n_graphs * nchunks + 2 * n_graphs) * H floats, nchunks = ceil(rows_per_graph / 64)
 extern "C" int magnet_instance_norm_f32(const float* x, int n_graphs, int rows_per_graph, int H, float eps, float* y,
                                         float* workspace, void* stream) {

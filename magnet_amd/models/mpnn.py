@@ -182,6 +182,9 @@ class MPNN(LightningModule):
         N, tw, H, kin = u.shape[0], self.time_window, self.hidden_features, self.kin
         topo = self._topology_of(data, N)
         csr, B, Ns = topo.csr, topo.n_graphs, topo.nodes_per_graph
+        gptr = getattr(topo, "gptr", None)                     # set only for batches of UNEQUAL graphs (foreign PyG Data)
+        if gptr is not None and tape is not None:
+            raise NotImplementedError("training on a batch of unequal graphs: the InstanceNorm backward assumes equal blocks")
         P = self._packed()
         as_t = lambda v: v.to(dev).float().reshape(-1) if torch.is_tensor(v) else torch.tensor([float(v)], device=dev)  # noqa: E731
         Lv, tm, dtv = as_t(L), as_t(tmax), as_t(dt)
@@ -202,12 +205,12 @@ class MPNN(LightningModule):
         # kernel and its update kernel normalise the raw update output while they load it (ops.mpnn_node_halves: weights resident
         # in LDS; ops.mpnn_node_update: persistent, W2 resident); only the statistics are computed in between, and the last hop's
         # output is normalised once for the read-out
-        fused_nodes = (tape is None and self.gemm == "fp16x3" and Ns > ops.NORM_SMALL_ROWS
+        fused_nodes = (tape is None and gptr is None and self.gemm == "fp16x3" and Ns > ops.NORM_SMALL_ROWS
                        and ops.node_halves_supported(kin, B, Ns, H) and self.fused_node_halves)
         # small graphs (the launch-bound 1-D configs): the same two kernels without the statistics plumbing - a 100-row launch of the
         # generic chain streams its weight chunks one after the other through ONE workgroup (20 / 22 us per launch, all latency), the
         # persistent kernels fetch theirs in one burst; InstanceNorm stays the one-launch small-graph kernel
-        small_nodes = (tape is None and self.gemm == "fp16x3" and Ns <= ops.NORM_SMALL_ROWS and kin in (32, 64) and H == 128
+        small_nodes = (tape is None and gptr is None and self.gemm == "fp16x3" and Ns <= ops.NORM_SMALL_ROWS and kin in (32, 64) and H == 128
                        and self.fused_node_halves)
         stats = None                                                        # (mean, var) of h when h is still un-normalised
         for li, lyr in enumerate(P.layers):
@@ -243,7 +246,9 @@ class MPNN(LightningModule):
             else:
                 ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
                         act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g)
-            if tape is None:
+            if gptr is not None:
+                ops.instance_norm_ragged(g, gptr, out=h)
+            elif tape is None:
                 ops.instance_norm(g, B, Ns, out=h)
             else:
                 h_in = h
@@ -310,11 +315,18 @@ class MPNN(LightningModule):
             return topo
         # foreign PyG-style Data: sort its edge_index by target on the device
         batch = data.batch
-        B = int(batch.max().item()) + 1
-        if N % B:
-            raise NotImplementedError("graphs of unequal size in one batch")
+        counts = torch.bincount(batch.reshape(-1).long())
+        B = counts.numel()
         csr = ops.csr_from_edge_index(data.edge_index, N)
-        return types.SimpleNamespace(csr=csr, n_graphs=B, nodes_per_graph=N // B, edge_index=data.edge_index)
+        if bool((counts == counts[0]).all()) and int(counts[0]) * B == N:
+            return types.SimpleNamespace(csr=csr, n_graphs=B, nodes_per_graph=N // B, edge_index=data.edge_index)
+        # graphs of unequal size (PyG batches allow it, models/mpnn.py:65-71; the reference's own _build_graph never makes one):
+        # the graphs must be contiguous row blocks, as every PyG Batch is; InstanceNorm then takes its rows from gptr
+        if not bool((batch[1:] >= batch[:-1]).all()):
+            raise NotImplementedError("data.batch must be sorted (each graph a contiguous block of rows, as in a PyG Batch)")
+        gptr = torch.zeros(B + 1, dtype=torch.int32, device=batch.device)
+        gptr[1:] = counts.cumsum(0).int()
+        return types.SimpleNamespace(csr=csr, n_graphs=B, nodes_per_graph=0, gptr=gptr, edge_index=data.edge_index)
 
     # ------------------------------------------------------------------ Lightning protocol
     def configure_optimizers(self):

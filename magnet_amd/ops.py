@@ -309,6 +309,17 @@ def instance_norm(x, n_graphs, rows_per_graph, eps=1e-5, out=None, return_var=Fa
     return out
 
 
+def instance_norm_ragged(x, gptr, eps=1e-5, out=None):
+    """per-graph InstanceNorm for graphs of unequal size: graph g owns rows gptr[g] .. gptr[g + 1] (int32, device)"""
+    x = _f32(x, "x")
+    ng, h = gptr.numel() - 1, x.shape[1]
+    out = torch.empty_like(x) if out is None else out
+    stats = torch.empty(2, max(ng, 1), h, device=x.device, dtype=torch.float32)
+    L.check(L.lib().magnet_instance_norm_ragged_f32(_p(x), _p(_i32(gptr)), ng, h, C.c_float(float(eps)), _p(out), _p(stats[0]),
+                                                    _p(stats[1]), _stream()), "instance_norm_ragged")
+    return out
+
+
 NORM_SMALL_ROWS = 2048          # csrc/mpnn_kernels.hip: graphs up to this size are normalised by ONE launch
 
 

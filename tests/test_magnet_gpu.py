@@ -360,3 +360,45 @@ def test_grid_inr_blend_in_the_decoder_epilogue_equals_the_separate_blend():
     for a, b in zip(*outs):
         assert rel_l2(a, b) < 1e-6
     assert rel_l2(outs[0][0], d["fwd_out_hr"] if "fwd_out_hr" in d else outs[1][0]) < 1e-5
+
+
+@pytest.mark.parametrize("hip_graph", [True, False])
+def test_magnet_gnn_1d_batch_32(hip_graph):
+    """configs/datamodule/h5_datamodule_implicit_gnn.yaml batch size 32 (all 1-D configs): B = 32 x (25 LR + 25 query) nodes through
+    magnet_gnn, replayed from one hipGraph and eagerly, against the oracle"""
+    hp, batch, oracle, model = _gnn_1d(25, 25, False, seed=32)
+    model.hip_graph = hip_graph
+    g = torch.Generator().manual_seed(7)
+    B = 32
+    big = {k: v[:1].repeat(B, *([1] * (v.dim() - 1))).clone() for k, v in batch.items()}
+    big["lr_frames"] += 0.05 * torch.randn(big["lr_frames"].shape, generator=g)          # 32 different trajectories, one mesh
+    big["hr_points"] += 0.05 * torch.randn(big["hr_points"].shape, generator=g)
+    pred = model.validation_step({k: v.cuda() for k, v in big.items()}, 0)
+    with torch.no_grad():
+        want = oracle.validation_step(big)
+    assert pred.shape == want.shape and rel_l2(pred, want) < 5 * OUT_TOL
+
+
+@pytest.mark.parametrize("hip_graph", [True, False])
+def test_magnet_cnn_1d_batch_32(hip_graph):
+    """the 1-D MAgNet[CNN] golden case replicated to the reference's batch size 32 (different trajectories on one grid)"""
+    import types
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    name, hp, salt, batch, d = load_case("magnet_cnn_1d")
+    hp.hip_graph = hip_graph
+    oracle = O.build(name, hp).eval()
+    fill_state_dict(oracle, salt)
+    model = FACTORY[name](hp).eval()
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda()
+    g = torch.Generator().manual_seed(9)
+    B = 32
+    big = {k: v[:1].repeat(B, *([1] * (v.dim() - 1))).clone() for k, v in batch.items()}
+    big["lr_frames"] += 0.05 * torch.randn(big["lr_frames"].shape, generator=g)
+    big["hr_points"] += 0.05 * torch.randn(big["hr_points"].shape, generator=g)
+    pred = model.validation_step({k: v.cuda() for k, v in big.items()}, 0)
+    with torch.no_grad():
+        want = oracle.validation_step(big)
+    assert pred.shape == want.shape and rel_l2(pred, want) < 5 * OUT_TOL

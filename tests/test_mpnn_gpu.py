@@ -180,3 +180,111 @@ def test_large_graph_node_kernels_match_the_oracle_rollout():
     with torch.no_grad():
         want = oracle.validation_step(batch)
     assert rel_l2(pred, want) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- the reference's own batch sizes
+def _synthetic_1d(B, N, nt, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.linspace(0, 16, N)
+    t = torch.linspace(0, 4, nt)
+    ph = torch.rand(B, 1, 1, generator=g) * 6.28
+    u = torch.sin(0.7 * x[None, :, None] + 2.0 * t[None, None, :] + ph) + 0.01 * torch.randn(B, N, nt, generator=g)
+    return {"u": u, "x": x[None, :, None].repeat(B, 1, 1), "t": t[None].repeat(B, 1)}
+
+
+@pytest.mark.parametrize("hip_graph", [True, False])
+def test_mpnn_1d_batch_32_matches_the_oracle(hip_graph):
+    """configs/datamodule/h5_datamodule_graph.yaml:16: the reference trains and validates the 1-D models with batch_size 32.
+    B = 32 x 50 nodes, tw = 25, nt = 250: replayed from one hipGraph and enqueued eagerly, both against the oracle."""
+    import types
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    hp = types.SimpleNamespace(lr=1e-3, weight_decay=0.0, factor=0.3, step_size=50, loss="l1", hidden_features=128, hidden_layer=5,
+                               time_window=25, teacher_forcing=False, neighbors=3, hip_graph=hip_graph)
+    oracle = O.build("mpnn", hp).eval()
+    fill_state_dict(oracle, 5)
+    model = FACTORY["mpnn"](hp).eval()
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda()
+    batch = _synthetic_1d(32, 50, 250, seed=3)
+    pred = model.validation_step({k: v.cuda() for k, v in batch.items()}, 0)
+    with torch.no_grad():
+        want = oracle.validation_step(batch)
+    assert pred.shape == want.shape and rel_l2(pred, want) < OUT_TOL
+
+
+def test_mpnn_2d_batch_8_at_64x64_matches_the_oracle():
+    """scripts/mpnn_2d/*.sh run batch_size 8 (configs/datamodule/h5_datamodule_graph_2d.yaml:17 says 4): B = 8 trajectories of a
+    64 x 64 mesh - 8 graphs of 4 096 nodes, the last batch size the persistent node kernels take (ops.node_halves_supported)."""
+    import types
+    import bench
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    hp = types.SimpleNamespace(**bench.HP)
+    oracle = O.build("mpnn_2d", hp).eval()
+    fill_state_dict(oracle, 17)
+    model = FACTORY["mpnn_2d"](hp).eval()
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda()
+    batch = bench.synthetic_batch(64, 8, 21, "cpu")
+    pred = model.validation_step({k: v.cuda() for k, v in batch.items()}, 0)
+    with torch.no_grad():
+        want = oracle.validation_step(batch)
+    assert rel_l2(pred, want) < OUT_TOL
+
+
+def test_more_than_eight_large_graphs_cross_the_node_kernel_boundary():
+    """> 8 graphs of > 2 048 nodes: ops.node_halves_supported turns the persistent node kernels off (their per-graph statistics
+    live in LDS for at most 8 graphs) and the generic launches + separate InstanceNorm take over - same numbers: B = 10 at 48 x 48
+    against the oracle, and sample by sample against B = 5 + 5 through the persistent kernels."""
+    import types
+    import bench
+    from magnet_amd import ops
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    hp = types.SimpleNamespace(**bench.HP)
+    oracle = O.build("mpnn_2d", hp).eval()
+    fill_state_dict(oracle, 19)
+    model = FACTORY["mpnn_2d"](hp).eval()
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda()
+    assert ops.node_halves_supported(model.kin, 8, 48 * 48, 128) and not ops.node_halves_supported(model.kin, 10, 48 * 48, 128)
+    batch = bench.synthetic_batch(48, 10, 23, "cpu")
+    cb = {k: v.cuda() for k, v in batch.items()}
+    pred = model.validation_step(cb, 0)
+    with torch.no_grad():
+        want = oracle.validation_step({k: v[:3] for k, v in batch.items()})     # three samples are enough for the CPU side
+    assert rel_l2(pred[:3], want) < OUT_TOL
+    halves = torch.cat([model.validation_step({k: v[i:i + 5] for k, v in cb.items()}, 0) for i in (0, 5)], 0)
+    assert rel_l2(pred, halves) < 2e-6
+
+
+def test_foreign_batch_of_unequal_graphs():
+    """models/mpnn.py:65-71: GNN_Layer.forward normalises with PyG's InstanceNorm(x, batch), which takes ANY batch vector; the
+    reference's _build_graph only ever makes equal graphs, but forward(data, ...) is public.  Three graphs of 37 / 64 / 21 nodes
+    (1-D meshes of different length) in one foreign Data against the oracle's forward on the same Data."""
+    import types
+    from oracle.pyg_semantics import radius_graph
+    name, hp, batch, d, oracle, model = _models("mpnn_1d")
+    tw = hp.time_window
+    g = torch.Generator().manual_seed(4)
+    sizes = [37, 64, 21]
+    xs = [torch.linspace(0, 16, n) for n in sizes]
+    pos_x = torch.cat(xs)
+    bvec = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(sizes)])
+    u = torch.cat([torch.sin(0.5 * x[:, None] + torch.linspace(0, 1, tw)[None, :] * 3 + i) for i, x in enumerate(xs)])
+    u = u + 0.01 * torch.randn(u.shape, generator=g)
+    pos = torch.cat([torch.full((pos_x.numel(), 1), 0.25), pos_x[:, None]], 1)
+    ei = radius_graph(pos_x[:, None], r=3 * float(xs[1][1] - xs[1][0]) + 1e-4, batch=bvec, loop=False)
+    data = types.SimpleNamespace(x=u, pos=pos, batch=bvec, edge_index=ei)
+    L, tmax, dt = torch.tensor(16.0), torch.tensor(4.0), torch.tensor(0.016)
+    with torch.no_grad():
+        want = oracle(data, L, tmax, dt)
+    cdata = types.SimpleNamespace(x=u.cuda(), pos=pos.cuda(), batch=bvec.cuda(), edge_index=ei.cuda())
+    got = model(cdata, L.cuda(), tmax.cuda(), dt.cuda())
+    assert got.shape == want.shape and rel_l2(got, want) < OUT_TOL
+    last = u[:, -1:]
+    assert rel_l2(got.cpu() - last, want - last) < INC_TOL

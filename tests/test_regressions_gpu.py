@@ -222,7 +222,7 @@ def test_fused_adam_and_torch_adam_exchange_checkpoints():
     c = make()
     oc = FusedAdam(c, lr=1e-2)
     bad = oref.state_dict()
-    bad["state"] = dict(bad["state"], **{7: bad["state"][0]})
+    bad["state"] = {**bad["state"], 7: bad["state"][0]}
     with pytest.raises(ValueError):
         oc.load_state_dict(bad)
 
