@@ -377,6 +377,16 @@ int magnet_mpnn_edge_bwd_f32(const float* A, const float* Bm, const float* dagg,
                              const int32_t* rowptr, int n_nodes, int n_edges, const void* w2_f16, const void* w2t_f16,
                              const float* b2, float* s1, float* dq, float* dp, float* dA, float* partials, void* stream);
 
+/* Weight packing on the device (magnet_amd/packing.py: the same layouts as torch index shuffles; no reference counterpart - the
+ * reference hands its nn.Linear weights to cuBLAS as they are).  Padded position (r, c) of the [np x kp] matrix takes
+ * w[r' stride_r + c' stride_c] with r' = row_src ? row_src[r] : r (r < n) and c' = col_src ? col_src[c] : c (c < k); -1 / out of
+ * range = 0.  mode 0: fp32 fragments [kt][nt][4][64][4]; 1: fp16 planes (h, 2^11 (w - h)) [kt][nt][2][2][64][8]; 2: three
+ * truncated bf16 pieces [kt][nt][2][3][64][8]; 3: one RNE bf16 plane [kt][nt][2][1][64][8].  bias_out [np] (may be null) = bias
+ * padded with zeros.  mode 1 sets range_bit in *status (device int, may be null) when some |w| >= 65504 or is not finite. */
+int magnet_pack_linear_f32(const float* w, long stride_r, long stride_c, int n, int k, const int32_t* row_src,
+                           const int32_t* col_src, const float* bias, int n_bias, int np, int kp, int mode, void* out,
+                           float* bias_out, int* status, int range_bit, void* stream);
+
 /* Measurement utility for bench.py (no reference counterpart): one wave on `stream` samples the shader clock for ~wall_us
  * microseconds while other streams run the workload.  out[0] = shader-clock ticks, out[1] = constant-rate ticks of the
  * wall clock whose rate (kHz) is returned through *wall_khz (host pointer): MHz = out[0] / out[1] * wall_khz / 1000. */

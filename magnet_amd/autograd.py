@@ -221,9 +221,8 @@ class _Mlp(torch.autograd.Function):
                     break
                 # dX = dz . W   (transposed packs, column block by column block)
                 dX = torch.empty(max(M, 1), Kp, device=dev, dtype=torch.float32)
-                Wp = _padded_weight(m, l, W, Np, Kp)
                 for (c0, w) in _tiles_of(Kp):
-                    tp = _tpack(pk, l, c0, w, Wp)
+                    tp = _tpack(m, pk, l, c0, w, W, Np, Kp)
                     if l > 0:      # ... with the ReLU mask of the layer below as the epilogue: dz_{l-1} = (X[l] > 0) ? dX : 0
                         ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), [tp], nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE,
                                 epi=ops.EPI_STORE_MASK, res=X[l][:, c0:], y=dX[:, c0:], ldy=Kp, ncols=w)
@@ -260,24 +259,26 @@ class _Mlp(torch.autograd.Function):
         return (None, *grads_src, *grads_par, *([d_res] if m.has_res else []))
 
 
-def _padded_weight(m, l, W, Np, Kp):
-    n, k = W.shape
-    Wp = torch.zeros(Np, Kp, device=W.device, dtype=torch.float32)
-    if l == 0 and m.first_cols is not None:
-        Wp[:n, m.col_map] = W.detach().float()[:, m.first_cols]
-    elif l == 0 and m.col_map is not None:
-        Wp[:n, m.col_map] = W.detach().float()
-    else:
-        Wp[:n, :k] = W.detach().float()
-    return Wp
-
-
-def _tpack(pk, l, c0, w, Wp):
-    """packed transpose of the padded weight block Wp[:, c0:c0+w] as a Linear [w outputs, Np inputs] (cached on pk)"""
+def _tpack(m, pk, l, c0, w, W, Np, Kp):
+    """packed transpose of the padded weight block Wp[:, c0:c0+w] as a Linear [w outputs, Np inputs] (cached on pk; the pack of a
+    step's weights lives as long as that step's ``pk``).  Wp is never materialised: the device packer reads W through its strides,
+    W.t() is a view, and the placement of W's columns inside the padded first-layer input (col_map / first_cols) becomes the
+    packer's row map."""
+    from .packing import pack_device, source_map
     cache = pk.__dict__.setdefault("_tpacks", {})
     key = (l, c0, w)
     if key not in cache:
-        cache[key] = pack(Wp[:, c0:c0 + w].t().contiguous(), None, BWD_GEMM)
+        n, k = W.shape
+        rows = None                                            # padded column c0 + r of Wp -> source column of W (identity: r < k)
+        if l == 0 and m.col_map is not None:
+            full = m.__dict__.get("_full_map")                # one map per mlp call, shared by its column tiles
+            if full is None:
+                full = m.__dict__["_full_map"] = source_map(m.col_map, Kp, W.device, source_cols=m.first_cols)
+            rows = full[c0:c0 + w].contiguous()
+            Wt = W.detach().t()
+        else:
+            Wt = W.detach().t()[c0:c0 + w] if c0 < k else W.detach().t()[:0]
+        cache[key] = pack_device(Wt, None, BWD_GEMM, w, Np, row_src=rows)
     return cache[key]
 
 

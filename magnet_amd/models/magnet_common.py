@@ -146,6 +146,8 @@ class MagnetBase(LightningModule):
         key = (params[0].device, sum(p._version for p in params), self._pack_gen)
         if self._pack_key != key:
             self._pack, self._pack_key = self._pack_weights(), key
+            from ..packing import raise_if_bad_weights
+            raise_if_bad_weights(params[0].device)   # the fp16x3 packs' range check: ONE host read per re-pack (not one per Linear)
         hold(self._pack)                    # a capture in progress keeps the packs its launches point into (magnet_amd/graphs.py)
         return self._pack
 

@@ -164,6 +164,9 @@ class MPNN(LightningModule):
                   c2.weight.detach().reshape(-1).contiguous(), c2.bias.detach().contiguous())
         assert nin <= kin
         self._pack_key, self._pack = key, P
+        if dev.type == "cuda":
+            from ..packing import raise_if_bad_weights
+            raise_if_bad_weights(dev)          # the fp16x3 packs' range check: ONE host read per re-pack (not one per Linear)
         hold(P)
         return P
 

@@ -88,7 +88,10 @@ def split_fp16x2(w: torch.Tensor):
     """Two-piece fp16 split: w ~= h + l / 2048 with h = fp16(w), l = fp16((w - h) * 2048) (both round-to-nearest;
     the remainder is exact in fp32 and the 2^11 scaling keeps it a normal fp16).  |w| must be < 65504."""
     w = w.detach().float().contiguous()
-    if not bool(torch.isfinite(w).all()) or float(w.abs().max()) >= 65504.0:
+    if w.is_cuda:            # no host round trip: the verdict lands in the device status word (raise_if_bad_weights reads it once)
+        bad = (~(w.abs() < 65504.0)).any().to(torch.int32)
+        _status_word(w.device).bitwise_or_(bad * _WEIGHT_RANGE_BIT)
+    elif not bool(torch.isfinite(w).all()) or float(w.abs().max()) >= 65504.0:
         raise ValueError("fp16x3 GEMM mode needs finite weights with |w| < 65504; use MAGNET_GEMM=bf16x6")
     h = w.half()
     lo = ((w - h.float()) * 2048.0).half()
@@ -186,7 +189,92 @@ def default_gemm() -> str:
     return mode
 
 
+# ---- device path: one HIP launch per Linear (magnet_pack_linear_f32, csrc/pack_kernels.hip) instead of the torch index shuffles above.
+# A training step re-packs every weight the optimizer touched; the torch path costs ~30 small kernels per Linear plus a host
+# synchronisation for the fp16 range check - ~60 000 launches and ~600 `.item()` round trips per MAgNet training step.
+_MODE_ID = {"fp32": 0, "fp16x3": 1, "bf16x6": 2, "bf16": 3}
+_OUT_DTYPE = {"fp32": torch.float32, "fp16x3": torch.float16, "bf16x6": torch.int16, "bf16": torch.bfloat16}
+_PLANES = {"fp32": 2, "fp16x3": 2, "bf16x6": 3, "bf16": 1}        # out elements per padded weight entry / (fp32: 1 float = 2 x 16 bit)
+_WEIGHT_RANGE_BIT = 1
+_status = {}             # device -> int32[1]: bit 0 = an fp16x3 pack met |w| >= 65504 or a non-finite weight
+_src_maps = {}           # (column placement, padded width, device) -> int32 source-column map
+
+
+def _status_word(dev):
+    if dev not in _status:
+        _status[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return _status[dev]
+
+
+def raise_if_bad_weights(dev) -> None:
+    """ONE host read for all packs since the last call (the models call it once per re-pack of their weights): the fp16x3 mode
+    represents a weight with two fp16 pieces and needs finite |w| < 65504"""
+    dev = torch.device(dev)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if dev in _status and int(_status[dev].item()):
+        _status[dev].zero_()
+        raise ValueError("fp16x3 GEMM mode needs finite weights with |w| < 65504; use MAGNET_GEMM=bf16x6")
+
+
+def source_map(placed_at, width: int, dev, source_cols=None):
+    """int32 [width] on ``dev``: padded position p takes source column source_cols[i] (default i) where placed_at[i] == p, -1
+    elsewhere; cached (the placements are static per call site)"""
+    if torch.is_tensor(placed_at) and placed_at.is_cuda:       # built on the device: reading it back would be a host synchronisation
+        m = torch.full((int(width),), -1, dtype=torch.int32, device=dev)
+        srcs = (torch.arange(placed_at.numel(), dtype=torch.int32, device=dev) if source_cols is None
+                else torch.as_tensor(source_cols, device=dev).to(torch.int32))
+        m[placed_at.to(dev).long()] = srcs
+        return m
+    pl = tuple(int(v) for v in (placed_at.tolist() if torch.is_tensor(placed_at) else placed_at))
+    sc = tuple(range(len(pl))) if source_cols is None else tuple(int(v) for v in (source_cols.tolist() if torch.is_tensor(source_cols)
+                                                                                   else source_cols))
+    key = (pl, sc, int(width), str(dev))
+    if key not in _src_maps:
+        m = torch.full((int(width),), -1, dtype=torch.int32)
+        m[torch.tensor(pl, dtype=torch.long)] = torch.tensor(sc, dtype=torch.int32)
+        if len(_src_maps) > 256:
+            _src_maps.clear()
+        _src_maps[key] = m.to(dev)
+    return _src_maps[key]
+
+
+def pack_device(w, b, mode: str, np_: int, kp: int, row_src=None, col_src=None):
+    """``w``: 2-D fp32 CUDA tensor or view (any strides: W.t() costs nothing); row_src / col_src: int32 device maps from padded
+    row / column to source row / column (-1 = zero), None = identity.  -> (flat packed planes, padded bias [np_])"""
+    import ctypes as C
+
+    from . import _lib as L
+    w = w.detach()
+    if w.dtype != torch.float32:
+        w = w.float()
+    dev = w.device
+    assert w.dim() == 2 and np_ % 32 == 0 and kp % 32 == 0, (w.shape, np_, kp)
+    out = torch.empty(np_ * kp * _PLANES[mode] // (2 if mode == "fp32" else 1), dtype=_OUT_DTYPE[mode], device=dev)
+    bp = torch.empty(np_, dtype=torch.float32, device=dev)
+    if b is not None:
+        b = b.detach()
+        b = b.float() if b.dtype != torch.float32 else b
+        b = b if b.is_contiguous() else b.contiguous()
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    st = _status_word(dev) if mode == "fp16x3" else None
+    L.check(L.lib().magnet_pack_linear_f32(ptr(w), C.c_long(w.stride(0)), C.c_long(w.stride(1)), w.shape[0], w.shape[1], ptr(row_src),
+                                           ptr(col_src), ptr(b), b.numel() if b is not None else 0, np_, kp, _MODE_ID[mode], ptr(out),
+                                           ptr(bp), ptr(st), _WEIGHT_RANGE_BIT, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+            "pack_linear")
+    return out, bp
+
+
 def pack(w, b, mode: str, k_pad=None, n_pad=None, col_map=None):
+    """(packed weight, padded bias) of a torch Linear weight [n_out, k_in] in the layout of GEMM mode ``mode``.  CUDA tensors are
+    packed by one HIP launch (any strides; the fp16 range check lands in a device status word, see raise_if_bad_weights); CPU
+    tensors by the torch index shuffles above (layout tests, no GPU needed)."""
+    if w.is_cuda:
+        n, k = w.shape
+        kp = k_pad or pad_to(k if col_map is None else int(max(col_map.tolist() if torch.is_tensor(col_map) else col_map)) + 1)
+        np_ = n_pad or pad_to(n)
+        cs = source_map(col_map, kp, w.device) if col_map is not None else None
+        return pack_device(w, b, mode, np_, kp, col_src=cs)
     if mode == "fp16x3":
         return pack_linear_fp16x2(w, b, k_pad=k_pad, n_pad=n_pad, col_map=col_map)
     if mode == "bf16x6":

@@ -611,3 +611,79 @@ def test_resident_convolution_equals_the_streamed_launch_and_is_deterministic(mo
             for _ in range(30):
                 assert torch.equal(net.rows(x), outs[0])
     assert rel_l2(outs[0], outs[1]) < 5e-7
+
+
+@pytest.mark.parametrize("mode", ["fp16x3", "bf16x6", "bf16", "fp32"])
+def test_device_weight_packing_equals_the_torch_layouts(mode):
+    """magnet_pack_linear_f32 (one launch per Linear) against magnet_amd.packing's torch index shuffles, bit for bit: odd sizes
+    (zero padding), a column placement map, a transposed view (strides), an explicit k_pad, subnormal / large values; and the
+    transposed backward packs of autograd._tpack against the padded-copy construction they replace."""
+    from magnet_amd import packing as P
+    torch.manual_seed(5)
+    ref = {"fp16x3": P.pack_linear_fp16x2, "bf16x6": P.pack_linear_bf16x3, "bf16": P.pack_linear_bf16x1, "fp32": P.pack_linear}[mode]
+
+    def same(a, b):
+        return a.dtype == b.dtype and a.shape == b.shape and torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+
+    for (n, k, kw) in [(128, 128, {}), (70, 45, {}), (128, 13, dict(k_pad=32)), (33, 257, {}), (128, 161, dict(k_pad=192)),
+                       (64, 96, dict(n_pad=128))]:
+        w = torch.randn(n, k) * torch.logspace(-6, 2, k)[None, :]          # magnitudes from 1e-6 to 1e2 (fp16 subnormal low pieces)
+        b = torch.randn(n)
+        want_w, want_b = ref(w, b, **kw)
+        got_w, got_b = P.pack(w.cuda(), b.cuda(), mode, **kw)
+        assert same(got_w.cpu(), want_w) and torch.equal(got_b.cpu(), want_b), (mode, n, k)
+        # column placement (the var column of update_net_1, the INR head's split columns)
+        cmap = torch.randperm(pad_to_32(k) + 32)[:k]
+        want_w, _ = ref(w, None, col_map=cmap, **{kk: vv for kk, vv in kw.items() if kk == "n_pad"})
+        got_w, got_b = P.pack(w.cuda(), None, mode, col_map=cmap, **{kk: vv for kk, vv in kw.items() if kk == "n_pad"})
+        assert same(got_w.cpu(), want_w) and float(got_b.abs().max()) == 0.0
+        # a transposed view is read through its strides
+        wt = torch.randn(k, n)
+        want_w, _ = ref(wt.t().contiguous(), None)
+        got_w, _ = P.pack(wt.cuda().t(), None, mode)
+        assert same(got_w.cpu(), want_w)
+    P.raise_if_bad_weights("cuda")                                         # nothing above left the fp16 range
+
+
+def pad_to_32(n):
+    return (n + 31) // 32 * 32
+
+
+def test_device_packing_flags_weights_outside_the_fp16_range():
+    from magnet_amd import packing as P
+    w = torch.randn(64, 64)
+    w[3, 5] = 7.0e4
+    P.pack(w.cuda(), None, "fp16x3")
+    with pytest.raises(ValueError, match="65504"):
+        P.raise_if_bad_weights("cuda")
+    P.raise_if_bad_weights("cuda")                                         # the word was cleared
+    w[3, 5] = float("nan")
+    P.pack(w.cuda(), None, "fp16x3")
+    with pytest.raises(ValueError):
+        P.raise_if_bad_weights("cuda")
+    P.pack(w.cuda(), None, "bf16x6")                                       # the full-range split does not care
+    P.raise_if_bad_weights("cuda")
+
+
+def test_transposed_backward_packs_equal_the_padded_copy_construction():
+    import types
+    from magnet_amd import autograd as AG
+    from magnet_amd import packing as P
+    torch.manual_seed(8)
+    n, k, Np, Kp = 64, 45, 64, 96
+    W = torch.randn(n, k).cuda()
+    cmap = torch.tensor(sorted(torch.randperm(Kp)[:k].tolist()))
+    for col_map, first_cols in ((None, None), (cmap, None), (cmap[:30], torch.randperm(k)[:30])):
+        m = types.SimpleNamespace(col_map=col_map, first_cols=first_cols)
+        Wp = torch.zeros(Np, Kp, device="cuda")
+        if first_cols is not None:
+            Wp[:n, col_map] = W[:, first_cols]
+        elif col_map is not None:
+            Wp[:n, col_map] = W
+        else:
+            Wp[:n, :k] = W
+        pk = types.SimpleNamespace()
+        for (c0, w) in AG._tiles_of(Kp):
+            want = P.pack_linear_bf16x3(Wp[:, c0:c0 + w].t().contiguous().cpu(), None)
+            got = AG._tpack(m, pk, 0, c0, w, W, Np, Kp)
+            assert torch.equal(got[0].cpu(), want[0]) and float(got[1].abs().max()) == 0.0, (c0, w)
