@@ -386,6 +386,7 @@ __global__ void __launch_bounds__(256) k_edge_range_fixup(const int32_t* __restr
 // i.e. twice the LDS weight traffic per edge (ds_read_b128 runs at 256 B/clk on gfx950: ~40 % of the LDS pipe).
 // Operand layouts (checked by scripts/dev/mfma16_probe.cpp): A = W2 rows, lane l: row 16t + (l & 15), k = 32s + 8(l >> 4) + 0..7;
 // B = activations, lane l: edge l & 15, the same k; D: lane l: edge l & 15, rows 16t + 4(l >> 4) + 0..3.
+typedef unsigned int u32;
 constexpr int T16_STRIDE = 132;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -393,7 +394,7 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f3
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <bool L2E>
+template <bool L2E, bool SINGLE>
 __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A, const float* __restrict__ Bm,
                                                      const int32_t* __restrict__ src, const int32_t* __restrict__ tgt,
                                                      const int32_t* __restrict__ rowptr, int E,
@@ -401,6 +402,22 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
                                                      const float* __restrict__ b2, float* __restrict__ agg,
                                                      float* __restrict__ partials) {
     auto sw = [](float x) { return L2E ? act_swish_l2e(x) : act_swish(x); };
+    // SINGLE (round 3): the weight planes arrive pre-scaled by 2^11 (plane 0 = 2^11 hw, plane 1 = 2^11 (w - hw)) and the low piece of
+    // an activation stays UNSCALED (l = x - h, an fp16 subnormal for small x - the MFMA keeps them, scripts/dev/edge9_probe.cpp), so
+    // all three products of the split carry the factor 2^11 and share ONE accumulator: no cross accumulator (32 registers), no
+    // fold; and the two pieces come straight out of the Swish - h = fp16(v r), l = fp16(v r - h), one v_fma_mix each, r = 1 / (1 + 2^-v)
+    // - instead of two multiplies and a five-instruction split per value pair.
+    constexpr float acc_scale = SINGLE ? 2048.0f : 1.0f;
+    auto pieces = [](float v0, float v1, u32& hw, u32& lw) {       // SINGLE: Swish of the pair -> one word of each plane
+        const float r0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(L2E ? -v0 : -v0 * MAGNET_LOG2E));
+        const float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(L2E ? -v1 : -v1 * MAGNET_LOG2E));
+        u32 h, l;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(v0), "v"(r0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(v1), "v"(r1));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v0), "v"(r0), "v"(h));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v1), "v"(r1), "v"(h));
+        hw = h, lw = l;
+    };
     constexpr float deg_scale = L2E ? MAGNET_LOG2E : 1.0f;
     __shared__ __attribute__((aligned(16))) u32x4 wl[4 * 8 * 2 * 64];          // 64 KiB
     __shared__ __attribute__((aligned(16))) float tb[8][16 * T16_STRIDE];      // 66 KiB
@@ -423,9 +440,10 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
 #pragma unroll
     for (int t = 0; t < 8; ++t) {             // loop-invariant C operand of every tile's first main product
         bias[t] = *reinterpret_cast<const f32x4*>(b2 + 16 * t + 4 * q);
-        if (L2E) bias[t] *= MAGNET_LOG2E;
+        bias[t] *= (L2E ? MAGNET_LOG2E : 1.0f) * acc_scale;
     }
-    float in[4][8];
+    float in[4][8];                           // !SINGLE: Swish(A + Bm) of the four k steps, split when the step comes up
+    u32 ph[4][4], pl[4][4];                   // SINGLE: the two fp16 planes of the same values (word p = values 2 p, 2 p + 1)
     f32x4 la[2][2], lb[2][2];                 // gather staging: two sets of one k step (8 columns of A[i], 8 of Bm[j])
     TileIdx ix = tile_idx<16>(tile, e_hi, src, tgt, j);
     RunMeta md;
@@ -443,8 +461,13 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
             for (int g = 0; g < 2; ++g) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(pa + 32 * s + 4 * g);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(pb + 32 * s + 4 * g);
+                if (SINGLE) {
+                    pieces(a[0] + b[0], a[1] + b[1], ph[s][2 * g], pl[s][2 * g]);
+                    pieces(a[2] + b[2], a[3] + b[3], ph[s][2 * g + 1], pl[s][2 * g + 1]);
+                } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) in[s][4 * g + c] = sw(a[c] + b[c]);
+                    for (int c = 0; c < 4; ++c) in[s][4 * g + c] = sw(a[c] + b[c]);
+                }
             }
 #pragma unroll
         for (int g = 0; g < 2; ++g) {          // k step 3 stays raw: groups 4-7 of the first iteration turn it into in[3]
@@ -474,9 +497,14 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
             u32x4 xs[2][2], wr[2][2][2];          // weight fragments: [buffer][tile of the pair][plane]
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const u32x2 w = Split<GEMM_FP16X3>::pair(in[0][2 * p], in[0][2 * p + 1]);
-                xs[0][0][p] = w[0];
-                xs[0][1][p] = w[1];
+                if (SINGLE) {
+                    xs[0][0][p] = ph[0][p];
+                    xs[0][1][p] = pl[0][p];
+                } else {
+                    const u32x2 w = Split<GEMM_FP16X3>::pair(in[0][2 * p], in[0][2 * p + 1]);
+                    xs[0][0][p] = w[0];
+                    xs[0][1][p] = w[1];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -501,9 +529,14 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
                 if (dg + 1 < 16) rv = *reinterpret_cast<const f32x2*>(tr + (dg + 1) * T16_STRIDE);
                 __builtin_amdgcn_sched_barrier(0);    // LDS requests first (see k_mpnn_edge7)
                 if (s + 1 < 4) {
-                    const u32x2 w = Split<GEMM_FP16X3>::pair(in[s + 1][2 * tp], in[s + 1][2 * tp + 1]);
-                    xs[(s + 1) & 1][0][tp] = w[0];
-                    xs[(s + 1) & 1][1][tp] = w[1];
+                    if (SINGLE) {
+                        xs[(s + 1) & 1][0][tp] = ph[s + 1][tp];
+                        xs[(s + 1) & 1][1][tp] = pl[s + 1][tp];
+                    } else {
+                        const u32x2 w = Split<GEMM_FP16X3>::pair(in[s + 1][2 * tp], in[s + 1][2 * tp + 1]);
+                        xs[(s + 1) & 1][0][tp] = w[0];
+                        xs[(s + 1) & 1][1][tp] = w[1];
+                    }
                 }
                 if (s == 0) {   // first k step: the accumulators start from the bias registers / the inline constant 0
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -511,12 +544,21 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
                     outc[t0] = z, outc[t1] = z;
                 }
                 const int bsel = dg & 1;
-                outc[t0] = mfma16(wr[bsel][0][1], xs[s & 1][0], outc[t0]);
-                outc[t1] = mfma16(wr[bsel][1][1], xs[s & 1][0], outc[t1]);
-                out[t0] = mfma16(wr[bsel][0][0], xs[s & 1][0], out[t0]);
-                out[t1] = mfma16(wr[bsel][1][0], xs[s & 1][0], out[t1]);
-                outc[t0] = mfma16(wr[bsel][0][0], xs[s & 1][1], outc[t0]);
-                outc[t1] = mfma16(wr[bsel][1][0], xs[s & 1][1], outc[t1]);
+                if (SINGLE) {
+                    out[t0] = mfma16(wr[bsel][0][1], xs[s & 1][0], out[t0]);
+                    out[t1] = mfma16(wr[bsel][1][1], xs[s & 1][0], out[t1]);
+                    out[t0] = mfma16(wr[bsel][0][0], xs[s & 1][0], out[t0]);
+                    out[t1] = mfma16(wr[bsel][1][0], xs[s & 1][0], out[t1]);
+                    out[t0] = mfma16(wr[bsel][0][0], xs[s & 1][1], out[t0]);
+                    out[t1] = mfma16(wr[bsel][1][0], xs[s & 1][1], out[t1]);
+                } else {
+                    outc[t0] = mfma16(wr[bsel][0][1], xs[s & 1][0], outc[t0]);
+                    outc[t1] = mfma16(wr[bsel][1][1], xs[s & 1][0], outc[t1]);
+                    out[t0] = mfma16(wr[bsel][0][0], xs[s & 1][0], out[t0]);
+                    out[t1] = mfma16(wr[bsel][1][0], xs[s & 1][0], out[t1]);
+                    outc[t0] = mfma16(wr[bsel][0][0], xs[s & 1][1], outc[t0]);
+                    outc[t1] = mfma16(wr[bsel][1][0], xs[s & 1][1], outc[t1]);
+                }
                 {                                 // transposed read of one edge of the previous tile, Swish, running sum
                     acc[0] += sw(cur[0]);
                     acc[1] += sw(cur[1]);
@@ -529,11 +571,19 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
                 // staged rows -> Swish(A + Bm), four values per double group, pinned to it (see k_mpnn_edge7)
                 if ((dg & 3) >= 2) {
                     const int sc = ((dg >> 2) + 3) & 3, idx = dg & 1, set = sc & 1;   // dg 2-3: k step 3, 6-7: 0, 10-11: 1, 14-15: 2
+                    if (SINGLE) {
+                        u32 h0, l0, h1, l1;
+                        pieces(la[set][idx][0] + lb[set][idx][0], la[set][idx][1] + lb[set][idx][1], h0, l0);
+                        pieces(la[set][idx][2] + lb[set][idx][2], la[set][idx][3] + lb[set][idx][3], h1, l1);
+                        asm volatile("" : "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1));
+                        ph[sc][2 * idx] = h0, pl[sc][2 * idx] = l0, ph[sc][2 * idx + 1] = h1, pl[sc][2 * idx + 1] = l1;
+                    } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        float v = sw(la[set][idx][c] + lb[set][idx][c]);
-                        asm volatile("" : "+v"(v));
-                        in[sc][4 * idx + c] = v;
+                        for (int c = 0; c < 4; ++c) {
+                            float v = sw(la[set][idx][c] + lb[set][idx][c]);
+                            asm volatile("" : "+v"(v));
+                            in[sc][4 * idx + c] = v;
+                        }
                     }
                 }
                 if ((dg & 3) == 0) {
@@ -552,7 +602,7 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
         for (int t = 0; t < 8; ++t) {
             f32x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = fmaf(outc[t][r], 1.0f / 2048.0f, out[t][r]);
+            for (int r = 0; r < 4; ++r) o[r] = SINGLE ? out[t][r] * (1.0f / 2048.0f) : fmaf(outc[t][r], 1.0f / 2048.0f, out[t][r]);
             *reinterpret_cast<f32x4*>(tw + 16 * t) = o;
         }
         pmd = md;
@@ -695,11 +745,17 @@ extern "C" int magnet_mpnn_edge_fp16x3_t16_f32(const float* A, const float* Bm, 
     const dim3 g(min((tiles + 7) / 8, ncu)), b(512);
     const u32x4* ws = reinterpret_cast<const u32x4*>(w2_t16);
     hipStream_t s = (hipStream_t)stream;
-    if (a_bm_log2e_scaled) hipLaunchKernelGGL(k_mpnn_edge16<true>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
-    else hipLaunchKernelGGL(k_mpnn_edge16<false>, g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+    const bool l2e = (a_bm_log2e_scaled & 1) != 0, single = (a_bm_log2e_scaled & 2) != 0;   // bit 1: planes pre-scaled by 2^11 (one accumulator)
+    if (single) {
+        if (l2e) hipLaunchKernelGGL((k_mpnn_edge16<true, true>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+        else hipLaunchKernelGGL((k_mpnn_edge16<false, true>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+    } else {
+        if (l2e) hipLaunchKernelGGL((k_mpnn_edge16<true, false>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+        else hipLaunchKernelGGL((k_mpnn_edge16<false, false>), g, b, 0, s, A, Bm, src, tgt, rowptr, n_edges, ws, b2, agg, partials);
+    }
     const int nranges = (int)g.x * 8, tpw = (tiles + nranges - 1) / nranges;      // as computed inside the kernel
     const int fb = max((n_rows + 255) / 256, (nranges + 3) / 4);
     hipLaunchKernelGGL(k_edge_range_fixup, dim3(fb), dim3(256), 0, s, tgt, rowptr, n_rows, n_edges, tpw, 4, nranges,
-                       a_bm_log2e_scaled ? MAGNET_LOG2E : 1.0f, partials, agg);
+                       l2e ? MAGNET_LOG2E : 1.0f, partials, agg);
     return (int)hipGetLastError();
 }

@@ -94,6 +94,8 @@ class MPNN(LightningModule):
         self.edge_l2e = bool(int(os.environ.get("MAGNET_EDGE_L2E", "1"))) and bool(getattr(hparams, "edge_l2e", True))
         # inference, fp16x3: 16-edge tiles with two waves per SIMD (k_mpnn_edge16) instead of 32-edge tiles (A/B knob)
         self.edge_t16 = bool(int(os.environ.get("MAGNET_EDGE_T16", "1"))) and bool(getattr(hparams, "edge_t16", True))
+        # fp16x3, 16-edge tiles: one accumulator for the three products of the split (weight planes pre-scaled by 2^11; A/B knob)
+        self.edge_single = bool(int(os.environ.get("MAGNET_EDGE_SINGLE", "0"))) and bool(getattr(hparams, "edge_single", True))
         # fp16x3: the transposed 32-edge-tile kernel (k_mpnn_edge32t, generation 9) instead of k_mpnn_edge16 (A/B knob)
         self.edge_t32 = bool(int(os.environ.get("MAGNET_EDGE_T32", "0"))) and bool(getattr(hparams, "edge_t32", True))
         assert self.edge_gemm in GEMM_MODES
@@ -149,7 +151,10 @@ class MPNN(LightningModule):
                 L.pre_b_l2e = pack(wb * ops.LOG2E, None, self.gemm, k_pad=H + kin)
             L.msg2 = pack(m2.weight, m2.bias, self.edge_gemm)
             if self.edge_t16 and self.edge_gemm == "fp16x3":
-                L.msg2_t16 = pack_edge16_fp16x2(m2.weight, m2.bias)
+                try:                            # one-accumulator variant (planes pre-scaled by 2^11); |w| >= 31.98 keeps the two-accumulator one
+                    L.msg2_t16, L.msg2_t16_single = pack_edge16_fp16x2(m2.weight, m2.bias, scaled=self.edge_single), self.edge_single
+                except ValueError:
+                    L.msg2_t16, L.msg2_t16_single = pack_edge16_fp16x2(m2.weight, m2.bias), False
             if self.edge_t32 and self.edge_gemm == "fp16x3":
                 try:
                     L.msg2_t32 = pack_edge32t_fp16x2(m2.weight, m2.bias)
@@ -232,7 +237,7 @@ class MPNN(LightningModule):
             if hasattr(lyr, "msg2_t32"):          # training forward too (plain halves: l2e is False with a tape)
                 ops.mpnn_edge32t(A, Bm, csr, lyr.msg2_t32[0], lyr.msg2_t32[1], agg, partials, l2e=l2e)
             elif hasattr(lyr, "msg2_t16"):
-                ops.mpnn_edge16(A, Bm, csr, lyr.msg2_t16[0], lyr.msg2_t16[1], agg, partials, l2e=l2e)
+                ops.mpnn_edge16(A, Bm, csr, lyr.msg2_t16[0], lyr.msg2_t16[1], agg, partials, l2e=l2e, single=lyr.msg2_t16_single)
             else:
                 ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials, l2e=l2e)
             if fused_nodes:

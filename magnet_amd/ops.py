@@ -252,12 +252,14 @@ def edge_scratch_floats(n_edges: int) -> int:
     return max((int(n_edges) + 15) // 16, 1) * 2 * 128
 
 
-def mpnn_edge16(A, Bm, csr, w2_t16, b2, agg, partials, l2e=False):
+def mpnn_edge16(A, Bm, csr, w2_t16, b2, agg, partials, l2e=False, single=False):
     """the same op on 16-edge tiles with two waves per SIMD (k_mpnn_edge16, fp16x3 only); w2_t16 from
-    packing.pack_edge16_fp16x2 - the fragment order differs from the 32-edge kernels' packs"""
+    packing.pack_edge16_fp16x2 - the fragment order differs from the 32-edge kernels' packs.  single: the planes were packed
+    with scaled=True (both carry 2^11): one accumulator for the three products of the split, pieces straight out of the Swish"""
     assert w2_t16.dtype == torch.float16 and partials.numel() >= edge_scratch_floats(csr.E)
     L.check(L.lib().magnet_mpnn_edge_fp16x3_t16_f32(_p(A), _p(Bm), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.E, csr.N,
-                                                    _p(w2_t16), _p(b2), _p(agg), _p(partials), int(l2e), _stream()),
+                                                    _p(w2_t16), _p(b2), _p(agg), _p(partials), int(l2e) | (2 if single else 0),
+                                                    _stream()),
             "mpnn_edge_fp16x3_t16")
     return agg
 

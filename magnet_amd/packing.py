@@ -119,12 +119,18 @@ def pack_linear_fp16x2(w: torch.Tensor, b: torch.Tensor | None, k_pad: int | Non
     return out.view(-1), bp
 
 
-def pack_edge16_fp16x2(w: torch.Tensor, b: torch.Tensor | None):
+def pack_edge16_fp16x2(w: torch.Tensor, b: torch.Tensor | None, scaled: bool = False):
     """message_net_2 (128 x 128) for the 16-edge-tile edge kernel (k_mpnn_edge16): the two fp16 planes in the
     v_mfma_f32_16x16x32_f16 A-operand order [4 k steps][8 output tiles][2 planes][64 lanes][8 fp16] - lane l of (s, t)
-    holds W[16 t + (l & 15)][32 s + 8 (l >> 4) + 0..7] - plus the fp32 bias."""
+    holds W[16 t + (l & 15)][32 s + 8 (l >> 4) + 0..7] - plus the fp32 bias.  ``scaled``: both planes carry 2^11 (the kernel's
+    one-accumulator variant, ops.mpnn_edge16(single=True))."""
     assert tuple(w.shape) == (128, 128), w.shape
-    planes = [pl.view(8, 16, 4, 4, 8).permute(2, 0, 3, 1, 4).reshape(4, 8, 64, 8) for pl in split_fp16x2(w)]
+    h, lo = split_fp16x2(w)
+    if scaled:     # the single-accumulator variant of the kernel: plane 0 = 2^11 fp16(w) (exact while |w| < 31.98), see pack_edge32t_fp16x2
+        if float(h.float().abs().max()) * 2048.0 >= 65504.0:
+            raise ValueError("pack_edge16_fp16x2(scaled=True): |w| >= 31.98 does not survive the 2^11 pre-scaling of the high plane")
+        h = (h.float() * 2048.0).half()
+    planes = [pl.view(8, 16, 4, 4, 8).permute(2, 0, 3, 1, 4).reshape(4, 8, 64, 8) for pl in (h, lo)]
     out = torch.stack(planes, dim=2).contiguous()            # [s, t, plane, lane, 8]
     bp = torch.zeros(128, dtype=torch.float32, device=w.device)
     if b is not None:

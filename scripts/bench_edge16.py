@@ -38,11 +38,13 @@ def timeit(fn, reps=20):
 ops.mpnn_edge(A, Bm, csr, w32[0], w32[1], agg, partials)
 ref = agg.clone()
 A2, B2 = A * ops.LOG2E, Bm * ops.LOG2E
-for l2e in (False, True):
+w16s = pack_edge16_fp16x2(m2.weight, m2.bias, scaled=True)
+for l2e, single in ((False, False), (True, False), (False, True), (True, True)):
     agg.fill_(float("nan"))
     Ax, Bx = (A2, B2) if l2e else (A, Bm)
-    ms = min(timeit(lambda: ops.mpnn_edge16(Ax, Bx, csr, w16[0], w16[1], agg, partials, l2e=l2e)) for _ in range(3))
-    print(f"k_mpnn_edge16 l2e={l2e} : {ms:.4f} ms  {2 * E * H * H / ms / 1e9:.1f} TFLOP/s-eq "
+    wq = w16s if single else w16
+    ms = min(timeit(lambda: ops.mpnn_edge16(Ax, Bx, csr, wq[0], wq[1], agg, partials, l2e=l2e, single=single)) for _ in range(3))
+    print(f"k_mpnn_edge16{' single-accumulator' if single else ''} l2e={l2e} : {ms:.4f} ms  {2 * E * H * H / ms / 1e9:.1f} TFLOP/s-eq "
           f"(incl. fix-up), frac of 833 = {2 * E * H * H / ms / 1e9 / 833.3:.3f}, rel-diff vs fp32 kernel {float((agg - ref).norm() / ref.norm()):.2e} "
           f"nan={int(torch.isnan(agg).sum())}")
 
