@@ -182,6 +182,13 @@ int magnet_mpnn_edge_fp16x3_t16_f32(const float* A, const float* Bm, const int32
 int magnet_mpnn_edge_fp16x3_t32_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
                                     const int32_t* rowptr, int n_edges, int n_rows, const void* w2_t32, const float* b2,
                                     float* agg, float* partials, int a_bm_log2e_scaled, void* stream);
+/* The same op, WAVE-SPECIALISED (k_mpnn_edge_ws, generation 10): eight lean waves per workgroup - two gather whole
+ * rows and apply the first Swish, four run the transposed GEMM with their slice of W2 resident in registers, two apply the second
+ * Swish and the running mean - pipelined over consecutive tiles through LDS, two workgroups per CU.  Arguments and result contract
+ * as magnet_mpnn_edge_fp16x3_t32_f32 (w2_t32 from packing.pack_edge32t_fp16x2; a_bm_log2e_scaled 0 / 1). */
+int magnet_mpnn_edge_fp16x3_ws_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
+                                   const int32_t* rowptr, int n_edges, int n_rows, const void* w2_t32, const float* b2,
+                                   float* agg, float* partials, int a_bm_log2e_scaled, void* stream);
 /* out[n][k] = u[n][tw-1] + dt*(k+1) * Conv1d(8->1,k2)([Swish](Conv1d(1->8,k1,stride s1)(h[n])))[k];
  * models/mpnn.py:197-201 with the conv specs of :140-163. */
 int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1, int k1,

@@ -427,13 +427,15 @@ __global__ void k_norm_apply(const float* __restrict__ x, const float* __restric
 #ifdef MAGNET_DEV_VARIANTS
 extern int g_edge6_ablation;
 extern int g_edge9_ablation;
+extern int g_edge_ws_ablation;
 static int g_edge_variant = 102;   // persistent v2 kernel, 8 waves / workgroup
 // 102 = k_mpnn_edge2<8> (default), 0 = first-generation k_mpnn_edge, 1x/11x = ablations (results invalid)
 extern "C" int magnet_debug_set_variant(int which, int value) {
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls (e.g. torch's device probing)
     if (which == 0) g_edge_variant = value;
     if (which == 1) g_edge6_ablation = value;
-    if (which == 2) g_edge9_ablation = value;      // k_mpnn_edge32t ablation flags (mpnn_edge32t.hip)
+    if (which == 2) g_edge9_ablation = value;
+    if (which == 3) g_edge_ws_ablation = value;    // k_mpnn_edge_ws role ablations (mpnn_edge_ws.hip)      // k_mpnn_edge32t ablation flags (mpnn_edge32t.hip)
     return 0;
 }
 #endif

@@ -228,8 +228,8 @@ EDGE_ENTRY = {torch.float16: "magnet_mpnn_edge_fp16x3_f32", torch.int16: "magnet
 
 EDGE_ENTRY_L2E = {torch.float16: "magnet_mpnn_edge_fp16x3_l2e_f32", torch.bfloat16: "magnet_mpnn_edge_bf16_l2e_f32"}
 # fp16x3 entry points with their own weight packs (ops.mpnn_edge16 ...), and the kernel behind every entry (bench.py names it)
-EDGE_ENTRY_EXTRA = ("magnet_mpnn_edge_fp16x3_t16_f32", "magnet_mpnn_edge_fp16x3_t32_f32")
-EDGE_KERNEL_OF_ENTRY = {"magnet_mpnn_edge_fp16x3_t16_f32": "k_mpnn_edge16", "magnet_mpnn_edge_fp16x3_t32_f32": "k_mpnn_edge32t", "magnet_mpnn_edge_fp16x3_f32": "k_mpnn_edge7",
+EDGE_ENTRY_EXTRA = ("magnet_mpnn_edge_fp16x3_t16_f32", "magnet_mpnn_edge_fp16x3_t32_f32", "magnet_mpnn_edge_fp16x3_ws_f32")
+EDGE_KERNEL_OF_ENTRY = {"magnet_mpnn_edge_fp16x3_t16_f32": "k_mpnn_edge16", "magnet_mpnn_edge_fp16x3_t32_f32": "k_mpnn_edge32t", "magnet_mpnn_edge_fp16x3_ws_f32": "k_mpnn_edge_ws", "magnet_mpnn_edge_fp16x3_f32": "k_mpnn_edge7",
                         "magnet_mpnn_edge_fp16x3_l2e_f32": "k_mpnn_edge7", "magnet_mpnn_edge_bf16_f32": "k_mpnn_edge7",
                         "magnet_mpnn_edge_bf16_l2e_f32": "k_mpnn_edge7", "magnet_mpnn_edge_bf16x6_f32": "k_mpnn_edge6",
                         "magnet_mpnn_edge_f32": "k_mpnn_edge2"}
@@ -273,6 +273,16 @@ def mpnn_edge32t(A, Bm, csr, w2_t32, b2, agg, partials, l2e=False, paired=False)
                                                     _p(w2_t32), _p(b2), _p(agg), _p(partials), int(l2e) | (2 if paired else 0),
                                                     _stream()),
             "mpnn_edge_fp16x3_t32")
+    return agg
+
+
+def mpnn_edge_ws(A, Bm, csr, w2_t32, b2, agg, partials, l2e=False):
+    """the same op by the wave-specialised kernel (k_mpnn_edge_ws, generation 10: gather / GEMM / epilogue waves pipelined through
+    LDS, fp16x3 only); w2_t32 from packing.pack_edge32t_fp16x2"""
+    assert w2_t32.dtype == torch.float16 and partials.numel() >= edge_scratch_floats(csr.E)
+    L.check(L.lib().magnet_mpnn_edge_fp16x3_ws_f32(_p(A), _p(Bm), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.E, csr.N,
+                                                   _p(w2_t32), _p(b2), _p(agg), _p(partials), int(l2e), _stream()),
+            "mpnn_edge_fp16x3_ws")
     return agg
 
 

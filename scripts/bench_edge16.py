@@ -66,6 +66,13 @@ for l2e, paired in ((False, False), (True, False), (False, True), (True, True)):
     print(f"k_mpnn_edge32{'p (pairs, 2 waves/SIMD)' if paired else 't (generation 9, 1 wave/SIMD)'} l2e={l2e} : {ms:.4f} ms  frac of 833 = "
           f"{2 * E * H * H / ms / 1e9 / 833.3:.3f}, rel-diff vs fp32 kernel {float((agg - ref).norm() / ref.norm()):.2e} nan={int(torch.isnan(agg).sum())}")
 
+for l2e in (False, True):
+    agg.fill_(float("nan"))
+    Ax, Bx = (A2, B2) if l2e else (A, Bm)
+    ms = min(timeit(lambda: ops.mpnn_edge_ws(Ax, Bx, csr, w32t[0], w32t[1], agg, partials, l2e=l2e)) for _ in range(3))
+    print(f"k_mpnn_edge_ws (generation 10: wave-specialised, 4 waves/SIMD) l2e={l2e} : {ms:.4f} ms  frac of 833 = "
+          f"{2 * E * H * H / ms / 1e9 / 833.3:.3f}, rel-diff vs fp32 kernel {float((agg - ref).norm() / ref.norm()):.2e} nan={int(torch.isnan(agg).sum())}")
+
 # ---- clock / power under a sustained loop of each kernel (is the part power-limited? DESIGN.md 10.2)
 if os.environ.get("EDGE_CLOCKS", "0") == "1":
     import ctypes as C, glob, re, subprocess, threading, time

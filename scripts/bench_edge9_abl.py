@@ -44,3 +44,28 @@ for abl, name in names.items():
     ms = min(timeit(lambda: ops.mpnn_edge32t(A, Bm, csr, w[0], w[1], agg, partials, l2e=True)) for _ in range(3))
     print(f"ABL {abl:2d} {name:46s}: {ms:.4f} ms")
 ops.L.lib().magnet_debug_set_variant(2, 0)
+
+# ---- k_mpnn_edge_ws: which role sets the step time?  (1 = P idle, 2 = M idle, 4 = E idle)
+for abl, name in ((0, "as shipped"), (6, "P only"), (5, "M only"), (3, "E only"), (4, "P + M"), (2, "P + E"), (1, "M + E"), (7, "barriers only")):
+    ops.L.lib().magnet_debug_set_variant(3, abl)
+    ms = min(timeit(lambda: ops.mpnn_edge_ws(A, Bm, csr, w[0], w[1], agg, partials, l2e=True)) for _ in range(3))
+    print(f"WS ABL {abl} {name:14s}: {ms:.4f} ms")
+ops.L.lib().magnet_debug_set_variant(3, 0)
+
+# ---- cycle trace of workgroup 0 (development build): where does a step go, per role?
+import ctypes as C
+lib = ops.L.lib()
+lib.magnet_debug_ws_trace.restype = C.c_int
+buf = (C.c_longlong * 32)()
+ops.mpnn_edge_ws(A, Bm, csr, w[0], w[1], agg, partials, l2e=True)
+torch.cuda.synchronize()
+lib.magnet_debug_ws_trace(None, 1)
+ops.mpnn_edge_ws(A, Bm, csr, w[0], w[1], agg, partials, l2e=True)
+torch.cuda.synchronize()
+lib.magnet_debug_ws_trace(buf, 0)
+steps = (E + 31) // 32 / 512
+names = {0: "P barrier+loop", 1: "P rows wait + Swish (slots 0-7)", 2: "P pieces + LDS writes", 3: "P requests", 5: "P rows wait + Swish (8-15)",
+         6: "P pieces + LDS writes", 7: "P requests", 8: "M barrier+loop", 9: "M frag reads + MFMA issue", 10: "M acc sum + Y stores",
+         16: "E barrier+loop", 17: "E meta", 18: "E 32 edges"}
+for k, nm in names.items():
+    print(f"trace {k:2d} {nm:34s}: {buf[k] / steps:8.0f} cycles per step")

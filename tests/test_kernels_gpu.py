@@ -262,7 +262,7 @@ def test_mpnn_edge_log2e_scaled_inputs_give_the_same_mean():
 @pytest.mark.parametrize("case", ["ragged", "no_edges", "under_one_tile", "one_row_owns_everything", "every_row_one_edge",
                                   "small_values"])
 @pytest.mark.parametrize("l2e", [False, True])
-@pytest.mark.parametrize("kernel", ["edge16", "edge16s", "edge32t", "edge32p"])
+@pytest.mark.parametrize("kernel", ["edge16", "edge16s", "edge32t", "edge32p", "edgews"])
 def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
     """k_mpnn_edge16 (16-edge tiles, v_mfma_f32_16x16x32_f16, two waves per SIMD, its own weight fragment order) and k_mpnn_edge32t
     (generation 9: transposed 32-edge tiles, lane = output feature, one accumulator, unscaled fp16-subnormal low pieces) against a
@@ -299,6 +299,9 @@ def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
     if kernel in ("edge16", "edge16s"):       # edge16s: the one-accumulator variant (planes pre-scaled by 2^11)
         w, b = pack_edge16_fp16x2(lin.weight.cuda(), lin.bias.cuda(), scaled=kernel == "edge16s")
         ops.mpnn_edge16(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e, single=kernel == "edge16s")
+    elif kernel == "edgews":                  # generation 10: wave-specialised (gather / GEMM / epilogue waves through LDS)
+        w, b = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
+        ops.mpnn_edge_ws(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e)
     else:
         w, b = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
         ops.mpnn_edge32t(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e, paired=kernel == "edge32p")
