@@ -37,8 +37,8 @@ Extra objects on the JSON line:
                   (configs/trainer/default.yaml:5); the headline mode fp16x3 holds ~22-bit operands.
   cpu_baseline  - the oracle (torch-CPU restatement of the reference op sequence) timed on this
                   box's host cores on a bounded sample (rollouts of one 128 x 128 trajectory;
-                  forward calls only, graph construction excluded), rank 0, N = 1 only; the thread count is the best of
-                  {physical cores / 2, physical cores, logical CPUs} by a one-forward sweep (all three reported).
+                  forward calls only, graph construction excluded), rank 0, N = 1 only; the thread count is the better of
+                  {physical cores / 2, physical cores} by a one-forward sweep (both reported).
   dist          - what the process group saw: backend, world size, per-rank ms_per_step; `training_step.allreduce_ms` =
                   the gradient all-reduce of one step (HIP events).
   traffic (inside both roofline objects) - HBM bytes per launch from the newest committed PMC measurement of this same
@@ -189,8 +189,8 @@ def cpu_baseline(W=128, timed=3):
     """the oracle's free-running rollout of ONE trajectory on a W x W mesh on the host cores, fp32,
     no_grad, 1 warm-up rollout + ``timed`` timed rollouts, median; the radius-graph build is timed separately (the oracle
     builds it by brute force) and excluded from the rollout time, as the reference's own CPU numbers in BASELINE.md are.
-    Thread count: the fastest of {physical / 2, physical, logical} on one forward call (torch's default = logical CPUs
-    oversubscribes an SMT part); `cores` is the count the timed rollouts used."""
+    Thread count: the faster of {physical / 2, physical} on one forward call (torch's default = logical CPUs oversubscribes an
+    SMT part by an order of magnitude); `cores` is the count the timed rollouts used."""
     from oracle import models as O
     torch.manual_seed(0)
     hp = types.SimpleNamespace(**HP)
@@ -217,7 +217,9 @@ def cpu_baseline(W=128, timed=3):
     logical, phys = len(os.sched_getaffinity(0)), physical_cores()
     default_threads = torch.get_num_threads()
     sweep = {}
-    for n in sorted({max(1, phys // 2), phys, logical}):
+    # (torch's default, one thread per LOGICAL cpu, is not a candidate on an SMT box: measured 44 s per forward at 256 threads against 3.2 s at
+    # 64 on the pool's EPYC 9575F - trying it would cost the bench a minute and a half)
+    for n in sorted({max(1, phys // 2), phys} | ({logical} if logical <= phys else set())):
         torch.set_num_threads(n)
         rollout(1)                                                        # thread pool / allocator warm-up at this size
         sweep[n] = round(rollout(1), 2)                                   # one forward call

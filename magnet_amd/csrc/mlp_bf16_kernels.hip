@@ -380,6 +380,16 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
     MLP_CASE(5, 2, 2, ACT_RELU, false, true, EPI_STORE)
     MLP_CASE(5, 2, 4, ACT_RELU, false, true, EPI_STORE)
     MLP_CASE(5, 2, 4, ACT_RELU, false, true, EPI_QUADBLEND)
+    // single Linear + LayerNorm (+ residual / CSR mean / quad blend): the LAST layer of a chain with mlp_layers != 4, whose hidden layers run as
+    // one-Linear launches (magnet_amd/ops.py:_mlp_by_layers; models/backbones/mlp.py:9-28 is generic in its depth)
+    MLP_CASE(1, 4, 4, ACT_NONE, false, true, EPI_STORE)
+    MLP_CASE(1, 4, 4, ACT_NONE, false, true, EPI_STORE_RES)
+    MLP_CASE(1, 4, 4, ACT_NONE, false, true, EPI_SEGMEAN)
+    MLP_CASE(1, 1, 1, ACT_NONE, false, true, EPI_STORE)
+    MLP_CASE(1, 1, 1, ACT_NONE, false, true, EPI_STORE_RES)
+    MLP_CASE(1, 1, 1, ACT_NONE, false, true, EPI_SEGMEAN)
+    MLP_CASE(1, 2, 2, ACT_NONE, false, true, EPI_STORE)
+    MLP_CASE(1, 4, 4, ACT_NONE, false, true, EPI_QUADBLEND)
     MLP_CASE_SMALL(2, 4, 4, ACT_SWISH, true, false, EPI_STORE)
     MLP_CASE_SMALL(2, 4, 4, ACT_SWISH, true, false, EPI_STORE_RES)
     MLP_CASE_SMALL(1, 4, 4, ACT_NONE, false, false, EPI_STORE)

@@ -42,8 +42,8 @@ class MAgNetCNN(MagnetBase):
         self.interpolation, self.radius, self.teacher_forcing = hparams.interpolation, hparams.radius, hparams.teacher_forcing
         # A/B knob: the 2-D area blend inside the decoder chain's epilogue (EPI_QUADBLEND) instead of a blend pass over materialised predictions
         self.fused_blend = bool(getattr(hparams, "fused_blend", __import__("os").environ.get("MAGNET_FUSED_BLEND", "1") != "0"))
-        if self.mlp_layers != 4:
-            raise NotImplementedError("the HIP MLP kernel is instantiated for mlp_layers == 4 (5 Linears)")
+        if not 1 <= self.mlp_layers <= 5:        # 4 (every shipped config): the fused 5-Linear kernel; other depths run layer by layer
+            raise NotImplementedError("mlp_layers must be between 1 and 5")
         T, D, Lm, Hm, C, K = self.time_slice, self.latent_dim, self.mlp_layers, self.mlp_hidden, self.n_chan, self.num_message_passing_steps
         self.encoder = EDSR(in_chan=T, n_chan=C, res_layers=self.res_layers, kernel_size=self.kernel_size,
                             res_scale=self.res_scale, mode="2d" if d == 2 else "1d")

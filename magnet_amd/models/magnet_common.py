@@ -99,7 +99,7 @@ def pack_graph_net(enc: Encoder, proc: Processor, ldn: int):
     for k, g in enumerate(proc.gnn_stacks):
         D = g.node_fn[0].out_dim
         chain_for, pre_i, pre_j = pack_interaction_edge(g.edge_fn, D)
-        factored = g.edge_fn[0].hidden <= D                        # see MagnetBase._graph_net
+        factored = g.edge_fn[0].hidden <= D and len(g.edge_fn[0].linears()) == 5      # see MagnetBase._graph_net (fused chain only)
         hops.append(types.SimpleNamespace(edge=pack_mlp_ln(g.edge_fn), node=pack_mlp_ln(g.node_fn),
                                           edge_f=chain_for(2 ** k) if factored else None, pre_i=pre_i, pre_j=pre_j))
     return types.SimpleNamespace(node=pack_mlp_ln(enc.node_fn, k_pad=ldn), edge=pack_mlp_ln(enc.edge_fn, k_pad=ldn), hops=hops)
@@ -216,7 +216,7 @@ class MagnetBase(LightningModule):
         # gathered rows (hidden <= latent: MAgNet[GNN] 128 / 128; the CNN models' 64-wide chains over 32-wide latents keep the
         # concatenated form - measured: C5 edge chain 1.55 -> 1.21 ms, C4b 0.38 -> 0.39 ms)
         Hm = pk.hops[0].edge.ht * 32 if pk.hops else 0
-        factored = 0 < Hm <= D
+        factored = 0 < Hm <= D and pk.hops[0].edge_f is not None
         resident_halves = (factored and D == 128 and Hm == 128 and pk.hops[0].pre_i[0].dtype == torch.float16       # (fp16x3 planes)
                            and os.environ.get("MAGNET_FUSED_HALVES", "1") != "0")
         if factored:

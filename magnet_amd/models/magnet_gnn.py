@@ -42,8 +42,8 @@ class MAgNetGNN(MagnetBase):
         self.codec_neighbors, self.teacher_forcing = hparams.codec_neighbors, hparams.teacher_forcing
         self.noise, self.interpolation = hparams.noise, hparams.interpolation
         self.coord_dim = d = getattr(hparams, "coord_dim", 2)
-        if self.mlp_layers != 4:
-            raise NotImplementedError("the HIP MLP kernel is instantiated for mlp_layers == 4 (5 Linears)")
+        if not 1 <= self.mlp_layers <= 5:        # 4 (every shipped config): the fused 5-Linear kernel; other depths run layer by layer
+            raise NotImplementedError("mlp_layers must be between 1 and 5")
         T, D, Lm, Hm, K = self.time_slice, self.latent_dim, self.mlp_layers, self.mlp_hidden, self.num_message_passing_steps
         self.encoder = Encoder(T + d + 1, D, T + d, D, Lm, Hm)
         self.processor = Processor(D, D, D, D, K, Lm, Hm)

@@ -146,9 +146,36 @@ def mlp(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STO
         res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0, pre=None,
         x0_out=None, hid=None):
     """Run the fused MLP kernel.  ``layers``: list of (packed_w, padded_b).  Returns y."""
+    if nl > 1 and colgroups == 1 and not L.lib().magnet_mlp_supported(nl, ht, ot, act, int(last_act), int(ln is not None),
+                                                                       EPI_STORE if epi == EPI_QUADBLEND else epi):
+        return _mlp_by_layers(M, kts, layers, nl=nl, ht=ht, ot=ot, act=act, last_act=last_act, ln=ln, epi=epi, y=y, ldy=ldy,
+                              ncols=ncols, res=res, tgt=tgt, rowptr=rowptr, partials=partials, pre=pre, x0_out=x0_out, hid=hid)
     mlp_plan(M, kts, layers, nl=nl, ht=ht, ot=ot, act=act, last_act=last_act, ln=ln, epi=epi, y=y, ldy=ldy, ncols=ncols,
              res=res, tgt=tgt, rowptr=rowptr, partials=partials, colgroups=colgroups, groups_in_block=groups_in_block,
              y_group_stride=y_group_stride, pre=pre, x0_out=x0_out, hid=hid)()
+    return y
+
+
+def _mlp_by_layers(M, kts, layers, *, nl, ht, ot, act, last_act, ln, epi, y, ldy, ncols, res, tgt, rowptr, partials, pre, x0_out, hid):
+    """A chain depth the fused kernel is not instantiated for (the reference's MLP is generic in ``mlp_layers``,
+    models/backbones/mlp.py:9-28; every shipped config uses 4, i.e. the fused 5-Linear kernel): the hidden layers as one-Linear
+    launches that materialise [M, hidden], the last Linear with the chain's LayerNorm / epilogue.  Correct, not fast."""
+    if pre is not None:
+        raise NotImplementedError("a factored first layer needs the fused chain kernel (5 Linears)")
+    dev = y.device
+    if x0_out is not None:                                     # tape output (training recompute): the assembled first-layer input
+        a, keep = mlp_args(M, kts)
+        L.check(L.lib().magnet_mlp_materialize_input_f32(C.byref(a), _p(x0_out), x0_out.shape[1], _stream()), "materialize_input")
+    hid = list(hid) if hid is not None else [None] * nl
+    h, src = None, kts
+    for l in range(nl - 1):
+        h = hid[l] if hid[l] is not None else torch.empty(max(M, 1), ht * 32, device=dev, dtype=torch.float32)
+        mlp_plan(M, src, [layers[l]], nl=1, ht=ht, ot=ht, act=act, last_act=True, y=h)()
+        src = ktiles(Term(h, ht * 32))
+    if hid[nl - 1] is not None:                                # tape output: the last Linear's raw result (before LayerNorm)
+        mlp_plan(M, src, [layers[nl - 1]], nl=1, ht=ot, ot=ot, act=ACT_NONE, last_act=False, y=hid[nl - 1])()
+    mlp_plan(M, src, [layers[nl - 1]], nl=1, ht=ot, ot=ot, act=act if last_act else ACT_NONE, last_act=last_act, ln=ln, epi=epi, y=y,
+             ldy=ldy, ncols=ncols, res=res, tgt=tgt, rowptr=rowptr, partials=partials)()
     return y
 
 

@@ -402,3 +402,39 @@ def test_magnet_cnn_1d_batch_32(hip_graph):
     with torch.no_grad():
         want = oracle.validation_step(big)
     assert pred.shape == want.shape and rel_l2(pred, want) < 5 * OUT_TOL
+
+
+@pytest.mark.parametrize("tag,layers", [("magnet_gnn_tiny", 2), ("magnet_gnn_tiny", 3), ("magnet_cnn_1d", 3), ("magnet_cnn_2d", 1)])
+def test_mlp_depths_other_than_four(tag, layers):
+    """models/backbones/mlp.py:9-28 is generic in its depth; every shipped config uses mlp_layers = 4 (the fused 5-Linear kernel).  Other
+    depths run their hidden layers as one-Linear launches and the last Linear with the chain's LayerNorm / epilogue
+    (ops._mlp_by_layers): forward, rollout and one training step against the oracle built with the same hyper-parameter."""
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    name, hp, salt, batch, d = load_case(tag)
+    hp.mlp_layers = layers
+    oracle = O.build(name, hp).eval()
+    fill_state_dict(oracle, salt)
+    model = FACTORY[name](hp).eval()
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda()
+    args = forward_args(name, hp, batch)
+    with torch.no_grad():
+        want = oracle(*args)
+    got = model(*[a.cuda() for a in args])
+    for g_, w_, key in zip(got, want, ("out_hr", "out_lr", "hr_points")):
+        assert rel_l2(g_, w_) < OUT_TOL, (key, rel_l2(g_, w_))
+    cb = {k: v.cuda() for k, v in batch.items()}
+    pred = model.validation_step(cb, 0)
+    with torch.no_grad():        # (the single forward meets the 1e-5 bar above; these untrained shallow nets amplify fp32 rounding ~7x per fed-back step)
+        assert rel_l2(pred, oracle.validation_step(batch)) < 2e-4
+    # one training step: the loss of the same rollout, gradients for every parameter
+    model.train()
+    loss = model.training_step(cb, 0)
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    oracle.train()
+    want_loss = oracle.training_step(batch) if hasattr(oracle, "training_step") else None
+    if want_loss is not None:
+        assert abs(float(loss.detach()) - float(want_loss.detach())) < 2e-5 * max(1.0, abs(float(want_loss.detach())))
