@@ -71,6 +71,9 @@ class EDSR(nn.Module):
             self._pack = dict(head=mk(self.head_conv, cin), tail=mk(self.tail_conv, self.n_chan),
                               blocks=[(mk(b.conv_1, self.n_chan), mk(b.conv_2, self.n_chan)) for b in self.res_layers])
             self._pack_key = key
+            if params[0].is_cuda:
+                from ...packing import raise_if_bad_weights
+                raise_if_bad_weights(params[0].device)   # fp16x3 range check of the packs just made: one host read per re-pack
         return self._pack
 
     def _tap_table(self, B, spatial, device):

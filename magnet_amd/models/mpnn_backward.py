@@ -63,6 +63,9 @@ def _packed_bwd(m):
     Q.e1t = pack(e1.t(), None, mode)
     Q.e0t = pack(padk(e0).t(), None, mode)                               # [kin, H]
     m._pack_bwd, m._pack_bwd_key = Q, m._pack_key
+    if dev.type == "cuda":
+        from ..packing import raise_if_bad_weights
+        raise_if_bad_weights(dev)              # the fp16 planes of W2 / W2^T for the fused edge backward: one host read per re-pack
     return Q
 
 
