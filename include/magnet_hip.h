@@ -384,6 +384,16 @@ int magnet_mpnn_edge_bwd_f32(const float* A, const float* Bm, const float* dagg,
                              const int32_t* rowptr, int n_nodes, int n_edges, const void* w2_f16, const void* w2t_f16,
                              const float* b2, float* s1, float* dq, float* dp, float* dA, float* partials, void* stream);
 
+/* The same backward with the weight gradient of message_net_2 formed inside the kernel (what torch autograd returns for
+ * message_net_2.weight / .bias, models/mpnn.py:32-35): dW2 [128][128] (+)= dq^T s1, db2 [128] (+)= column sums of dq - s1 and dq are
+ * never written to memory; dp [n_edges][128] and dA [n_nodes][128] as above.  workspace: magnet_mpnn_edge_bwd_w_workspace() floats
+ * (per-workgroup partial sums, added in workgroup order: deterministic). */
+int magnet_mpnn_edge_bwd_w_workspace(void);
+int magnet_mpnn_edge_bwd_w_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src, const int32_t* tgt,
+                               const int32_t* rowptr, int n_nodes, int n_edges, const void* w2_f16, const void* w2t_f16,
+                               const float* b2, float* dp, float* dA, float* partials, float* dW2, float* db2, int accumulate,
+                               float* workspace, void* stream);
+
 /* Weight packing on the device (magnet_amd/packing.py: the same layouts as torch index shuffles; no reference counterpart - the
  * reference hands its nn.Linear weights to cuBLAS as they are).  Padded position (r, c) of the [np x kp] matrix takes
  * w[r' stride_r + c' stride_c] with r' = row_src ? row_src[r] : r (r < n) and c' = col_src ? col_src[c] : c (c < k); -1 / out of

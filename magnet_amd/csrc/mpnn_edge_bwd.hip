@@ -279,6 +279,370 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same backward with the weight gradient of message_net_2 formed IN the kernel: dW2 = dq^T s1 and db2 = colsum(dq) never see
+// s1 / dq in HBM (8.8 GB written and 8.8 GB read back per hop at 8.6 M edges; k_mpnn_edge_bwd above + k_wgrad_split).
+//
+// The contraction of dW2 runs over EDGES, the lane dimension of every register tile this kernel holds, and a 128 x 128 fp32
+// accumulator is 256 registers per wave - so the four waves of the workgroup (one per SIMD, in lockstep on the t-th tile of their
+// ranges) each own a 32-row slab of dW2 (rows = features of dq; 64 accumulator registers) and see every wave's tile through LDS:
+//   * what is left of the 160 KiB beside the two weight orientations (128 KiB) holds ONE tile's dq [128 features][32 edges] and HALF
+//     of its s1 [64 features][32 edges], fp32, feature-major with a 36-float row stride: the publishing wave writes dwords (lane =
+//     edge: conflict-free), every wave reads 16-byte runs of 8 consecutive edges of one feature (conflict-free for the b128 lane
+//     groups) - i.e. its MFMA operands "lane = feature, registers = edges" come straight out of the transposition;
+//   * the waves publish in turn (4 rounds per step, 4 barriers per round); a round's second s1 half is written while the others run
+//     the MFMAs of the first half.  Only the publisher's STORES are conditional: values defined under `if (wave == s)` (a
+//     parallel-staging variant with resident operands was tried first) made hipcc sink computations into the branches and spill
+//     300-500 registers;
+//   * arithmetic: the fp16 split with ONE accumulator (x y ~ hx hy + lx hy + hx ly, the low pieces UNSCALED fp16 - subnormal at
+//     worst, the matrix cores keep subnormals), 3 v_mfma_f32_32x32x16_f16 per 16 edges and 32 x 32 block; the two GEMMs of the data
+//     path use the same scheme (gemm128_single) because the cross accumulators of the two-accumulator form are the 64 registers the
+//     dW2 slab needs.  dq ~ 1e-7 is outside fp16's range, so it is staged times G = 2^k, ONE power of two per launch chosen from
+//     max|dagg| (k_absmax_partial; |dq| <= 1.1 max|dagg|, G max|dq| < 2^15), exact and divided out of the per-workgroup partial sums;
+//   * register roles are rotated so that nothing is recomputed: s1 stays in x until it has been staged (GEMM 1 only reads it), dq is
+//     formed in place in GEMM 1's accumulator, GEMM 2 accumulates into x, and Swish'(p) comes from the same sigmoid as s1 - one
+//     sigmoid per element less than k_mpnn_edge_bwd.
+// Per-workgroup partial sums [grid][128][128] / [grid][128] leave once at the end; k_reduce_partials adds them in workgroup order.
+#define EBW_ES 36
+
+__global__ void __launch_bounds__(256) k_absmax_partial(const float* __restrict__ x, long n4, float* __restrict__ part) {
+    __shared__ float wm[4];
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = x4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+}
+
+// one word of each fp16 plane from two values: h = RTZ fp16, l = RNE fp16 of the exact remainder, NOT scaled
+__device__ __forceinline__ void split_f16_plain(float a0, float a1, unsigned& h, unsigned& l) {
+    h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a0, a1));
+    float d0, d1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(h), "v"(a0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(h), "v"(a1));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(l) : "v"(d0));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, 0" : "+v"(l) : "v"(d1));
+}
+// 8 consecutive edges of one staged feature row -> the two planes of an MFMA operand
+__device__ __forceinline__ float stage_operand(const float* __restrict__ row, f16x8& hi, f16x8& lo) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(row), b = *reinterpret_cast<const f32x4*>(row + 4);
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split_f16_plain(a[0], a[1], h0, l0);
+    split_f16_plain(a[2], a[3], h1, l1);
+    split_f16_plain(b[0], b[1], h2, l2);
+    split_f16_plain(b[2], b[3], h3, l3);
+    const u32x4 h = {h0, h1, h2, h3}, l = {l0, l1, l2, l3};
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = __builtin_bit_cast(f16x8, l);
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+}
+
+// acc[nt] += 2^11 W x for the wave's [128 x 32] register tile with ONE accumulator per output block: the planes in LDS are
+// (2^11 hw, 2^11 lw) - plane 0 of the standard fp16x3 pack scaled while it was copied in - and the activation's low piece is the
+// unscaled fp16 remainder, so the three products of the split share one scale (no cross accumulator, no fold: 64 registers that the
+// dW2 slab needs).  Two output blocks per group: consecutive MFMAs never write the same accumulator.
+__device__ __forceinline__ void gemm128_single(const u32x4* __restrict__ wl, const f32x16 (&x)[4], f32x16 (&acc)[4], int lane) {
+    u32x4 xs[2][2], wr[2][2][2];                   // xs[slot parity][plane]; wr[group parity][block of the pair][plane]
+    auto quarter = [&](int slot, int q) {
+        unsigned h, l;
+        const f32x16& t = x[slot >> 1];
+        const int m = slot & 1;
+        split_f16_plain(t[8 * m + 2 * q], t[8 * m + 2 * q + 1], h, l);
+        xs[slot & 1][0][q] = h;
+        xs[slot & 1][1][q] = l;
+    };
+    auto wload = [&](int gq) {
+        const int slot = gq >> 1, pr = gq & 1;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const u32x4* wp = wl + ((((slot >> 1) * 4 + 2 * pr + b) * 2 + (slot & 1)) * 2) * 64 + lane;
+            wr[gq & 1][b][0] = wp[0];
+            wr[gq & 1][b][1] = wp[64];
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) quarter(0, q);
+    wload(0);
+#pragma unroll
+    for (int gq = 0; gq < 16; ++gq) {              // gq = slot * 2 + pair, slot = kt * 2 + m
+        const int slot = gq >> 1, pr = gq & 1;
+        if (gq + 1 < 16) wload(gq + 1);
+        if (slot + 1 < 8) {
+            quarter(slot + 1, 2 * pr);
+            quarter(slot + 1, 2 * pr + 1);
+        }
+        const f16x8 xh = __builtin_bit_cast(f16x8, xs[slot & 1][0]), xl = __builtin_bit_cast(f16x8, xs[slot & 1][1]);
+        const f16x8 w0h = __builtin_bit_cast(f16x8, wr[gq & 1][0][0]), w0l = __builtin_bit_cast(f16x8, wr[gq & 1][0][1]);
+        const f16x8 w1h = __builtin_bit_cast(f16x8, wr[gq & 1][1][0]), w1l = __builtin_bit_cast(f16x8, wr[gq & 1][1][1]);
+        f32x16& a0 = acc[2 * pr];
+        f32x16& a1 = acc[2 * pr + 1];
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0l, xh, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l, xh, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h, xl, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, xl, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h, xh, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, xh, a1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// plane 0 (the fp16 high pieces) of the standard pack times 2^11
+__device__ __forceinline__ u32x4 scale_plane_2048(u32x4 v) {
+    // (one vector multiply: written as a loop over the four words that assigns o[c], hipcc 7.2 scales word 0 and stores it in all four)
+    return __builtin_bit_cast(u32x4, (f16x8)(__builtin_bit_cast(f16x8, v) * (_Float16)2048.0f));
+}
+
+// workgroup barrier for LDS hand-overs only: __syncthreads() also waits for vmcnt(0), i.e. for the dp stores and the prefetched rows
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd_w(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                            const float* __restrict__ dagg, const int32_t* __restrict__ src,
+                                                            const int32_t* __restrict__ tgt, const int32_t* __restrict__ rowptr,
+                                                            int E, const u32x4* __restrict__ w2s, const u32x4* __restrict__ w2ts,
+                                                            const float* __restrict__ b2, float* __restrict__ dp_out,
+                                                            float* __restrict__ dA, float* __restrict__ partials,
+                                                            const float* __restrict__ amax_part, int n_amax,
+                                                            float* __restrict__ wpart, float* __restrict__ bpart) {
+    constexpr int NP = 2;
+    constexpr int ES = EBW_ES;
+    __shared__ __attribute__((aligned(16))) u32x4 wl[32 * NP * 64];          // W2   planes (2^11 hw, 2^11 lw), 64 KiB
+    __shared__ __attribute__((aligned(16))) u32x4 wt[32 * NP * 64];          // W2^T planes, 64 KiB
+    __shared__ __attribute__((aligned(16))) float bl[128];                   // 2^11 b2
+    __shared__ __attribute__((aligned(16))) float sdq[128 * ES];             // one tile's G dq, [feature][edge]
+    __shared__ __attribute__((aligned(16))) float ss1[64 * ES];              // half of its s1
+    __shared__ float gsc[4];
+    for (int i = threadIdx.x; i < 32 * NP * 64; i += 256) {                  // [kt][nt][m][plane][64 lanes]: plane = bit 6 of i
+        const bool hi_plane = ((i >> 6) & 1) == 0;
+        wl[i] = hi_plane ? scale_plane_2048(w2s[i]) : w2s[i];
+        wt[i] = hi_plane ? scale_plane_2048(w2ts[i]) : w2ts[i];
+    }
+    if (threadIdx.x < 128) bl[threadIdx.x] = b2[threadIdx.x] * 2048.0f;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the per-wave branches are s_cbranch)
+    const int half = lane >> 5, j = lane & 31;
+    float G, invG;
+    {
+        float m = 0.f;
+        for (int i = threadIdx.x; i < n_amax; i += 256) m = fmaxf(m, amax_part[i]);
+#pragma unroll
+        for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) gsc[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(gsc[0], gsc[1]), fmaxf(gsc[2], gsc[3]));
+        const unsigned eb = (__float_as_uint(m) >> 23) & 0xFFu;               // max|dagg| in [2^(eb-127), 2^(eb-126))
+        const bool ok = eb >= 14u && eb < 255u;
+        G = ok ? __uint_as_float((267u - eb) << 23) : 1.0f;                   // 2^(140-eb): G * 1.1 max|dagg| < 2^15
+        invG = ok ? __uint_as_float((eb - 13u) << 23) : 1.0f;
+    }
+    const int ntiles = (E + 31) / 32;
+    const int nb8 = gridDim.x / 8;
+    const int vb = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * nb8 + blockIdx.x / 8 : blockIdx.x;
+    const int tpw = (ntiles + gridDim.x * 4 - 1) / (gridDim.x * 4);
+    int tile = (vb * 4 + wave) * tpw;
+    // every wave runs tpw steps (the barriers below are workgroup-wide); tiles past the end are all-invalid lanes: clamped loads,
+    // zero contributions, no stores
+    f32x16 ga[4], gb[4];
+    {
+        const int e = min(tile * 32 + j, E - 1);
+        const float* pa = A + (size_t)tgt[e] * 128 + 4 * half;
+        const float* pb = Bm + (size_t)src[e] * 128 + 4 * half;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(pa + kt * 32 + 8 * g);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(pb + kt * 32 + 8 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ga[kt][4 * g + c] = a[c];
+                    gb[kt][4 * g + c] = b[c];
+                }
+            }
+    }
+    int m_ti, m_tnext, m_rs, m_re;
+    {
+        const int e_raw = tile * 32 + j;
+        m_ti = tgt[e_raw < E ? e_raw : E - 1];
+        m_tnext = (e_raw + 1 < E && j < 31) ? tgt[e_raw + 1] : -2;
+        m_rs = rowptr[m_ti];
+        m_re = rowptr[m_ti + 1];
+    }
+    f32x16 accw[4];                                                           // G dW2[32 wave + row][32 b + column]
+    zero_tiles<4>(accw);
+    float bsum = 0.f;
+    for (int step = 0; step < tpw; ++step, ++tile) {
+        const TileMeta md = tile_meta_from(tile, E, j, m_ti, m_tnext, m_rs, m_re);
+        const int e = min(tile * 32 + j, E - 1);
+        const int ti = md.ti;
+        const float inv_deg = md.e_ok ? 1.0f / (float)(md.re - md.rs) : 0.0f;   // (invalid lanes: dq = 0)
+        const size_t row = (size_t)e * 128 + 4 * half;
+        const int tn = tile + 1;
+        const int en = min(tn * 32 + j, E - 1);
+        const int tin = tgt[en];
+        const int tnn = (tn * 32 + j + 1 < E && j < 31) ? tgt[min(tn * 32 + j + 1, E - 1)] : -2;
+        const int sjn = src[en];                                           // (the row pointers are formed where the rows are requested)
+        // register roles: p = A[i] + Bm[j], then Swish'(p) (both from ONE sigmoid, for the dp phase); x = s1, intact until it has
+        // been staged for the weight gradient, then GEMM 2's accumulator; acc = GEMM 1's accumulator, then dq in place
+        f32x16 p[4], x[4], acc[4], gd[4];
+        {   // dagg rows (consumed after GEMM 1)
+            const float* pd = dagg + (size_t)ti * 128 + 4 * half;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 d = *reinterpret_cast<const f32x4*>(pd + nt * 32 + 8 * g);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gd[nt][4 * g + c] = d[c];
+                }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = ga[kt][i] + gb[kt][i], sg = sigmoid_fast(v);
+                x[kt][i] = v * sg;
+                p[kt][i] = sg * (1.0f + v * (1.0f - sg));
+            }
+            asm volatile("" : "+v"(p[kt]));                                   // formed here: sunk to the dp phase, v AND sg would stay alive
+        }
+        // ---- GEMM 1: 2^11 q = 2^11 (W2 s1 + b2)
+        {
+            int boff = 0;
+            asm volatile("" : "+v"(boff));
+            init_bias<4>(acc, bl + boff, half);
+        }
+        gemm128_single(wl, x, acc, lane);
+        // ---- dq = dagg[i] / deg * Swish'(q), in place; then times the per-edge power of two of GEMM 2's fp16 split
+        float mx = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = gd[nt][i] * inv_deg * dswish(acc[nt][i] * (1.0f / 2048.0f));
+                acc[nt][i] = v;
+                mx = fmaxf(mx, fabsf(v));
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const unsigned eb = (__float_as_uint(mx) >> 23) & 0xFFu;
+        const float sc = __uint_as_float((254u - eb) << 23);
+        const float usc = __uint_as_float(eb << 23);
+        // ---- dW2 += dq^T s1, db2 += colsum(dq): the four tiles of this step, one publisher at a time (its stores are the only
+        // conditional code: no value is defined under a branch)
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) {
+            wg_barrier();                                                     // staging free: everybody has read the previous round
+            if (wave == s) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sdq[(nt * 32 + 8 * (i >> 2) + 4 * half + (i & 3)) * ES + j] = acc[nt][i] * G;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ss1[(nt * 32 + 8 * (i >> 2) + 4 * half + (i & 3)) * ES + j] = x[nt][i];
+            }
+            wg_barrier();
+            f16x8 ah[2], al[2], xh[2][2], xl[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bsum += stage_operand(sdq + (wave * 32 + j) * ES + 16 * ks + 8 * half, ah[ks], al[ks]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) stage_operand(ss1 + (b * 32 + j) * ES + 16 * ks + 8 * half, xh[b][ks], xl[b][ks]);
+            wg_barrier();                                                     // first half of s1 consumed (it sits in registers)
+            if (wave == s) {
+#pragma unroll
+                for (int nt = 2; nt < 4; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ss1[((nt - 2) * 32 + 8 * (i >> 2) + 4 * half + (i & 3)) * ES + j] = x[nt][i];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                accw[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], xh[0][ks], accw[0], 0, 0, 0);
+                accw[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], xh[1][ks], accw[1], 0, 0, 0);
+                accw[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], xl[0][ks], accw[0], 0, 0, 0);
+                accw[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], xl[1][ks], accw[1], 0, 0, 0);
+                accw[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], xh[0][ks], accw[0], 0, 0, 0);
+                accw[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], xh[1][ks], accw[1], 0, 0, 0);
+            }
+            wg_barrier();                                                     // second half staged
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) stage_operand(ss1 + (b * 32 + j) * ES + 16 * ks + 8 * half, xh[b][ks], xl[b][ks]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                accw[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], xh[0][ks], accw[2], 0, 0, 0);
+                accw[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], xh[1][ks], accw[3], 0, 0, 0);
+                accw[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], xl[0][ks], accw[2], 0, 0, 0);
+                accw[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], xl[1][ks], accw[3], 0, 0, 0);
+                accw[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], xh[0][ks], accw[2], 0, 0, 0);
+                accw[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], xh[1][ks], accw[3], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] *= sc;
+        // next tile's Bm rows (scattered sources, long latency): in flight during GEMM 2 and the dp phase
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(Bm + (size_t)sjn * 128 + 4 * half + kt * 32 + 8 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gb[kt][4 * g + c] = b[c];
+            }
+        const int rsn = rowptr[tin], ren = rowptr[tin + 1];
+        // ---- GEMM 2: 2^11 ds1 = 2^11 W2^T dq, accumulated in x
+        zero_tiles<4>(x);
+        gemm128_single(wt, acc, x, lane);
+        // next tile's A rows (a handful of distinct targets, cache hits): in flight during the dp phase
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(A + (size_t)tin * 128 + 4 * half + kt * 32 + 8 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ga[kt][4 * g + c] = a[c];
+            }
+        // ---- dp = ds1 * Swish'(p)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[kt][i] = x[kt][i] * (1.0f / 2048.0f) * usc * p[kt][i];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (md.e_ok) {
+                    const f32x4 o = {x[kt][4 * g], x[kt][4 * g + 1], x[kt][4 * g + 2], x[kt][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(dp_out + row + kt * 32 + 8 * g) = o;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[kt][4 * g + c] = seg_scan_sum(x[kt][4 * g + c], md);
+            }
+        }
+        store_run_results<4, false>(x, md, dA, partials, half);
+        m_ti = tin, m_tnext = tnn, m_rs = rsn, m_re = ren;
+    }
+    // ---- this workgroup's partial sums (C/D row = dq feature, column = s1 feature)
+    float* wout = wpart + (size_t)blockIdx.x * 128 * 128;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            wout[(size_t)n * 128 + b * 32 + j] = accw[b][r] * invG;
+        }
+    bsum += __shfl_xor(bsum, 32);
+    if (half == 0) bpart[(size_t)blockIdx.x * 128 + wave * 32 + j] = bsum * invG;
+}
+
 // combine the tile-boundary partial sums and zero the rows without edges
 __global__ void __launch_bounds__(256) k_segsum_fixup(const int32_t* __restrict__ rowptr, int N, const float* __restrict__ partials,
                                                       float* __restrict__ out) {
@@ -322,6 +686,52 @@ extern "C" int magnet_mpnn_edge_bwd_f32(const float* A, const float* Bm, const f
         const u32x4* w = reinterpret_cast<const u32x4*>(w2_f16);
         const u32x4* wT = reinterpret_cast<const u32x4*>(w2t_f16);
 hipLaunchKernelGGL(k_mpnn_edge_bwd, g, b, 0, s, A, Bm, dagg, src, tgt, rowptr, n_edges, w, wT, b2, s1, dq, dp, dA, partials);
+    }
+    hipLaunchKernelGGL(k_segsum_fixup, dim3((n_nodes + 3) / 4), dim3(256), 0, s, rowptr, n_nodes, partials, dA);
+    return (int)hipGetLastError();
+}
+
+// The same, with dW2 [128][128] (+)= dq^T s1 and db2 [128] (+)= colsum(dq) formed in the kernel (k_mpnn_edge_bwd_w): s1 and dq are
+// never written.  workspace: magnet_mpnn_edge_bwd_w_workspace() floats (per-workgroup partial sums + the |dagg| maxima).
+#define EBW_AMAX_BLOCKS 256
+extern "C" int magnet_reduce_partials_f32(const float* partial, int nblk, long n, float scale, float* out, int accumulate,
+                                          void* stream);      // train_kernels.hip
+extern "C" int magnet_mpnn_edge_bwd_w_workspace(void) {
+    int dev, ncu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    return ncu * (128 * 128 + 128) + EBW_AMAX_BLOCKS;
+}
+extern "C" int magnet_mpnn_edge_bwd_w_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src,
+                                          const int32_t* tgt, const int32_t* rowptr, int n_nodes, int n_edges,
+                                          const void* w2_f16, const void* w2t_f16, const float* b2, float* dp, float* dA,
+                                          float* partials, float* dW2, float* db2, int accumulate, float* workspace, void* stream) {
+    (void)hipGetLastError();
+    if (n_nodes <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_edges > 0) {
+        static int ncu = 0;
+        if (!ncu) {
+            hipDeviceProp_t prop;
+            int dev;
+            hipGetDevice(&dev);
+            hipGetDeviceProperties(&prop, dev);
+            ncu = prop.multiProcessorCount;
+        }
+        const int tiles = (n_edges + 31) / 32;
+        const int grid = min((tiles + 3) / 4, ncu);
+        float* wpart = workspace;
+        float* bpart = wpart + (size_t)ncu * 128 * 128;
+        float* amax = bpart + (size_t)ncu * 128;
+        const long n4 = (long)n_nodes * 32;
+        const int nab = (int)min((long)EBW_AMAX_BLOCKS, (n4 + 255) / 256);
+        hipLaunchKernelGGL(k_absmax_partial, dim3(nab), dim3(256), 0, s, dagg, n4, amax);
+        const u32x4* w = reinterpret_cast<const u32x4*>(w2_f16);
+        const u32x4* wT = reinterpret_cast<const u32x4*>(w2t_f16);
+        hipLaunchKernelGGL(k_mpnn_edge_bwd_w, dim3(grid), dim3(256), 0, s, A, Bm, dagg, src, tgt, rowptr, n_edges, w, wT, b2, dp, dA,
+                           partials, amax, nab, wpart, bpart);
+        magnet_reduce_partials_f32(wpart, grid, 128L * 128, 1.0f, dW2, accumulate, stream);
+        magnet_reduce_partials_f32(bpart, grid, 128L, 1.0f, db2, accumulate, stream);
     }
     hipLaunchKernelGGL(k_segsum_fixup, dim3((n_nodes + 3) / 4), dim3(256), 0, s, rowptr, n_nodes, partials, dA);
     return (int)hipGetLastError();

@@ -97,7 +97,8 @@ class MPNN(LightningModule):
         # fp16x3, 16-edge tiles: one accumulator for the three products of the split (weight planes pre-scaled by 2^11; A/B knob)
         self.edge_single = bool(int(os.environ.get("MAGNET_EDGE_SINGLE", "0"))) and bool(getattr(hparams, "edge_single", True))
         # fp16x3: the transposed 32-edge-tile kernel (k_mpnn_edge32t, generation 9) instead of k_mpnn_edge16 (A/B knob)
-        self.edge_t32 = bool(int(os.environ.get("MAGNET_EDGE_T32", "0"))) and bool(getattr(hparams, "edge_t32", True))
+        # (2 = its two-waves-per-SIMD sibling k_mpnn_edge32p)
+        self.edge_t32 = int(os.environ.get("MAGNET_EDGE_T32", "0")) if getattr(hparams, "edge_t32", True) else 0
         assert self.edge_gemm in GEMM_MODES
         self.gemm = getattr(hparams, "gemm", self.edge_gemm)     # node-level Linears (same two choices)
         # backward-data GEMMs: gradients of a mean loss are ~1e-7, inside fp16's subnormal range, so the fp16 split is
@@ -106,8 +107,8 @@ class MPNN(LightningModule):
         assert self.bwd_gemm in ("bf16x6", "fp32")
         # edge block of the backward: "fused" (one kernel, mpnn_edge_bwd.hip) or "unfused" (materialising reference path)
         self.optimizer_kind = getattr(hparams, "optimizer", "fused")     # "fused" (magnet_amd.optim.FusedAdam) | "torch"
-        self.edge_bwd = getattr(hparams, "edge_bwd", "fused")
-        assert self.edge_bwd in ("fused", "unfused")
+        self.edge_bwd = getattr(hparams, "edge_bwd", os.environ.get("MAGNET_EDGE_BWD", "fused_w"))
+        assert self.edge_bwd in ("fused_w", "fused", "unfused")
         # fp16x3 only: sticky device-side range / finiteness status, read once per rollout (ops.RangeGuard)
         self._guard = ops.RangeGuard("fp16x3" in (self.gemm, self.edge_gemm) and bool(getattr(hparams, "range_check", True)))
         self._pack_key, self._pack, self._pack_gen = None, None, 0
@@ -235,7 +236,7 @@ class MPNN(LightningModule):
                 ops.mlp(N, ops.ktiles(T(h, H), T(node_in, kin)), [pa, pb], nl=1, ht=4, ot=4,
                         act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2, groups_in_block=True, y_group_stride=N * H)
             if hasattr(lyr, "msg2_t32"):          # training forward too (plain halves: l2e is False with a tape)
-                ops.mpnn_edge32t(A, Bm, csr, lyr.msg2_t32[0], lyr.msg2_t32[1], agg, partials, l2e=l2e)
+                ops.mpnn_edge32t(A, Bm, csr, lyr.msg2_t32[0], lyr.msg2_t32[1], agg, partials, l2e=l2e, paired=self.edge_t32 == 2)
             elif hasattr(lyr, "msg2_t16"):
                 ops.mpnn_edge16(A, Bm, csr, lyr.msg2_t16[0], lyr.msg2_t16[1], agg, partials, l2e=l2e, single=lyr.msg2_t16_single)
             else:

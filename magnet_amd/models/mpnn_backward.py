@@ -26,6 +26,7 @@ import types
 
 import torch
 
+from .. import _lib as L
 from .. import ops
 from ..packing import pack
 from .mpnn import _READOUT
@@ -109,10 +110,13 @@ def backward_call(m, tape, dout, G, ws):
     dnin = torch.zeros(N, kin, device=dev, dtype=torch.float32)
     dnin_l = torch.empty_like(dnin)
     z1, r1, z2, t1, t2, dagg, dA, dBm = (new() for _ in range(8))
-    fused = m.edge_bwd == "fused"
-    sp, d1, d2 = (enew() for _ in range(3))
+    fused = m.edge_bwd in ("fused", "fused_w")
+    fused_w = m.edge_bwd == "fused_w"                 # dW2 / db2 formed inside the edge kernel: no s1 / dq arrays at all
+    d2 = enew()
+    sp, d1 = (None, None) if fused_w else (enew(), enew())
     p, q = (None, None) if fused else (enew(), enew())
     partials = torch.empty(((E + 31) // 32) * 2 * H + 1, device=dev, dtype=torch.float32) if fused else None
+    ews = torch.empty(L.lib().magnet_mpnn_edge_bwd_w_workspace(), device=dev, dtype=torch.float32) if fused_w else None
     o_k = kin // 32
 
     for li in reversed(range(len(P.layers))):
@@ -131,7 +135,10 @@ def backward_call(m, tape, dout, G, ws):
         ops.wgrad(dz1, nin, 0, kin, g.w3, 2 * H, None, ws)
         lin(N, ops.ktiles(T(dz1, H)), qb.dagg, dagg)
         # ---- mean aggregation + message MLP at edge granularity                      mpnn.py:73-79, :46
-        if E > 0 and m.edge_bwd == "fused":
+        if E > 0 and fused_w:
+            ops.mpnn_edge_bwd_w(tp.A, tp.Bm, dagg, csr, qb.w2_f16[0], qb.w2t_f16[0], qb.w2_f16[1], d2, dA, partials, g.w2, g.b2, ews)
+            ops.segment_sum128(d2, bs.rowptr, N, perm=bs.perm, out=dBm)
+        elif E > 0 and fused:
             ops.mpnn_edge_bwd(tp.A, tp.Bm, dagg, csr, qb.w2_f16[0], qb.w2t_f16[0], qb.w2_f16[1], sp, d1, d2, dA, partials)
             ops.wgrad(d1, sp, 0, H, g.w2, 0, g.b2, ws, M=E)
             ops.segment_sum128(d2, bs.rowptr, N, perm=bs.perm, out=dBm)

@@ -44,6 +44,14 @@ for a in abls:
     print(f"edge_bwd ablation {a:2d}: {ms:.3f} ms   ({4*E*H*H/ms/1e9:.1f} TFLOP/s fp32-equivalent, {3*E*H*4/ms/1e6:.0f} GB/s written)")
 ws = ops.wgrad_workspace(E, "cuda")
 gW, gb = torch.zeros(H, H, device="cuda"), torch.zeros(H, device="cuda")
+if _lib.DEV:
+    _lib.lib().magnet_debug_set_edge_bwd_ablation(0)
+gW2, gb2 = torch.zeros(H, H, device="cuda"), torch.zeros(H, device="cuda")
+ms = timeit(lambda: ops.mpnn_edge_bwd_w(A, Bm, dagg, csr, w2[0], w2t[0], w2[1], dp, dA, partials, gW2, gb2, accumulate=False))
+print(f"edge_bwd_w (dW2 / db2 in the kernel, no s1 / dq): {ms:.3f} ms   ({E*H*4/ms/1e6:.0f} GB/s written)")
+ops.mpnn_edge_bwd(A, Bm, dagg, csr, w2[0], w2t[0], w2[1], s1, dq, dp, dA, partials)
+ops.wgrad(dq, s1, 0, H, gW, 0, gb, ws, accumulate=False, M=E)
+print("dW2 fused vs separate: rel", float((gW2 - gW).norm() / gW.norm()), " db2:", float((gb2 - gb).norm() / gb.norm()))
 ms = timeit(lambda: ops.wgrad(dq, s1, 0, H, gW, 0, gb, ws, M=E))
 print(f"wgrad (E rows): {ms:.3f} ms   {2*E*H*H/ms/1e9:.1f} TFLOP/s, {2*E*H*4/ms/1e6:.0f} GB/s read")
 bs = ops.csr_by_target(csr.tgt, csr.src, N)

@@ -182,7 +182,51 @@ def test_fused_edge_backward_matches_autograd():
     assert rel_l2(s1, sw(A64[t] + B64[s]).detach()) < 1e-6
 
 
-@pytest.mark.parametrize("edge_bwd", ["fused", "unfused"])
+@pytest.mark.parametrize("case", ["random", "one_tile", "many_tiles_per_wave", "tiny_gradients", "accumulate"])
+def test_fused_edge_backward_with_weight_gradient_matches_autograd(case):
+    """magnet_mpnn_edge_bwd_w_f32 (dW2 / db2 formed inside the kernel, s1 / dq never written) against torch autograd (fp64) of the
+    same edge block and against the kernel that writes s1 / dq (bit-identical dp and dA: the data path is the same code)."""
+    from magnet_amd import ops
+    from magnet_amd.packing import pack
+    torch.manual_seed(11)
+    N, E = {"one_tile": (9, 20), "many_tiles_per_wave": (3000, 150001)}.get(case, (500, 7001))
+    scale = 1e-12 if case == "tiny_gradients" else 1e-7
+    src = torch.randint(0, N, (E,), dtype=torch.int32, device="cuda")
+    tgt = torch.randint(0, max(N - 3, 1), (E,), dtype=torch.int32, device="cuda")
+    csr = ops.csr_by_target(src, tgt, N)
+    A, Bm = torch.randn(N, 128, device="cuda"), torch.randn(N, 128, device="cuda")
+    W2 = torch.randn(128, 128, device="cuda") / 11
+    b2 = torch.randn(128, device="cuda") * 0.1
+    dagg = torch.randn(N, 128, device="cuda") * scale
+    dagg[min(7, N - 1)] = 0
+    dagg[0, 0] = 40 * scale                                            # an outlier sets the launch-wide scale of the fp16 split
+    s, t = csr.src.long(), csr.tgt.long()
+    A64, B64 = A.double().requires_grad_(), Bm.double().requires_grad_()
+    W64, b64 = W2.double().requires_grad_(), b2.double().requires_grad_()
+    sw = lambda v: v * torch.sigmoid(v)  # noqa: E731
+    msg = sw(sw(A64[t] + B64[s]) @ W64.t() + b64)
+    deg = torch.bincount(t, minlength=N).clamp(min=1).double()
+    agg = torch.zeros(N, 128, dtype=torch.float64, device="cuda").index_add_(0, t, msg) / deg[:, None]
+    agg.backward(dagg.double())
+    w2p, w2tp = pack(W2, b2, "fp16x3"), pack(W2.t(), None, "fp16x3")
+    partials = torch.empty(((E + 31) // 32) * 2 * 128 + 1, device="cuda")
+    dp, dA = torch.empty(E, 128, device="cuda"), torch.full((N, 128), 7.0, device="cuda")
+    gW0, gb0 = (torch.randn(128, 128, device="cuda") * scale, torch.randn(128, device="cuda") * scale) if case == "accumulate" else \
+        (torch.zeros(128, 128, device="cuda"), torch.zeros(128, device="cuda"))
+    gW, gb = gW0.clone(), gb0.clone()
+    ops.mpnn_edge_bwd_w(A, Bm, dagg, csr, w2p[0], w2tp[0], w2p[1], dp, dA, partials, gW, gb)
+    assert rel_l2(gW - gW0, W64.grad) < 2e-6 and rel_l2(gb - gb0, b64.grad) < 2e-6
+    assert rel_l2(dA, A64.grad) < 2e-6
+    s1, dq, dp_ref = (torch.empty(E, 128, device="cuda") for _ in range(3))
+    dA_ref = torch.full((N, 128), 7.0, device="cuda")
+    ops.mpnn_edge_bwd(A, Bm, dagg, csr, w2p[0], w2tp[0], w2p[1], s1, dq, dp_ref, dA_ref, partials)
+    assert rel_l2(dp, dp_ref) < 1e-6 and rel_l2(dA, dA_ref) < 1e-6     # (Swish'(p) comes from another evaluation order: not bitwise)
+    gW2, gb2 = gW0.clone(), gb0.clone()                                # twice the same launch: bit-identical
+    ops.mpnn_edge_bwd_w(A, Bm, dagg, csr, w2p[0], w2tp[0], w2p[1], dp_ref, dA_ref, partials, gW2, gb2)
+    assert torch.equal(gW, gW2) and torch.equal(gb, gb2) and torch.equal(dp, dp_ref) and torch.equal(dA, dA_ref)
+
+
+@pytest.mark.parametrize("edge_bwd", ["fused_w", "fused", "unfused"])
 @pytest.mark.parametrize("teacher_forcing", [False, True])
 @pytest.mark.parametrize("tag", ["mpnn_1d", "mpnn_2d"])
 def test_training_step_gradients_match_autograd(tag, teacher_forcing, edge_bwd):
