@@ -58,6 +58,9 @@ def _packed_bwd(m):
         q.w2t = pack(W2.t(), None, mode)
         q.w2_f16 = pack(W2, lyr.message_net_2[0].bias, "fp16x3")         # fused edge backward: both packings as fp16 planes
         q.w2t_f16 = pack(W2.t(), None, "fp16x3")
+        if m.edge_bwd == "fused_w":                                      # that kernel scales the fp16 high planes by 2^11
+            from ..packing import flag_if_abs_reaches
+            flag_if_abs_reaches(W2, 31.98)
         q.w4t = pack(W4.t(), None, mode)
         Q.layers.append(q)
     e0, e1 = m.embedding_mlp[0].weight.detach().float(), m.embedding_mlp[2].weight.detach().float()

@@ -212,6 +212,16 @@ def _status_word(dev):
     return _status[dev]
 
 
+def flag_if_abs_reaches(w: torch.Tensor, limit: float) -> None:
+    """device-side (no host read): set the range bit of w's device when max|w| >= limit - for the kernels that pre-scale the
+    fp16 high plane by 2^11 (k_mpnn_edge_bwd_w: |w| < 31.98); reported by the next raise_if_bad_weights"""
+    if w.is_cuda:
+        bad = (~torch.isfinite(w).all()) | (w.detach().abs().amax() >= limit)
+        _status_word(w.device).bitwise_or_(bad.to(torch.int32) * _WEIGHT_RANGE_BIT)
+    elif not bool(torch.isfinite(w).all()) or float(w.detach().abs().max()) >= limit:
+        raise ValueError(f"fp16x3 GEMM mode: this kernel needs finite weights with |w| < {limit}; use MAGNET_GEMM=bf16x6")
+
+
 def raise_if_bad_weights(dev) -> None:
     """ONE host read for all packs since the last call (the models call it once per re-pack of their weights): the fp16x3 mode
     represents a weight with two fp16 pieces and needs finite |w| < 65504"""
@@ -220,7 +230,8 @@ def raise_if_bad_weights(dev) -> None:
         dev = torch.device("cuda", torch.cuda.current_device())
     if dev in _status and int(_status[dev].item()):
         _status[dev].zero_()
-        raise ValueError("fp16x3 GEMM mode needs finite weights with |w| < 65504; use MAGNET_GEMM=bf16x6")
+        raise ValueError("fp16x3 GEMM mode needs finite weights with |w| < 65504 (|w| < 31.98 for message_net_2 when training with "
+                         "edge_bwd='fused_w'); use MAGNET_GEMM=bf16x6 or edge_bwd='fused'")
 
 
 def source_map(placed_at, width: int, dev, source_cols=None):

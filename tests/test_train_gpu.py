@@ -254,6 +254,22 @@ def test_training_step_gradients_match_autograd(tag, teacher_forcing, edge_bwd):
         assert rel_l2(p.grad.flatten()[::stride], sample) < GOLD_TOL, n
 
 
+def test_fused_w_backward_refuses_weights_its_scaled_planes_cannot_hold():
+    """k_mpnn_edge_bwd_w keeps 2^11 fp16(W2) in LDS: |w| >= 31.98 must raise (one host read per re-pack), not overflow silently"""
+    hp, batch, oracle, model = _pair("mpnn_1d", edge_bwd="fused_w")
+    cb = {k: v.cuda() for k, v in batch.items()}
+    model.train()
+    with torch.no_grad():
+        model.gnn_layers[1].message_net_2[0].weight[3, 5] = 40.0
+    with pytest.raises(ValueError, match="31.98"):
+        model.training_step(cb, 0).backward()
+    hp2, _, _, ok = _pair("mpnn_1d", edge_bwd="fused")                   # the kernel that writes s1 / dq has no such limit
+    with torch.no_grad():
+        ok.gnn_layers[1].message_net_2[0].weight[3, 5] = 40.0
+    ok.train()
+    ok.training_step(cb, 0).backward()
+
+
 def test_training_step_is_deterministic_and_optimizer_steps():
     hp, batch, oracle, model = _pair("mpnn_2d")
     cb = {k: v.cuda() for k, v in batch.items()}
