@@ -86,14 +86,14 @@ def _recompute_tape(M, kts, pk, nl, x0, X, zL, K0):
     dev = x0.device
     Dp = pk.ot * 32
     lnflag = 1 if pk.ln is not None else 0
+    tape_only = pk.layers[0][0].dtype in (torch.float16, torch.int16)      # y = None: the chain's own output is not needed, not written
+    scratch = lambda: None if tape_only else torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32)  # noqa: E731
     if _tape_variant_ok(nl, pk):
-        scratch = torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32)      # the chain's own output is not needed
         ops.mlp(M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU, last_act=False, ln=None, epi=ops.EPI_STORE,
-                y=scratch, ncols=Dp, x0_out=x0, hid=X[1:] + [zL])
+                y=scratch(), ncols=Dp, x0_out=x0, hid=X[1:] + [zL])
     elif lnflag and L.lib().magnet_mlp_supported(nl, pk.ht, pk.ot, ops.ACT_RELU, 0, 1, ops.EPI_STORE):
-        scratch = torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32)
         ops.mlp(M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU, last_act=False, ln=pk.ln, epi=ops.EPI_STORE,
-                y=scratch, ncols=Dp, x0_out=x0, hid=X[1:] + [zL])
+                y=scratch(), ncols=Dp, x0_out=x0, hid=X[1:] + [zL])
     else:
         a, keep = ops.mlp_args(M, kts)
         L.check(L.lib().magnet_mlp_materialize_input_f32(C.byref(a), ops._p(x0), K0, ops._stream()), "materialize_input")
@@ -185,7 +185,8 @@ class _Mlp(torch.autograd.Function):
             if pk.ln is not None:
                 nblk = min(1024, (M + 3) // 4)
                 part = torch.empty(nblk, 2, D, device=dev, dtype=torch.float32)
-                dz = torch.zeros(max(M, 1), Dp, device=dev, dtype=torch.float32)
+                # (the kernel writes the D real columns of every row; padding columns, if any, must read as zero)
+                dz = (torch.empty if D == Dp and M > 0 else torch.zeros)(max(M, 1), Dp, device=dev, dtype=torch.float32)
                 L.check(L.lib().magnet_layernorm_bwd_f32(ops._p(zL), Dp, ops._p(d_rows), Dp, ops._p(pk.ln[0]), C.c_long(M), D,
                                                          C.c_float(pk.ln[2]), ops._p(dz), Dp, ops._p(part), ops._stream()),
                         "layernorm_bwd")

@@ -333,7 +333,8 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
             store_rows<OT, 0>(out, a.y, a.ldy, a.ncols, nullptr, 0, row >> 2, row_ok && (lane & 3) == 0, half);
         } else {
             float* yg = a.y + (a.y_group_stride ? (size_t)cg * a.y_group_stride : (size_t)cg * OT * 32);
-            store_rows<OT, EPI == EPI_STORE_MASK ? 2 : (EPI == EPI_STORE_RES ? 1 : 0)>(out, yg, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok, half);
+            // y == nullptr: a tape-only launch (the training backward's recompute wants x0_out / hid[], not the chain's own output)
+            store_rows<OT, EPI == EPI_STORE_MASK ? 2 : (EPI == EPI_STORE_RES ? 1 : 0)>(out, yg, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok && a.y != nullptr, half);
         }
         TRACE(32)
     }

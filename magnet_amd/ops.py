@@ -123,7 +123,11 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
         a.layer[i].w, a.layer[i].b = w.data_ptr(), b.data_ptr()
     if ln is not None:
         a.ln_g, a.ln_b, a.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
-    a.y, a.ldy, a.ncols = y.data_ptr(), int(ldy if ldy is not None else y.shape[-1]), int(ncols if ncols is not None else ot * 32)
+    if y is None:                   # tape-only launch (fp16x3 / bf16x6 kernels, plain store epilogue): nothing but x0_out / hid[] is written
+        assert epi == EPI_STORE and (x0_out is not None or hid) and layers[0][0].dtype in (torch.float16, torch.int16)
+        a.y, a.ldy, a.ncols = None, int(ot * 32), int(ncols if ncols is not None else ot * 32)
+    else:
+        a.y, a.ldy, a.ncols = y.data_ptr(), int(ldy if ldy is not None else y.shape[-1]), int(ncols if ncols is not None else ot * 32)
     if res is not None:
         a.res, a.ldres = res.data_ptr(), (res.stride(0) if res.dim() == 2 else res.shape[-1])
     if epi == EPI_SEGMEAN:
