@@ -535,11 +535,14 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd_w(const float* __restr
 #pragma unroll 1
         for (int s = 0; s < 4; ++s) {
             wg_barrier();                                                     // staging free: everybody has read the previous round
-            if (wave == s) {
+            // (the dq of publisher s > 0 is already there: staged during the second half of round s - 1, see below)
+            if (wave == 0 && s == 0) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) sdq[(nt * 32 + 8 * (i >> 2) + 4 * half + (i & 3)) * ES + j] = acc[nt][i] * G;
+            }
+            if (wave == s) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -559,6 +562,14 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd_w(const float* __restr
                 for (int nt = 2; nt < 4; ++nt)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) ss1[((nt - 2) * 32 + 8 * (i >> 2) + 4 * half + (i & 3)) * ES + j] = x[nt][i];
+            }
+            // everybody holds its dq operand in registers since the barrier above: the NEXT publisher stages its dq now, behind the
+            // MFMAs of the others, instead of at the top of its own round where the whole workgroup waits for it
+            if (wave == s + 1) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sdq[(nt * 32 + 8 * (i >> 2) + 4 * half + (i & 3)) * ES + j] = acc[nt][i] * G;
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
