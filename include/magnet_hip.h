@@ -338,7 +338,7 @@ int magnet_reduce_partials_f32(const float* partial, int nblk, long n, float sca
 /* x0[M][nkt*32] = the first-layer input magnet_mlp_* streams from its k-tile descriptors (materialised for the backward) */
 int magnet_mlp_materialize_input_f32(const magnet_mlp_args_t* args, float* x0, int ldx, void* stream);
 int magnet_relu_bwd_f32(const float* dy, const float* y, float* dz, long n, void* stream);
-/* LayerNorm backward over rows of D <= 256 columns from the pre-norm z; part: [min(1024, ceil(rows/4))][2][D] partial
+/* LayerNorm backward over rows of D <= 256 columns from the pre-norm z; part: [min(2048, ceil(rows/4))][2][D] partial
  * (dgamma | dbeta) sums for magnet_reduce_partials_f32 */
 int magnet_layernorm_bwd_f32(const float* z, int ldz, const float* dy, int ldd, const float* gamma, long rows, int D, float eps,
                              float* dz, int ldo, float* part, void* stream);

@@ -183,7 +183,7 @@ class _Mlp(torch.autograd.Function):
                 if pk.ln is not None:
                     zL = _linear(M, X[-1], pk.layers[nl - 1], pk.ot, relu=False)
             if pk.ln is not None:
-                nblk = min(1024, (M + 3) // 4)
+                nblk = min(2048, (M + 3) // 4)
                 part = torch.empty(nblk, 2, D, device=dev, dtype=torch.float32)
                 # (the kernel writes the D real columns of every row; padding columns, if any, must read as zero)
                 dz = (torch.empty if D == Dp and M > 0 else torch.zeros)(max(M, 1), Dp, device=dev, dtype=torch.float32)
