@@ -330,6 +330,12 @@ int magnet_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, int xcol
 /* general form: dY has n_out in {32, 64, 128} columns, dW is [n_out][ldw] (same workspace formula) */
 int magnet_wgrad_n_f32(const float* dY, int ldy, int n_out, const float* X, int ldx, int xcol, int kc, long M, float* dW,
                        int ldw, int wcol, float* db, float* workspace, int accumulate, void* stream);
+
+/* magnet_wgrad_n_f32 for `ntile` neighbouring column tiles of kc columns each - X[:, xcol + t kc ..) -> dW[:, wcol + t kc ..) - in one
+ * launch per kernel (the taps of a convolution, the column blocks of a wide first layer).  workspace: ntile * nblk * n_out * kc +
+ * nblk * n_out + ntile * n_out * kc floats, nblk = min(768, ceil(M / 32)). */
+int magnet_wgrad_tiles_f32(const float* dY, int ldy, int n_out, const float* X, int ldx, int xcol, int kc, int ntile, long M,
+                           float* dW, int ldw, int wcol, float* db, float* workspace, int accumulate, void* stream);
 int magnet_reduce_partials_f32(const float* partial, int nblk, long n, float scale, float* out, int accumulate,
                                void* stream);
 

@@ -113,6 +113,17 @@ def _tiles_of(width):
     return out
 
 
+def _tile_groups(width):
+    """_tiles_of with runs of equal-width blocks merged: (first column, block width, number of blocks)"""
+    out = []
+    for c0, w in _tiles_of(width):
+        if out and out[-1][1] == w and out[-1][0] + out[-1][1] * out[-1][2] == c0 and out[-1][2] < L.MAX_LAYERS:   # (one layer slot per group)
+            out[-1] = (out[-1][0], w, out[-1][2] + 1)
+        else:
+            out.append((c0, w, 1))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ fused MLP
 class _Mlp(torch.autograd.Function):
     @staticmethod
@@ -198,6 +209,7 @@ class _Mlp(torch.autograd.Function):
             # ---- walk the Linears back
             need_dx0 = any(ctx.needs_input_grad[1 + i] for i in range(m.n_src))
             ws = ops.wgrad_workspace(M, dev)
+            nblk_w = min(768, (M + 31) // 32)
             dX0 = None
             for l in range(nl - 1, -1, -1):
                 W, b = params[2 * l], params[2 * l + 1]
@@ -207,9 +219,12 @@ class _Mlp(torch.autograd.Function):
                 alloc = torch.empty if M > 0 else torch.zeros           # (no rows: the kernel returns without writing)
                 dWp = alloc(Np, Kp, device=dev, dtype=torch.float32)
                 dbp = alloc(Np, device=dev, dtype=torch.float32)
-                for j, (c0, w) in enumerate(_tiles_of(Kp)):
-                    L.check(L.lib().magnet_wgrad_n_f32(ops._p(dz), Np, Np, ops._p(X[l]), Kp, c0, w, C.c_long(M), ops._p(dWp), Kp, c0,
-                                                       ops._p(dbp if j == 0 else None), ops._p(ws), 0, ops._stream()), "wgrad_n")
+                for j, (c0, w, G) in enumerate(_tile_groups(Kp)):              # equal-width column blocks: one launch per kernel
+                    need = G * nblk_w * Np * w + nblk_w * Np + G * Np * w
+                    if ws.numel() < need:
+                        ws = torch.empty(need, device=dev, dtype=torch.float32)
+                    L.check(L.lib().magnet_wgrad_tiles_f32(ops._p(dz), Np, Np, ops._p(X[l]), Kp, c0, w, G, C.c_long(M), ops._p(dWp), Kp,
+                                                           c0, ops._p(dbp if j == 0 else None), ops._p(ws), 0, ops._stream()), "wgrad_tiles")
                 if l == 0 and m.first_cols is not None:
                     gW = torch.zeros_like(W)
                     gW[:, m.first_cols] = dWp[:n][:, m.col_map]
@@ -222,13 +237,15 @@ class _Mlp(torch.autograd.Function):
                     break
                 # dX = dz . W   (transposed packs, column block by column block)
                 dX = torch.empty(max(M, 1), Kp, device=dev, dtype=torch.float32)
-                for (c0, w) in _tiles_of(Kp):
-                    tp = _tpack(m, pk, l, c0, w, W, Np, Kp)
+                # column blocks of equal width go out as ONE launch (the kernel's column groups over gridDim.y): the nine 128-column
+                # taps of an EDSR convolution on a 64 x 64 map were nine 32-workgroup launches of 14 us each
+                for (c0, w, G) in _tile_groups(Kp):
+                    tps = [_tpack(m, pk, l, c0 + g * w, w, W, Np, Kp) for g in range(G)]
                     if l > 0:      # ... with the ReLU mask of the layer below as the epilogue: dz_{l-1} = (X[l] > 0) ? dX : 0
-                        ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), [tp], nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE,
+                        ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), tps, nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE, colgroups=G,
                                 epi=ops.EPI_STORE_MASK, res=X[l][:, c0:], y=dX[:, c0:], ldy=Kp, ncols=w)
                     else:
-                        ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), [tp], nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE,
+                        ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), tps, nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE, colgroups=G,
                                 y=dX[:, c0:], ldy=Kp, ncols=w)
                 if l > 0:
                     dz = dX

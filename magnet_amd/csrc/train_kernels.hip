@@ -205,6 +205,10 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_split(const float* __restrict_
     __shared__ __attribute__((aligned(16))) u32x4 pb[2][2 * 3 * 2 * KC];        // [stage][ks][piece][h][column]: 12 KiB per k tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, half = lane >> 5;
+    // gridDim.y > 1 (magnet_wgrad_tiles_f32): workgroup row y takes the column tile X[:, xcol + y KC ..) and its own partials
+    xcol += (int)blockIdx.y * KC;
+    partial += (size_t)blockIdx.y * gridDim.x * N * KC;
+    if (blockIdx.y) bpartial = nullptr;
     const bool active = wave * 32 < N;                                  // one 32-column n tile of dY per wave
     const bool conv = wave < KT;                                        // ... and one k tile of X to convert
     f32x16 acc[KT];
@@ -584,6 +588,40 @@ extern "C" int magnet_wgrad_n_f32(const float* dY, int ldy, int n_out, const flo
     float* tile = workspace + (size_t)nblk * (128 * kc + 128);
     hipLaunchKernelGGL(k_reduce_partials, dim3(nb((long)N * kc, 32)), dim3(256), 0, S_, part, nblk, (long)N * kc, 1.0f, tile, 0);
     hipLaunchKernelGGL(k_copy_cols, dim3(nb((long)N * kc, 256)), dim3(256), 0, S_, tile, kc, 0, dW, ldw, wcol, kc, (long)N, accumulate);
+    if (db) hipLaunchKernelGGL(k_reduce_partials, dim3(nb(N, 32)), dim3(256), 0, S_, bpart, nblk, (long)N, 1.0f, db, accumulate);
+    END();
+}
+// dW[r][wcol + t kc + c] (+)= tiles[t][r][c]
+__global__ void k_place_tiles(const float* __restrict__ tiles, int ntile, int N, int kc, float* __restrict__ dW, int ldw, int wcol,
+                              int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)ntile * N * kc) return;
+    const int t = (int)(i / ((long)N * kc)), r = (int)(i / kc) % N, c = (int)(i % kc);
+    float* d = dW + (size_t)r * ldw + wcol + t * kc + c;
+    *d = accumulate ? *d + tiles[i] : tiles[i];
+}
+// The same for `ntile` neighbouring column tiles of kc columns each, X[:, xcol + t kc ..) -> dW[:, wcol + t kc ..), in ONE launch of each
+// kernel (gridDim.y = ntile): the nine 128-column taps of an EDSR convolution on a 64 x 64 map were nine 128-workgroup launches plus
+// nine reductions and nine copies.  workspace: ntile * nblk * n_out * kc + nblk * n_out + ntile * n_out * kc floats.
+extern "C" int magnet_wgrad_tiles_f32(const float* dY, int ldy, int n_out, const float* X, int ldx, int xcol, int kc, int ntile, long M,
+                                      float* dW, int ldw, int wcol, float* db, float* workspace, int accumulate, void* stream) {
+    BEGIN();
+    if (M <= 0 || ntile <= 0) return 0;
+    if (kc % 32 || kc < 32 || kc > 128 || (n_out != 32 && n_out != 64 && n_out != 128)) return -2;
+    const int N = n_out;
+    const int nblk = (int)((M + WG_SLAB - 1) / WG_SLAB < 768 ? (M + WG_SLAB - 1) / WG_SLAB : 768);
+    float* part = workspace;
+    float* bpart = workspace + (size_t)ntile * nblk * N * kc;
+    float* tiles = bpart + (size_t)nblk * N;
+    const dim3 g(nblk, ntile);
+    switch (kc / 32) {
+        case 1: hipLaunchKernelGGL(k_wgrad_split<1>, g, dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, db ? bpart : nullptr); break;
+        case 2: hipLaunchKernelGGL(k_wgrad_split<2>, g, dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, db ? bpart : nullptr); break;
+        case 3: hipLaunchKernelGGL(k_wgrad_split<3>, g, dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, db ? bpart : nullptr); break;
+        default: hipLaunchKernelGGL(k_wgrad_split<4>, g, dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, db ? bpart : nullptr); break;
+    }
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nb((long)N * kc, 32), ntile), dim3(256), 0, S_, part, nblk, (long)N * kc, 1.0f, tiles, 0);
+    hipLaunchKernelGGL(k_place_tiles, dim3(nb((long)ntile * N * kc, 256)), dim3(256), 0, S_, tiles, ntile, N, kc, dW, ldw, wcol, accumulate);
     if (db) hipLaunchKernelGGL(k_reduce_partials, dim3(nb(N, 32)), dim3(256), 0, S_, bpart, nblk, (long)N, 1.0f, db, accumulate);
     END();
 }

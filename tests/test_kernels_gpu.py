@@ -690,3 +690,32 @@ def test_transposed_backward_packs_equal_the_padded_copy_construction():
             want = P.pack_linear_bf16x3(Wp[:, c0:c0 + w].t().contiguous().cpu(), None)
             got = AG._tpack(m, pk, 0, c0, w, W, Np, Kp)
             assert torch.equal(got[0].cpu(), want[0]) and float(got[1].abs().max()) == 0.0, (c0, w)
+
+
+@pytest.mark.parametrize("M,n_out,kc,ntile", [(4096, 128, 128, 6), (1000, 64, 64, 3), (70, 128, 32, 2), (50000, 32, 128, 1)])
+def test_weight_gradient_of_several_column_tiles_in_one_launch(M, n_out, kc, ntile):
+    """magnet_wgrad_tiles_f32 (gridDim.y = column tiles) == one magnet_wgrad_n_f32 launch per tile (bitwise: same kernel, same
+    partials, same reduction order) and == fp64 on the host"""
+    import ctypes as C
+    from magnet_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(3)
+    dY = (torch.randn(M, n_out, generator=g) * 1e-6).cuda()
+    X = torch.randn(M, 32 + ntile * kc, generator=g).cuda()
+    nblk = min(768, (M + 31) // 32)
+    ws = torch.empty(ntile * nblk * n_out * kc + nblk * n_out + ntile * n_out * kc + nblk * (128 * 128 + 128) + 128 * 128, device="cuda")
+    dW = torch.full((n_out, 16 + ntile * kc), 7.0, device="cuda")
+    db = torch.full((n_out,), 7.0, device="cuda")
+    L.check(L.lib().magnet_wgrad_tiles_f32(ops._p(dY), n_out, n_out, ops._p(X), X.shape[1], 32, kc, ntile, C.c_long(M), ops._p(dW),
+                                           dW.shape[1], 16, ops._p(db), ops._p(ws), 0, ops._stream()), "wgrad_tiles")
+    ref, rb = torch.full_like(dW, 7.0), torch.full_like(db, 7.0)
+    for t in range(ntile):
+        L.check(L.lib().magnet_wgrad_n_f32(ops._p(dY), n_out, n_out, ops._p(X), X.shape[1], 32 + t * kc, kc, C.c_long(M), ops._p(ref),
+                                           ref.shape[1], 16 + t * kc, ops._p(rb if t == 0 else None), ops._p(ws), 0, ops._stream()), "wgrad_n")
+    assert torch.equal(dW, ref) and torch.equal(db, rb)
+    assert torch.equal(dW[:, :16], torch.full((n_out, 16), 7.0, device="cuda"))
+    want = dY.double().t() @ X.double()[:, 32:]
+    assert rel_l2(dW[:, 16:], want) < 2e-6 and rel_l2(db, dY.double().sum(0)) < 2e-6
+    acc = dW.clone()                                                     # accumulate = 1 adds to what is there
+    L.check(L.lib().magnet_wgrad_tiles_f32(ops._p(dY), n_out, n_out, ops._p(X), X.shape[1], 32, kc, ntile, C.c_long(M), ops._p(acc),
+                                           acc.shape[1], 16, None, ops._p(ws), 1, ops._stream()), "wgrad_tiles")
+    assert rel_l2(acc[:, 16:], 2 * want) < 2e-6
