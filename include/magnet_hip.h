@@ -355,6 +355,12 @@ int magnet_edge_mean_bwd_cols_f32(const float* dagg, const int32_t* tgt, const i
  * power of two times 4: the scatter-add that undoes a row gather */
 int magnet_segment_sum_cols_f32(const float* x, int ldx, int xcol, const int32_t* rowptr, const int32_t* perm, int n_rows,
                                 int width, float scale, float* out, int ldo, int ocol, int accumulate, void* stream);
+/* the same for n_runs <= 9 gathers of the same source rows in one launch (host arrays of n_runs device pointers / column offsets: the
+ * taps of a convolution): out[r] (+)= scale * sum_u sum_{k in row r of run u} x[perms[u] ? perms[u][k] : k][xcols[u] : +width], runs added
+ * in index order */
+int magnet_segment_sum_cols_runs_f32(const float* x, int ldx, const int32_t* const* rowptrs, const int32_t* const* perms,
+                                     const int32_t* xcols, int n_runs, int n_rows, int width, float scale, float* out, int ldo, int ocol,
+                                     int accumulate, void* stream);
 /* backward of magnet_inr_knn_blend_f32: dbase [2*nq][C], dvq [2*nq][T] (per (query, neighbour), to be scatter-added to the
  * LR nodes), part: [min(1024, ceil(nq/4))][2][C] partial (dwv | dwt) sums */
 int magnet_inr_knn_blend_bwd_f32(const float* dz, const float* w, const float* vals, const int32_t* nn2, const float* t,

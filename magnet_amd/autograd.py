@@ -52,6 +52,20 @@ def _segment_sum_cols(x, xcol, rowptr, perm, n_rows, width, scale, out, ocol):
             "segment_sum_cols")
 
 
+_SEG_RUNS = 9              # csrc/magnet_train_kernels.hip: MAGNET_SEG_RUNS
+
+
+def _segment_sum_cols_runs(x, runs, c0, n_rows, width, scale, out, ocol):
+    """out[:, ocol:ocol+width] += scale * sum over ``runs`` = [(rowptr, perm, first column of x)] of the by-row sums: one launch for up to
+    nine gathers of the same rows (accumulates, like _segment_sum_cols)"""
+    n = len(runs)
+    rp = (C.c_void_p * n)(*[r[0].data_ptr() for r in runs])
+    pm = (C.c_void_p * n)(*[(r[1].data_ptr() if r[1] is not None else None) for r in runs])
+    xc = (C.c_int32 * n)(*[int(r[2]) + c0 for r in runs])
+    L.check(L.lib().magnet_segment_sum_cols_runs_f32(ops._p(x), x.stride(0), rp, pm, xc, n, n_rows, width, C.c_float(scale), ops._p(out),
+                                                     out.stride(0), ocol, 1, ops._stream()), "segment_sum_cols_runs")
+
+
 def _pad_cols(t, width):
     if t.shape[1] == width and t.is_contiguous():
         return t
@@ -257,6 +271,7 @@ class _Mlp(torch.autograd.Function):
                 for si, s in enumerate(srcs):
                     if ctx.needs_input_grad[1 + si]:
                         grads_src[si] = torch.zeros(s.shape, device=dev, dtype=torch.float32)
+                pending = {}                 # (source, column, width, scale) -> gathered runs that can share launches (the taps of a convolution)
                 for (si, col, idx, scale, rdiv, kt0, width) in m.runs:
                     g = grads_src[si]
                     if g is None:
@@ -272,8 +287,19 @@ class _Mlp(torch.autograd.Function):
                         rowptr, perm = m.rowptr, None                           # gathered by the CSR's own sorted target
                     else:
                         rowptr, perm = _inverse_csr(idx, g2.shape[0], m.inv_cache)
+                        if width <= 256 and rdiv == 1:
+                            pending.setdefault((si, col, width, scale), []).append((rowptr, perm, kt0 * 32))
+                            continue
                     for (c0, w) in _tiles_of(width):
                         _segment_sum_cols(dX0, kt0 * 32 + c0, rowptr, perm, g2.shape[0], w, scale, g2, col + c0)
+                for (si, col, width, scale), runs in pending.items():
+                    g2 = grads_src[si].view(-1, grads_src[si].shape[-1])
+                    for (c0, w) in _tiles_of(width):
+                        if len(runs) == 1:
+                            _segment_sum_cols(dX0, runs[0][2] + c0, runs[0][0], runs[0][1], g2.shape[0], w, scale, g2, col + c0)
+                            continue
+                        for i0 in range(0, len(runs), _SEG_RUNS):
+                            _segment_sum_cols_runs(dX0, runs[i0:i0 + _SEG_RUNS], c0, g2.shape[0], w, scale, g2, col + c0)
         return (None, *grads_src, *grads_par, *([d_res] if m.has_res else []))
 
 

@@ -4,6 +4,7 @@
 // the backward recomputes a chain's activations layer by layer (magnet_mlp_* with one Linear) and walks it back with
 // these kernels + magnet_wgrad_f32 + the transposed-weight GEMMs.
 #include "common.cuh"
+#define MAGNET_SEG_RUNS 9          // runs per launch of k_segment_sum_cols_runs (the taps of a 3 x 3 convolution)
 
 #define S_ (hipStream_t) stream
 static inline unsigned nb(long n, int b) { return (unsigned)((n + b - 1) / b); }
@@ -159,6 +160,64 @@ __global__ void __launch_bounds__(256) k_segment_sum_cols(const float* __restric
     }
 }
 
+// The same for up to MAGNET_SEG_RUNS gathers of the SAME source rows at once (the taps of a convolution: one inverse CSR per tap, each
+// with its own column block of x): out[r] (+)= scale * sum_u sum_{k in row r of run u} x[perm_u[k]][xcol_u ..].  One launch instead of one
+// per tap, and - what makes it faster, not just fewer launches - the first entry of every run is fetched before any of them is consumed
+// (a wave is an in-order machine: run after run it would pay rowptr -> perm -> row as three dependent round trips NINE times).
+// Runs are added in index order: deterministic.
+struct SegRuns {
+    const int32_t* rowptr[MAGNET_SEG_RUNS];
+    const int32_t* perm[MAGNET_SEG_RUNS];
+    int32_t xcol[MAGNET_SEG_RUNS];
+    int32_t n;
+};
+__global__ void __launch_bounds__(256) k_segment_sum_cols_runs(const float* __restrict__ x, int ldx, const SegRuns runs, int N, int W,
+                                                               float scale, float* __restrict__ out, int ldo, int ocol, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const int q4 = W / 4;
+    const int per = 64 / (q4 < 64 ? q4 : 64);
+    const int sub = lane / q4, c4 = lane % q4;
+    const bool on = sub < per && c4 < q4;                               // (W <= 256: one pass over the float4 columns)
+    int k0[MAGNET_SEG_RUNS], e[MAGNET_SEG_RUNS];
+#pragma unroll
+    for (int u = 0; u < MAGNET_SEG_RUNS; ++u) {
+        const bool have = u < runs.n;
+        k0[u] = have ? runs.rowptr[u][r] + sub : 0;
+        e[u] = have ? runs.rowptr[u][r + 1] : 0;
+    }
+    long row[MAGNET_SEG_RUNS];
+#pragma unroll
+    for (int u = 0; u < MAGNET_SEG_RUNS; ++u) row[u] = (on && k0[u] < e[u]) ? (runs.perm[u] ? (long)runs.perm[u][k0[u]] : (long)k0[u]) : -1;
+    f32x4 part[MAGNET_SEG_RUNS];
+#pragma unroll
+    for (int u = 0; u < MAGNET_SEG_RUNS; ++u) {
+        part[u] = f32x4{0, 0, 0, 0};
+        if (row[u] >= 0) part[u] = *reinterpret_cast<const f32x4*>(x + row[u] * ldx + runs.xcol[u] + 4 * c4);
+    }
+    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < MAGNET_SEG_RUNS; ++u) {
+        if (on && u < runs.n)                                           // further entries of this row in run u (rare for a tap index)
+            for (int k = k0[u] + per; k < e[u]; k += per) {
+                const long rw = runs.perm[u] ? runs.perm[u][k] : k;
+                part[u] += *reinterpret_cast<const f32x4*>(x + rw * ldx + runs.xcol[u] + 4 * c4);
+            }
+        acc += part[u];
+    }
+    for (int off = q4; off < 64; off <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], off);
+    }
+    if (sub == 0 && c4 < q4) {
+        float* o = out + (size_t)r * ldo + ocol + 4 * c4;
+        f32x4 v = acc * scale;
+        if (accumulate) v += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = v;
+    }
+}
+
 // ---- backward of k_inr_knn_blend (magnet_kernels.hip; models/magnet_gnn.py:254-280).  Forward:
 // z[q, i, c] = om0 * l0 + om1 * l1,  l_j = base[2q + j][c] + wv[c] * vals[nn2[2q + j]][i] + wt[c] * t[b][i],
 // om_j = the normalised geometric blend weights (functions of the coordinates only).
@@ -289,6 +348,23 @@ extern "C" int magnet_edge_mean_bwd_cols_f32(const float* dagg, const int32_t* t
     if (n_edges <= 0) return 0;
     if (D % 4) return -2;
     hipLaunchKernelGGL(k_edge_mean_bwd_d, dim3(nb(n_edges * (D / 4), 256)), dim3(256), 0, S_, dagg, tgt, rowptr, n_edges, D, dm, ldm);
+    END();
+}
+extern "C" int magnet_segment_sum_cols_runs_f32(const float* x, int ldx, const int32_t* const* rowptrs, const int32_t* const* perms,
+                                                const int32_t* xcols, int n_runs, int n_rows, int width, float scale, float* out,
+                                                int ldo, int ocol, int accumulate, void* stream) {
+    BEGIN();
+    if (n_rows <= 0 || width <= 0 || n_runs <= 0) return 0;
+    if (n_runs > MAGNET_SEG_RUNS || width % 4 || width > 256 || (64 % (width / 4 < 64 ? width / 4 : 64))) return -2;
+    SegRuns runs;
+    for (int u = 0; u < MAGNET_SEG_RUNS; ++u) {
+        runs.rowptr[u] = u < n_runs ? rowptrs[u] : nullptr;
+        runs.perm[u] = u < n_runs ? perms[u] : nullptr;
+        runs.xcol[u] = u < n_runs ? xcols[u] : 0;
+    }
+    runs.n = n_runs;
+    hipLaunchKernelGGL(k_segment_sum_cols_runs, dim3(nb(n_rows, 4)), dim3(256), 0, S_, x, ldx, runs, n_rows, width, scale, out, ldo, ocol,
+                       accumulate);
     END();
 }
 extern "C" int magnet_segment_sum_cols_f32(const float* x, int ldx, int xcol, const int32_t* rowptr, const int32_t* perm,

@@ -165,8 +165,13 @@ class EDSR(nn.Module):
         def conv(src, width, layer, conv_mod, relu=False, res=None):
             ci = conv_mod.weight.shape[1]
             W2 = conv_mod.weight.reshape(conv_mod.weight.shape[0], ci, ntaps).permute(0, 2, 1).reshape(conv_mod.weight.shape[0], -1)
-            cmap = (torch.arange(ntaps, device=dev)[:, None] * width + torch.arange(ci, device=dev)[None, :]).reshape(-1)
-            pkc = types.SimpleNamespace(layers=[layer[0]], ln=None, ht=ot, ot=ot, out_dim=C, col_map=cmap)
+            # one namespace per convolution for as long as its pack lives: the backward caches the transposed packs of the nine taps on it
+            # (a fresh namespace per call re-packed them in each of the four forwards of a training rollout)
+            cache = pk.setdefault("_grad_ns", {})
+            pkc = cache.get((id(conv_mod), width))
+            if pkc is None:
+                cmap = (torch.arange(ntaps, device=dev)[:, None] * width + torch.arange(ci, device=dev)[None, :]).reshape(-1)
+                pkc = cache[(id(conv_mod), width)] = types.SimpleNamespace(layers=[layer[0]], ln=None, ht=ot, ot=ot, out_dim=C, col_map=cmap)
             groups = [ops.Term(src, width, idx=taps[t]) for t in range(ntaps)]
             return AG.mlp(P, groups, pkc, [W2, conv_mod.bias], epi=ops.EPI_STORE_RES if res is not None else ops.EPI_STORE,
                           res=res, final_relu=relu)

@@ -719,3 +719,26 @@ def test_weight_gradient_of_several_column_tiles_in_one_launch(M, n_out, kc, nti
     L.check(L.lib().magnet_wgrad_tiles_f32(ops._p(dY), n_out, n_out, ops._p(X), X.shape[1], 32, kc, ntile, C.c_long(M), ops._p(acc),
                                            acc.shape[1], 16, None, ops._p(ws), 1, ops._stream()), "wgrad_tiles")
     assert rel_l2(acc[:, 16:], 2 * want) < 2e-6
+
+
+@pytest.mark.parametrize("n_runs,width,rows,src_rows", [(9, 128, 4097, 4096), (2, 32, 300, 1000), (5, 256, 77, 500), (1, 64, 10, 64)])
+def test_segment_sum_of_several_gathers_in_one_launch(n_runs, width, rows, src_rows):
+    """magnet_segment_sum_cols_runs_f32 == one magnet_segment_sum_cols_f32 launch per run (same sums, run order) and == index_add on the host"""
+    from magnet_amd import autograd as AG, ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(src_rows, 32 + n_runs * width, generator=g).cuda()
+    out0 = torch.randn(rows, width + 8, generator=g).cuda()
+    runs, want = [], out0.double().clone()
+    for u in range(n_runs):
+        idx = torch.randint(0, rows, (src_rows,), generator=g, dtype=torch.int32).cuda()      # row k of x was gathered from row idx[k]
+        if u == 0:
+            idx[: src_rows // 2] = 3                                                           # one heavy row: many entries
+        rowptr, perm = AG._inverse_csr(idx, rows)
+        runs.append((rowptr, perm, 32 + u * width))
+        want[:, 4:4 + width].index_add_(0, idx.long(), 0.5 * x.double()[:, 32 + u * width:32 + (u + 1) * width])
+    got, ref = out0.clone(), out0.clone()
+    AG._segment_sum_cols_runs(x, runs, 0, rows, width, 0.5, got, 4)
+    for rp, pm, xc in runs:
+        AG._segment_sum_cols(x, xc, rp, pm, rows, width, 0.5, ref, 4)
+    assert rel_l2(got, want) < 1e-6 and rel_l2(got, ref) < 1e-6
+    assert torch.equal(got[:, :4], out0[:, :4]) and torch.equal(got[:, 4 + width:], out0[:, 4 + width:])
