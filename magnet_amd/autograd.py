@@ -31,18 +31,25 @@ BWD_GEMM = "bf16x6"
 _INV_CACHE: dict = {}          # (data_ptr, numel, n_rows) -> (idx kept alive, rowptr, perm); gather indices belong to cached topologies
 
 
-def _inverse_csr(idx: torch.Tensor, n_rows: int, cache: dict = None):
+def _inverse_csr(idx: torch.Tensor, n_rows: int, cache: dict = None, drop_last: bool = False):
     """CSR over the *values* of a gather index: rows = gathered-from rows, perm = gathering positions.  Built once per
     index tensor (the sort inside csr_by_target was a third of the first training profile): the cache keeps the index
-    tensor alive, so its address cannot be reused for different contents."""
-    key = (idx.data_ptr(), idx.numel(), n_rows)
+    tensor alive, so its address cannot be reused for different contents.  ``drop_last``: the last source row is a constant
+    padding row (the zero row every out-of-bounds tap of a convolution points at): its CSR row is emptied - nobody wants that
+    gradient, and as the one long row (a border's worth of entries walked by a single wave) it was the whole duration of the
+    scatter kernel."""
+    key = (idx.data_ptr(), idx.numel(), n_rows, drop_last)
     hit = _INV_CACHE.get(key)
     if hit is None:
         pos = torch.arange(idx.numel(), dtype=torch.int32, device=idx.device)
         c = ops.csr_by_target(pos, idx, n_rows)
+        rowptr = c.rowptr
+        if drop_last:
+            rowptr = rowptr.clone()
+            rowptr[n_rows] = rowptr[n_rows - 1]
         if len(_INV_CACHE) >= 64:
             _INV_CACHE.pop(next(iter(_INV_CACHE)))
-        hit = _INV_CACHE[key] = (idx, c.rowptr, c.perm)
+        hit = _INV_CACHE[key] = (idx, rowptr, c.perm)
     return hit[1], hit[2]
 
 
@@ -286,7 +293,7 @@ class _Mlp(torch.autograd.Function):
                     elif idx.data_ptr() == (m.tgt.data_ptr() if m.tgt is not None else -1):
                         rowptr, perm = m.rowptr, None                           # gathered by the CSR's own sorted target
                     else:
-                        rowptr, perm = _inverse_csr(idx, g2.shape[0], m.inv_cache)
+                        rowptr, perm = _inverse_csr(idx, g2.shape[0], m.inv_cache, drop_last=bool(getattr(pk, "last_row_is_padding", False)))
                         if width <= 256 and rdiv == 1:
                             pending.setdefault((si, col, width, scale), []).append((rowptr, perm, kt0 * 32))
                             continue
