@@ -396,6 +396,17 @@ int magnet_mpnn_edge_bwd_f32(const float* A, const float* Bm, const float* dagg,
                              const int32_t* rowptr, int n_nodes, int n_edges, const void* w2_f16, const void* w2t_f16,
                              const float* b2, float* s1, float* dq, float* dp, float* dA, float* partials, void* stream);
 
+/* One hidden 128 -> 128 Linear of an MLP chain walked back in one kernel (torch autograd through models/backbones/mlp.py:9-28):
+ * dx [M][lddx] = (mask ? x > 0 : 1) * (dz W), dW [128][128] (+)= dz^T x, db [128] (+)= column sums of dz.  wt_f16: fp16x3 planes of W^T
+ * packed as a Linear (|w| < 31.98: the kernel keeps 2^11 times the high plane).  amax_in: n_amax_in block maxima of |dz| - the amax_out
+ * of the call that produced dz - or NULL (one more pass over dz; needs ldz == 128); amax_out: NULL or magnet_linear_bwd128_grid(M)
+ * floats.  workspace: magnet_linear_bwd128_workspace() floats. */
+int magnet_linear_bwd128_workspace(void);
+int magnet_linear_bwd128_grid(long M);
+int magnet_linear_bwd128_f32(const float* dz, int ldz, const float* x, int ldx, const void* wt_f16, long M, int mask, float* dx,
+                             int lddx, float* dW, float* db, int accumulate, const float* amax_in, int n_amax_in, float* amax_out,
+                             float* workspace, void* stream);
+
 /* The same backward with the weight gradient of message_net_2 formed inside the kernel (what torch autograd returns for
  * message_net_2.weight / .bias, models/mpnn.py:32-35): dW2 [128][128] (+)= dq^T s1, db2 [128] (+)= column sums of dq - s1 and dq are
  * never written to memory; dp [n_edges][128] and dA [n_nodes][128] as above.  workspace: magnet_mpnn_edge_bwd_w_workspace() floats

@@ -232,10 +232,24 @@ class _Mlp(torch.autograd.Function):
             ws = ops.wgrad_workspace(M, dev)
             nblk_w = min(768, (M + 31) // 32)
             dX0 = None
+            amax, lb_ws = None, None
             for l in range(nl - 1, -1, -1):
                 W, b = params[2 * l], params[2 * l + 1]
                 n, k = W.shape
                 Np, Kp = dz.shape[1], X[l].shape[1]
+                # a hidden 128 -> 128 Linear over many rows: data gradient + ReLU mask + weight and bias gradients in ONE kernel
+                # (csrc/linear_bwd.hip: dz and X[l] are read once instead of twice, no partial-sum passes over [M, 128] arrays)
+                if (l > 0 and n == k == Np == Kp == 128 and M >= _FUSED_LAYER_ROWS and pk.layers[0][0].dtype == torch.float16
+                        and dz.is_contiguous() and X[l].is_contiguous()):
+                    if lb_ws is None:
+                        lb_ws = torch.empty(L.lib().magnet_linear_bwd128_workspace(), device=dev, dtype=torch.float32)
+                    dX = torch.empty(M, 128, device=dev, dtype=torch.float32)
+                    dWp, dbp = torch.empty(128, 128, device=dev, dtype=torch.float32), torch.empty(128, device=dev, dtype=torch.float32)
+                    amax = ops.linear_bwd128(dz, X[l], _tpack16(pk, l, W), dX, dWp, dbp, lb_ws, mask=True, amax_in=amax)
+                    grads_par[2 * l], grads_par[2 * l + 1] = dWp, dbp
+                    dz = dX
+                    continue
+                amax = None
                 # the column tiles cover all Kp columns and all Np rows: written, not accumulated - no zero fill needed
                 alloc = torch.empty if M > 0 else torch.zeros           # (no rows: the kernel returns without writing)
                 dWp = alloc(Np, Kp, device=dev, dtype=torch.float32)
@@ -308,6 +322,19 @@ class _Mlp(torch.autograd.Function):
                         for i0 in range(0, len(runs), _SEG_RUNS):
                             _segment_sum_cols_runs(dX0, runs[i0:i0 + _SEG_RUNS], c0, g2.shape[0], w, scale, g2, col + c0)
         return (None, *grads_src, *grads_par, *([d_res] if m.has_res else []))
+
+
+_FUSED_LAYER_ROWS = 4096          # below this the persistent one-workgroup-per-CU kernel leaves most of the chip idle
+
+
+def _tpack16(pk, l, W):
+    """fp16x3 planes of W^T as a Linear, for ops.linear_bwd128 (cached on pk like the transposed bf16x6 packs)"""
+    from .packing import flag_if_abs_reaches
+    cache = pk.__dict__.setdefault("_tpacks16", {})
+    if l not in cache:
+        flag_if_abs_reaches(W.detach(), 31.98)          # that kernel keeps 2^11 x the high plane (reported by the next range check)
+        cache[l] = pack(W.detach().t(), None, "fp16x3")[0]
+    return cache[l]
 
 
 def _tpack(m, pk, l, c0, w, W, Np, Kp):
