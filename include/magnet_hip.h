@@ -406,6 +406,10 @@ int magnet_linear_bwd128_grid(long M);
 int magnet_linear_bwd128_f32(const float* dz, int ldz, const float* x, int ldx, const void* wt_f16, long M, int mask, float* dx,
                              int lddx, float* dW, float* db, int accumulate, const float* amax_in, int n_amax_in, float* amax_out,
                              float* workspace, void* stream);
+/* the same for a 64 -> 64 Linear (dW [64][64], db [64]; the hidden width of MAgNet[CNN]'s MLPs); same workspace and grid functions */
+int magnet_linear_bwd64_f32(const float* dz, int ldz, const float* x, int ldx, const void* wt_f16, long M, int mask, float* dx,
+                            int lddx, float* dW, float* db, int accumulate, const float* amax_in, int n_amax_in, float* amax_out,
+                            float* workspace, void* stream);
 
 /* The same backward with the weight gradient of message_net_2 formed inside the kernel (what torch autograd returns for
  * message_net_2.weight / .bias, models/mpnn.py:32-35): dW2 [128][128] (+)= dq^T s1, db2 [128] (+)= column sums of dq - s1 and dq are

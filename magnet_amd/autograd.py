@@ -237,14 +237,14 @@ class _Mlp(torch.autograd.Function):
                 W, b = params[2 * l], params[2 * l + 1]
                 n, k = W.shape
                 Np, Kp = dz.shape[1], X[l].shape[1]
-                # a hidden 128 -> 128 Linear over many rows: data gradient + ReLU mask + weight and bias gradients in ONE kernel
+                # a hidden 128 -> 128 (or 64 -> 64) Linear over many rows: data gradient + ReLU mask + weight and bias gradients in ONE kernel
                 # (csrc/linear_bwd.hip: dz and X[l] are read once instead of twice, no partial-sum passes over [M, 128] arrays)
-                if (l > 0 and n == k == Np == Kp == 128 and M >= _FUSED_LAYER_ROWS and pk.layers[0][0].dtype == torch.float16
+                if (l > 0 and n == k == Np == Kp and Np in (128, 64) and M >= _FUSED_LAYER_ROWS and pk.layers[0][0].dtype == torch.float16
                         and dz.is_contiguous() and X[l].is_contiguous()):
                     if lb_ws is None:
                         lb_ws = torch.empty(L.lib().magnet_linear_bwd128_workspace(), device=dev, dtype=torch.float32)
-                    dX = torch.empty(M, 128, device=dev, dtype=torch.float32)
-                    dWp, dbp = torch.empty(128, 128, device=dev, dtype=torch.float32), torch.empty(128, device=dev, dtype=torch.float32)
+                    dX = torch.empty(M, Np, device=dev, dtype=torch.float32)
+                    dWp, dbp = torch.empty(Np, Np, device=dev, dtype=torch.float32), torch.empty(Np, device=dev, dtype=torch.float32)
                     amax = ops.linear_bwd128(dz, X[l], _tpack16(pk, l, W), dX, dWp, dbp, lb_ws, mask=True, amax_in=amax)
                     grads_par[2 * l], grads_par[2 * l + 1] = dWp, dbp
                     dz = dX

@@ -30,7 +30,10 @@ __device__ __forceinline__ float stage_operand(const float* __restrict__ row, f1
 // (2^11 hw, 2^11 lw) - plane 0 of the standard fp16x3 pack scaled while it was copied in - and the activation's low piece is the
 // unscaled fp16 remainder, so the three products of the split share one scale (no cross accumulator, no fold: 64 registers that the
 // dW2 slab needs).  Two output blocks per group: consecutive MFMAs never write the same accumulator.
-__device__ __forceinline__ void gemm128_single(const u32x4* __restrict__ wl, const f32x16 (&x)[4], f32x16 (&acc)[4], int lane) {
+template <int NT>
+__device__ __forceinline__ void gemm_single(const u32x4* __restrict__ wl, const f32x16 (&x)[NT], f32x16 (&acc)[NT], int lane) {
+    static_assert(NT % 2 == 0, "output blocks are taken in pairs");
+    constexpr int NPR = NT / 2, NG = 2 * NT * NPR;  // pairs per slot, groups: gq = slot * NPR + pair, slot = kt * 2 + m
     u32x4 xs[2][2], wr[2][2][2];                   // xs[slot parity][plane]; wr[group parity][block of the pair][plane]
     auto quarter = [&](int slot, int q) {
         unsigned h, l;
@@ -41,10 +44,10 @@ __device__ __forceinline__ void gemm128_single(const u32x4* __restrict__ wl, con
         xs[slot & 1][1][q] = l;
     };
     auto wload = [&](int gq) {
-        const int slot = gq >> 1, pr = gq & 1;
+        const int slot = gq / NPR, pr = gq % NPR;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const u32x4* wp = wl + ((((slot >> 1) * 4 + 2 * pr + b) * 2 + (slot & 1)) * 2) * 64 + lane;
+            const u32x4* wp = wl + ((((slot >> 1) * NT + 2 * pr + b) * 2 + (slot & 1)) * 2) * 64 + lane;
             wr[gq & 1][b][0] = wp[0];
             wr[gq & 1][b][1] = wp[64];
         }
@@ -53,12 +56,12 @@ __device__ __forceinline__ void gemm128_single(const u32x4* __restrict__ wl, con
     for (int q = 0; q < 4; ++q) quarter(0, q);
     wload(0);
 #pragma unroll
-    for (int gq = 0; gq < 16; ++gq) {              // gq = slot * 2 + pair, slot = kt * 2 + m
-        const int slot = gq >> 1, pr = gq & 1;
-        if (gq + 1 < 16) wload(gq + 1);
-        if (slot + 1 < 8) {
-            quarter(slot + 1, 2 * pr);
-            quarter(slot + 1, 2 * pr + 1);
+    for (int gq = 0; gq < NG; ++gq) {
+        const int slot = gq / NPR, pr = gq % NPR;
+        if (gq + 1 < NG) wload(gq + 1);
+        if (slot + 1 < 2 * NT) {                   // the next slot's split, spread over this slot's groups
+#pragma unroll
+            for (int q = pr * 4 / NPR; q < (pr + 1) * 4 / NPR; ++q) quarter(slot + 1, q);
         }
         const f16x8 xh = __builtin_bit_cast(f16x8, xs[slot & 1][0]), xl = __builtin_bit_cast(f16x8, xs[slot & 1][1]);
         const f16x8 w0h = __builtin_bit_cast(f16x8, wr[gq & 1][0][0]), w0l = __builtin_bit_cast(f16x8, wr[gq & 1][0][1]);
@@ -73,6 +76,9 @@ __device__ __forceinline__ void gemm128_single(const u32x4* __restrict__ wl, con
         a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, xh, a1, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+__device__ __forceinline__ void gemm128_single(const u32x4* __restrict__ wl, const f32x16 (&x)[4], f32x16 (&acc)[4], int lane) {
+    gemm_single<4>(wl, x, acc, lane);
 }
 // plane 0 (the fp16 high pieces) of the standard pack times 2^11
 __device__ __forceinline__ u32x4 scale_plane_2048(u32x4 v) {

@@ -744,30 +744,31 @@ def test_segment_sum_of_several_gathers_in_one_launch(n_runs, width, rows, src_r
     assert torch.equal(got[:, :4], out0[:, :4]) and torch.equal(got[:, 4 + width:], out0[:, 4 + width:])
 
 
+@pytest.mark.parametrize("Wd", [128, 64])
 @pytest.mark.parametrize("M,mask,chained", [(128, True, False), (5000, True, True), (70, False, False), (33000, True, True), (4096, False, True)])
-def test_linear_backward_of_a_hidden_layer_in_one_kernel(M, mask, chained):
+def test_linear_backward_of_a_hidden_layer_in_one_kernel(M, mask, chained, Wd):
     """magnet_linear_bwd128_f32: dx = (x > 0) * (dz W), dW = dz^T x, db = colsum(dz) against fp64 on the host; gradients ~1e-7 with an
     outlier row (it sets the launch-wide scale of the staged dz); ``chained``: the block maxima come from a previous call's amax_out"""
     from magnet_amd import _lib as L, ops
     from magnet_amd.packing import pack
     g = torch.Generator().manual_seed(21)
-    W = (torch.randn(128, 128, generator=g) * 0.1).cuda()
-    x = torch.relu(torch.randn(M, 128, generator=g)).cuda()
-    dz = (torch.randn(M, 128, generator=g) * 1e-7).cuda()
+    W = (torch.randn(Wd, Wd, generator=g) * 0.1).cuda()
+    x = torch.relu(torch.randn(M, Wd, generator=g)).cuda()
+    dz = (torch.randn(M, Wd, generator=g) * 1e-7).cuda()
     dz[M // 2] *= 300
     dz[min(3, M - 1)] = 0
     wt = pack(W.t().contiguous(), None, "fp16x3")[0]
     ws = torch.empty(L.lib().magnet_linear_bwd128_workspace(), device="cuda")
     amax = None
     if chained:                                                         # a first call whose dx is this test's dz: its maxima describe dz
-        dz0 = (torch.randn(M, 128, generator=g) * 1e-7).cuda()
-        eye = pack(torch.eye(128).cuda(), None, "fp16x3")[0]
-        dz = torch.empty(M, 128, device="cuda")
-        amax = ops.linear_bwd128(dz0, x, eye, dz, torch.empty(128, 128, device="cuda"), torch.empty(128, device="cuda"), ws, mask=False)
+        dz0 = (torch.randn(M, Wd, generator=g) * 1e-7).cuda()
+        eye = pack(torch.eye(Wd).cuda(), None, "fp16x3")[0]
+        dz = torch.empty(M, Wd, device="cuda")
+        amax = ops.linear_bwd128(dz0, x, eye, dz, torch.empty(Wd, Wd, device="cuda"), torch.empty(Wd, device="cuda"), ws, mask=False)
         assert rel_l2(dz, dz0) < 1e-6
         assert abs(float(amax[0][:amax[1]].max()) - float(dz.abs().max())) <= 1e-6 * float(dz.abs().max())
-    dx = torch.full((M, 128), float("nan"), device="cuda")
-    dW, db = torch.full((128, 128), 7.0, device="cuda"), torch.full((128,), 7.0, device="cuda")
+    dx = torch.full((M, Wd), float("nan"), device="cuda")
+    dW, db = torch.full((Wd, Wd), 7.0, device="cuda"), torch.full((Wd,), 7.0, device="cuda")
     out = ops.linear_bwd128(dz, x, wt, dx, dW, db, ws, mask=mask, amax_in=amax)
     want = dz.double() @ W.double()
     if mask:

@@ -436,7 +436,7 @@ def test_differentiable_fused_mlp_matches_torch_autograd(hidden, D, epi):
         assert rel_l2(a_, b_) < tol, i
 
 
-@pytest.mark.parametrize("hidden,D,epi", [(128, 128, "segmean"), (128, 128, "res"), (128, 1, "store")])
+@pytest.mark.parametrize("hidden,D,epi", [(128, 128, "segmean"), (128, 128, "res"), (128, 1, "store"), (64, 32, "segmean"), (64, 10, "store")])
 def test_differentiable_fused_mlp_with_the_one_kernel_layer_backward(hidden, D, epi, monkeypatch):
     """the same comparison with the hidden 128 -> 128 Linears walked back by k_linear_bwd128 (ops.linear_bwd128; the models take that
     path from 4096 rows on): forced on at these row counts, and checked that it really ran"""
@@ -446,7 +446,7 @@ def test_differentiable_fused_mlp_with_the_one_kernel_layer_backward(hidden, D, 
     monkeypatch.setattr(AG, "_FUSED_LAYER_ROWS", 1)
     monkeypatch.setattr(ops, "linear_bwd128", lambda *a, **k: (calls.append(a[0].shape[0]), orig(*a, **k))[1])
     test_differentiable_fused_mlp_matches_torch_autograd(hidden, D, epi)
-    assert len(calls) == (4 if D == 128 else 3), calls               # layers 4..1 (the last Linear only when it is 128 wide)
+    assert len(calls) == (4 if D == hidden else 3), calls            # layers 4..1 (the last Linear only when it is square)
 
 
 @pytest.mark.parametrize("teacher_forcing", [False, True])
