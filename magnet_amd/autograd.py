@@ -124,6 +124,19 @@ def _recompute_tape(M, kts, pk, nl, x0, X, zL, K0):
             zL.copy_(_linear(M, X[nl - 1], pk.layers[nl - 1], pk.ot, relu=False))
 
 
+def _keep_tape(nbytes, dev):
+    """does the tape of one chain stay in memory from the forward to the backward?  MAGNET_KEEP_TAPE = 1 / 0 / auto (default): yes while
+    it takes less than a quarter of what is still free and the device stays below 60 % full - later calls of a long rollout then fall
+    back to recomputing by themselves"""
+    import os
+    mode = os.environ.get("MAGNET_KEEP_TAPE", "auto")
+    if mode in ("0", "1"):
+        return mode == "1"
+    total = torch.cuda.get_device_properties(dev).total_memory
+    used = torch.cuda.memory_allocated(dev)
+    return nbytes < 0.25 * (total - used) and used + nbytes < 0.6 * total
+
+
 def _tiles_of(width):
     """decompose a padded width into launchable output widths (128 / 64 / 32 columns)"""
     out, c = [], 0
@@ -161,17 +174,31 @@ class _Mlp(torch.autograd.Function):
             seg = dict(tgt=m.tgt, rowptr=m.rowptr,
                        partials=torch.empty(((m.M + 31) // 32) * 2 * pk.ot * 32 + 1, device=y.device, dtype=torch.float32))
         nl = len(pk.layers)
+        # the backward's tape (assembled first-layer input, every hidden activation, the last Linear's raw output under a LayerNorm):
+        # written by THIS launch when it fits in memory (288 GB per GPU: a C5 training rollout keeps ~150 GB of it), else recomputed by
+        # one more launch of the chain in the backward
+        tape = ()
+        K0 = len(m.tiles) * 32
+        if nl > 1 and not m.final_relu and pk.layers[0][0].dtype in (torch.float16, torch.int16) and m.M > 0 and \
+                any(ctx.needs_input_grad[1:]) and _keep_tape(4 * m.M * (K0 + (nl - 1) * pk.ht * 32 + pk.ot * 32), y.device):
+            new = lambda w: torch.empty(m.M, w, device=y.device, dtype=torch.float32)  # noqa: E731
+            tape = (new(K0), *[new(pk.ht * 32) for _ in range(nl - 1)], *([new(pk.ot * 32)] if pk.ln is not None else []))
+            seg = dict(seg, x0_out=tape[0], hid=list(tape[1:nl]) + [tape[nl] if pk.ln is not None else None])
         ops.mlp(m.M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU if (nl > 1 or m.final_relu) else ops.ACT_NONE,
                 last_act=m.final_relu, ln=pk.ln, epi=m.epi, y=y, res=res, ncols=pk.out_dim, **seg)
         if m.epi == ops.EPI_SEGMEAN:
             ops.segmean_fixup(m.rowptr, m.out_rows, pk.ot * 32, seg["partials"], y)
         ctx.meta = m
-        ctx.save_for_backward(*tensors, *([y] if m.final_relu else []))
+        ctx.n_tape = len(tape)
+        ctx.save_for_backward(*tensors, *([y] if m.final_relu else []), *tape)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         m, tensors = ctx.meta, ctx.saved_tensors
+        tape = ()
+        if ctx.n_tape:
+            tape, tensors = tensors[-ctx.n_tape:], tensors[:-ctx.n_tape]
         if m.final_relu:                                                 # y = ReLU(chain): mask the incoming gradient first
             y_out, tensors = tensors[-1], tensors[:-1]
             masked = torch.empty_like(y_out)
@@ -199,12 +226,18 @@ class _Mlp(torch.autograd.Function):
             # out of the registers the chain runs in (round 1: a materialisation pass + one single-Linear launch per layer, each
             # re-reading and re-writing an [M, width] array).  Multi-layer chains only; a single Linear needs x0 alone.
             K0 = len(m.tiles) * 32
-            x0 = torch.empty(max(M, 1), K0, device=dev, dtype=torch.float32)
             kts = [[(ops.Term(srcs[si], 32, idx=idx, scale=scale, rdiv=rdiv), col) for (si, col, idx, scale, rdiv) in tile]
                    for tile in m.tiles]
             grads_par = [None] * m.n_par
             zL = None
-            if nl > 1:
+            if tape:                                                      # kept by the forward launch
+                x0, X = tape[0], list(tape[:nl])
+                zL = tape[nl] if pk.ln is not None else None
+            else:
+                x0 = torch.empty(max(M, 1), K0, device=dev, dtype=torch.float32)
+            if tape:
+                pass
+            elif nl > 1:
                 X = [x0] + [torch.empty(max(M, 1), pk.ht * 32, device=dev, dtype=torch.float32) for _ in range(nl - 1)]
                 zL = torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32) if pk.ln is not None else None
                 _recompute_tape(M, kts, pk, nl, x0, X, zL, K0)
