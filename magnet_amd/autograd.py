@@ -147,6 +147,43 @@ def _tiles_of(width):
     return out
 
 
+def _groups_of_ktiles(kts):
+    """sorted k-tile indices -> [(first column, block width, number of blocks)]: maximal runs cut into blocks of at most four k
+    tiles, equal-width neighbours merged (as _tile_groups does for a whole width)"""
+    out, i = [], 0
+    while i < len(kts):
+        j = i
+        while j + 1 < len(kts) and kts[j + 1] == kts[j] + 1:
+            j += 1
+        c, left = kts[i] * 32, (j - i + 1) * 32
+        while left > 0:
+            w = 128 if left >= 128 else (64 if left >= 64 else 32)
+            if out and out[-1][1] == w and out[-1][0] + out[-1][1] * out[-1][2] == c and out[-1][2] < L.MAX_LAYERS:
+                out[-1] = (out[-1][0], w, out[-1][2] + 1)
+            else:
+                out.append((c, w, 1))
+            c, left = c + w, left - w
+        i = j + 1
+    return out
+
+
+def _factored_first_layer(m, srcs, M):
+    """k tiles of the first Linear whose input is a pure row gather (every Term covering them has an index, rdiv = 1) of far fewer
+    source rows than M: there d(source) = sum over the gathering rows of dz W and dW = sum of dz^T x commute with the gather -
+    dz is summed over each source row's gatherers FIRST ([M, Np] -> [n_src, Np]) and the GEMMs run at source granularity.  The
+    backward twin of the forward's factored first layer.  Returns {k tile: True} for those tiles."""
+    nkt = len(m.tiles)
+    ok = [True] * nkt
+    seen = [False] * nkt
+    for (si, col, idx, scale, rdiv, kt0, width) in m.runs:
+        rows = srcs[si].reshape(-1, srcs[si].shape[-1]).shape[0]
+        good = idx is not None and rdiv == 1 and width % 32 == 0 and 2 * rows <= M
+        for kt in range(kt0, kt0 + width // 32):
+            seen[kt] = True
+            ok[kt] = ok[kt] and good
+    return [ok[kt] and seen[kt] for kt in range(nkt)]
+
+
 def _tile_groups(width):
     """_tiles_of with runs of equal-width blocks merged: (first column, block width, number of blocks)"""
     out = []
@@ -156,6 +193,57 @@ def _tile_groups(width):
         else:
             out.append((c0, w, 1))
     return out
+
+
+def _first_layer_at_source_rows(ctx, m, pk, srcs, params, dz, fk, dWp, dbp, Np, Kp, dev):
+    """the factored k tiles of the first Linear (see _factored_first_layer): per gathered run S = the sum of dz over the rows that
+    gathered each source row ([n_src, Np]; by the CSR's own target: contiguous segments), then dW[:, tile] (+)= scale S^T src and
+    d src (+)= scale S W[:, tile] as launches over n_src rows.  Writes dWp's factored columns (and dbp = column sums of dz when asked);
+    returns the per-source gradient buffers it created (None for sources without a factored run)."""
+    W = params[0]
+    M = dz.shape[0]
+    sums, first_of_kt, grads = {}, {}, [None] * m.n_src
+    ws = None
+    for (si, col, idx, scale, rdiv, kt0, width) in m.runs:
+        if not fk[kt0]:
+            continue
+        src2 = srcs[si].reshape(-1, srcs[si].shape[-1])
+        n_src = src2.shape[0]
+        key = idx.data_ptr()
+        if key not in sums:                                              # sum of dz over the gatherers of every source row
+            S = torch.empty(n_src, Np, device=dev, dtype=torch.float32)
+            if m.tgt is not None and key == m.tgt.data_ptr():
+                rowptr, perm = m.rowptr, None
+            else:
+                rowptr, perm = _inverse_csr(idx, n_src, m.inv_cache)
+            L.check(L.lib().magnet_segment_sum_cols_f32(ops._p(dz), dz.stride(0), 0, ops._p(rowptr), ops._p(perm), n_src, Np, C.c_float(1.0),
+                                                        ops._p(S), Np, 0, 0, ops._stream()), "segment_sum_cols")
+            sums[key] = S
+            if dbp is not None and not first_of_kt:                       # db = column sums of dz = column sums of any complete S
+                ops.reduce_partials(S, n_src, Np, dbp, accumulate=False)
+        S = sums[key]
+        Ss = S if scale == 1.0 else S * scale
+        nblk = min(768, (n_src + 31) // 32)
+        for (c0, w, G) in _tile_groups(width):
+            need = G * nblk * Np * w + nblk * Np + G * Np * w
+            if ws is None or ws.numel() < need:
+                ws = torch.empty(need, device=dev, dtype=torch.float32)
+            acc = 1 if first_of_kt.get(kt0 + c0 // 32) else 0             # the second Term of a differenced pair adds to the first's columns
+            L.check(L.lib().magnet_wgrad_tiles_f32(ops._p(Ss), Np, Np, ops._p(src2), src2.stride(0), col + c0, w, G, C.c_long(n_src),
+                                                   ops._p(dWp), Kp, kt0 * 32 + c0, None, ops._p(ws), acc, ops._stream()), "wgrad_tiles")
+        for kt in range(kt0, kt0 + width // 32):
+            first_of_kt[kt] = True
+        if ctx.needs_input_grad[1 + si]:
+            if grads[si] is None:
+                grads[si] = torch.zeros(srcs[si].shape, device=dev, dtype=torch.float32)
+            g2 = grads[si].view(-1, grads[si].shape[-1])
+            tmp = torch.empty(n_src, width, device=dev, dtype=torch.float32)
+            for (c0, w, G) in _tile_groups(width):
+                tps = [_tpack(m, pk, 0, kt0 * 32 + c0 + g * w, w, W, Np, Kp) for g in range(G)]
+                ops.mlp(n_src, ops.ktiles(ops.Term(Ss, Np)), tps, nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE, colgroups=G,
+                        y=tmp[:, c0:], ldy=width, ncols=w)
+            ops.copy_cols(tmp, 0, g2, col, width, accumulate=True)
+    return grads
 
 
 # ------------------------------------------------------------------------------------------------ fused MLP
@@ -287,7 +375,16 @@ class _Mlp(torch.autograd.Function):
                 alloc = torch.empty if M > 0 else torch.zeros           # (no rows: the kernel returns without writing)
                 dWp = alloc(Np, Kp, device=dev, dtype=torch.float32)
                 dbp = alloc(Np, device=dev, dtype=torch.float32)
-                for j, (c0, w, G) in enumerate(_tile_groups(Kp)):              # equal-width column blocks: one launch per kernel
+                col_groups = _tile_groups(Kp)
+                factored = None
+                if l == 0 and M >= _FUSED_LAYER_ROWS and Np in (32, 64, 128):
+                    fk = _factored_first_layer(m, srcs, M)
+                    if any(fk):
+                        factored = fk
+                        col_groups = _groups_of_ktiles([kt for kt in range(Kp // 32) if not fk[kt]])
+                        grads_src_f = _first_layer_at_source_rows(ctx, m, pk, srcs, params, dz, fk, dWp, dbp if not col_groups else None,
+                                                                  Np, Kp, dev)
+                for j, (c0, w, G) in enumerate(col_groups):                    # equal-width column blocks: one launch per kernel
                     need = G * nblk_w * Np * w + nblk_w * Np + G * Np * w
                     if ws.numel() < need:
                         ws = torch.empty(need, device=dev, dtype=torch.float32)
@@ -307,7 +404,7 @@ class _Mlp(torch.autograd.Function):
                 dX = torch.empty(max(M, 1), Kp, device=dev, dtype=torch.float32)
                 # column blocks of equal width go out as ONE launch (the kernel's column groups over gridDim.y): the nine 128-column
                 # taps of an EDSR convolution on a 64 x 64 map were nine 32-workgroup launches of 14 us each
-                for (c0, w, G) in _tile_groups(Kp):
+                for (c0, w, G) in col_groups:
                     tps = [_tpack(m, pk, l, c0 + g * w, w, W, Np, Kp) for g in range(G)]
                     if l > 0:      # ... with the ReLU mask of the layer below as the epilogue: dz_{l-1} = (X[l] > 0) ? dX : 0
                         ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), tps, nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE, colgroups=G,
@@ -324,11 +421,12 @@ class _Mlp(torch.autograd.Function):
             if need_dx0:
                 for si, s in enumerate(srcs):
                     if ctx.needs_input_grad[1 + si]:
-                        grads_src[si] = torch.zeros(s.shape, device=dev, dtype=torch.float32)
+                        grads_src[si] = torch.zeros(s.shape, device=dev, dtype=torch.float32) if factored is None or grads_src_f[si] is None \
+                            else grads_src_f[si]
                 pending = {}                 # (source, column, width, scale) -> gathered runs that can share launches (the taps of a convolution)
                 for (si, col, idx, scale, rdiv, kt0, width) in m.runs:
                     g = grads_src[si]
-                    if g is None:
+                    if g is None or (factored is not None and factored[kt0]):      # (done at source granularity above)
                         continue
                     g2 = g.view(-1, g.shape[-1])
                     if idx is None and rdiv == 1 and scale == 1.0:

@@ -445,8 +445,13 @@ def test_differentiable_fused_mlp_with_the_one_kernel_layer_backward(hidden, D, 
     orig = ops.linear_bwd128
     monkeypatch.setattr(AG, "_FUSED_LAYER_ROWS", 1)
     monkeypatch.setattr(ops, "linear_bwd128", lambda *a, **k: (calls.append(a[0].shape[0]), orig(*a, **k))[1])
+    fact = []
+    orig_f = AG._first_layer_at_source_rows
+    monkeypatch.setattr(AG, "_first_layer_at_source_rows", lambda *a, **k: (fact.append(sum(a[6])), orig_f(*a, **k))[1])
     test_differentiable_fused_mlp_matches_torch_autograd(hidden, D, epi)
     assert len(calls) == (4 if D == hidden else 3), calls            # layers 4..1 (the last Linear only when it is square)
+    # the gathered node terms of the edge chain ([x_i | x_j | e]: 2 of 3 blocks) took the source-granularity first layer
+    assert fact == ([2 * (128 if hidden == 128 else 32) // 32] if epi == "segmean" else []), fact
 
 
 @pytest.mark.parametrize("teacher_forcing", [False, True])
