@@ -348,6 +348,9 @@ int magnet_relu_bwd_f32(const float* dy, const float* y, float* dz, long n, void
  * (dgamma | dbeta) sums for magnet_reduce_partials_f32 */
 int magnet_layernorm_bwd_f32(const float* z, int ldz, const float* dy, int ldd, const float* gamma, long rows, int D, float eps,
                              float* dz, int ldo, float* part, void* stream);
+/* the same, plus amax [min(2048, ceil(rows/4))]: per-workgroup maxima of |dz| - the amax_in of magnet_linear_bwd128_f32 / 64 */
+int magnet_layernorm_bwd_amax_f32(const float* z, int ldz, const float* dy, int ldd, const float* gamma, long rows, int D, float eps,
+                                  float* dz, int ldo, float* part, float* amax, void* stream);
 /* dm[e][0:D] = dagg[tgt[e]][0:D] / deg(tgt[e]) */
 int magnet_edge_mean_bwd_cols_f32(const float* dagg, const int32_t* tgt, const int32_t* rowptr, long n_edges, int D, float* dm,
                                   int ldm, void* stream);

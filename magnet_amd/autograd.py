@@ -126,7 +126,7 @@ def _recompute_tape(M, kts, pk, nl, x0, X, zL, K0):
 
 def _keep_tape(nbytes, dev):
     """does the tape of one chain stay in memory from the forward to the backward?  MAGNET_KEEP_TAPE = 1 / 0 / auto (default): yes while
-    it takes less than a quarter of what is still free and the device stays below 60 % full - later calls of a long rollout then fall
+    it takes less than a quarter of what is still free and the device stays below 70 % full (MAGNET_TAPE_CAP) - later calls of a long rollout then fall
     back to recomputing by themselves"""
     import os
     mode = os.environ.get("MAGNET_KEEP_TAPE", "auto")
@@ -134,7 +134,7 @@ def _keep_tape(nbytes, dev):
         return mode == "1"
     total = torch.cuda.get_device_properties(dev).total_memory
     used = torch.cuda.memory_allocated(dev)
-    return nbytes < 0.25 * (total - used) and used + nbytes < 0.6 * total
+    return nbytes < 0.25 * (total - used) and used + nbytes < float(os.environ.get("MAGNET_TAPE_CAP", "0.7")) * total
 
 
 def _tiles_of(width):
@@ -340,20 +340,21 @@ class _Mlp(torch.autograd.Function):
                 part = torch.empty(nblk, 2, D, device=dev, dtype=torch.float32)
                 # (the kernel writes the D real columns of every row; padding columns, if any, must read as zero)
                 dz = (torch.empty if D == Dp and M > 0 else torch.zeros)(max(M, 1), Dp, device=dev, dtype=torch.float32)
-                L.check(L.lib().magnet_layernorm_bwd_f32(ops._p(zL), Dp, ops._p(d_rows), Dp, ops._p(pk.ln[0]), C.c_long(M), D,
-                                                         C.c_float(pk.ln[2]), ops._p(dz), Dp, ops._p(part), ops._stream()),
-                        "layernorm_bwd")
+                ln_amax = torch.empty(nblk, device=dev, dtype=torch.float32) if D == Dp else None   # block maxima of |dz| for k_linear_bwd
+                L.check(L.lib().magnet_layernorm_bwd_amax_f32(ops._p(zL), Dp, ops._p(d_rows), Dp, ops._p(pk.ln[0]), C.c_long(M), D,
+                                                              C.c_float(pk.ln[2]), ops._p(dz), Dp, ops._p(part), ops._p(ln_amax),
+                                                              ops._stream()), "layernorm_bwd")
                 gb = torch.zeros(2 * D, device=dev, dtype=torch.float32)
                 ops.reduce_partials(part, nblk, 2 * D, gb)
                 grads_par[2 * nl], grads_par[2 * nl + 1] = gb[:D], gb[D:]
             else:
-                dz = d_rows
+                dz, ln_amax = d_rows, None
             # ---- walk the Linears back
             need_dx0 = any(ctx.needs_input_grad[1 + i] for i in range(m.n_src))
             ws = ops.wgrad_workspace(M, dev)
             nblk_w = min(768, (M + 31) // 32)
             dX0 = None
-            amax, lb_ws = None, None
+            amax, lb_ws = ((ln_amax, nblk) if ln_amax is not None else None), None
             for l in range(nl - 1, -1, -1):
                 W, b = params[2 * l], params[2 * l + 1]
                 n, k = W.shape

@@ -49,9 +49,11 @@ __global__ void k_relu_bwd(const float* __restrict__ dy, const float* __restrict
 // dgamma = sum dy * zhat and dbeta = sum dy ([grid][2][D], reduced by magnet_reduce_partials_f32).  One wave per row.
 __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__ z, int ldz, const float* __restrict__ dy, int ldd,
                                                        const float* __restrict__ gamma, long rows, int D, float eps,
-                                                       float* __restrict__ dz, int ldo, float* __restrict__ part) {
+                                                       float* __restrict__ dz, int ldo, float* __restrict__ part,
+                                                       float* __restrict__ amax /* [grid] block maxima of |dz|, or nullptr */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ float sg[4][2][256];
+    float dzmax = 0.f;
     float ag[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};              // this lane's columns lane, lane+64, ...
     const float invD = 1.0f / (float)D;
     for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
@@ -97,7 +99,11 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = lane + 64 * k;
-            if (c < D) dz[r * ldo + c] = (g[k] - m1 - zh[k] * m2) * rstd;
+            if (c < D) {
+                const float v = (g[k] - m1 - zh[k] * m2) * rstd;
+                dz[r * ldo + c] = v;
+                dzmax = fmaxf(dzmax, fabsf(v));
+            }
         }
     }
 #pragma unroll
@@ -109,6 +115,14 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__
     for (int c = threadIdx.x; c < 2 * D; c += 256) {
         const int w = c / D, col = c % D;
         part[(size_t)blockIdx.x * 2 * D + c] = sg[0][w][col] + sg[1][w][col] + sg[2][w][col] + sg[3][w][col];
+    }
+    if (amax) {                                  // what the next kernel (k_linear_bwd) needs to pick its power-of-two scale: no pass of its own
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dzmax = fmaxf(dzmax, __shfl_xor(dzmax, off));
+        __syncthreads();
+        if (lane == 0) sg[0][0][wave] = dzmax;
+        __syncthreads();
+        if (threadIdx.x == 0) amax[blockIdx.x] = fmaxf(fmaxf(sg[0][0][0], sg[0][0][1]), fmaxf(sg[0][0][2], sg[0][0][3]));
     }
 }
 
@@ -339,7 +353,17 @@ extern "C" int magnet_layernorm_bwd_f32(const float* z, int ldz, const float* dy
     if (rows <= 0) return 0;
     if (D < 1 || D > 256) return -2;
     const unsigned grid = nb(rows, 4) < 2048u ? nb(rows, 4) : 2048u;
-    hipLaunchKernelGGL(k_layernorm_bwd, dim3(grid), dim3(256), 0, S_, z, ldz, dy, ldd, gamma, rows, D, eps, dz, ldo, part);
+    hipLaunchKernelGGL(k_layernorm_bwd, dim3(grid), dim3(256), 0, S_, z, ldz, dy, ldd, gamma, rows, D, eps, dz, ldo, part, (float*)nullptr);
+    END();
+}
+// the same, and amax [min(2048, ceil(rows/4))] = per-workgroup maxima of |dz| (the amax_in of magnet_linear_bwd128_f32 / 64)
+extern "C" int magnet_layernorm_bwd_amax_f32(const float* z, int ldz, const float* dy, int ldd, const float* gamma, long rows, int D,
+                                             float eps, float* dz, int ldo, float* part, float* amax, void* stream) {
+    BEGIN();
+    if (rows <= 0) return 0;
+    if (D < 1 || D > 256) return -2;
+    const unsigned grid = nb(rows, 4) < 2048u ? nb(rows, 4) : 2048u;
+    hipLaunchKernelGGL(k_layernorm_bwd, dim3(grid), dim3(256), 0, S_, z, ldz, dy, ldd, gamma, rows, D, eps, dz, ldo, part, amax);
     END();
 }
 extern "C" int magnet_edge_mean_bwd_cols_f32(const float* dagg, const int32_t* tgt, const int32_t* rowptr, long n_edges, int D,
