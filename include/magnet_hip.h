@@ -85,6 +85,8 @@ typedef struct {
                               * keeps these tensors alive instead): the first Linear's assembled input rows [M][nkt*32], */
     float* hid[MAGNET_MAX_LAYERS]; /* ... hid[l], l < nl-1: layer l's output after its activation [M][ht*32]; hid[nl-1]: the last
                               * Linear's raw output before last_act / LayerNorm [M][ot*32] */
+    uint64_t x0_skip;        /* bit kt set: k tile kt of x0_out is NOT written (a backward that walks gathered k tiles back at
+                              * source-row granularity never reads them) */
 } magnet_mlp_args_t;
 
 /* Fused gather/concat -> NL x (Linear [+ activation]) -> [LayerNorm] -> store | +residual | CSR mean.
@@ -348,9 +350,12 @@ int magnet_relu_bwd_f32(const float* dy, const float* y, float* dz, long n, void
  * (dgamma | dbeta) sums for magnet_reduce_partials_f32 */
 int magnet_layernorm_bwd_f32(const float* z, int ldz, const float* dy, int ldd, const float* gamma, long rows, int D, float eps,
                              float* dz, int ldo, float* part, void* stream);
-/* the same, plus amax [min(2048, ceil(rows/4))]: per-workgroup maxima of |dz| - the amax_in of magnet_linear_bwd128_f32 / 64 */
+/* the same, plus amax [min(2048, ceil(rows/4))]: per-workgroup maxima of |dz| - the amax_in of magnet_linear_bwd128_f32 / 64 (NULL:
+ * not wanted); tgt / rowptr != NULL: the rows are CSR-ordered edges and dy [n_nodes][ldd] is the gradient of their per-target mean - row
+ * r takes dy[tgt[r]] / deg(tgt[r]) (magnet_edge_mean_bwd_cols_f32 fused into the load) */
 int magnet_layernorm_bwd_amax_f32(const float* z, int ldz, const float* dy, int ldd, const float* gamma, long rows, int D, float eps,
-                                  float* dz, int ldo, float* part, float* amax, void* stream);
+                                  float* dz, int ldo, float* part, float* amax, const int32_t* tgt, const int32_t* rowptr,
+                                  void* stream);
 /* dm[e][0:D] = dagg[tgt[e]][0:D] / deg(tgt[e]) */
 int magnet_edge_mean_bwd_cols_f32(const float* dagg, const int32_t* tgt, const int32_t* rowptr, long n_edges, int D, float* dm,
                                   int ldm, void* stream);

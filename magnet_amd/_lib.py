@@ -43,7 +43,7 @@ class MlpArgs(C.Structure):
                 ("res", C.c_void_p), ("ldres", C.c_int32),
                 ("tgt", C.c_void_p), ("rowptr", C.c_void_p), ("partials", C.c_void_p), ("ncolgroups", C.c_int32),
                 ("groups_in_block", C.c_int32), ("y_group_stride", C.c_int64), ("pre", Src * 2),
-                ("x0_out", C.c_void_p), ("hid", C.c_void_p * MAX_LAYERS)]
+                ("x0_out", C.c_void_p), ("hid", C.c_void_p * MAX_LAYERS), ("x0_skip", C.c_uint64)]
 
 
 def declared_symbols() -> list[str]:

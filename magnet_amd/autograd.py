@@ -96,7 +96,7 @@ def _tape_variant_ok(nl, pk):
     return bool(L.lib().magnet_mlp_supported(nl, pk.ht, pk.ot, ops.ACT_RELU, 0, 0, ops.EPI_STORE))
 
 
-def _recompute_tape(M, kts, pk, nl, x0, X, zL, K0):
+def _recompute_tape(M, kts, pk, nl, x0, X, zL, K0, x0_skip=0):
     """fill the backward's tape - x0 (assembled first-layer input), X[1:] (activated output of every hidden layer) and zL (the
     last Linear's raw output, LayerNorm chains only) - by re-running the forward:
 
@@ -111,10 +111,10 @@ def _recompute_tape(M, kts, pk, nl, x0, X, zL, K0):
     scratch = lambda: None if tape_only else torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32)  # noqa: E731
     if _tape_variant_ok(nl, pk):
         ops.mlp(M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU, last_act=False, ln=None, epi=ops.EPI_STORE,
-                y=scratch(), ncols=Dp, x0_out=x0, hid=X[1:] + [zL])
+                y=scratch(), ncols=Dp, x0_out=x0, hid=X[1:] + [zL], x0_skip=x0_skip)
     elif lnflag and L.lib().magnet_mlp_supported(nl, pk.ht, pk.ot, ops.ACT_RELU, 0, 1, ops.EPI_STORE):
         ops.mlp(M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU, last_act=False, ln=pk.ln, epi=ops.EPI_STORE,
-                y=scratch(), ncols=Dp, x0_out=x0, hid=X[1:] + [zL])
+                y=scratch(), ncols=Dp, x0_out=x0, hid=X[1:] + [zL], x0_skip=x0_skip)
     else:
         a, keep = ops.mlp_args(M, kts)
         L.check(L.lib().magnet_mlp_materialize_input_f32(C.byref(a), ops._p(x0), K0, ops._stream()), "materialize_input")
@@ -182,6 +182,14 @@ def _factored_first_layer(m, srcs, M):
             seen[kt] = True
             ok[kt] = ok[kt] and good
     return [ok[kt] and seen[kt] for kt in range(nkt)]
+
+
+def _x0_skip_mask(m, srcs, M, np_):
+    """bit kt set: the backward walks k tile kt of the first Linear back at source-row granularity (_factored_first_layer) and never
+    reads that k tile of the assembled input - the tape does not have to hold it"""
+    if M < _FUSED_LAYER_ROWS or np_ not in (32, 64, 128):
+        return 0
+    return sum(1 << kt for kt, f in enumerate(_factored_first_layer(m, srcs, M)) if f)
 
 
 def _tile_groups(width):
@@ -271,7 +279,8 @@ class _Mlp(torch.autograd.Function):
                 any(ctx.needs_input_grad[1:]) and _keep_tape(4 * m.M * (K0 + (nl - 1) * pk.ht * 32 + pk.ot * 32), y.device):
             new = lambda w: torch.empty(m.M, w, device=y.device, dtype=torch.float32)  # noqa: E731
             tape = (new(K0), *[new(pk.ht * 32) for _ in range(nl - 1)], *([new(pk.ot * 32)] if pk.ln is not None else []))
-            seg = dict(seg, x0_out=tape[0], hid=list(tape[1:nl]) + [tape[nl] if pk.ln is not None else None])
+            seg = dict(seg, x0_out=tape[0], hid=list(tape[1:nl]) + [tape[nl] if pk.ln is not None else None],
+                       x0_skip=_x0_skip_mask(m, srcs, m.M, pk.ht * 32))
         ops.mlp(m.M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU if (nl > 1 or m.final_relu) else ops.ACT_NONE,
                 last_act=m.final_relu, ln=pk.ln, epi=m.epi, y=y, res=res, ncols=pk.out_dim, **seg)
         if m.epi == ops.EPI_SEGMEAN:
@@ -303,7 +312,10 @@ class _Mlp(torch.autograd.Function):
         with torch.no_grad():
             # ---- epilogue
             d_res = dy if m.has_res else None
-            if m.epi == ops.EPI_SEGMEAN:
+            mean_in_ln = m.epi == ops.EPI_SEGMEAN and pk.ln is not None and dy.shape[1] == Dp      # the LayerNorm backward gathers dy[tgt] / deg itself
+            if mean_in_ln:
+                d_rows = None
+            elif m.epi == ops.EPI_SEGMEAN:
                 d_rows = torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32)
                 L.check(L.lib().magnet_edge_mean_bwd_cols_f32(ops._p(dy), ops._p(m.tgt), ops._p(m.rowptr), C.c_long(M), Dp,
                                                               ops._p(d_rows), Dp, ops._stream()), "edge_mean_bwd_cols")
@@ -328,7 +340,7 @@ class _Mlp(torch.autograd.Function):
             elif nl > 1:
                 X = [x0] + [torch.empty(max(M, 1), pk.ht * 32, device=dev, dtype=torch.float32) for _ in range(nl - 1)]
                 zL = torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32) if pk.ln is not None else None
-                _recompute_tape(M, kts, pk, nl, x0, X, zL, K0)
+                _recompute_tape(M, kts, pk, nl, x0, X, zL, K0, x0_skip=_x0_skip_mask(m, srcs, M, pk.ht * 32))
             else:
                 a, keep = ops.mlp_args(M, kts)
                 L.check(L.lib().magnet_mlp_materialize_input_f32(C.byref(a), ops._p(x0), K0, ops._stream()), "materialize_input")
@@ -341,9 +353,10 @@ class _Mlp(torch.autograd.Function):
                 # (the kernel writes the D real columns of every row; padding columns, if any, must read as zero)
                 dz = (torch.empty if D == Dp and M > 0 else torch.zeros)(max(M, 1), Dp, device=dev, dtype=torch.float32)
                 ln_amax = torch.empty(nblk, device=dev, dtype=torch.float32) if D == Dp else None   # block maxima of |dz| for k_linear_bwd
-                L.check(L.lib().magnet_layernorm_bwd_amax_f32(ops._p(zL), Dp, ops._p(d_rows), Dp, ops._p(pk.ln[0]), C.c_long(M), D,
-                                                              C.c_float(pk.ln[2]), ops._p(dz), Dp, ops._p(part), ops._p(ln_amax),
-                                                              ops._stream()), "layernorm_bwd")
+                L.check(L.lib().magnet_layernorm_bwd_amax_f32(ops._p(zL), Dp, ops._p(dy if mean_in_ln else d_rows), Dp, ops._p(pk.ln[0]),
+                                                              C.c_long(M), D, C.c_float(pk.ln[2]), ops._p(dz), Dp, ops._p(part),
+                                                              ops._p(ln_amax), ops._p(m.tgt if mean_in_ln else None),
+                                                              ops._p(m.rowptr if mean_in_ln else None), ops._stream()), "layernorm_bwd")
                 gb = torch.zeros(2 * D, device=dev, dtype=torch.float32)
                 ops.reduce_partials(part, nblk, 2 * D, gb)
                 grads_par[2 * nl], grads_par[2 * nl + 1] = gb[:D], gb[D:]

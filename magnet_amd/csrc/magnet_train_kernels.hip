@@ -50,7 +50,10 @@ __global__ void k_relu_bwd(const float* __restrict__ dy, const float* __restrict
 __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__ z, int ldz, const float* __restrict__ dy, int ldd,
                                                        const float* __restrict__ gamma, long rows, int D, float eps,
                                                        float* __restrict__ dz, int ldo, float* __restrict__ part,
-                                                       float* __restrict__ amax /* [grid] block maxima of |dz|, or nullptr */) {
+                                                       float* __restrict__ amax /* [grid] block maxima of |dz|, or nullptr */,
+                                                       const int32_t* __restrict__ tgt /* nullptr, or: row r's dy is the backward of a CSR
+                                                       mean - dy[tgt[r]] / deg(tgt[r]) (k_edge_mean_bwd_d fused into the load) */,
+                                                       const int32_t* __restrict__ rowptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ float sg[4][2][256];
     float dzmax = 0.f;
@@ -58,11 +61,18 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__
     const float invD = 1.0f / (float)D;
     for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
         float zv[4], dv[4], s = 0.f;
+        long rd = r;
+        float dsc = 1.0f;
+        if (tgt) {
+            const int t = tgt[r];
+            rd = t;
+            dsc = 1.0f / (float)(rowptr[t + 1] - rowptr[t]);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = lane + 64 * k;
             zv[k] = c < D ? z[r * ldz + c] : 0.f;
-            dv[k] = c < D ? dy[r * ldd + c] : 0.f;
+            dv[k] = c < D ? dy[rd * ldd + c] * dsc : 0.f;
             s += zv[k];
         }
 #pragma unroll
@@ -353,17 +363,21 @@ extern "C" int magnet_layernorm_bwd_f32(const float* z, int ldz, const float* dy
     if (rows <= 0) return 0;
     if (D < 1 || D > 256) return -2;
     const unsigned grid = nb(rows, 4) < 2048u ? nb(rows, 4) : 2048u;
-    hipLaunchKernelGGL(k_layernorm_bwd, dim3(grid), dim3(256), 0, S_, z, ldz, dy, ldd, gamma, rows, D, eps, dz, ldo, part, (float*)nullptr);
+    hipLaunchKernelGGL(k_layernorm_bwd, dim3(grid), dim3(256), 0, S_, z, ldz, dy, ldd, gamma, rows, D, eps, dz, ldo, part, (float*)nullptr,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr);
     END();
 }
-// the same, and amax [min(2048, ceil(rows/4))] = per-workgroup maxima of |dz| (the amax_in of magnet_linear_bwd128_f32 / 64)
+// the same, and amax [min(2048, ceil(rows/4))] = per-workgroup maxima of |dz| (the amax_in of magnet_linear_bwd128_f32 / 64); tgt /
+// rowptr != NULL: the rows are CSR-ordered edges and dy [n_nodes][ldd] is the gradient of their per-target MEAN - row r takes
+// dy[tgt[r]] / deg(tgt[r]) (magnet_edge_mean_bwd_cols_f32 fused into the load: the [rows][D] array in between is never written)
 extern "C" int magnet_layernorm_bwd_amax_f32(const float* z, int ldz, const float* dy, int ldd, const float* gamma, long rows, int D,
-                                             float eps, float* dz, int ldo, float* part, float* amax, void* stream) {
+                                             float eps, float* dz, int ldo, float* part, float* amax, const int32_t* tgt,
+                                             const int32_t* rowptr, void* stream) {
     BEGIN();
     if (rows <= 0) return 0;
-    if (D < 1 || D > 256) return -2;
+    if (D < 1 || D > 256 || (tgt && !rowptr)) return -2;
     const unsigned grid = nb(rows, 4) < 2048u ? nb(rows, 4) : 2048u;
-    hipLaunchKernelGGL(k_layernorm_bwd, dim3(grid), dim3(256), 0, S_, z, ldz, dy, ldd, gamma, rows, D, eps, dz, ldo, part, amax);
+    hipLaunchKernelGGL(k_layernorm_bwd, dim3(grid), dim3(256), 0, S_, z, ldz, dy, ldd, gamma, rows, D, eps, dz, ldo, part, amax, tgt, rowptr);
     END();
 }
 extern "C" int magnet_edge_mean_bwd_cols_f32(const float* dagg, const int32_t* tgt, const int32_t* rowptr, long n_edges, int D,

@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                 TRACE(13)
                 if (!(abl & 1)) mma_chunk<NT0, MODE, PIPE>(x, acc, accc, wbuf + (c % NBUF) * CH, lane);
                 TRACE(14)
-                if (a.x0_out && gi == 0) store_ktile(x, a.x0_out, a.nkt * 32, kt * 32, row, row_ok, half);
+                if (a.x0_out && gi == 0 && !((a.x0_skip >> kt) & 1)) store_ktile(x, a.x0_out, a.nkt * 32, kt * 32, row, row_ok, half);
             }
             fold_tiles<NT0, MODE>(acc, accc);
             if (NL > 1 && !pre_init) {                     // (other GEMM modes: added after the first layer)

@@ -22,7 +22,7 @@ __device__ __forceinline__ void stream_layer(const MagnetMlpArgs& a, const Magne
     for (int kt = 0; kt < a.nkt; ++kt) {
         const f32x16 x = load_ktile(a.kt[kt], row, half);
         mma_ktile<NT>(x, out, l0.w, kt, lane);
-        if (a.x0_out && row_ok) store_ktile(x, a.x0_out, a.nkt * 32, kt * 32, row, true, half);
+        if (a.x0_out && row_ok && !((a.x0_skip >> kt) & 1)) store_ktile(x, a.x0_out, a.nkt * 32, kt * 32, row, true, half);
     }
 }
 

@@ -90,7 +90,7 @@ def mlp_args(M, kts):
 
 def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STORE, y=None, ldy=None, ncols=None,
              res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0, pre=None,
-             x0_out=None, hid=None):
+             x0_out=None, hid=None, x0_skip=0):
     """Build the argument block of one fused-MLP launch once and return a zero-argument callable that enqueues it on the
     current stream.  For call sites that repeat the same launch on the same buffers (the EDSR convolution stack: 34
     launches of up to 36 gathered k tiles each) this removes the per-call descriptor marshalling from the host path."""
@@ -109,6 +109,7 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
     if x0_out is not None:
         assert x0_out.is_contiguous() and x0_out.shape[1] == len(kts) * 32
         a.x0_out = x0_out.data_ptr()
+        a.x0_skip = int(x0_skip)            # k tiles of x0 the caller will not read (bit kt)
     for i, t in enumerate(hid or ()):
         if t is not None:
             assert nl > 1 and t.is_contiguous() and t.shape[1] == (ot if i == nl - 1 else ht) * 32
@@ -148,7 +149,7 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
 
 def mlp(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STORE, y=None, ldy=None, ncols=None,
         res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0, pre=None,
-        x0_out=None, hid=None):
+        x0_out=None, hid=None, x0_skip=0):
     """Run the fused MLP kernel.  ``layers``: list of (packed_w, padded_b).  Returns y."""
     if nl > 1 and colgroups == 1 and not L.lib().magnet_mlp_supported(nl, ht, ot, act, int(last_act), int(ln is not None),
                                                                        EPI_STORE if epi == EPI_QUADBLEND else epi):
@@ -156,7 +157,7 @@ def mlp(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STO
                               ncols=ncols, res=res, tgt=tgt, rowptr=rowptr, partials=partials, pre=pre, x0_out=x0_out, hid=hid)
     mlp_plan(M, kts, layers, nl=nl, ht=ht, ot=ot, act=act, last_act=last_act, ln=ln, epi=epi, y=y, ldy=ldy, ncols=ncols,
              res=res, tgt=tgt, rowptr=rowptr, partials=partials, colgroups=colgroups, groups_in_block=groups_in_block,
-             y_group_stride=y_group_stride, pre=pre, x0_out=x0_out, hid=hid)()
+             y_group_stride=y_group_stride, pre=pre, x0_out=x0_out, hid=hid, x0_skip=x0_skip)()
     return y
 
 

@@ -30,7 +30,7 @@ def test_mlp_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.Src) == 32
     assert ctypes.sizeof(_lib.KTile) == 80
     assert ctypes.sizeof(_lib.Layer) == 16
-    assert ctypes.sizeof(_lib.MlpArgs) == 8 + 80 * _lib.MAX_KT + 16 * 6 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 2 * 32 + 8 + 8 * 6   # ..., ncolgroups|groups_in_block, y_group_stride, pre[2], x0_out, hid[6]
+    assert ctypes.sizeof(_lib.MlpArgs) == 8 + 80 * _lib.MAX_KT + 16 * 6 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 2 * 32 + 8 + 8 * 6 + 8   # ..., ncolgroups|groups_in_block, y_group_stride, pre[2], x0_out, hid[6], x0_skip
 
 
 def test_supported_mlp_variants():
