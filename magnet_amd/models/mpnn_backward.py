@@ -62,6 +62,12 @@ def _packed_bwd(m):
             from ..packing import flag_if_abs_reaches
             flag_if_abs_reaches(W2, 31.98)
         q.w4t = pack(W4.t(), None, mode)
+        if mode == "bf16x6":            # large graphs: update_net_2 and the agg block of update_net_1 walked back by k_linear_bwd128
+            from ..packing import flag_if_abs_reaches
+            q.w4t_f16 = pack(W4.t(), None, "fp16x3")[0]
+            q.daggt_f16 = pack(W3[:, H:2 * H].t(), None, "fp16x3")[0]
+            flag_if_abs_reaches(W4, 31.98)
+            flag_if_abs_reaches(W3[:, H:2 * H], 31.98)
         Q.layers.append(q)
     e0, e1 = m.embedding_mlp[0].weight.detach().float(), m.embedding_mlp[2].weight.detach().float()
     Q.e1t = pack(e1.t(), None, mode)
@@ -82,6 +88,9 @@ def _grad_buffers(m, dev):
         G.layers.append(types.SimpleNamespace(w1a=z(H, H + kin), w1b=z(H, H + kin), b1=z(H), w2=z(H, H), b2=z(H),
                                               w3=z(H, 2 * H + kin), b3=z(H), w4=z(H, H), b4=z(H)))
     return G
+
+
+_NODE_ONE_KERNEL = __import__("os").environ.get("MAGNET_NODE_ONE_KERNEL", "1") != "0"      # A/B knob
 
 
 def _source_csr(topo):
@@ -122,6 +131,7 @@ def backward_call(m, tape, dout, G, ws):
     ews = torch.empty(L.lib().magnet_mpnn_edge_bwd_w_workspace(), device=dev, dtype=torch.float32) if fused_w else None
     o_k = kin // 32
 
+    lbw = None
     for li in reversed(range(len(P.layers))):
         lyr, qb, tp, g = P.layers[li], Q.layers[li], tape.layers[li], G.layers[li]
         dg = ops.instance_norm_bwd(dh, tp.h_out, tp.var, B, Ns)
@@ -130,13 +140,24 @@ def backward_call(m, tape, dout, G, ws):
         ops.swish_fwd(z1, r1)
         lin(N, ops.ktiles(T(r1, H)), lyr.upd2, z2)
         dz2 = ops.swish_bwd(dg, z2, t1)
-        ops.wgrad(dz2, r1, 0, H, g.w4, 0, g.b4, ws)
-        lin(N, ops.ktiles(T(dz2, H)), qb.w4t, t2)
+        one_kernel = N >= 4096 and hasattr(qb, "w4t_f16") and _NODE_ONE_KERNEL     # data + weight + bias gradient of a 128 x 128 Linear in one kernel
+        if one_kernel:
+            if lbw is None:
+                lbw = (torch.empty(L.lib().magnet_linear_bwd128_workspace(), device=dev, dtype=torch.float32),
+                       torch.empty(H, H, device=dev, dtype=torch.float32), torch.empty(H, device=dev, dtype=torch.float32))
+            ops.linear_bwd128(dz2, r1, qb.w4t_f16, t2, g.w4, g.b4, lbw[0], mask=False, want_amax=False, accumulate=True)
+        else:
+            ops.wgrad(dz2, r1, 0, H, g.w4, 0, g.b4, ws)
+            lin(N, ops.ktiles(T(dz2, H)), qb.w4t, t2)
         dz1 = ops.swish_bwd(t2, z1, t2)
         ops.wgrad(dz1, tp.h_in, 0, H, g.w3, 0, g.b3, ws)
-        ops.wgrad(dz1, tp.agg, 0, H, g.w3, H, None, ws)
         ops.wgrad(dz1, nin, 0, kin, g.w3, 2 * H, None, ws)
-        lin(N, ops.ktiles(T(dz1, H)), qb.dagg, dagg)
+        if one_kernel:                                                   # dagg = dz1 W3[:, agg block], dW3[:, agg block] += dz1^T agg
+            ops.linear_bwd128(dz1, tp.agg, qb.daggt_f16, dagg, lbw[1], lbw[2], lbw[0], mask=False, want_amax=False)
+            ops.copy_cols(lbw[1], 0, g.w3, H, H, accumulate=True)
+        else:
+            ops.wgrad(dz1, tp.agg, 0, H, g.w3, H, None, ws)
+            lin(N, ops.ktiles(T(dz1, H)), qb.dagg, dagg)
         # ---- mean aggregation + message MLP at edge granularity                      mpnn.py:73-79, :46
         if E > 0 and fused_w:
             ops.mpnn_edge_bwd_w(tp.A, tp.Bm, dagg, csr, qb.w2_f16[0], qb.w2t_f16[0], qb.w2_f16[1], d2, dA, partials, g.w2, g.b2, ews)

@@ -515,16 +515,17 @@ def mpnn_edge_bwd_w(A, Bm, dagg, csr, w2_f16, w2t_f16, b2, dp, dA, partials, dW2
     return dA
 
 
-def linear_bwd128(dz, x, wt_f16, dx, dW, db, ws, mask=True, amax_in=None, want_amax=True):
+def linear_bwd128(dz, x, wt_f16, dx, dW, db, ws, mask=True, amax_in=None, want_amax=True, accumulate=False):
     """one hidden W -> W Linear (W = dz.shape[1]: 128 or 64) walked back in one kernel: dx = (x > 0) * (dz W), dW = dz^T x,
-    db = colsum(dz) (all written).  ``amax_in`` / the return value: (block maxima of |.|, count) handed from one layer's call to the
+    db = colsum(dz) (written, or added to what is there with ``accumulate``).  ``amax_in`` / the return value: (block maxima of |.|, count) handed from one layer's call to the
     next (None: computed here)"""
     M, W = dz.shape
     assert W in (128, 64) and x.shape[1] >= W and dW.is_contiguous() and dW.shape == (W, W) and db.is_contiguous()
     n_out = L.lib().magnet_linear_bwd128_grid(C.c_long(M))
     amax_out = torch.empty(max(n_out, 1), device=dz.device, dtype=torch.float32) if want_amax else None
     fn = L.lib().magnet_linear_bwd128_f32 if W == 128 else L.lib().magnet_linear_bwd64_f32
-    L.check(fn(_p(dz), dz.stride(0), _p(x), x.stride(0), _p(wt_f16), C.c_long(M), int(bool(mask)), _p(dx), dx.stride(0), _p(dW), _p(db), 0,
+    L.check(fn(_p(dz), dz.stride(0), _p(x), x.stride(0), _p(wt_f16), C.c_long(M), int(bool(mask)), _p(dx), dx.stride(0), _p(dW), _p(db),
+               int(bool(accumulate)),
                _p(amax_in[0]) if amax_in else None, int(amax_in[1]) if amax_in else 0, _p(amax_out), _p(ws), _stream()), "linear_bwd")
     return (amax_out, n_out) if want_amax else None
 
