@@ -341,6 +341,8 @@ def edge_roofline(model, batch, dev, W, B, passes=3):
     for e_, o_ in origs.items():
         setattr(ops.L._lib, e_, timed(e_, o_))
     probe = ClockProbe(dev)
+    mode_was = model.hip_graph
+    model.hip_graph = False                             # kernel by kernel: a replayed hipGraph does not pass through the timed wrappers
     try:
         with probe:
             for _ in range(passes):
@@ -348,6 +350,7 @@ def edge_roofline(model, batch, dev, W, B, passes=3):
                 model.validation_step(batch, 0)
                 probe.collect()
     finally:
+        model.hip_graph = mode_was
         for e_, o_ in origs.items():
             setattr(ops.L._lib, e_, o_)
     ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
@@ -666,13 +669,18 @@ def main():
         return
 
     torch.manual_seed(0)
-    # hip_graph = False: every timed step rebuilds the radius graph + CSR (a host-visible edge count), which a replayed hipGraph
-    # would skip; at the metric size the default "auto" is eager anyway, the flag only matters for small --mesh runs
-    model = FACTORY["mpnn_2d"](types.SimpleNamespace(**HP, hip_graph=False)).to(dev).eval()
+    # hip_graph = "rebuild": every timed step builds the radius graph + CSR afresh (eagerly: the edge count is read on the host) and
+    # then replays the rollout's ~300 kernels from ONE hipGraph whose topology buffers were just overwritten with the fresh arrays
+    # (models/mpnn.py: _replay_with_rebuild).  Same GPU work as enqueueing kernel by kernel (MAGNET_BENCH_EAGER=1: the round-2
+    # behaviour - hip_graph = False + drop_topology_cache() per step), but the rate no longer depends on how busy the host is: on
+    # shared boxes the eager loop was measured between 28 and 40 ms per rollout with identical kernel times.
+    eager = os.environ.get("MAGNET_BENCH_EAGER", "0") == "1"
+    model = FACTORY["mpnn_2d"](types.SimpleNamespace(**HP, hip_graph=False if eager else "rebuild")).to(dev).eval()
     batch = synthetic_batch(W, B, 1000 + rank, dev)          # every rank owns B different trajectories
 
     def step():
-        model.drop_topology_cache()                              # rebuild radius graph + CSR every step
+        if eager:
+            model.drop_topology_cache()                          # rebuild radius graph + CSR every step
         return model.validation_step(batch, 0)
 
     def barrier():

@@ -22,6 +22,9 @@ feedback glue between them - into ONE hipGraph (``torch.cuda.CUDAGraph`` is hipG
   ``RolloutGraph`` reads it after the replay.
 
 Used by default when a rollout's graph has at most ``AUTO_MAX_ROWS`` node rows (``hip_graph`` hparam: True / False / "auto").
+MPNN also takes ``hip_graph="rebuild"``: the radius graph + CSR are built afresh before EVERY replay (what the reference does per
+forward call) and copied into the buffers the captured kernels read - the rollout's ~300 launches become one, the graph
+construction stays in every rollout (models/mpnn.py: _replay_with_rebuild).
 """
 from __future__ import annotations
 
@@ -89,6 +92,12 @@ class RolloutGraph:
         e["graph"].replay()
         return tuple(o.clone() for o in e["out"])
 
+    def peek(self, batch: dict, generation):
+        """the capture a call with this batch would replay (shapes / dtypes / generation only: the caller vouches for the topology),
+        or None"""
+        key = (generation,) + tuple((k, tuple(v.shape), v.dtype, str(v.device)) for k, v in sorted(batch.items()))
+        return self._entries.get(key)
+
     def _capture(self, fn, batch: dict):
         # floating inputs are kept as fp32 (what every model converts to first): `.float()` inside the rollout is then a view
         # of the static buffer and the topology caches recognise it by identity in the capture pass
@@ -117,4 +126,6 @@ def wants_graph(setting, rows: int) -> bool:
     """``hip_graph`` hparam: True / False / "auto" (default: replay when the rollout's graph has few rows)"""
     if setting in (True, False):
         return bool(setting)
+    if setting == "rebuild":
+        return True
     return rows <= AUTO_MAX_ROWS

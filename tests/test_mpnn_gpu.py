@@ -288,3 +288,25 @@ def test_foreign_batch_of_unequal_graphs():
     assert got.shape == want.shape and rel_l2(got, want) < OUT_TOL
     last = u[:, -1:]
     assert rel_l2(got.cpu() - last, want - last) < INC_TOL
+
+
+def test_rollout_replayed_with_a_rebuilt_radius_graph_equals_eager():
+    """hip_graph="rebuild": the radius graph + CSR are built afresh before every replay and copied into the captured buffers - bitwise
+    the eager rollout, also after the mesh changed (different edge count: a new capture) and back"""
+    import types
+    import bench
+    from magnet_amd.models.factory import FACTORY
+    torch.manual_seed(0)
+    hp = dict(bench.HP)
+    eager = FACTORY["mpnn_2d"](types.SimpleNamespace(**hp, hip_graph=False)).cuda().eval()
+    graph = FACTORY["mpnn_2d"](types.SimpleNamespace(**hp, hip_graph="rebuild")).cuda().eval()
+    graph.load_state_dict(eager.state_dict())
+    a = bench.synthetic_batch(32, 2, 7, "cuda")
+    b = bench.synthetic_batch(32, 2, 8, "cuda")
+    b["x"] = b["x"] * 0.5                                              # the same nodes closer together: the same count, another geometry
+    c = bench.synthetic_batch(24, 2, 9, "cuda")                        # another mesh size: other shapes, its own capture
+    for batch in (a, a, b, c, a, b):
+        want = eager.validation_step(batch, 0)
+        got = graph.validation_step(batch, 0)
+        assert torch.equal(got, want)
+    assert graph._topo.csr.E > 0
