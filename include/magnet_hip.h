@@ -414,7 +414,9 @@ int magnet_linear_bwd128_grid(long M);
 int magnet_linear_bwd128_f32(const float* dz, int ldz, const float* x, int ldx, const void* wt_f16, long M, int mask, float* dx,
                              int lddx, float* dW, float* db, int accumulate, const float* amax_in, int n_amax_in, float* amax_out,
                              float* workspace, void* stream);
-/* the same for a 64 -> 64 Linear (dW [64][64], db [64]; the hidden width of MAgNet[CNN]'s MLPs); same workspace and grid functions */
+/* the same for a 64 -> 64 Linear (dW [64][64], db [64]; the hidden width of MAgNet[CNN]'s MLPs); same workspace function, amax_out:
+ * magnet_linear_bwd64_grid(M) floats */
+int magnet_linear_bwd64_grid(long M);
 int magnet_linear_bwd64_f32(const float* dz, int ldz, const float* x, int ldx, const void* wt_f16, long M, int mask, float* dx,
                             int lddx, float* dW, float* db, int accumulate, const float* amax_in, int n_amax_in, float* amax_out,
                             float* workspace, void* stream);

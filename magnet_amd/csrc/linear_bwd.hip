@@ -30,9 +30,10 @@ struct LinBwdArgs {
 // NT = width / 32.  NT = 4: every wave owns one 32-row slab of dW and meets the four 32-feature blocks of x in four rounds.  NT = 2 (hidden
 // width 64): two waves share a slab of dz, each takes one of the two blocks of x - both staged in a single round.
 template <int NT>
-__global__ void __launch_bounds__(256, 1) k_linear_bwd(const LinBwdArgs a) {
+__global__ void __launch_bounds__(256, NT == 2 ? 2 : 1) k_linear_bwd(const LinBwdArgs a) {
     constexpr int ES = LB_ES, W = 32 * NT;
-    constexpr int XB = NT == 4 ? 1 : 2;                                      // blocks of x staged per round
+    constexpr int XB = 1;                                                     // blocks of x staged per round (NT = 2: 72 KiB of LDS, two
+                                                                              // workgroups per CU - one's memory phase under the other's MFMAs)
     constexpr int NR = NT / XB;                                               // rounds per step
     constexpr int NACC = NT == 4 ? 4 : 1;
     __shared__ __attribute__((aligned(16))) u32x4 wl[NT * NT * 4 * 64];       // W^T planes (2^11 hw, 2^11 lw)
@@ -114,13 +115,15 @@ __global__ void __launch_bounds__(256, 1) k_linear_bwd(const LinBwdArgs a) {
         wg_barrier();                                                         // G dz of all four tiles staged
         // ---- this wave's slab of dz (32 features x 128 rows) as fp16 planes, kept for the rounds below; db
         f16x8 ah[4][2], al[4][2];
-        float cs = 0.f;
+        if (NT == 4) {                                                        // (NT = 2: read in the wave's own round - 64 registers it does not have)
+            float cs = 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                cs += stage_operand(sdz + (t * W + slab * 32 + j) * ES + 16 * ks + 8 * half, ah[t][ks], al[t][ks]);
-        bsum += cs;
+                for (int ks = 0; ks < 2; ++ks)
+                    cs += stage_operand(sdz + (t * W + slab * 32 + j) * ES + 16 * ks + 8 * half, ah[t][ks], al[t][ks]);
+            bsum += cs;
+        }
         // ---- dx = (x > 0) * (dz W)
         {
             float* o = a.dx + row * a.lddx + 4 * half;
@@ -150,11 +153,18 @@ __global__ void __launch_bounds__(256, 1) k_linear_bwd(const LinBwdArgs a) {
                     my_x[(q * 32 + 8 * (i >> 2) + 4 * half + (i & 3)) * ES + j] = row_ok ? xr[rd * XB + q][i] : 0.f;
             wg_barrier();
             f32x16& cw = accw[NT == 4 ? rd : 0];
+            if (NT == 4 || xblk == rd)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 f16x8 xh[2], xl[2];
+                if (NT != 4) {
+                    float cs = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) stage_operand(sx + (t * 32 * XB + xblk * 32 + j) * ES + 16 * ks + 8 * half, xh[ks], xl[ks]);
+                    for (int ks = 0; ks < 2; ++ks) cs += stage_operand(sdz + (t * W + slab * 32 + j) * ES + 16 * ks + 8 * half, ah[t][ks], al[t][ks]);
+                    bsum += cs;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) stage_operand(sx + (t * 32 + j) * ES + 16 * ks + 8 * half, xh[ks], xl[ks]);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     cw = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t][ks], xh[ks], cw, 0, 0, 0);
@@ -191,7 +201,7 @@ __global__ void __launch_bounds__(256, 1) k_linear_bwd(const LinBwdArgs a) {
 extern "C" int magnet_reduce_partials_f32(const float* partial, int nblk, long n, float scale, float* out, int accumulate,
                                           void* stream);      // train_kernels.hip
 
-static int lb_grid(long M) {
+static int lb_grid(long M, int per_cu = 1) {
     static int ncu = 0;
     if (!ncu) {
         hipDeviceProp_t prop;
@@ -200,7 +210,7 @@ static int lb_grid(long M) {
         ncu = prop.multiProcessorCount;
     }
     const long steps = (M + 127) / 128;
-    return (int)(steps < ncu ? steps : ncu);
+    return (int)(steps < (long)ncu * per_cu ? steps : (long)ncu * per_cu);
 }
 #define LB_AMAX_BLOCKS 256
 // workspace floats of magnet_linear_bwd{128,64}_f32: per-workgroup partial sums of dW and db, one set of block maxima
@@ -213,7 +223,7 @@ static int launch_linear_bwd(const float* dz, int ldz, const float* x, int ldx, 
     (void)hipGetLastError();
     if (M <= 0) return 0;
     if (ldz < W || ldx < W || lddx < W || (ldz | ldx | lddx) % 4) return -2;
-    const int grid = lb_grid(M);
+    const int grid = lb_grid(M, NT == 2 ? 2 : 1);
     LinBwdArgs a;
     a.dz = dz, a.ldz = ldz, a.x = x, a.ldx = ldx, a.wt = reinterpret_cast<const u32x4*>(wt_f16), a.dx = dx, a.lddx = lddx, a.M = M;
     a.mask = mask;
@@ -255,3 +265,4 @@ extern "C" int magnet_linear_bwd64_f32(const float* dz, int ldz, const float* x,
                                 stream);
 }
 extern "C" int magnet_linear_bwd128_grid(long M) { return lb_grid(M); }
+extern "C" int magnet_linear_bwd64_grid(long M) { return lb_grid(M, 2); }

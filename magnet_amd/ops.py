@@ -521,7 +521,7 @@ def linear_bwd128(dz, x, wt_f16, dx, dW, db, ws, mask=True, amax_in=None, want_a
     next (None: computed here)"""
     M, W = dz.shape
     assert W in (128, 64) and x.shape[1] >= W and dW.is_contiguous() and dW.shape == (W, W) and db.is_contiguous()
-    n_out = L.lib().magnet_linear_bwd128_grid(C.c_long(M))
+    n_out = (L.lib().magnet_linear_bwd128_grid if W == 128 else L.lib().magnet_linear_bwd64_grid)(C.c_long(M))
     amax_out = torch.empty(max(n_out, 1), device=dz.device, dtype=torch.float32) if want_amax else None
     fn = L.lib().magnet_linear_bwd128_f32 if W == 128 else L.lib().magnet_linear_bwd64_f32
     L.check(fn(_p(dz), dz.stride(0), _p(x), x.stride(0), _p(wt_f16), C.c_long(M), int(bool(mask)), _p(dx), dx.stride(0), _p(dW), _p(db),
