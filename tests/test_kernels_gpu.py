@@ -779,3 +779,40 @@ def test_linear_backward_of_a_hidden_layer_in_one_kernel(M, mask, chained, Wd):
     dx2, dW2, db2 = torch.empty_like(dx), torch.empty_like(dW), torch.empty_like(db)
     ops.linear_bwd128(dz, x, wt, dx2, dW2, db2, ws, mask=mask, amax_in=amax)
     assert torch.equal(dx, dx2) and torch.equal(dW, dW2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("D,rows,mean", [(64, 5003, False), (64, 5003, True), (128, 777, True), (32, 4096, False), (48, 300, False), (128, 3, False)])
+def test_layernorm_backward_with_block_maxima_and_fused_mean_gather(D, rows, mean):
+    """magnet_layernorm_bwd_amax_f32 (16-byte-access kernel for D in {32, 64, 128}, one row per wave otherwise) against fp64 autograd of
+    LayerNorm; ``mean``: the rows are CSR-ordered edges and dy is the gradient of their per-target mean (gathered and divided in the load)"""
+    import ctypes as C
+    from magnet_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(rows, D, generator=g).cuda()
+    gamma = (torch.rand(D, generator=g) + 0.5).cuda()
+    if mean:
+        n_nodes = max(rows // 7, 1)
+        tgt = torch.sort(torch.randint(0, n_nodes, (rows,), generator=g)).values.to(torch.int32).cuda()
+        rowptr = torch.zeros(n_nodes + 1, dtype=torch.int32, device="cuda")
+        rowptr[1:] = torch.cumsum(torch.bincount(tgt.long(), minlength=n_nodes), 0).to(torch.int32)
+        dy_nodes = (torch.randn(n_nodes, D, generator=g) * 1e-6).cuda()
+        deg = (rowptr[1:] - rowptr[:-1]).clamp(min=1).double()
+        dy = dy_nodes.double()[tgt.long()] / deg[tgt.long()][:, None]
+        src, tp, rp = dy_nodes, tgt, rowptr
+    else:
+        dy = (torch.randn(rows, D, generator=g) * 1e-6).cuda().double()
+        src, tp, rp = dy.float(), None, None
+        dy = src.double()
+    z64 = z.double().requires_grad_()
+    g64 = gamma.double().requires_grad_()
+    b64 = torch.zeros(D, dtype=torch.float64, device="cuda", requires_grad=True)
+    torch.nn.functional.layer_norm(z64, (D,), g64, b64, 1e-5).backward(dy)
+    nblk = min(2048, (rows + 3) // 4)
+    dz = torch.full((rows, D), float("nan"), device="cuda")
+    part = torch.empty(nblk, 2, D, device="cuda")
+    amax = torch.empty(nblk, device="cuda")
+    L.check(L.lib().magnet_layernorm_bwd_amax_f32(ops._p(z), D, ops._p(src), D, ops._p(gamma), C.c_long(rows), D, C.c_float(1e-5), ops._p(dz), D,
+                                                  ops._p(part), ops._p(amax), ops._p(tp), ops._p(rp), ops._stream()), "layernorm_bwd")
+    assert rel_l2(dz, z64.grad) < 2e-6
+    assert rel_l2(part[:, 0].double().sum(0), g64.grad) < 2e-6 and rel_l2(part[:, 1].double().sum(0), b64.grad) < 2e-6
+    assert abs(float(amax.max()) - float(dz.abs().max())) <= 1e-6 * float(dz.abs().max())
