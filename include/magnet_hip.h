@@ -312,6 +312,9 @@ int magnet_conv_tap_index(int n_images, int H, int W, int k, int d, int32_t* tap
  *      backward-data products reuse magnet_mlp_* with transposed packed weights. ---- */
 int magnet_swish_fwd_f32(const float* z, float* r, long n, void* stream);                       /* mpnn.py:15-24 */
 int magnet_swish_bwd_f32(const float* dr, const float* z, float* dz, long n, void* stream);
+/* the same, and amax256[b & 255] = max(amax256[b & 255], max |dz| of workgroup b): 256 floats ZEROED by the caller - the amax_in of
+ * magnet_linear_bwd128_f32 for this dz (n_amax_in = 256) without a pass of its own */
+int magnet_swish_bwd_amax_f32(const float* dr, const float* z, float* dz, long n, float* amax256, void* stream);
 int magnet_axpy_f32(const float* a, const float* b, float alpha, float* out, long n, void* stream);
 int magnet_mul_f32(const float* a, const float* b, float* out, long n, void* stream);
 int magnet_copy_cols_f32(const float* src, int ld_src, int scol, float* dst, int ld_dst, int dcol, int w, long rows,

@@ -333,15 +333,13 @@ class _Mlp(torch.autograd.Function):
             if tape:                                                      # kept by the forward launch
                 x0, X = tape[0], list(tape[:nl])
                 zL = tape[nl] if pk.ln is not None else None
-            else:
-                x0 = torch.empty(max(M, 1), K0, device=dev, dtype=torch.float32)
-            if tape:
-                pass
             elif nl > 1:
+                x0 = torch.empty(max(M, 1), K0, device=dev, dtype=torch.float32)
                 X = [x0] + [torch.empty(max(M, 1), pk.ht * 32, device=dev, dtype=torch.float32) for _ in range(nl - 1)]
                 zL = torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32) if pk.ln is not None else None
                 _recompute_tape(M, kts, pk, nl, x0, X, zL, K0, x0_skip=_x0_skip_mask(m, srcs, M, pk.ht * 32))
             else:
+                x0 = torch.empty(max(M, 1), K0, device=dev, dtype=torch.float32)
                 a, keep = ops.mlp_args(M, kts)
                 L.check(L.lib().magnet_mlp_materialize_input_f32(C.byref(a), ops._p(x0), K0, ops._stream()), "materialize_input")
                 X = [x0]

@@ -43,6 +43,34 @@ __global__ void k_swish_bwd(const float* __restrict__ dr, const float* __restric
     }
     st4(dz, i4, cnt, o);
 }
+// the same, plus amax[blockIdx.x & 255] = max(..., |dz| of this workgroup): the block maxima magnet_linear_bwd128_f32 wants as amax_in
+// (256 floats zeroed by the caller; a maximum does not depend on the order of the atomics: deterministic)
+__global__ void __launch_bounds__(256) k_swish_bwd_amax(const float* __restrict__ dr, const float* __restrict__ z, float* __restrict__ dz,
+                                                        long n, float* __restrict__ amax) {
+    __shared__ float wm[4];
+    const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int cnt = i4 >= n ? 0 : ((n - i4) < 4 ? (int)(n - i4) : 4);
+    float m = 0.f;
+    if (cnt) {
+        const f32x4 g = ld4(dr, i4, cnt), v = ld4(z, i4, cnt);
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float s = sigmoidf_fast(v[c]);
+            o[c] = g[c] * s * (1.0f + v[c] * (1.0f - s));
+            if (c < cnt) m = fmaxf(m, fabsf(o[c]));
+        }
+        st4(dz, i4, cnt, o);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        atomicMax(reinterpret_cast<unsigned*>(amax) + (blockIdx.x & 255), __float_as_uint(m));      // (non-negative floats order as their bits)
+    }
+}
 // out = a + alpha * b   (out may alias a)
 __global__ void k_axpy(const float* a, const float* b, float alpha, float* out, long n) {
     EW_BODY(, )
@@ -512,6 +540,12 @@ extern "C" int magnet_swish_bwd_f32(const float* dr, const float* z, float* dz, 
     BEGIN();
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_swish_bwd, dim3(nb((n + 3) / 4, 256)), dim3(256), 0, S_, dr, z, dz, n);
+    END();
+}
+extern "C" int magnet_swish_bwd_amax_f32(const float* dr, const float* z, float* dz, long n, float* amax256, void* stream) {
+    BEGIN();
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_swish_bwd_amax, dim3(nb((n + 3) / 4, 256)), dim3(256), 0, S_, dr, z, dz, n, amax256);
     END();
 }
 extern "C" int magnet_axpy_f32(const float* a, const float* b, float alpha, float* out, long n, void* stream) {

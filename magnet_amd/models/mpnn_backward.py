@@ -139,21 +139,22 @@ def backward_call(m, tape, dout, G, ws):
         lin(N, ops.ktiles(T(tp.h_in, H), T(tp.agg, H), T(nin, kin)), lyr.upd1, z1)
         ops.swish_fwd(z1, r1)
         lin(N, ops.ktiles(T(r1, H)), lyr.upd2, z2)
-        dz2 = ops.swish_bwd(dg, z2, t1)
         one_kernel = N >= 4096 and hasattr(qb, "w4t_f16") and _NODE_ONE_KERNEL     # data + weight + bias gradient of a 128 x 128 Linear in one kernel
+        am = torch.zeros(2, 256, device=dev, dtype=torch.float32) if one_kernel else None     # block maxima of |dz2|, |dz1| from the Swish backward
+        dz2 = ops.swish_bwd(dg, z2, t1, amax=am[0] if one_kernel else None)
         if one_kernel:
             if lbw is None:
                 lbw = (torch.empty(L.lib().magnet_linear_bwd128_workspace(), device=dev, dtype=torch.float32),
                        torch.empty(H, H, device=dev, dtype=torch.float32), torch.empty(H, device=dev, dtype=torch.float32))
-            ops.linear_bwd128(dz2, r1, qb.w4t_f16, t2, g.w4, g.b4, lbw[0], mask=False, want_amax=False, accumulate=True)
+            ops.linear_bwd128(dz2, r1, qb.w4t_f16, t2, g.w4, g.b4, lbw[0], mask=False, want_amax=False, accumulate=True, amax_in=(am[0], 256))
         else:
             ops.wgrad(dz2, r1, 0, H, g.w4, 0, g.b4, ws)
             lin(N, ops.ktiles(T(dz2, H)), qb.w4t, t2)
-        dz1 = ops.swish_bwd(t2, z1, t2)
+        dz1 = ops.swish_bwd(t2, z1, t2, amax=am[1] if one_kernel else None)
         ops.wgrad(dz1, tp.h_in, 0, H, g.w3, 0, g.b3, ws)
         ops.wgrad(dz1, nin, 0, kin, g.w3, 2 * H, None, ws)
         if one_kernel:                                                   # dagg = dz1 W3[:, agg block], dW3[:, agg block] += dz1^T agg
-            ops.linear_bwd128(dz1, tp.agg, qb.daggt_f16, dagg, lbw[1], lbw[2], lbw[0], mask=False, want_amax=False)
+            ops.linear_bwd128(dz1, tp.agg, qb.daggt_f16, dagg, lbw[1], lbw[2], lbw[0], mask=False, want_amax=False, amax_in=(am[1], 256))
             ops.copy_cols(lbw[1], 0, g.w3, H, H, accumulate=True)
         else:
             ops.wgrad(dz1, tp.agg, 0, H, g.w3, H, None, ws)

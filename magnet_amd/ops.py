@@ -460,9 +460,13 @@ def swish_fwd(z, out=None):
     return out
 
 
-def swish_bwd(dr, z, out=None):
+def swish_bwd(dr, z, out=None, amax=None):
+    """dz = dr * Swish'(z); ``amax``: a zeroed float[256] that receives the block maxima of |dz| (-> linear_bwd128(amax_in=(amax, 256)))"""
     out = torch.empty_like(z) if out is None else out
-    L.check(L.lib().magnet_swish_bwd_f32(_p(dr), _p(z), _p(out), C.c_long(z.numel()), _stream()), "swish_bwd")
+    if amax is not None:
+        L.check(L.lib().magnet_swish_bwd_amax_f32(_p(dr), _p(z), _p(out), C.c_long(z.numel()), _p(amax), _stream()), "swish_bwd")
+    else:
+        L.check(L.lib().magnet_swish_bwd_f32(_p(dr), _p(z), _p(out), C.c_long(z.numel()), _stream()), "swish_bwd")
     return out
 
 

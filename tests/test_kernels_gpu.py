@@ -816,3 +816,14 @@ def test_layernorm_backward_with_block_maxima_and_fused_mean_gather(D, rows, mea
     assert rel_l2(dz, z64.grad) < 2e-6
     assert rel_l2(part[:, 0].double().sum(0), g64.grad) < 2e-6 and rel_l2(part[:, 1].double().sum(0), b64.grad) < 2e-6
     assert abs(float(amax.max()) - float(dz.abs().max())) <= 1e-6 * float(dz.abs().max())
+
+
+@pytest.mark.parametrize("n", [5, 1000, 262144 * 128 + 3])
+def test_swish_backward_leaves_the_block_maxima_of_its_output(n):
+    from magnet_amd import ops
+    g = torch.Generator().manual_seed(8)
+    dr, z = (torch.randn(n, generator=g) * 1e-6).cuda(), torch.randn(n, generator=g).cuda()
+    amax = torch.zeros(256, device="cuda")
+    out = ops.swish_bwd(dr, z, amax=amax)
+    assert torch.equal(out, ops.swish_bwd(dr, z))
+    assert float(amax.max()) == float(out.abs().max())
