@@ -789,6 +789,84 @@ __global__ void __launch_bounds__(256, 1) k_node_update(NodeUpdateArgs a) {
     }
 }
 
+// The same update for launches of at most one 128-row tile per CU (the launch-bound 1-D configs: 100 rows = one workgroup): the
+// persistent kernel's W1 chunk stream is nine dependent L2 -> register -> LDS hand-overs with a barrier each - 16.8 us for 100 rows, a
+// third of a C1 hop.  Here nothing is streamed: ALL of W1 (9 x 16 KiB, kin = 32) is requested in one burst of LDS-DMA loads, the tile's
+// source rows and W2 (64 registers per lane) in the same breath; one wait, one barrier, the first layer runs without another; W2 then
+// takes W1's place in LDS (one more barrier) and the store tiles the space behind it.  Same accumulation order as k_node_update (agg /
+// node_in k tiles first, h last): bitwise the same results.  No InstanceNorm on load, no statistics (the small-graph path has neither).
+__global__ void __launch_bounds__(256, 1) k_node_update_burst(NodeUpdateArgs a) {
+    constexpr int MODE = GEMM_FP16X3, NKT = 9;
+    __shared__ __attribute__((aligned(16))) u32x4 wb[NKT * 1024];                     // W1 whole; later W2 in [0, 4096) + the store tiles
+    __shared__ __attribute__((aligned(16))) float bl[2][128];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, j = lane & 31;
+    const long row0 = (long)blockIdx.x * 128 + wave * 32;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) dma_chunk<16>(a.w1 + kt * 1024, wb + kt * 1024, wave, lane);
+    f32x4 xr[NKT][4];
+    {
+        const long r = min(row0 + j, a.n - 1);                                        // clamped: rows past the end are dropped at the store
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const float* p = kt < 4 ? a.h + r * 128 + kt * 32 + 4 * half
+                           : kt < 8 ? a.agg + r * 128 + (kt - 4) * 32 + 4 * half
+                                    : a.node_in + r * a.kin + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xr[kt][g] = *reinterpret_cast<const f32x4*>(p + 8 * g);
+        }
+    }
+    u32x4 w2r[16];
+    {
+        const u32x4* g2 = reinterpret_cast<const u32x4*>(a.w2);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w2r[q] = g2[q * 256 + threadIdx.x];
+    }
+    if (threadIdx.x < 128) bl[0][threadIdx.x] = a.b1[threadIdx.x];
+    else bl[1][threadIdx.x - 128] = a.b2[threadIdx.x - 128];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  // the DMA'd chunks (the compiler does not track them)
+    __syncthreads();
+    f32x16 acc[4], accc[4];
+    init_bias<4>(acc, bl[0], half);
+    zero_tiles<4>(accc);
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) {
+        const int kt = i < NKT - 4 ? i + 4 : i - (NKT - 4);                           // agg and node_in first, h last (as k_node_update)
+        f32x16 x;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[4 * g + c] = xr[kt][g][c];
+        mma_chunk<4, MODE, false>(x, acc, accc, wb + kt * 1024, lane);
+    }
+    fold_tiles<4, MODE>(acc, accc);
+    f32x16 h0[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        apply_act<ACT_SWISH>(acc[t]);
+        h0[t] = acc[t];
+    }
+    __syncthreads();                                                                  // everybody is done with W1
+#pragma unroll
+    for (int q = 0; q < 16; ++q) wb[q * 256 + threadIdx.x] = w2r[q];
+    __syncthreads();
+    init_bias<4>(acc, bl[1], half);
+    zero_tiles<4>(accc);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) mma_chunk<4, MODE, false>(h0[kt], acc, accc, wb + kt * 1024, lane);
+    fold_tiles<4, MODE>(acc, accc);
+    float* tl = reinterpret_cast<float*>(wb + 4096) + wave * 32 * NH_TS;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        apply_act<ACT_SWISH>(acc[t]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[t][4 * g + c] += xr[t][g][c];
+        store_tile_lines(acc[t], tl, a.y, t * 32, row0, a.n, lane);
+    }
+}
+
 // y [n_rows][128] = hn + Swish(W2 Swish(W1 [hn | agg | node_in] + b1) + b2), hn = mean ? (h - mean[g]) / sqrt(var[g] + eps) : h;
 // w1 / w2: fp16x3 planes as magnet_mlp_fp16x3_f32 takes them.  Returns -2 for kin not in {32, 64} or more than 8 graphs (the
 // caller then uses the generic chain).  y must not alias h.  part_sum / part_m2 ([n_rows / 128][128] each, n_rows % 128 == 0): per
@@ -818,6 +896,12 @@ extern "C" int magnet_mpnn_node_update_f32(const float* h, const float* agg, con
     const long ntiles = (n_rows + 127) / 128;
     const int grid = (int)(ntiles < ncu ? ntiles : ncu);
     hipStream_t s = (hipStream_t)stream;
+    static int burst = -1;             // MAGNET_NODE_BURST=0: the persistent kernel for small launches too (A/B knob)
+    if (burst < 0) { const char* e = getenv("MAGNET_NODE_BURST"); burst = (e && e[0] == '0') ? 0 : 1; }
+    if (burst && kin == 32 && !mean && !part_sum && ntiles <= ncu) {
+        hipLaunchKernelGGL(k_node_update_burst, dim3((int)ntiles), dim3(256), 0, s, a);
+        return (int)hipGetLastError();
+    }
     if (kin == 32 && mean) hipLaunchKernelGGL((k_node_update<9, true>), dim3(grid), dim3(256), 0, s, a);
     else if (kin == 32) hipLaunchKernelGGL((k_node_update<9, false>), dim3(grid), dim3(256), 0, s, a);
     else if (mean) hipLaunchKernelGGL((k_node_update<10, true>), dim3(grid), dim3(256), 0, s, a);
