@@ -319,6 +319,10 @@ int magnet_axpy_f32(const float* a, const float* b, float alpha, float* out, lon
 int magnet_mul_f32(const float* a, const float* b, float* out, long n, void* stream);
 int magnet_copy_cols_f32(const float* src, int ld_src, int scol, float* dst, int ld_dst, int dcol, int w, long rows,
                          int accumulate, void* stream);
+/* dst[r, dcol:dcol+w] (+)= scale * src[r, scol:scol+w] with 16-byte accesses (w, the column offsets and the row strides multiples of 4,
+ * 16-byte aligned bases; -2 otherwise) */
+int magnet_copy_cols_scaled_f32(const float* src, int ld_src, int scol, float* dst, int ld_dst, int dcol, int w, long rows,
+                                float scale, int accumulate, void* stream);
 /* p[e] = A[tgt[e]] + Bm[src[e]]: pre-activation of message_net_1 (mpnn.py:75-76), recomputed for the backward */
 int magnet_edge_pre_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt, long n_edges, float* p,
                         void* stream);

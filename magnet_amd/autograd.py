@@ -441,8 +441,8 @@ class _Mlp(torch.autograd.Function):
                     if g is None or (factored is not None and factored[kt0]):      # (done at source granularity above)
                         continue
                     g2 = g.view(-1, g.shape[-1])
-                    if idx is None and rdiv == 1 and scale == 1.0:
-                        ops.copy_cols(dX0, kt0 * 32, g2, col, width, accumulate=True)
+                    if idx is None and rdiv == 1 and (scale == 1.0 or not ((width | col | g2.stride(0)) & 3)):
+                        ops.copy_cols(dX0, kt0 * 32, g2, col, width, accumulate=True, scale=scale)   # (dense rows: a scaled column copy)
                         continue
                     if idx is None:                                              # dense rows (shared by rdiv consecutive rows)
                         rowptr = torch.arange(0, M + rdiv, rdiv, dtype=torch.int32, device=dev).clamp_(max=M)

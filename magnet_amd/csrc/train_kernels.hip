@@ -93,6 +93,20 @@ __global__ void k_copy_cols(const float* __restrict__ src, int lds_, int scol, f
     *d = accumulate ? *d + v : v;
 }
 
+// dst[r, dcol : dcol+w] (+)= scale * src[r, scol : scol+w] with 16-byte accesses (w, both column offsets and both row strides multiples
+// of 4): the gradient of a dense, scaled k-tile source (e.g. MAgNet's 2^k e: models/magnet_gnn.py:76-77 under Q2)
+__global__ void k_copy_cols4(const float* __restrict__ src, int lds_, int scol, float* __restrict__ dst, int ldd, int dcol, int w4,
+                             long rows, float scale, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * w4) return;
+    const long r = i / w4;
+    const int c = (int)(i % w4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src + r * lds_ + scol + c) * scale;
+    float* d = dst + r * ldd + dcol + c;
+    if (accumulate) v += *reinterpret_cast<const f32x4*>(d);
+    *reinterpret_cast<f32x4*>(d) = v;
+}
+
 // p[e] = A[tgt[e]] + Bm[src[e]]                                  (recomputed pre-activation of message_net_1)
 __global__ void k_edge_pre(const float* __restrict__ A, const float* __restrict__ Bm, const int32_t* __restrict__ src,
                            const int32_t* __restrict__ tgt, long E, float* __restrict__ p) {
@@ -565,6 +579,15 @@ extern "C" int magnet_copy_cols_f32(const float* src, int ld_src, int scol, floa
     BEGIN();
     if (rows <= 0 || w <= 0) return 0;
     hipLaunchKernelGGL(k_copy_cols, dim3(nb(rows * w, 256)), dim3(256), 0, S_, src, ld_src, scol, dst, ld_dst, dcol, w, rows,
+                       accumulate);
+    END();
+}
+extern "C" int magnet_copy_cols_scaled_f32(const float* src, int ld_src, int scol, float* dst, int ld_dst, int dcol, int w, long rows,
+                                           float scale, int accumulate, void* stream) {
+    BEGIN();
+    if (rows <= 0 || w <= 0) return 0;
+    if ((w | scol | dcol | ld_src | ld_dst) & 3 || (((uintptr_t)src | (uintptr_t)dst) & 15)) return -2;
+    hipLaunchKernelGGL(k_copy_cols4, dim3(nb(rows * (w / 4), 256)), dim3(256), 0, S_, src, ld_src, scol, dst, ld_dst, dcol, w / 4, rows, scale,
                        accumulate);
     END();
 }

@@ -478,8 +478,14 @@ def axpy(a, b, alpha=1.0, out=None):
     return out
 
 
-def copy_cols(src, scol, dst, dcol, w, accumulate=False):
+def copy_cols(src, scol, dst, dcol, w, accumulate=False, scale=1.0):
+    """dst[:, dcol:dcol+w] (+)= scale * src[:, scol:scol+w]"""
     rows = src.shape[0]
+    if not ((w | scol | dcol | src.stride(0) | dst.stride(0)) & 3) and not ((src.data_ptr() | dst.data_ptr()) & 15):
+        L.check(L.lib().magnet_copy_cols_scaled_f32(_p(src), src.stride(0), scol, _p(dst), dst.stride(0), dcol, w, C.c_long(rows),
+                                                    C.c_float(float(scale)), int(accumulate), _stream()), "copy_cols")
+        return dst
+    assert scale == 1.0, "scaled column copies need 16-byte aligned blocks"
     L.check(L.lib().magnet_copy_cols_f32(_p(src), src.stride(0), scol, _p(dst), dst.stride(0), dcol, w, C.c_long(rows),
                                          int(accumulate), _stream()), "copy_cols")
     return dst
