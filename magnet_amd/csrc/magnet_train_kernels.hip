@@ -148,7 +148,8 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd_v4(const float* __restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, c4 = lane % LPR;
     __shared__ float sg[4][2][128];
-    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
+    const f32x4 gm = {gamma[4 * c4], gamma[4 * c4 + 1], gamma[4 * c4 + 2], gamma[4 * c4 + 3]};   // (a parameter: a view into the optimizer's flat
+                                                                                              // buffer, 4-byte aligned only)
     f32x4 ag = {0, 0, 0, 0}, ab = {0, 0, 0, 0};
     float dzmax = 0.f;
     const float invD = 1.0f / (float)D;
@@ -465,7 +466,7 @@ extern "C" int magnet_layernorm_bwd_amax_f32(const float* z, int ldz, const floa
     if (D < 1 || D > 256 || (tgt && !rowptr)) return -2;
     const unsigned grid = nb(rows, 4) < 2048u ? nb(rows, 4) : 2048u;
     const bool v4 = (D == 32 || D == 64 || D == 128) && !((ldz | ldd | ldo) & 3) &&
-                    !(((uintptr_t)z | (uintptr_t)dy | (uintptr_t)dz | (uintptr_t)gamma) & 15);
+                    !(((uintptr_t)z | (uintptr_t)dy | (uintptr_t)dz) & 15);
     if (v4 && D == 32)
         hipLaunchKernelGGL(k_layernorm_bwd_v4<8>, dim3(grid), dim3(256), 0, S_, z, ldz, dy, ldd, gamma, rows, eps, dz, ldo, part, amax, tgt, rowptr);
     else if (v4 && D == 64)
