@@ -366,6 +366,7 @@ class _Mlp(torch.autograd.Function):
             nblk_w = min(768, (M + 31) // 32)
             dX0 = None
             amax, lb_ws = ((ln_amax, nblk) if ln_amax is not None else None), None
+            tpacks_emit_amax = BWD_GEMM == "bf16x6"                       # (the split-GEMM kernels' masked store can emit block maxima)
             for l in range(nl - 1, -1, -1):
                 W, b = params[2 * l], params[2 * l + 1]
                 n, k = W.shape
@@ -416,16 +417,20 @@ class _Mlp(torch.autograd.Function):
                 dX = torch.empty(max(M, 1), Kp, device=dev, dtype=torch.float32)
                 # column blocks of equal width go out as ONE launch (the kernel's column groups over gridDim.y): the nine 128-column
                 # taps of an EDSR convolution on a 64 x 64 map were nine 32-workgroup launches of 14 us each
+                # (l > 0: the launch also leaves the block maxima of what it stores - the layer below, if it takes the one-kernel path,
+                # needs them for its power-of-two scale and would otherwise make a pass of its own over dX)
+                mx = torch.zeros(256, device=dev, dtype=torch.float32) if l > 0 and M >= _FUSED_LAYER_ROWS and tpacks_emit_amax else None
                 for (c0, w, G) in col_groups:
                     tps = [_tpack(m, pk, l, c0 + g * w, w, W, Np, Kp) for g in range(G)]
                     if l > 0:      # ... with the ReLU mask of the layer below as the epilogue: dz_{l-1} = (X[l] > 0) ? dX : 0
                         ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), tps, nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE, colgroups=G,
-                                epi=ops.EPI_STORE_MASK, res=X[l][:, c0:], y=dX[:, c0:], ldy=Kp, ncols=w)
+                                epi=ops.EPI_STORE_MASK, res=X[l][:, c0:], y=dX[:, c0:], ldy=Kp, ncols=w, partials=mx)
                     else:
                         ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), tps, nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE, colgroups=G,
                                 y=dX[:, c0:], ldy=Kp, ncols=w)
                 if l > 0:
                     dz = dX
+                    amax = (mx, 256) if mx is not None else None
                 else:
                     dX0 = dX
             # ---- scatter the first-layer input gradient back through the gathers

@@ -523,7 +523,7 @@ __device__ __forceinline__ void store_ktile(const f32x16& x, float* __restrict__
 template <int NT, int RES>
 __device__ __forceinline__ void store_rows(const f32x16 (&v)[NT], float* __restrict__ y, int ldy, int ncols,
                                             const float* __restrict__ res, int ldres, int row, bool row_ok,
-                                            int half) {
+                                            int half, float* vmax = nullptr /* running max of |what was stored| (vector path) */) {
     if (!row_ok) return;
     const bool vec = ((ldy & 3) == 0) && (!RES || (ldres & 3) == 0);
 #pragma unroll
@@ -541,6 +541,7 @@ __device__ __forceinline__ void store_rows(const f32x16 (&v)[NT], float* __restr
                     for (int c = 0; c < 4; ++c) t[c] = r[c] > 0.f ? t[c] : 0.f;
                 }
                 *reinterpret_cast<f32x4*>(y + (size_t)row * ldy + n0) = t;
+                if (vmax) *vmax = fmaxf(fmaxf(*vmax, fmaxf(fabsf(t[0]), fabsf(t[1]))), fmaxf(fabsf(t[2]), fabsf(t[3])));
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -549,6 +550,7 @@ __device__ __forceinline__ void store_rows(const f32x16 (&v)[NT], float* __restr
                         if (RES == 1) x += res[(size_t)row * ldres + n0 + c];
                         if (RES == 2) x = res[(size_t)row * ldres + n0 + c] > 0.f ? x : 0.f;
                         y[(size_t)row * ldy + n0 + c] = x;
+                        if (vmax) *vmax = fmaxf(*vmax, fabsf(x));
                     }
             }
         }

@@ -334,6 +334,15 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
         } else {
             float* yg = a.y + (a.y_group_stride ? (size_t)cg * a.y_group_stride : (size_t)cg * OT * 32);
             // y == nullptr: a tape-only launch (the training backward's recompute wants x0_out / hid[], not the chain's own output)
+            if (EPI == EPI_STORE_MASK && a.partials) {
+                // partials != NULL on a masked store: 256 floats (zeroed by the caller) that receive the block maxima of |y| - the
+                // amax_in of magnet_linear_bwd128_f32 / 64 for the layer below (a maximum: the order of the atomics does not matter)
+                float mx = 0.f;
+                store_rows<OT, 2>(out, yg, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok && a.y != nullptr, half, &mx);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+                if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(a.partials) + ((blockIdx.x * 4 + wave) & 255), __float_as_uint(mx));
+            } else
             store_rows<OT, EPI == EPI_STORE_MASK ? 2 : (EPI == EPI_STORE_RES ? 1 : 0)>(out, yg, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok && a.y != nullptr, half);
         }
         TRACE(32)

@@ -133,6 +133,9 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
         a.res, a.ldres = res.data_ptr(), (res.stride(0) if res.dim() == 2 else res.shape[-1])
     if epi == EPI_SEGMEAN:
         a.tgt, a.rowptr, a.partials = tgt.data_ptr(), rowptr.data_ptr(), partials.data_ptr()
+    elif epi == EPI_STORE_MASK and partials is not None:       # a zeroed float[256] that receives the block maxima of |y| (split-GEMM kernels)
+        assert partials.numel() >= 256 and partials.dtype == torch.float32 and layers[0][0].dtype in (torch.float16, torch.int16)
+        a.partials = partials.data_ptr()
     kind = layers[0][0].dtype                                 # float16: fp16x3, int16: bf16x6, float32: fp32 MFMA
     assert all(w.dtype == kind for w, _ in layers)
     name = {torch.float16: "magnet_mlp_fp16x3_f32", torch.int16: "magnet_mlp_bf16x6_f32", torch.float32: "magnet_mlp_f32",
