@@ -436,10 +436,21 @@ class _Mlp(torch.autograd.Function):
             # ---- scatter the first-layer input gradient back through the gathers
             grads_src = [None] * m.n_src
             if need_dx0:
+                # a source that enters as ONE dense full-width run (MAgNet's edge latents) is written, not accumulated: no zero fill,
+                # no read of the destination
+                runs_of = {}
+                for r_ in m.runs:
+                    runs_of.setdefault(r_[0], []).append(r_)
+                written_once = {si for si, rs in runs_of.items()
+                                if len(rs) == 1 and rs[0][2] is None and rs[0][4] == 1 and rs[0][1] == 0
+                                and rs[0][6] == srcs[si].shape[-1] and not ((rs[0][6] | srcs[si].shape[-1]) & 3)
+                                and srcs[si].reshape(-1, srcs[si].shape[-1]).shape[0] == M and (factored is None or not factored[rs[0][5]])}
                 for si, s in enumerate(srcs):
                     if ctx.needs_input_grad[1 + si]:
-                        grads_src[si] = torch.zeros(s.shape, device=dev, dtype=torch.float32) if factored is None or grads_src_f[si] is None \
-                            else grads_src_f[si]
+                        if factored is not None and grads_src_f[si] is not None:
+                            grads_src[si] = grads_src_f[si]
+                        else:
+                            grads_src[si] = (torch.empty if si in written_once else torch.zeros)(s.shape, device=dev, dtype=torch.float32)
                 pending = {}                 # (source, column, width, scale) -> gathered runs that can share launches (the taps of a convolution)
                 for (si, col, idx, scale, rdiv, kt0, width) in m.runs:
                     g = grads_src[si]
@@ -447,7 +458,7 @@ class _Mlp(torch.autograd.Function):
                         continue
                     g2 = g.view(-1, g.shape[-1])
                     if idx is None and rdiv == 1 and (scale == 1.0 or not ((width | col | g2.stride(0)) & 3)):
-                        ops.copy_cols(dX0, kt0 * 32, g2, col, width, accumulate=True, scale=scale)   # (dense rows: a scaled column copy)
+                        ops.copy_cols(dX0, kt0 * 32, g2, col, width, accumulate=si not in written_once, scale=scale)   # (dense rows: a scaled column copy)
                         continue
                     if idx is None:                                              # dense rows (shared by rdiv consecutive rows)
                         rowptr = torch.arange(0, M + rdiv, rdiv, dtype=torch.int32, device=dev).clamp_(max=M)
