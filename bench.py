@@ -555,9 +555,14 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
                  "what": "rollout through autograd Functions (HIP forward + backward kernels, unfused) + one gradient all-reduce + fused Adam",
                  "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],
                  "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
-        del tmodel, opt
+        del tmodel, opt, last, train_step
     del model, batch
+    # the autograd graph of the last training step (and the ~200 GB of backward tape its Functions kept) sits in
+    # reference cycles until the cyclic collector runs; the next leg decides how much tape IT may keep from what is allocated now
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
     if rank != 0:
         return None
     return {
@@ -786,7 +791,9 @@ def main():
                  "allreduce_bytes": 4 * n_grad,
                  "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],
                  "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
-        del tmodel, opt
+        del tmodel, opt, last, train_step
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
 
     cpu = None
@@ -811,7 +818,10 @@ def main():
         # keep as much of their backward tape in HBM as fits
         del model
         torch.cuda.empty_cache()
-        for key, name in (("c4b", "magnet_cnn_2d"), ("c5", "magnet_gnn")):
+        order = (("c4b", "magnet_cnn_2d"), ("c5", "magnet_gnn"))
+        if os.environ.get("MAGNET_BENCH_C5_FIRST", "0") == "1":
+            order = order[::-1]
+        for key, name in order:
             extras[key] = bench_magnet(name, 1, max(1, min(K, 10)), max(1, min(Wm, 2)), 256, min(args.train_steps, 2), dev, rank, world,
                                        dist, max_over_ranks)
         if rank == 0:
