@@ -124,24 +124,18 @@ __global__ void __launch_bounds__(256, NT == 2 ? 2 : 1) k_linear_bwd(const LinBw
                     cs += stage_operand(sdz + (t * W + slab * 32 + j) * ES + 16 * ks + 8 * half, ah[t][ks], al[t][ks]);
             bsum += cs;
         }
-        // ---- dx = (x > 0) * (dz W)
-        {
-            float* o = a.dx + row * a.lddx + 4 * half;
+        // ---- dx = (x > 0) * (dz W): formed now (x is about to be staged away), STORED after the rounds - behind the next step's x
+        // loads in the memory queue: vmcnt retires in order, so a load consumed at the top of the next step must not sit behind
+        // 64 KiB of stores whose acknowledgement takes microseconds
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        float t = acc[nt][4 * g + c] * (1.0f / 2048.0f) * usc;
-                        if (a.mask) t = xr[nt][4 * g + c] > 0.f ? t : 0.f;
-                        v[c] = t;
-                        dxmax = fmaxf(dxmax, fabsf(t));
-                    }
-                    if (row_ok) *reinterpret_cast<f32x4*>(o + nt * 32 + 8 * g) = v;
-                }
-        }
+            for (int i = 0; i < 16; ++i) {
+                float t = acc[nt][i] * (1.0f / 2048.0f) * usc;
+                if (a.mask) t = xr[nt][i] > 0.f ? t : 0.f;
+                acc[nt][i] = t;
+                dxmax = fmaxf(dxmax, fabsf(t));
+            }
         // ---- dW += dz^T x: NR rounds, XB 32-feature blocks of x of all four tiles per round
 #pragma unroll
         for (int rd = 0; rd < NR; ++rd) {
@@ -175,6 +169,17 @@ __global__ void __launch_bounds__(256, NT == 2 ? 2 : 1) k_linear_bwd(const LinBw
         }
         asm volatile("" ::: "memory");
         if (step + gridDim.x < nsteps) load_tile(xr, a.x, a.ldx, step + gridDim.x);
+        asm volatile("" ::: "memory");
+        if (row_ok) {
+            float* o = a.dx + row * a.lddx + 4 * half;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(o + nt * 32 + 8 * g) = v;
+                }
+        }
         wg_barrier();                                                         // staging free for the next step
     }
     // ---- this workgroup's partial sums (C/D row = dz feature = output of the Linear, column = x feature = its input)
