@@ -254,8 +254,11 @@ class MPNN(LightningModule):
             if small_nodes:
                 ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g)
             else:
+                # with a tape: the launch also leaves Swish(z1) and z2 (the update net's hidden activation and its raw output) for the
+                # backward, which then recomputes only z1 (two [N, 128] arrays per hop against a GEMM launch and a Swish pass)
+                keep = (new(), new()) if tape is not None and lyr.upd1[0].dtype in (torch.float16, torch.int16) else None
                 ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
-                        act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g)
+                        act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g, hid=list(keep) if keep else None)
             if gptr is not None:
                 ops.instance_norm_ragged(g, gptr, out=h)
             elif tape is None:
@@ -263,7 +266,8 @@ class MPNN(LightningModule):
             else:
                 h_in = h
                 h, var = ops.instance_norm(g, B, Ns, out=new(), return_var=True)
-                tape.layers.append(types.SimpleNamespace(h_in=h_in, A=A, Bm=Bm, agg=agg, var=var, h_out=h))
+                tape.layers.append(types.SimpleNamespace(h_in=h_in, A=A, Bm=Bm, agg=agg, var=var, h_out=h,
+                                                         r1=keep[0] if keep else None, z2=keep[1] if keep else None))
         if tape is not None:
             tape.h = h
         k1, s1, k2 = _READOUT[tw]

@@ -121,7 +121,8 @@ def backward_call(m, tape, dout, G, ws):
     ops.reduce_partials(gp, gp.shape[0], gp.shape[1], G.conv)
     dnin = torch.zeros(N, kin, device=dev, dtype=torch.float32)
     dnin_l = torch.empty_like(dnin)
-    z1, r1, z2, t1, t2, dagg, dA, dBm = (new() for _ in range(8))
+    z1, r1_buf, z2_buf, t1, t2, dagg, dA, dBm = (new() for _ in range(8))
+    r1, z2 = r1_buf, z2_buf
     fused = m.edge_bwd in ("fused", "fused_w")
     fused_w = m.edge_bwd == "fused_w"                 # dW2 / db2 formed inside the edge kernel: no s1 / dq arrays at all
     d2 = enew()
@@ -137,8 +138,12 @@ def backward_call(m, tape, dout, G, ws):
         dg = ops.instance_norm_bwd(dh, tp.h_out, tp.var, B, Ns)
         # ---- update MLP (recomputed pre-activations)                                 mpnn.py:81-90
         lin(N, ops.ktiles(T(tp.h_in, H), T(tp.agg, H), T(nin, kin)), lyr.upd1, z1)
-        ops.swish_fwd(z1, r1)
-        lin(N, ops.ktiles(T(r1, H)), lyr.upd2, z2)
+        if getattr(tp, "r1", None) is not None:                           # kept by the forward launch
+            r1, z2 = tp.r1, tp.z2
+        else:
+            r1, z2 = r1_buf, z2_buf
+            ops.swish_fwd(z1, r1)
+            lin(N, ops.ktiles(T(r1, H)), lyr.upd2, z2)
         one_kernel = N >= 4096 and hasattr(qb, "w4t_f16") and _NODE_ONE_KERNEL     # data + weight + bias gradient of a 128 x 128 Linear in one kernel
         am = torch.zeros(2, 256, device=dev, dtype=torch.float32) if one_kernel else None     # block maxima of |dz2|, |dz1| from the Swish backward
         dz2 = ops.swish_bwd(dg, z2, t1, amax=am[0] if one_kernel else None)
@@ -193,6 +198,7 @@ def backward_call(m, tape, dout, G, ws):
 
     # ---- embedding MLP                                                                mpnn.py:131-136
     lin(N, ops.ktiles(T(nin, kin)), P.emb[0], z1)
+    r1, z2 = r1_buf, z2_buf
     ops.swish_fwd(z1, r1)
     lin(N, ops.ktiles(T(r1, H)), P.emb[1], z2)
     dz2 = ops.swish_bwd(dh, z2, t1)
