@@ -437,6 +437,12 @@ int magnet_mpnn_edge_bwd_w_f32(const float* A, const float* Bm, const float* dag
                                const int32_t* rowptr, int n_nodes, int n_edges, const void* w2_f16, const void* w2t_f16,
                                const float* b2, float* dp, float* dA, float* partials, float* dW2, float* db2, int accumulate,
                                float* workspace, void* stream);
+/* the same with the block maxima of |dagg| handed in (amax_in [n_amax_in]: the amax_out of the magnet_linear_bwd128_f32 call that
+ * produced dagg; NULL: computed here with a pass over dagg) */
+int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src, const int32_t* tgt,
+                                    const int32_t* rowptr, int n_nodes, int n_edges, const void* w2_f16, const void* w2t_f16,
+                                    const float* b2, float* dp, float* dA, float* partials, float* dW2, float* db2, int accumulate,
+                                    float* workspace, const float* amax_in, int n_amax_in, void* stream);
 
 /* Weight packing on the device (magnet_amd/packing.py: the same layouts as torch index shuffles; no reference counterpart - the
  * reference hands its nn.Linear weights to cuBLAS as they are).  Padded position (r, c) of the [np x kp] matrix takes

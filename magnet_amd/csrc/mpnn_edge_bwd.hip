@@ -639,10 +639,25 @@ extern "C" int magnet_mpnn_edge_bwd_w_workspace(void) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
     return ncu * (128 * 128 + 128) + EBW_AMAX_BLOCKS;
 }
+extern "C" int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src,
+                                               const int32_t* tgt, const int32_t* rowptr, int n_nodes, int n_edges,
+                                               const void* w2_f16, const void* w2t_f16, const float* b2, float* dp, float* dA,
+                                               float* partials, float* dW2, float* db2, int accumulate, float* workspace,
+                                               const float* amax_in, int n_amax_in, void* stream);
 extern "C" int magnet_mpnn_edge_bwd_w_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src,
                                           const int32_t* tgt, const int32_t* rowptr, int n_nodes, int n_edges,
                                           const void* w2_f16, const void* w2t_f16, const float* b2, float* dp, float* dA,
                                           float* partials, float* dW2, float* db2, int accumulate, float* workspace, void* stream) {
+    return magnet_mpnn_edge_bwd_w_amax_f32(A, Bm, dagg, src, tgt, rowptr, n_nodes, n_edges, w2_f16, w2t_f16, b2, dp, dA, partials, dW2, db2,
+                                           accumulate, workspace, nullptr, 0, stream);
+}
+// amax_in != NULL: n_amax_in block maxima of |dagg| left by the kernel that produced it (magnet_linear_bwd128_f32's amax_out) - no
+// maxima pass over dagg here
+extern "C" int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src,
+                                               const int32_t* tgt, const int32_t* rowptr, int n_nodes, int n_edges,
+                                               const void* w2_f16, const void* w2t_f16, const float* b2, float* dp, float* dA,
+                                               float* partials, float* dW2, float* db2, int accumulate, float* workspace,
+                                               const float* amax_in, int n_amax_in, void* stream) {
     (void)hipGetLastError();
     if (n_nodes <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -661,8 +676,13 @@ extern "C" int magnet_mpnn_edge_bwd_w_f32(const float* A, const float* Bm, const
         float* bpart = wpart + (size_t)ncu * 128 * 128;
         float* amax = bpart + (size_t)ncu * 128;
         const long n4 = (long)n_nodes * 32;
-        const int nab = (int)min((long)EBW_AMAX_BLOCKS, (n4 + 255) / 256);
-        hipLaunchKernelGGL(k_absmax_partial, dim3(nab), dim3(256), 0, s, dagg, n4, amax);
+        int nab = (int)min((long)EBW_AMAX_BLOCKS, (n4 + 255) / 256);
+        if (amax_in) {
+            amax = const_cast<float*>(amax_in);
+            nab = n_amax_in;
+        } else {
+            hipLaunchKernelGGL(k_absmax_partial, dim3(nab), dim3(256), 0, s, dagg, n4, amax);
+        }
         const u32x4* w = reinterpret_cast<const u32x4*>(w2_f16);
         const u32x4* wT = reinterpret_cast<const u32x4*>(w2t_f16);
         hipLaunchKernelGGL(k_mpnn_edge_bwd_w, dim3(grid), dim3(256), 0, s, A, Bm, dagg, src, tgt, rowptr, n_edges, w, wT, b2, dp, dA,

@@ -159,14 +159,16 @@ def backward_call(m, tape, dout, G, ws):
         ops.wgrad(dz1, tp.h_in, 0, H, g.w3, 0, g.b3, ws)
         ops.wgrad(dz1, nin, 0, kin, g.w3, 2 * H, None, ws)
         if one_kernel:                                                   # dagg = dz1 W3[:, agg block], dW3[:, agg block] += dz1^T agg
-            ops.linear_bwd128(dz1, tp.agg, qb.daggt_f16, dagg, lbw[1], lbw[2], lbw[0], mask=False, want_amax=False, amax_in=(am[1], 256))
+            dagg_amax = ops.linear_bwd128(dz1, tp.agg, qb.daggt_f16, dagg, lbw[1], lbw[2], lbw[0], mask=False, amax_in=(am[1], 256))
             ops.copy_cols(lbw[1], 0, g.w3, H, H, accumulate=True)
         else:
+            dagg_amax = None
             ops.wgrad(dz1, tp.agg, 0, H, g.w3, H, None, ws)
             lin(N, ops.ktiles(T(dz1, H)), qb.dagg, dagg)
         # ---- mean aggregation + message MLP at edge granularity                      mpnn.py:73-79, :46
         if E > 0 and fused_w:
-            ops.mpnn_edge_bwd_w(tp.A, tp.Bm, dagg, csr, qb.w2_f16[0], qb.w2t_f16[0], qb.w2_f16[1], d2, dA, partials, g.w2, g.b2, ews)
+            ops.mpnn_edge_bwd_w(tp.A, tp.Bm, dagg, csr, qb.w2_f16[0], qb.w2t_f16[0], qb.w2_f16[1], d2, dA, partials, g.w2, g.b2, ews,
+                                amax_in=dagg_amax)
             ops.segment_sum128(d2, bs.rowptr, N, perm=bs.perm, out=dBm)
         elif E > 0 and fused:
             ops.mpnn_edge_bwd(tp.A, tp.Bm, dagg, csr, qb.w2_f16[0], qb.w2t_f16[0], qb.w2_f16[1], sp, d1, d2, dA, partials)
