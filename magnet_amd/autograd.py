@@ -6,12 +6,18 @@ only chains them and differentiates the data movement in between (``cat`` / ``pe
 keeps the rollout feedback (``models/magnet_gnn.py:442-475``) differentiable without bespoke glue.
 
 ``mlp`` is the workhorse: the fused gather/concat -> N x (Linear + ReLU) -> [LayerNorm] -> store | +residual | CSR-mean
-kernel.  Its forward is the inference kernel, unchanged.  Its backward recomputes the chain layer by layer (one-Linear
-launches of the same kernel, activations materialised), then walks it back: LayerNorm backward, weight gradients with
-``magnet_wgrad_n_f32`` (fp32 MFMA, fixed-order reduction), data gradients with transposed packs in the bf16x6 split
-(full fp32 exponent range for ~1e-7 gradients), ReLU masks, and finally the scatter-add of the first-layer input
-gradient back through every gathered / concatenated / differenced source (``magnet_segment_sum_cols_f32`` over the
-inverse CSR of the gather index).  Correctness-first: nothing here is fused yet.
+kernel.  Its forward is the inference kernel; when the backward's tape (assembled first-layer input, hidden activations,
+pre-LayerNorm output) fits in memory the same launch writes it (``_keep_tape``), else the backward recomputes the chain with one
+tape-only launch.  The backward then walks the chain back:
+
+* LayerNorm backward (``magnet_layernorm_bwd_amax_f32``: 16-byte accesses, gathers dy[tgt] / deg itself behind a CSR mean, leaves the
+  block maxima of its output for the next kernel);
+* hidden W -> W Linears (W = 128 / 64) over many rows in ONE kernel each - data gradient, ReLU mask, weight and bias gradient
+  (``ops.linear_bwd128``); other Linears: a backward-data GEMM with transposed packs in the bf16x6 split (full fp32 exponent range
+  for ~1e-7 gradients) with the ReLU mask in its epilogue + ``magnet_wgrad_tiles_f32``, equal-width column blocks in one launch;
+* the first Linear: k tiles that are pure row gathers are walked back at source-row granularity (dz summed over each source row's
+  gatherers first, ``_first_layer_at_source_rows``), the rest at row granularity followed by the scatter-add through the gathers
+  (``magnet_segment_sum_cols_f32`` / ``_runs_f32`` over the inverse CSR of each gather index, a column copy for dense sources).
 """
 from __future__ import annotations
 
