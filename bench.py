@@ -528,7 +528,7 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
         if Wq == 256 and B == 1 and mode in SPLIT_PRODUCTS:      # the recorded PMC passes are of this exact workload
             roof["traffic"], roof["traffic_source"] = measured_traffic(f"{name}:edge_mlp")
     # ---- training step (autograd Functions with HIP backward kernels, one gradient all-reduce, fused Adam) - unfused,
-    # correctness-first path; reported beside the rollout, never mixed into `value`
+    # the training step; reported beside the rollout, never mixed into `value`
     train = None
     if train_steps > 0:
         from magnet_amd.sharding import allreduce_gradients
@@ -552,7 +552,7 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
         t_el = max_over_ranks(time.perf_counter() - t0, dev)
         train = {"ms_per_step": round(t_el / train_steps * 1e3, 3), "steps": train_steps, "warmup": 1,
                  "value": world * B * nodes * pred_steps * train_steps / t_el, "unit": "mesh-node-updates/s",
-                 "what": "rollout through autograd Functions (HIP forward + backward kernels, unfused) + one gradient all-reduce + fused Adam",
+                 "what": "rollout through autograd Functions (HIP forward + backward kernels; hidden Linears walked back in one kernel, first Linear at source-row granularity, tape kept in HBM when it fits) + one gradient all-reduce + fused Adam",
                  "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],
                  "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
         del tmodel, opt, last, train_step

@@ -16,9 +16,15 @@ Gradients are accumulated in the padded layouts the kernels use and mapped to th
 calls on the value ``training_step`` returns - fills ``.grad`` exactly as it does for the reference.
 
 Arithmetic: backward-data GEMMs run in the ``bwd_gemm`` mode (default "bf16x6": exact 3-piece bf16 split, fp32
-exponent range - gradients of a mean loss are ~1e-7 and would fall into fp16's subnormals, so the 2-piece fp16
-split of the forward is not used here); weight gradients use fp32 MFMA with a fixed-order two-stage reduction
-(deterministic).
+exponent range - gradients of a mean loss are ~1e-7 and would fall into fp16's subnormals); weight gradients on the bf16
+matrix cores through the same split with a fixed-order two-stage reduction (deterministic).  Where a gradient goes through
+the fp16 split after all it is scaled by an exact power of two first: per row in the data GEMMs of the fused kernels, per
+launch (from block maxima handed from kernel to kernel) where it is an operand of a weight gradient.
+
+Round 3: the edge block's backward also forms message_net_2's weight / bias gradient
+(``ops.mpnn_edge_bwd_w``: s1 and dq never reach memory); on large graphs update_net_2 and the agg block of update_net_1 are
+walked back by ``ops.linear_bwd128`` (data + weight + bias gradient in one kernel), and the forward launch keeps the update
+net's hidden activation and raw output.
 """
 from __future__ import annotations
 
