@@ -454,6 +454,31 @@ def test_differentiable_fused_mlp_with_the_one_kernel_layer_backward(hidden, D, 
     assert fact == ([2 * (128 if hidden == 128 else 32) // 32] if epi == "segmean" else []), fact
 
 
+@pytest.mark.parametrize("hidden,D,epi", [(128, 128, "segmean"), (64, 32, "segmean"), (128, 1, "store")])
+def test_gradients_do_not_depend_on_whether_the_tape_was_kept_or_recomputed(hidden, D, epi, monkeypatch):
+    """the forward launch writing the backward's tape (MAGNET_KEEP_TAPE=1) and the backward recomputing it (=0) give bitwise the same
+    gradients (the same kernel code produces the same arrays), with and without the one-kernel layer backward"""
+    from magnet_amd import autograd as AG
+    grads = {}
+    for rows in (1 << 30, 1):
+        monkeypatch.setattr(AG, "_FUSED_LAYER_ROWS", rows)
+        for keep in ("1", "0"):
+            monkeypatch.setenv("MAGNET_KEEP_TAPE", keep)
+            seen = []
+            orig = AG._Mlp.backward
+
+            def spy(ctx, dy, _orig=orig, _seen=seen):
+                out = _orig(ctx, dy)
+                _seen.append([g.clone() for g in out if torch.is_tensor(g)])
+                return out
+            monkeypatch.setattr(AG._Mlp, "backward", staticmethod(spy))
+            test_differentiable_fused_mlp_matches_torch_autograd(hidden, D, epi)
+            monkeypatch.setattr(AG._Mlp, "backward", staticmethod(orig))
+            grads[(rows, keep)] = seen[0]
+        a, b = grads[(rows, "1")], grads[(rows, "0")]
+        assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+
+
 @pytest.mark.parametrize("teacher_forcing", [False, True])
 def test_magnet_gnn_training_step_gradients(teacher_forcing):
     """MAgNet[GNN] training_step (BASELINE.json configs[4]): loss.backward() through the HIP autograd Functions.
