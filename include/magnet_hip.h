@@ -109,6 +109,13 @@ int magnet_mlp_bf16x6_f32(const magnet_mlp_args_t* args, int nl, int ht, int ot,
  * layer[l].w: planes [kt][nt][m][2][64 lanes][8 fp16] (magnet_amd/packing.py:pack_linear_fp16x2). */
 int magnet_mlp_fp16x3_f32(const magnet_mlp_args_t* args, int nl, int ht, int ot, int act, int last_act, int ln, int epi,
                           void* stream);
+/* The same three fp16 products in ONE accumulator per output block (no cross accumulator to zero and fold: fewer VALU instructions
+ * and registers per layer): layer[l].w = the fp16x3 planes with the HIGH plane times 2^11, layer[l].b = 2^11 b
+ * (packing mode "fp16x3s", |w| < 31.98), the activation's low piece is the unscaled fp16 remainder.  Instantiated for the 5-Linear
+ * chains (models/backbones/mlp.py:9-28 with mlp_layers = 4) only: -3 for any other shape, magnet_mlp_fp16x3s_supported says which. */
+int magnet_mlp_fp16x3s_f32(const magnet_mlp_args_t* args, int nl, int ht, int ot, int act, int last_act, int ln, int epi,
+                           void* stream);
+int magnet_mlp_fp16x3s_supported(int nl, int ht, int ot, int act, int last_act, int ln, int epi);
 /* REDUCED precision, opt-in (BASELINE.json config 2 "bf16"): inputs and weights rounded to ONE bf16 piece (RNE), one MFMA
  * product, fp32 accumulate; ~1e-2 relative deviation from the fp32 result.  layer[l].w: one bf16 plane
  * [kt][nt][m][1][64 lanes][8 bf16] (packing.py:pack_linear_bf16x1). */

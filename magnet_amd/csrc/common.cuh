@@ -290,7 +290,7 @@ __device__ __forceinline__ f32x16 mma_split6(bf16x8 wh, bf16x8 wm, bf16x8 wl, bf
 // post-norm hidden state on this path); bf16x6 has the full fp32 range and remains selectable.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
-enum { GEMM_BF16X6 = 0, GEMM_FP16X3 = 1, GEMM_BF16 = 2 };
+enum { GEMM_BF16X6 = 0, GEMM_FP16X3 = 1, GEMM_BF16 = 2, GEMM_FP16X3S = 3 };
 
 template <int MODE>
 struct Split;
@@ -345,6 +345,50 @@ struct Split<GEMM_FP16X3> {
     static __device__ __forceinline__ void fold(f32x16& accM, const f32x16& accC) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) accM[i] = fmaf(accC[i], 1.0f / 2048.0f, accM[i]);
+    }
+};
+
+// "fp16x3s": the same three products in ONE accumulator (the arithmetic of split_single.cuh / k_mpnn_edge32t).  The
+// weight planes are (2^11 hw, 2^11 lw) - packing mode "fp16x3s" scales the high plane and the bias on the way in, |w| < 31.98 -
+// and the activation's low piece is the UNSCALED fp16 remainder (an fp16 subnormal below |x| ~ 0.12, which the MFMA keeps: absolute
+// error 2^-25 per value), so all three products carry 2^11 and a layer ends with one multiply by 2^-11 instead of
+// "zero the cross accumulator, fold it in": per value and layer 1 (descale) + 1.5 (split: cvt_pkrtz per pair, one mixed-precision
+// fma per value) VALU instructions against 1 + 1 + 2.5, and NT x 16 fewer registers.
+template <>
+struct Split<GEMM_FP16X3S> {
+    static constexpr int NP = 2;
+    static __device__ __forceinline__ void quarter(const f32x16& tile, int m, int p, u32x4 (&planes)[2]) {
+        const float a0 = tile[8 * m + 2 * p], a1 = tile[8 * m + 2 * p + 1];
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a0, a1));
+        unsigned l;
+        // l = fp16_rne(a - h): the difference is exact inside the fma (h is a truncation of a), one rounding into the plane word
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a0));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(a1));
+        planes[0][p] = h;
+        planes[1][p] = l;
+    }
+    static __device__ __forceinline__ void mma(const u32x4 (&w)[2], const u32x4 (&x)[2], f32x16& accM, f32x16&) {
+        const f16x8 wh = __builtin_bit_cast(f16x8, w[0]), wl = __builtin_bit_cast(f16x8, w[1]);
+        const f16x8 xh = __builtin_bit_cast(f16x8, x[0]), xl = __builtin_bit_cast(f16x8, x[1]);
+        accM = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, accM, 0, 0, 0);
+        accM = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accM, 0, 0, 0);
+        accM = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, accM, 0, 0, 0);
+    }
+    // two output blocks at a time: consecutive MFMAs never write the same accumulator
+    static __device__ __forceinline__ void mma2(const u32x4 (&w0)[2], const u32x4 (&w1)[2], const u32x4 (&x)[2], f32x16& a0, f32x16& a1) {
+        const f16x8 w0h = __builtin_bit_cast(f16x8, w0[0]), w0l = __builtin_bit_cast(f16x8, w0[1]);
+        const f16x8 w1h = __builtin_bit_cast(f16x8, w1[0]), w1l = __builtin_bit_cast(f16x8, w1[1]);
+        const f16x8 xh = __builtin_bit_cast(f16x8, x[0]), xl = __builtin_bit_cast(f16x8, x[1]);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0l, xh, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l, xh, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h, xl, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, xl, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h, xh, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, xh, a1, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void fold(f32x16& accM, const f32x16&) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accM[i] *= 1.0f / 2048.0f;
     }
 };
 

@@ -48,6 +48,46 @@ __device__ __forceinline__ void wait_all_but_one_chunk() {
 template <int NT, int MODE, bool PIPE>
 __device__ __forceinline__ void mma_chunk(const f32x16& x, f32x16 (&accM)[NT], f32x16 (&accC)[NT], const u32x4* wl, int lane) {
     constexpr int NP = Split<MODE>::NP;
+    if constexpr (MODE == GEMM_FP16X3S && NT % 2 == 0) {
+        // one accumulator per output block: the blocks are taken in pairs so that consecutive MFMAs write different accumulators
+        using S = Split<GEMM_FP16X3S>;
+        constexpr int NPR = NT / 2, NG = 2 * NPR;          // groups gq = m * NPR + pair
+        if (!PIPE) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                u32x4 xs[2];
+                split_slot<MODE>(x, m, xs);
+#pragma unroll
+                for (int pr = 0; pr < NPR; ++pr) {
+                    u32x4 w0[2], w1[2];
+                    const u32x4* wp = wl + (((2 * pr) * 2 + m) * 2) * 64 + lane;
+                    w0[0] = wp[0]; w0[1] = wp[64]; w1[0] = wp[4 * 64]; w1[1] = wp[5 * 64];
+                    S::mma2(w0, w1, xs, accM[2 * pr], accM[2 * pr + 1]);
+                }
+            }
+            return;
+        }
+        u32x4 xs[2][2], wr[2][2][2];
+        auto wload = [&](int gq) {
+            const int m = gq / NPR, pr = gq % NPR;
+            const u32x4* wp = wl + (((2 * pr) * 2 + m) * 2) * 64 + lane;
+            wr[gq & 1][0][0] = wp[0]; wr[gq & 1][0][1] = wp[64]; wr[gq & 1][1][0] = wp[4 * 64]; wr[gq & 1][1][1] = wp[5 * 64];
+        };
+        split_slot<MODE>(x, 0, xs[0]);
+        wload(0);
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            const int m = gq / NPR, pr = gq % NPR;
+            if (gq + 1 < NG) wload(gq + 1);
+            if (m == 0) {
+#pragma unroll
+                for (int p = pr * 4 / NPR; p < (pr + 1) * 4 / NPR; ++p) S::quarter(x, 1, p, xs[1]);
+            }
+            S::mma2(wr[gq & 1][0], wr[gq & 1][1], xs[m], accM[2 * pr], accM[2 * pr + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
     if (!PIPE) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -93,7 +133,7 @@ __device__ __forceinline__ void mma_chunk(const f32x16& x, f32x16 (&accM)[NT], f
 }
 template <int NT, int MODE>
 __device__ __forceinline__ void fold_tiles(f32x16 (&accM)[NT], f32x16 (&accC)[NT]) {
-    if (MODE == GEMM_FP16X3) {
+    if (MODE == GEMM_FP16X3 || MODE == GEMM_FP16X3S) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) Split<MODE>::fold(accM[n], accC[n]);
     }
@@ -180,13 +220,13 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
             // accumulator's initial value and pre[1] the cross accumulator's (scaled by 2^11 after it has landed: the fold divides it
             // out again) - pure loads issued here, first touched after the first barrier, instead of 2 x 16 gathered loads that the
             // wave waited for between the first layer and its activation
-            const bool pre_init = NL > 1 && MODE == GEMM_FP16X3 && a.pre[0].p && a.pre[1].p;
+            const bool pre_init = NL > 1 && (MODE == GEMM_FP16X3 || MODE == GEMM_FP16X3S) && a.pre[0].p && a.pre[1].p;
             if (pre_init) {
                 load_rows<NT0>(acc, a.pre[0], row, half);
                 load_rows<NT0>(accc, a.pre[1], row, half);
             } else {
-                init_bias<NT0>(acc, l0.b, half);
-                zero_tiles<NT0>(accc);
+                init_bias<NT0>(acc, l0.b, half);                            // (fp16x3s: the pack holds 2^11 b)
+                if (MODE != GEMM_FP16X3S) zero_tiles<NT0>(accc);
             }
             KRaw xr = ktile_raw(a.kt[0], ktile_rows(a.kt[0], row), half);
             KRows rn = ktile_rows(a.kt[a.nkt > 1 ? 1 : 0], row);          // indices of k tile 1, requested one iteration early
@@ -205,7 +245,10 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
 #pragma unroll
                     for (int t = 0; t < NT0; ++t)
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) accc[t][q] *= 2048.0f;
+                        for (int q = 0; q < 16; ++q) {
+                            if (MODE == GEMM_FP16X3S) acc[t][q] = (acc[t][q] + accc[t][q]) * 2048.0f;   // the one accumulator starts from both rows
+                            else accc[t][q] *= 2048.0f;
+                        }
                 }
                 // raw loads of x tile kt+1 (its indices arrived during the previous iteration), indices of x tile kt+2, then
                 // chunk c+2: the next iteration's counted wait then covers both
@@ -244,7 +287,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
             const bool last = (l == NL - 1);
             const bool src0 = (l & 1);                     // odd layers read h0, even layers read h1
             f32x16 cc[NTMAX];
-            zero_tiles<NTMAX>(cc);
+            if (MODE != GEMM_FP16X3S) zero_tiles<NTMAX>(cc);
             f32x16(&cco)[OT] = reinterpret_cast<f32x16(&)[OT]>(cc);
             f32x16(&cch)[HT] = reinterpret_cast<f32x16(&)[HT]>(cc);
             if (last) init_bias<OT>(out, a.layer[l].b, half);
@@ -363,6 +406,7 @@ typedef void (*mlp_fn)(const MagnetMlpArgs);
 template <int MODE>
 static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int epi, bool small = false) {
     mlp_fn fn = nullptr;
+    if constexpr (MODE != GEMM_FP16X3S) {                  // (the one-accumulator mode is instantiated for 5-Linear chains only ...)
     MLP_CASE(2, 4, 4, ACT_SWISH, true, false, EPI_STORE)
     MLP_CASE(2, 4, 4, ACT_SWISH, true, false, EPI_STORE_RES)
     MLP_CASE(1, 4, 4, ACT_NONE, false, false, EPI_STORE)
@@ -379,10 +423,12 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
     MLP_CASE(1, 4, 4, ACT_NONE, false, false, EPI_STORE_MASK)
     MLP_CASE(1, 2, 2, ACT_NONE, false, false, EPI_STORE_MASK)
     MLP_CASE(1, 1, 1, ACT_NONE, false, false, EPI_STORE_MASK)
+    // (... and there for the 64-wide ones: the 128-wide chains stay at two waves per SIMD either way and take the same time)
     MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_STORE)
     MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_STORE_RES)
     MLP_CASE(5, 4, 4, ACT_RELU, false, true, EPI_SEGMEAN)
     MLP_CASE(5, 4, 1, ACT_RELU, false, false, EPI_STORE)
+    }
     MLP_CASE(5, 2, 1, ACT_RELU, false, true, EPI_STORE)
     MLP_CASE(5, 2, 1, ACT_RELU, false, true, EPI_STORE_RES)
     MLP_CASE(5, 2, 1, ACT_RELU, false, true, EPI_SEGMEAN)
@@ -390,6 +436,7 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
     MLP_CASE(5, 2, 2, ACT_RELU, false, true, EPI_STORE)
     MLP_CASE(5, 2, 4, ACT_RELU, false, true, EPI_STORE)
     MLP_CASE(5, 2, 4, ACT_RELU, false, true, EPI_QUADBLEND)
+    if constexpr (MODE != GEMM_FP16X3S) {
     // single Linear + LayerNorm (+ residual / CSR mean / quad blend): the LAST layer of a chain with mlp_layers != 4, whose hidden layers run as
     // one-Linear launches (magnet_amd/ops.py:_mlp_by_layers; models/backbones/mlp.py:9-28 is generic in its depth)
     MLP_CASE(1, 4, 4, ACT_NONE, false, true, EPI_STORE)
@@ -403,6 +450,7 @@ static mlp_fn pick(int nl, int ht, int ot, int act, int last_act, int ln, int ep
     MLP_CASE_SMALL(2, 4, 4, ACT_SWISH, true, false, EPI_STORE)
     MLP_CASE_SMALL(2, 4, 4, ACT_SWISH, true, false, EPI_STORE_RES)
     MLP_CASE_SMALL(1, 4, 4, ACT_NONE, false, false, EPI_STORE)
+    }
     return fn;
 }
 
@@ -1047,6 +1095,20 @@ extern "C" int magnet_mlp_fp16x3_f32(const MagnetMlpArgs* args, int nl, int ht, 
     if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
     if (args->ncolgroups > 1 && (nl != 1 || args->ncolgroups > MAGNET_MAX_LAYERS)) return -2;
     return launch_mlp(pick<GEMM_FP16X3>(nl, ht, ot, act, last_act, ln, epi, args->M <= SMALL_M), args, stream);
+}
+
+// the 5-Linear chains with ONE accumulator per output block (Split<GEMM_FP16X3S>, common.cuh): layer[l].w / .b from packing mode
+// "fp16x3s" (high plane and bias times 2^11).  Returns -3 for any other chain shape.
+extern "C" int magnet_mlp_fp16x3s_f32(const MagnetMlpArgs* args, int nl, int ht, int ot, int act, int last_act, int ln,
+                                      int epi, void* stream) {
+    (void)hipGetLastError();
+    if (!args || args->M <= 0) return args && args->M == 0 ? 0 : -1;
+    if (args->nkt < 1 || args->nkt > MAGNET_MAX_KT) return -2;
+    if (args->ncolgroups > 1) return -2;
+    return launch_mlp(pick<GEMM_FP16X3S>(nl, ht, ot, act, last_act, ln, epi, false), args, stream);
+}
+extern "C" int magnet_mlp_fp16x3s_supported(int nl, int ht, int ot, int act, int last_act, int ln, int epi) {
+    return pick<GEMM_FP16X3S>(nl, ht, ot, act, last_act, ln, epi, false) != nullptr;
 }
 
 #ifdef MAGNET_DEV_VARIANTS

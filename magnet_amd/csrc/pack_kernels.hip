@@ -8,7 +8,7 @@
 #include "common.cuh"
 
 namespace {
-enum { PACK_FP32 = 0, PACK_FP16X2 = 1, PACK_BF16X3 = 2, PACK_BF16X1 = 3 };
+enum { PACK_FP32 = 0, PACK_FP16X2 = 1, PACK_BF16X3 = 2, PACK_BF16X1 = 3, PACK_FP16X2S = 4 };   // 4: fp16x3s - high plane and bias times 2^11
 
 struct PackSrc {
     const float* w;
@@ -36,7 +36,7 @@ __device__ __forceinline__ unsigned short bf16_rne_bits(float x) {
 template <int MODE>
 __global__ void __launch_bounds__(256) k_pack16(PackSrc s, int NT, int KT, unsigned short* __restrict__ out, int* __restrict__ status,
                                                 int range_bit) {
-    constexpr int NP = MODE == PACK_FP16X2 ? 2 : (MODE == PACK_BF16X3 ? 3 : 1);
+    constexpr int NP = (MODE == PACK_FP16X2 || MODE == PACK_FP16X2S) ? 2 : (MODE == PACK_BF16X3 ? 3 : 1);
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)KT * NT * 2 * 64;
     if (t >= total) return;
@@ -53,6 +53,11 @@ __global__ void __launch_bounds__(256) k_pack16(PackSrc s, int NT, int KT, unsig
             bad |= !(fabsf(v) < 65504.0f);                                  // also catches NaN / inf
             const _Float16 hv = (_Float16)v;
             pl[0][e] = __builtin_bit_cast(unsigned short, hv);
+            pl[1][e] = f2h_bits((v - (float)hv) * 2048.0f);
+        } else if (MODE == PACK_FP16X2S) {
+            bad |= !(fabsf(v) < 31.98f);                                    // 2^11 hw has to stay below the fp16 maximum
+            const _Float16 hv = (_Float16)v;
+            pl[0][e] = f2h_bits((float)hv * 2048.0f);                       // exact: a power of two, in range
             pl[1][e] = f2h_bits((v - (float)hv) * 2048.0f);
         } else if (MODE == PACK_BF16X3) {
             const unsigned u = __builtin_bit_cast(unsigned, v);
@@ -75,7 +80,7 @@ __global__ void __launch_bounds__(256) k_pack16(PackSrc s, int NT, int KT, unsig
         for (int q = 0; q < 4; ++q) w4[q] = (unsigned)pl[p][2 * q] | ((unsigned)pl[p][2 * q + 1] << 16);
         *reinterpret_cast<u32x4*>(out + ((((tile * 2 + m) * NP + p) * 64 + lane) * 8)) = w4;
     }
-    if (MODE == PACK_FP16X2 && status && bad) atomicOr(status, range_bit);
+    if ((MODE == PACK_FP16X2 || MODE == PACK_FP16X2S) && status && bad) atomicOr(status, range_bit);
 }
 
 // fp32 fragments [kt][nt][g][lane 64][4]:  W[nt*32 + (lane & 31)][kt*32 + 8 g + 4 (lane >> 5) + c]
@@ -92,9 +97,9 @@ __global__ void __launch_bounds__(256) k_pack32(PackSrc s, int NT, int KT, float
     *reinterpret_cast<f32x4*>(out + t * 4) = v;
 }
 
-__global__ void k_pad_bias(const float* __restrict__ b, int n, int np, float* __restrict__ out) {
+__global__ void k_pad_bias(const float* __restrict__ b, int n, int np, float scale, float* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < np) out[i] = (b && i < n) ? b[i] : 0.f;
+    if (i < np) out[i] = (b && i < n) ? b[i] * scale : 0.f;
 }
 }  // namespace
 
@@ -116,8 +121,9 @@ extern "C" int magnet_pack_linear_f32(const float* w, long stride_r, long stride
         if (mode == PACK_FP16X2) hipLaunchKernelGGL(k_pack16<PACK_FP16X2>, g, b, 0, st, s, NT, KT, o, status, range_bit);
         else if (mode == PACK_BF16X3) hipLaunchKernelGGL(k_pack16<PACK_BF16X3>, g, b, 0, st, s, NT, KT, o, status, range_bit);
         else if (mode == PACK_BF16X1) hipLaunchKernelGGL(k_pack16<PACK_BF16X1>, g, b, 0, st, s, NT, KT, o, status, range_bit);
+        else if (mode == PACK_FP16X2S) hipLaunchKernelGGL(k_pack16<PACK_FP16X2S>, g, b, 0, st, s, NT, KT, o, status, range_bit);
         else return -2;
     }
-    if (bias_out) hipLaunchKernelGGL(k_pad_bias, dim3((np + 255) / 256), dim3(256), 0, st, bias, n_bias, np, bias_out);
+    if (bias_out) hipLaunchKernelGGL(k_pad_bias, dim3((np + 255) / 256), dim3(256), 0, st, bias, n_bias, np, mode == PACK_FP16X2S ? 2048.0f : 1.0f, bias_out);
     return (int)hipGetLastError();
 }

@@ -5,7 +5,7 @@ from __future__ import annotations
 
 from torch import nn
 
-from ...packing import default_gemm, pack, pad_to
+from ...packing import chain_gemm, default_gemm, pack, pad_to
 
 
 class MLP(nn.Module):
@@ -27,8 +27,8 @@ class MLP(nn.Module):
         return [m for m in self.layers if isinstance(m, nn.Linear)]
 
     def packed(self, k_pad=None, col_map=None, mode=None):
-        mode = mode or default_gemm()
         lins = self.linears()
+        mode = chain_gemm(len(lins), self.hidden, mode or default_gemm())
         out = [pack(lins[0].weight, lins[0].bias, mode, k_pad=k_pad or pad_to(self.in_dim), col_map=col_map)]
         out += [pack(l.weight, l.bias, mode) for l in lins[1:]]
         return out

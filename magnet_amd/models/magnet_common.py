@@ -79,16 +79,17 @@ def pack_interaction_edge(seq, D):
     are computed once per NODE by a single-Linear launch and gathered into the chain's first pre-activation (magnet_hip.h:
     magnet_mlp_args_t.pre): the first layer of the edge chain does a third of its flops and reads D instead of 3 D columns
     per edge - the factorisation SURVEY.md 7 (step 4) names, as for MPNN's message_net_1."""
-    from ..packing import default_gemm, pack
+    from ..packing import chain_gemm, default_gemm, pack
     mlp, ln = seq[0], seq[1]
     lins = mlp.linears()
     mode = default_gemm()
+    cmode = chain_gemm(len(lins), mlp.hidden, mode)                     # the chain's own Linears (the per-node products run the node kernels)
     W0 = lins[0].weight.detach()
     assert W0.shape[1] == 3 * D and D % 32 == 0
     # b0 travels with the receiver's product (the chain kernel starts its first accumulator FROM the gathered row, magnet_hip.h: pre);
     # `e_scale` = 2^k of hop k (Q2: e_k = 2^k e_0) is folded into W0c - a power of two, exact - so that the kernel loads e_0 unscaled
     def chain_for(e_scale):
-        layers = [pack(W0[:, 2 * D:] * float(e_scale), None, mode)] + [pack(l.weight, l.bias, mode) for l in lins[1:]]
+        layers = [pack(W0[:, 2 * D:] * float(e_scale), None, cmode)] + [pack(l.weight, l.bias, cmode) for l in lins[1:]]
         return types.SimpleNamespace(layers=layers, ln=(ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps),
                                      ht=mlp.hidden // 32, ot=pad_to(mlp.out_dim) // 32, out_dim=mlp.out_dim, col_map=None)
     return chain_for, pack(W0[:, :D], lins[0].bias, mode), pack(W0[:, D:2 * D], None, mode)

@@ -8,6 +8,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib as L
+from .packing import SinglePlanes
 from ._lib import ACT_NONE, ACT_RELU, ACT_SWISH, EPI_QUADBLEND, EPI_SEGMEAN, EPI_STORE, EPI_STORE_MASK, EPI_STORE_RES  # noqa: F401
 
 
@@ -140,6 +141,10 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
     assert all(w.dtype == kind for w, _ in layers)
     name = {torch.float16: "magnet_mlp_fp16x3_f32", torch.int16: "magnet_mlp_bf16x6_f32", torch.float32: "magnet_mlp_f32",
             torch.bfloat16: "magnet_mlp_bf16_f32"}[kind]
+    single = [isinstance(w, SinglePlanes) for w, _ in layers]
+    if any(single):                                            # packing mode "fp16x3s": the one-accumulator chain kernel
+        assert all(single) and colgroups == 1
+        name = "magnet_mlp_fp16x3s_f32"
     fn = getattr(L.lib(), name)
     ref = C.byref(a)
     what = f"{name}(nl={nl},ht={ht},ot={ot},act={act},ln={ln is not None},epi={epi})"
@@ -154,6 +159,10 @@ def mlp(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STO
         res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0, pre=None,
         x0_out=None, hid=None, x0_skip=0):
     """Run the fused MLP kernel.  ``layers``: list of (packed_w, padded_b).  Returns y."""
+    if isinstance(layers[0][0], SinglePlanes) and not L.lib().magnet_mlp_fp16x3s_supported(
+            nl, ht, ot, act, int(last_act), int(ln is not None), epi):
+        raise NotImplementedError(f"no one-accumulator chain kernel for (nl={nl}, ht={ht}, ot={ot}, ln={ln is not None}, epi={epi}): "
+                                  "set MAGNET_CHAIN_GEMM=fp16x3")
     if nl > 1 and colgroups == 1 and not L.lib().magnet_mlp_supported(nl, ht, ot, act, int(last_act), int(ln is not None),
                                                                        EPI_STORE if epi == EPI_QUADBLEND else epi):
         return _mlp_by_layers(M, kts, layers, nl=nl, ht=ht, ot=ot, act=act, last_act=last_act, ln=ln, epi=epi, y=y, ldy=ldy,

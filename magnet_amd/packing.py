@@ -188,6 +188,28 @@ def pack_linear_bf16x1(w: torch.Tensor, b: torch.Tensor | None, k_pad: int | Non
 GEMM_MODES = ("fp16x3", "bf16x6", "fp32", "bf16")
 
 
+class SinglePlanes(torch.Tensor):
+    """fp16 planes of packing mode "fp16x3s" (high plane and bias times 2^11: the one-accumulator chain kernel,
+    magnet_mlp_fp16x3s_f32).  Same dtype and size as an "fp16x3" pack - the type is what tells ops.mlp_plan which entry to call."""
+
+    @staticmethod
+    def __new__(cls, t):
+        return torch.Tensor._make_subclass(cls, t, False)
+
+
+def chain_gemm(n_linears: int, hidden: int, mode: str) -> str:
+    """GEMM mode of a register-chained MLP with ``n_linears`` Linears of width ``hidden`` whose model-wide mode is ``mode``: the
+    5-Linear 64-wide chains run the one-accumulator form of fp16x3 - 124 instead of 142 registers, i.e. four waves per SIMD instead
+    of three, and 40 % fewer VALU instructions per layer (the 128-wide chains stay at two waves per SIMD either way
+    and gain nothing).  MAGNET_CHAIN_GEMM=fp16x3 keeps the two-accumulator form (A/B runs, |w| >= 31.98)."""
+    import os
+    if mode == "fp16x3" and n_linears == 5 and hidden == 64:
+        m = os.environ.get("MAGNET_CHAIN_GEMM", "fp16x3s")
+        assert m in ("fp16x3", "fp16x3s"), m
+        return m
+    return mode
+
+
 def default_gemm() -> str:
     import os
     mode = os.environ.get("MAGNET_GEMM", "fp16x3")
@@ -198,9 +220,9 @@ def default_gemm() -> str:
 # ---- device path: one HIP launch per Linear (magnet_pack_linear_f32, csrc/pack_kernels.hip) instead of the torch index shuffles above.
 # A training step re-packs every weight the optimizer touched; the torch path costs ~30 small kernels per Linear plus a host
 # synchronisation for the fp16 range check - ~60 000 launches and ~600 `.item()` round trips per MAgNet training step.
-_MODE_ID = {"fp32": 0, "fp16x3": 1, "bf16x6": 2, "bf16": 3}
-_OUT_DTYPE = {"fp32": torch.float32, "fp16x3": torch.float16, "bf16x6": torch.int16, "bf16": torch.bfloat16}
-_PLANES = {"fp32": 2, "fp16x3": 2, "bf16x6": 3, "bf16": 1}        # out elements per padded weight entry / (fp32: 1 float = 2 x 16 bit)
+_MODE_ID = {"fp32": 0, "fp16x3": 1, "bf16x6": 2, "bf16": 3, "fp16x3s": 4}
+_OUT_DTYPE = {"fp32": torch.float32, "fp16x3": torch.float16, "bf16x6": torch.int16, "bf16": torch.bfloat16, "fp16x3s": torch.float16}
+_PLANES = {"fp32": 2, "fp16x3": 2, "bf16x6": 3, "bf16": 1, "fp16x3s": 2}        # out elements per padded weight entry / (fp32: 1 float = 2 x 16 bit)
 _WEIGHT_RANGE_BIT = 1
 _status = {}             # device -> int32[1]: bit 0 = an fp16x3 pack met |w| >= 65504 or a non-finite weight
 _src_maps = {}           # (column placement, padded width, device) -> int32 source-column map
@@ -274,12 +296,12 @@ def pack_device(w, b, mode: str, np_: int, kp: int, row_src=None, col_src=None):
         b = b.float() if b.dtype != torch.float32 else b
         b = b if b.is_contiguous() else b.contiguous()
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-    st = _status_word(dev) if mode == "fp16x3" else None
+    st = _status_word(dev) if mode in ("fp16x3", "fp16x3s") else None
     L.check(L.lib().magnet_pack_linear_f32(ptr(w), C.c_long(w.stride(0)), C.c_long(w.stride(1)), w.shape[0], w.shape[1], ptr(row_src),
                                            ptr(col_src), ptr(b), b.numel() if b is not None else 0, np_, kp, _MODE_ID[mode], ptr(out),
                                            ptr(bp), ptr(st), _WEIGHT_RANGE_BIT, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
             "pack_linear")
-    return out, bp
+    return (SinglePlanes(out) if mode == "fp16x3s" else out), bp
 
 
 def pack(w, b, mode: str, k_pad=None, n_pad=None, col_map=None):
@@ -294,6 +316,12 @@ def pack(w, b, mode: str, k_pad=None, n_pad=None, col_map=None):
         return pack_device(w, b, mode, np_, kp, col_src=cs)
     if mode == "fp16x3":
         return pack_linear_fp16x2(w, b, k_pad=k_pad, n_pad=n_pad, col_map=col_map)
+    if mode == "fp16x3s":
+        flag_if_abs_reaches(w, 31.98)
+        planes, bp = pack_linear_fp16x2(w, b, k_pad=k_pad, n_pad=n_pad, col_map=col_map)
+        planes = planes.view(-1, 2, 512).clone()
+        planes[:, 0] *= 2048.0                                  # exact: a power of two, |w| < 31.98
+        return SinglePlanes(planes.view(-1)), bp * 2048.0
     if mode == "bf16x6":
         return pack_linear_bf16x3(w, b, k_pad=k_pad, n_pad=n_pad, col_map=col_map)
     if mode == "bf16":

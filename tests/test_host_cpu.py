@@ -236,3 +236,21 @@ def test_large_graph_node_kernel_gate():
     assert not ops.node_halves_supported(32, 4, 2050)           # graph boundaries must fall on 32-row tiles
     assert not ops.node_halves_supported(32, 4, 65536, h=64)
     assert ops.NORM_SMALL_ROWS == 2048
+
+
+def test_one_accumulator_pack_is_the_fp16x3_pack_with_high_plane_and_bias_times_2048():
+    """packing mode "fp16x3s" (torch layout path): same slot map as "fp16x3", plane 0 and the bias scaled by 2^11 (exact), a
+    SinglePlanes tensor so that ops.mlp_plan picks magnet_mlp_fp16x3s_f32; |w| >= 31.98 is refused"""
+    from magnet_amd import packing
+    g = torch.Generator().manual_seed(5)
+    w, b = torch.randn(64, 40, generator=g), torch.randn(64, generator=g)
+    p1, b1 = packing.pack(w, b, "fp16x3")
+    p2, b2 = packing.pack(w, b, "fp16x3s")
+    assert isinstance(p2, packing.SinglePlanes) and not isinstance(p1, packing.SinglePlanes) and p2.dtype == torch.float16
+    a1, a2 = p1.view(-1, 2, 512).float(), torch.Tensor(p2).view(-1, 2, 512).float()
+    assert torch.equal(a2[:, 0], a1[:, 0] * 2048.0) and torch.equal(a2[:, 1], a1[:, 1]) and torch.equal(b2, b1 * 2048.0)
+    assert packing.chain_gemm(5, 64, "fp16x3") == "fp16x3s" and packing.chain_gemm(5, 128, "fp16x3") == "fp16x3"
+    assert packing.chain_gemm(5, 64, "bf16x6") == "bf16x6" and packing.chain_gemm(3, 64, "fp16x3") == "fp16x3"
+    w[1, 2] = 40.0
+    with pytest.raises(ValueError):
+        packing.pack(w, b, "fp16x3s")

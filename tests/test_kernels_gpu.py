@@ -124,11 +124,23 @@ def test_instance_norm_matches_pyg_restatement():
     assert rel_l2(got, want) < 1e-6
 
 
-@pytest.mark.parametrize("mode", ["fp16x3", "bf16x6", "fp32"])
+def _two_accumulator_form(monkeypatch, mode, hidden):
+    """"fp16x3-2acc": the 64-wide 5-Linear chains in the two-accumulator form of fp16x3 (their default is the one-accumulator form
+    "fp16x3s", packing.chain_gemm)"""
+    if mode != "fp16x3-2acc":
+        return mode
+    if hidden != 64:
+        pytest.skip("the 128-wide chains have one form")
+    monkeypatch.setenv("MAGNET_CHAIN_GEMM", "fp16x3")
+    return "fp16x3"
+
+
+@pytest.mark.parametrize("mode", ["fp16x3", "fp16x3-2acc", "bf16x6", "fp32"])
 @pytest.mark.parametrize("hidden,out,k_in,ln", [(128, 128, 45, True), (64, 32, 96, True), (128, 7, 128, False), (64, 64, 40, True)])
-def test_generic_mlp_matches_torch(hidden, out, k_in, ln, mode):
+def test_generic_mlp_matches_torch(hidden, out, k_in, ln, mode, monkeypatch):
     """5 Linears + ReLU (+LayerNorm) through magnet_mlp_f32 vs torch fp64 on the host."""
     from magnet_amd import ops
+    mode = _two_accumulator_form(monkeypatch, mode, hidden)
     from magnet_amd.models.backbones.mlp import MLP
     from magnet_amd.models.magnet_common import pack_mlp, pack_mlp_ln, run_mlp
     from magnet_amd.packing import pad_to
@@ -152,10 +164,11 @@ def test_generic_mlp_matches_torch(hidden, out, k_in, ln, mode):
     assert rel_l2(y, ref) < 2e-6
 
 
-@pytest.mark.parametrize("mode", ["fp16x3", "bf16x6", "fp32"])
-def test_mlp_gather_difference_and_segmean_epilogue(mode):
+@pytest.mark.parametrize("mode", ["fp16x3", "fp16x3-2acc", "bf16x6", "fp32"])
+def test_mlp_gather_difference_and_segmean_epilogue(mode, monkeypatch):
     """the edge path: gathered / differenced sources -> MLP -> LayerNorm -> fused CSR mean == unfused."""
     from magnet_amd import ops
+    mode = _two_accumulator_form(monkeypatch, mode, 64)
     from magnet_amd.models.backbones.mlp import MLP
     from magnet_amd.models.magnet_common import pack_mlp_ln, run_mlp
     from oracle.pyg_semantics import scatter_mean
@@ -827,3 +840,57 @@ def test_swish_backward_leaves_the_block_maxima_of_its_output(n):
     out = ops.swish_bwd(dr, z, amax=amax)
     assert torch.equal(out, ops.swish_bwd(dr, z))
     assert float(amax.max()) == float(out.abs().max())
+
+
+def test_one_accumulator_chain_is_what_the_64_wide_chains_run_and_keeps_small_activations():
+    """packing.chain_gemm: a 5-Linear 64-wide chain is packed as "fp16x3s" (high plane and bias times 2^11) and runs
+    magnet_mlp_fp16x3s_f32; the low piece of an activation is an UNSCALED fp16 there (a subnormal for small values), so the case
+    that has to be shown is small inputs: 1e-3-sized rows through the chain against fp64, and against the two-accumulator form."""
+    import os
+    from magnet_amd import ops
+    from magnet_amd.models.backbones.mlp import MLP
+    from magnet_amd.models.magnet_common import pack_mlp_ln, run_mlp
+    from magnet_amd.packing import SinglePlanes
+    torch.manual_seed(3)
+    import copy
+    m, norm = MLP(96, [64] * 4, 32), torch.nn.LayerNorm(32)
+    seq = torch.nn.Sequential(copy.deepcopy(m), copy.deepcopy(norm)).cuda()
+    m, norm = m.double(), norm.double()
+    pk = pack_mlp_ln(seq)
+    assert all(isinstance(w, SinglePlanes) for w, _ in pk.layers)
+    old = os.environ.get("MAGNET_CHAIN_GEMM")
+    os.environ["MAGNET_CHAIN_GEMM"] = "fp16x3"
+    try:
+        pk2 = pack_mlp_ln(seq)
+    finally:
+        os.environ.pop("MAGNET_CHAIN_GEMM") if old is None else os.environ.__setitem__("MAGNET_CHAIN_GEMM", old)
+    assert not any(isinstance(w, SinglePlanes) for w, _ in pk2.layers)
+    # same planes up to the scaling of the high one
+    a, b = pk.layers[1][0].view(-1, 2, 512).float(), pk2.layers[1][0].view(-1, 2, 512).float()
+    assert torch.equal(a[:, 1], b[:, 1]) and torch.equal(a[:, 0], b[:, 0] * 2048.0)
+    assert torch.equal(pk.layers[1][1], pk2.layers[1][1] * 2048.0)
+    M = 4099
+    for scale in (1.0, 1e-3, 30.0):
+        x = torch.randn(M, 96) * scale
+        y, y2 = torch.empty(M, 32, device="cuda"), torch.empty(M, 32, device="cuda")
+        run_mlp(M, ops.ktiles(ops.Term(x.cuda(), 96)), pk, y)
+        run_mlp(M, ops.ktiles(ops.Term(x.cuda(), 96)), pk2, y2)
+        with torch.no_grad():
+            ref = norm(_torch_mlp(m, x.double()))
+        # (a LayerNorm of 1e-3-sized rows amplifies by 1 / std: the bar is the two-accumulator form's own error on the same input)
+        e1, e2 = rel_l2(y, ref), rel_l2(y2, ref)
+        assert e1 < max(2e-6, 3 * e2), (scale, e1, e2)
+
+
+def test_one_accumulator_pack_flags_weights_out_of_its_range():
+    """|w| >= 31.98: 2^11 w does not fit an fp16 - the pack sets the device status word, raise_if_bad_weights reports it"""
+    from magnet_amd import packing
+    w = torch.randn(64, 64, device="cuda")
+    packing.pack(w, None, "fp16x3s")
+    packing.raise_if_bad_weights(w.device)
+    w[3, 5] = 32.0
+    packing.pack(w, None, "fp16x3s")
+    with pytest.raises(ValueError):
+        packing.raise_if_bad_weights(w.device)
+    packing.pack(w, None, "fp16x3")            # the two-accumulator form takes it
+    packing.raise_if_bad_weights(w.device)

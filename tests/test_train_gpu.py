@@ -494,7 +494,7 @@ def test_magnet_gnn_training_step_gradients(teacher_forcing):
     a kink-limited comparison can give: equal loss, the half of the network upstream of the flipped units (LR-mesh graph
     net, INR decoder) to rounding, everything within a few percent and in the same direction."""
     import copy
-    from magnet_amd import autograd as AG
+    from magnet_amd import autograd as AG, ops
     from magnet_amd.models.factory import FACTORY
     from oracle import models as O
     from oracle.weightgen import fill_state_dict
@@ -536,12 +536,14 @@ def test_magnet_gnn_training_step_gradients(teacher_forcing):
     for rec in calls:
         x32 = rec["x"]
         xh = AG._pad_cols(x32, (x32.shape[1] + 31) // 32 * 32)
+        M, nl = x32.shape[0], len(lins)
+        X = [torch.empty_like(xh)] + [torch.empty(M, pk.ht * 32, device=xh.device) for _ in range(nl - 1)]
+        AG._recompute_tape(M, ops.ktiles(ops.Term(xh, xh.shape[1])), pk, nl, X[0], X, None, xh.shape[1])   # the backward's own tape launch
         h = x32.double()
         for i, lin in enumerate(lins):
             h = lin(h)
             if i < len(lins) - 1:
-                xh = AG._linear(x32.shape[0], xh, pk.layers[i], pk.ht, relu=True)
-                h = h * (xh[:, :h.shape[1]] > 0).double()
+                h = h * (X[i + 1][:, :h.shape[1]] > 0).double()
         h.backward(rec["dy"].double())
     assert len(calls) == 2
     for i, lin in enumerate(lins):
