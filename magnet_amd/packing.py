@@ -253,7 +253,8 @@ def raise_if_bad_weights(dev) -> None:
     if dev in _status and int(_status[dev].item()):
         _status[dev].zero_()
         raise ValueError("fp16x3 GEMM mode needs finite weights with |w| < 65504 (|w| < 31.98 for message_net_2 when training with "
-                         "edge_bwd='fused_w'); use MAGNET_GEMM=bf16x6 or edge_bwd='fused'")
+                         "edge_bwd='fused_w' and for the 64-wide 5-Linear chains of the MAgNet models); use MAGNET_GEMM=bf16x6, "
+                         "edge_bwd='fused' or MAGNET_CHAIN_GEMM=fp16x3")
 
 
 def source_map(placed_at, width: int, dev, source_cols=None):
