@@ -738,3 +738,21 @@ def test_differentiable_mlp_shared_rows_source():
     assert rel_l2(y, h.detach()) < 2e-6
     h.backward(gy.double())
     assert rel_l2(a.grad, a64.grad) < 5e-5 and rel_l2(b.grad, b64.grad) < 5e-5
+
+
+def test_rccl_process_group_runs_the_training_collectives_on_one_rank():
+    """scripts/rccl_check.py in a fresh process: backend "nccl" (= RCCL), world size 1 on cuda:0 - the flat-gradient all-reduce after
+    a real HIP backward, the scalar MAX / SUM reductions, all-gather, barriers.  Two RCCL ranks cannot share this box's single GPU
+    (the 2-rank test above runs over gloo); this is the part of the N > 1 path that CAN execute on RCCL here."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "rccl_check.py")], capture_output=True, text=True,
+                       timeout=600, env=env)
+    if "RCCL_INIT_FAILED" in r.stdout:
+        pytest.skip("no RCCL communicator on this box: " + r.stdout.strip()[-300:])
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
