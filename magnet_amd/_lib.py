@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # MAGNET_DEV_LIB=1 (development scripts only): the library built by `python -m magnet_amd.build --dev`, which additionally
 # exports the run-time variant / ablation knobs of include/magnet_hip_dev.h
 DEV = os.environ.get("MAGNET_DEV_LIB", "0") == "1"
-LIB_PATH = os.path.join(HERE, "csrc", "libmagnet_hip_dev.so" if DEV else "libmagnet_hip.so")
+# MAGNET_LIB_PATH (development scripts only): another build of the same library, e.g. an experiment variant
+LIB_PATH = os.environ.get("MAGNET_LIB_PATH") or os.path.join(HERE, "csrc", "libmagnet_hip_dev.so" if DEV else "libmagnet_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "magnet_hip.h")
 
 MAX_KT, MAX_LAYERS = 36, 6

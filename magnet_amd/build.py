@@ -73,6 +73,17 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
         raise RuntimeError("link failed:\n" + r.stderr)
     if verbose:
         print(f"[magnet_amd.build] built {lib} from {len(srcs)} sources", file=sys.stderr)
+    # the linked code objects are checked for the one hazard hipcc does not cover: an inline-asm VALU write that a v_mfma reads
+    # fewer than two wait states later (magnet_amd/hazard_check.py) - a library with such a pair is not shipped
+    from . import hazard_check
+    if os.path.exists(hazard_check.OBJDUMP):
+        bad = hazard_check.violations(hazard_check.disassemble(lib))
+        if bad:
+            os.remove(lib)
+            lines = "\n".join(f"  {n[:60]}: {w}  ->  {m}" for n, _, _, w, m in bad[:8])
+            raise RuntimeError(f"{len(bad)} VALU-write -> MFMA-read pair(s) without wait states in {lib}:\n{lines}")
+        if verbose:
+            print("[magnet_amd.build] hazard check: no VALU write closer than 2 wait states to an MFMA that reads it", file=sys.stderr)
     return lib
 
 

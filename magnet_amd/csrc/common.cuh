@@ -295,6 +295,15 @@ enum { GEMM_BF16X6 = 0, GEMM_FP16X3 = 1, GEMM_BF16 = 2, GEMM_FP16X3S = 3 };
 template <int MODE>
 struct Split;
 
+// hipcc's hazard recognizer does not look inside inline asm: between an asm VALU instruction that writes a VGPR and a v_mfma that reads it
+// as SrcA / SrcB / SrcC it inserts nothing, where it keeps two wait states for every VALU instruction it emitted itself.
+// MAGNET_MIX_TAIL closes the asm block of the LAST piece of a plane word with the missing wait states.
+#ifndef MAGNET_MIX_TAIL
+#define MAGNET_MIX_TAIL "\n\ts_nop 1"
+#endif
+// the same guarantee for a whole operand at once: every write to the two planes happens before, every MFMA that reads them after
+__device__ __forceinline__ void mfma_operand_fence(u32x4& hi, u32x4& lo) { asm volatile("s_nop 1" : "+v"(hi), "+v"(lo)); }
+
 template <>
 struct Split<GEMM_BF16X6> {
     static constexpr int NP = 3;                       // planes per slot
@@ -317,7 +326,9 @@ struct Split<GEMM_FP16X3> {
         planes[0][p] = w[0];
         planes[1][p] = w[1];
     }
-    // one word of each plane from two values: {(h1 << 16 | h0), (l1 << 16 | l0)}
+    // one word of each plane from two values: {(h1 << 16 | h0), (l1 << 16 | l0)}.  TAIL = false: without the closing wait states - the
+    // caller fences the finished planes itself (mfma_operand_fence) before an MFMA reads them.
+    template <bool TAIL = true>
     static __device__ __forceinline__ u32x2 pair(float a0, float a1) {
         const unsigned h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a0, a1));
         // five instructions per value pair (hipcc's own lowering of the C expression takes nine): the remainder a - h is a
@@ -329,7 +340,8 @@ struct Split<GEMM_FP16X3> {
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(h), "v"(a0));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(h), "v"(a1));
         asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l) : "v"(d0), "s"(k2048));
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l) : "v"(d1), "s"(k2048));
+        if (TAIL) asm("v_fma_mixhi_f16 %0, %1, %2, 0" MAGNET_MIX_TAIL : "+v"(l) : "v"(d1), "s"(k2048));
+        else asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l) : "v"(d1), "s"(k2048));
         const u32x2 w = {h, l};
         return w;
     }
@@ -363,7 +375,7 @@ struct Split<GEMM_FP16X3S> {
         unsigned l;
         // l = fp16_rne(a - h): the difference is exact inside the fma (h is a truncation of a), one rounding into the plane word
         asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a0));
-        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(a1));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" MAGNET_MIX_TAIL : "+v"(l) : "v"(h), "v"(a1));
         planes[0][p] = h;
         planes[1][p] = l;
     }

@@ -16,6 +16,9 @@
 //       - the Swish + segmented DPP scan of two of tile t-1's 64 output registers          (VALU)
 //   sched_barriers after every group keep hipcc from undoing the placement.
 #include "common.cuh"
+#ifndef MAGNET_EDGE16_FENCE
+#define MAGNET_EDGE16_FENCE 0
+#endif
 #include "edge_tile.cuh"
 
 #ifndef EDGE6_CONTIGUOUS
@@ -413,9 +416,9 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
         const float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(L2E ? -v1 : -v1 * MAGNET_LOG2E));
         u32 h, l;
         asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(v0), "v"(r0));
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(v1), "v"(r1));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" MAGNET_MIX_TAIL : "+v"(h) : "v"(v1), "v"(r1));
         asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v0), "v"(r0), "v"(h));
-        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v1), "v"(r1), "v"(h));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" MAGNET_MIX_TAIL : "+v"(l) : "v"(v1), "v"(r1), "v"(h));
         hw = h, lw = l;
     };
     constexpr float deg_scale = L2E ? MAGNET_LOG2E : 1.0f;
@@ -501,11 +504,19 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
                     xs[0][0][p] = ph[0][p];
                     xs[0][1][p] = pl[0][p];
                 } else {
-                    const u32x2 w = Split<GEMM_FP16X3>::pair(in[0][2 * p], in[0][2 * p + 1]);
+                    const u32x2 w = Split<GEMM_FP16X3>::pair<false>(in[0][2 * p], in[0][2 * p + 1]);
                     xs[0][0][p] = w[0];
                     xs[0][1][p] = w[1];
                 }
             }
+            // the plane words come out of inline asm, which hipcc's hazard recognizer does not see (common.cuh, MAGNET_MIX_TAIL).  This
+            // kernel's software pipeline puts a whole double group (LDS requests, the next pair's split) between the last word of an
+            // operand and the first MFMA that reads it, and every build is checked for that on the linked ISA
+            // (magnet_amd/hazard_check.py); -DMAGNET_EDGE16_FENCE=1 adds an explicit fence per finished operand instead (four per
+            // tile: measured +5 % on the kernel, the volatile asm breaks hipcc's interleaving of the double groups)
+#if MAGNET_EDGE16_FENCE
+            if (!SINGLE) mfma_operand_fence(xs[0][0], xs[0][1]);
+#endif
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 wr[0][u][0] = wl[(u * 2 + 0) * 64 + lane];
@@ -533,9 +544,12 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
                         xs[(s + 1) & 1][0][tp] = ph[s + 1][tp];
                         xs[(s + 1) & 1][1][tp] = pl[s + 1][tp];
                     } else {
-                        const u32x2 w = Split<GEMM_FP16X3>::pair(in[s + 1][2 * tp], in[s + 1][2 * tp + 1]);
+                        const u32x2 w = Split<GEMM_FP16X3>::pair<false>(in[s + 1][2 * tp], in[s + 1][2 * tp + 1]);
                         xs[(s + 1) & 1][0][tp] = w[0];
                         xs[(s + 1) & 1][1][tp] = w[1];
+#if MAGNET_EDGE16_FENCE
+                        if (tp == 3) mfma_operand_fence(xs[(s + 1) & 1][0], xs[(s + 1) & 1][1]);
+#endif
                     }
                 }
                 if (s == 0) {   // first k step: the accumulators start from the bias registers / the inline constant 0

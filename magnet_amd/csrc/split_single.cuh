@@ -10,7 +10,7 @@ __device__ __forceinline__ void split_f16_plain(float a0, float a1, unsigned& h,
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(h), "v"(a0));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(h), "v"(a1));
     asm("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(l) : "v"(d0));
-    asm("v_fma_mixhi_f16 %0, %1, 1.0, 0" : "+v"(l) : "v"(d1));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, 0" MAGNET_MIX_TAIL : "+v"(l) : "v"(d1));    // (wait states: common.cuh, MAGNET_MIX_TAIL)
 }
 // 8 consecutive edges of one staged feature row -> the two planes of an MFMA operand
 __device__ __forceinline__ float stage_operand(const float* __restrict__ row, f16x8& hi, f16x8& lo) {

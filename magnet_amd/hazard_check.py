@@ -1,0 +1,115 @@
+"""Build-time check of the shipped code objects: no v_mfma may read a VGPR that a VALU instruction wrote fewer than two wait states
+earlier.
+
+Why this exists.  On gfx950 a VALU write of a VGPR needs two wait states before a v_mfma reads that register as
+SrcA / SrcB / SrcC.  hipcc's hazard recognizer keeps them for every VALU instruction it emits itself, but it does not look inside inline
+asm: a `v_fma_mixhi_f16` written as asm (the fp16 split of this library) directly in front of the MFMA that consumes its result is
+left alone, the MFMA reads the register's OLD contents now and then, and the kernel is wrong in one k element of one operand -
+intermittently, depending on how busy the matrix pipe is when the pair issues (the round-2 "biases from LDS" failure,
+scripts/dev/stress_bias_lds.py).  The sources close every asm block that can feed an MFMA with the missing wait states
+(csrc/common.cuh: MAGNET_MIX_TAIL, mfma_operand_fence); this module verifies the RESULT: it disassembles libmagnet_hip.so's gfx950 code
+objects and walks every kernel linearly.
+
+    python -m magnet_amd.hazard_check [path/to/lib.so]      -> exit code 1 and a listing when a violation exists
+"""
+from __future__ import annotations
+
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+MIN_WAIT_STATES = 2
+_RANGE = re.compile(r"^([va])\[(\d+):(\d+)\]$")
+_ONE = re.compile(r"^([va])(\d+)$")
+
+
+def _regs(tok: str) -> list:
+    """registers of one operand as ('v' | 'a', index) - architectural and accumulation VGPRs are different files"""
+    tok = tok.strip()
+    m = _RANGE.match(tok)
+    if m:
+        return [(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)]
+    m = _ONE.match(tok)
+    if m:
+        return [(m.group(1), int(m.group(2)))]
+    return []
+
+
+def disassemble(lib: str) -> list[tuple[str, list[str]]]:
+    """[(kernel name, [instruction text ...])] of every gfx950 code object bundled in ``lib``"""
+    if not os.path.exists(OBJDUMP):
+        raise FileNotFoundError(OBJDUMP)
+    out = []
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, local)
+        subprocess.run([OBJDUMP, "--offloading", "lib.so"], cwd=tmp, check=True, capture_output=True)
+        for f in sorted(os.listdir(tmp)):
+            if "gfx950" not in f:
+                continue
+            txt = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+            cur = None
+            for line in txt.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if m:
+                    cur = (m.group(1), [])
+                    out.append(cur)
+                elif cur is not None and line.startswith("\t"):
+                    ins = line.split("//")[0].strip()
+                    if ins:
+                        cur[1].append(ins)
+    return out
+
+
+def violations(kernels) -> list[tuple[str, int, int, str, str]]:
+    """(kernel, instruction index of the MFMA, wait states found, the writer, the MFMA) for every VALU-write -> MFMA-read closer than
+    MIN_WAIT_STATES.  Linear walk (a branch target in between can only make the real distance longer or the pair unrelated)."""
+    bad = []
+    for name, ins in kernels:
+        last = {}                                        # vgpr -> index of the VALU instruction that wrote it last
+        for k, line in enumerate(ins):
+            op = line.split()[0]
+            args = re.split(r",\s*", line[len(op):].strip())
+            if op.startswith(("v_mfma", "v_smfmac")):
+                for tok in args[1:4]:
+                    for r in _regs(tok):
+                        kw = last.get(r)
+                        if kw is None or k - kw > MIN_WAIT_STATES:
+                            continue
+                        ws = 0
+                        for q in range(kw + 1, k):
+                            o = ins[q].split()
+                            ws += int(o[1], 0) + 1 if o[0] == "s_nop" else 1
+                        if ws < MIN_WAIT_STATES:
+                            bad.append((name, k, ws, ins[kw], line))
+                for r in _regs(args[0]):
+                    last.pop(r, None)
+            elif op.startswith("v_"):
+                if not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+                    for r in _regs(args[0]):
+                        last[r] = k
+            elif op.startswith(("ds_read", "ds_load", "global_load", "buffer_load", "scratch_load", "flat_load")):
+                for r in _regs(args[0]):
+                    last.pop(r, None)
+    return bad
+
+
+def check(lib: str | None = None) -> list:
+    from . import _lib
+    return violations(disassemble(lib or _lib.LIB_PATH))
+
+
+if __name__ == "__main__":
+    path = sys.argv[1] if len(sys.argv) > 1 else None
+    found = check(path)
+    seen = set()
+    for name, k, ws, w, m in found:
+        if (name, w, m) not in seen:
+            seen.add((name, w, m))
+            print(f"{name[:70]}: {ws} wait state(s) between\n      {w}\n      {m}")
+    print(f"{len(found)} VALU-write -> MFMA-read pair(s) closer than {MIN_WAIT_STATES} wait states")
+    sys.exit(1 if found else 0)

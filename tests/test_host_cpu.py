@@ -254,3 +254,21 @@ def test_one_accumulator_pack_is_the_fp16x3_pack_with_high_plane_and_bias_times_
     w[1, 2] = 40.0
     with pytest.raises(ValueError):
         packing.pack(w, b, "fp16x3s")
+
+
+def test_shipped_library_has_no_valu_write_right_in_front_of_an_mfma_that_reads_it():
+    """hipcc does not insert the two wait states between an INLINE-ASM VALU write and a v_mfma that reads the register (it does for
+    its own instructions); the round-2 "biases from LDS" failure was exactly that.  The sources close their asm
+    blocks with the wait states; this disassembles the built library's gfx950 code objects and checks the result."""
+    import os
+    from magnet_amd import hazard_check
+    if not os.path.exists(hazard_check.OBJDUMP) or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("needs llvm-objdump and the built library")
+    kernels = hazard_check.disassemble(_lib.LIB_PATH)
+    assert len(kernels) > 100 and sum(any(i.startswith("v_mfma") for i in ins) for _, ins in kernels) > 50
+    assert hazard_check.violations(kernels) == []
+    # the checker itself: a synthetic kernel with the pattern, with one and with two wait states in between
+    mk = lambda mid: [("k", ["v_fma_mixhi_f16 v101, v53, s7, 0", *mid, "v_mfma_f32_32x32x16_f16 v[32:47], v[56:59], v[100:103], v[32:47]"])]  # noqa: E731
+    assert len(hazard_check.violations(mk(["s_and_b64 s[4:5], s[0:1], s[2:3]"]))) == 1
+    assert hazard_check.violations(mk(["s_nop 1"])) == [] and hazard_check.violations(mk(["s_nop 0", "v_mov_b32 v1, v2"])) == []
+    assert hazard_check.violations([("k", ["v_fma_mixhi_f16 v13, v53, s7, 0", "v_mfma_f32_32x32x16_f16 a[0:15], v[56:59], v[100:103], a[0:15]"])]) == []
