@@ -77,7 +77,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
     # fewer than two wait states later (magnet_amd/hazard_check.py) - a library with such a pair is not shipped
     from . import hazard_check
     if os.path.exists(hazard_check.OBJDUMP):
-        bad = hazard_check.violations(hazard_check.disassemble(lib))
+        bad = hazard_check.check(lib)
         if bad:
             os.remove(lib)
             lines = "\n".join(f"  {n[:60]}: {w}  ->  {m}" for n, _, _, w, m in bad[:8])

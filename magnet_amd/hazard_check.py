@@ -98,9 +98,61 @@ def violations(kernels) -> list[tuple[str, int, int, str, str]]:
     return bad
 
 
+def _passes(op: str) -> int:
+    """matrix-pipe passes of an MFMA mnemonic (4 cycles each); unknown shapes count as the longest"""
+    if "32x32x16" in op or "16x16x4_f32" in op or "16x16x4f32" in op or "32x32x8" in op and "xf32" not in op:
+        return 8
+    if "16x16x32" in op or "16x16x16" in op:
+        return 4
+    return 16
+
+
+def mfma_result_reads(kernels) -> list[tuple[str, int, int, int, str, str]]:
+    """the other direction: (kernel, index, wait states found, wait states needed, the MFMA, the reader) for every VALU instruction that
+    reads an MFMA result sooner than passes + 2 wait states after the MFMA (the least hipcc keeps for its own instructions on gfx950)"""
+    bad = []
+    for name, ins in kernels:
+        last = {}                                        # vgpr -> (index of the MFMA that wrote it, passes)
+        for k, line in enumerate(ins):
+            op = line.split()[0]
+            args = re.split(r",\s*", line[len(op):].strip())
+            if op.startswith(("v_mfma", "v_smfmac")):
+                for r in _regs(args[0]):
+                    last[r] = (k, _passes(op))
+                continue
+            if op.startswith("v_"):
+                for tok in args[1:]:
+                    for r in _regs(tok.split()[0] if tok else tok):
+                        hit = last.get(r)
+                        if hit is None:
+                            continue
+                        km, np_ = hit
+                        need = np_ + 2
+                        if k - km > need:
+                            continue
+                        ws = 0
+                        for q in range(km + 1, k):
+                            o = ins[q].split()
+                            if o[0] == "s_nop":
+                                ws += int(o[1], 0) + 1
+                            elif o[0].startswith(("v_mfma", "v_smfmac")):
+                                ws += _passes(o[0])              # a following MFMA occupies the pipe for its own passes first
+                            else:
+                                ws += 1
+                        if ws < need:
+                            bad.append((name, k, ws, need, ins[km], line))
+                for r in _regs(args[0]):
+                    last.pop(r, None)
+            elif op.startswith(("ds_read", "ds_load", "global_load", "buffer_load", "scratch_load", "flat_load")):
+                for r in _regs(args[0]):
+                    last.pop(r, None)
+    return bad
+
+
 def check(lib: str | None = None) -> list:
     from . import _lib
-    return violations(disassemble(lib or _lib.LIB_PATH))
+    k = disassemble(lib or _lib.LIB_PATH)
+    return violations(k) + [(n, i, ws, m, r) for n, i, ws, _, m, r in mfma_result_reads(k)]
 
 
 if __name__ == "__main__":
@@ -111,5 +163,5 @@ if __name__ == "__main__":
         if (name, w, m) not in seen:
             seen.add((name, w, m))
             print(f"{name[:70]}: {ws} wait state(s) between\n      {w}\n      {m}")
-    print(f"{len(found)} VALU-write -> MFMA-read pair(s) closer than {MIN_WAIT_STATES} wait states")
+    print(f"{len(found)} VALU-write -> MFMA-read pair(s) closer than {MIN_WAIT_STATES} wait states / MFMA results read too early")
     sys.exit(1 if found else 0)
