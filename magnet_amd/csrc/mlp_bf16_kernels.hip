@@ -12,6 +12,9 @@
 // (packing.pack_linear_bf16x3), layer[l].b at the zero-padded fp32 bias.
 #include "common.cuh"
 #include "edge_tile.cuh"
+#ifndef MAGNET_BIAS_LDS
+#define MAGNET_BIAS_LDS 1
+#endif
 
 template <int A, int B>
 struct MaxI { static constexpr int v = A > B ? A : B; };
@@ -175,9 +178,13 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
     // weight chunk ring; a 128-wide CSR-mean epilogue reuses it as four 32 x 68 float transposition tiles (34 KiB)
     constexpr bool LDS_MEAN = (EPI == EPI_SEGMEAN && OT == 4);
     constexpr int SMEM_U4 = (LDS_MEAN && NBUF * CH < 4 * 32 * 68 / 4) ? 4 * 32 * 68 / 4 : NBUF * CH;
-#ifdef MAGNET_BIAS_LDS
-    // EXPERIMENT (round 2: intermittently wrong, profiles/r2/chain_sq_counters.txt; round 3: scripts/dev/stress_bias_lds.py): the biases
-    // of layers 1 .. NL-1 staged BEHIND the weight ring in the same __shared__ array and read with ds_read at the top of their layer
+#if MAGNET_BIAS_LDS
+    // the biases of layers 1 .. NL-1 staged BEHIND the weight ring in the same __shared__ array and read with ds_read at the top of their
+    // layer: from global memory they are 16 loads that are the wave's youngest VMEM operations right before the layer's first
+    // `s_waitcnt vmcnt(0)` - an exposed L2 round trip per layer and tile (C5 edge chain 1.18 -> 1.14 ms, C4b 0.390 -> 0.376 ms).  Round 2
+    // built this and found it intermittently wrong; round 3 found why (a missing hazard wait behind the inline-asm split, DESIGN.md
+    // 10.10 - nothing to do with the biases) and ships it.  MAGNET_BIAS_LDS=0: biases from global memory (the variants of the
+    // root-cause hunt, profiles/r3/bias_lds_root_cause.txt, lived here under values 2 .. 10)
     constexpr int BIAS_F = (NL > 1 ? NL - 1 : 1) * NTMAX * 32;
     __shared__ __attribute__((aligned(16))) u32x4 smem[SMEM_U4 + BIAS_F / 4];
     float* sbias = reinterpret_cast<float*>(smem + SMEM_U4);
@@ -305,55 +312,13 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
             if (MODE != GEMM_FP16X3S) zero_tiles<NTMAX>(cc);
             f32x16(&cco)[OT] = reinterpret_cast<f32x16(&)[OT]>(cc);
             f32x16(&cch)[HT] = reinterpret_cast<f32x16(&)[HT]>(cc);
-#ifdef MAGNET_BIAS_LDS
-            // variants of the experiment (scripts/dev/stress_bias_lds.py):  1 plain | 2 + 64 idle cycles first | 3 + lgkmcnt(0) right after |
-            // 4 + vmcnt(0) first (none of this wave's LDS-DMA in flight) | 5 read after the layer's first barrier instead | 6 read into
-            // temporaries and moved (the ds_read does not write accumulator registers) | 7 = 1 with ds_read_b32 | 8 / 9 / 10 = 1 with
-            // 2 000 idle cycles / a second barrier / 32 idle cycles after every hidden-layer barrier
-            auto bias_from_lds = [&]() {
-#if MAGNET_BIAS_LDS == 2
-                asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#elif MAGNET_BIAS_LDS == 4
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+#if MAGNET_BIAS_LDS
+            {
                 const float* sb = sbias + (l - 1) * NTMAX * 32;
-#if MAGNET_BIAS_LDS == 6
-                f32x16 tmp[NTMAX];
-                if (last) init_bias<OT>(reinterpret_cast<f32x16(&)[OT]>(tmp), sb, half);
-                else init_bias<HT>(reinterpret_cast<f32x16(&)[HT]>(tmp), sb, half);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int t = 0; t < (last ? OT : HT); ++t)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        float v;
-                        asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(tmp[t][q]));
-                        if (last) out[t < OT ? t : 0][q] = v;
-                        else if (src0) h1[t < HT ? t : 0][q] = v;
-                        else h0[t < HT ? t : 0][q] = v;
-                    }
-#elif MAGNET_BIAS_LDS == 7
-#pragma unroll
-                for (int t = 0; t < (last ? OT : HT); ++t)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const float v = *reinterpret_cast<const volatile float*>(sb + t * 32 + 8 * (q >> 2) + 4 * half + (q & 3));
-                        if (last) out[t < OT ? t : 0][q] = v;
-                        else if (src0) h1[t < HT ? t : 0][q] = v;
-                        else h0[t < HT ? t : 0][q] = v;
-                    }
-#else
                 if (last) init_bias<OT>(out, sb, half);
                 else if (src0) init_bias<HT>(h1, sb, half);
                 else init_bias<HT>(h0, sb, half);
-#endif
-#if MAGNET_BIAS_LDS == 3
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-            };
-#if MAGNET_BIAS_LDS != 5
-            bias_from_lds();
-#endif
+            }
 #else
             if (last) init_bias<OT>(out, a.layer[l].b, half);
             else if (src0) init_bias<HT>(h1, a.layer[l].b, half);
@@ -371,15 +336,6 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                 TRACE(21)
                 if (!(abl & 8)) __syncthreads();
                 TRACE(22)
-#if defined(MAGNET_BIAS_LDS) && MAGNET_BIAS_LDS == 5
-                if (kt == 0) bias_from_lds();
-#elif defined(MAGNET_BIAS_LDS) && MAGNET_BIAS_LDS == 8
-                asm volatile("s_sleep 32" ::: "memory");               // 8: ~2 000 idle cycles between the barrier and the first fragment read
-#elif defined(MAGNET_BIAS_LDS) && MAGNET_BIAS_LDS == 9
-                __syncthreads();                                       // 9: a second barrier
-#elif defined(MAGNET_BIAS_LDS) && MAGNET_BIAS_LDS == 10
-                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // 10: 32 idle cycles
-#endif
                 // chunk c+2
                 if (!(abl & 2)) {
                     const int k2 = kt + DIST;

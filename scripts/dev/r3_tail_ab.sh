@@ -1,7 +1,9 @@
-# same-box A/B: the product library (wait states behind every asm split) against a build without them (variants/libmagnet_hip_notail.so)
+# same-box A/B of library builds: bash scripts/dev/r3_tail_ab.sh product notail | product bl0 ...  (variants/libmagnet_hip_<name>.so)
+# (round 3: the wait states behind every asm split vs a build without them; biases from LDS vs from global memory)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3s; mkdir -p $O; cd $R
 HEAD="--steps 20 --warmup 2 --no-cpu-baseline --no-extra-cases --train-steps 3 --no-precision-modes"
-for i in 1 2; do for v in product notail; do
+VARS=${@:-product notail}
+for i in 1 2; do for v in $VARS; do
   if [ $v = product ]; then unset MAGNET_LIB_PATH; else export MAGNET_LIB_PATH=$R/magnet_amd/csrc/variants/libmagnet_hip_$v.so; fi
   python bench.py $HEAD > $O/tail_ab.log 2>&1
   python - $O/tail_ab.log "$v headline" <<'PY'
