@@ -83,7 +83,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
             lines = "\n".join(f"  {n[:60]}: {w}  ->  {m}" for n, _, _, w, m in bad[:8])
             raise RuntimeError(f"{len(bad)} VALU-write -> MFMA-read pair(s) without wait states in {lib}:\n{lines}")
         if verbose:
-            print("[magnet_amd.build] hazard check: no VALU write closer than 2 wait states to an MFMA that reads it", file=sys.stderr)
+            print("[magnet_amd.build] hazard check passed (VALU -> MFMA, MFMA -> VALU, transcendental -> VALU wait states)", file=sys.stderr)
     return lib
 
 

@@ -301,6 +301,9 @@ struct Split;
 #ifndef MAGNET_MIX_TAIL
 #define MAGNET_MIX_TAIL "\n\ts_nop 1"
 #endif
+// ... and one wait state between a transcendental (v_exp / v_rcp ...) and a VALU instruction that reads its result (gfx940+ "trans
+// forwarding hazard"): asm blocks whose inputs come straight out of a Swish start with MAGNET_TRANS_HEAD
+#define MAGNET_TRANS_HEAD "s_nop 0\n\t"
 // the same guarantee for a whole operand at once: every write to the two planes happens before, every MFMA that reads them after
 __device__ __forceinline__ void mfma_operand_fence(u32x4& hi, u32x4& lo) { asm volatile("s_nop 1" : "+v"(hi), "+v"(lo)); }
 

@@ -415,8 +415,8 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
         const float r0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(L2E ? -v0 : -v0 * MAGNET_LOG2E));
         const float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(L2E ? -v1 : -v1 * MAGNET_LOG2E));
         u32 h, l;
-        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(v0), "v"(r0));
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0" MAGNET_MIX_TAIL : "+v"(h) : "v"(v1), "v"(r1));
+        asm(MAGNET_TRANS_HEAD "v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(v0), "v"(r0));
+        asm(MAGNET_TRANS_HEAD "v_fma_mixhi_f16 %0, %1, %2, 0" MAGNET_MIX_TAIL : "+v"(h) : "v"(v1), "v"(r1));
         asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v0), "v"(r0), "v"(h));
         asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" MAGNET_MIX_TAIL : "+v"(l) : "v"(v1), "v"(r1), "v"(h));
         hw = h, lw = l;

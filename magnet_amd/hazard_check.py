@@ -1,5 +1,6 @@
-"""Build-time check of the shipped code objects: no v_mfma may read a VGPR that a VALU instruction wrote fewer than two wait states
-earlier.
+"""Build-time check of the shipped code objects for the hazards hipcc does not cover behind inline asm: no v_mfma may read a VGPR that a
+VALU instruction wrote fewer than two wait states earlier; no VALU instruction may read an MFMA result before the MFMA's passes + 2;
+no VALU instruction may read a transcendental's result in the next issue slot.
 
 Why this exists.  On gfx950 a VALU write of a VGPR needs two wait states before a v_mfma reads that register as
 SrcA / SrcB / SrcC.  hipcc's hazard recognizer keeps them for every VALU instruction it emits itself, but it does not look inside inline
@@ -149,10 +150,34 @@ def mfma_result_reads(kernels) -> list[tuple[str, int, int, int, str, str]]:
     return bad
 
 
+_TRANS = ("v_exp_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_log_", "v_sin_", "v_cos_")
+
+
+def trans_result_reads(kernels) -> list[tuple[str, int, int, str, str]]:
+    """third rule (gfx940+ "trans forwarding hazard"): a non-transcendental VALU instruction must not read the result of a
+    transcendental in the very next issue slot - (kernel, index, 0, the transcendental, the reader)"""
+    bad = []
+    for name, ins in kernels:
+        for k in range(len(ins) - 1):
+            op = ins[k].split()[0]
+            if not op.startswith(_TRANS):
+                continue
+            dst = set(_regs(re.split(r",\s*", ins[k][len(op):].strip())[0]))
+            nxt = ins[k + 1]
+            op2 = nxt.split()[0]
+            if not op2.startswith("v_") or op2.startswith(_TRANS):
+                continue
+            for tok in re.split(r",\s*", nxt[len(op2):].strip())[1:]:
+                if dst & set(_regs(tok.split()[0] if tok else tok)):
+                    bad.append((name, k + 1, 0, ins[k], nxt))
+                    break
+    return bad
+
+
 def check(lib: str | None = None) -> list:
     from . import _lib
     k = disassemble(lib or _lib.LIB_PATH)
-    return violations(k) + [(n, i, ws, m, r) for n, i, ws, _, m, r in mfma_result_reads(k)]
+    return violations(k) + [(n, i, ws, m, r) for n, i, ws, _, m, r in mfma_result_reads(k)] + trans_result_reads(k)
 
 
 if __name__ == "__main__":

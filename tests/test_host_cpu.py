@@ -266,7 +266,7 @@ def test_shipped_library_has_no_valu_write_right_in_front_of_an_mfma_that_reads_
         pytest.skip("needs llvm-objdump and the built library")
     kernels = hazard_check.disassemble(_lib.LIB_PATH)
     assert len(kernels) > 100 and sum(any(i.startswith("v_mfma") for i in ins) for _, ins in kernels) > 50
-    assert hazard_check.violations(kernels) == [] and hazard_check.mfma_result_reads(kernels) == []
+    assert hazard_check.violations(kernels) == [] and hazard_check.mfma_result_reads(kernels) == [] and hazard_check.trans_result_reads(kernels) == []
     # the checker itself: a synthetic kernel with the pattern, with one and with two wait states in between
     mk = lambda mid: [("k", ["v_fma_mixhi_f16 v101, v53, s7, 0", *mid, "v_mfma_f32_32x32x16_f16 v[32:47], v[56:59], v[100:103], v[32:47]"])]  # noqa: E731
     assert len(hazard_check.violations(mk(["s_and_b64 s[4:5], s[0:1], s[2:3]"]))) == 1
@@ -276,3 +276,5 @@ def test_shipped_library_has_no_valu_write_right_in_front_of_an_mfma_that_reads_
     assert len(hazard_check.mfma_result_reads(early)) == 1
     early[0][1][1] = "s_nop 9"
     assert hazard_check.mfma_result_reads(early) == []
+    assert len(hazard_check.trans_result_reads([("k", ["v_rcp_f32_e32 v42, v84", "v_fma_mixlo_f16 v46, v80, v42, 0"])])) == 1
+    assert hazard_check.trans_result_reads([("k", ["v_rcp_f32_e32 v42, v84", "s_nop 0", "v_fma_mixlo_f16 v46, v80, v42, 0"])]) == []
