@@ -405,23 +405,6 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
                                                      const float* __restrict__ b2, float* __restrict__ agg,
                                                      float* __restrict__ partials) {
     auto sw = [](float x) { return L2E ? act_swish_l2e(x) : act_swish(x); };
-    // two values at a time: the add and the multiply of a Swish are packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32: two values
-    // per lane and issue slot) - hipcc does not pair them by itself, and this kernel runs at the sum of its VALU, transcendental
-    // and matrix time.  Same operations per value as `sw`, so the results are bit-identical.
-    auto sw2 = [](f32x2 x) {
-        const f32x2 t = L2E ? -x : x * (-MAGNET_LOG2E);
-        f32x2 d = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-        d += 1.0f;
-        const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-        return x * r;
-    };
-    auto sw2_acc = [](f32x2 x, f32x2 sum) {       // sum + Swish(x) with the multiply and the add as ONE v_pk_fma_f32
-        const f32x2 t = L2E ? -x : x * (-MAGNET_LOG2E);
-        f32x2 d = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-        d += 1.0f;
-        const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-        return __builtin_elementwise_fma(x, r, sum);
-    };
     // SINGLE (round 3): the weight planes arrive pre-scaled by 2^11 (plane 0 = 2^11 hw, plane 1 = 2^11 (w - hw)) and the low piece of
     // an activation stays UNSCALED (l = x - h, an fp16 subnormal for small x - the MFMA keeps them, scripts/dev/edge9_probe.cpp), so
     // all three products of the split carry the factor 2^11 and share ONE accumulator: no cross accumulator (32 registers), no
@@ -485,14 +468,8 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
                     pieces(a[0] + b[0], a[1] + b[1], ph[s][2 * g], pl[s][2 * g]);
                     pieces(a[2] + b[2], a[3] + b[3], ph[s][2 * g + 1], pl[s][2 * g + 1]);
                 } else {
-                    const f32x4 ab = a + b;
 #pragma unroll
-                    for (int c = 0; c < 4; c += 2) {
-                        const f32x2 x = {ab[c], ab[c + 1]};
-                        const f32x2 v = sw2(x);
-                        in[s][4 * g + c] = v[0];
-                        in[s][4 * g + c + 1] = v[1];
-                    }
+                    for (int c = 0; c < 4; ++c) in[s][4 * g + c] = sw(a[c] + b[c]);
                 }
             }
 #pragma unroll
@@ -575,15 +552,15 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
 #endif
                     }
                 }
-                // first k step: the main accumulators start from the bias registers (read as the C operand of the first main product:
-                // no copy), the cross accumulators from the inline constant 0
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 c0 = s == 0 ? bias[t0] : out[t0], c1 = s == 0 ? bias[t1] : out[t1];
-                if (s == 0) outc[t0] = z, outc[t1] = z;
+                if (s == 0) {   // first k step: the accumulators start from the bias registers / the inline constant 0
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    out[t0] = bias[t0], out[t1] = bias[t1];
+                    outc[t0] = z, outc[t1] = z;
+                }
                 const int bsel = dg & 1;
                 if (SINGLE) {
-                    out[t0] = mfma16(wr[bsel][0][1], xs[s & 1][0], c0);
-                    out[t1] = mfma16(wr[bsel][1][1], xs[s & 1][0], c1);
+                    out[t0] = mfma16(wr[bsel][0][1], xs[s & 1][0], out[t0]);
+                    out[t1] = mfma16(wr[bsel][1][1], xs[s & 1][0], out[t1]);
                     out[t0] = mfma16(wr[bsel][0][0], xs[s & 1][0], out[t0]);
                     out[t1] = mfma16(wr[bsel][1][0], xs[s & 1][0], out[t1]);
                     out[t0] = mfma16(wr[bsel][0][0], xs[s & 1][1], out[t0]);
@@ -591,13 +568,14 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
                 } else {
                     outc[t0] = mfma16(wr[bsel][0][1], xs[s & 1][0], outc[t0]);
                     outc[t1] = mfma16(wr[bsel][1][1], xs[s & 1][0], outc[t1]);
-                    out[t0] = mfma16(wr[bsel][0][0], xs[s & 1][0], c0);
-                    out[t1] = mfma16(wr[bsel][1][0], xs[s & 1][0], c1);
+                    out[t0] = mfma16(wr[bsel][0][0], xs[s & 1][0], out[t0]);
+                    out[t1] = mfma16(wr[bsel][1][0], xs[s & 1][0], out[t1]);
                     outc[t0] = mfma16(wr[bsel][0][0], xs[s & 1][1], outc[t0]);
                     outc[t1] = mfma16(wr[bsel][1][0], xs[s & 1][1], outc[t1]);
                 }
                 {                                 // transposed read of one edge of the previous tile, Swish, running sum
-                    acc = sw2_acc(cur, acc);
+                    acc[0] += sw(cur[0]);
+                    acc[1] += sw(cur[1]);
                     if (pmd.ends & (1u << dg)) {
                         emit_run(acc, pmd, dg, e_lo, e_hi, range, deg_scale, agg, partials, lane);
                         acc[0] = 0.f;
@@ -614,14 +592,11 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
                         asm volatile("" : "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1));
                         ph[sc][2 * idx] = h0, pl[sc][2 * idx] = l0, ph[sc][2 * idx + 1] = h1, pl[sc][2 * idx + 1] = l1;
                     } else {
-                        const f32x4 ab = la[set][idx] + lb[set][idx];
 #pragma unroll
-                        for (int c = 0; c < 4; c += 2) {
-                            const f32x2 x = {ab[c], ab[c + 1]};
-                            f32x2 v = sw2(x);
+                        for (int c = 0; c < 4; ++c) {
+                            float v = sw(la[set][idx][c] + lb[set][idx][c]);
                             asm volatile("" : "+v"(v));
-                            in[sc][4 * idx + c] = v[0];
-                            in[sc][4 * idx + c + 1] = v[1];
+                            in[sc][4 * idx + c] = v;
                         }
                     }
                 }
@@ -639,8 +614,9 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
         // this tile's raw GEMM output -> the wave's LDS tile (row = edge), consumed during the next iteration
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const f32x4 k2 = {1.0f / 2048.0f, 1.0f / 2048.0f, 1.0f / 2048.0f, 1.0f / 2048.0f};
-            const f32x4 o = SINGLE ? out[t] * k2 : __builtin_elementwise_fma(outc[t], k2, out[t]);      // two v_pk_fma_f32
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = SINGLE ? out[t][r] * (1.0f / 2048.0f) : fmaf(outc[t][r], 1.0f / 2048.0f, out[t][r]);
             *reinterpret_cast<f32x4*>(tw + 16 * t) = o;
         }
         pmd = md;
@@ -651,7 +627,8 @@ __global__ void __launch_bounds__(512) k_mpnn_edge16(const float* __restrict__ A
     // the last tile's rows
     for (int e = 0; e < 16; ++e) {
         const f32x2 cur = *reinterpret_cast<const f32x2*>(tr + e * T16_STRIDE);
-        acc = sw2_acc(cur, acc);
+        acc[0] += sw(cur[0]);
+        acc[1] += sw(cur[1]);
         if (pmd.ends & (1u << e)) {
             const int ti = __shfl(pmd.ti, e), rs = __shfl(pmd.rs, e), re = __shfl(pmd.re, e);
             const bool complete = rs >= e_lo && re <= e_hi;
