@@ -253,6 +253,14 @@ int magnet_mpnn_node_update_f32(const float* h, const float* agg, const float* n
                                 const float* var, float eps, int n_graphs, int rows_per_graph, const void* w1_f16,
                                 const float* b1, const void* w2_f16, const float* b2, float* y, float* part_sum, float* part_m2,
                                 void* stream);
+/* The same update followed by the hop's InstanceNorm (GNN_Layer.forward, models/mpnn.py:69-70: x = self.norm(update, batch)) in ONE
+ * launch, for a batch that fits one workgroup (BASELINE.json configs[0]: 2 x 50 nodes - a rollout bound by its number of launches):
+ *   y_norm = InstanceNorm(h + Swish(W2 Swish(W1 [h | agg | node_in] + b1) + b2))   over blocks of rows_per_graph rows
+ * (biased variance, eps inside the square root; the last block may be short).  Equal to magnet_mpnn_node_update_f32 followed by
+ * magnet_instance_norm_f32 to rounding.  -2 unless kin == 32, n_rows <= 128, rows_per_graph >= 1.  y_norm must not alias h. */
+int magnet_mpnn_node_update_norm_small_f32(const float* h, const float* agg, const float* node_in, int kin, long n_rows,
+                                           int rows_per_graph, float eps, const void* w1_f16, const float* b1, const void* w2_f16,
+                                           const float* b2, float* y_norm, void* stream);
 /* mean / biased variance [n_graphs][H] from per-chunk partials of chunk_rows rows (rows_per_graph % chunk_rows == 0; the chunks of a
  * graph consecutive): the merge step of PyG InstanceNorm's statistics (pairwise-variance identity, fixed order). */
 int magnet_colstat_final_f32(const float* part_sum, const float* part_m2, int n_graphs, int rows_per_graph, int chunk_rows, int H,

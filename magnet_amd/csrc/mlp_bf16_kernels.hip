@@ -883,6 +883,11 @@ __global__ void __launch_bounds__(256, 1) k_node_update(NodeUpdateArgs a) {
 // source rows and W2 (64 registers per lane) in the same breath; one wait, one barrier, the first layer runs without another; W2 then
 // takes W1's place in LDS (one more barrier) and the store tiles the space behind it.  Same accumulation order as k_node_update (agg /
 // node_in k tiles first, h last): bitwise the same results.  No InstanceNorm on load, no statistics (the small-graph path has neither).
+// NORM_OUT (a launch of ONE workgroup, n <= 128 rows: BASELINE.json configs[0], 2 x 50 nodes): the InstanceNorm of the hop
+// (GNN_Layer.forward, models/mpnn.py:69-70: x = self.norm(update, batch)) applied to the update's output before it leaves - the tile
+// goes to LDS, every (graph, column) gets its mean and centred second moment in two passes over at most 128 LDS rows, and what is
+// stored is the normalised h of the next hop: one launch per hop less in a rollout that is bound by launches (C1: 5 -> 4 per hop).
+template <bool NORM_OUT>
 __global__ void __launch_bounds__(256, 1) k_node_update_burst(NodeUpdateArgs a) {
     constexpr int MODE = GEMM_FP16X3, NKT = 9;
     __shared__ __attribute__((aligned(16))) u32x4 wb[NKT * 1024];                     // W1 whole; later W2 in [0, 4096) + the store tiles
@@ -951,7 +956,53 @@ __global__ void __launch_bounds__(256, 1) k_node_update_burst(NodeUpdateArgs a) 
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[t][4 * g + c] += xr[t][g][c];
-        store_tile_lines(acc[t], tl, a.y, t * 32, row0, a.n, lane);
+        if constexpr (!NORM_OUT) store_tile_lines(acc[t], tl, a.y, t * 32, row0, a.n, lane);
+    }
+    if constexpr (NORM_OUT) {
+        constexpr int TS = 132;                                                       // 128 x 132 floats = 66 KiB of the 80 KiB behind W2
+        float* yt = reinterpret_cast<float*>(wb + 4096);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) yt[(wave * 32 + j) * TS + t * 32 + 8 * (i >> 2) + 4 * half + (i & 3)] = acc[t][i];
+        __syncthreads();
+        const int c = threadIdx.x & 127, n = (int)a.n, rpg = a.rows_per_graph;
+        for (int r0 = (int)(threadIdx.x >> 7) * rpg; r0 < n; r0 += 2 * rpg) {         // graphs alternate between the two thread halves
+            const int r1 = min(r0 + rpg, n);
+            const float cnt = (float)(r1 - r0);
+            // eight independent partial sums per pass: a single running sum would wait one LDS latency per row (measured: the fused
+            // launch was then SLOWER than the two it replaces)
+            const float* col = yt + c;
+            float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int r = r0;
+            for (; r + 8 <= r1; r += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) p[q] += col[(r + q) * TS];
+            }
+            for (; r < r1; ++r) p[0] += col[r * TS];
+            const float m = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) / cnt;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) p[q] = 0.f;
+            for (r = r0; r + 8 <= r1; r += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float d = col[(r + q) * TS] - m;
+                    p[q] += d * d;
+                }
+            }
+            for (; r < r1; ++r) {
+                const float d = col[r * TS] - m;
+                p[0] += d * d;
+            }
+            const float m2 = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+            const float inv = 1.0f / sqrtf(m2 / cnt + a.eps);
+            float* out = a.y + c;
+            for (r = r0; r + 8 <= r1; r += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) out[(size_t)(r + q) * 128] = (col[(r + q) * TS] - m) * inv;
+            }
+            for (; r < r1; ++r) out[(size_t)r * 128] = (col[r * TS] - m) * inv;
+        }
     }
 }
 
@@ -987,13 +1038,33 @@ extern "C" int magnet_mpnn_node_update_f32(const float* h, const float* agg, con
     static int burst = -1;             // MAGNET_NODE_BURST=0: the persistent kernel for small launches too (A/B knob)
     if (burst < 0) { const char* e = getenv("MAGNET_NODE_BURST"); burst = (e && e[0] == '0') ? 0 : 1; }
     if (burst && kin == 32 && !mean && !part_sum && ntiles <= ncu) {
-        hipLaunchKernelGGL(k_node_update_burst, dim3((int)ntiles), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_node_update_burst<false>, dim3((int)ntiles), dim3(256), 0, s, a);
         return (int)hipGetLastError();
     }
     if (kin == 32 && mean) hipLaunchKernelGGL((k_node_update<9, true>), dim3(grid), dim3(256), 0, s, a);
     else if (kin == 32) hipLaunchKernelGGL((k_node_update<9, false>), dim3(grid), dim3(256), 0, s, a);
     else if (mean) hipLaunchKernelGGL((k_node_update<10, true>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_node_update<10, false>), dim3(grid), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+// The same update followed by the hop's InstanceNorm (models/mpnn.py:69-70) in ONE launch, for a batch that fits one workgroup:
+// y_norm [n_rows][128] = InstanceNorm(h + Swish(W2 Swish(W1 [h | agg | node_in] + b1) + b2)) over blocks of rows_per_graph rows (the
+// last block may be short), biased variance, eps inside the square root - what magnet_mpnn_node_update_f32 followed by
+// magnet_instance_norm_f32 computes (fixed summation order; equal to them to rounding, not bitwise).  -2 unless kin == 32,
+// 1 <= n_rows <= 128 and rows_per_graph >= 1: the caller then issues the two launches.  y_norm must not alias h.
+extern "C" int magnet_mpnn_node_update_norm_small_f32(const float* h, const float* agg, const float* node_in, int kin, long n_rows,
+                                                      int rows_per_graph, float eps, const void* w1_f16, const float* b1,
+                                                      const void* w2_f16, const float* b2, float* y_norm, void* stream) {
+    (void)hipGetLastError();
+    if (n_rows <= 0) return 0;
+    if (kin != 32 || n_rows > 128 || rows_per_graph < 1) return -2;
+    NodeUpdateArgs a;
+    a.part_sum = nullptr, a.part_m2 = nullptr, a.mean = nullptr, a.var = nullptr;
+    a.eps = eps, a.n_graphs = (int)((n_rows + rows_per_graph - 1) / rows_per_graph), a.rows_per_graph = rows_per_graph;
+    a.h = h, a.agg = agg, a.node_in = node_in, a.kin = kin, a.n = n_rows, a.y = y_norm, a.b1 = b1, a.b2 = b2;
+    a.w1 = reinterpret_cast<const f32x4*>(w1_f16), a.w2 = reinterpret_cast<const f32x4*>(w2_f16);
+    hipLaunchKernelGGL(k_node_update_burst<true>, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -100,6 +100,8 @@ class MPNN(LightningModule):
         # fp16x3: the transposed 32-edge-tile kernel (k_mpnn_edge32t, generation 9) instead of k_mpnn_edge16 (A/B knob)
         # (2 = its two-waves-per-SIMD sibling k_mpnn_edge32p)
         self.edge_t32 = int(os.environ.get("MAGNET_EDGE_T32", "0")) if getattr(hparams, "edge_t32", True) else 0
+        # small batches (<= 128 rows): update + InstanceNorm of a hop in one launch (A/B knob)
+        self.fused_small_norm = bool(int(os.environ.get("MAGNET_SMALL_NORM", "1"))) and bool(getattr(hparams, "fused_small_norm", True))
         assert self.edge_gemm in GEMM_MODES
         self.gemm = getattr(hparams, "gemm", self.edge_gemm)     # node-level Linears (same two choices)
         # backward-data GEMMs: gradients of a mean loss are ~1e-7, inside fp16's subnormal range, so the fp16 split is
@@ -250,6 +252,11 @@ class MPNN(LightningModule):
                     ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g, stats=stats, rows_per_graph=Ns)
                     stats = ops.instance_norm_stats(g, B, Ns)
                 h, g = g, h                                                 # h: raw update output + its statistics
+                continue
+            if small_nodes and self.fused_small_norm and ops.mpnn_node_update_norm_small_supported(kin, N):
+                # the whole batch in one workgroup (C1: 2 x 50 nodes): the update kernel applies the hop's InstanceNorm itself
+                ops.mpnn_node_update_norm_small(h, agg, node_in, lyr.upd1, lyr.upd2, g, Ns)
+                h, g = g, h
                 continue
             if small_nodes:
                 ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g)

@@ -429,6 +429,21 @@ def mpnn_node_update(h, agg, node_in, upd1, upd2, y, stats=None, rows_per_graph=
     return mv[0], mv[1]
 
 
+def mpnn_node_update_norm_small_supported(kin: int, n_rows: int) -> bool:
+    """csrc/mlp_bf16_kernels.hip: update + InstanceNorm in one launch when the whole batch fits one workgroup"""
+    return kin == 32 and 1 <= n_rows <= 128
+
+
+def mpnn_node_update_norm_small(h, agg, node_in, upd1, upd2, y_norm, rows_per_graph, eps=1e-5):
+    """y_norm = InstanceNorm(h + update_net(h, agg, node_in)) over blocks of ``rows_per_graph`` rows, one launch (n <= 128 rows)"""
+    assert y_norm.data_ptr() != h.data_ptr()
+    L.check(L.lib().magnet_mpnn_node_update_norm_small_f32(_p(h), _p(agg), _p(node_in), node_in.shape[1], C.c_long(h.shape[0]),
+                                                           int(rows_per_graph), C.c_float(float(eps)), _p(upd1[0]), _p(upd1[1]),
+                                                           _p(upd2[0]), _p(upd2[1]), _p(y_norm), _stream()),
+            "mpnn_node_update_norm_small")
+    return y_norm
+
+
 def conv_resident_plan(fmap, width, taps, packs, relu, res, y, ldy):
     """prebuilt launch of magnet_conv_resident_f32 (EDSR 3 x 3 convolution on a small map, weights resident in LDS) or None when the
     shape is outside that kernel; ``packs``: per 32-column group (fp16x3 planes, bias)"""

@@ -894,3 +894,62 @@ def test_one_accumulator_pack_flags_weights_out_of_its_range():
         packing.raise_if_bad_weights(w.device)
     packing.pack(w, None, "fp16x3")            # the two-accumulator form takes it
     packing.raise_if_bad_weights(w.device)
+
+
+@pytest.mark.parametrize("n_graphs,rows", [(2, 50), (1, 128), (3, 37), (2, 32), (1, 7), (4, 32)])
+def test_small_update_with_fused_instance_norm_equals_the_two_launches(n_graphs, rows):
+    """magnet_mpnn_node_update_norm_small_f32 (the update of a hop and its InstanceNorm in one launch when the whole batch fits one
+    workgroup - BASELINE configs[0]) against magnet_mpnn_node_update_f32 followed by magnet_instance_norm_f32, and against fp64."""
+    import types
+    import bench
+    from magnet_amd import ops
+    from magnet_amd.models.factory import FACTORY
+    torch.manual_seed(4)
+    hp = dict(bench.HP)
+    m = FACTORY["mpnn_2d"](types.SimpleNamespace(**hp)).cuda().eval()
+    lyr = m._packed().layers[0]
+    N, H, kin = n_graphs * rows, 128, m.kin
+    assert kin == 32 and ops.mpnn_node_update_norm_small_supported(kin, N)
+    h, agg = torch.randn(N, H, device="cuda") * 2 + 1, torch.randn(N, H, device="cuda")
+    node_in = torch.randn(N, kin, device="cuda")
+    y = torch.empty(N, H, device="cuda")
+    ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, y)
+    want = ops.instance_norm(y, n_graphs, rows)
+    got = torch.full((N, H), float("nan"), device="cuda")
+    ops.mpnn_node_update_norm_small(h, agg, node_in, lyr.upd1, lyr.upd2, got, rows)
+    assert rel_l2(got, want) < 2e-6
+    y64 = y.double().view(n_graphs, rows, H)
+    ref = ((y64 - y64.mean(1, keepdim=True)) / torch.sqrt(y64.var(1, unbiased=False, keepdim=True) + 1e-5)).view(N, H)
+    assert rel_l2(got, ref) < 2e-6
+    again = torch.empty_like(got)
+    for _ in range(20):
+        ops.mpnn_node_update_norm_small(h, agg, node_in, lyr.upd1, lyr.upd2, again, rows)
+        assert torch.equal(again, got)
+    assert not ops.mpnn_node_update_norm_small_supported(kin, 129) and not ops.mpnn_node_update_norm_small_supported(64, 100)
+
+
+def test_mpnn_1d_rollout_with_the_fused_small_norm_equals_the_two_launch_path(monkeypatch):
+    """C1-sized mpnn (2 x 50 nodes): the rollout with the update kernel applying the InstanceNorm equals the path with a separate
+    InstanceNorm launch to rounding (MAGNET_SMALL_NORM=0)"""
+    from magnet_amd import ops
+    from magnet_amd.models.factory import FACTORY
+    from tests.helpers import load_case
+    name, hp, salt, batch, d = load_case("mpnn_1d")
+    n_rows = batch["u"].shape[0] * batch["u"].shape[1]
+    if not ops.mpnn_node_update_norm_small_supported(32, n_rows):
+        pytest.skip(f"the fixture's batch has {n_rows} rows: more than one workgroup")
+    from oracle.weightgen import fill_state_dict
+    from oracle import models as O
+    oracle = O.build(name, hp)
+    fill_state_dict(oracle, salt)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    outs = []
+    for knob in ("1", "0"):
+        monkeypatch.setenv("MAGNET_SMALL_NORM", knob)
+        model = FACTORY[name](hp)
+        model.load_state_dict(oracle.state_dict())
+        model = model.cuda().eval()
+        with torch.no_grad():
+            o = model.validation_step(cb, 0)
+        outs.append(o[0] if isinstance(o, (tuple, list)) else o)
+    assert torch.is_tensor(outs[0]) and rel_l2(outs[0], outs[1]) < 1e-6 and not torch.equal(outs[0], outs[1])     # (two different paths ran)
