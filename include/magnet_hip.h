@@ -198,6 +198,29 @@ int magnet_mpnn_edge_fp16x3_t32_f32(const float* A, const float* Bm, const int32
 int magnet_mpnn_edge_fp16x3_ws_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
                                    const int32_t* rowptr, int n_edges, int n_rows, const void* w2_t32, const float* b2,
                                    float* agg, float* partials, int a_bm_log2e_scaled, void* stream);
+/* The fp16x3 edge op on tiles ALIGNED TO CSR ROWS (k_mpnn_edge_rows32, generation 11) - GNN_Layer.message + the mean
+ * of models/mpnn.py:73-79,46 for the rows that own a tile.  tiles: n_tiles descriptors of four int32 {first edge, row, edges in the
+ * tile (1..32) | (edges of the row outside the tile) << 8, degree of the row}, at most one per row, rows ascending.  strag_row /
+ * strag_src: the STRAGGLERS - (target, source) of the one edge a row has beyond its tile when there is exactly one (the 33rd edge of
+ * an MPNN row) - rows ascending, strag_ptr[r] = stragglers of the rows before r ([n_rows + 1]; NULL = none); every wave sends the
+ * stragglers of its own rows through the same pipeline first and leaves their messages in agg[row].  Rows whose tile leaves two or more edges outside must hold the MEAN over those edges in agg[row] on entry
+ * (magnet_mpnn_edge_fp16x3_t16_f32 on the remainder edge list leaves exactly that).  On return agg[row] is the mean over all of the
+ * row's edges for every row with a tile; rows without a tile are not touched.  src: the full CSR's sources [n_edges];
+ * w2_t32 / b2 / a_bm_log2e_scaled (bit 0) as for magnet_mpnn_edge_fp16x3_t32_f32.  No scratch.
+ * magnet_row_tiles_count / _fill build the plan. */
+int magnet_mpnn_edge_rows_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const void* tiles, int n_tiles,
+                                     const int32_t* strag_ptr, const int32_t* strag_row, const int32_t* strag_src,
+                                     const void* w2_t32, const float* b2, float* agg, int a_bm_log2e_scaled, void* stream);
+/* The tile plan of a CSR graph for the kernel above.  _count, per row r: has_tile[r] = (deg_r >= pmin); has_strag[r] = the row has a
+ * tile and exactly one edge beyond it; n_rem[r] = its edges for the remainder pass (those outside the tile unless that is the one
+ * straggler; all of them without a tile).  _fill: given the exclusive prefix sums tile_ptr / strag_ptr / rem_ptr [n_rows + 1] of the
+ * three arrays, writes the descriptors, the straggler list and the remainder edge list
+ * (src_rem, tgt_rem; still sorted by target, rem_ptr is its rowptr). */
+int magnet_row_tiles_count(const int32_t* rowptr, int n_rows, int pmin, int32_t* has_tile, int32_t* has_strag, int32_t* n_rem,
+                           void* stream);
+int magnet_row_tiles_fill(const int32_t* rowptr, const int32_t* src, int n_rows, const int32_t* tile_ptr, const int32_t* strag_ptr,
+                          const int32_t* rem_ptr, void* tiles, int32_t* strag_row, int32_t* strag_src, int32_t* src_rem,
+                          int32_t* tgt_rem, void* stream);
 /* out[n][k] = u[n][tw-1] + dt*(k+1) * Conv1d(8->1,k2)([Swish](Conv1d(1->8,k1,stride s1)(h[n])))[k];
  * models/mpnn.py:197-201 with the conv specs of :140-163. */
 int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1, int k1,

@@ -24,7 +24,10 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 # per-source additions: the lane-per-node read-out is one fully unrolled block; below the default pragma-unroll threshold
 # hipcc unrolls it partially, indexes the row registers dynamically and puts them in scratch
-EXTRA_FLAGS = {"readout_kernels.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
+# mpnn_edge_rows.hip: hipcc's SLP vectoriser pairs the epilogue's per-value fma into v_pk_fma_f32 and pays two v_mov per pair to line the
+# operands up - packed fp32 beside MFMAs is slower than the scalar form to begin with
+EXTRA_FLAGS = {"readout_kernels.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
+               "mpnn_edge_rows.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

@@ -100,6 +100,9 @@ class MPNN(LightningModule):
         # fp16x3: the transposed 32-edge-tile kernel (k_mpnn_edge32t, generation 9) instead of k_mpnn_edge16 (A/B knob)
         # (2 = its two-waves-per-SIMD sibling k_mpnn_edge32p)
         self.edge_t32 = int(os.environ.get("MAGNET_EDGE_T32", "0")) if getattr(hparams, "edge_t32", True) else 0
+        # fp16x3: the row-aligned kernel (k_mpnn_edge_rows32, generation 11) where the graph's rows are long enough to own tiles
+        # (2-D meshes: 30 .. 33 edges per row); A/B knob, DESIGN.md 11.1
+        self.edge_rows = bool(int(os.environ.get("MAGNET_EDGE_ROWS", "0"))) and bool(getattr(hparams, "edge_rows", True))
         # small batches (<= 128 rows): update + InstanceNorm of a hop in one launch (A/B knob)
         self.fused_small_norm = bool(int(os.environ.get("MAGNET_SMALL_NORM", "1"))) and bool(getattr(hparams, "fused_small_norm", True))
         assert self.edge_gemm in GEMM_MODES
@@ -159,9 +162,13 @@ class MPNN(LightningModule):
                     L.msg2_t16, L.msg2_t16_single = pack_edge16_fp16x2(m2.weight, m2.bias, scaled=self.edge_single), self.edge_single
                 except ValueError:
                     L.msg2_t16, L.msg2_t16_single = pack_edge16_fp16x2(m2.weight, m2.bias), False
-            if self.edge_t32 and self.edge_gemm == "fp16x3":
+            if (self.edge_t32 or self.edge_rows) and self.edge_gemm == "fp16x3":
                 try:
-                    L.msg2_t32 = pack_edge32t_fp16x2(m2.weight, m2.bias)
+                    t32 = pack_edge32t_fp16x2(m2.weight, m2.bias)
+                    if self.edge_t32:
+                        L.msg2_t32 = t32
+                    if self.edge_rows and hasattr(L, "msg2_t16"):
+                        L.msg2_rows = t32
                 except ValueError:              # |w| >= 31.98: the pre-scaled high plane would overflow; this layer keeps the 16-edge kernel
                     pass
             cmap = torch.cat([torch.arange(2 * H), torch.tensor([2 * H + tw + dp])])   # var column inside node_in
@@ -238,7 +245,11 @@ class MPNN(LightningModule):
             else:
                 ops.mlp(N, ops.ktiles(T(h, H), T(node_in, kin)), [pa, pb], nl=1, ht=4, ot=4,
                         act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2, groups_in_block=True, y_group_stride=N * H)
-            if hasattr(lyr, "msg2_t32"):          # training forward too (plain halves: l2e is False with a tape)
+            plan = self._row_plan(topo) if hasattr(lyr, "msg2_rows") else None
+            if plan is not None:                  # tiles aligned to CSR rows (+ the remainder edges through k_mpnn_edge16)
+                ops.mpnn_edge_rows(A, Bm, csr, plan, lyr.msg2_t16[0], lyr.msg2_rows[0], lyr.msg2_t16[1], agg, partials, l2e=l2e,
+                                   single16=lyr.msg2_t16_single)
+            elif hasattr(lyr, "msg2_t32"):        # training forward too (plain halves: l2e is False with a tape)
                 ops.mpnn_edge32t(A, Bm, csr, lyr.msg2_t32[0], lyr.msg2_t32[1], agg, partials, l2e=l2e, paired=self.edge_t32 == 2)
             elif hasattr(lyr, "msg2_t16"):
                 ops.mpnn_edge16(A, Bm, csr, lyr.msg2_t16[0], lyr.msg2_t16[1], agg, partials, l2e=l2e, single=lyr.msg2_t16_single)
@@ -289,6 +300,17 @@ class MPNN(LightningModule):
             out = ops.mpnn_readout(h, u, tw, P.conv[0], P.conv[1], k1, s1, P.conv[2], P.conv[3], k2, self.readout_swish, dtv)
         self._guard.outputs(out)
         return out
+
+    def _row_plan(self, topo):
+        """the tile plan of the topology's CSR for k_mpnn_edge_rows32, built once per topology (ops.row_tiles) and kept with it;
+        None when fewer than half of the edges would land in tiles (1-D meshes: 6 edges per row - k_mpnn_edge16 alone is better)"""
+        plan = getattr(topo, "row_plan", False)
+        if plan is False:
+            plan = ops.row_tiles(topo.csr)
+            if 2 * (plan.rem.E) > topo.csr.E:
+                plan = None
+            topo.row_plan = plan
+        return plan
 
     # ------------------------------------------------------------------ graph (mpnn.py:216-251)
     def _radius(self, x0, nx):
@@ -449,8 +471,16 @@ class MPNN(LightningModule):
         same = seen is not None and seen[0] is batch["x"] and seen[1] == _graph_ident(batch["x"])
         held = next((o for o in e["keep"] if hasattr(o, "csr") and hasattr(o, "coords")), None) if same else None
         if held is not None and held.csr.E == fresh.csr.E and held.csr.N == fresh.csr.N and held.coords.shape == fresh.coords.shape:
-            for dst, src in ((held.csr.rowptr, fresh.csr.rowptr), (held.csr.src, fresh.csr.src), (held.csr.tgt, fresh.csr.tgt),
-                             (held.coords, fresh.coords)):
+            pairs = [(held.csr.rowptr, fresh.csr.rowptr), (held.csr.src, fresh.csr.src), (held.csr.tgt, fresh.csr.tgt),
+                     (held.coords, fresh.coords)]
+            hp = getattr(held, "row_plan", None)
+            if hp:                             # the tile plan is part of the graph: rebuilt from the fresh CSR like the CSR itself
+                fp = ops.row_tiles(fresh.csr, hp.pmin)
+                if (fp.n_tiles, fp.n_strag, fp.rem.E) == (hp.n_tiles, hp.n_strag, hp.rem.E):
+                    pairs += [(hp.tiles, fp.tiles), (hp.strag_ptr, fp.strag_ptr), (hp.strag_row, fp.strag_row),
+                              (hp.strag_src, fp.strag_src), (hp.rem.rowptr, fp.rem.rowptr), (hp.rem.src, fp.rem.src),
+                              (hp.rem.tgt, fp.rem.tgt)]
+            for dst, src in pairs:
                 dst.copy_(src)
         out = self._rollout_graph(self.rollout, b3, generation=self._pack_key)
         self._guard.raise_if_set(f"{type(self).__name__} rollout")

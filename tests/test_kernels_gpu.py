@@ -273,9 +273,9 @@ def test_mpnn_edge_log2e_scaled_inputs_give_the_same_mean():
 
 
 @pytest.mark.parametrize("case", ["ragged", "no_edges", "under_one_tile", "one_row_owns_everything", "every_row_one_edge",
-                                  "small_values"])
+                                  "small_values", "mpnn_like"])
 @pytest.mark.parametrize("l2e", [False, True])
-@pytest.mark.parametrize("kernel", ["edge16", "edge16s", "edge32t", "edge32p", "edgews"])
+@pytest.mark.parametrize("kernel", ["edge16", "edge16s", "edge32t", "edge32p", "edgews", "rows"])
 def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
     """k_mpnn_edge16 (16-edge tiles, v_mfma_f32_16x16x32_f16, two waves per SIMD, its own weight fragment order) and k_mpnn_edge32t
     (generation 9: transposed 32-edge tiles, lane = output feature, one accumulator, unscaled fp16-subnormal low pieces) against a
@@ -289,6 +289,14 @@ def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
     if case in ("ragged", "small_values"):
         n = 301
         rowptr, tgt = _random_csr(n, 45, seed=5, long_rows=3)
+    elif case == "mpnn_like":                  # the degrees of an MPNN_2d radius graph: 33 inside, 14 .. 32 on the frame, a few empty rows
+        g = torch.Generator().manual_seed(17)
+        n = 2500
+        deg = torch.where(torch.rand(n, generator=g) < 0.7, torch.full((n,), 33), torch.randint(14, 33, (n,), generator=g))
+        deg[torch.randint(0, n, (9,), generator=g)] = 0
+        rowptr = torch.zeros(n + 1, dtype=torch.int32)
+        rowptr[1:] = deg.cumsum(0)
+        tgt = torch.repeat_interleave(torch.arange(n), deg)
     else:
         n, deg = {"no_edges": (5, [0] * 5), "under_one_tile": (6, [3, 0, 7, 1, 0, 2]),
                   "one_row_owns_everything": (3, [0, 40001, 0]), "every_row_one_edge": (3001, [1, 2] * 1500 + [1])}[case]
@@ -312,6 +320,16 @@ def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
     if kernel in ("edge16", "edge16s"):       # edge16s: the one-accumulator variant (planes pre-scaled by 2^11)
         w, b = pack_edge16_fp16x2(lin.weight.cuda(), lin.bias.cuda(), scaled=kernel == "edge16s")
         ops.mpnn_edge16(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e, single=kernel == "edge16s")
+    elif kernel == "rows":                    # generation 11: tiles aligned to CSR rows + the remainder edges through k_mpnn_edge16
+        w16, b = pack_edge16_fp16x2(lin.weight.cuda(), lin.bias.cuda())
+        w32, _ = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
+        plan = ops.row_tiles(csr)
+        deg = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
+        has = deg >= plan.pmin
+        left = deg - torch.where(has, deg.clamp(max=32), 0)
+        strag = has & (left == 1)
+        assert plan.n_tiles == int(has.sum()) and plan.n_strag == int(strag.sum()) and plan.rem.E == int(left[~strag].sum())
+        ops.mpnn_edge_rows(A.cuda() * scale, Bm.cuda() * scale, csr, plan, w16, w32, b, agg, partials, l2e=l2e)
     elif kernel == "edgews":                  # generation 10: wave-specialised (gather / GEMM / epilogue waves through LDS)
         w, b = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
         ops.mpnn_edge_ws(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e)
