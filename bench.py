@@ -129,8 +129,9 @@ def synthetic_magnet_batch(name, B, Wq, seed, device):
     return {k: v.to(device) for k, v in batch.items()}, n_lr + Wq * Wq
 
 
-DTYPE_NOTE = {"fp16x3": "f32-class (GEMM operands as 2 fp16 pieces, 3 MFMA products, ~2^-22 relative, fp32 accumulate; |values| < 65504, "
-                        "guarded at run time)",
+DTYPE_NOTE = {"fp16x3": "f32-class, full fp32 range (GEMM operands as 2 fp16 pieces, 3 MFMA products, ~2^-22 relative, fp32 accumulate; a "
+                        "rollout whose values or weights reach 65504 is repeated in the bf16x6 split in the same call - "
+                        "`precision_modes.bf16x6` is what such data runs at)",
               "bf16x6": "f32-class (GEMM operands as 3 bf16 pieces, 6 MFMA products, ~2^-24 relative, fp32 accumulate; full fp32 range)",
               "fp32": "f32 (fp32 MFMA)",
               "bf16": "bf16 - REDUCED precision (inputs and weights rounded to one bf16 piece, fp32 accumulate): not the headline, "

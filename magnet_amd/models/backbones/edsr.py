@@ -72,8 +72,12 @@ class EDSR(nn.Module):
                               blocks=[(mk(b.conv_1, self.n_chan), mk(b.conv_2, self.n_chan)) for b in self.res_layers])
             self._pack_key = key
             if params[0].is_cuda:
-                from ...packing import raise_if_bad_weights
-                raise_if_bad_weights(params[0].device)   # fp16x3 range check of the packs just made: one host read per re-pack
+                from ...packing import bad_weights, widen
+                if bad_weights(params[0].device):        # fp16x3 range check of the packs just made: one host read per re-pack
+                    self._pack_key = None
+                    if widen("EDSR: a convolution weight does not fit the two fp16 planes (|w| >= 65504)"):
+                        return self.packed()             # the same packs in the full-range split
+                    raise ValueError("EDSR: non-finite convolution weights")
         return self._pack
 
     def _tap_table(self, B, spatial, device):

@@ -123,8 +123,19 @@ class MagnetBase(LightningModule):
             out = self._rollout_graph(fn, {k: batch[k] for k in keys}, generation=self._pack_key)
         else:
             out = fn(batch)
-        self._guard.raise_if_set(f"{type(self).__name__} rollout")
+        why = self._guard.tripped()
+        if why:                                 # out of the fp16 pieces' range: the same rollout in the full-range split
+            self._widen(why)
+            return self._graphed(fn, batch, keys, rows)
         return out
+
+    def _widen(self, reason: str):
+        """the range guard tripped (or a weight does not fit the fp16 planes): from here on the full-range bf16x6 split
+        (packing.widen, process-wide).  The caller repeats what it was doing."""
+        from ..packing import widen
+        widen(f"{type(self).__name__}: {reason}")
+        self._guard.clear()
+        self._weights_changed()                 # every pack (EDSR's launch plans included) is rebuilt in the new mode
 
     def _init_common(self, hparams):
         self.lr, self.weight_decay = hparams.lr, hparams.weight_decay
@@ -133,7 +144,8 @@ class MagnetBase(LightningModule):
         self.mse_criterion, self.mae_criterion = nn.MSELoss(), nn.L1Loss()
         self._pack_key, self._pack, self._pack_gen = None, None, 0
         self._topo_cache = TopologyCache()
-        # fp16x3 only: sticky device-side range / finiteness status, read once per rollout (ops.RangeGuard)
+        # fp16x3 only: sticky device-side range / finiteness status, read once per rollout (ops.RangeGuard); a trip repeats the
+        # rollout in the full-range bf16x6 split (_widen)
         from ..packing import default_gemm
         self._guard = ops.RangeGuard(default_gemm() == "fp16x3" and bool(getattr(hparams, "range_check", True)))
         self.optimizer_kind = getattr(hparams, "optimizer", "fused")     # "fused" (magnet_amd.optim.FusedAdam) | "torch"
@@ -143,12 +155,15 @@ class MagnetBase(LightningModule):
 
     # ---- packed-weight cache -------------------------------------------------------------
     def _packed(self):
+        from ..packing import bad_weights, default_gemm
         params = list(self.parameters())
-        key = (params[0].device, sum(p._version for p in params), self._pack_gen)
+        key = (params[0].device, sum(p._version for p in params), self._pack_gen, default_gemm())
         if self._pack_key != key:
             self._pack, self._pack_key = self._pack_weights(), key
-            from ..packing import raise_if_bad_weights
-            raise_if_bad_weights(params[0].device)   # the fp16x3 packs' range check: ONE host read per re-pack (not one per Linear)
+            if bad_weights(params[0].device):        # the fp16x3 packs' range check: ONE host read per re-pack (not one per Linear)
+                self._pack_key = None
+                self._widen("a weight does not fit the fp16 planes (|w| >= 65504; 31.98 for the one-accumulator chains)")
+                return self._packed()
         hold(self._pack)                    # a capture in progress keeps the packs its launches point into (magnet_amd/graphs.py)
         return self._pack
 

@@ -24,6 +24,7 @@ from torch import nn
 from .. import ops
 from ..lightning_compat import LightningModule
 from ..packing import GEMM_MODES, default_gemm, pack, pack_edge16_fp16x2, pack_edge32t_fp16x2, pad_to
+from ..packing import effective as effective_gemm
 from ..graphs import _ident as _graph_ident
 from ..graphs import RolloutGraph, capturing, hold, wants_graph
 from ..topo_cache import TopologyCache
@@ -90,7 +91,7 @@ class MPNN(LightningModule):
         self.kin = pad_to(tw + self.dpos + 1)
         # arithmetic of the Linears: "fp16x3" / "bf16x6" = fp32 GEMMs on the fp16 / bf16 matrix cores through an exact
         # split (fp32-class accuracy), "fp32" = fp32 MFMA; optional hparams, not in the reference's config
-        self.edge_gemm = getattr(hparams, "edge_gemm", default_gemm())
+        self._edge_gemm_hp = getattr(hparams, "edge_gemm", None)
         # inference: fold log2(e) into the per-node halves of message_net_1 for the edge kernel's base-2 Swish (A/B knob)
         self.edge_l2e = bool(int(os.environ.get("MAGNET_EDGE_L2E", "1"))) and bool(getattr(hparams, "edge_l2e", True))
         # inference, fp16x3: 16-edge tiles with two waves per SIMD (k_mpnn_edge16) instead of 32-edge tiles (A/B knob)
@@ -106,7 +107,7 @@ class MPNN(LightningModule):
         # small batches (<= 128 rows): update + InstanceNorm of a hop in one launch (A/B knob)
         self.fused_small_norm = bool(int(os.environ.get("MAGNET_SMALL_NORM", "1"))) and bool(getattr(hparams, "fused_small_norm", True))
         assert self.edge_gemm in GEMM_MODES
-        self.gemm = getattr(hparams, "gemm", self.edge_gemm)     # node-level Linears (same two choices)
+        self._gemm_hp = getattr(hparams, "gemm", None)           # node-level Linears (same two choices)
         # backward-data GEMMs: gradients of a mean loss are ~1e-7, inside fp16's subnormal range, so the fp16 split is
         # not offered there ("bf16x6" keeps the fp32 exponent range; "fp32" = fp32 MFMA)
         self.bwd_gemm = getattr(hparams, "bwd_gemm", "bf16x6")
@@ -116,6 +117,7 @@ class MPNN(LightningModule):
         self.edge_bwd = getattr(hparams, "edge_bwd", os.environ.get("MAGNET_EDGE_BWD", "fused_w"))
         assert self.edge_bwd in ("fused_w", "fused", "unfused")
         # fp16x3 only: sticky device-side range / finiteness status, read once per rollout (ops.RangeGuard)
+        # (a trip repeats the rollout in the full-range bf16x6 split: _widen)
         self._guard = ops.RangeGuard("fp16x3" in (self.gemm, self.edge_gemm) and bool(getattr(hparams, "range_check", True)))
         self._pack_key, self._pack, self._pack_gen = None, None, 0
         self._topo_cache, self._topo = TopologyCache(4), None       # _topo: the topology of the latest _build_graph
@@ -128,10 +130,28 @@ class MPNN(LightningModule):
         self.fused_node_stats = bool(getattr(hparams, "fused_node_stats", os.environ.get("MAGNET_FUSED_STATS", "0") != "0"))
         self._rollout_graph = RolloutGraph(topology_keys=("x",))
 
+    # ------------------------------------------------------------------ arithmetic of the Linears
+    @property
+    def edge_gemm(self):
+        """message_net_2 inside the edge kernel; "fp16x3" becomes "bf16x6" once the process has been widened (packing.widen)"""
+        return effective_gemm(self._edge_gemm_hp) if self._edge_gemm_hp else default_gemm()
+
+    @property
+    def gemm(self):
+        return effective_gemm(self._gemm_hp) if self._gemm_hp else self.edge_gemm
+
+    def _widen(self, reason: str):
+        """the range guard tripped (or a weight does not fit the fp16 planes): from here on the full-range split.  The caller
+        repeats what it was doing."""
+        from ..packing import widen
+        widen(f"{type(self).__name__}: {reason}")
+        self._guard.clear()
+        self._pack_gen += 1
+
     # ------------------------------------------------------------------ packed weights (cached)
     def _packed(self):
         params = list(self.parameters())
-        key = (params[0].device, sum(p._version for p in params), self._pack_gen)
+        key = (params[0].device, sum(p._version for p in params), self._pack_gen, self.gemm, self.edge_gemm)
         if self._pack_key == key:
             hold(self._pack)                # a capture in progress keeps the packs its launches point into (magnet_amd/graphs.py)
             return self._pack
@@ -181,8 +201,11 @@ class MPNN(LightningModule):
         assert nin <= kin
         self._pack_key, self._pack = key, P
         if dev.type == "cuda":
-            from ..packing import raise_if_bad_weights
-            raise_if_bad_weights(dev)          # the fp16x3 packs' range check: ONE host read per re-pack (not one per Linear)
+            from ..packing import bad_weights
+            if bad_weights(dev):               # the fp16x3 packs' range check: ONE host read per re-pack (not one per Linear)
+                self._pack_key = None
+                self._widen("a weight does not fit the two fp16 planes (|w| >= 65504)")
+                return self._packed()
         hold(P)
         return P
 
@@ -424,7 +447,10 @@ class MPNN(LightningModule):
             nxt = u[:, (i + 1) * tw:(i + 2) * tw] if teacher_forcing else y_hat
             graph = self._build_graph(nxt, t, x, [self._next_step(i)] * B)
         if tapes is None and not capturing():                  # with tapes: rollout_with_grad checks after its own bookkeeping
-            self._guard.raise_if_set(f"{type(self).__name__} rollout")
+            why = self._guard.tripped()
+            if why:                                            # out of the fp16 pieces' range: the same rollout in the full-range split
+                self._widen(why)
+                return self.rollout(batch, teacher_forcing)
         return torch.cat(u_hat, dim=1), target
 
     def training_step(self, train_batch, batch_idx):
@@ -448,7 +474,10 @@ class MPNN(LightningModule):
         if u.is_cuda and wants_graph(self.hip_graph, u.shape[0] * u.shape[1]):
             self._packed()
             out = self._rollout_graph(self.rollout, {k: batch[k] for k in ("u", "x", "t")}, generation=self._pack_key)
-            self._guard.raise_if_set(f"{type(self).__name__} rollout")
+            why = self._guard.tripped()
+            if why:
+                self._widen(why)
+                return self._inference_rollout(batch)
             return out
         return self.rollout(batch)
 
@@ -483,7 +512,10 @@ class MPNN(LightningModule):
             for dst, src in pairs:
                 dst.copy_(src)
         out = self._rollout_graph(self.rollout, b3, generation=self._pack_key)
-        self._guard.raise_if_set(f"{type(self).__name__} rollout")
+        why = self._guard.tripped()
+        if why:
+            self._widen(why)
+            return self._replay_with_rebuild(batch)
         return out
 
     def validation_step(self, val_batch, batch_idx):

@@ -263,9 +263,14 @@ class _Rollout(torch.autograd.Function):
         tapes = []
         with torch.no_grad():
             u_hat, target = m.rollout(batch, teacher_forcing, tapes=tapes)
+        why = m._guard.tripped()
+        if why:                                # out of the fp16 pieces' range: the same forward (and its tapes) in the full-range split
+            m._widen(why)
+            tapes = []
+            with torch.no_grad():
+                u_hat, target = m.rollout(batch, teacher_forcing, tapes=tapes)
         ctx.m, ctx.tapes, ctx.tf = m, tapes, teacher_forcing
         m._last_target = target
-        m._guard.raise_if_set(f"{type(m).__name__} training rollout")
         return u_hat.contiguous()
 
     @staticmethod

@@ -216,12 +216,19 @@ ST_IN_RANGE, ST_IN_NONFINITE, ST_OUT_NONFINITE = 1, 2, 4
 class RangeGuard:
     """Sticky device-side status word for the fp16x3 GEMM mode (two fp16 pieces per value: magnitudes >= 65504 overflow to
     inf silently).  ``inputs(x)`` flags out-of-range / non-finite entries of an array that enters a GEMM chain,
-    ``outputs(y)`` non-finite entries of a result; ``raise_if_set()`` reads the word once (one host sync - the models call
-    it once per rollout) and raises, pointing to the full-range ``bf16x6`` mode.  Inactive (no launches, no sync) in the
-    other GEMM modes."""
+    ``outputs(y)`` non-finite entries of a result; ``tripped()`` reads the word once (one host sync - the models call it once per
+    rollout) and says whether the rollout has to be repeated in the full-range ``bf16x6`` split (the models then call
+    packing.widen() and run again: the reference computes in fp32 over the whole fp32 range, configs/trainer/default.yaml:5, so data
+    of that magnitude must get the reference's result, not an error).  Inactive (no launches, no sync) in the other GEMM modes and
+    once the process has been widened."""
 
     def __init__(self, active: bool):
-        self.active, self._status = bool(active), None
+        self.enabled, self._status = bool(active), None
+
+    @property
+    def active(self):
+        from .packing import wide
+        return self.enabled and not wide()
 
     def _word(self, dev):
         if self._status is None or self._status.device != dev:
@@ -239,21 +246,26 @@ class RangeGuard:
             L.check(L.lib().magnet_status_check_f32(_p(y), C.c_long(y.numel()), C.c_float(float("inf")), ST_OUT_NONFINITE,
                                                     ST_OUT_NONFINITE, 0, _p(self._word(y.device)), _stream()), "status_check")
 
-    def raise_if_set(self, what: str):
+    def tripped(self) -> str | None:
+        """None: nothing flagged (or inactive).  Otherwise the reason the fp16x3 result cannot be trusted: an input of a GEMM chain
+        had magnitude >= 65504, or finite inputs gave a non-finite prediction (an intermediate left the fp16 range - or the data
+        contain a genuine 0/0, e.g. duplicate LR nodes in the INR blend, which the reference turns into NaN as well: the repeat in
+        bf16x6 then reproduces that NaN).  Non-finite INPUTS are not a reason: the reference propagates them too."""
         if not self.active or self._status is None:
-            return
+            return None
         st = int(self._status.item())
         if st == 0:
-            return
+            return None
         self._status.zero_()
-        hint = ('select the full-range split with hparams.gemm = hparams.edge_gemm = "bf16x6" (or MAGNET_GEMM=bf16x6); '
-                "fp16x3 represents values with two fp16 pieces and needs |value| < 65504")
         if st & ST_IN_RANGE:
-            raise OverflowError(f"magnet_amd {what}: an input of the fp16x3 GEMM chain has magnitude >= 65504 - {hint}")
+            return "an input of the fp16x3 GEMM chain has magnitude >= 65504"
         if st & ST_OUT_NONFINITE and not st & ST_IN_NONFINITE:
-            raise OverflowError(f"magnet_amd {what}: non-finite prediction from finite inputs in fp16x3 mode - an intermediate "
-                                f"left the fp16 range (or the data contain a 0/0, e.g. duplicate LR nodes in the INR blend, "
-                                f"which the reference turns into NaN as well; hparams.range_check = False disables this guard) - {hint}")
+            return "non-finite prediction from finite inputs in fp16x3 mode (an intermediate left the fp16 range)"
+        return None
+
+    def clear(self):
+        if self._status is not None:
+            self._status.zero_()
 
 
 # ------------------------------------------------------------------------------------ MPNN pieces

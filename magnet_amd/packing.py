@@ -210,11 +210,45 @@ def chain_gemm(n_linears: int, hidden: int, mode: str) -> str:
     return mode
 
 
+_wide = False            # process-wide: the fp16x3 modes have been widened to bf16x6 (a value left the fp16 range, see widen())
+
+
+def wide() -> bool:
+    return _wide
+
+
+def widen(reason: str) -> bool:
+    """Switch every fp16x3 / fp16x3s GEMM of this process to the full-range bf16x6 split (same fp32-class accuracy, the whole fp32
+    exponent range, ~1.7 x the rollout time).  Called by the models when their range guard trips - an input, an intermediate or a
+    weight reached the limit of the two-fp16-piece representation (65504; 31.98 for the pre-scaled planes) - so that such data gets
+    the reference's result instead of an error (configs/trainer/default.yaml:5: the reference computes in fp32 over the whole fp32
+    range).  Sticky until narrow(): data of that scale rarely comes alone.  -> True when this call made the switch."""
+    global _wide
+    if _wide:
+        return False
+    import warnings
+    warnings.warn(f"magnet_amd: {reason}; switching the fp16x3 GEMMs of this process to the full-range bf16x6 split "
+                  "(same accuracy, slower) - magnet_amd.packing.narrow() goes back", RuntimeWarning, stacklevel=3)
+    _wide = True
+    return True
+
+
+def narrow() -> None:
+    """back to the configured GEMM modes (the models re-pack on their next call)"""
+    global _wide
+    _wide = False
+
+
+def effective(mode: str) -> str:
+    """the mode a Linear configured as ``mode`` runs in right now"""
+    return "bf16x6" if _wide and mode in ("fp16x3", "fp16x3s") else mode
+
+
 def default_gemm() -> str:
     import os
     mode = os.environ.get("MAGNET_GEMM", "fp16x3")
     assert mode in GEMM_MODES, mode
-    return mode
+    return effective(mode)
 
 
 # ---- device path: one HIP launch per Linear (magnet_pack_linear_f32, csrc/pack_kernels.hip) instead of the torch index shuffles above.
@@ -244,14 +278,22 @@ def flag_if_abs_reaches(w: torch.Tensor, limit: float) -> None:
         raise ValueError(f"fp16x3 GEMM mode: this kernel needs finite weights with |w| < {limit}; use MAGNET_GEMM=bf16x6")
 
 
-def raise_if_bad_weights(dev) -> None:
-    """ONE host read for all packs since the last call (the models call it once per re-pack of their weights): the fp16x3 mode
-    represents a weight with two fp16 pieces and needs finite |w| < 65504"""
+def bad_weights(dev) -> bool:
+    """ONE host read for all packs since the last call (the models call it once per re-pack of their weights) -> True when an
+    fp16x3 pack met a weight outside its range; the flag is cleared"""
     dev = torch.device(dev)
     if dev.type == "cuda" and dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
     if dev in _status and int(_status[dev].item()):
         _status[dev].zero_()
+        return True
+    return False
+
+
+def raise_if_bad_weights(dev) -> None:
+    """bad_weights() as an exception (callers without a fallback): the fp16x3 mode represents a weight with two fp16 pieces and
+    needs finite |w| < 65504"""
+    if bad_weights(dev):
         raise ValueError("fp16x3 GEMM mode needs finite weights with |w| < 65504 (|w| < 31.98 for message_net_2 when training with "
                          "edge_bwd='fused_w' and for the 64-wide 5-Linear chains of the MAgNet models); use MAGNET_GEMM=bf16x6, "
                          "edge_bwd='fused' or MAGNET_CHAIN_GEMM=fp16x3")
