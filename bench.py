@@ -20,9 +20,9 @@ Extra objects on the JSON line:
                   DESIGN.md) / mean launch time measured with HIP events on the launch stream, in an untimed pass that runs
                   BEFORE the training leg.  `clock_mhz` = the shader clock sampled by a one-wave probe kernel on a second
                   stream while that pass runs (the part is power limited: ~2.1 GHz, not the 2.4 GHz `peak` assumes);
-                  `peak_at_clock` / `frac_at_clock` rescale to it.  `limiter`: what really bounds the kernel ("issue": it
-                  runs at the sum of its matrix-pipe, VALU and transcendental time; `mfma_share` = matrix-pipe
-                  cycles / kernel cycles = the roofline fraction).  The
+                  `peak_at_clock` / `frac_at_clock` rescale to it.  The kernel runs at the near-additive sum of its matrix-pipe
+                  time, its LDS weight-fragment reads, its gathers and its transcendentals, so the fraction is
+                  the matrix pipe's share of that sum.  The
                   kernel evaluates every fp32 product through a split into 16-bit pieces on the matrix cores
                   (default fp16x3: 2 pieces, 3 fp16 MFMA products, ~2^-22 relative; bf16x6: 3 pieces, 6 products), so its
                   ceiling is the dense 16-bit MFMA peak / 3 = 833 TFLOP/s of fp32-equivalent work (`peak`);
@@ -36,9 +36,10 @@ Extra objects on the JSON line:
                   relative L2 against the oracle on a 48 x 48 mesh.  The reference computes in fp32
                   (configs/trainer/default.yaml:5); the headline mode fp16x3 holds ~22-bit operands.
   cpu_baseline  - the oracle (torch-CPU restatement of the reference op sequence) timed on this
-                  box's host cores on a bounded sample (rollouts of one 128 x 128 trajectory;
-                  forward calls only, graph construction excluded), rank 0, N = 1 only; the thread count is the better of
-                  {physical cores / 2, physical cores} by a one-forward sweep (both reported).
+                  box's host cores on a bounded sample: `value` = ONE free-running rollout of one 256 x 256 trajectory (the
+                  metric's mesh, ~50 s); thread count from a one-forward sweep over {physical cores / 2, physical cores} on a
+                  128 x 128 mesh, whose 1 + 3 rollouts are reported beside it (`value_128x128`); forward calls only, graph
+                  construction excluded; rank 0, N = 1 only.
   dist          - what the process group saw: backend, world size, per-rank ms_per_step; `training_step.allreduce_ms` =
                   the gradient all-reduce of one step (HIP events).
   traffic (inside both roofline objects) - HBM bytes per launch from the newest committed PMC measurement of this same
@@ -49,8 +50,14 @@ Extra objects on the JSON line:
   c4b, c5       - the other two 256^2 cases of SURVEY.md 8(d) as complete objects of the same contract (value, ms_per_step, roofline of
                   their dominant kernel - the InteractionNetwork edge chain of the joint graph -, training_step): `magnet_cnn_2d` 64^2 LR
                   grid -> 256^2 queries and `magnet_gnn` 256 irregular LR nodes -> 256^2 queries, one trajectory per GPU.
+                  `ms_per_step` replays the rollout from one hipGraph with the topology of the first call; `ms_per_step_rebuild` is the
+                  eager loop with radius search / CSR / k-NN rebuilt every step (what the reference does and what the headline's
+                  figure includes), `ms_per_step_eager` the same loop with the cached topology.
   c1            - BASELINE.json configs[0] on the GPU: `mpnn` 1-D, 2 x 50 nodes, 9-forward rollout replayed from one hipGraph (ms per
                   rollout, and the kernel-by-kernel time beside it); rank 0 only.
+  ref_shapes    - the shapes the reference's own run scripts train and validate on (64 x 64 meshes at batch 4 / 8 / 32, 512-point
+                  irregular meshes at batch 32; bench_ref_shapes): training step ms / C-ABI calls / peak memory, validation rollout
+                  enqueued kernel by kernel and replayed from one hipGraph; rank 0, N = 1 only.
   training_step - the same workload trained: rollout with tape, HIP backward
                   kernels, ONE flat gradient all-reduce over RCCL, fused Adam; ms per step and the node-updates/s it
                   corresponds to (all ranks), `--train-steps` timed steps after one warm-up.  Never part of `value`.
@@ -186,7 +193,7 @@ def physical_cores():
         return max(1, (os.cpu_count() or 2) // 2)
 
 
-def cpu_baseline(W=128, timed=3):
+def cpu_baseline(W=128, timed=3, metric_mesh=256):
     """the oracle's free-running rollout of ONE trajectory on a W x W mesh on the host cores, fp32,
     no_grad, 1 warm-up rollout + ``timed`` timed rollouts, median; the radius-graph build is timed separately (the oracle
     builds it by brute force) and excluded from the rollout time, as the reference's own CPU numbers in BASELINE.md are.
@@ -231,22 +238,46 @@ def cpu_baseline(W=128, timed=3):
         dt = rollout()
         if k > 0:
             times.append(dt)
-    torch.set_num_threads(default_threads)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": W * W * tw * n_calls / med, "unit": "mesh-node-updates/s", "cores": best, "physical_cores": phys,
-            "logical_cpus": logical, "one_forward_s_by_threads": {str(k): v for k, v in sweep.items()},
-            "cpu_model": cpu_model_string(), "kind": "port", "rollouts_s": [round(v, 2) for v in times], "graph_build_s": round(t_graph, 2),
-            "sample": f"oracle mpnn_2d, {W}x{W} mesh, 1 trajectory, 1 warm-up + {timed} timed free-running rollouts of {n_calls} forward "
-                      f"calls each, median {med:.1f} s (radius-graph build {t_graph:.1f} s timed separately, excluded), fp32, no_grad, "
-                      f"torch {torch.__version__} CPU, {best} threads (best of {sorted(sweep)} on one forward call; {phys} physical "
-                      f"cores, {logical} logical CPUs)"}
+    out = {"value": W * W * tw * n_calls / med, "unit": "mesh-node-updates/s", "cores": best, "physical_cores": phys,
+           "logical_cpus": logical, "one_forward_s_by_threads": {str(k): v for k, v in sweep.items()},
+           "cpu_model": cpu_model_string(), "kind": "port", "rollouts_s": [round(v, 2) for v in times], "graph_build_s": round(t_graph, 2),
+           "sample": f"oracle mpnn_2d, {W}x{W} mesh, 1 trajectory, 1 warm-up + {timed} timed free-running rollouts of {n_calls} forward "
+                     f"calls each, median {med:.1f} s (radius-graph build {t_graph:.1f} s timed separately, excluded), fp32, no_grad, "
+                     f"torch {torch.__version__} CPU, {best} threads (best of {sorted(sweep)} on one forward call; {phys} physical "
+                     f"cores, {logical} logical CPUs)"}
+    if metric_mesh and metric_mesh != W:
+        # the metric's own mesh (BASELINE.md section 3 promised it): ONE timed rollout of one 256 x 256 trajectory at the thread count
+        # found above (~50 s; the thread pool and the allocator are warm from the smaller mesh), the graph built by the oracle's own
+        # brute-force search (timed, excluded as above).  `value` is this figure; the smaller mesh's stays beside it.
+        Wm = metric_mesh
+        bm = synthetic_batch(Wm, 1, 0, "cpu")
+        um, xm, tm_ = bm["u"].permute(0, 2, 1), bm["x"], bm["t"]
+        t0 = time.perf_counter()
+        gm = model._build_graph(um[:, :tw], tm_, xm, [tw - 1])
+        tg = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for i in range(n_calls):
+                y = model(gm, xm[0, -1], tm_[0, -1], tm_[0][1] - tm_[0][0])
+                gm.x = y
+                gm.pos = torch.cat([torch.full((Wm * Wm, 1), float(tm_[0, (i + 2) * tw - 1])), gm.pos[:, 1:]], 1)
+        dtm = time.perf_counter() - t0
+        out[f"value_{W}x{W}"], out["value"] = out["value"], Wm * Wm * tw * n_calls / dtm
+        out["metric_mesh_rollout_s"], out["metric_mesh_graph_build_s"] = round(dtm, 2), round(tg, 2)
+        out["sample"] = (f"oracle mpnn_2d, ONE free-running rollout ({n_calls} forward calls) of one {Wm}x{Wm} trajectory - the metric's mesh - "
+                         f"in {dtm:.1f} s at {best} threads (radius-graph build {tg:.1f} s excluded); thread count and a median of {timed} from: "
+                         + out["sample"])
+    torch.set_num_threads(default_threads)
+    return out
 
 
 class ClockProbe:
     """Shader clock under load: a one-wave kernel on a side stream reads the shader-clock counter and the constant-rate wall
     clock for ``wall_us`` microseconds while the main stream runs the workload (magnet_clock_probe, include/magnet_hip.h).
-    Beside it, best effort, the driver's own figure (the starred level of sysfs pp_dpm_sclk), sampled by a host thread."""
+    (The driver's sysfs figure that used to be reported beside it named another device on some boxes of the pool - 107 MHz in the
+    round-3 record - and is gone.)"""
 
     def __init__(self, dev):
         import ctypes as C
@@ -254,42 +285,13 @@ class ClockProbe:
         self.out = torch.zeros(2, dtype=torch.int64, device=dev)
         self.stream = torch.cuda.Stream(device=dev)
         self.khz = C.c_int(0)
-        self.samples, self.sysfs = [], []
-        self._stop = None
-
-    @staticmethod
-    def _sysfs_mhz():
-        import glob
-        import re
-        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
-            try:
-                for line in open(f):
-                    if "*" in line:
-                        m = re.search(r"(\d+)\s*[Mm][Hh]z", line)
-                        if m:
-                            return int(m.group(1))
-            except OSError:
-                continue
-        return None
+        self.samples = []
 
     def __enter__(self):
-        import threading
-        self._stop = threading.Event()
-
-        def loop():
-            while not self._stop.is_set():
-                v = self._sysfs_mhz()
-                if v:
-                    self.sysfs.append(v)
-                self._stop.wait(0.004)
-
-        self._thread = threading.Thread(target=loop, daemon=True)
-        self._thread.start()
         return self
 
     def __exit__(self, *exc):
-        self._stop.set()
-        self._thread.join()
+        pass
 
     def sample(self, wall_us):
         """enqueue one probe now (call right before the work it should overlap); read it with ``collect`` after a sync"""
@@ -308,9 +310,7 @@ class ClockProbe:
                 self.samples.append(mhz)
 
     def result(self):
-        probe = sum(self.samples) / len(self.samples) if self.samples else None
-        sysfs = sorted(self.sysfs)[len(self.sysfs) // 2] if self.sysfs else None
-        return probe, sysfs
+        return sum(self.samples) / len(self.samples) if self.samples else None
 
 
 def edge_roofline(model, batch, dev, W, B, passes=3):
@@ -354,6 +354,9 @@ def edge_roofline(model, batch, dev, W, B, passes=3):
         model.hip_graph = mode_was
         for e_, o_ in origs.items():
             setattr(ops.L._lib, e_, o_)
+    if not ev:
+        raise RuntimeError("edge_roofline: the model dispatched its edge op through an entry point that is not wrapped here "
+                           f"(wrapped: {sorted(origs)}); add it to ops.EDGE_ENTRY_EXTRA")
     ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
     flops = 2.0 * E * H * H
     ach = flops / (ms * 1e-3) / 1e12
@@ -361,20 +364,20 @@ def edge_roofline(model, batch, dev, W, B, passes=3):
     nprod = SPLIT_PRODUCTS.get(mode, 1)
     peak = MFMA_BF16_PEAK_TFLOPS / nprod if mode in SPLIT_PRODUCTS else MFMA_F32_PEAK_TFLOPS
     kname = ops.EDGE_KERNEL_OF_ENTRY.get(next(iter(used)) if len(used) == 1 else None, "k_mpnn_edge?")
-    clk, clk_sysfs = probe.result()
-    roof = {"kernel": kname, "bound": "mfma", "limiter": "issue",
+    clk = probe.result()
+    roof = {"kernel": kname, "bound": "mfma",
             "achieved": round(ach, 2), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
             "launch_ms": round(ms, 4), "launches_timed": len(ev), "flops_per_launch": flops, "gemm_mode": mode,
             "algorithmic_hbm_bytes": 3 * N * H * 4 + 2 * E * 4 + 4 * (N + 1),
             "executed_mfma_tflops": round(ach * nprod, 1), "mfma_16bit_dense_peak": MFMA_BF16_PEAK_TFLOPS,
             "fp32_mfma_peak_for_reference": MFMA_F32_PEAK_TFLOPS,
-            "clock_mhz": round(clk, 1) if clk else None, "clock_mhz_sysfs": clk_sysfs, "peak_clock_mhz": PEAK_CLOCK_MHZ,
-            "mfma_share": round(ach / peak, 4),
+            "clock_mhz": round(clk, 1) if clk else None, "peak_clock_mhz": PEAK_CLOCK_MHZ,
             "note": "fp32-class GEMM: operands split into 16-bit pieces on the matrix cores "
-                    f"({nprod} MFMA products per fp32 product, fp32 accumulate); peak = 2500 / {nprod}.  limiter 'issue': the kernel runs at "
-                    "the SUM of its matrix-pipe, VALU and transcendental time (two Swish per edge-feature), so the matrix-pipe share "
-                    "of its cycles (mfma_share) IS the fraction; measured before the training leg"}
+                    f"({nprod} MFMA products per fp32 product, fp32 accumulate); peak = 2500 / {nprod}.  The kernel runs at the near-additive "
+                    "sum of its matrix-pipe time, its LDS weight-fragment reads, its gathers and its two Swish per edge-feature "
+                    "(ablations: profiles/r4/edge_rows.txt, DESIGN.md 11.1), so the fraction is the matrix pipe's share of that sum; "
+                    "measured before the training leg"}
     if clk:
         roof["peak_at_clock"] = round(peak * clk / PEAK_CLOCK_MHZ, 1)
         roof["frac_at_clock"] = round(ach / (peak * clk / PEAK_CLOCK_MHZ), 4)
@@ -481,6 +484,25 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
     T = hp["time_slice"]
     pred_steps = (NT - T) // T * T
     value = world * B * nodes * pred_steps * K / elapsed
+    # ---- the same rollout with the graphs REBUILT every step, as the reference does per forward call (models/magnet_gnn.py:293, :247) and
+    # as the headline leg does per rollout: radius search over LR nodes and over LR nodes + queries, CSR, k-NN - kernel by kernel (a
+    # captured rollout has its topology baked in), with the cached-topology figure of the same eager loop beside it
+    rebuild = {}
+    mode_was = model.hip_graph
+    model.hip_graph = False
+    try:
+        for label, drop in (("ms_per_step_eager", False), ("ms_per_step_rebuild", True)):
+            model.validation_step(batch, 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                if drop:
+                    model.drop_topology_cache()
+                model.validation_step(batch, 0)
+            torch.cuda.synchronize()
+            rebuild[label] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+    finally:
+        model.hip_graph = mode_was
     roof = None
     if rank == 0:      # dominant kernel: the InteractionNetwork edge MLP (5 Linears + LayerNorm + CSR mean) of the joint graph
         D, H = hp["latent_dim"], hp["mlp_hidden"]
@@ -574,7 +596,7 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
         return None
     return {
         "metric": f"mesh-node-updates/s (nodes x steps x batch), {name} 256^2-query rollout", "value": value,
-        "unit": "mesh-node-updates/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
+        "unit": "mesh-node-updates/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3, **rebuild,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": DTYPE_NOTE[__import__("magnet_amd.packing", fromlist=["default_gemm"]).default_gemm()], "data": "synthetic",
         "config": {"workload": f"{name} free-running rollout, {nodes - Wq * Wq} LR nodes + {Wq}x{Wq} queries, nt={NT}, "
@@ -613,6 +635,132 @@ def bench_c1(dev, reps=50):
             "ms_per_rollout": round(out["graph"][0] * 1e3, 3), "ms_per_rollout_eager": round(out["eager"][0] * 1e3, 3),
             "value": B * N * steps / out["graph"][0], "unit": "mesh-node-updates/s", "graph_replay_equals_eager_bitwise": same,
             "how": "whole rollout replayed from one hipGraph (default when B*N <= 4096 rows)"}
+
+
+def bench_ref_shapes(dev):
+    """What the reference's own run scripts train and validate on (rank 0, N = 1 only) - the shapes a user of the reference meets,
+    next to the 256^2 metric cases that nobody trains:
+      c4a          mpnn_2d, 64 x 64 regular mesh, batch 4                      scripts/mpnn_2d/mpnn_2d_b1_64_regular.sh:27-36
+      gnn_64       magnet_gnn, 64 x 64 mesh: 2048 LR nodes ([::2]) + 256 sampled queries (validation: + the other 2048), batch 8
+                                                                                scripts/magnet_gnn/magnet_gnn_2d_b1_64_regular.sh:26-36, datamodule/dataset_2d.py:107-121
+      gnn_512      magnet_gnn, 512 irregular points: 256 LR + 256 queries, batch 32; validation on the 32 x 32 test mesh (512 + 512)
+                                                                                scripts/magnet_gnn/magnet_gnn_2d_b1_512_irregular_concentrated.sh:26-36
+      cnn_64       magnet_cnn_2d, 64 x 64 frames: 32 x 32 LR grid (bilinear) + 256 sampled queries (validation: all 4096), batch 32,
+                   teacher forcing                                             scripts/magnet_cnn_2d/magnet_cnn_2d_b1_64_regular.sh:26-36, configs/datamodule/h5_datamodule_implicit_2d.yaml:15
+    Per case: the training step (forward with tape + HIP backward + fused Adam; ms, C-ABI calls, peak memory) and the validation
+    rollout enqueued kernel by kernel and replayed from one hipGraph (ms each; `hip_graph="auto"` picks the replay up to
+    magnet_amd.graphs.AUTO_MAX_ROWS node rows)."""
+    from magnet_amd import ops
+    from magnet_amd.models.factory import FACTORY
+    from magnet_amd.utils import make_coord
+    g = torch.Generator().manual_seed(4)
+
+    def mesh_pts(n_side):
+        lin = torch.linspace(-1, 1, n_side)
+        return torch.stack(torch.meshgrid(lin, lin, indexing="xy"), -1).reshape(-1, 2)
+
+    def gnn_batch(B, pts, nq, train):
+        N = pts.shape[0]
+        lr_c = pts[::2]
+        rest = torch.arange(N)[1::2]
+        q = rest[torch.randperm(rest.numel(), generator=g)[:nq]].sort().values if train else rest
+        u = torch.randn(B, NT, 1, N, generator=g)
+        return {"t": torch.linspace(0, 1, NT)[None].repeat(B, 1), "lr_frames": u[..., ::2].contiguous(),
+                "hr_points": u[:, :, 0, q].unsqueeze(-1).contiguous(), "coords_hr": pts[q][None].repeat(B, 1, 1),
+                "coords_lr": lr_c[None].repeat(B, 1, 1)}, lr_c.shape[0] + q.numel()
+
+    def cnn_batch(B, W, nq, train):
+        allc = make_coord([W, W])
+        q = torch.randperm(W * W, generator=g)[:nq].sort().values if train else torch.arange(W * W)
+        return {"t": torch.linspace(0, 1, NT)[None].repeat(B, 1), "lr_frames": torch.randn(B, NT, 1, W // 2, W // 2, generator=g),
+                "hr_points": torch.randn(B, NT, q.numel(), 1, generator=g), "coords": allc[q][None].repeat(B, 1, 1),
+                "cells": torch.full((B, q.numel(), 2), 2.0 / W)}, (W // 2) ** 2 + q.numel()
+
+    irr = torch.clamp(torch.randn(512, 2, generator=g) * 0.25, -1, 1)
+    irr = 2 * (irr - irr.min(0).values) / (irr.max(0).values - irr.min(0).values) - 1
+    cases = {
+        "c4a": ("mpnn_2d", dict(HP), lambda train: (synthetic_batch(64, 4, 11, "cpu"), 64 * 64)),
+        "gnn_64": ("magnet_gnn", dict(MAGNET_HP["magnet_gnn"]), lambda train: gnn_batch(8, mesh_pts(64), 256, train)),
+        "gnn_512": ("magnet_gnn", dict(MAGNET_HP["magnet_gnn"]), lambda train: gnn_batch(32, irr if train else mesh_pts(32), 256, train)),
+        "cnn_64": ("magnet_cnn_2d", dict(MAGNET_HP["magnet_cnn_2d"], teacher_forcing=True), lambda train: cnn_batch(32, 64, 256, train)),
+    }
+    lib = ops.L.lib()
+    names = [n for n in ops.L.declared_symbols() if hasattr(lib, n)]
+    out = {}
+    for key, (name, hp, mk) in cases.items():
+        torch.manual_seed(0)
+        res = {"model": name}
+        # ---- training step
+        batch, nodes = mk(True)
+        batch = {k: v.to(dev) for k, v in batch.items()}
+        B = batch["t"].shape[0]
+        tm = FACTORY[name](types.SimpleNamespace(**hp)).to(dev).train()
+        opt = tm.configure_optimizers()["optimizer"]
+
+        def train_step():
+            opt.zero_grad(set_to_none=True)
+            loss = tm.training_step(batch, 0)
+            loss.backward()
+            opt.step()
+            return loss
+
+        train_step()
+        train_step()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        calls = [0]
+        origs = {n: getattr(lib, n) for n in names}
+
+        def counted(fn):
+            def f(*a):
+                calls[0] += 1
+                return fn(*a)
+            return f
+
+        for n, fn in origs.items():
+            setattr(ops.L._lib, n, counted(fn))
+        try:
+            train_step()
+        finally:
+            for n, fn in origs.items():
+                setattr(ops.L._lib, n, fn)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            train_step()
+        torch.cuda.synchronize()
+        res["train"] = {"batch": B, "nodes_per_sample": nodes, "ms_per_step": round((time.perf_counter() - t0) / 5 * 1e3, 3),
+                        "c_abi_calls_per_step": calls[0], "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 3)}
+        del tm, opt, train_step
+        # ---- validation rollout: kernel by kernel, and replayed from one hipGraph
+        batch, nodes = mk(False)
+        batch = {k: v.to(dev) for k, v in batch.items()}
+        val = {"batch": batch["t"].shape[0], "nodes_per_sample": nodes, "rows": batch["t"].shape[0] * nodes}
+        ref = None
+        for label, flag in (("eager", False), ("graph", True)):
+            torch.manual_seed(0)
+            vm = FACTORY[name](types.SimpleNamespace(**hp, hip_graph=flag)).to(dev).eval()
+            for _ in range(3):
+                y = vm.validation_step(batch, 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                vm.validation_step(batch, 0)
+            torch.cuda.synchronize()
+            val[f"ms_per_rollout_{label}"] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
+            if ref is None:
+                ref = y
+            else:
+                val["graph_replay_equals_eager_bitwise"] = bool(torch.equal(ref, y))
+            del vm
+        from magnet_amd.graphs import wants_graph
+        val["auto_picks"] = "graph" if wants_graph("auto", val["rows"]) else "eager"
+        res["validation"] = val
+        out[key] = res
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
 
 
 def free_port():
@@ -833,6 +981,8 @@ def main():
                                        dist, max_over_ranks)
         if rank == 0:
             extras["c1"] = bench_c1(dev)
+            if world == 1:
+                extras["ref_shapes"] = bench_ref_shapes(dev)
 
     if world > 1:
         dist.barrier()

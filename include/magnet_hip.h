@@ -276,6 +276,14 @@ int magnet_mpnn_node_update_f32(const float* h, const float* agg, const float* n
                                 const float* var, float eps, int n_graphs, int rows_per_graph, const void* w1_f16,
                                 const float* b1, const void* w2_f16, const float* b2, float* y, float* part_sum, float* part_m2,
                                 void* stream);
+/* The same update with the ONE-accumulator packs (packing mode "fp16x3s": planes and biases of both Linears carry 2^11, |w| < 31.98)
+ * by k_node_update2: two workgroups per CU (the planes of update_net_2 are streamed through LDS like those of update_net_1 instead of
+ * living there, <= 256 registers per wave, the residual rows are read a second time).  kin = 32 only (-2 otherwise: the caller uses
+ * magnet_mpnn_node_update_f32).  Same arguments, same result contract. */
+int magnet_mpnn_node_update2_f32(const float* h, const float* agg, const float* node_in, int kin, long n_rows, const float* mean,
+                                const float* var, float eps, int n_graphs, int rows_per_graph, const void* w1_f16,
+                                const float* b1, const void* w2_f16, const float* b2, float* y, float* part_sum, float* part_m2,
+                                void* stream);
 /* The same update followed by the hop's InstanceNorm (GNN_Layer.forward, models/mpnn.py:69-70: x = self.norm(update, batch)) in ONE
  * launch, for a batch that fits one workgroup (BASELINE.json configs[0]: 2 x 50 nodes - a rollout bound by its number of launches):
  *   y_norm = InstanceNorm(h + Swish(W2 Swish(W1 [h | agg | node_in] + b1) + b2))   over blocks of rows_per_graph rows

@@ -138,9 +138,12 @@ def _keep_tape(nbytes, dev):
     mode = os.environ.get("MAGNET_KEEP_TAPE", "auto")
     if mode in ("0", "1"):
         return mode == "1"
-    total = torch.cuda.get_device_properties(dev).total_memory
-    used = torch.cuda.memory_allocated(dev)
-    return nbytes < 0.25 * (total - used) and used + nbytes < float(os.environ.get("MAGNET_TAPE_CAP", "0.7")) * total
+    # what the DEVICE reports (other processes, RCCL buffers, captured graphs' pools count) plus what torch's allocator holds in reserve
+    # and would hand out without asking the driver
+    free_dev, total = torch.cuda.mem_get_info(dev)
+    free = free_dev + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    used = total - free
+    return nbytes < 0.25 * free and used + nbytes < float(os.environ.get("MAGNET_TAPE_CAP", "0.7")) * total
 
 
 def _tiles_of(width):
@@ -187,7 +190,20 @@ def _factored_first_layer(m, srcs, M):
         for kt in range(kt0, kt0 + width // 32):
             seen[kt] = True
             ok[kt] = ok[kt] and good
-    return [ok[kt] and seen[kt] for kt in range(nkt)]
+    ok = [ok[kt] and seen[kt] for kt in range(nkt)]
+    # the callers decide per RUN from its first k tile (source-row walk, x0 tape skip, column groups): a run is factored only when ALL
+    # of its k tiles are - one tile shared with a dense Term un-factors the whole run (and every run that shares a tile with it)
+    changed = True
+    while changed:
+        changed = False
+        for (si, col, idx, scale, rdiv, kt0, width) in m.runs:
+            tiles = range(kt0, kt0 + max(width // 32, 1))
+            if any(ok[kt] for kt in tiles if kt < nkt) and not all(ok[kt] for kt in tiles if kt < nkt):
+                for kt in tiles:
+                    if kt < nkt:
+                        ok[kt] = False
+                changed = True
+    return ok
 
 
 def _x0_skip_mask(m, srcs, M, np_):

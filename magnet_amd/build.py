@@ -78,15 +78,20 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
         print(f"[magnet_amd.build] built {lib} from {len(srcs)} sources", file=sys.stderr)
     # the linked code objects are checked for the one hazard hipcc does not cover: an inline-asm VALU write that a v_mfma reads
     # fewer than two wait states later (magnet_amd/hazard_check.py) - a library with such a pair is not shipped
+    # (not optional: without llvm-objdump the build fails - hazard_check.objdump() says where it looked)
     from . import hazard_check
-    if os.path.exists(hazard_check.OBJDUMP):
+    try:
         bad = hazard_check.check(lib)
-        if bad:
-            os.remove(lib)
-            lines = "\n".join(f"  {n[:60]}: {w}  ->  {m}" for n, _, _, w, m in bad[:8])
-            raise RuntimeError(f"{len(bad)} VALU-write -> MFMA-read pair(s) without wait states in {lib}:\n{lines}")
-        if verbose:
-            print("[magnet_amd.build] hazard check passed (VALU -> MFMA, MFMA -> VALU, transcendental -> VALU wait states)", file=sys.stderr)
+    except Exception:
+        os.remove(lib)
+        raise
+    if bad:
+        os.remove(lib)
+        lines = "\n".join(f"  {n[:60]}: {w}  ->  {m}" for n, _, _, w, m in bad[:8])
+        raise RuntimeError(f"{len(bad)} hazard pair(s) without the wait states they need in {lib}:\n{lines}")
+    if verbose:
+        print("[magnet_amd.build] hazard check passed (VALU -> MFMA, MFMA -> VALU, transcendental -> VALU, VALU-SGPR -> VMEM, VALU -> lane ops, "
+              "M0 -> LDS-DMA; loop seams included)", file=sys.stderr)
     return lib
 
 

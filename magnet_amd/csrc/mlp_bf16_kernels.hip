@@ -11,6 +11,7 @@
 // layer[l].w points at that layer's planes in fragment order [kt][nt][m][plane][64 lanes][8 bf16]
 // (packing.pack_linear_bf16x3), layer[l].b at the zero-padded fp32 bias.
 #include "common.cuh"
+#include <type_traits>
 #include "edge_tile.cuh"
 #ifndef MAGNET_BIAS_LDS
 #define MAGNET_BIAS_LDS 1
@@ -877,6 +878,215 @@ __global__ void __launch_bounds__(256, 1) k_node_update(NodeUpdateArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------- MPNN node update, two workgroups per CU (round 4)
+// k_node_update above is bound by neither roof (160 us at 4 x 256^2 rows: 0.19 of the split's MFMA ceiling, 0.43 of the copy ceiling):
+// ONE wave per SIMD issues ~10 k cycles of MFMAs and ~7 k cycles of VALU work per 128-row tile and spends the other 60 % of a tile's
+// 42 k cycles behind its 13 barriers and its own loads, with nobody else on the SIMD to fill the gaps.  This variant makes room for a
+// SECOND workgroup per CU (the two drift against each other: matrix time of one beside the memory time of the other):
+//   * LDS per workgroup 64 KiB -> the planes of update_net_2 are streamed through the chunk slots like those of update_net_1 (13 or 14
+//     chunks of 16 KiB per tile from L2) instead of living in LDS (64 KiB);
+//   * <= 256 registers per wave -> ONE accumulator per output block (GEMM_FP16X3S: planes pre-scaled by 2^11, |w| < 31.98 - the
+//     caller falls back to k_node_update otherwise), source rows three k tiles ahead in a ring of three register sets instead of a
+//     whole tile ahead, and the residual h is read again at the end of the tile (an L2 hit: the same rows were loaded ~9 k tile
+//     steps earlier) instead of being held in 64 registers.
+// Same arithmetic as the one-accumulator chains (Split<GEMM_FP16X3S>), same output layout, same optional statistics partials.
+template <int NKT, bool NORM>
+__global__ void __launch_bounds__(256, 2) k_node_update2(NodeUpdateArgs a) {
+    constexpr int MODE = GEMM_FP16X3S;
+    constexpr int NS = NKT + 4;                                       // chunk steps per tile: update_net_1's k tiles, then update_net_2's
+    __shared__ __attribute__((aligned(16))) u32x4 wsl[2][1024];
+    __shared__ __attribute__((aligned(16))) float tls[4][32 * NH_TS];
+    __shared__ __attribute__((aligned(16))) float bl[2][128];
+    __shared__ __attribute__((aligned(16))) float st[2][NH_MAX_GRAPHS][128];          // mean, 1 / sqrt(var + eps)
+    __shared__ __attribute__((aligned(16))) float ws[4][2][128];                      // per wave: column sums / centred squares of a tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    float* tl = tls[wave];
+    if (NORM)
+        for (int i = threadIdx.x; i < a.n_graphs * 128; i += 256) {
+            st[0][i >> 7][i & 127] = a.mean[i];
+            st[1][i >> 7][i & 127] = 1.0f / sqrtf(a.var[i] + a.eps);
+        }
+    if (threadIdx.x < 128) bl[0][threadIdx.x] = a.b1[threadIdx.x];
+    else bl[1][threadIdx.x - 128] = a.b2[threadIdx.x - 128];
+    const u32x4* g1 = reinterpret_cast<const u32x4*>(a.w1);
+    const u32x4* g2 = reinterpret_cast<const u32x4*>(a.w2);
+    // first-layer step i takes k tile kseq(i): agg and node_in first, h last (as k_node_update: same accumulation order)
+    auto kseq = [](int i) { return i < NKT - 4 ? i + 4 : i - (NKT - 4); };
+    auto chunk = [&](int step) { return step < NKT ? g1 + kseq(step) * 1024 : g2 + (step - NKT) * 1024; };
+    const long ntiles = (a.n + 127) / 128;
+    long tile = blockIdx.x;
+    if (tile >= ntiles) return;                                       // (whole workgroup: uniform)
+    // chunk stream: this thread's four pieces of the NEXT step's chunk wait in registers, are written to the free slot right after the
+    // barrier of the current step, and the step after that is requested.  (Tried instead: LDS-DMA two steps ahead into a ring of three
+    // slots with counted vmcnt waits - 135 us against 128 us on the 4 x 256^2 graph: the chunk stream is not what the kernel waits for.)
+    u32x4 wr[4];
+    // (uniform chunk base kept opaque in SGPRs + one 32-bit per-thread offset: written with 64-bit per-thread pointers hipcc keeps all 52
+    // chunk addresses of a tile alive as loop invariants - 104 registers - and spills them)
+    const unsigned voff = threadIdx.x * 16u;
+    auto wload = [&](int step) {
+        const char* c = reinterpret_cast<const char*>(chunk(step));
+        asm volatile("" : "+s"(c));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wr[q] = *reinterpret_cast<const u32x4*>(c + (voff + q * 4096u));
+    };
+    auto wstore = [&](int slot) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wsl[slot][q * 256 + threadIdx.x] = wr[q];
+    };
+    wload(0);
+    wstore(0);
+    wload(1);
+    int par = 0;                                                      // LDS slot of the chunk of step 0 of this tile
+    // source rows: a ring of three sets, step i of a tile reads set i % 3 (NKT is 9 or 10: the ring position is kept across tiles by
+    // taking the next tile's first steps in the order the ring leaves them)
+    f32x4 xr[3][4];
+    // three base pointers per tile (this lane's row of h / agg / node_in), every load at a compile-time offset from one of them.  The row
+    // index is made opaque per tile: left alone hipcc turns each of the ~50 distinct load addresses into an induction variable of its
+    // own and spills them (106 registers).
+    struct Rows { const float* h; const float* agg; const float* nin; };
+    auto rows_of = [&](long tl_) {
+        long r = min(min(tl_, ntiles - 1) * 128 + wave * 32 + j, a.n - 1);         // clamped: rows past the end are dropped later
+        asm volatile("" : "+v"(r));
+        Rows p;
+        p.h = a.h + r * 128 + 4 * half;
+        p.agg = a.agg + r * 128 + 4 * half;
+        p.nin = a.node_in + r * a.kin + 4 * half;
+        return p;
+    };
+    auto request = [&](int set, const Rows& rw, int kt) {
+        const float* p = kt < 4 ? rw.h + kt * 32 : kt < 8 ? rw.agg + (kt - 4) * 32 : rw.nin + (kt - 8) * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xr[set][g] = *reinterpret_cast<const f32x4*>(p + 8 * g);
+    };
+    static_assert(NKT % 3 == 0, "row sets: step i <-> set i % 3 in every tile");
+    auto body = [&]() __attribute__((always_inline)) {
+        constexpr int ROT = 0;
+        const long row0 = tile * 128 + wave * 32;
+        const int gid = NORM ? (int)(min(row0 + j, a.n - 1) / a.rows_per_graph) : 0;
+        const Rows cur = rows_of(tile), nxt = rows_of(tile + gridDim.x);
+        f32x16 acc[4], accc[4];
+        init_bias<4>(acc, bl[0], half);
+#pragma unroll
+        for (int i = 0; i < NKT; ++i) {
+            const int kt = kseq(i);
+            const int slot = (par + i) & 1;
+            __syncthreads();                                          // chunk of step i complete in `slot`; the other slot is free
+            wstore(slot ^ 1);                                         // chunk of step i + 1
+            wload((i + 2) % NS);                                      // chunk of step i + 2 (the next tile's first ones at the end)
+            f32x16 x;
+            const int set = (i + ROT) % 3;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[4 * g + c] = xr[set][g][c];
+            if (kt < 4 && NORM) {                                      // normalise on load
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 m = *reinterpret_cast<const f32x4*>(&st[0][gid][kt * 32 + 8 * g + 4 * half]);
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(&st[1][gid][kt * 32 + 8 * g + 4 * half]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[4 * g + c] = (x[4 * g + c] - m[c]) * r[c];
+                }
+            }
+            // the set is free: rows of step i + 3 (this tile's, or the next tile's step i + 3 - NKT)
+            if (i + 3 < NKT) request(set, cur, kseq(i + 3));
+            else request(set, nxt, kseq(i + 3 - NKT));
+            mma_chunk<4, MODE, false>(x, acc, accc, wsl[slot], lane);
+        }
+        fold_tiles<4, MODE>(acc, accc);
+        f32x16 h0[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            apply_act<ACT_SWISH>(acc[t]);
+            h0[t] = acc[t];
+        }
+        init_bias<4>(acc, bl[1], half);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int i = NKT + kt;
+            const int slot = (par + i) & 1;
+            __syncthreads();
+            wstore(slot ^ 1);
+            wload((i + 2) % NS);
+            mma_chunk<4, MODE, false>(h0[kt], acc, accc, wsl[slot], lane);
+        }
+        fold_tiles<4, MODE>(acc, accc);
+        // residual: the (normalised) h rows again - requested before the second Swish, they come out of L2.  (The barrier keeps hipcc from
+        // hoisting these 16 loads above the second layer, where h0 is still alive: 64 registers too many.)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 hres[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) hres[t][g] = *reinterpret_cast<const f32x4*>(cur.h + t * 32 + 8 * g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            apply_act<ACT_SWISH>(acc[t]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 hv = hres[t][g];
+                if (NORM) {
+                    const f32x4 m = *reinterpret_cast<const f32x4*>(&st[0][gid][t * 32 + 8 * g + 4 * half]);
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(&st[1][gid][t * 32 + 8 * g + 4 * half]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) hv[c] = (hv[c] - m[c]) * r[c];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[t][4 * g + c] += hv[c];
+            }
+            store_tile_lines(acc[t], tl, a.y, t * 32, row0, a.n, lane);
+            if (a.part_sum) {                                    // as k_node_update: the tile is still in the wave's LDS tile
+                float vcol[16], sm = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    vcol[r] = tl[(16 * half + r) * NH_TS + j];
+                    sm += vcol[r];
+                }
+                sm += __shfl_xor(sm, 32);
+                const float mu = sm * (1.0f / 32.0f);
+                float q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) q = fmaf(vcol[r] - mu, vcol[r] - mu, q);
+                q += __shfl_xor(q, 32);
+                if (half == 0) {
+                    ws[wave][0][t * 32 + j] = sm;
+                    ws[wave][1][t * 32 + j] = q;
+                }
+            }
+        }
+        if (a.part_sum) {
+            __syncthreads();
+            if (wave == 0) {                                     // merge the four 32-row chunks of this 128-row tile (fixed order)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const int col = lane + 64 * cc;
+                    float s4[4], tot = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        s4[w] = ws[w][0][col];
+                        tot += s4[w];
+                    }
+                    const float mu = tot * (1.0f / 128.0f);
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float d = s4[w] * (1.0f / 32.0f) - mu;
+                        m2 += ws[w][1][col] + 32.0f * d * d;
+                    }
+                    a.part_sum[tile * 128 + col] = tot;
+                    a.part_m2[tile * 128 + col] = m2;
+                }
+            }
+        }
+        par = (par + NS) & 1;
+    };
+    // prologue: rows of steps 0 .. 2 of the first tile
+#pragma unroll
+    for (int i = 0; i < 3; ++i) request(i, rows_of(tile), kseq(i));
+    for (; tile < ntiles; tile += gridDim.x) body();
+}
+
 // The same update for launches of at most one 128-row tile per CU (the launch-bound 1-D configs: 100 rows = one workgroup): the
 // persistent kernel's W1 chunk stream is nine dependent L2 -> register -> LDS hand-overs with a barrier each - 16.8 us for 100 rows, a
 // third of a C1 hop.  Here nothing is streamed: ALL of W1 (9 x 16 KiB, kin = 32) is requested in one burst of LDS-DMA loads, the tile's
@@ -1010,6 +1220,38 @@ __global__ void __launch_bounds__(256, 1) k_node_update_burst(NodeUpdateArgs a) 
 // w1 / w2: fp16x3 planes as magnet_mlp_fp16x3_f32 takes them.  Returns -2 for kin not in {32, 64} or more than 8 graphs (the
 // caller then uses the generic chain).  y must not alias h.  part_sum / part_m2 ([n_rows / 128][128] each, n_rows % 128 == 0): per
 // 128-row tile the column sums of y and the squares centred on the tile's column means - input of magnet_colstat_final_f32.
+// planes_scaled != 0: w1 / w2 / b1 / b2 are the ONE-accumulator packs (packing mode "fp16x3s": planes and biases carry 2^11) and the
+// launch is k_node_update2 (two workgroups per CU); 0: the two-accumulator packs and k_node_update, as before.
+extern "C" int magnet_mpnn_node_update2_f32(const float* h, const float* agg, const float* node_in, int kin, long n_rows,
+                                            const float* mean, const float* var, float eps, int n_graphs, int rows_per_graph,
+                                            const void* w1_f16s, const float* b1s, const void* w2_f16s, const float* b2s, float* y,
+                                            float* part_sum, float* part_m2, void* stream) {
+    (void)hipGetLastError();
+    if (n_rows <= 0) return 0;
+    if (kin != 32) return -2;                 // (kin = 64 - the 1-D tw = 50 config - spills at 256 registers: k_node_update serves it)
+    if (mean && (n_graphs > NH_MAX_GRAPHS || n_graphs < 1 || rows_per_graph < 1 || !var)) return -2;
+    if (part_sum && (n_rows % 128 || !part_m2)) return -2;
+    NodeUpdateArgs a;
+    a.part_sum = part_sum, a.part_m2 = part_m2;
+    a.mean = mean, a.var = var, a.eps = eps, a.n_graphs = n_graphs, a.rows_per_graph = rows_per_graph;
+    a.h = h, a.agg = agg, a.node_in = node_in, a.kin = kin, a.n = n_rows, a.y = y, a.b1 = b1s, a.b2 = b2s;
+    a.w1 = reinterpret_cast<const f32x4*>(w1_f16s), a.w2 = reinterpret_cast<const f32x4*>(w2_f16s);
+    static int ncu = 0;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        int dev;
+        hipGetDevice(&dev);
+        hipGetDeviceProperties(&prop, dev);
+        ncu = prop.multiProcessorCount;
+    }
+    const long ntiles = (n_rows + 127) / 128;
+    const int grid = (int)(ntiles < 2 * ncu ? ntiles : 2 * ncu);
+    hipStream_t s = (hipStream_t)stream;
+    if (mean) hipLaunchKernelGGL((k_node_update2<9, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_node_update2<9, false>), dim3(grid), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
 extern "C" int magnet_mpnn_node_update_f32(const float* h, const float* agg, const float* node_in, int kin, long n_rows,
                                            const float* mean, const float* var, float eps, int n_graphs, int rows_per_graph,
                                            const void* w1_f16, const float* b1, const void* w2_f16, const float* b2, float* y,

@@ -22,8 +22,32 @@ import subprocess
 import sys
 import tempfile
 
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+def objdump() -> str:
+    """llvm-objdump of the ROCm installation that built the library: $ROCM_PATH, the directory hipcc lives in, /opt/rocm.  The check is
+    not optional (a library that was not checked is not shipped): FileNotFoundError when none of them has it."""
+    roots = [os.environ.get("ROCM_PATH"), os.environ.get("HIP_PATH")]
+    hipcc = shutil.which("hipcc")
+    if hipcc:
+        roots.append(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))))
+    roots.append("/opt/rocm")
+    tried = []
+    for r in roots:
+        if not r:
+            continue
+        for rel in ("lib/llvm/bin/llvm-objdump", "llvm/bin/llvm-objdump", "bin/llvm-objdump"):
+            cand = os.path.join(r, rel)
+            tried.append(cand)
+            if os.path.exists(cand):
+                return cand
+    which = shutil.which("llvm-objdump")
+    if which:
+        return which
+    raise FileNotFoundError("llvm-objdump not found (looked in " + ", ".join(dict.fromkeys(tried)) + " and on PATH): the hazard check of the "
+                            "built library cannot run; set ROCM_PATH")
+
+
 MIN_WAIT_STATES = 2
+SEAM = 24                # instructions looked at on either side of a backward branch (covers a 16-pass MFMA + 2)
 _RANGE = re.compile(r"^([va])\[(\d+):(\d+)\]$")
 _ONE = re.compile(r"^([va])(\d+)$")
 
@@ -40,29 +64,68 @@ def _regs(tok: str) -> list:
     return []
 
 
-def disassemble(lib: str) -> list[tuple[str, list[str]]]:
-    """[(kernel name, [instruction text ...])] of every gfx950 code object bundled in ``lib``"""
-    if not os.path.exists(OBJDUMP):
-        raise FileNotFoundError(OBJDUMP)
+class Kernel(list):
+    """the instruction texts of one kernel (a list, as the rules take it) + each instruction's byte address and, for branches, the
+    address they jump to (None otherwise) - what loop_seams() needs"""
+
+    def __init__(self, ins=(), addr=(), target=()):
+        super().__init__(ins)
+        self.addr, self.target = list(addr), list(target)
+
+
+def disassemble(lib: str) -> list[tuple[str, "Kernel"]]:
+    """[(kernel name, Kernel [instruction text ...])] of every gfx950 code object bundled in ``lib``"""
+    tool = objdump()
     out = []
     with tempfile.TemporaryDirectory() as tmp:
         local = os.path.join(tmp, "lib.so")
         shutil.copy(lib, local)
-        subprocess.run([OBJDUMP, "--offloading", "lib.so"], cwd=tmp, check=True, capture_output=True)
-        for f in sorted(os.listdir(tmp)):
-            if "gfx950" not in f:
-                continue
-            txt = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+        try:
+            subprocess.run([tool, "--offloading", "lib.so"], cwd=tmp, check=True, capture_output=True)
+            objs = [f for f in sorted(os.listdir(tmp)) if "gfx950" in f]
+            texts = [subprocess.run([tool, "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout for f in objs]
+        except subprocess.CalledProcessError as e:
+            raise RuntimeError(f"hazard check: {' '.join(e.cmd)} failed with code {e.returncode}:\n{(e.stderr or b'')[-2000:]}") from e
+        if not objs:
+            raise RuntimeError(f"hazard check: {lib} bundles no gfx950 code object")
+        for txt in texts:
             cur = None
             for line in txt.splitlines():
-                m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                m = re.match(r"^([0-9a-f]+) <(\S+)>:", line)
                 if m:
-                    cur = (m.group(1), [])
+                    cur = (m.group(2), Kernel())
+                    cur[1].base = int(m.group(1), 16)
                     out.append(cur)
                 elif cur is not None and line.startswith("\t"):
-                    ins = line.split("//")[0].strip()
-                    if ins:
-                        cur[1].append(ins)
+                    parts = line.split("//")
+                    ins = parts[0].strip()
+                    if not ins:
+                        continue
+                    am = re.match(r"\s*([0-9A-Fa-f]+):", parts[1]) if len(parts) > 1 else None
+                    tm = re.search(r"<[^>]*\+0x([0-9a-fA-F]+)>", parts[1]) if len(parts) > 1 and ins.startswith(("s_cbranch", "s_branch")) else None
+                    cur[1].append(ins)
+                    cur[1].addr.append(int(am.group(1), 16) if am else None)
+                    cur[1].target.append(cur[1].base + int(tm.group(1), 16) if tm else None)
+    return out
+
+
+def loop_seams(kernels):
+    """A linear walk never pairs the last instructions of a loop body with the first ones of the next iteration.  For every BACKWARD
+    branch this returns a pseudo kernel: the SEAM instructions up to and including the branch, followed by the SEAM instructions at its
+    target - the order they execute in when the branch is taken.  [(name @ branch address, [instruction ...], index of the first
+    instruction behind the seam)]"""
+    out = []
+    for name, ins in kernels:
+        addr, target = getattr(ins, "addr", None), getattr(ins, "target", None)
+        if not addr:
+            continue
+        index_of = {a: i for i, a in enumerate(addr) if a is not None}
+        for b, tgt in enumerate(target):
+            if tgt is None or addr[b] is None or tgt > addr[b] or tgt not in index_of:
+                continue
+            t = index_of[tgt]
+            head = list(ins[max(0, b - SEAM + 1): b + 1])
+            out.append((f"{name} @loop 0x{addr[b]:x}->0x{tgt:x}", head + list(ins[t: t + SEAM]), len(head)))
     return out
 
 
@@ -174,10 +237,111 @@ def trans_result_reads(kernels) -> list[tuple[str, int, int, str, str]]:
     return bad
 
 
+_SREG = re.compile(r"^(s\d+|s\[\d+:\d+\]|vcc|vcc_lo|vcc_hi|m0|exec)$")
+
+
+def _sregs(tok: str) -> list:
+    tok = tok.strip()
+    m = re.match(r"^s\[(\d+):(\d+)\]$", tok)
+    if m:
+        return [("s", i) for i in range(int(m.group(1)), int(m.group(2)) + 1)]
+    m = re.match(r"^s(\d+)$", tok)
+    if m:
+        return [("s", int(m.group(1)))]
+    if tok in ("vcc", "vcc_lo", "vcc_hi"):
+        return [("vcc", 0)]
+    if tok == "m0":
+        return [("m0", 0)]
+    return []
+
+
+def _wait_states(ins, a, b) -> int:
+    """wait states between instruction a and instruction b (exclusive): every instruction in between is one, s_nop N is N + 1"""
+    ws = 0
+    for q in range(a + 1, b):
+        o = ins[q].split()
+        ws += int(o[1], 0) + 1 if o[0] == "s_nop" else 1
+    return ws
+
+
+_VMEM = ("buffer_", "global_", "flat_", "scratch_", "tbuffer_")
+
+
+def sgpr_and_lane_hazards(kernels) -> list[tuple[str, int, int, str, str]]:
+    """The data hazards of hand-placed (inline-asm) code that the three MFMA rules do not cover - hipcc pads them for its own
+    instructions only:
+      * a VALU instruction that writes an SGPR / VCC (v_readfirstlane, v_readlane, v_cmp ... with an SGPR destination) and a VMEM
+        instruction that reads that SGPR (address, descriptor, offset): 5 wait states;
+      * a VALU write of a VGPR and a v_permlane* that reads it: 2 wait states; a v_readlane / v_readfirstlane that reads it: 1;
+      * a write of M0 (s_mov_b32 m0 ..., s_add ... m0) and an LDS-DMA load (`... lds`, `*_load_lds_*`) right behind it: 1 wait state
+        (the same for s_setreg_b32 in front of an LDS-DMA load).
+    -> (kernel, index of the reader, wait states found, the writer, the reader)"""
+    bad = []
+    for name, ins in kernels:
+        s_last, v_last, m0_last = {}, {}, None
+        for k, line in enumerate(ins):
+            op = line.split()[0]
+            args = [a.strip() for a in re.split(r",\s*", line[len(op):].strip())] if len(line) > len(op) else []
+            is_vmem = op.startswith(_VMEM)
+            if is_vmem:
+                for tok in args:
+                    for r in _sregs(tok.split()[0] if tok else tok):
+                        kw = s_last.get(r)
+                        if kw is not None and _wait_states(ins, kw, k) < 5:
+                            bad.append((name, k, _wait_states(ins, kw, k), ins[kw], line))
+                if (" lds" in line or "_lds_" in op) and m0_last is not None and _wait_states(ins, m0_last, k) < 1:
+                    bad.append((name, k, 0, ins[m0_last], line))
+            if op.startswith(("v_permlane", "v_readlane", "v_readfirstlane")):
+                need = 2 if op.startswith("v_permlane") else 1
+                srcs = args if op.startswith("v_permlane") else args[1:2]          # permlane swaps read (and write) both operands
+                for tok in srcs:
+                    for r in _regs(tok):
+                        kw = v_last.get(r)
+                        if kw is not None and _wait_states(ins, kw, k) < need:
+                            bad.append((name, k, _wait_states(ins, kw, k), ins[kw], line))
+            # ---- writers
+            if op.startswith("v_") and args:
+                dst = args[0]
+                if _sregs(dst):
+                    for r in _sregs(dst):
+                        s_last[r] = k
+                elif op.startswith("v_cmp") and not dst.startswith("v"):
+                    s_last[("vcc", 0)] = k
+                else:
+                    for r in _regs(dst):
+                        v_last[r] = k
+                    if op.startswith("v_permlane") and len(args) > 1:
+                        for r in _regs(args[1]):
+                            v_last[r] = k
+            elif op.startswith("s_") and args:
+                for r in _sregs(args[0]):
+                    s_last.pop(r, None)                      # a SALU write ends the VALU-written state of that SGPR
+                if args[0] == "m0" or op.startswith("s_setreg"):
+                    m0_last = k
+            if is_vmem or op.startswith("ds_"):
+                for r in (_regs(args[0]) if args else []):
+                    v_last.pop(r, None)
+    return bad
+
+
 def check(lib: str | None = None) -> list:
+    """every violation of every rule in the linked library, loop seams included - [] is what ships"""
     from . import _lib
-    k = disassemble(lib or _lib.LIB_PATH)
-    return violations(k) + [(n, i, ws, m, r) for n, i, ws, _, m, r in mfma_result_reads(k)] + trans_result_reads(k)
+    return check_kernels(disassemble(lib or _lib.LIB_PATH))
+
+
+def check_kernels(k) -> list:
+    found = violations(k) + [(n, i, ws, m, r) for n, i, ws, _, m, r in mfma_result_reads(k)] + trans_result_reads(k) + sgpr_and_lane_hazards(k)
+    seams = loop_seams(k)
+    body = [(n, i) for n, i, _ in seams]
+    first_behind = {n: f for n, _, f in seams}
+    seen = {(w, m) for _, _, _, w, m in found}
+    for hit in (violations(body) + [(n, i, ws, m, r) for n, i, ws, _, m, r in mfma_result_reads(body)] + trans_result_reads(body)
+                + sgpr_and_lane_hazards(body)):
+        n, i, ws, w, m = hit
+        if i >= first_behind[n] and (w, m) not in seen:       # the reader sits behind the seam: a pair the linear walk cannot see
+            found.append(hit)
+    return found
 
 
 if __name__ == "__main__":

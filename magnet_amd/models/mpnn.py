@@ -104,6 +104,7 @@ class MPNN(LightningModule):
         # fp16x3: the row-aligned kernel (k_mpnn_edge_rows32, generation 11) where the graph's rows are long enough to own tiles
         # (2-D meshes: 30 .. 33 edges per row); A/B knob, DESIGN.md 11.1
         self.edge_rows = bool(int(os.environ.get("MAGNET_EDGE_ROWS", "0"))) and bool(getattr(hparams, "edge_rows", True))
+        self.node_update2 = bool(int(os.environ.get("MAGNET_NODE_UPDATE2", "1"))) and bool(getattr(hparams, "node_update2", True))
         # small batches (<= 128 rows): update + InstanceNorm of a hop in one launch (A/B knob)
         self.fused_small_norm = bool(int(os.environ.get("MAGNET_SMALL_NORM", "1"))) and bool(getattr(hparams, "fused_small_norm", True))
         assert self.edge_gemm in GEMM_MODES
@@ -194,6 +195,11 @@ class MPNN(LightningModule):
             cmap = torch.cat([torch.arange(2 * H), torch.tensor([2 * H + tw + dp])])   # var column inside node_in
             L.upd1 = pack(u1.weight, u1.bias, self.gemm, k_pad=2 * H + kin, col_map=cmap)
             L.upd2 = pack(u2.weight, u2.bias, self.gemm)
+            # large graphs, inference: the update net in the one-accumulator form (planes x 2^11, |w| < 31.98 - flagged on the device and
+            # checked with the other packs below) for k_node_update2, two workgroups per CU (A/B knob MAGNET_NODE_UPDATE2)
+            if self.node_update2 and self.gemm == "fp16x3" and kin == 32:
+                L.upd1s = pack(u1.weight, u1.bias, "fp16x3s", k_pad=2 * H + kin, col_map=cmap)
+                L.upd2s = pack(u2.weight, u2.bias, "fp16x3s")
             P.layers.append(L)
         c1, c2 = self.output_mlp[0], self.output_mlp[-1]
         P.conv = (c1.weight.detach().reshape(-1).contiguous(), c1.bias.detach().contiguous(),
@@ -279,11 +285,11 @@ class MPNN(LightningModule):
             else:
                 ops.mpnn_edge(A, Bm, csr, lyr.msg2[0], lyr.msg2[1], agg, partials, l2e=l2e)
             if fused_nodes:
+                u1p, u2p = (lyr.upd1s, lyr.upd2s) if hasattr(lyr, "upd1s") else (lyr.upd1, lyr.upd2)
                 if Ns % 128 == 0 and self.fused_node_stats:   # the update kernel emits the partials of the output's InstanceNorm statistics itself
-                    stats = ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g, stats=stats, rows_per_graph=Ns,
-                                                 stats_out_graphs=B)
+                    stats = ops.mpnn_node_update(h, agg, node_in, u1p, u2p, g, stats=stats, rows_per_graph=Ns, stats_out_graphs=B)
                 else:
-                    ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g, stats=stats, rows_per_graph=Ns)
+                    ops.mpnn_node_update(h, agg, node_in, u1p, u2p, g, stats=stats, rows_per_graph=Ns)
                     stats = ops.instance_norm_stats(g, B, Ns)
                 h, g = g, h                                                 # h: raw update output + its statistics
                 continue

@@ -46,6 +46,8 @@ def _packed_bwd(m):
     H, tw, dp, kin = m.hidden_features, m.time_window, m.dpos, m.kin
     mode = m.bwd_gemm
     dev = next(m.parameters()).device
+    from ..packing import wide
+    f16_planes = not wide()
     Q = types.SimpleNamespace(layers=[], mode=mode)
     padk = lambda w: torch.cat([w, torch.zeros(w.shape[0], kin - w.shape[1], device=dev)], 1)  # noqa: E731
     for lyr in m.gnn_layers:
@@ -62,15 +64,18 @@ def _packed_bwd(m):
         q.dnin = pack(torch.cat([wan.t(), wbn.t()], 1), None, mode)     # [kin, 2H]
         q.dagg = pack(W3[:, H:2 * H].t(), None, mode)
         q.w2t = pack(W2.t(), None, mode)
-        q.w2_f16 = pack(W2, lyr.message_net_2[0].bias, "fp16x3")         # fused edge backward: both packings as fp16 planes
-        q.w2t_f16 = pack(W2.t(), None, "fp16x3")
-        if m.edge_bwd == "fused_w":                                      # that kernel scales the fp16 high planes by 2^11
+        # The fused kernels of the backward hold weights as fp16 planes whatever `mode` is (their activations are recomputed from
+        # post-InstanceNorm data): not built once the process has been widened to the full-range split (packing.widen) - the
+        # backward then takes the materialising bf16x6 path for the edge block and the per-Linear path for the node block.
+        if f16_planes:
             from ..packing import flag_if_abs_reaches
-            flag_if_abs_reaches(W2, 31.98)
+            q.w2_f16 = pack(W2, lyr.message_net_2[0].bias, "fp16x3")     # fused edge backward: both packings as fp16 planes
+            q.w2t_f16 = pack(W2.t(), None, "fp16x3")
+            if m.edge_bwd == "fused_w":                                  # that kernel scales the fp16 high planes by 2^11
+                flag_if_abs_reaches(W2, 31.98)
         q.w4t = pack(W4.t(), None, mode)
-        if mode == "bf16x6":            # large graphs: update_net_2 and the agg block of update_net_1 walked back by k_linear_bwd128
-            from ..packing import flag_if_abs_reaches
-            q.w4t_f16 = pack(W4.t(), None, "fp16x3")[0]
+        if mode == "bf16x6" and f16_planes and _NODE_ONE_KERNEL:         # large graphs: update_net_2 and the agg block of update_net_1
+            q.w4t_f16 = pack(W4.t(), None, "fp16x3")[0]                  # walked back by k_linear_bwd128 (planes pre-scaled by 2^11)
             q.daggt_f16 = pack(W3[:, H:2 * H].t(), None, "fp16x3")[0]
             flag_if_abs_reaches(W4, 31.98)
             flag_if_abs_reaches(W3[:, H:2 * H], 31.98)
@@ -79,9 +84,15 @@ def _packed_bwd(m):
     Q.e1t = pack(e1.t(), None, mode)
     Q.e0t = pack(padk(e0).t(), None, mode)                               # [kin, H]
     m._pack_bwd, m._pack_bwd_key = Q, m._pack_key
-    if dev.type == "cuda":
-        from ..packing import raise_if_bad_weights
-        raise_if_bad_weights(dev)              # the fp16 planes of W2 / W2^T for the fused edge backward: one host read per re-pack
+    if dev.type == "cuda" and f16_planes:
+        from ..packing import bad_weights
+        if bad_weights(dev):                   # the fp16 planes of the fused backward kernels: one host read per re-pack
+            # |w| >= 31.98 in message_net_2 / update_net_2 / the agg block of update_net_1 (or >= 65504 anywhere): the planes those
+            # kernels pre-scale by 2^11 would overflow.  The forward of this step is valid (its own packs passed their check); the
+            # backward - and everything from the next step on - runs in the full-range split.
+            m._widen("a weight does not fit the pre-scaled fp16 planes of the fused backward kernels (|w| >= 31.98; "
+                     "MAGNET_NODE_ONE_KERNEL=0 / edge_bwd='fused' avoid those kernels)")
+            return _packed_bwd(m)
     return Q
 
 
@@ -129,8 +140,9 @@ def backward_call(m, tape, dout, G, ws):
     dnin_l = torch.empty_like(dnin)
     z1, r1_buf, z2_buf, t1, t2, dagg, dA, dBm = (new() for _ in range(8))
     r1, z2 = r1_buf, z2_buf
-    fused = m.edge_bwd in ("fused", "fused_w")
-    fused_w = m.edge_bwd == "fused_w"                 # dW2 / db2 formed inside the edge kernel: no s1 / dq arrays at all
+    has_f16 = hasattr(Q.layers[0], "w2_f16") if Q.layers else False       # not after packing.widen (see _packed_bwd)
+    fused = m.edge_bwd in ("fused", "fused_w") and has_f16
+    fused_w = m.edge_bwd == "fused_w" and has_f16     # dW2 / db2 formed inside the edge kernel: no s1 / dq arrays at all
     d2 = enew()
     sp, d1 = (None, None) if fused_w else (enew(), enew())
     p, q = (None, None) if fused else (enew(), enew())

@@ -487,9 +487,12 @@ def mpnn_node_update(h, agg, node_in, upd1, upd2, y, stats=None, rows_per_graph=
         assert rows_per_graph % 128 == 0 and n == stats_out_graphs * rows_per_graph
         part = torch.empty(2, n // 128, 128, device=h.device, dtype=torch.float32)
         ps, pm = part[0], part[1]
-    L.check(L.lib().magnet_mpnn_node_update_f32(_p(h), _p(agg), _p(node_in), node_in.shape[1], C.c_long(n), _p(mean), _p(var),
-                                                C.c_float(float(eps)), ng, int(rows_per_graph), _p(upd1[0]), _p(upd1[1]),
-                                                _p(upd2[0]), _p(upd2[1]), _p(y), _p(ps), _p(pm), _stream()), "mpnn_node_update")
+    # one-accumulator packs (packing mode "fp16x3s"): k_node_update2, two workgroups per CU; else the two-accumulator k_node_update
+    single = isinstance(upd1[0], SinglePlanes) and isinstance(upd2[0], SinglePlanes)
+    entry = L.lib().magnet_mpnn_node_update2_f32 if single else L.lib().magnet_mpnn_node_update_f32
+    L.check(entry(_p(h), _p(agg), _p(node_in), node_in.shape[1], C.c_long(n), _p(mean), _p(var),
+                  C.c_float(float(eps)), ng, int(rows_per_graph), _p(upd1[0]), _p(upd1[1]),
+                  _p(upd2[0]), _p(upd2[1]), _p(y), _p(ps), _p(pm), _stream()), "mpnn_node_update")
     if not stats_out_graphs:
         return y
     mv = torch.empty(2, stats_out_graphs, 128, device=h.device, dtype=torch.float32)

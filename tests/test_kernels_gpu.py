@@ -505,12 +505,17 @@ def test_mpnn_2d_rollout_with_fused_node_halves_equals_the_unfused_path():
     assert rel_l2(outs[0], outs[1]) < 1e-6
 
 
-@pytest.mark.parametrize("kin,n", [(32, 4 * 4096), (32, 1000 + 13), (64, 2 * 640 + 5), (32, 70)])
-def test_node_update_persistent_kernel_matches_generic_chain(kin, n):
+@pytest.mark.parametrize("single", [False, True])
+@pytest.mark.parametrize("kin,n", [(32, 4 * 4096), (32, 1000 + 13), (64, 2 * 640 + 5), (32, 70), (32, 300 * 128 + 77)])
+def test_node_update_persistent_kernel_matches_generic_chain(kin, n, single):
     """magnet_mpnn_node_update_f32 (persistent, W2 resident, W1 streamed, h k tiles last) == the generic two-Linear launch with
-    the residual epilogue, and both against fp64 on the host."""
+    the residual epilogue, and both against fp64 on the host.  single: the one-accumulator packs -> magnet_mpnn_node_update2_f32
+    (k_node_update2: two workgroups per CU, both Linears streamed, residual rows read again; round 4) - 300 tiles + a ragged one gives
+    every workgroup of its 512-block grid... more than one tile and the last one a partial tile."""
     from magnet_amd import ops
     from magnet_amd.packing import pack
+    if single and kin != 32:
+        pytest.skip("k_node_update2 is instantiated for kin = 32")
     g = torch.Generator().manual_seed(5)
     H = 128
     w1, w2 = torch.randn(H, 2 * H + kin, generator=g) * 0.08, torch.randn(H, H, generator=g) * 0.1
@@ -518,11 +523,14 @@ def test_node_update_persistent_kernel_matches_generic_chain(kin, n):
     h, agg = torch.randn(n, H, generator=g).cuda(), torch.randn(n, H, generator=g).cuda()
     node_in = torch.randn(n, kin, generator=g).cuda()
     u1, u2 = pack(w1.cuda(), b1.cuda(), "fp16x3", k_pad=2 * H + kin), pack(w2.cuda(), b2.cuda(), "fp16x3")
+    g1, g2 = u1, u2                                                    # the generic chain always takes the two-accumulator packs
+    if single:
+        u1, u2 = pack(w1.cuda(), b1.cuda(), "fp16x3s", k_pad=2 * H + kin), pack(w2.cuda(), b2.cuda(), "fp16x3s")
     y = torch.full((n, H), float("nan"), device="cuda")
     ops.mpnn_node_update(h, agg, node_in, u1, u2, y)
     ref = torch.empty(n, H, device="cuda")
     T = ops.Term
-    ops.mlp(n, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [u1, u2], nl=2, ht=4, ot=4, act=ops.ACT_SWISH, last_act=True,
+    ops.mlp(n, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [g1, g2], nl=2, ht=4, ot=4, act=ops.ACT_SWISH, last_act=True,
             epi=ops.EPI_STORE_RES, res=h, y=ref)
     assert rel_l2(y, ref) < 5e-7
     sw = lambda v: v * torch.sigmoid(v)  # noqa: E731

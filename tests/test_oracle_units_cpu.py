@@ -159,3 +159,17 @@ def test_scatter_mean_matches_torch_scatter_reduce():
     got = S.scatter_mean(src, idx, 45)
     want = torch.zeros(45, 5).scatter_reduce(0, idx[:, None].expand(-1, 5), src, reduce="mean", include_self=False)
     assert torch.allclose(got, want, atol=1e-6) and float(got[7].abs().sum()) == 0.0
+
+
+def test_pinning_kit_runs_its_cases_through_the_restatement():
+    """scripts/pin_third_party.py compares oracle/pyg_semantics.py with the real torch_cluster / torch_scatter / torch_geometric on a host
+    that has them (they cannot be installed here).  Its --self-test runs every case with the restatement on both
+    sides: the kit itself works, covers the cap-active and tie cases, and ends in PINNED."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "pin_third_party.py"), "--self-test"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cap ACTIVE, loop=False" in r.stdout and "exact ties" in r.stdout and r.stdout.strip().endswith("every case")

@@ -133,6 +133,37 @@ def test_rollout_graph_keeps_the_topology_tensors_it_compares_by_identity():
         assert rel_l2(pred, want) < 5e-5, scale
 
 
+def test_a_mesh_that_changes_every_batch_is_not_captured_again_and_again():
+    """irregular data brings new coordinates with every batch (datamodule/dataset_2d.py:99-101): a capture is three rollouts and would be
+    thrown away by the next batch.  After two captures in a row that a different mesh replaced before they paid off, that batch shape
+    is enqueued kernel by kernel (RolloutGraph.volatile); every batch still gets the oracle's result for ITS mesh, and a shape whose
+    mesh stays is still replayed."""
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    name, hp, salt, batch, d = load_case("mpnn_1d")
+    oracle = O.build(name, hp).eval()
+    fill_state_dict(oracle, salt)
+    model = FACTORY[name](types.SimpleNamespace(**vars(hp), hip_graph=True)).eval()
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda()
+    captures = []
+    orig = model._rollout_graph._capture
+    model._rollout_graph._capture = lambda fn, b: (captures.append(1), orig(fn, b))[1]
+    for scale in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5):
+        b = {k: v.clone() for k, v in batch.items()}
+        b["x"] = batch["x"] * scale
+        pred = model.validation_step({k: v.cuda() for k, v in b.items()}, 0).cpu()
+        with torch.no_grad():
+            want = oracle.validation_step(b)
+        assert rel_l2(pred, want) < 5e-5, scale
+    assert len(captures) == 3, captures            # 1.0, 0.9, 0.8 were captured; from then on the shape counts as volatile
+    half = {k: v[:1].clone().cuda() for k, v in batch.items()}         # another batch shape, one mesh: captured once, replayed after
+    for _ in range(3):
+        model.validation_step(half, 0)
+    assert len(captures) == 4
+
+
 @pytest.mark.parametrize("tag", ["magnet_cnn_1d", "magnet_cnn_2d", "magnet_gnn_tiny"])
 def test_captured_rollouts_outlive_the_caches_they_were_built_from(tag):
     """A captured rollout bakes in pointers to buffers owned by model-side caches: EDSR keeps ONE launch plan (feature maps with
