@@ -637,23 +637,12 @@ def bench_c1(dev, reps=50):
             "how": "whole rollout replayed from one hipGraph (default when B*N <= 4096 rows)"}
 
 
-def bench_ref_shapes(dev):
-    """What the reference's own run scripts train and validate on (rank 0, N = 1 only) - the shapes a user of the reference meets,
-    next to the 256^2 metric cases that nobody trains:
-      c4a          mpnn_2d, 64 x 64 regular mesh, batch 4                      scripts/mpnn_2d/mpnn_2d_b1_64_regular.sh:27-36
-      gnn_64       magnet_gnn, 64 x 64 mesh: 2048 LR nodes ([::2]) + 256 sampled queries (validation: + the other 2048), batch 8
-                                                                                scripts/magnet_gnn/magnet_gnn_2d_b1_64_regular.sh:26-36, datamodule/dataset_2d.py:107-121
-      gnn_512      magnet_gnn, 512 irregular points: 256 LR + 256 queries, batch 32; validation on the 32 x 32 test mesh (512 + 512)
-                                                                                scripts/magnet_gnn/magnet_gnn_2d_b1_512_irregular_concentrated.sh:26-36
-      cnn_64       magnet_cnn_2d, 64 x 64 frames: 32 x 32 LR grid (bilinear) + 256 sampled queries (validation: all 4096), batch 32,
-                   teacher forcing                                             scripts/magnet_cnn_2d/magnet_cnn_2d_b1_64_regular.sh:26-36, configs/datamodule/h5_datamodule_implicit_2d.yaml:15
-    Per case: the training step (forward with tape + HIP backward + fused Adam; ms, C-ABI calls, peak memory) and the validation
-    rollout enqueued kernel by kernel and replayed from one hipGraph (ms each; `hip_graph="auto"` picks the replay up to
-    magnet_amd.graphs.AUTO_MAX_ROWS node rows)."""
-    from magnet_amd import ops
-    from magnet_amd.models.factory import FACTORY
+def ref_shape_cases():
+    """{key: (model name, hparams dict, make(train: bool) -> (cpu batch, nodes per sample))} - the shapes of the reference's run scripts
+    (see bench_ref_shapes)"""
     from magnet_amd.utils import make_coord
     g = torch.Generator().manual_seed(4)
+
 
     def mesh_pts(n_side):
         lin = torch.linspace(-1, 1, n_side)
@@ -684,6 +673,25 @@ def bench_ref_shapes(dev):
         "gnn_512": ("magnet_gnn", dict(MAGNET_HP["magnet_gnn"]), lambda train: gnn_batch(32, irr if train else mesh_pts(32), 256, train)),
         "cnn_64": ("magnet_cnn_2d", dict(MAGNET_HP["magnet_cnn_2d"], teacher_forcing=True), lambda train: cnn_batch(32, 64, 256, train)),
     }
+    return cases
+
+
+def bench_ref_shapes(dev):
+    """What the reference's own run scripts train and validate on (rank 0, N = 1 only) - the shapes a user of the reference meets,
+    next to the 256^2 metric cases that nobody trains:
+      c4a          mpnn_2d, 64 x 64 regular mesh, batch 4                      scripts/mpnn_2d/mpnn_2d_b1_64_regular.sh:27-36
+      gnn_64       magnet_gnn, 64 x 64 mesh: 2048 LR nodes ([::2]) + 256 sampled queries (validation: + the other 2048), batch 8
+                                                                                scripts/magnet_gnn/magnet_gnn_2d_b1_64_regular.sh:26-36, datamodule/dataset_2d.py:107-121
+      gnn_512      magnet_gnn, 512 irregular points: 256 LR + 256 queries, batch 32; validation on the 32 x 32 test mesh (512 + 512)
+                                                                                scripts/magnet_gnn/magnet_gnn_2d_b1_512_irregular_concentrated.sh:26-36
+      cnn_64       magnet_cnn_2d, 64 x 64 frames: 32 x 32 LR grid (bilinear) + 256 sampled queries (validation: all 4096), batch 32,
+                   teacher forcing                                             scripts/magnet_cnn_2d/magnet_cnn_2d_b1_64_regular.sh:26-36, configs/datamodule/h5_datamodule_implicit_2d.yaml:15
+    Per case: the training step (forward with tape + HIP backward + fused Adam; ms, C-ABI calls, peak memory) and the validation
+    rollout enqueued kernel by kernel and replayed from one hipGraph (ms each; `hip_graph="auto"` picks the replay up to
+    magnet_amd.graphs.AUTO_MAX_ROWS node rows)."""
+    from magnet_amd import ops
+    from magnet_amd.models.factory import FACTORY
+    cases = ref_shape_cases()
     lib = ops.L.lib()
     names = [n for n in ops.L.declared_symbols() if hasattr(lib, n)]
     out = {}

@@ -75,6 +75,19 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_QUERIES = {}
+
+
+def query(name: str, *args) -> int:
+    """value of a pure query entry point (``*_supported``, ``*_workspace``, ``*_grid``: functions of their integer arguments only),
+    cached: a MAgNet training step at the reference's batch sizes is host bound and asks these ~600 times per step"""
+    key = (name, args)
+    if key not in _QUERIES:
+        long_arg = name.endswith("_grid")                      # (these take the row count as a C long)
+        _QUERIES[key] = int(getattr(lib(), name)(*[C.c_long(a) if long_arg else a for a in args]))
+    return _QUERIES[key]
+
+
 def check(code: int, what: str) -> None:
     if code != 0:
         raise RuntimeError(f"{what} failed with code {code}"

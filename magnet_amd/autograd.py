@@ -99,7 +99,7 @@ def _tape_variant_ok(nl, pk):
     """is there a store-epilogue instantiation of the fused kernel for this chain without LayerNorm? (nl, ht, ot, ReLU, no
     last_act, no LN, STORE): the projector / decoder shapes (5, 4, 1), (5, 2, 1) exist; the LayerNorm chains use their own
     (5, ht, ot, LN) variants with the LayerNorm switched on and its output discarded."""
-    return bool(L.lib().magnet_mlp_supported(nl, pk.ht, pk.ot, ops.ACT_RELU, 0, 0, ops.EPI_STORE))
+    return bool(L.query("magnet_mlp_supported", nl, pk.ht, pk.ot, ops.ACT_RELU, 0, 0, ops.EPI_STORE))
 
 
 def _recompute_tape(M, kts, pk, nl, x0, X, zL, K0, x0_skip=0):
@@ -118,7 +118,7 @@ def _recompute_tape(M, kts, pk, nl, x0, X, zL, K0, x0_skip=0):
     if _tape_variant_ok(nl, pk):
         ops.mlp(M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU, last_act=False, ln=None, epi=ops.EPI_STORE,
                 y=scratch(), ncols=Dp, x0_out=x0, hid=X[1:] + [zL], x0_skip=x0_skip)
-    elif lnflag and L.lib().magnet_mlp_supported(nl, pk.ht, pk.ot, ops.ACT_RELU, 0, 1, ops.EPI_STORE):
+    elif lnflag and L.query("magnet_mlp_supported", nl, pk.ht, pk.ot, ops.ACT_RELU, 0, 1, ops.EPI_STORE):
         ops.mlp(M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU, last_act=False, ln=pk.ln, epi=ops.EPI_STORE,
                 y=scratch(), ncols=Dp, x0_out=x0, hid=X[1:] + [zL], x0_skip=x0_skip)
     else:
@@ -130,20 +130,32 @@ def _recompute_tape(M, kts, pk, nl, x0, X, zL, K0, x0_skip=0):
             zL.copy_(_linear(M, X[nl - 1], pk.layers[nl - 1], pk.ot, relu=False))
 
 
+_MEM = {"t": -1.0, "dev": None, "free": 0, "total": 1, "granted": 0}
+
+
 def _keep_tape(nbytes, dev):
     """does the tape of one chain stay in memory from the forward to the backward?  MAGNET_KEEP_TAPE = 1 / 0 / auto (default): yes while
     it takes less than a quarter of what is still free and the device stays below 70 % full (MAGNET_TAPE_CAP) - later calls of a long rollout then fall
-    back to recomputing by themselves"""
+    back to recomputing by themselves.  "Free" is what the DEVICE reports (other processes, RCCL buffers, captured graphs' pools count)
+    plus what torch's allocator holds in reserve; the figures are refreshed at most every 50 ms - a training step at the reference's
+    batch sizes asks ~100 times and torch.cuda.memory_stats costs 0.1 ms a call (a fifth of such a step) - and the bytes granted since
+    the last refresh are subtracted."""
     import os
+    import time
     mode = os.environ.get("MAGNET_KEEP_TAPE", "auto")
     if mode in ("0", "1"):
         return mode == "1"
-    # what the DEVICE reports (other processes, RCCL buffers, captured graphs' pools count) plus what torch's allocator holds in reserve
-    # and would hand out without asking the driver
-    free_dev, total = torch.cuda.mem_get_info(dev)
-    free = free_dev + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-    used = total - free
-    return nbytes < 0.25 * free and used + nbytes < float(os.environ.get("MAGNET_TAPE_CAP", "0.7")) * total
+    now = time.perf_counter()
+    if _MEM["dev"] != dev or now - _MEM["t"] > 0.05:
+        free_dev, total = torch.cuda.mem_get_info(dev)
+        _MEM.update(t=now, dev=dev, total=total, granted=0,
+                    free=free_dev + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev))
+    free = _MEM["free"] - _MEM["granted"]
+    used = _MEM["total"] - free
+    ok = nbytes < 0.25 * free and used + nbytes < float(os.environ.get("MAGNET_TAPE_CAP", "0.7")) * _MEM["total"]
+    if ok:
+        _MEM["granted"] += nbytes
+    return ok
 
 
 def _tiles_of(width):
@@ -398,7 +410,7 @@ class _Mlp(torch.autograd.Function):
                 if (l > 0 and n == k == Np == Kp and Np in (128, 64) and M >= _FUSED_LAYER_ROWS and pk.layers[0][0].dtype == torch.float16
                         and dz.is_contiguous() and X[l].is_contiguous()):
                     if lb_ws is None:
-                        lb_ws = torch.empty(L.lib().magnet_linear_bwd128_workspace(), device=dev, dtype=torch.float32)
+                        lb_ws = torch.empty(L.query("magnet_linear_bwd128_workspace"), device=dev, dtype=torch.float32)
                     dX = torch.empty(M, Np, device=dev, dtype=torch.float32)
                     dWp, dbp = torch.empty(Np, Np, device=dev, dtype=torch.float32), torch.empty(Np, device=dev, dtype=torch.float32)
                     amax = ops.linear_bwd128(dz, X[l], _tpack16(pk, l, W), dX, dWp, dbp, lb_ws, mask=True, amax_in=amax)

@@ -162,6 +162,8 @@ class MagnetBase(LightningModule):
             self._pack, self._pack_key = self._pack_weights(), key
             if bad_weights(params[0].device):        # the fp16x3 packs' range check: ONE host read per re-pack (not one per Linear)
                 self._pack_key = None
+                if not all(bool(torch.isfinite(p).all()) for p in params):      # a diverged run must not be papered over
+                    raise FloatingPointError(f"{type(self).__name__}: non-finite weights")
                 self._widen("a weight does not fit the fp16 planes (|w| >= 65504; 31.98 for the one-accumulator chains)")
                 return self._packed()
         hold(self._pack)                    # a capture in progress keeps the packs its launches point into (magnet_amd/graphs.py)

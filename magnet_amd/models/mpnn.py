@@ -210,6 +210,8 @@ class MPNN(LightningModule):
             from ..packing import bad_weights
             if bad_weights(dev):               # the fp16x3 packs' range check: ONE host read per re-pack (not one per Linear)
                 self._pack_key = None
+                if not all(bool(torch.isfinite(p).all()) for p in params):      # a diverged run must not be papered over
+                    raise FloatingPointError(f"{type(self).__name__}: non-finite weights")
                 self._widen("a weight does not fit the two fp16 planes (|w| >= 65504)")
                 return self._packed()
         hold(P)

@@ -159,12 +159,12 @@ def mlp(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EPI_STO
         res=None, tgt=None, rowptr=None, partials=None, colgroups=1, groups_in_block=False, y_group_stride=0, pre=None,
         x0_out=None, hid=None, x0_skip=0):
     """Run the fused MLP kernel.  ``layers``: list of (packed_w, padded_b).  Returns y."""
-    if isinstance(layers[0][0], SinglePlanes) and not L.lib().magnet_mlp_fp16x3s_supported(
-            nl, ht, ot, act, int(last_act), int(ln is not None), epi):
+    if isinstance(layers[0][0], SinglePlanes) and not L.query("magnet_mlp_fp16x3s_supported",
+                                                              nl, ht, ot, act, int(last_act), int(ln is not None), epi):
         raise NotImplementedError(f"no one-accumulator chain kernel for (nl={nl}, ht={ht}, ot={ot}, ln={ln is not None}, epi={epi}): "
                                   "set MAGNET_CHAIN_GEMM=fp16x3")
-    if nl > 1 and colgroups == 1 and not L.lib().magnet_mlp_supported(nl, ht, ot, act, int(last_act), int(ln is not None),
-                                                                       EPI_STORE if epi == EPI_QUADBLEND else epi):
+    if nl > 1 and colgroups == 1 and not L.query("magnet_mlp_supported", nl, ht, ot, act, int(last_act), int(ln is not None),
+                                                  EPI_STORE if epi == EPI_QUADBLEND else epi):
         return _mlp_by_layers(M, kts, layers, nl=nl, ht=ht, ot=ot, act=act, last_act=last_act, ln=ln, epi=epi, y=y, ldy=ldy,
                               ncols=ncols, res=res, tgt=tgt, rowptr=rowptr, partials=partials, pre=pre, x0_out=x0_out, hid=hid)
     mlp_plan(M, kts, layers, nl=nl, ht=ht, ot=ot, act=act, last_act=last_act, ln=ln, epi=epi, y=y, ldy=ldy, ncols=ncols,
@@ -631,7 +631,7 @@ def linear_bwd128(dz, x, wt_f16, dx, dW, db, ws, mask=True, amax_in=None, want_a
     next (None: computed here)"""
     M, W = dz.shape
     assert W in (128, 64) and x.shape[1] >= W and dW.is_contiguous() and dW.shape == (W, W) and db.is_contiguous()
-    n_out = (L.lib().magnet_linear_bwd128_grid if W == 128 else L.lib().magnet_linear_bwd64_grid)(C.c_long(M))
+    n_out = L.query("magnet_linear_bwd128_grid" if W == 128 else "magnet_linear_bwd64_grid", int(M))
     amax_out = torch.empty(max(n_out, 1), device=dz.device, dtype=torch.float32) if want_amax else None
     fn = L.lib().magnet_linear_bwd128_f32 if W == 128 else L.lib().magnet_linear_bwd64_f32
     L.check(fn(_p(dz), dz.stride(0), _p(x), x.stride(0), _p(wt_f16), C.c_long(M), int(bool(mask)), _p(dx), dx.stride(0), _p(dW), _p(db),

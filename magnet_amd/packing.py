@@ -272,8 +272,18 @@ def flag_if_abs_reaches(w: torch.Tensor, limit: float) -> None:
     """device-side (no host read): set the range bit of w's device when max|w| >= limit - for the kernels that pre-scale the
     fp16 high plane by 2^11 (k_mpnn_edge_bwd_w: |w| < 31.98); reported by the next raise_if_bad_weights"""
     if w.is_cuda:
-        bad = (~torch.isfinite(w).all()) | (w.detach().abs().amax() >= limit)
-        _status_word(w.device).bitwise_or_(bad.to(torch.int32) * _WEIGHT_RANGE_BIT)
+        # ONE launch (magnet_status_check_f32) instead of the ten small torch kernels of `isfinite().all() | abs().amax() >= limit` and
+        # their host-side dispatch: a MAgNet training step at the reference's batch sizes is host bound, and this runs once per Linear
+        # and backward (DESIGN.md 11.3)
+        import ctypes as C
+
+        from . import _lib as L
+        x = w.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        L.check(L.lib().magnet_status_check_f32(C.c_void_p(x.data_ptr()), C.c_long(x.numel()), C.c_float(float(limit)), _WEIGHT_RANGE_BIT,
+                                                _WEIGHT_RANGE_BIT, 0, C.c_void_p(_status_word(w.device).data_ptr()),
+                                                C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)), "status_check")
     elif not bool(torch.isfinite(w).all()) or float(w.detach().abs().max()) >= limit:
         raise ValueError(f"fp16x3 GEMM mode: this kernel needs finite weights with |w| < {limit}; use MAGNET_GEMM=bf16x6")
 

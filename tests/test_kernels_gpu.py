@@ -705,6 +705,18 @@ def test_device_packing_flags_weights_outside_the_fp16_range():
         P.raise_if_bad_weights("cuda")
     P.pack(w.cuda(), None, "bf16x6")                                       # the full-range split does not care
     P.raise_if_bad_weights("cuda")
+    # flag_if_abs_reaches (the pre-scaled planes' limit, one status-check launch): below / at the limit, a strided view, a NaN
+    v = torch.randn(64, 96).cuda()
+    v[5, 70] = 31.0
+    P.flag_if_abs_reaches(v, 31.98)
+    assert not P.bad_weights("cuda")
+    P.flag_if_abs_reaches(v[:, 64:], 30.0)                                 # a column block (not contiguous) that holds the 31.0
+    assert P.bad_weights("cuda") and not P.bad_weights("cuda")
+    P.flag_if_abs_reaches(v[:, :64], 30.0)                                 # ... and one that does not
+    assert not P.bad_weights("cuda")
+    v[0, 0] = float("nan")
+    P.flag_if_abs_reaches(v, 1e9)
+    assert P.bad_weights("cuda")
 
 
 def test_transposed_backward_packs_equal_the_padded_copy_construction():
