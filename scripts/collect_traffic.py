@@ -20,7 +20,9 @@ import sys
 KERNELS = {"k_mpnn_edge16": ("k_mpnn_edge16", True), "k_mpnn_edge7": ("k_mpnn_edge7", True), "k_mpnn_edge6": ("k_mpnn_edge6", True),
            "k_segment_mean<128>": ("k_segment_mean<128>", False),
            "magnet_gnn:edge_mlp": ("k_mlp_bf16<1, 5, 4, 4, 2, false, true, 2", True),       # fp16x3, 5 Linears 128-wide, LN, CSR mean
-           "magnet_cnn_2d:edge_mlp": ("k_mlp_bf16<1, 5, 2, 1, 2, false, true, 2", True)}    # 64-wide hidden, 32-wide output
+           "magnet_cnn_2d:edge_mlp": ("k_mlp_bf16<3, 5, 2, 1, 2, false, true, 2", True),    # one-accumulator fp16x3s, 64-wide hidden, 32-wide output
+           "k_mpnn_edge_rows32": ("k_mpnn_edge_rows32", True), "k_node_update2": ("k_node_update2<9, true>", False),
+           "k_node_halves": ("k_node_halves<5>", False)}
 
 
 def mean_per_launch(d, counter):

@@ -86,12 +86,14 @@ except Exception as ex:  # noqa: BLE001
 if os.environ.get("GLUE_CPROFILE", "1") == "1":
     import cProfile, io, pstats
     pr = cProfile.Profile()
-    pr.enable()
-    step()
-    pr.disable()
+    with torch.autograd.set_multithreading_enabled(False):        # the engine then runs the Functions' backward in THIS thread: cProfile sees them
+        step()
+        pr.enable()
+        step()
+        pr.disable()
     torch.cuda.synchronize()
     for sort in ("tottime", "cumulative"):
         buf = io.StringIO()
-        pstats.Stats(pr, stream=buf).sort_stats(sort).print_stats(22)
+        pstats.Stats(pr, stream=buf).sort_stats(sort).print_stats(45)
         print(f"---- cProfile by {sort}")
-        print("\n".join(l for l in buf.getvalue().splitlines() if l.strip())[:4200])
+        print("\n".join(l for l in buf.getvalue().splitlines() if l.strip())[:9000])
