@@ -809,6 +809,9 @@ def main():
                          "the objects `c4b` / `c5`); magnet_cnn_2d / magnet_gnn make one of those the headline of the line")
     ap.add_argument("--no-extra-cases", action="store_true", help="skip the c4b / c5 / c1 objects of the default line")
     ap.add_argument("--no-precision-modes", action="store_true", help="skip the bf16x6 / fp32 timings and the 48 x 48 oracle check")
+    ap.add_argument("--no-ref-shapes", action="store_true", help="skip the ref_shapes object (the reference's own training / validation "
+                                                                 "shapes); the PMC traffic passes do: its launches share kernel names and "
+                                                                 "grid sizes with the roofline launches")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:       # N ranks as fresh children, before any GPU call here
@@ -989,7 +992,7 @@ def main():
                                        dist, max_over_ranks)
         if rank == 0:
             extras["c1"] = bench_c1(dev)
-            if world == 1:
+            if world == 1 and not args.no_ref_shapes:
                 extras["ref_shapes"] = bench_ref_shapes(dev)
 
     if world > 1:

@@ -538,6 +538,141 @@ __global__ void __launch_bounds__(256) k_mpnn_readout_bwd(const float* __restric
         gpart[(size_t)blockIdx.x * GP + q] = sg[0][q] + sg[1][q] + sg[2][q] + sg[3][q];
 }
 
+// The same backward with the read-out's shape as template arguments (the five (k1, s1, k2) the reference defines, models/mpnn.py:140-163):
+// every inner loop has a compile-time trip count and constant LDS offsets, the (channel, position) pairs of the two convolutions are
+// spread over all 64 lanes (the generic kernel above leaves 45 of them idle: one lane per conv1 position), and a lane keeps its share of
+// the parameter gradients in registers across its nodes instead of read-modify-writing them in LDS per node.  Same partials layout.
+// 1.6 ms -> see DESIGN.md 11.4 per launch at 4 x 256^2 nodes (it ran at 0.17 TB/s of its 268 MB).
+template <int K1, int S1, int K2, int TW, bool SW>
+__global__ void __launch_bounds__(256) k_mpnn_readout_bwd_t(const float* __restrict__ h, const float* __restrict__ dout, int N,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ w2, const float* __restrict__ dt,
+                                                            float* __restrict__ dh, float* __restrict__ du_last, float* __restrict__ gpart) {
+    constexpr int L1 = (128 - K1) / S1 + 1, GP = 8 * K1 + 8 + 8 * K2 + 1;
+    constexpr int NA = (8 * L1 + 63) / 64;                 // rounds of the (channel, position) phase
+    constexpr int NPP = (K1 + S1 - 1) / S1;                // conv1 positions that touch one input column, at most
+    static_assert(L1 <= 64 && TW <= 64 && L1 - K2 + 1 == TW && 8 * K1 <= 128 && 8 * K2 <= 128, "read-out shape");
+    __shared__ float sh[4][128 + 16], sz[4][8 * L1], sdz[4][8 * L1], sd[4][64];
+    __shared__ float sw1[8 * K1], sw2[8 * K2], sb1[8];
+    __shared__ float sg[4][GP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q = threadIdx.x; q < 8 * K1; q += 256) sw1[q] = w1[q];
+    for (int q = threadIdx.x; q < 8 * K2; q += 256) sw2[q] = w2[q];
+    if (threadIdx.x < 8) sb1[threadIdx.x] = b1[threadIdx.x];
+    if (lane < 16) sh[wave][128 + lane] = 0.f;             // (reads past column 127 of clamped positions)
+    __syncthreads();
+    int plo[2], phi[2];                                    // conv1 positions p touching h[x], x = lane + 64 i
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int x = lane + 64 * i;
+        phi[i] = min(x / S1, L1 - 1);
+        plo[i] = x - K1 + 1 <= 0 ? 0 : (x - K1 + S1) / S1;
+    }
+    float gw1[2] = {0.f, 0.f}, gw2[2] = {0.f, 0.f}, gb1 = 0.f, gb2 = 0.f;      // this lane's entries of the parameter gradients
+    const float dt0 = dt[0];
+    float* hs = sh[wave];
+    float* zs = sz[wave];
+    float* dzs = sdz[wave];
+    float* ds = sd[wave];
+    for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
+        hs[lane] = h[(size_t)n * 128 + lane];
+        hs[lane + 64] = h[(size_t)n * 128 + lane + 64];
+        float dsum = 0.f, dd = 0.f;
+        if (lane < TW) {
+            const float d = dout[(size_t)n * TW + lane];
+            dsum = d;
+            dd = d * dt0 * (float)(lane + 1);                           // d diff
+        }
+        ds[lane] = dd;                                                  // (zero beyond TW)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
+        if (lane == 0) du_last[n] = dsum;                               // d u[n, tw-1]
+        gb2 += dd;                                                      // db2 = sum_j ddiff[j]: lane j's share, reduced at the end
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {                                  // (channel c, conv1 position p) pairs over all lanes
+            const int q = lane + 64 * r;
+            if (q < 8 * L1) {
+                const int c = q / L1, pp = q - c * L1;
+                float z = sb1[c];
+#pragma unroll
+                for (int k = 0; k < K1; ++k) z = fmaf(sw1[c * K1 + k], hs[pp * S1 + k], z);
+                float g = 0.f;                                          // d act(z)[c][p] = sum_k w2[c][k] ddiff[p - k]
+#pragma unroll
+                for (int k = 0; k < K2; ++k) {
+                    const int jj = pp - k;
+                    g = fmaf(sw2[c * K2 + k], (jj >= 0 && jj < TW) ? ds[jj & 63] : 0.f, g);
+                }
+                if (SW) {
+                    const float sg_ = sigmoidf_fast(z);
+                    zs[q] = z * sg_;
+                    g *= sg_ * (1.0f + z * (1.0f - sg_));
+                } else {
+                    zs[q] = z;
+                }
+                dzs[q] = g;
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                                   // dh[x] = sum_{c,p} w1[c][x - p s1] dz[c][p]
+            const int x = lane + 64 * i;
+            float g = 0.f;
+#pragma unroll
+            for (int t = 0; t < NPP; ++t) {
+                const int pp = plo[i] + t;
+                if (pp <= phi[i]) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) g = fmaf(sw1[c * K1 + x - pp * S1], dzs[c * L1 + pp], g);
+                }
+            }
+            dh[(size_t)n * 128 + x] = g;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                                   // dw1[c][k] += sum_p dz[c][p] h[p*s1+k]
+            const int q = lane + 64 * i;
+            if (q < 8 * K1) {
+                const int c = q / K1, k = q - c * K1;
+                float g = 0.f;
+#pragma unroll
+                for (int pp = 0; pp < L1; ++pp) g = fmaf(dzs[c * L1 + pp], hs[pp * S1 + k], g);
+                gw1[i] += g;
+            }
+        }
+        if (lane < 8) {                                                 // db1[c]
+            float g = 0.f;
+#pragma unroll
+            for (int pp = 0; pp < L1; ++pp) g += dzs[lane * L1 + pp];
+            gb1 += g;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                                   // dw2[c][k] += sum_j ddiff[j] a[c][j+k]
+            const int q = lane + 64 * i;
+            if (q < 8 * K2) {
+                const int c = q / K2, k = q - c * K2;
+                float g = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < TW; ++jj) g = fmaf(ds[jj], zs[c * L1 + jj + k], g);
+                gw2[i] += g;
+            }
+        }
+        wave_lds_sync();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gb2 += __shfl_xor(gb2, off);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = lane + 64 * i;
+        if (q < 8 * K1) sg[wave][q] = gw1[i];
+        if (q < 8 * K2) sg[wave][8 * K1 + 8 + q] = gw2[i];
+    }
+    if (lane < 8) sg[wave][8 * K1 + lane] = gb1;
+    if (lane == 0) sg[wave][8 * K1 + 8 + 8 * K2] = gb2;
+    __syncthreads();
+    for (int q = threadIdx.x; q < GP; q += 256)
+        gpart[(size_t)blockIdx.x * GP + q] = sg[0][q] + sg[1][q] + sg[2][q] + sg[3][q];
+}
+
 // ------------------------------------------------------------------------------------ C entry points
 #define S_ (hipStream_t) stream
 static inline unsigned nb(long n, int b) { return (unsigned)((n + b - 1) / b); }
@@ -725,6 +860,16 @@ extern "C" int magnet_mpnn_readout_bwd_f32(const float* h, const float* dout, in
     const int L1 = (128 - k1) / s1 + 1;
     if (L1 > 64 || tw > 64 || k1 > 16 || k2 > 16 || L1 - k2 + 1 != tw) return -2;
     const unsigned grid = nb(n, 4) < 1024u ? nb(n, 4) : 1024u;
+#define RO_BWD(K1_, S1_, K2_, TW_, SW_)                                                                                            \
+    if (k1 == K1_ && s1 == S1_ && k2 == K2_ && tw == TW_ && (use_swish != 0) == SW_) {                                             \
+        hipLaunchKernelGGL((k_mpnn_readout_bwd_t<K1_, S1_, K2_, TW_, SW_>), dim3(grid), dim3(256), 0, S_, h, dout, n, w1, b1, w2, dt, dh, \
+                           du_last, gpart);                                                                                        \
+        END();                                                                                                                     \
+    }
+    // the read-outs the reference defines (models/mpnn.py:140-163; 1-D tw = 10 has no Swish, mpnn_2d.py has one)
+    RO_BWD(16, 6, 10, 10, true) RO_BWD(16, 6, 10, 10, false) RO_BWD(16, 5, 8, 16, true) RO_BWD(15, 4, 10, 20, true)
+    RO_BWD(16, 3, 14, 25, true) RO_BWD(12, 2, 10, 50, true)
+#undef RO_BWD
     hipLaunchKernelGGL(k_mpnn_readout_bwd, dim3(grid), dim3(256), 0, S_, h, dout, n, tw, w1, b1, k1, s1, w2, k2, use_swish, dt,
                        dh, du_last, gpart);
     END();

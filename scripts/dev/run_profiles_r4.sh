@@ -20,7 +20,7 @@ if [ $WHAT = all ] || [ $WHAT = headline ]; then stats headline $HEAD; fi
 if [ $WHAT = all ] || [ $WHAT = c4b ]; then stats c4b --workload magnet_cnn_2d --traj 1 --steps 10 --warmup 2 --train-steps 0; fi
 if [ $WHAT = all ] || [ $WHAT = c5 ]; then stats c5 --workload magnet_gnn --traj 1 --steps 10 --warmup 2 --train-steps 0; fi
 if [ $WHAT = all ] || [ $WHAT = traffic ]; then
-  P="--steps 1 --warmup 1 --no-cpu-baseline --train-steps 0 --no-precision-modes"
+  P="--steps 1 --warmup 1 --no-cpu-baseline --train-steps 0 --no-precision-modes --no-ref-shapes"
   timeout -k 5 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py $P > $O/fetch.log 2>&1
   timeout -k 5 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py $P > $O/write.log 2>&1
   cd $R && python3 scripts/collect_traffic.py $O/fetch $O/write $O/traffic_$V.json > /dev/null
