@@ -479,6 +479,11 @@ int magnet_linear_bwd64_f32(const float* dz, int ldz, const float* x, int ldx, c
  * never written to memory; dp [n_edges][128] and dA [n_nodes][128] as above.  workspace: magnet_mpnn_edge_bwd_w_workspace() floats
  * (per-workgroup partial sums, added in workgroup order: deterministic). */
 int magnet_mpnn_edge_bwd_w_workspace(void);
+/* Which kernel serves the two entry points below: 1 (default) = k_mpnn_edge_bwd_wp (csrc/mpnn_edge_bwd_wp.hip: every wave forms the
+ * weight gradient of its own tiles in the accumulator half of the register file, no workgroup barrier in the loop), 0 =
+ * k_mpnn_edge_bwd_w (the shared-slab kernel, kept for same-process A/B runs).  Returns the previous value; any other argument only
+ * queries.  The results differ in the order of the fp32 additions of dW2 / db2 only. */
+int magnet_mpnn_edge_bwd_w_generation(int generation);
 int magnet_mpnn_edge_bwd_w_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src, const int32_t* tgt,
                                const int32_t* rowptr, int n_nodes, int n_edges, const void* w2_f16, const void* w2t_f16,
                                const float* b2, float* dp, float* dA, float* partials, float* dW2, float* db2, int accumulate,

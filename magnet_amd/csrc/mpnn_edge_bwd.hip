@@ -633,11 +633,25 @@ int magnet_launch_absmax_partial(const float* x, long n4, float* part, int nbloc
 #define EBW_AMAX_BLOCKS 256
 extern "C" int magnet_reduce_partials_f32(const float* partial, int nblk, long n, float scale, float* out, int accumulate,
                                           void* stream);      // train_kernels.hip
+// mpnn_edge_bwd_wp.hip: generation 2 of the kernel (every wave forms the weight gradient of its own tiles; no barrier in the loop)
+int magnet_launch_edge_bwd_wp(const float* A, const float* Bm, const float* dagg, const int32_t* src, const int32_t* tgt,
+                              const int32_t* rowptr, int n_edges, const void* w2_f16, const void* w2t_f16, const float* b2, float* dp,
+                              float* dA, float* partials, const float* amax, int n_amax, float* wpart, float* bpart, float* pscr,
+                              int grid, void* stream);
+// 1 (default): k_mpnn_edge_bwd_wp; 0: k_mpnn_edge_bwd_w (the shared-slab kernel of round 3, kept for A/B runs) - same results up to
+// the order of the fp32 additions of dW2 / db2
+static int g_ebw_generation = 1;
+extern "C" int magnet_mpnn_edge_bwd_w_generation(int generation) {
+    const int was = g_ebw_generation;
+    if (generation == 0 || generation == 1) g_ebw_generation = generation;
+    return was;
+}
 extern "C" int magnet_mpnn_edge_bwd_w_workspace(void) {
     int dev, ncu = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-    return ncu * (128 * 128 + 128) + EBW_AMAX_BLOCKS;
+    // per-workgroup partial sums of dW2 and db2, the |dagg| maxima, and generation 2's parking block (16 KiB per wave)
+    return ncu * (128 * 128 + 128) + EBW_AMAX_BLOCKS + ncu * 4 * 4096;
 }
 extern "C" int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src,
                                                const int32_t* tgt, const int32_t* rowptr, int n_nodes, int n_edges,
@@ -685,8 +699,13 @@ extern "C" int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, 
         }
         const u32x4* w = reinterpret_cast<const u32x4*>(w2_f16);
         const u32x4* wT = reinterpret_cast<const u32x4*>(w2t_f16);
-        hipLaunchKernelGGL(k_mpnn_edge_bwd_w, dim3(grid), dim3(256), 0, s, A, Bm, dagg, src, tgt, rowptr, n_edges, w, wT, b2, dp, dA,
-                           partials, amax, nab, wpart, bpart);
+        float* pscr = bpart + (size_t)ncu * 128 + EBW_AMAX_BLOCKS;
+        if (g_ebw_generation == 1)
+            magnet_launch_edge_bwd_wp(A, Bm, dagg, src, tgt, rowptr, n_edges, w2_f16, w2t_f16, b2, dp, dA, partials, amax, nab, wpart, bpart,
+                                      pscr, grid, stream);
+        else
+            hipLaunchKernelGGL(k_mpnn_edge_bwd_w, dim3(grid), dim3(256), 0, s, A, Bm, dagg, src, tgt, rowptr, n_edges, w, wT, b2, dp, dA,
+                               partials, amax, nab, wpart, bpart);
         magnet_reduce_partials_f32(wpart, grid, 128L * 128, 1.0f, dW2, accumulate, stream);
         magnet_reduce_partials_f32(bpart, grid, 128L, 1.0f, db2, accumulate, stream);
     }

@@ -14,7 +14,7 @@ from torch import nn
 
 from ... import ops
 from ...graphs import hold
-from ...packing import default_gemm, pack, pad_to
+from ...packing import default_gemm, pack, pad_to, param_list
 
 
 class ResBlock(nn.Module):
@@ -56,7 +56,7 @@ class EDSR(nn.Module):
     # ------------------------------------------------------------------ packed weights / tap tables (cached)
     def packed(self, mode=None):
         mode = mode or default_gemm()
-        params = list(self.parameters())
+        params = param_list(self)
         # _pack_gen: bumped by the owning model when an optimizer wrote the parameters behind torch's version counters
         # (FusedAdam); it is part of the key so that the launch plans built on the old packs (_plan) go stale with them
         key = (params[0].device, sum(p._version for p in params), mode, self._pack_gen)

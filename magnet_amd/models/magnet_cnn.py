@@ -17,7 +17,7 @@ import torch
 
 from .. import _lib as L
 from .. import ops
-from ..packing import pad_to
+from ..packing import pad_to, param_list
 from ..utils import make_coord
 from .backbones.edsr import EDSR
 from .backbones.mlp import MLP
@@ -67,7 +67,7 @@ class MAgNetCNN(MagnetBase):
         return self.encoder(x_t.reshape(B, T * x_t.shape[2], *x_t.shape[3:]))
 
     def forward(self, x_t, coords, cell, t, hr_last, hiddens=None):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in param_list(self)):
             return self._forward_grad(x_t, coords, cell, t, hr_last)
         with torch.no_grad():
             return self._forward(x_t, coords, cell, t, hr_last)

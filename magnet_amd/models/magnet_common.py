@@ -20,7 +20,7 @@ from .. import _lib as L
 from .. import ops
 from ..lightning_compat import LightningModule
 from ..graphs import RolloutGraph, capturing, hold, wants_graph  # noqa: F401
-from ..packing import pad_to, pad_vec
+from ..packing import pad_to, pad_vec, param_list
 from ..topo_cache import TopologyCache
 from .backbones.mlp import MLP
 
@@ -156,7 +156,7 @@ class MagnetBase(LightningModule):
     # ---- packed-weight cache -------------------------------------------------------------
     def _packed(self):
         from ..packing import bad_weights, default_gemm
-        params = list(self.parameters())
+        params = param_list(self)
         key = (params[0].device, sum(p._version for p in params), self._pack_gen, default_gemm())
         if self._pack_key != key:
             self._pack, self._pack_key = self._pack_weights(), key

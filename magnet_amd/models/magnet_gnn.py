@@ -21,7 +21,7 @@ from torch import nn
 from .. import _lib as L
 from .. import ops
 from ..graphs import capturing
-from ..packing import default_gemm, pack, pad_to
+from ..packing import default_gemm, pack, pad_to, param_list
 from .backbones.mlp import MLP
 from .magnet_common import (Decoder, Encoder, MagnetBase, Processor, pack_graph_net, pack_mlp)
 
@@ -67,7 +67,7 @@ class MAgNetGNN(MagnetBase):
             projector=pack_mlp(self.projector), decoder=pack_mlp(self._decoder.node_fn))
 
     def forward(self, x_lr, lr_coords, hr_coords, t, hr_last):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in param_list(self)):
             return self._forward_grad(x_lr, lr_coords, hr_coords, t, hr_last)
         with torch.no_grad():
             return self._forward(x_lr, lr_coords, hr_coords, t, hr_last)

@@ -23,7 +23,7 @@ from torch import nn
 
 from .. import ops
 from ..lightning_compat import LightningModule
-from ..packing import GEMM_MODES, default_gemm, pack, pack_edge16_fp16x2, pack_edge32t_fp16x2, pad_to
+from ..packing import GEMM_MODES, default_gemm, pack, pack_edge16_fp16x2, pack_edge32t_fp16x2, pad_to, param_list
 from ..packing import effective as effective_gemm
 from ..graphs import _ident as _graph_ident
 from ..graphs import RolloutGraph, capturing, hold, wants_graph
@@ -151,7 +151,7 @@ class MPNN(LightningModule):
 
     # ------------------------------------------------------------------ packed weights (cached)
     def _packed(self):
-        params = list(self.parameters())
+        params = param_list(self)
         key = (params[0].device, sum(p._version for p in params), self._pack_gen, self.gemm, self.edge_gemm)
         if self._pack_key == key:
             hold(self._pack)                # a capture in progress keeps the packs its launches point into (magnet_amd/graphs.py)
