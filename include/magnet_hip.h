@@ -87,6 +87,12 @@ typedef struct {
                               * Linear's raw output before last_act / LayerNorm [M][ot*32] */
     uint64_t x0_skip;        /* bit kt set: k tile kt of x0_out is NOT written (a backward that walks gathered k tiles back at
                               * source-row granularity never reads them) */
+    int32_t* status;         /* fp16x3 / fp16x3s kernels, nl > 1, NULL = off: device status word that receives `status_bit` (atomic OR)
+                              * when an activation BETWEEN two Linears of the chain reaches 65504 - the high fp16 piece saturates there,
+                              * and a ReLU can turn the resulting -inf of the next layer into a finite (wrong) output that no check of
+                              * the chain's inputs or outputs sees.  The host repeats such a rollout in bf16x6 (ops.RangeGuard). */
+    int32_t status_bit;
+    int32_t pad2_;
 } magnet_mlp_args_t;
 
 /* Fused gather/concat -> NL x (Linear [+ activation]) -> [LayerNorm] -> store | +residual | CSR mean.

@@ -44,7 +44,8 @@ class MlpArgs(C.Structure):
                 ("res", C.c_void_p), ("ldres", C.c_int32),
                 ("tgt", C.c_void_p), ("rowptr", C.c_void_p), ("partials", C.c_void_p), ("ncolgroups", C.c_int32),
                 ("groups_in_block", C.c_int32), ("y_group_stride", C.c_int64), ("pre", Src * 2),
-                ("x0_out", C.c_void_p), ("hid", C.c_void_p * MAX_LAYERS), ("x0_skip", C.c_uint64)]
+                ("x0_out", C.c_void_p), ("hid", C.c_void_p * MAX_LAYERS), ("x0_skip", C.c_uint64),
+                ("status", C.c_void_p), ("status_bit", C.c_int32), ("pad2_", C.c_int32)]
 
 
 def declared_symbols() -> list[str]:

@@ -522,12 +522,28 @@ _FUSED_LAYER_ROWS = 4096          # below this the persistent one-workgroup-per-
 
 def _tpack16(pk, l, W):
     """fp16x3 planes of W^T as a Linear, for ops.linear_bwd128 (cached on pk like the transposed bf16x6 packs)"""
-    from .packing import flag_if_abs_reaches
+    from .packing import flag_if_abs_reaches, recording
     cache = pk.__dict__.setdefault("_tpacks16", {})
-    if l not in cache:
-        flag_if_abs_reaches(W.detach(), 31.98)          # that kernel keeps 2^11 x the high plane (reported by the next range check)
-        cache[l] = pack(W.detach().t(), None, "fp16x3")[0]
-    return cache[l]
+    rec, key = _tpack_recorder(pk, W, cache, l)
+    if key not in cache:
+        with recording(rec):                            # (re-packed in place with the forward's packs after an optimizer step)
+            flag_if_abs_reaches(W.detach(), 31.98)      # that kernel keeps 2^11 x the high plane (reported by the next range check)
+            cache[key] = pack(W.detach().t(), None, "fp16x3")[0]
+    return cache[key]
+
+
+def _tpack_recorder(pk, W, cache, key):
+    """(recorder to record under, cache key) of a transposed pack cached on the chain namespace ``pk``.  A namespace whose packs are
+    replayed in place after an optimizer step (packing.PackRecorder, attached as pk._rec) outlives the step: a transposed pack of a
+    PARAMETER is recorded and replayed with them; one made from a temporary (EDSR hands its convolution weights over as a permuted
+    copy) cannot be replayed, so its key carries the recorder's generation - rebuilt after every replay, older generations dropped."""
+    rec = pk.__dict__.get("_rec")
+    if rec is None or rec.backed(W):
+        return rec, key
+    gen = rec.generation
+    for k in [k for k in cache if isinstance(k, tuple) and k and k[0] == "gen" and k[1] != gen]:
+        del cache[k]
+    return None, ("gen", gen, key)
 
 
 def _tpack(m, pk, l, c0, w, W, Np, Kp):
@@ -535,9 +551,9 @@ def _tpack(m, pk, l, c0, w, W, Np, Kp):
     step's weights lives as long as that step's ``pk``).  Wp is never materialised: the device packer reads W through its strides,
     W.t() is a view, and the placement of W's columns inside the padded first-layer input (col_map / first_cols) becomes the
     packer's row map."""
-    from .packing import pack_device, source_map
+    from .packing import pack_device, recording, source_map
     cache = pk.__dict__.setdefault("_tpacks", {})
-    key = (l, c0, w)
+    rec, key = _tpack_recorder(pk, W, cache, (l, c0, w))
     if key not in cache:
         n, k = W.shape
         rows = None                                            # padded column c0 + r of Wp -> source column of W (identity: r < k)
@@ -549,7 +565,8 @@ def _tpack(m, pk, l, c0, w, W, Np, Kp):
             Wt = W.detach().t()
         else:
             Wt = W.detach().t()[c0:c0 + w] if c0 < k else W.detach().t()[:0]
-        cache[key] = pack_device(Wt, None, BWD_GEMM, w, Np, row_src=rows)
+        with recording(rec):
+            cache[key] = pack_device(Wt, None, BWD_GEMM, w, Np, row_src=rows)
     return cache[key]
 
 

@@ -72,6 +72,9 @@ struct MagnetMlpArgs {
     float* x0_out;                 // tape outputs (training backward), nullptr = off: assembled first-layer input rows [M][nkt*32]
     float* hid[MAGNET_MAX_LAYERS]; // hid[l]: layer l's activated output [M][HT*32]; hid[NL-1]: raw output of the last Linear [M][OT*32]
     uint64_t x0_skip;              // bit kt set: k tile kt of x0_out is not written
+    int32_t* status;               // fp16 split modes, NL > 1, nullptr = off: `status_bit` is OR-ed in when a HIDDEN activation reaches 65504
+    int32_t status_bit;
+    int32_t pad_;
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -100,6 +103,13 @@ __device__ __forceinline__ void apply_act(f32x16& v) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.0f);
     }
+}
+
+// running maximum of |v| over a register tile (v_max3_f32 with |.| modifiers: one instruction per two values)
+__device__ __forceinline__ void track_abs_max(const f32x16& v, float& m) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) m = fmaxf(fmaxf(m, fabsf(v[i])), fabsf(v[i + 1]));
+    asm volatile("" : "+v"(m));             // formed HERE: a result that is only read at the end of the kernel is sunk there, with the tile alive
 }
 
 // accumulators <- bias (lane (row, half) register 4g+c holds column nt*32 + 8g + 4half + c)

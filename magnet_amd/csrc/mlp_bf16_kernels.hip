@@ -173,6 +173,10 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
     constexpr int NTMAX = MaxI<HT, OT>::v;
     constexpr int PPN = 2 * Split<MODE>::NP;                              // 1 KiB pieces per output tile and k tile
     constexpr int NBUF = DIST + 1;
+    // fp16 split modes: the largest |activation| handed from one Linear of the chain to the next (args.status, magnet_hip.h) - one
+    // v_max3_f32 per two values
+    constexpr bool TRACK_SAT = NL > 1 && (MODE == GEMM_FP16X3 || MODE == GEMM_FP16X3S);
+    float sat = 0.f;
     constexpr bool PIPE = (NL >= 5 && HT >= 4) || DIST == 2;             // see mma_chunk; the one-workgroup-per-CU variants too:
                                                                          // nobody else on the SIMD hides the LDS latency of a group
     constexpr int CH = NTMAX * PPN * 64;                                   // u32x4 per chunk buffer
@@ -298,6 +302,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                 for (int t = 0; t < NT0; ++t) {
                     apply_act<ACT>(acc[t]);
                     h0[t < HT ? t : 0] = acc[t];
+                    if (TRACK_SAT) track_abs_max(acc[t], sat);
                 }
                 if (a.hid[0]) store_rows<HT, 0>(h0, a.hid[0], HT * 32, HT * 32, nullptr, 0, row, row_ok, half);
             }
@@ -364,6 +369,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                 for (int t = 0; t < HT; ++t) {
                     if (src0) apply_act<ACT>(h1[t]);
                     else apply_act<ACT>(h0[t]);
+                    if (TRACK_SAT) track_abs_max(src0 ? h1[t] : h0[t], sat);
                 }
                 if (a.hid[l]) {
                     if (src0) store_rows<HT, 0>(h1, a.hid[l], HT * 32, HT * 32, nullptr, 0, row, row_ok, half);
@@ -421,6 +427,10 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
             store_rows<OT, EPI == EPI_STORE_MASK ? 2 : (EPI == EPI_STORE_RES ? 1 : 0)>(out, yg, a.ldy, a.ncols, a.res + cg * OT * 32, a.ldres, row, row_ok && a.y != nullptr, half);
         }
         TRACE(32)
+    }
+    if (TRACK_SAT && a.status) {
+        // (NaN compares false: a non-finite activation that came from non-finite INPUTS is the input / output checks' business)
+        if (__builtin_amdgcn_ballot_w64(sat >= 65504.0f) && (threadIdx.x & 63) == 0) atomicOr(a.status, a.status_bit);
     }
 }
 

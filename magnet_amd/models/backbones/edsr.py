@@ -52,26 +52,38 @@ class EDSR(nn.Module):
         self._pack_key, self._pack, self._pack_gen, self._taps = None, None, 0, {}
         self.resident_conv = __import__("os").environ.get("MAGNET_RESIDENT_CONV", "1") != "0"      # A/B knob
         self._plan_key, self._plan_val = None, None
+        self._pack_id = 0
+        self._pack_replay = __import__("os").environ.get("MAGNET_PACK_REPLAY", "1") != "0"      # A/B knob (packing.PackRecorder)
 
     # ------------------------------------------------------------------ packed weights / tap tables (cached)
     def packed(self, mode=None):
         mode = mode or default_gemm()
         params = param_list(self)
-        # _pack_gen: bumped by the owning model when an optimizer wrote the parameters behind torch's version counters
-        # (FusedAdam); it is part of the key so that the launch plans built on the old packs (_plan) go stale with them
+        # _pack_gen: bumped by the owning model when an optimizer wrote the parameters behind torch's version counters (FusedAdam)
         key = (params[0].device, sum(p._version for p in params), mode, self._pack_gen)
         if self._pack_key != key:
-            cin = pad_to(self.in_chan)
+            from ...packing import PackRecorder, derived, recording, weights_check_due
+            rec, rkey = self.__dict__.get("_pack_rec"), (params[0].device, mode)
+            if self._pack is not None and rec is not None and rec.key == rkey and rec.usable() and self._pack_replay:
+                # the weights changed, the structure did not: the recorded pack launches again, into the same buffers - the launch
+                # plans built on them (_plan) and everything cached on the pack dict stay valid (packing.PackRecorder)
+                rec.replay()
+            else:
+                cin = pad_to(self.in_chan)
+                rec = PackRecorder(params, rkey) if params[0].is_cuda else None
 
-            def mk(conv, cp):
-                """(whole pack, per-32-output-column packs): the second form feeds the column-split launch"""
-                w, b = _as_linear(conv, cp), conv.bias.detach().float()
-                return pack(w, b, mode), [pack(w[g:g + 32], b[g:g + 32], mode) for g in range(0, w.shape[0], 32)]
+                def mk(conv, cp):
+                    """(whole pack, per-32-output-column packs): the second form feeds the column-split launch"""
+                    w, b = derived(lambda: _as_linear(conv, cp)), conv.bias.detach().float()
+                    return pack(w, b, mode), [pack(w[g:g + 32], b[g:g + 32], mode) for g in range(0, w.shape[0], 32)]
 
-            self._pack = dict(head=mk(self.head_conv, cin), tail=mk(self.tail_conv, self.n_chan),
-                              blocks=[(mk(b.conv_1, self.n_chan), mk(b.conv_2, self.n_chan)) for b in self.res_layers])
+                with recording(rec):
+                    self._pack = dict(head=mk(self.head_conv, cin), tail=mk(self.tail_conv, self.n_chan),
+                                      blocks=[(mk(b.conv_1, self.n_chan), mk(b.conv_2, self.n_chan)) for b in self.res_layers])
+                self.__dict__["_pack_rec"] = rec
+                self._pack_id += 1                       # (the launch plans are keyed on it: new buffers, new plans)
             self._pack_key = key
-            if params[0].is_cuda:
+            if params[0].is_cuda and weights_check_due(params[0].device):   # (inside a rollout scope the owning model reads it at the end)
                 from ...packing import bad_weights, widen
                 if bad_weights(params[0].device):        # fp16x3 range check of the packs just made: one host read per re-pack
                     self._pack_key = None
@@ -92,13 +104,13 @@ class EDSR(nn.Module):
     def weights_changed(self):
         """parameters were rewritten in place without a version bump: drop the packs and every launch plan built on them"""
         self._pack_gen += 1
-        self._pack_key = self._plan_key = self._plan_val = None
+        self._pack_key = None                    # (the plans go with the pack BUFFERS, _pack_id, not with their contents)
 
     # ------------------------------------------------------------------ forward
     def _plan(self, B, cin, spatial, dev):
         """buffers + the 2 * res_layers + 2 prebuilt launches for one input geometry (cached with the packed weights)"""
         pk = self.packed()
-        key = (B, cin, tuple(spatial), str(dev), self._pack_key)
+        key = (B, cin, tuple(spatial), str(dev), self._pack_id)
         if self._plan_key == key:
             return self._plan_val
         P = B * int(torch.tensor(spatial).prod())
@@ -177,7 +189,7 @@ class EDSR(nn.Module):
                 cmap = (torch.arange(ntaps, device=dev)[:, None] * width + torch.arange(ci, device=dev)[None, :]).reshape(-1)
                 # last_row_is_padding: every gathered source is as_rows(...), its last row the zero row of the out-of-bounds taps
                 pkc = cache[(id(conv_mod), width)] = types.SimpleNamespace(layers=[layer[0]], ln=None, ht=ot, ot=ot, out_dim=C, col_map=cmap,
-                                                                           last_row_is_padding=True)
+                                                                           last_row_is_padding=True, _rec=self.__dict__.get("_pack_rec"))
             groups = [ops.Term(src, width, idx=taps[t]) for t in range(ntaps)]
             return AG.mlp(P, groups, pkc, [W2, conv_mod.bias], epi=ops.EPI_STORE_RES if res is not None else ops.EPI_STORE,
                           res=res, final_relu=relu)

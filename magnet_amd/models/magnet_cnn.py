@@ -187,18 +187,19 @@ class MAgNetCNN(MagnetBase):
         T = self.time_slice
         fut = vals[:, T:]
         inp, hr_last, outs, hrs = u[:, :T], vals[:, T - 1], [], []
-        for i in range(fut.shape[1] // T):
-            out_hr, out_lr, hr_points = self.forward(inp, coords, cells, t[:, i * T:(i + 2) * T], hr_last)
-            outs.append(torch.cat([out_hr, self._lr_as_nodes(out_lr) if self.DIM == 2 else out_lr], dim=2))
-            hrs.append(hr_points)
-            if self.teacher_forcing:
-                inp, hr_last = u[:, (i + 1) * T:(i + 2) * T], vals[:, (i + 2) * T - 1]
-            else:
-                inp = out_lr if self.DIM == 2 else out_lr.permute(0, 1, 3, 2)
-                hr_last = out_hr[:, -1]
+        with self._rollout_scope():
+            for i in range(fut.shape[1] // T):
+                out_hr, out_lr, hr_points = self.forward(inp, coords, cells, t[:, i * T:(i + 2) * T], hr_last)
+                outs.append(torch.cat([out_hr, self._lr_as_nodes(out_lr) if self.DIM == 2 else out_lr], dim=2))
+                hrs.append(hr_points)
+                if self.teacher_forcing:
+                    inp, hr_last = u[:, (i + 1) * T:(i + 2) * T], vals[:, (i + 2) * T - 1]
+                else:
+                    inp = out_lr if self.DIM == 2 else out_lr.permute(0, 1, 3, 2)
+                    hr_last = out_hr[:, -1]
         pred, hr_hat = torch.cat(outs, dim=1), torch.cat(hrs, dim=1)
         target = torch.cat([fut, self._lr_as_nodes(u[:, T:])], dim=2)
-        why = self._guard.tripped()
+        why = self._range_trip()
         if why:                                 # out of the fp16 pieces' range: the same step in the full-range split
             self._widen(why)
             return self.training_step(train_batch, batch_idx)

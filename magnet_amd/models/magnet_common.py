@@ -79,7 +79,7 @@ def pack_interaction_edge(seq, D):
     are computed once per NODE by a single-Linear launch and gathered into the chain's first pre-activation (magnet_hip.h:
     magnet_mlp_args_t.pre): the first layer of the edge chain does a third of its flops and reads D instead of 3 D columns
     per edge - the factorisation SURVEY.md 7 (step 4) names, as for MPNN's message_net_1."""
-    from ..packing import chain_gemm, default_gemm, pack
+    from ..packing import chain_gemm, default_gemm, derived, pack
     mlp, ln = seq[0], seq[1]
     lins = mlp.linears()
     mode = default_gemm()
@@ -89,7 +89,8 @@ def pack_interaction_edge(seq, D):
     # b0 travels with the receiver's product (the chain kernel starts its first accumulator FROM the gathered row, magnet_hip.h: pre);
     # `e_scale` = 2^k of hop k (Q2: e_k = 2^k e_0) is folded into W0c - a power of two, exact - so that the kernel loads e_0 unscaled
     def chain_for(e_scale):
-        layers = [pack(W0[:, 2 * D:] * float(e_scale), None, cmode)] + [pack(l.weight, l.bias, cmode) for l in lins[1:]]
+        first = derived(lambda: lins[0].weight.detach()[:, 2 * D:] * float(e_scale))      # (refreshed in place on a pack replay)
+        layers = [pack(first, None, cmode)] + [pack(l.weight, l.bias, cmode) for l in lins[1:]]
         return types.SimpleNamespace(layers=layers, ln=(ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps),
                                      ht=mlp.hidden // 32, ot=pad_to(mlp.out_dim) // 32, out_dim=mlp.out_dim, col_map=None)
     return chain_for, pack(W0[:, :D], lins[0].bias, mode), pack(W0[:, D:2 * D], None, mode)
@@ -106,9 +107,46 @@ def pack_graph_net(enc: Encoder, proc: Processor, ldn: int):
     return types.SimpleNamespace(node=pack_mlp_ln(enc.node_fn, k_pad=ldn), edge=pack_mlp_ln(enc.edge_fn, k_pad=ldn), hops=hops)
 
 
+def _tag_recorder(tree, rec, _seen=None):
+    """every chain namespace of a packed-weight tree learns its recorder: the backward builds its transposed packs lazily and caches
+    them ON the namespace (autograd._tpack / _tpack16) - with a recorder they are re-packed in place with the forward's packs"""
+    seen = _seen if _seen is not None else set()
+    if id(tree) in seen:
+        return
+    seen.add(id(tree))
+    if isinstance(tree, types.SimpleNamespace):
+        if hasattr(tree, "layers"):
+            tree._rec = rec
+        for v in list(vars(tree).values()):
+            _tag_recorder(v, rec, seen)
+    elif isinstance(tree, (list, tuple)):
+        for v in tree:
+            _tag_recorder(v, rec, seen)
+    elif isinstance(tree, dict):
+        for v in tree.values():
+            _tag_recorder(v, rec, seen)
+
+
 def run_mlp(M, kts, pk, y, *, epi=ops.EPI_STORE, res=None, ncols=None, ldy=None, **seg):
     return ops.mlp(M, kts, pk.layers, nl=len(pk.layers), ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU, last_act=False,
                    ln=pk.ln, epi=epi, y=y, res=res, ncols=ncols if ncols is not None else pk.out_dim, ldy=ldy, **seg)
+
+
+class _RolloutScope:
+    """deferred weight checks (packing.deferred_weight_checks) + the range guard armed for the chain kernels (ops.RangeGuard.armed)"""
+
+    def __init__(self, model):
+        from ..packing import deferred_weight_checks
+        self.parts = (deferred_weight_checks(), model._guard.armed())
+
+    def __enter__(self):
+        for p in self.parts:
+            p.__enter__()
+
+    def __exit__(self, *exc):
+        for p in reversed(self.parts):
+            p.__exit__(*exc)
+        return False
 
 
 class MagnetBase(LightningModule):
@@ -118,16 +156,42 @@ class MagnetBase(LightningModule):
     def _graphed(self, fn, batch, keys, rows):
         """run ``fn(batch)`` (an inference rollout returning a tuple of tensors) - replayed from one hipGraph when the graph
         is small (launch bound), else directly"""
-        if next(iter(batch.values())).is_cuda and wants_graph(self.hip_graph, rows):
-            self._packed()
-            out = self._rollout_graph(fn, {k: batch[k] for k in keys}, generation=self._pack_key)
-        else:
-            out = fn(batch)
-        why = self._guard.tripped()
+        with self._rollout_scope():
+            if next(iter(batch.values())).is_cuda and wants_graph(self.hip_graph, rows):
+                self._packed()
+                out = self._rollout_graph(fn, {k: batch[k] for k in keys}, generation=self._pack_key)
+            else:
+                out = fn(batch)
+        why = self._range_trip()
         if why:                                 # out of the fp16 pieces' range: the same rollout in the full-range split
             self._widen(why)
             return self._graphed(fn, batch, keys, rows)
         return out
+
+    def _rollout_scope(self):
+        """``with self._rollout_scope():`` a rollout / training step whose caller reads the range status at its END (_range_trip): the
+        fp16 range check of weights packed inside is read there too, instead of right behind the pack launches - where the host would
+        wait for the previous step's backward and optimizer kernels (7.8 ms per read at the reference's batch sizes)"""
+        return _RolloutScope(self)
+
+    def _range_trip(self):
+        """the reason this rollout has to be repeated in the full-range split, or None: the data guard's status word and - when packs
+        were made inside the rollout scope - the packers' (one host read each, at a point where the stream is nearly empty)"""
+        from ..packing import pending_weight_check
+        why = self._guard.tripped()
+        if pending_weight_check(param_list(self)[0].device):
+            why = self._weights_trip() or why
+        return why
+
+    def _weights_trip(self):
+        from ..packing import bad_weights
+        params = param_list(self)
+        if not bad_weights(params[0].device):    # the fp16x3 packs' range check: ONE host read per re-pack (not one per Linear)
+            return None
+        self._pack_key = None
+        if not all(bool(torch.isfinite(p).all()) for p in params):      # a diverged run must not be papered over
+            raise FloatingPointError(f"{type(self).__name__}: non-finite weights")
+        return "a weight does not fit the fp16 planes (|w| >= 65504; 31.98 for the one-accumulator chains)"
 
     def _widen(self, reason: str):
         """the range guard tripped (or a weight does not fit the fp16 planes): from here on the full-range bf16x6 split
@@ -143,6 +207,8 @@ class MagnetBase(LightningModule):
         self.criterion = {"l1": nn.L1Loss(), "l2": nn.MSELoss(), "smooth_l1": nn.SmoothL1Loss()}[self.loss]
         self.mse_criterion, self.mae_criterion = nn.MSELoss(), nn.L1Loss()
         self._pack_key, self._pack, self._pack_gen = None, None, 0
+        # re-pack in place after an optimizer step (packing.PackRecorder) instead of rebuilding the packed namespace; A/B knob
+        self._pack_replay = os.environ.get("MAGNET_PACK_REPLAY", "1") != "0"
         self._topo_cache = TopologyCache()
         # fp16x3 only: sticky device-side range / finiteness status, read once per rollout (ops.RangeGuard); a trip repeats the
         # rollout in the full-range bf16x6 split (_widen)
@@ -155,17 +221,27 @@ class MagnetBase(LightningModule):
 
     # ---- packed-weight cache -------------------------------------------------------------
     def _packed(self):
-        from ..packing import bad_weights, default_gemm
+        from ..packing import PackRecorder, default_gemm, recording, weights_check_due
         params = param_list(self)
         key = (params[0].device, sum(p._version for p in params), self._pack_gen, default_gemm())
         if self._pack_key != key:
-            self._pack, self._pack_key = self._pack_weights(), key
-            if bad_weights(params[0].device):        # the fp16x3 packs' range check: ONE host read per re-pack (not one per Linear)
-                self._pack_key = None
-                if not all(bool(torch.isfinite(p).all()) for p in params):      # a diverged run must not be papered over
-                    raise FloatingPointError(f"{type(self).__name__}: non-finite weights")
-                self._widen("a weight does not fit the fp16 planes (|w| >= 65504; 31.98 for the one-accumulator chains)")
-                return self._packed()
+            rec = self.__dict__.get("_pack_rec")
+            rkey = (params[0].device, default_gemm(), len(params))
+            if self._pack is not None and rec is not None and rec.key == rkey and rec.usable() and self._pack_replay:
+                # the weights changed, the structure did not: the recorded pack launches again, into the same buffers (packing.PackRecorder)
+                rec.replay()
+            else:
+                rec = PackRecorder(params, rkey) if params[0].is_cuda else None
+                with recording(rec):
+                    self._pack = self._pack_weights()
+                self.__dict__["_pack_rec"] = rec
+                _tag_recorder(self._pack, rec)
+            self._pack_key = key
+            if capturing() or weights_check_due(params[0].device):    # (else: read at the end of the rollout, _range_trip)
+                why = self._weights_trip()
+                if why:
+                    self._widen(why)
+                    return self._packed()
         hold(self._pack)                    # a capture in progress keeps the packs its launches point into (magnet_amd/graphs.py)
         return self._pack
 

@@ -54,16 +54,20 @@ class MAgNetGNN(MagnetBase):
         self._decoder = Decoder(D, T, Lm, Hm)
 
     def _pack_weights(self):
+        from ..packing import derived
         T, D, d = self.time_slice, self.latent_dim, self.coord_dim
         ldn = pad_to(T + d + 1)
-        W = self.proj_head.weight.detach()
-        cols = torch.cat([torch.arange(D), D + 1 + torch.arange(d)])           # enc, rel
+        head = self.proj_head
+        dev = head.weight.device
+        cols = torch.cat([torch.arange(D), D + 1 + torch.arange(d)]).to(dev)   # enc, rel
         cmap = torch.cat([torch.arange(D), D + torch.arange(d)])
+        # (derived: computed from parameters - refreshed in place when the packs are replayed after an optimizer step)
         return types.SimpleNamespace(
             graph1=pack_graph_net(self.encoder, self.processor, ldn),
             graph2=pack_graph_net(self._encoder, self._processor, ldn),
-            proj_base=pack(W[:, cols], self.proj_head.bias, default_gemm(), k_pad=D + 32, col_map=cmap),
-            proj_wv=W[:, D].float().contiguous(), proj_wt=W[:, D + d + 1].float().contiguous(),
+            proj_base=pack(derived(lambda: head.weight.detach()[:, cols]), head.bias, default_gemm(), k_pad=D + 32, col_map=cmap),
+            proj_wv=derived(lambda: head.weight.detach()[:, D].float().contiguous()),
+            proj_wt=derived(lambda: head.weight.detach()[:, D + d + 1].float().contiguous()),
             projector=pack_mlp(self.projector), decoder=pack_mlp(self._decoder.node_fn))
 
     def forward(self, x_lr, lr_coords, hr_coords, t, hr_last):
@@ -97,10 +101,15 @@ class MAgNetGNN(MagnetBase):
                                                        Lr, Nq, ops._p(nn2), ops._p(rel), ops._p(w), ops._stream()), "inr_knn_prepare")
         ot = Cn // 32
         Wp = self.proj_head.weight
-        cols = torch.cat([torch.arange(D), D + 1 + torch.arange(d)]).to(dev)       # enc, rel columns of proj_head
-        cmap = torch.cat([torch.arange(D), D + torch.arange(d)]).to(dev)
-        pb = types.SimpleNamespace(layers=[pk.proj_base], ln=None, ht=ot, ot=ot, out_dim=Cn, col_map=cmap)
-        base = AG.mlp(M2, [ops.Term(enc, D, idx=nn2), ops.Term(rel, 32)], pb, [Wp, self.proj_head.bias], first_cols=cols)
+        # one namespace for as long as the pack tree lives: the backward caches proj_head's transposed packs on it (a fresh one per
+        # call re-packed them in each of the four forwards of a training rollout)
+        pb = pk.__dict__.get("_proj_ns")
+        if pb is None:
+            cols = torch.cat([torch.arange(D), D + 1 + torch.arange(d)]).to(dev)       # enc, rel columns of proj_head
+            cmap = torch.cat([torch.arange(D), D + torch.arange(d)]).to(dev)
+            pb = pk.__dict__["_proj_ns"] = types.SimpleNamespace(layers=[pk.proj_base], ln=None, ht=ot, ot=ot, out_dim=Cn, col_map=cmap,
+                                                                 cols=cols, _rec=self.__dict__.get("_pack_rec"))
+        base = AG.mlp(M2, [ops.Term(enc, D, idx=nn2), ops.Term(rel, 32)], pb, [Wp, self.proj_head.bias], first_cols=pb.cols)
         meta = types.SimpleNamespace(w=w, nn2=nn2, t=t.contiguous(), B=B, L=Lr, Nq=Nq, T=T, C=Cn, mode=_MODES[self.interpolation],
                                      col_v=D, col_t=D + d + 1, inv_cache={})
         z = AG.knn_blend(base, u.reshape(B * Lr, T), Wp, meta)
@@ -173,6 +182,16 @@ class MAgNetGNN(MagnetBase):
         return x + (self.noise * draw).to(x.device)
 
     def _rollout(self, batch, teacher_forcing=False, noise=False):
+        with self._rollout_scope():
+            pred, target, hr_hat, vals = self._rollout_body(batch, teacher_forcing, noise)
+        if not capturing():
+            why = self._range_trip()
+            if why:                             # out of the fp16 pieces' range: the same rollout in the full-range split (the input
+                self._widen(why)                # noise, when configured, is drawn again)
+                return self._rollout(batch, teacher_forcing, noise)
+        return pred, target, hr_hat, vals
+
+    def _rollout_body(self, batch, teacher_forcing, noise):
         t, u = batch["t"].float(), batch["lr_frames"].float()
         vals = batch["hr_points"].float()
         hr_c, lr_c = batch["coords_hr"].float(), batch["coords_lr"].float()
@@ -193,11 +212,6 @@ class MAgNetGNN(MagnetBase):
             hr_last = self._noisy(hr_last, noise)
         pred = torch.cat(outs, dim=1)
         target = torch.cat([fut, u[:, T:].permute(0, 1, 3, 2)], dim=2)
-        if not capturing():
-            why = self._guard.tripped()
-            if why:                             # out of the fp16 pieces' range: the same rollout in the full-range split (the input
-                self._widen(why)                # noise, when configured, is drawn again)
-                return self._rollout(batch, teacher_forcing, noise)
         return pred, target, torch.cat(hrs, dim=1), vals
 
     def training_step(self, train_batch, batch_idx):

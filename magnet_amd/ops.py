@@ -137,6 +137,10 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
         a.y, a.ldy, a.ncols = y.data_ptr(), int(ldy if ldy is not None else y.shape[-1]), int(ncols if ncols is not None else ot * 32)
     if res is not None:
         a.res, a.ldres = res.data_ptr(), (res.stride(0) if res.dim() == 2 else res.shape[-1])
+    g = RangeGuard.current
+    if nl > 1 and g is not None and g.active and layers[0][0].dtype == torch.float16:      # see RangeGuard.armed
+        a.status, a.status_bit = g._word(layers[0][0].device).data_ptr(), ST_CHAIN_RANGE
+        keep.append(g._status)
     if epi == EPI_SEGMEAN:
         a.tgt, a.rowptr, a.partials = tgt.data_ptr(), rowptr.data_ptr(), partials.data_ptr()
     elif epi == EPI_STORE_MASK and partials is not None:       # a zeroed float[256] that receives the block maxima of |y| (split-GEMM kernels)
@@ -215,7 +219,7 @@ def segment_mean(msg: torch.Tensor, rowptr: torch.Tensor, n_rows: int, out: torc
 
 # ------------------------------------------------------------------------------------ fp16x3 range guard
 FP16_LIMIT = 65504.0
-ST_IN_RANGE, ST_IN_NONFINITE, ST_OUT_NONFINITE = 1, 2, 4
+ST_IN_RANGE, ST_IN_NONFINITE, ST_OUT_NONFINITE, ST_CHAIN_RANGE = 1, 2, 4, 8
 
 
 class RangeGuard:
@@ -227,8 +231,17 @@ class RangeGuard:
     of that magnitude must get the reference's result, not an error).  Inactive (no launches, no sync) in the other GEMM modes and
     once the process has been widened."""
 
+    current = None          # the guard of the rollout in progress (armed()): the chain kernels launched meanwhile report into its word
+
     def __init__(self, active: bool):
         self.enabled, self._status = bool(active), None
+
+    def armed(self):
+        """``with guard.armed():`` every multi-Linear fp16x3 chain launched inside also reports an activation BETWEEN two of its Linears
+        that reaches 65504 (magnet_mlp_args_t.status): there the high fp16 piece saturates, the next layer sees +-inf, and a ReLU turns
+        -inf into a finite - wrong - output that neither the input nor the output check sees (found on a diverging magnet_cnn_2d run
+        whose masked overflow surfaced only as NaN gradients one step later)"""
+        return _Armed(self)
 
     @property
     def active(self):
@@ -264,6 +277,8 @@ class RangeGuard:
         self._status.zero_()
         if st & ST_IN_RANGE:
             return "an input of the fp16x3 GEMM chain has magnitude >= 65504"
+        if st & ST_CHAIN_RANGE:
+            return "an activation inside an fp16x3 MLP chain reached 65504"
         if st & ST_OUT_NONFINITE and not st & ST_IN_NONFINITE:
             return "non-finite prediction from finite inputs in fp16x3 mode (an intermediate left the fp16 range)"
         return None
@@ -271,6 +286,18 @@ class RangeGuard:
     def clear(self):
         if self._status is not None:
             self._status.zero_()
+
+
+class _Armed:
+    def __init__(self, guard):
+        self.g = guard
+
+    def __enter__(self):
+        self.prev, RangeGuard.current = RangeGuard.current, self.g
+
+    def __exit__(self, *exc):
+        RangeGuard.current = self.prev
+        return False
 
 
 # ------------------------------------------------------------------------------------ MPNN pieces

@@ -292,9 +292,17 @@ def flag_if_abs_reaches(w: torch.Tensor, limit: float) -> None:
         x = w.detach()
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
-        L.check(L.lib().magnet_status_check_f32(C.c_void_p(x.data_ptr()), C.c_long(x.numel()), C.c_float(float(limit)), _WEIGHT_RANGE_BIT,
-                                                _WEIGHT_RANGE_BIT, 0, C.c_void_p(_status_word(w.device).data_ptr()),
-                                                C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)), "status_check")
+        fn = L.lib().magnet_status_check_f32
+        sw = _status_word(w.device)
+        args = (C.c_void_p(x.data_ptr()), C.c_long(x.numel()), C.c_float(float(limit)), _WEIGHT_RANGE_BIT, _WEIGHT_RANGE_BIT, 0,
+                C.c_void_p(sw.data_ptr()))
+        L.check(fn(*args, C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)), "status_check")
+        rec = _active_recorder
+        if rec is not None:
+            if rec.backed(x):
+                rec.launches.append((fn, args, "status_check", (x, sw)))
+            else:
+                rec.ok = False
     elif not bool(torch.isfinite(w).all()) or float(w.detach().abs().max()) >= limit:
         raise ValueError(f"fp16x3 GEMM mode: this kernel needs finite weights with |w| < {limit}; use MAGNET_GEMM=bf16x6")
 
@@ -307,6 +315,41 @@ def bad_weights(dev) -> bool:
         dev = torch.device("cuda", torch.cuda.current_device())
     if dev in _status and int(_status[dev].item()):
         _status[dev].zero_()
+        return True
+    return False
+
+
+# A rollout / training step whose caller reads the range status at its END opens a scope; packs made inside leave the status word unread
+# until then.  Reading it right behind the pack launches makes the host wait for everything queued before them - at the start of a
+# training step that is the previous step's backward and optimizer (7.8 ms per read at the reference's batch sizes).
+_defer_depth = 0
+_unchecked = set()
+
+
+class deferred_weight_checks:
+    def __enter__(self):
+        global _defer_depth
+        _defer_depth += 1
+
+    def __exit__(self, *exc):
+        global _defer_depth
+        _defer_depth -= 1
+        return False
+
+
+def weights_check_due(dev) -> bool:
+    """packs were just made on ``dev``: True = read the status word now (bad_weights); False = a scope is open and its owner will read
+    it at the end (pending_weight_check)"""
+    if _defer_depth > 0:
+        _unchecked.add(torch.device(dev))
+        return False
+    return True
+
+
+def pending_weight_check(dev) -> bool:
+    dev = torch.device(dev)
+    if dev in _unchecked:
+        _unchecked.discard(dev)
         return True
     return False
 
@@ -342,6 +385,75 @@ def source_map(placed_at, width: int, dev, source_cols=None):
     return _src_maps[key]
 
 
+# ------------------------------------------------------------------------------------------------ re-packing in place
+class PackRecorder:
+    """The pack launches of one model, recorded while its packed-weight namespace is built, so that after an optimizer step the SAME
+    launches run again into the SAME output buffers instead of rebuilding the namespace (at the reference's batch sizes
+    a MAgNet training step is host bound, and re-packing ~200 Linears + ~170 transposed packs of the backward through the generic
+    path was 20 of its 80 ms).  Pointer-stable packs also keep everything cached ON the pack namespaces (transposed packs, EDSR launch
+    plans) alive across steps.
+
+    Valid only while every recorded input is a view of a parameter's storage (or a tensor registered with ``derived``, which is
+    refreshed first): a pack whose input was a temporary copy marks the recorder ``ok = False`` and the owner falls back to a rebuild."""
+
+    def __init__(self, params, key=None):
+        self.params = list(params)
+        self.storages = {p.untyped_storage().data_ptr() for p in self.params}
+        self.launches, self.derived, self.ok, self.key = [], [], True, key
+        self.generation = 0          # replays so far: what is cached on a pack namespace but NOT replayed carries it in its key
+
+    def backed(self, t) -> bool:
+        return t is None or t.untyped_storage().data_ptr() in self.storages
+
+    def usable(self) -> bool:
+        """the parameters still live where they lived when the launches were recorded (.to() / load_state_dict(assign=True) move them)"""
+        return self.ok and all(p.untyped_storage().data_ptr() in self.storages for p in self.params)
+
+    def replay(self) -> None:
+        from . import _lib as L
+        from .ops import _stream
+        self.generation += 1
+        with torch.no_grad():
+            for t, fn in self.derived:
+                t.copy_(fn())
+        st = _stream()
+        for fn, args, what, _keep in self.launches:
+            L.check(fn(*args, st), what)
+
+
+_active_recorder = None
+
+
+class recording:
+    """``with recording(rec):`` pack_device / flag_if_abs_reaches / derived calls inside are added to ``rec`` (None: no recording)"""
+
+    def __init__(self, rec):
+        self.rec = rec
+
+    def __enter__(self):
+        global _active_recorder
+        self.prev, _active_recorder = _active_recorder, self.rec
+        return self.rec
+
+    def __exit__(self, *exc):
+        global _active_recorder
+        _active_recorder = self.prev
+        return False
+
+
+def derived(fn):
+    """``fn()`` -> a tensor computed FROM parameters (a column selection, a scaled block, a permuted convolution weight) that a pack or a
+    kernel reads: under a recorder it is kept and refreshed with ``copy_(fn())`` before the pack launches are replayed"""
+    t = fn()
+    rec = _active_recorder
+    if rec is not None and t.is_cuda:
+        if rec.backed(t):                              # a view of a parameter needs no refresh (and copy_ onto itself would be wrong)
+            return t
+        rec.derived.append((t, fn))
+        rec.storages.add(t.untyped_storage().data_ptr())
+    return t
+
+
 def pack_device(w, b, mode: str, np_: int, kp: int, row_src=None, col_src=None):
     """``w``: 2-D fp32 CUDA tensor or view (any strides: W.t() costs nothing); row_src / col_src: int32 device maps from padded
     row / column to source row / column (-1 = zero), None = identity.  -> (flat packed planes, padded bias [np_])"""
@@ -361,10 +473,16 @@ def pack_device(w, b, mode: str, np_: int, kp: int, row_src=None, col_src=None):
         b = b if b.is_contiguous() else b.contiguous()
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
     st = _status_word(dev) if mode in ("fp16x3", "fp16x3s") else None
-    L.check(L.lib().magnet_pack_linear_f32(ptr(w), C.c_long(w.stride(0)), C.c_long(w.stride(1)), w.shape[0], w.shape[1], ptr(row_src),
-                                           ptr(col_src), ptr(b), b.numel() if b is not None else 0, np_, kp, _MODE_ID[mode], ptr(out),
-                                           ptr(bp), ptr(st), _WEIGHT_RANGE_BIT, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
-            "pack_linear")
+    fn = L.lib().magnet_pack_linear_f32
+    args = (ptr(w), C.c_long(w.stride(0)), C.c_long(w.stride(1)), w.shape[0], w.shape[1], ptr(row_src), ptr(col_src), ptr(b),
+            b.numel() if b is not None else 0, np_, kp, _MODE_ID[mode], ptr(out), ptr(bp), ptr(st), _WEIGHT_RANGE_BIT)
+    L.check(fn(*args, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "pack_linear")
+    rec = _active_recorder
+    if rec is not None:
+        if rec.backed(w) and rec.backed(b):
+            rec.launches.append((fn, args, "pack_linear", (w, b, row_src, col_src, out, bp, st)))
+        else:
+            rec.ok = False                            # packed from a temporary: a replay would read stale data
     return (SinglePlanes(out) if mode == "fp16x3s" else out), bp
 
 

@@ -30,7 +30,18 @@ def test_mlp_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.Src) == 32
     assert ctypes.sizeof(_lib.KTile) == 80
     assert ctypes.sizeof(_lib.Layer) == 16
-    assert ctypes.sizeof(_lib.MlpArgs) == 8 + 80 * _lib.MAX_KT + 16 * 6 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 2 * 32 + 8 + 8 * 6 + 8   # ..., ncolgroups|groups_in_block, y_group_stride, pre[2], x0_out, hid[6], x0_skip
+    assert ctypes.sizeof(_lib.MlpArgs) == 8 + 80 * _lib.MAX_KT + 16 * 6 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 2 * 32 + 8 + 8 * 6 + 8 + 8 + 8   # ..., ncolgroups|groups_in_block, y_group_stride, pre[2], x0_out, hid[6], x0_skip, status, status_bit|pad
+    # ... and against the C compiler's own reading of the header: size and the offset of every field the kernels were given later
+    import os, subprocess, tempfile
+    fields = ["pre", "x0_out", "hid", "x0_skip", "status", "status_bit"]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "magnet_hip.h"\nint main(void) { printf("%zu", sizeof(magnet_mlp_args_t));' + \
+        "".join(f' printf(" %zu", offsetof(magnet_mlp_args_t, {f}));' for f in fields) + " return 0; }\n"
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.dirname(_lib.HEADER), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
+        got = [int(v) for v in subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()]
+    assert got[0] == ctypes.sizeof(_lib.MlpArgs)
+    assert got[1:] == [getattr(_lib.MlpArgs, f).offset for f in fields]
 
 
 def test_supported_mlp_variants():

@@ -421,6 +421,46 @@ def test_overflow_inside_the_chain_is_repeated_in_the_full_range_split(narrow_af
     assert torch.isfinite(pred).all() and rel_l2(pred, want) < 5e-5
 
 
+def test_overflow_between_the_linears_of_a_relu_chain_is_caught_although_the_output_is_finite(narrow_after):
+    """MAgNet's chains are Linear / ReLU: a hidden activation above 65504 becomes +-inf in the next layer, and ReLU turns -inf (and NaN)
+    into 0 - the prediction is finite and wrong, the output check sees nothing.  The chain kernels report the largest activation they
+    hand from one Linear to the next into the armed guard's status word (magnet_mlp_args_t.status), and the rollout is repeated in
+    bf16x6.  (Found at the reference's magnet_cnn_2d batch size: a diverging run whose masked overflow surfaced as NaN gradients.)"""
+    from magnet_amd import ops
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    name, hp, salt, batch, d = load_case("magnet_gnn_tiny")
+    oracle = O.build(name, hp).eval()
+    fill_state_dict(oracle, salt)
+    with torch.no_grad():
+        lins = [m for m in oracle.encoder.node_fn[0].modules() if isinstance(m, torch.nn.Linear)]
+        for lin in lins[:3]:                                           # inputs ~ 1, weights < 31.98: the third hidden layer is ~ 1e6
+            lin.weight.mul_(60.0)
+        assert max(float(l.weight.abs().max()) for l in lins) < 31.0
+        want = oracle.validation_step(batch)
+    model = FACTORY[name](hp).eval()
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda()
+    cb = {k: v.cuda() for k, v in batch.items()}
+    with pytest.warns(RuntimeWarning, match="inside an fp16x3 MLP chain|non-finite"):
+        pred = model.validation_step(cb, 0)
+    assert narrow_after.wide() and torch.isfinite(pred).all() and rel_l2(pred, want) < 5e-5
+    # ... and the kernel-level statement: the flag is raised by the chain launch itself, only while a guard is armed
+    narrow_after.narrow()
+    from magnet_amd.models.magnet_common import pack_mlp_ln, run_mlp
+    seq = model.encoder.node_fn
+    pk = pack_mlp_ln(seq, k_pad=32 * ((seq[0].in_dim + 31) // 32))
+    x = torch.randn(4096, 32 * ((seq[0].in_dim + 31) // 32), device="cuda")
+    y = torch.empty(4096, 32 * pk.ot, device="cuda")
+    g = ops.RangeGuard(True)
+    run_mlp(4096, ops.ktiles(ops.Term(x, x.shape[1])), pk, y)
+    assert g.tripped() is None                                         # (not armed: nothing reported)
+    with g.armed():
+        run_mlp(4096, ops.ktiles(ops.Term(x, x.shape[1])), pk, y)
+    assert "inside an fp16x3 MLP chain" in (g.tripped() or "")
+
+
 def test_weights_beyond_the_fp16_planes_switch_the_split_instead_of_raising(narrow_after):
     """a weight >= 65504 cannot be held as two fp16 pieces: the packs are rebuilt in the full-range split"""
     from magnet_amd.models.factory import FACTORY
