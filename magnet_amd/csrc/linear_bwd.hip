@@ -203,8 +203,8 @@ __global__ void __launch_bounds__(256, NT == 2 ? 2 : 1) k_linear_bwd(const LinBw
     }
 }
 
-extern "C" int magnet_reduce_partials_f32(const float* partial, int nblk, long n, float scale, float* out, int accumulate,
-                                          void* stream);      // train_kernels.hip
+int magnet_launch_reduce_partials2(const float* pa, long na, float* oa, const float* pb, long nb_, float* ob, int nblk, float scale,
+                                   int accumulate, void* stream);      // train_kernels.hip: both reductions in one launch
 
 static int lb_grid(long M, int per_cu = 1) {
     static int ncu = 0;
@@ -249,9 +249,7 @@ static int launch_linear_bwd(const float* dz, int ldz, const float* x, int ldx, 
     hipLaunchKernelGGL(k_linear_bwd<NT>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
-    rc = magnet_reduce_partials_f32(a.wpart, grid, (long)W * W, 1.0f, dW, accumulate, stream);
-    if (rc) return rc;
-    return magnet_reduce_partials_f32(a.bpart, grid, (long)W, 1.0f, db, accumulate, stream);
+    return magnet_launch_reduce_partials2(a.wpart, (long)W * W, dW, a.bpart, (long)W, db, grid, 1.0f, accumulate, stream);
 }
 // dx [M][lddx] = (mask ? x > 0 : 1) * (dz W),  dW [W][W] (+)= dz^T x,  db [W] (+)= colsum(dz) for one W -> W Linear (W = 128 / 64);
 // wt_f16: fp16x3 planes of W^T packed as a Linear (packing.pack(W.t(), None, "fp16x3"); |w| < 31.98).  amax_in: n_amax_in block maxima

@@ -631,8 +631,8 @@ int magnet_launch_absmax_partial(const float* x, long n4, float* part, int nbloc
 // The same, with dW2 [128][128] (+)= dq^T s1 and db2 [128] (+)= colsum(dq) formed in the kernel (k_mpnn_edge_bwd_w): s1 and dq are
 // never written.  workspace: magnet_mpnn_edge_bwd_w_workspace() floats (per-workgroup partial sums + the |dagg| maxima).
 #define EBW_AMAX_BLOCKS 256
-extern "C" int magnet_reduce_partials_f32(const float* partial, int nblk, long n, float scale, float* out, int accumulate,
-                                          void* stream);      // train_kernels.hip
+int magnet_launch_reduce_partials2(const float* pa, long na, float* oa, const float* pb, long nb_, float* ob, int nblk, float scale,
+                                   int accumulate, void* stream);      // train_kernels.hip: both reductions in one launch
 // mpnn_edge_bwd_wp.hip: generation 2 of the kernel (every wave forms the weight gradient of its own tiles; no barrier in the loop)
 int magnet_launch_edge_bwd_wp(const float* A, const float* Bm, const float* dagg, const int32_t* src, const int32_t* tgt,
                               const int32_t* rowptr, int n_edges, const void* w2_f16, const void* w2t_f16, const float* b2, float* dp,
@@ -706,8 +706,7 @@ extern "C" int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, 
         else
             hipLaunchKernelGGL(k_mpnn_edge_bwd_w, dim3(grid), dim3(256), 0, s, A, Bm, dagg, src, tgt, rowptr, n_edges, w, wT, b2, dp, dA,
                                partials, amax, nab, wpart, bpart);
-        magnet_reduce_partials_f32(wpart, grid, 128L * 128, 1.0f, dW2, accumulate, stream);
-        magnet_reduce_partials_f32(bpart, grid, 128L, 1.0f, db2, accumulate, stream);
+        magnet_launch_reduce_partials2(wpart, 128L * 128, dW2, bpart, 128L, db2, grid, 1.0f, accumulate, stream);
     }
     hipLaunchKernelGGL(k_segsum_fixup, dim3((n_nodes + 3) / 4), dim3(256), 0, s, rowptr, n_nodes, partials, dA);
     return (int)hipGetLastError();

@@ -385,6 +385,40 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict
     }
 }
 
+// Two reductions of the same partial count in ONE launch (a Linear's dW [n_a] and db [n_b]: the second was four workgroups of 5 us of
+// launch latency - 1 150 of the 2 050 launches of a magnet_gnn training step at the reference's batch size were reductions).  Workgroups
+// [0, ceil(n_a / 32)) serve a, the rest b; same summation order as k_reduce_partials.
+__global__ void __launch_bounds__(256) k_reduce_partials2(const float* __restrict__ pa, long na, float* __restrict__ oa,
+                                                          const float* __restrict__ pb, long nb_, float* __restrict__ ob, int nblk,
+                                                          float scale, int accumulate) {
+    __shared__ float sm[8][32];
+    const int blocks_a = (int)((na + 31) / 32);
+    const bool second = (int)blockIdx.x >= blocks_a;
+    const float* p = second ? pb : pa;
+    const long n = second ? nb_ : na;
+    float* out = second ? ob : oa;
+    const int jj = threadIdx.x & 31, sub = threadIdx.x >> 5;
+    const long j = (long)((int)blockIdx.x - (second ? blocks_a : 0)) * 32 + jj;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (j < n) {
+        int b = sub;
+        for (; b + 56 < nblk; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += p[(size_t)(b + 8 * u) * n + j];
+        }
+        for (; b < nblk; b += 8) a[0] += p[(size_t)b * n + j];
+    }
+    const float acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    sm[sub][jj] = acc;
+    __syncthreads();
+    if (sub == 0 && j < n) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tot += sm[q][jj];
+        out[j] = accumulate ? out[j] + scale * tot : scale * tot;
+    }
+}
+
 // per-graph column sums of dy and of dy * yhat over chunks of STAT_CHUNK rows (H <= 1024)
 #define STAT_CHUNK 128
 __global__ void k_colstat2_partial(const float* __restrict__ dy, const float* __restrict__ yhat, int rows_per_graph, int H,
@@ -828,6 +862,13 @@ extern "C" int magnet_reduce_partials_f32(const float* partial, int nblk, long n
     BEGIN();
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_reduce_partials, dim3(nb(n, 32)), dim3(256), 0, S_, partial, nblk, n, scale, out, accumulate);
+    END();
+}
+int magnet_launch_reduce_partials2(const float* pa, long na, float* oa, const float* pb, long nb_, float* ob, int nblk, float scale,
+                                   int accumulate, void* stream) {
+    BEGIN();
+    if (na <= 0 || nb_ <= 0) return -2;
+    hipLaunchKernelGGL(k_reduce_partials2, dim3(nb(na, 32) + nb(nb_, 32)), dim3(256), 0, S_, pa, na, oa, pb, nb_, ob, nblk, scale, accumulate);
     END();
 }
 // dx = InstanceNorm backward of dy given the normalised output yhat and the biased variance var [n_graphs][H]

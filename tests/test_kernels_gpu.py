@@ -113,6 +113,28 @@ def test_knn_matches_restatement():
     assert torch.equal(got.cpu().long(), want)
 
 
+@pytest.mark.parametrize("L,Nq,dim,k", [(1024, 256, 2, 4), (3, 50, 2, 4), (200, 33, 3, 8), (64, 64, 1, 2), (130, 7, 2, 1)])
+def test_knn_wave_kernel_on_lattices_with_ties_and_short_graphs(L, Nq, dim, k):
+    """one wave per query (k_knn_wave): candidates are spread over the lanes and merged - ties (lattice points at equal distance, in
+    different lanes), fewer than k candidates (-1 fill), k up to 8, 1-D / 3-D, the reference's training shape 1024 x 256"""
+    from magnet_amd import ops
+    from oracle.pyg_semantics import knn
+    g = torch.Generator().manual_seed(L + Nq)
+    B = 3
+    side = max(2, int(round(L ** (1.0 / dim))))
+    lat = torch.stack(torch.meshgrid(*([torch.arange(side, dtype=torch.float32)] * dim), indexing="ij"), -1).reshape(-1, dim)
+    x = torch.cat([lat[torch.randperm(lat.shape[0], generator=g)][:L] if lat.shape[0] >= L else torch.rand(L, dim, generator=g) * side
+                   for _ in range(B)])
+    y = torch.cat([(torch.randint(0, 2 * side, (Nq, dim), generator=g).float() * 0.5) for _ in range(B)])    # cell centres and corners: exact ties
+    bx, by = torch.arange(B).repeat_interleave(L), torch.arange(B).repeat_interleave(Nq)
+    want = knn(x, y, k, bx, by)
+    got = ops.knn(x.cuda(), ops.graph_ptr(B, L, "cuda"), y.cuda(), ops.graph_ptr(B, Nq, "cuda"), k).cpu().long()
+    if L >= k:
+        assert torch.equal(got, want[1].view(B * Nq, k))
+    else:                                                 # the restatement drops missing neighbours, the kernel pads with -1
+        assert torch.equal(got[:, :L], want[1].view(B * Nq, L)) and bool((got[:, L:] == -1).all())
+
+
 def test_instance_norm_matches_pyg_restatement():
     from magnet_amd import ops
     from oracle.pyg_semantics import instance_norm
