@@ -87,8 +87,9 @@ typedef struct {
                               * Linear's raw output before last_act / LayerNorm [M][ot*32] */
     uint64_t x0_skip;        /* bit kt set: k tile kt of x0_out is NOT written (a backward that walks gathered k tiles back at
                               * source-row granularity never reads them) */
-    int32_t* status;         /* fp16x3 / fp16x3s kernels, nl > 1, NULL = off: device status word that receives `status_bit` (atomic OR)
-                              * when an activation BETWEEN two Linears of the chain reaches 65504 - the high fp16 piece saturates there,
+    int32_t* status;         /* fp16x3 / fp16x3s kernels, NULL = off: device status word that receives `status_bit` (atomic OR) when an
+                              * activation BETWEEN two Linears of the chain, or the launch's output when no LayerNorm bounds it (it
+                              * may feed another fp16 launch: EDSR's convolutions), reaches 65504 - the high fp16 piece saturates there,
                               * and a ReLU can turn the resulting -inf of the next layer into a finite (wrong) output that no check of
                               * the chain's inputs or outputs sees.  The host repeats such a rollout in bf16x6 (ops.RangeGuard). */
     int32_t status_bit;
@@ -243,9 +244,12 @@ int magnet_mpnn_readout_norm_f32(const float* h, const float* mean, const float*
  * gathered-tap GEMM with the weights resident in LDS: y[p][32 g .. 32 g + 32) = act(sum_t W_t fmap[tap[t][p]] + b) (+ res[p]) for the
  * ncg <= 4 column groups g.  fmap [P + 1][width] (row P all zero: the padding), width in {32, 128}, tap [9][P] from
  * magnet_conv_tap_index, w[g] / b[g] the fp16x3 packs of rows 32 g .. 32 g + 32 of the [Co][9 * width] weight
- * (packing.pack_linear_fp16x2).  -2 for other shapes: use magnet_mlp_fp16x3_f32 (same arithmetic, streamed weights). */
+ * (packing.pack_linear_fp16x2).  -2 for other shapes: use magnet_mlp_fp16x3_f32 (same arithmetic, streamed weights).
+ * status (NULL = off): device word that receives status_bit when an output reaches 65504 - the next convolution splits its input
+ * into fp16 pieces (see magnet_mlp_args_t.status). */
 int magnet_conv_resident_f32(const float* fmap, int width, const int32_t* tap, int ntaps, int P, const void* const* w,
-                             const float* const* b, int ncg, int relu, const float* res, float* y, int ldy, void* stream);
+                             const float* const* b, int ncg, int relu, const float* res, float* y, int ldy, int32_t* status,
+                             int status_bit, void* stream);
 /* PyG InstanceNorm(x, batch) with batch = contiguous blocks of rows_per_graph rows (models/mpnn.py:63,70).
  * workspace: (2*n_graphs*ceil(rows_per_graph/64) + 2*n_graphs) * H floats. */
 int magnet_instance_norm_f32(const float* x, int n_graphs, int rows_per_graph, int H, float eps, float* y,

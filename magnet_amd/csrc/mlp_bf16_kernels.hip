@@ -176,6 +176,9 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
     // fp16 split modes: the largest |activation| handed from one Linear of the chain to the next (args.status, magnet_hip.h) - one
     // v_max3_f32 per two values
     constexpr bool TRACK_SAT = NL > 1 && (MODE == GEMM_FP16X3 || MODE == GEMM_FP16X3S);
+    // ... and of what the launch hands to whoever reads its output (another fp16 GEMM launch, as between the convolutions of EDSR),
+    // unless a LayerNorm bounds it
+    constexpr bool TRACK_OUT = !LN && (MODE == GEMM_FP16X3 || MODE == GEMM_FP16X3S);
     float sat = 0.f;
     constexpr bool PIPE = (NL >= 5 && HT >= 4) || DIST == 2;             // see mma_chunk; the one-workgroup-per-CU variants too:
                                                                          // nobody else on the SIMD hides the LDS latency of a group
@@ -383,6 +386,10 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
             for (int t = 0; t < OT; ++t) apply_act<ACT>(out[t]);
         }
         TRACE(30)
+        if (TRACK_OUT && row_ok) {
+#pragma unroll
+            for (int t = 0; t < OT; ++t) track_abs_max(out[t], sat);
+        }
         if (LN) layer_norm_rows<OT>(out, a.ln_g, a.ln_b, a.ln_eps, half);
         TRACE(31)
 
@@ -428,7 +435,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
         }
         TRACE(32)
     }
-    if (TRACK_SAT && a.status) {
+    if ((TRACK_SAT || TRACK_OUT) && a.status) {
         // (NaN compares false: a non-finite activation that came from non-finite INPUTS is the input / output checks' business)
         if (__builtin_amdgcn_ballot_w64(sat >= 65504.0f) && (threadIdx.x & 63) == 0) atomicOr(a.status, a.status_bit);
     }
@@ -1335,6 +1342,8 @@ struct ConvResidentArgs {
     const float* res;          // [P + 1][ldy] or nullptr
     float* y;                  // [P + 1][ldy]
     int P, width, ntaps, ldy, relu;
+    int32_t* status;           // nullptr = off: status_bit is OR-ed in when an output reaches 65504 (see magnet_mlp_args_t.status)
+    int status_bit;
 };
 template <int NKT, int TPT /* k tiles per tap = width / 32 */, int RING /* k tiles of gathered rows in flight per wave */>
 __global__ void __launch_bounds__(128, 1) k_conv_resident(ConvResidentArgs a) {
@@ -1391,6 +1400,11 @@ __global__ void __launch_bounds__(128, 1) k_conv_resident(ConvResidentArgs a) {
     }
     fold_tiles<1, MODE>(acc, accc);
     if (a.relu) apply_act<ACT_RELU>(acc[0]);
+    if (a.status) {                                                   // (rows past the end are copies of the last row: nothing new)
+        float sat = 0.f;
+        track_abs_max(acc[0], sat);
+        if (__builtin_amdgcn_ballot_w64(sat >= 65504.0f) && lane == 0) atomicOr(a.status, a.status_bit);
+    }
     if (row < a.P) {
         float* yo = a.y + (size_t)row * a.ldy + cg * 32 + 4 * half;
         const float* ro = a.res ? a.res + (size_t)row * a.ldy + cg * 32 + 4 * half : nullptr;
@@ -1407,12 +1421,14 @@ __global__ void __launch_bounds__(128, 1) k_conv_resident(ConvResidentArgs a) {
 // channels: y[:, 32 g .. 32 g + 32) for g < ncg.  w[g] / b[g]: the per-column-group fp16x3 packs the generic launch takes
 // (magnet_amd/models/backbones/edsr.py).  Returns -2 for shapes outside this kernel (the caller then uses magnet_mlp_fp16x3_f32).
 extern "C" int magnet_conv_resident_f32(const float* fmap, int width, const int32_t* tap, int ntaps, int P, const void* const* w,
-                                        const float* const* b, int ncg, int relu, const float* res, float* y, int ldy, void* stream) {
+                                        const float* const* b, int ncg, int relu, const float* res, float* y, int ldy, int32_t* status,
+                                        int status_bit, void* stream) {
     (void)hipGetLastError();
     if (P <= 0) return 0;
     if ((width != 32 && width != 128) || (ntaps != 9 && ntaps != 3) || ncg < 1 || ncg > 4) return -2;
     ConvResidentArgs a;
     a.fmap = fmap, a.tap = tap, a.res = res, a.y = y, a.P = P, a.width = width, a.ntaps = ntaps, a.ldy = ldy, a.relu = relu;
+    a.status = status, a.status_bit = status_bit;
     for (int g = 0; g < ncg; ++g) a.w[g] = reinterpret_cast<const f32x4*>(w[g]), a.b[g] = b[g];
     const dim3 grid((P + 63) / 64, ncg), block(128);
     // (the tap index of a k tile is compile-time: 3 x 3 in 2-D, k = 3 in 1-D)

@@ -110,7 +110,8 @@ class EDSR(nn.Module):
     def _plan(self, B, cin, spatial, dev):
         """buffers + the 2 * res_layers + 2 prebuilt launches for one input geometry (cached with the packed weights)"""
         pk = self.packed()
-        key = (B, cin, tuple(spatial), str(dev), self._pack_id)
+        g = ops.RangeGuard.current                                # (the prebuilt launches report into the armed guard's status word)
+        key = (B, cin, tuple(spatial), str(dev), self._pack_id, id(g) if g is not None and g.active else None)
         if self._plan_key == key:
             return self._plan_val
         P = B * int(torch.tensor(spatial).prod())

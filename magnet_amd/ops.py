@@ -138,7 +138,7 @@ def mlp_plan(M, kts, layers, *, nl, ht, ot, act, last_act=False, ln=None, epi=EP
     if res is not None:
         a.res, a.ldres = res.data_ptr(), (res.stride(0) if res.dim() == 2 else res.shape[-1])
     g = RangeGuard.current
-    if nl > 1 and g is not None and g.active and layers[0][0].dtype == torch.float16:      # see RangeGuard.armed
+    if g is not None and g.active and layers[0][0].dtype == torch.float16:                  # see RangeGuard.armed
         a.status, a.status_bit = g._word(layers[0][0].device).data_ptr(), ST_CHAIN_RANGE
         keep.append(g._status)
     if epi == EPI_SEGMEAN:
@@ -278,7 +278,7 @@ class RangeGuard:
         if st & ST_IN_RANGE:
             return "an input of the fp16x3 GEMM chain has magnitude >= 65504"
         if st & ST_CHAIN_RANGE:
-            return "an activation inside an fp16x3 MLP chain reached 65504"
+            return "an activation inside an fp16x3 MLP chain (or handed from one fp16x3 launch to the next) reached 65504"
         if st & ST_OUT_NONFINITE and not st & ST_IN_NONFINITE:
             return "non-finite prediction from finite inputs in fp16x3 mode (an intermediate left the fp16 range)"
         return None
@@ -556,9 +556,12 @@ def conv_resident_plan(fmap, width, taps, packs, relu, res, y, ldy):
         return None
     wp = (C.c_void_p * ncg)(*[w.data_ptr() for w, _ in packs])
     bp = (C.c_void_p * ncg)(*[b.data_ptr() for _, b in packs])
-    keep = (fmap, taps, packs, res, y)
+    g = RangeGuard.current
+    word = g._word(fmap.device) if g is not None and g.active else None                    # see RangeGuard.armed
+    keep = (fmap, taps, packs, res, y, word)
     fn = L.lib().magnet_conv_resident_f32
-    args = (_p(fmap), int(width), _p(taps), int(ntaps), int(P), wp, bp, ncg, int(bool(relu)), _p(res), _p(y), int(ldy))
+    args = (_p(fmap), int(width), _p(taps), int(ntaps), int(P), wp, bp, ncg, int(bool(relu)), _p(res), _p(y), int(ldy), _p(word),
+            ST_CHAIN_RANGE)
 
     def go(_keep=keep):
         L.check(fn(*args, _stream()), "conv_resident")

@@ -461,6 +461,29 @@ def test_overflow_between_the_linears_of_a_relu_chain_is_caught_although_the_out
     assert "inside an fp16x3 MLP chain" in (g.tripped() or "")
 
 
+def test_feature_maps_beyond_the_fp16_range_between_two_convolutions_are_caught(narrow_after):
+    """EDSR's convolutions are separate launches with a ReLU in between: a feature map that reaches 65504 saturates the next
+    convolution's fp16 pieces, and the ReLU after it can hide the resulting -inf.  Every fp16 launch reports the largest value it hands
+    on (no LayerNorm behind it) into the armed guard; the rollout is repeated in bf16x6 and meets the oracle."""
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    name, hp, salt, batch, d = load_case("magnet_cnn_2d")
+    oracle = O.build(name, hp).eval()
+    fill_state_dict(oracle, salt)
+    with torch.no_grad():
+        oracle.encoder.head_conv.weight.mul_(2.0e5)                    # inputs ~ 1: the head feature map is ~ 1e5
+        assert float(oracle.encoder.head_conv.weight.abs().max()) < 60000
+        want = oracle.validation_step(batch)
+    model = FACTORY[name](hp).eval()
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda()
+    cb = {k: v.cuda() for k, v in batch.items()}
+    with pytest.warns(RuntimeWarning, match="reached 65504|non-finite"):
+        pred = model.validation_step(cb, 0)
+    assert narrow_after.wide() and torch.isfinite(pred).all() and rel_l2(pred, want) < 5e-5
+
+
 def test_weights_beyond_the_fp16_planes_switch_the_split_instead_of_raising(narrow_after):
     """a weight >= 65504 cannot be held as two fp16 pieces: the packs are rebuilt in the full-range split"""
     from magnet_amd.models.factory import FACTORY
