@@ -583,6 +583,7 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
                  "value": world * B * nodes * pred_steps * train_steps / t_el, "unit": "mesh-node-updates/s",
                  "what": "rollout through autograd Functions (HIP forward + backward kernels; hidden Linears walked back in one kernel, first Linear at source-row granularity, tape kept in HBM when it fits) + one gradient all-reduce + fused Adam",
                  "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],
+                 "widened_to_bf16x6": __import__("magnet_amd.packing", fromlist=["wide"]).wide(),
                  "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
         del tmodel, opt, last, train_step
     del model, batch
@@ -695,14 +696,18 @@ def bench_ref_shapes(dev):
     lib = ops.L.lib()
     names = [n for n in ops.L.declared_symbols() if hasattr(lib, n)]
     out = {}
+    from magnet_amd import packing
     for key, (name, hp, mk) in cases.items():
         torch.manual_seed(0)
         res = {"model": name}
-        # ---- training step
+        packing.narrow()                   # (a leg that left the fp16 range must not hand the NEXT one the wider split)
+        # ---- training step.  lr = 1e-6: eight Adam steps at the configs' 1e-3 on RANDOM fields make EDSR's feature maps grow past
+        # 65504 (scripts/dev/many_steps.py cnn_64 24) - the step would then be timed in the bf16x6 fallback, which real
+        # (smooth, normalised) data never enter.  The work of a step does not depend on the learning rate; `widened` says what ran.
         batch, nodes = mk(True)
         batch = {k: v.to(dev) for k, v in batch.items()}
         B = batch["t"].shape[0]
-        tm = FACTORY[name](types.SimpleNamespace(**hp)).to(dev).train()
+        tm = FACTORY[name](types.SimpleNamespace(**dict(hp, lr=1e-6))).to(dev).train()
         opt = tm.configure_optimizers()["optimizer"]
 
         def train_step():
@@ -738,8 +743,10 @@ def bench_ref_shapes(dev):
             train_step()
         torch.cuda.synchronize()
         res["train"] = {"batch": B, "nodes_per_sample": nodes, "ms_per_step": round((time.perf_counter() - t0) / 5 * 1e3, 3),
-                        "c_abi_calls_per_step": calls[0], "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 3)}
+                        "c_abi_calls_per_step": calls[0], "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 3),
+                        "lr": 1e-6, "widened_to_bf16x6": packing.wide()}
         del tm, opt, train_step
+        packing.narrow()
         # ---- validation rollout: kernel by kernel, and replayed from one hipGraph
         batch, nodes = mk(False)
         batch = {k: v.to(dev) for k, v in batch.items()}
@@ -763,6 +770,7 @@ def bench_ref_shapes(dev):
             del vm
         from magnet_amd.graphs import wants_graph
         val["auto_picks"] = "graph" if wants_graph("auto", val["rows"]) else "eager"
+        val["widened_to_bf16x6"] = packing.wide()
         res["validation"] = val
         out[key] = res
         import gc
@@ -956,6 +964,7 @@ def main():
                  "allreduce_ms": round(sum(s_.elapsed_time(e_) for s_, e_ in ar_events) / len(ar_events), 4),
                  "allreduce_bytes": 4 * n_grad,
                  "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],
+                 "widened_to_bf16x6": __import__("magnet_amd.packing", fromlist=["wide"]).wide(),
                  "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
         del tmodel, opt, last, train_step
         import gc

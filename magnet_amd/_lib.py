@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -m magnet_amd.build` (hipcc, gfx950). "
                 "magnet_amd has no CPU fallback.")
+        if os.environ.get("MAGNET_LIB_PATH"):
+            _check_variant(LIB_PATH)
         _lib = C.CDLL(LIB_PATH)
         for name in declared_symbols():
             fn = getattr(_lib, name)          # AttributeError if the .so does not export it
@@ -74,6 +76,24 @@ def lib() -> C.CDLL:
                          "magnet_debug_set_edge_bwd_ablation"):
                 getattr(_lib, name).restype = C.c_int
     return _lib
+
+
+def _check_variant(path: str) -> None:
+    """a library that did not come out of magnet_amd.build (MAGNET_LIB_PATH: experiment variants of the dev scripts) gets the same
+    code-object hazard check before it is loaded - once per file (a stamp next to it remembers the size and mtime that passed)"""
+    st = os.stat(path)
+    stamp, sig = path + ".hazard_ok", f"{st.st_size} {st.st_mtime_ns}"
+    if os.path.exists(stamp) and open(stamp).read().strip() == sig:
+        return
+    from . import hazard_check
+    bad = hazard_check.check(path)
+    if bad:
+        raise RuntimeError(f"{path}: {len(bad)} instruction pair(s) without the wait states they need (magnet_amd/hazard_check.py); "
+                           f"first: {bad[0][3]}  ->  {bad[0][4]}")
+    try:
+        open(stamp, "w").write(sig)
+    except OSError:
+        pass
 
 
 _QUERIES = {}

@@ -45,12 +45,13 @@ __global__ void __launch_bounds__(256) k_pack16(PackSrc s, int NT, int KT, unsig
     const int nt = (int)(tile % NT), kt = (int)(tile / NT);
     const int i = lane & 31, h = lane >> 5;
     unsigned short pl[NP][8];
-    bool bad = false;
+    bool bad = false, big = false;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float v = pack_fetch(s, nt * 32 + i, kt * 32 + 16 * m + 8 * (e >> 2) + 4 * h + (e & 3));
         if (MODE == PACK_FP16X2) {
             bad |= !(fabsf(v) < 65504.0f);                                  // also catches NaN / inf
+            big |= !(fabsf(v) < 31.98f);                                    // fits these planes, not the 2^11-scaled ones of the training kernels
             const _Float16 hv = (_Float16)v;
             pl[0][e] = __builtin_bit_cast(unsigned short, hv);
             pl[1][e] = f2h_bits((v - (float)hv) * 2048.0f);
@@ -81,6 +82,9 @@ __global__ void __launch_bounds__(256) k_pack16(PackSrc s, int NT, int KT, unsig
         *reinterpret_cast<u32x4*>(out + ((((tile * 2 + m) * NP + p) * 64 + lane) * 8)) = w4;
     }
     if ((MODE == PACK_FP16X2 || MODE == PACK_FP16X2S) && status && bad) atomicOr(status, range_bit);
+    // range_bit << 1: a weight in [31.98, 65504) - harmless for this pack, but the one-kernel backward of a hidden Linear and the edge
+    // backward keep 2^11 x the fp16 high plane of the SAME weight; a training step reads this before its backward runs (packing.bad_weights)
+    else if (MODE == PACK_FP16X2 && status && big) atomicOr(status, range_bit << 1);
 }
 
 // fp32 fragments [kt][nt][g][lane 64][4]:  W[nt*32 + (lane & 31)][kt*32 + 8 g + 4 (lane >> 5) + c]

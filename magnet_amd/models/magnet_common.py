@@ -186,7 +186,9 @@ class MagnetBase(LightningModule):
     def _weights_trip(self):
         from ..packing import bad_weights
         params = param_list(self)
-        if not bad_weights(params[0].device):    # the fp16x3 packs' range check: ONE host read per re-pack (not one per Linear)
+        # the fp16x3 packs' range check: ONE host read per re-pack (not one per Linear); with gradients on, also the 31.98 limit of the
+        # backward's scaled planes
+        if not bad_weights(params[0].device, training=torch.is_grad_enabled() and self.training):
             return None
         self._pack_key = None
         if not all(bool(torch.isfinite(p).all()) for p in params):      # a diverged run must not be papered over

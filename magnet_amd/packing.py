@@ -307,16 +307,21 @@ def flag_if_abs_reaches(w: torch.Tensor, limit: float) -> None:
         raise ValueError(f"fp16x3 GEMM mode: this kernel needs finite weights with |w| < {limit}; use MAGNET_GEMM=bf16x6")
 
 
-def bad_weights(dev) -> bool:
+def bad_weights(dev, training: bool = False) -> bool:
     """ONE host read for all packs since the last call (the models call it once per re-pack of their weights) -> True when an
-    fp16x3 pack met a weight outside its range; the flag is cleared"""
+    fp16x3 pack met a weight outside its range; the flag is cleared.  ``training``: a weight in [31.98, 65504) counts as well - it
+    fits the forward's two-accumulator planes, but the backward kernels that keep 2^11 x the high plane (linear_bwd128 / 64, the edge
+    backward) would overflow on it; the pack kernel notes it (bit 2) so that the step is widened BEFORE its backward runs, not one
+    optimizer step of NaN gradients later"""
     dev = torch.device(dev)
     if dev.type == "cuda" and dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
-    if dev in _status and int(_status[dev].item()):
+    if dev not in _status:
+        return False
+    st = int(_status[dev].item())
+    if st:
         _status[dev].zero_()
-        return True
-    return False
+    return bool(st & _WEIGHT_RANGE_BIT) or (training and bool(st & (_WEIGHT_RANGE_BIT << 1)))
 
 
 # A rollout / training step whose caller reads the range status at its END opens a scope; packs made inside leave the status word unread

@@ -89,3 +89,34 @@ def test_a_weight_beyond_the_fp16_range_is_still_caught_when_the_check_is_deferr
         assert torch.equal(loss.detach(), twin.training_step(batch, 0).detach())
     finally:
         packing.narrow()
+
+
+def test_a_weight_the_scaled_backward_planes_cannot_hold_widens_the_step_before_its_backward_runs():
+    """31.98 <= |w| < 65504 fits the forward's planes but not the 2^11-scaled ones of linear_bwd128 / the edge backward: the pack
+    kernel notes it, the training step reads the note at the end of its forward and repeats itself in bf16x6 - the gradients are
+    those of a model that was in bf16x6 all along (before: NaN gradients, reported one optimizer step later)"""
+    import bench
+    from magnet_amd import packing
+    from magnet_amd.models.factory import FACTORY
+    name, hp, mk = bench.ref_shape_cases()["gnn_512"]
+    torch.manual_seed(0)
+    model = FACTORY[name](types.SimpleNamespace(**hp)).cuda().train()
+    batch, _ = mk(True)
+    batch = {k: v.cuda() for k, v in batch.items()}
+    try:
+        with torch.no_grad():
+            model.encoder.node_fn[0].linears()[2].weight[3, 5] = 40.0
+        with pytest.warns(RuntimeWarning):
+            torch.manual_seed(5)
+            loss = model.training_step(batch, 0)
+        assert packing.wide()
+        loss.backward()
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        assert all(bool(torch.isfinite(g).all()) for g in grads.values())
+        twin = FACTORY[name](types.SimpleNamespace(**hp)).cuda().train()
+        twin.load_state_dict(copy.deepcopy(model.state_dict()))
+        torch.manual_seed(5)
+        twin.training_step(batch, 0).backward()
+        assert all(torch.equal(g, dict(twin.named_parameters())[n].grad) for n, g in grads.items())
+    finally:
+        packing.narrow()
