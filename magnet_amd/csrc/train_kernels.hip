@@ -837,7 +837,7 @@ extern "C" int magnet_wgrad_tiles_f32(const float* dY, int ldy, int n_out, const
     const int N = n_out;
     // row blocks (= partial sums per tile): ~768 workgroups over ALL tiles.  768 per tile made a six-tile launch 4 608 workgroups of 43
     // rows each at the reference's EDSR shape (32 768 pixels) and its reduction a 113 MB read: 89 + 83 us per convolution
-    const int cap = ntile > 1 ? (768 / ntile > 96 ? 768 / ntile : 96) : 768;
+    const int cap = ntile > 1 ? (768 / ntile > 32 ? 768 / ntile : 32) : 768;   // (x ntile <= 768: one round of three workgroups per CU)
     const int nblk = (int)((M + WG_SLAB - 1) / WG_SLAB < cap ? (M + WG_SLAB - 1) / WG_SLAB : cap);
     float* part = workspace;
     float* bpart = workspace + (size_t)ntile * nblk * N * kc;
