@@ -190,7 +190,8 @@ class EDSR(nn.Module):
                 cmap = (torch.arange(ntaps, device=dev)[:, None] * width + torch.arange(ci, device=dev)[None, :]).reshape(-1)
                 # last_row_is_padding: every gathered source is as_rows(...), its last row the zero row of the out-of-bounds taps
                 pkc = cache[(id(conv_mod), width)] = types.SimpleNamespace(layers=[layer[0]], ln=None, ht=ot, ot=ot, out_dim=C, col_map=cmap,
-                                                                           last_row_is_padding=True, _rec=self.__dict__.get("_pack_rec"))
+                                                                           last_row_is_padding=True, conv_taps=True,
+                                                                           _rec=self.__dict__.get("_pack_rec"))
             groups = [ops.Term(src, width, idx=taps[t]) for t in range(ntaps)]
             return AG.mlp(P, groups, pkc, [W2, conv_mod.bias], epi=ops.EPI_STORE_RES if res is not None else ops.EPI_STORE,
                           res=res, final_relu=relu)
