@@ -408,6 +408,10 @@ int magnet_reduce_partials_f32(const float* partial, int nblk, long n, float sca
  *      autograd does for models/magnet_gnn.py:312-376 and models/backbones/mlp.py:23-28 + nn.LayerNorm in the reference. ---- */
 /* x0[M][nkt*32] = the first-layer input magnet_mlp_* streams from its k-tile descriptors (materialised for the backward) */
 int magnet_mlp_materialize_input_f32(const magnet_mlp_args_t* args, float* x0, int ldx, void* stream);
+/* Host only, no launch: fills args->nkt and args->kt[] with the descriptors of `ntaps` gathered taps of one source block (tap t, block
+ * k: src[idx[t * n_rows + row]][32 k .. 32 k + 32), idx from magnet_conv_tap_index) - a convolution of models/backbones/edsr.py:32-60 as
+ * a gathered-tap Linear.  Nothing else in *args is touched.  -2: width not a multiple of 32, more than MAGNET_MAX_KT tiles. */
+int magnet_mlp_args_set_taps(magnet_mlp_args_t* args, const float* src, int ld, int width, const int32_t* idx, long n_rows, int ntaps);
 int magnet_relu_bwd_f32(const float* dy, const float* y, float* dz, long n, void* stream);
 /* LayerNorm backward over rows of D <= 256 columns from the pre-norm z; part: [min(2048, ceil(rows/4))][2][D] partial
  * (dgamma | dbeta) sums for magnet_reduce_partials_f32 */

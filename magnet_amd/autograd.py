@@ -218,53 +218,6 @@ def _factored_first_layer(m, srcs, M):
     return ok
 
 
-def _conv_taps(m, pk, srcs, M):
-    """the chain is ONE convolution written as a gathered-tap Linear and its namespace says so (``pk.conv_taps``, set by EDSR: the
-    rows of the index table are the taps of magnet_conv_tap_index - row-major offsets, so tap T - 1 - t is the opposite of tap t -
-    and the source's last row is the zero padding row): every run gathers the full width of the same source through consecutive rows
-    of one [T][M] table -> (source index, source width, T), else None"""
-    if not getattr(pk, "conv_taps", False) or len(pk.layers) != 1 or pk.ln is not None or not m.runs or m.first_cols is not None:
-        return None
-    si0, col0, idx0, _, _, _, w0 = m.runs[0]
-    src_rows, src_w = srcs[si0].reshape(-1, srcs[si0].shape[-1]).shape
-    if idx0 is None or col0 != 0 or w0 != src_w or w0 % 32 or w0 > 128 or src_rows != M + 1 or idx0.dtype != torch.int32:
-        return None
-    for t, (si, col, idx, scale, rdiv, kt0, width) in enumerate(m.runs):
-        if (si != si0 or col != 0 or width != w0 or idx is None or scale != 1.0 or rdiv != 1 or kt0 != t * (w0 // 32)
-                or idx.numel() != M or idx.data_ptr() != idx0.data_ptr() + 4 * t * M):
-            return None
-    if len(m.tiles) != len(m.runs) * (w0 // 32) or len(m.runs) * pk.ot * 32 > L.MAX_KT * 32:      # (K of the transposed launch = T x Np)
-        return None
-    return si0, w0, len(m.runs)
-
-
-def _conv_input_grad(m, pk, srcs, W, dz, taps, dev):
-    """d(feature map) of a convolution = the convolution of dz with the transposed weight blocks over the OPPOSITE taps:
-        dsrc[p] = sum_t W_t^T dz[q : nbr_t(q) = p] = sum_t W_t^T dz[nbr_(T-1-t)(p)]
-    - ONE launch of the forward's own gathered-tap kernel on dz (K = T x Np) that writes [P][C], instead of dz W (a [P][T x C] array:
-    75 MB at the reference's magnet_cnn_2d batch size), its by-tap inverse CSRs and the segment sums that fold it back (93 + 64 us ->
-    58 us per convolution)."""
-    si, w0, T = taps
-    M, Np = m.M, dz.shape[1]
-    n, k = W.shape
-    cache = pk.__dict__.setdefault("_tpacks", {})
-    rec, key = _tpack_recorder(pk, W, cache, ("conv_t",))
-    if key not in cache:
-        from .packing import recording
-        Wp = torch.zeros(Np, T * w0, device=dev, dtype=torch.float32)
-        cols = m.col_map if m.col_map is not None else torch.arange(k, device=dev)
-        Wp[:n, torch.as_tensor(cols, device=dev).long()] = W.detach().float()
-        Wt = Wp.reshape(Np, T, w0).permute(2, 1, 0).reshape(w0, T * Np).contiguous()      # [C in][t][co]: out = source channel
-        with recording(None):                                                           # (made from a temporary: never replayed)
-            cache[key] = pack(Wt, None, BWD_GEMM)
-    dzp = torch.cat([dz, torch.zeros(1, Np, device=dev, dtype=torch.float32)])        # + the zero row the out-of-image taps gather
-    kts = ops.ktiles(*[ops.Term(dzp, Np, idx=m.runs[T - 1 - t][2]) for t in range(T)])
-    g = torch.empty(M + 1, w0, device=dev, dtype=torch.float32)
-    g[M:].zero_()
-    ops.mlp(M, kts, [cache[key]], nl=1, ht=w0 // 32, ot=w0 // 32, act=ops.ACT_NONE, y=g, ldy=w0, ncols=w0)
-    return si, g.view(srcs[si].shape)
-
-
 def _x0_skip_mask(m, srcs, M, np_):
     """bit kt set: the backward walks k tile kt of the first Linear back at source-row granularity (_factored_first_layer) and never
     reads that k tile of the assembled input - the tape does not have to hold it"""
@@ -443,8 +396,6 @@ class _Mlp(torch.autograd.Function):
                 dz, ln_amax = d_rows, None
             # ---- walk the Linears back
             need_dx0 = any(ctx.needs_input_grad[1 + i] for i in range(m.n_src))
-            conv = _conv_taps(m, pk, srcs, M) if nl == 1 and need_dx0 and M > 0 and BWD_GEMM == "bf16x6" else None
-            conv_grad = None
             ws = ops.wgrad_workspace(M, dev)
             nblk_w = min(768, (M + 31) // 32)
             dX0 = None
@@ -496,9 +447,6 @@ class _Mlp(torch.autograd.Function):
                 grads_par[2 * l], grads_par[2 * l + 1] = gW.contiguous(), dbp[:n].contiguous()
                 if l == 0 and not need_dx0:
                     break
-                if l == 0 and conv is not None:                               # a convolution: its input gradient in one launch
-                    conv_grad = _conv_input_grad(m, pk, srcs, W, dz, conv, dev)
-                    break
                 # dX = dz . W   (transposed packs, column block by column block)
                 dX = torch.empty(max(M, 1), Kp, device=dev, dtype=torch.float32)
                 # column blocks of equal width go out as ONE launch (the kernel's column groups over gridDim.y): the nine 128-column
@@ -521,9 +469,7 @@ class _Mlp(torch.autograd.Function):
                     dX0 = dX
             # ---- scatter the first-layer input gradient back through the gathers
             grads_src = [None] * m.n_src
-            if conv_grad is not None:
-                grads_src[conv_grad[0]] = conv_grad[1]
-            elif need_dx0:
+            if need_dx0:
                 # a source that enters as ONE dense full-width run (MAgNet's edge latents) is written, not accumulated: no zero fill,
                 # no read of the destination
                 runs_of = {}
@@ -622,6 +568,92 @@ def _tpack(m, pk, l, c0, w, W, Np, Kp):
         with recording(rec):
             cache[key] = pack_device(Wt, None, BWD_GEMM, w, Np, row_src=rows)
     return cache[key]
+
+
+# ------------------------------------------------------------------------------------------------ convolution (EDSR)
+class _Conv(torch.autograd.Function):
+    """One convolution of EDSR (models/backbones/edsr.py:32-60) as a gathered-tap Linear, HIP forward and backward, with everything
+    the generic ``_Mlp`` works out per call known in advance: T taps of one feature map with a zero padding row, no LayerNorm, one
+    Linear.  The argument blocks come from one C call each (ops.TapTiles), and
+      * d(feature map) is ONE launch of the forward's own kernel on dz with the transposed weight blocks over the OPPOSITE taps
+        (dsrc[p] = sum_t W_t^T dz[nbr_(T-1-t)(p)]: the taps of magnet_conv_tap_index are row-major offsets, tap T - 1 - t undoes tap t)
+        instead of dz W (a [P][T x C] array), T inverse CSRs and their segment sums: 157 -> 66 us per convolution at the reference's
+        magnet_cnn_2d batch size;
+      * dW = dz^T x0 over the materialised taps (magnet_wgrad_tiles_f32), db = column sums of dz."""
+
+    @staticmethod
+    def forward(ctx, meta, src, W2, bias, res):
+        m, pk = meta, meta.pk
+        y = torch.empty(m.P, pk.out_dim, device=src.device, dtype=torch.float32)
+        ops.mlp(m.P, ops.TapTiles(src, m.width, m.taps), pk.layers, nl=1, ht=pk.ht, ot=pk.ot,
+                act=ops.ACT_RELU if m.relu else ops.ACT_NONE, last_act=m.relu, epi=ops.EPI_STORE_RES if res is not None else ops.EPI_STORE,
+                y=y, res=res, ncols=pk.out_dim)
+        ctx.meta = m
+        ctx.save_for_backward(src, W2, *([y] if m.relu else []))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        m, pk = ctx.meta, ctx.meta.pk
+        src, W2 = ctx.saved_tensors[:2]
+        dev, P, T, w0 = dy.device, m.P, m.taps.shape[0], m.width
+        Np, K0 = pk.ot * 32, m.taps.shape[0] * m.width
+        n, k = W2.shape
+        assert pk.out_dim == Np, "EDSR feature widths are multiples of 32"
+        dy = dy.contiguous().float()
+        with torch.no_grad():
+            d_res = dy if ctx.needs_input_grad[4] else None
+            if m.relu:                                                       # y = ReLU(conv): mask the incoming gradient first
+                dz = torch.empty_like(dy)
+                L.check(L.lib().magnet_relu_bwd_f32(ops._p(dy), ops._p(ctx.saved_tensors[2]), ops._p(dz), C.c_long(dy.numel()),
+                                                    ops._stream()), "relu_bwd")
+            else:
+                dz = dy
+            gW = gb = gsrc = None
+            if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+                x0 = torch.empty(P, K0, device=dev, dtype=torch.float32)
+                a, keep = ops.mlp_args(P, ops.TapTiles(src, w0, m.taps))
+                L.check(L.lib().magnet_mlp_materialize_input_f32(C.byref(a), ops._p(x0), K0, ops._stream()), "materialize_input")
+                dWp = torch.empty(Np, K0, device=dev, dtype=torch.float32)
+                dbp = torch.empty(Np, device=dev, dtype=torch.float32)
+                nblk_w = min(768, (P + 31) // 32)
+                ws = None
+                for j, (c0, w, G) in enumerate(_tile_groups(K0)):
+                    need = G * nblk_w * Np * w + nblk_w * Np + G * Np * w
+                    if ws is None or ws.numel() < need:
+                        ws = torch.empty(need, device=dev, dtype=torch.float32)
+                    L.check(L.lib().magnet_wgrad_tiles_f32(ops._p(dz), Np, Np, ops._p(x0), K0, c0, w, G, C.c_long(P), ops._p(dWp), K0, c0,
+                                                           ops._p(dbp if j == 0 else None), ops._p(ws), 0, ops._stream()), "wgrad_tiles")
+                gW = (dWp[:n][:, pk.col_map] if pk.col_map is not None else dWp[:n, :k]).contiguous()
+                gb = dbp[:n].contiguous()
+            if ctx.needs_input_grad[1]:
+                cache = pk.__dict__.setdefault("_tpacks", {})
+                rec, key = _tpack_recorder(pk, W2, cache, ("conv_t",))
+                if key not in cache:
+                    from .packing import recording
+                    Wp = torch.zeros(Np, K0, device=dev, dtype=torch.float32)
+                    if pk.col_map is not None:
+                        Wp[:n, pk.col_map.long()] = W2.detach().float()
+                    else:
+                        Wp[:n, :k] = W2.detach().float()
+                    Wt = Wp.reshape(Np, T, w0).permute(2, 1, 0).reshape(w0, T * Np).contiguous()     # [source channel][t][co]
+                    with recording(None):                                    # (made from a temporary: never replayed)
+                        cache[key] = pack(Wt, None, BWD_GEMM)
+                dzp = torch.cat([dz, torch.zeros(1, Np, device=dev, dtype=torch.float32)])       # + the zero row of the out-of-image taps
+                gsrc = torch.empty(P + 1, w0, device=dev, dtype=torch.float32)
+                gsrc[P:].zero_()
+                ops.mlp(P, ops.TapTiles(dzp, Np, m.taps_rev), [cache[key]], nl=1, ht=w0 // 32, ot=w0 // 32, act=ops.ACT_NONE, y=gsrc,
+                        ldy=w0, ncols=w0)
+        return None, gsrc, gW, gb, d_res
+
+
+def conv(src, taps, taps_rev, pk, W2, bias, relu=False, res=None):
+    """differentiable EDSR convolution: ``src`` [P + 1, width] channels-last rows (last row zero), ``taps`` [T, P] from
+    ops.conv_tap_index and ``taps_rev`` = taps.flip(0) (the opposite taps, contiguous), ``pk`` the chain namespace of the packed weight
+    (layers, ht, ot, out_dim, col_map), ``W2`` [Co, T * Ci] / ``bias`` the parameters behind it (views of the conv's own)"""
+    assert not (relu and res is not None)
+    meta = types.SimpleNamespace(P=int(taps.shape[1]), width=int(src.shape[1]), taps=taps, taps_rev=taps_rev, pk=pk, relu=bool(relu))
+    return _Conv.apply(meta, ops._f32(src, "conv source"), W2, bias, res)
 
 
 def mlp(M, groups, pk, params, *, epi=ops.EPI_STORE, res=None, csr=None, out_rows=None, first_cols=None, final_relu=False):

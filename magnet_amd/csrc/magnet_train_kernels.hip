@@ -436,6 +436,29 @@ extern "C" int magnet_mlp_materialize_input_f32(const MagnetMlpArgs* args, float
     hipLaunchKernelGGL(k_materialize_ktiles, dim3(nb((long)args->M * args->nkt * 8, 256)), dim3(256), 0, S_, *args, x0, ldx);
     END();
 }
+// Host only: the k-tile descriptors of `ntaps` gathered taps of ONE source block - tap t, 32-column block k is
+// src[idx[t * n_rows + row]][32 k .. 32 k + 32) - written into `a` (nkt, kt[]; nothing else is touched).  A convolution as a
+// gathered-tap Linear has up to 36 of these; filling them field by field from Python cost 35 us per launch, 30 ms of a magnet_cnn_2d
+// training step at the reference's batch size.
+extern "C" int magnet_mlp_args_set_taps(MagnetMlpArgs* a, const float* src, int ld, int width, const int32_t* idx, long n_rows,
+                                        int ntaps) {
+    if (!a || !src || !idx || width % 32 || width < 32 || ntaps < 1 || ntaps * (width / 32) > MAGNET_MAX_KT || ld < width || ld % 4) return -2;
+    const int w32 = width / 32;
+    a->nkt = ntaps * w32;
+    for (int t = 0; t < ntaps; ++t)
+        for (int k = 0; k < w32; ++k) {
+            MagnetKTile& kt = a->kt[t * w32 + k];
+            kt.n = 1;
+            kt.s[0].p = src;
+            kt.s[0].idx = idx + (size_t)t * n_rows;
+            kt.s[0].ld = ld;
+            kt.s[0].col = 32 * k;
+            kt.s[0].scale = 1.0f;
+            kt.s[0].rdiv = 1;
+            kt.s[1] = MagnetSrc{};
+        }
+    return 0;
+}
 extern "C" int magnet_relu_bwd_f32(const float* dy, const float* y, float* dz, long n, void* stream) {
     BEGIN();
     if (n <= 0) return 0;

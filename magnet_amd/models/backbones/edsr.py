@@ -179,22 +179,22 @@ class EDSR(nn.Module):
         def as_rows(t_rows):                                   # append the all-zero padding row
             return torch.cat([t_rows, torch.zeros(1, t_rows.shape[1], device=dev, dtype=torch.float32)], 0)
 
+        rev = self._taps.setdefault(("rev", B, tuple(spatial), str(dev)), None)
+        if rev is None:
+            rev = self._taps[("rev", B, tuple(spatial), str(dev))] = taps.flip(0).contiguous()      # tap T - 1 - t undoes tap t
+
         def conv(src, width, layer, conv_mod, relu=False, res=None):
             ci = conv_mod.weight.shape[1]
             W2 = conv_mod.weight.reshape(conv_mod.weight.shape[0], ci, ntaps).permute(0, 2, 1).reshape(conv_mod.weight.shape[0], -1)
-            # one namespace per convolution for as long as its pack lives: the backward caches the transposed packs of the nine taps on it
-            # (a fresh namespace per call re-packed them in each of the four forwards of a training rollout)
+            # one namespace per convolution for as long as its pack lives: the backward caches its transposed pack on it
             cache = pk.setdefault("_grad_ns", {})
             pkc = cache.get((id(conv_mod), width))
             if pkc is None:
-                cmap = (torch.arange(ntaps, device=dev)[:, None] * width + torch.arange(ci, device=dev)[None, :]).reshape(-1)
-                # last_row_is_padding: every gathered source is as_rows(...), its last row the zero row of the out-of-bounds taps
+                cmap = None if ci == width else \
+                    (torch.arange(ntaps, device=dev)[:, None] * width + torch.arange(ci, device=dev)[None, :]).reshape(-1)
                 pkc = cache[(id(conv_mod), width)] = types.SimpleNamespace(layers=[layer[0]], ln=None, ht=ot, ot=ot, out_dim=C, col_map=cmap,
-                                                                           last_row_is_padding=True, conv_taps=True,
                                                                            _rec=self.__dict__.get("_pack_rec"))
-            groups = [ops.Term(src, width, idx=taps[t]) for t in range(ntaps)]
-            return AG.mlp(P, groups, pkc, [W2, conv_mod.bias], epi=ops.EPI_STORE_RES if res is not None else ops.EPI_STORE,
-                          res=res, final_relu=relu)
+            return AG.conv(src, taps, rev, pkc, W2, conv_mod.bias, relu=relu, res=res)
 
         cp = pad_to(cin)
         xin = torch.zeros(P, cp, device=dev, dtype=torch.float32)

@@ -75,9 +75,29 @@ def ktiles(*groups):
     return out
 
 
+@dataclass
+class TapTiles:
+    """the k tiles of a convolution written as a gathered-tap Linear: tap t is src[taps[t][row], 0 : width) - what
+    ``ktiles(*[Term(src, width, idx=taps[t]) for t in range(T)])`` describes, kept as ONE object so that the argument block is filled by
+    one C call (magnet_mlp_args_set_taps) instead of T * width / 32 descriptors field by field from Python"""
+    src: torch.Tensor           # [rows, ld] fp32, ld >= width
+    width: int
+    taps: torch.Tensor          # [T, M] int32, contiguous
+
+    def __len__(self):
+        return self.taps.shape[0] * (self.width // 32)
+
+
 def mlp_args(M, kts):
     """argument block with the row count and the first-layer k-tile descriptors filled in -> (args, keep-alive list)"""
     a = L.MlpArgs()
+    if isinstance(kts, TapTiles):
+        src, taps = _f32(kts.src, "mlp source"), kts.taps
+        assert taps.dtype == torch.int32 and taps.is_contiguous() and taps.shape[1] == M and src.dim() == 2
+        a.M = int(M)
+        L.check(L.lib().magnet_mlp_args_set_taps(C.byref(a), _p(src), src.stride(0), int(kts.width), _p(taps), C.c_long(taps.shape[1]),
+                                                 int(taps.shape[0])), "mlp_args_set_taps")
+        return a, [src, taps]
     a.M, a.nkt = int(M), len(kts)
     assert 1 <= len(kts) <= L.MAX_KT
     keep = []
