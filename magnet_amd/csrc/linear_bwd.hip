@@ -13,6 +13,13 @@
 #include "common.cuh"
 #include "split_single.cuh"
 
+// Development ablations (scripts/dev/build_lb_ablations.sh, profiles/r4/linear_bwd_ablations.txt): -DLB_ABL=<bits> compiles pieces out -
+// 1 the loop's loads, 2 the dx stores, 4 the weight gradient's MFMAs, 8 the data GEMM, 16 the x operand reads + splits, 32 the barriers.
+// Timing only (the results are wrong); the shipped library is built with 0.
+#ifndef LB_ABL
+#define LB_ABL 0
+#endif
+#define LB_BARRIER() do { if (!(LB_ABL & 32)) wg_barrier(); } while (0)
 #define LB_ES 36                        // staging row stride (floats): 32 rows + 4 pad
 struct LinBwdArgs {
     const float* dz;                    // [M][ldz] gradient at the layer's output, 128 columns
@@ -108,11 +115,12 @@ __global__ void __launch_bounds__(256, NT == 2 ? 2 : 1) k_linear_bwd(const LinBw
         // ---- data GEMM: 2^11 sc (dz W)
         f32x16 acc[NT];
         zero_tiles<NT>(acc);
-        gemm_single<NT>(wl, dzr, acc, lane);
+        if (!(LB_ABL & 8)) gemm_single<NT>(wl, dzr, acc, lane);
+        else for (int nt = 0; nt < NT; ++nt) acc[nt] = dzr[nt];
         // next step's dz rows: into the registers the GEMM has just released, in flight during everything below
         asm volatile("" ::: "memory");
-        if (step + gridDim.x < nsteps) load_tile(dzr, a.dz, a.ldz, step + gridDim.x);
-        wg_barrier();                                                         // G dz of all four tiles staged
+        if (!(LB_ABL & 1) && step + gridDim.x < nsteps) load_tile(dzr, a.dz, a.ldz, step + gridDim.x);
+        LB_BARRIER();                                                         // G dz of all four tiles staged
         // ---- this wave's slab of dz (32 features x 128 rows) as fp16 planes, kept for the rounds below; db
         f16x8 ah[4][2], al[4][2];
         if (NT == 4) {                                                        // (NT = 2: read in the wave's own round - 64 registers it does not have)
@@ -139,13 +147,13 @@ __global__ void __launch_bounds__(256, NT == 2 ? 2 : 1) k_linear_bwd(const LinBw
         // ---- dW += dz^T x: NR rounds, XB 32-feature blocks of x of all four tiles per round
 #pragma unroll
         for (int rd = 0; rd < NR; ++rd) {
-            if (rd) wg_barrier();                                             // the previous blocks have been read by everybody
+            if (rd) LB_BARRIER();                                             // the previous blocks have been read by everybody
 #pragma unroll
             for (int q = 0; q < XB; ++q)
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     my_x[(q * 32 + 8 * (i >> 2) + 4 * half + (i & 3)) * ES + j] = row_ok ? xr[rd * XB + q][i] : 0.f;
-            wg_barrier();
+            LB_BARRIER();
             f32x16& cw = accw[NT == 4 ? rd : 0];
             if (NT == 4 || xblk == rd)
 #pragma unroll
@@ -158,9 +166,13 @@ __global__ void __launch_bounds__(256, NT == 2 ? 2 : 1) k_linear_bwd(const LinBw
                     bsum += cs;
                 }
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) stage_operand(sx + (t * 32 + j) * ES + 16 * ks + 8 * half, xh[ks], xl[ks]);
+                for (int ks = 0; ks < 2; ++ks) {
+                    if ((LB_ABL & 16) && (rd | t)) { xh[ks] = ah[t][ks], xl[ks] = al[t][ks]; continue; }
+                    stage_operand(sx + (t * 32 + j) * ES + 16 * ks + 8 * half, xh[ks], xl[ks]);
+                }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
+                    if (LB_ABL & 4) { cw[0] += (float)xh[ks][0] + (float)xl[ks][1]; continue; }
                     cw = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t][ks], xh[ks], cw, 0, 0, 0);
                     cw = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t][ks], xl[ks], cw, 0, 0, 0);
                     cw = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t][ks], xh[ks], cw, 0, 0, 0);
@@ -168,9 +180,9 @@ __global__ void __launch_bounds__(256, NT == 2 ? 2 : 1) k_linear_bwd(const LinBw
             }
         }
         asm volatile("" ::: "memory");
-        if (step + gridDim.x < nsteps) load_tile(xr, a.x, a.ldx, step + gridDim.x);
+        if (!(LB_ABL & 1) && step + gridDim.x < nsteps) load_tile(xr, a.x, a.ldx, step + gridDim.x);
         asm volatile("" ::: "memory");
-        if (row_ok) {
+        if (!(LB_ABL & 2) && row_ok) {
             float* o = a.dx + row * a.lddx + 4 * half;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -180,7 +192,7 @@ __global__ void __launch_bounds__(256, NT == 2 ? 2 : 1) k_linear_bwd(const LinBw
                     *reinterpret_cast<f32x4*>(o + nt * 32 + 8 * g) = v;
                 }
         }
-        wg_barrier();                                                         // staging free for the next step
+        LB_BARRIER();                                                         // staging free for the next step
     }
     // ---- this workgroup's partial sums (C/D row = dz feature = output of the Linear, column = x feature = its input)
     float* wout = a.wpart + (size_t)blockIdx.x * W * W;
@@ -203,6 +215,222 @@ __global__ void __launch_bounds__(256, NT == 2 ? 2 : 1) k_linear_bwd(const LinBw
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Generation 1 of the 128-wide kernel (k_linear_bwd_r; profiles/r4/linear_bwd_ablations.txt is why).  Generation 0 above runs one wave per
+// SIMD with 64 KiB of W planes + 72 KiB of staging in LDS; its compute (0.65 ms at 2.1 M rows) and its memory traffic (0.70 ms) take
+// turns.  Here: eight waves (two per SIMD) on 32-row steps.
+//  * W^T lives in REGISTERS: wave w owns in-features 16 w .. + 15 of the data GEMM (dx^T = W^T dz^T, v_mfma_f32_16x16x32_f16; its 4 k tiles
+//    x 2 planes of A fragments are 32 registers, read once from the standard pack) - no W in LDS at all;
+//  * dz and x are split into fp16 planes ONCE, by the wave that loaded them (4 rows per wave, a lane = 8 consecutive features: 512-byte
+//    coalesced rows), and written row-major [row][feature] to LDS: one image of G dz for the data GEMM's B operand (lane = row, two
+//    ds_read_b64 per k slot, in the pack's k order), one image of G dz and one of x for the weight gradient, whose operands (lane =
+//    feature, registers = rows) come out of ds_read_b64_tr_b16 (profiles/r4/tr_read_probe.txt) - no v_perm, no split on the reading side;
+//  * wave w owns rows 16 w .. + 15 of dW (dz features) x all 128 columns: 8 accumulators of 4 registers;
+//  * the step's operands are double buffered: ONE barrier per step; the next step's rows are loaded while this step's GEMMs run.
+// G dz serves both GEMMs (generation 0 scaled the data GEMM's rows one by one): a row 2^16 times smaller than the launch maximum still has
+// 22 bits, below that its error is bounded by 2^-38 of the launch maximum.
+#define LR_SD 136                       // halfwords per row, data-GEMM image (272 B = 68 banks: 16 rows x 2 k groups hit 64 distinct banks)
+#define LR_ST 144                       // halfwords per row, transposed-read images (288 B = 72 banks: the 8 rows of a 32-lane pass tile the banks)
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+struct LrBuf {
+    unsigned short dzd[2][32][LR_SD];   // [plane][row][feature] G dz
+    unsigned short dzt[2][32][LR_ST];
+    unsigned short xt[2][32][LR_ST];    // x
+};
+typedef __attribute__((address_space(1))) const char* lr_gconst;
+typedef __attribute__((address_space(1))) char* lr_gbytes;
+// 16 bytes at (wave-uniform base made opaque) + 32-bit lane offset + immediate: see wgrad_private.cuh ldg4; the explicit address space
+// keeps the access global_* after the base went through an asm statement
+__device__ __forceinline__ f32x4 lr_ldg4(const float* base, unsigned off, int imm) {
+    return *reinterpret_cast<__attribute__((address_space(1))) const f32x4*>((lr_gconst)(base) + off + imm);
+}
+__device__ __forceinline__ void lr_stg4(float* base, unsigned off, int imm, const f32x4& v) {
+    *reinterpret_cast<__attribute__((address_space(1))) f32x4*>((lr_gbytes)(base) + off + imm) = v;
+}
+__device__ __forceinline__ u32x2 lr_tr(const unsigned short* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p)));
+}
+__device__ __forceinline__ float lr_dot_ones(unsigned w, float acc) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w), one, acc, false);
+}
+
+__global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) LrBuf sb[2];
+    __shared__ float gsc[8];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n16 = lane & 15, q4 = lane >> 4;
+    float G, invG;
+    {
+        float m = 0.f;
+        for (int i = threadIdx.x; i < a.n_amax; i += 512) m = fmaxf(m, a.amax_in[i]);
+#pragma unroll
+        for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) gsc[wave] = m;
+        __syncthreads();
+        m = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) m = fmaxf(m, gsc[w]);
+        const unsigned eb = (__float_as_uint(m) >> 23) & 0xFFu;
+        const bool ok = eb >= 14u && eb < 255u;
+        G = ok ? __uint_as_float((267u - eb) << 23) : 1.0f;                   // 2^(140-eb): G max|dz| < 2^14
+        invG = ok ? __uint_as_float((eb - 13u) << 23) : 1.0f;
+        __syncthreads();
+    }
+    // ---- the wave's 16 in-features of W^T as A fragments (lane = in-feature, k group q4: the pack's k slots (kt, q4 >> 1, q4 & 1))
+    f16x8 wh[4], wlo[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        const int idx = (((kt * 4 + (wave >> 1)) * 2 + (q4 >> 1)) * 2) * 64 + 16 * (wave & 1) + n16 + 32 * (q4 & 1);
+        wh[kt] = __builtin_bit_cast(f16x8, scale_plane_2048(a.wt[idx]));
+        wlo[kt] = __builtin_bit_cast(f16x8, a.wt[idx + 64]);
+    }
+    const long nsteps = (a.M + 31) / 32;
+    const int prow = 4 * wave + q4;                                           // the row of a step this lane loads and splits (features 8 n16 ..)
+    f32x4 dv[2], xv[2];
+    auto load_rows = [&](long step) {
+        const int rr = (int)min((long)prow, a.M - 1 - step * 32);             // (rows past the end: clamped here, zeroed below)
+        const float* bz = a.dz + step * 32 * a.ldz;
+        const float* bx = a.x + step * 32 * a.ldx;
+        asm volatile("" : "+s"(bz), "+s"(bx));
+        const unsigned oz = ((unsigned)rr * (unsigned)a.ldz + 8u * n16) * 4u, ox = ((unsigned)rr * (unsigned)a.ldx + 8u * n16) * 4u;
+        dv[0] = lr_ldg4(bz, oz, 0), dv[1] = lr_ldg4(bz, oz, 16);
+        xv[0] = lr_ldg4(bx, ox, 0), xv[1] = lr_ldg4(bx, ox, 16);
+    };
+    f32x4 accw[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) accw[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f, dxmax = 0.f;
+    long step = blockIdx.x;
+    if (step < nsteps) load_rows(step);
+    for (int it = 0; step < nsteps; step += gridDim.x, ++it) {
+        LrBuf& B = sb[it & 1];
+        // ---- this lane's 8 values of dz and of x as fp16 planes, once for the whole workgroup
+        {
+            const bool pok = step * 32 + prow < a.M;
+            u32x4 zh, zl, xh, xl;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4& d = dv[c >> 1];
+                const f32x4& x = xv[c >> 1];
+                unsigned h, l;
+                split_f16_plain(pok ? d[2 * (c & 1)] * G : 0.f, pok ? d[2 * (c & 1) + 1] * G : 0.f, h, l);
+                zh[c] = h, zl[c] = l;
+                split_f16_plain(pok ? x[2 * (c & 1)] : 0.f, pok ? x[2 * (c & 1) + 1] : 0.f, h, l);
+                xh[c] = h, xl[c] = l;
+            }
+            *reinterpret_cast<u32x4*>(&B.dzd[0][prow][8 * n16]) = zh;
+            *reinterpret_cast<u32x4*>(&B.dzd[1][prow][8 * n16]) = zl;
+            *reinterpret_cast<u32x4*>(&B.dzt[0][prow][8 * n16]) = zh;
+            *reinterpret_cast<u32x4*>(&B.dzt[1][prow][8 * n16]) = zl;
+            *reinterpret_cast<u32x4*>(&B.xt[0][prow][8 * n16]) = xh;
+            *reinterpret_cast<u32x4*>(&B.xt[1][prow][8 * n16]) = xl;
+        }
+        // ---- x at this lane's dx positions (the ReLU mask; L2 hits: the rows were loaded one step ago), then the next step's rows: the
+        // epilogue's wait for the mask must not include the prefetch (vmcnt retires in order)
+        f32x4 xm[2];
+        float* const bdx = a.dx + step * 32 * a.lddx;
+        unsigned odx[2];
+        bool rok[2];
+        {
+            const float* bx = a.x + step * 32 * a.ldx;
+            asm volatile("" : "+s"(bx));
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const long row = step * 32 + 16 * rb + n16;
+                rok[rb] = row < a.M;
+                const int rr = (int)min((long)(16 * rb + n16), a.M - 1 - step * 32);
+                odx[rb] = ((unsigned)(16 * rb + n16) * (unsigned)a.lddx + 16u * wave + 4u * q4) * 4u;
+                if (a.mask) xm[rb] = lr_ldg4(bx, ((unsigned)rr * (unsigned)a.ldx + 16u * wave + 4u * q4) * 4u, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (step + gridDim.x < nsteps) load_rows(step + gridDim.x);
+        asm volatile("" ::: "memory");
+        wg_barrier();                                                         // the step's planes are in LDS (double buffered: the only barrier)
+        // ---- data GEMM: acc[rb] = 2^11 G (dz W)^T for rows 16 rb .., the wave's 16 in-features
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int f0 = 32 * kt + 16 * (q4 >> 1) + 4 * (q4 & 1);
+                const u32x2 h0 = *reinterpret_cast<const u32x2*>(&B.dzd[0][16 * rb + n16][f0]);
+                const u32x2 h1 = *reinterpret_cast<const u32x2*>(&B.dzd[0][16 * rb + n16][f0 + 8]);
+                const u32x2 l0 = *reinterpret_cast<const u32x2*>(&B.dzd[1][16 * rb + n16][f0]);
+                const u32x2 l1 = *reinterpret_cast<const u32x2*>(&B.dzd[1][16 * rb + n16][f0 + 8]);
+                const f16x8 zh = __builtin_bit_cast(f16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+                const f16x8 zl = __builtin_bit_cast(f16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[kt], zh, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kt], zl, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kt], zh, acc[rb], 0, 0, 0);
+            }
+        // ---- dW slab += (G dz)^T x over the step's 32 rows (k order: lane group q4 takes rows 4 q4 .. + 3 and 16 + 4 q4 .. + 3), db
+        {
+            const int r0 = 4 * q4 + (n16 >> 2), c0 = 4 * (n16 & 3);
+            const u32x2 a0 = lr_tr(&B.dzt[0][r0][16 * wave + c0]), a1 = lr_tr(&B.dzt[0][16 + r0][16 * wave + c0]);
+            const u32x2 b0 = lr_tr(&B.dzt[1][r0][16 * wave + c0]), b1 = lr_tr(&B.dzt[1][16 + r0][16 * wave + c0]);
+            const f16x8 ah = __builtin_bit_cast(f16x8, u32x4{a0[0], a0[1], a1[0], a1[1]});
+            const f16x8 al = __builtin_bit_cast(f16x8, u32x4{b0[0], b0[1], b1[0], b1[1]});
+            float cs = lr_dot_ones(a0[0], 0.f);
+            cs = lr_dot_ones(a0[1], cs), cs = lr_dot_ones(a1[0], cs), cs = lr_dot_ones(a1[1], cs);
+            cs = lr_dot_ones(b0[0], cs), cs = lr_dot_ones(b0[1], cs), cs = lr_dot_ones(b1[0], cs), cs = lr_dot_ones(b1[1], cs);
+            bsum += cs;
+#pragma unroll
+            for (int xb = 0; xb < 8; ++xb) {
+                const u32x2 p0 = lr_tr(&B.xt[0][r0][16 * xb + c0]), p1 = lr_tr(&B.xt[0][16 + r0][16 * xb + c0]);
+                const u32x2 q0 = lr_tr(&B.xt[1][r0][16 * xb + c0]), q1 = lr_tr(&B.xt[1][16 + r0][16 * xb + c0]);
+                const f16x8 xh = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p1[0], p1[1]});
+                const f16x8 xl = __builtin_bit_cast(f16x8, u32x4{q0[0], q0[1], q1[0], q1[1]});
+                accw[xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh, accw[xb], 0, 0, 0);
+                accw[xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl, accw[xb], 0, 0, 0);
+                accw[xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh, accw[xb], 0, 0, 0);
+            }
+        }
+        // ---- dx = (x > 0) * (dz W): C/D row 4 q4 + i = in-feature 16 wave + 4 q4 + i, column n16 = row 16 rb + n16
+        {
+            float* bo = bdx;
+            asm volatile("" : "+s"(bo));
+            const float sc = (1.0f / 2048.0f) * invG;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                f32x4 t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = acc[rb][i] * sc;
+                    if (a.mask) v = xm[rb][i] > 0.f ? v : 0.f;
+                    t[i] = v;
+                    dxmax = fmaxf(dxmax, fabsf(v));
+                }
+                if (rok[rb]) lr_stg4(bo, odx[rb], 0, t);
+            }
+        }
+    }
+    // ---- this workgroup's partial sums
+    float* wout = a.wpart + (size_t)blockIdx.x * 128 * 128;
+#pragma unroll
+    for (int xb = 0; xb < 8; ++xb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wout[(size_t)(16 * wave + 4 * q4 + i) * 128 + 16 * xb + n16] = accw[xb][i] * invG;
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (q4 == 0) a.bpart[(size_t)blockIdx.x * 128 + 16 * wave + n16] = bsum * invG;
+    if (a.amax_out) {
+#pragma unroll
+        for (int o = 32; o; o >>= 1) dxmax = fmaxf(dxmax, __shfl_xor(dxmax, o));
+        __syncthreads();
+        if (lane == 0) gsc[wave] = dxmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) m = fmaxf(m, gsc[w]);
+            a.amax_out[blockIdx.x] = m;
+        }
+    }
+}
+
 int magnet_launch_reduce_partials2(const float* pa, long na, float* oa, const float* pb, long nb_, float* ob, int nblk, float scale,
                                    int accumulate, void* stream);      // train_kernels.hip: both reductions in one launch
 
@@ -218,6 +446,19 @@ static int lb_grid(long M, int per_cu = 1) {
     return (int)(steps < (long)ncu * per_cu ? steps : (long)ncu * per_cu);
 }
 #define LB_AMAX_BLOCKS 256
+// which kernel serves magnet_linear_bwd128_f32: 1 (default) = k_linear_bwd_r (32-row steps, eight waves), 0 = k_linear_bwd<4>
+static int g_lb_generation = 1;
+extern "C" int magnet_linear_bwd128_generation(int generation) {
+    const int prev = g_lb_generation;
+    if (generation == 0 || generation == 1) g_lb_generation = generation;
+    return prev;
+}
+static int lb_grid128(long M) {
+    if (g_lb_generation == 0) return lb_grid(M);
+    const int ncu = lb_grid(1L << 40);
+    const long steps = (M + 31) / 32;
+    return (int)(steps < (long)ncu ? steps : (long)ncu);
+}
 // workspace floats of magnet_linear_bwd{128,64}_f32: per-workgroup partial sums of dW and db, one set of block maxima
 extern "C" int magnet_linear_bwd128_workspace(void) { return lb_grid(1L << 40) * (128 * 128 + 128) + LB_AMAX_BLOCKS; }
 template <int NT>
@@ -228,7 +469,7 @@ static int launch_linear_bwd(const float* dz, int ldz, const float* x, int ldx, 
     (void)hipGetLastError();
     if (M <= 0) return 0;
     if (ldz < W || ldx < W || lddx < W || (ldz | ldx | lddx) % 4) return -2;
-    const int grid = lb_grid(M, NT == 2 ? 2 : 1);
+    const int grid = NT == 4 ? lb_grid128(M) : lb_grid(M, 2);
     LinBwdArgs a;
     a.dz = dz, a.ldz = ldz, a.x = x, a.ldx = ldx, a.wt = reinterpret_cast<const u32x4*>(wt_f16), a.dx = dx, a.lddx = lddx, a.M = M;
     a.mask = mask;
@@ -246,7 +487,10 @@ static int launch_linear_bwd(const float* dz, int ldz, const float* x, int ldx, 
         a.amax_in = own_amax, a.n_amax = nab;
     }
     a.amax_out = amax_out;
-    hipLaunchKernelGGL(k_linear_bwd<NT>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (NT == 4 && g_lb_generation == 1)
+        hipLaunchKernelGGL(k_linear_bwd_r, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(k_linear_bwd<NT>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     return magnet_launch_reduce_partials2(a.wpart, (long)W * W, dW, a.bpart, (long)W, db, grid, 1.0f, accumulate, stream);
@@ -267,5 +511,5 @@ extern "C" int magnet_linear_bwd64_f32(const float* dz, int ldz, const float* x,
     return launch_linear_bwd<2>(dz, ldz, x, ldx, wt_f16, M, mask, dx, lddx, dW, db, accumulate, amax_in, n_amax_in, amax_out, workspace,
                                 stream);
 }
-extern "C" int magnet_linear_bwd128_grid(long M) { return lb_grid(M); }
+extern "C" int magnet_linear_bwd128_grid(long M) { return lb_grid128(M); }
 extern "C" int magnet_linear_bwd64_grid(long M) { return lb_grid(M, 2); }
