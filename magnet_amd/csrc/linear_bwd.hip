@@ -221,22 +221,26 @@ __global__ void __launch_bounds__(256, NT == 2 ? 2 : 1) k_linear_bwd(const LinBw
 // turns.  Here: eight waves (two per SIMD) on 32-row steps.
 //  * W^T lives in REGISTERS: wave w owns in-features 16 w .. + 15 of the data GEMM (dx^T = W^T dz^T, v_mfma_f32_16x16x32_f16; its 4 k tiles
 //    x 2 planes of A fragments are 32 registers, read once from the standard pack) - no W in LDS at all;
-//  * dz and x are split into fp16 planes ONCE, by the wave that loaded them (4 rows per wave, a lane = 8 consecutive features: 512-byte
-//    coalesced rows), and written row-major [row][feature] to LDS: one image of G dz for the data GEMM's B operand (lane = row, two
-//    ds_read_b64 per k slot, in the pack's k order), one image of G dz and one of x for the weight gradient, whose operands (lane =
-//    feature, registers = rows) come out of ds_read_b64_tr_b16 (profiles/r4/tr_read_probe.txt) - no v_perm, no split on the reading side;
+//  * dz and x are split into fp16 planes ONCE, by the wave that loaded them (4 rows per wave, a lane = 2 x 4 features: 512-byte coalesced
+//    rows), and written row-major [row][position] to LDS: ONE image of G dz and one of x.  The data GEMM's B operand (lane = row) is one
+//    ds_read_b128 per k slot and plane; the weight gradient's operands (lane = feature, registers = rows) come out of
+//    ds_read_b64_tr_b16 (profiles/r4/tr_read_probe.txt) - no v_perm, no split on the reading side;
 //  * wave w owns rows 16 w .. + 15 of dW (dz features) x all 128 columns: 8 accumulators of 4 registers;
 //  * the step's operands are double buffered: ONE barrier per step; the next step's rows are loaded while this step's GEMMs run.
 // G dz serves both GEMMs (generation 0 scaled the data GEMM's rows one by one): a row 2^16 times smaller than the launch maximum still has
 // 22 bits, below that its error is bounded by 2^-38 of the launch maximum.
-#define LR_SD 136                       // halfwords per row, data-GEMM image (272 B = 68 banks: 16 rows x 2 k groups hit 64 distinct banks)
-#define LR_ST 144                       // halfwords per row, transposed-read images (288 B = 72 banks: the 8 rows of a 32-lane pass tile the banks)
+#define LR_ST 144                       // halfwords per row: 288 B = 72 banks - the 8 rows of a transposed read's 32-lane group tile the 64 banks
+                                        // (3.0 LDS cycles per read, the floor: scripts/dev/tr_bank_probe.cpp), and so do the 16-lane groups of the
+                                        // data GEMM's ds_read_b128
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+// Within every block of 16 features the images hold feature 8 hi + 4 kg + c at position 8 kg + 4 hi + c (bits 2 and 3 swapped): the 8 k values
+// the standard pack puts in one lane of an A fragment - features 4 kg + c and 8 + 4 kg + c of a 16-feature k slot - are then ONE 16-byte
+// read for the data GEMM, and the same image serves the transposed reads (whose lane i is then feature lr_sw(i) of its block).
 struct LrBuf {
-    unsigned short dzd[2][32][LR_SD];   // [plane][row][feature] G dz
-    unsigned short dzt[2][32][LR_ST];
-    unsigned short xt[2][32][LR_ST];    // x
+    unsigned short dz[2][32][LR_ST];    // [plane][row][position] G dz
+    unsigned short x[2][32][LR_ST];
 };
+__device__ __forceinline__ int lr_sw(int i) { return (i & 3) | ((i & 4) << 1) | ((i & 8) >> 1); }
 typedef __attribute__((address_space(1))) const char* lr_gconst;
 typedef __attribute__((address_space(1))) char* lr_gbytes;
 // 16 bytes at (wave-uniform base made opaque) + 32-bit lane offset + immediate: see wgrad_private.cuh ldg4; the explicit address space
@@ -256,6 +260,7 @@ __device__ __forceinline__ float lr_dot_ones(unsigned w, float acc) {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w), one, acc, false);
 }
 
+template <int PF>        // steps of rows in flight ahead of the one being computed (2 and 3 measured: no gain, profiles/r4/linear_bwd_gen1.txt)
 __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
     __shared__ __attribute__((aligned(16))) LrBuf sb[2];
     __shared__ float gsc[8];
@@ -287,45 +292,52 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
         wlo[kt] = __builtin_bit_cast(f16x8, a.wt[idx + 64]);
     }
     const long nsteps = (a.M + 31) / 32;
-    const int prow = 4 * wave + q4;                                           // the row of a step this lane loads and splits (features 8 n16 ..)
-    f32x4 dv[2], xv[2];
-    auto load_rows = [&](long step) {
-        const int rr = (int)min((long)prow, a.M - 1 - step * 32);             // (rows past the end: clamped here, zeroed below)
+    // the two rows of a step this lane loads and splits: 4 wave + (lane >> 5) and + 2, features 4 (lane & 31) .. + 3 of each - every load
+    // instruction reads two whole 512-byte rows; the four values land at position ppos of the images (see LrBuf)
+    const int l32 = lane & 31, prow = 4 * wave + (lane >> 5);
+    const int ppos = 16 * (l32 >> 2) + 8 * (l32 & 1) + 4 * ((l32 >> 1) & 1);
+    f32x4 dvs[PF][2], xvs[PF][2];
+    auto load_rows = [&](long step, f32x4 (&dv)[2], f32x4 (&xv)[2]) {
+        const long last = a.M - 1 - step * 32;
+        const int rr0 = (int)min((long)prow, last), rr1 = (int)min((long)(prow + 2), last);   // (rows past the end: clamped here, zeroed below)
         const float* bz = a.dz + step * 32 * a.ldz;
         const float* bx = a.x + step * 32 * a.ldx;
         asm volatile("" : "+s"(bz), "+s"(bx));
-        const unsigned oz = ((unsigned)rr * (unsigned)a.ldz + 8u * n16) * 4u, ox = ((unsigned)rr * (unsigned)a.ldx + 8u * n16) * 4u;
-        dv[0] = lr_ldg4(bz, oz, 0), dv[1] = lr_ldg4(bz, oz, 16);
-        xv[0] = lr_ldg4(bx, ox, 0), xv[1] = lr_ldg4(bx, ox, 16);
+        dv[0] = lr_ldg4(bz, ((unsigned)rr0 * (unsigned)a.ldz + 4u * l32) * 4u, 0);
+        dv[1] = lr_ldg4(bz, ((unsigned)rr1 * (unsigned)a.ldz + 4u * l32) * 4u, 0);
+        xv[0] = lr_ldg4(bx, ((unsigned)rr0 * (unsigned)a.ldx + 4u * l32) * 4u, 0);
+        xv[1] = lr_ldg4(bx, ((unsigned)rr1 * (unsigned)a.ldx + 4u * l32) * 4u, 0);
     };
     f32x4 accw[8];
 #pragma unroll
     for (int b = 0; b < 8; ++b) accw[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f, dxmax = 0.f;
     long step = blockIdx.x;
-    if (step < nsteps) load_rows(step);
-    for (int it = 0; step < nsteps; step += gridDim.x, ++it) {
-        LrBuf& B = sb[it & 1];
-        // ---- this lane's 8 values of dz and of x as fp16 planes, once for the whole workgroup
-        {
-            const bool pok = step * 32 + prow < a.M;
-            u32x4 zh, zl, xh, xl;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4& d = dv[c >> 1];
-                const f32x4& x = xv[c >> 1];
+    for (int p = 0; p < PF; ++p)
+        if (step + (long)p * gridDim.x < nsteps) load_rows(step + (long)p * gridDim.x, dvs[p], xvs[p]);
+    // one step; set = which register set holds its rows (the loop is unrolled PF times: register arrays are not indexed at run time)
+    auto body = [&](long step, int buf, f32x4 (&dv)[2], f32x4 (&xv)[2]) {
+        LrBuf& B = sb[buf];
+        // ---- this lane's 2 x 4 values of dz and of x as fp16 planes, once for the whole workgroup
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool pok = step * 32 + prow + 2 * k < a.M;
+            const f32x4& d = dv[k];
+            const f32x4& x = xv[k];
+            u32x2 zh, zl, xh, xl;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
                 unsigned h, l;
-                split_f16_plain(pok ? d[2 * (c & 1)] * G : 0.f, pok ? d[2 * (c & 1) + 1] * G : 0.f, h, l);
+                split_f16_plain(pok ? d[2 * c] * G : 0.f, pok ? d[2 * c + 1] * G : 0.f, h, l);
                 zh[c] = h, zl[c] = l;
-                split_f16_plain(pok ? x[2 * (c & 1)] : 0.f, pok ? x[2 * (c & 1) + 1] : 0.f, h, l);
+                split_f16_plain(pok ? x[2 * c] : 0.f, pok ? x[2 * c + 1] : 0.f, h, l);
                 xh[c] = h, xl[c] = l;
             }
-            *reinterpret_cast<u32x4*>(&B.dzd[0][prow][8 * n16]) = zh;
-            *reinterpret_cast<u32x4*>(&B.dzd[1][prow][8 * n16]) = zl;
-            *reinterpret_cast<u32x4*>(&B.dzt[0][prow][8 * n16]) = zh;
-            *reinterpret_cast<u32x4*>(&B.dzt[1][prow][8 * n16]) = zl;
-            *reinterpret_cast<u32x4*>(&B.xt[0][prow][8 * n16]) = xh;
-            *reinterpret_cast<u32x4*>(&B.xt[1][prow][8 * n16]) = xl;
+            *reinterpret_cast<u32x2*>(&B.dz[0][prow + 2 * k][ppos]) = zh;
+            *reinterpret_cast<u32x2*>(&B.dz[1][prow + 2 * k][ppos]) = zl;
+            *reinterpret_cast<u32x2*>(&B.x[0][prow + 2 * k][ppos]) = xh;
+            *reinterpret_cast<u32x2*>(&B.x[1][prow + 2 * k][ppos]) = xl;
         }
         // ---- x at this lane's dx positions (the ReLU mask; L2 hits: the rows were loaded one step ago), then the next step's rows: the
         // epilogue's wait for the mask must not include the prefetch (vmcnt retires in order)
@@ -346,7 +358,7 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
             }
         }
         asm volatile("" ::: "memory");
-        if (step + gridDim.x < nsteps) load_rows(step + gridDim.x);
+        if (step + (long)PF * gridDim.x < nsteps) load_rows(step + (long)PF * gridDim.x, dv, xv);
         asm volatile("" ::: "memory");
         wg_barrier();                                                         // the step's planes are in LDS (double buffered: the only barrier)
         // ---- data GEMM: acc[rb] = 2^11 G (dz W)^T for rows 16 rb .., the wave's 16 in-features
@@ -355,13 +367,8 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
-                const int f0 = 32 * kt + 16 * (q4 >> 1) + 4 * (q4 & 1);
-                const u32x2 h0 = *reinterpret_cast<const u32x2*>(&B.dzd[0][16 * rb + n16][f0]);
-                const u32x2 h1 = *reinterpret_cast<const u32x2*>(&B.dzd[0][16 * rb + n16][f0 + 8]);
-                const u32x2 l0 = *reinterpret_cast<const u32x2*>(&B.dzd[1][16 * rb + n16][f0]);
-                const u32x2 l1 = *reinterpret_cast<const u32x2*>(&B.dzd[1][16 * rb + n16][f0 + 8]);
-                const f16x8 zh = __builtin_bit_cast(f16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
-                const f16x8 zl = __builtin_bit_cast(f16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+                const f16x8 zh = *reinterpret_cast<const f16x8*>(&B.dz[0][16 * rb + n16][32 * kt + 8 * q4]);
+                const f16x8 zl = *reinterpret_cast<const f16x8*>(&B.dz[1][16 * rb + n16][32 * kt + 8 * q4]);
                 acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[kt], zh, acc[rb], 0, 0, 0);
                 acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kt], zl, acc[rb], 0, 0, 0);
                 acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kt], zh, acc[rb], 0, 0, 0);
@@ -369,8 +376,8 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
         // ---- dW slab += (G dz)^T x over the step's 32 rows (k order: lane group q4 takes rows 4 q4 .. + 3 and 16 + 4 q4 .. + 3), db
         {
             const int r0 = 4 * q4 + (n16 >> 2), c0 = 4 * (n16 & 3);
-            const u32x2 a0 = lr_tr(&B.dzt[0][r0][16 * wave + c0]), a1 = lr_tr(&B.dzt[0][16 + r0][16 * wave + c0]);
-            const u32x2 b0 = lr_tr(&B.dzt[1][r0][16 * wave + c0]), b1 = lr_tr(&B.dzt[1][16 + r0][16 * wave + c0]);
+            const u32x2 a0 = lr_tr(&B.dz[0][r0][16 * wave + c0]), a1 = lr_tr(&B.dz[0][16 + r0][16 * wave + c0]);
+            const u32x2 b0 = lr_tr(&B.dz[1][r0][16 * wave + c0]), b1 = lr_tr(&B.dz[1][16 + r0][16 * wave + c0]);
             const f16x8 ah = __builtin_bit_cast(f16x8, u32x4{a0[0], a0[1], a1[0], a1[1]});
             const f16x8 al = __builtin_bit_cast(f16x8, u32x4{b0[0], b0[1], b1[0], b1[1]});
             float cs = lr_dot_ones(a0[0], 0.f);
@@ -379,8 +386,8 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
             bsum += cs;
 #pragma unroll
             for (int xb = 0; xb < 8; ++xb) {
-                const u32x2 p0 = lr_tr(&B.xt[0][r0][16 * xb + c0]), p1 = lr_tr(&B.xt[0][16 + r0][16 * xb + c0]);
-                const u32x2 q0 = lr_tr(&B.xt[1][r0][16 * xb + c0]), q1 = lr_tr(&B.xt[1][16 + r0][16 * xb + c0]);
+                const u32x2 p0 = lr_tr(&B.x[0][r0][16 * xb + c0]), p1 = lr_tr(&B.x[0][16 + r0][16 * xb + c0]);
+                const u32x2 q0 = lr_tr(&B.x[1][r0][16 * xb + c0]), q1 = lr_tr(&B.x[1][16 + r0][16 * xb + c0]);
                 const f16x8 xh = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p1[0], p1[1]});
                 const f16x8 xl = __builtin_bit_cast(f16x8, u32x4{q0[0], q0[1], q1[0], q1[1]});
                 accw[xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh, accw[xb], 0, 0, 0);
@@ -406,16 +413,24 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
                 if (rok[rb]) lr_stg4(bo, odx[rb], 0, t);
             }
         }
+    };
+    for (int it = 0; step < nsteps; it += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            if (step >= nsteps) break;
+            body(step, (it + p) & 1, dvs[p], xvs[p]);
+            step += gridDim.x;
+        }
     }
     // ---- this workgroup's partial sums
     float* wout = a.wpart + (size_t)blockIdx.x * 128 * 128;
 #pragma unroll
     for (int xb = 0; xb < 8; ++xb)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wout[(size_t)(16 * wave + 4 * q4 + i) * 128 + 16 * xb + n16] = accw[xb][i] * invG;
+        for (int i = 0; i < 4; ++i) wout[(size_t)(16 * wave + lr_sw(4 * q4 + i)) * 128 + 16 * xb + lr_sw(n16)] = accw[xb][i] * invG;
     bsum += __shfl_xor(bsum, 16);
     bsum += __shfl_xor(bsum, 32);
-    if (q4 == 0) a.bpart[(size_t)blockIdx.x * 128 + 16 * wave + n16] = bsum * invG;
+    if (q4 == 0) a.bpart[(size_t)blockIdx.x * 128 + 16 * wave + lr_sw(n16)] = bsum * invG;
     if (a.amax_out) {
 #pragma unroll
         for (int o = 32; o; o >>= 1) dxmax = fmaxf(dxmax, __shfl_xor(dxmax, o));
@@ -488,7 +503,8 @@ static int launch_linear_bwd(const float* dz, int ldz, const float* x, int ldx, 
     }
     a.amax_out = amax_out;
     if (NT == 4 && g_lb_generation == 1)
-        hipLaunchKernelGGL(k_linear_bwd_r, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(k_linear_bwd_r<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+
     else
         hipLaunchKernelGGL(k_linear_bwd<NT>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     int rc = (int)hipGetLastError();

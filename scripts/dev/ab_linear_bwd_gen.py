@@ -83,7 +83,8 @@ for _ in range(20):
     b = run(1, dz, x, wt, True)
     bad += int(not (torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])))
 print("gen1 repeat launches that differ:", bad, "of 20")
-# timing
+# timing (generations 2 / 3 = generation 1 with two / three steps of rows in flight)
+GENS = tuple(int(v) for v in os.environ.get('LB_GENS', '0,1').split(','))
 for M in (2105344, 218752, 18432):
     dz = torch.randn(M, 128, device="cuda") * 1e-7
     x = torch.relu(torch.randn(M, 128, device="cuda"))
@@ -91,7 +92,7 @@ for M in (2105344, 218752, 18432):
     dx, dW, db = torch.empty(M, 128, device="cuda"), torch.empty(128, 128, device="cuda"), torch.empty(128, device="cuda")
     line = f"M={M:8d}:"
     for rep in range(3):
-        for gen in (0, 1):
+        for gen in GENS:
             use(gen)
             am = ops.linear_bwd128(dz, x, wt, dx, dW, db, ws)
             for _ in range(3):

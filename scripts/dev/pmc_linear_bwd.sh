@@ -1,4 +1,4 @@
-# Dev: SQ counters of k_linear_bwd<4> at the E-level row count of C5 (three separate --pmc passes, kernel trace only)
+# Dev: SQ counters of the kernel behind magnet_linear_bwd128_f32 (default generation) at the E-level row count of C5 (three separate --pmc passes, kernel trace only)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_linear_bwd; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -13,7 +13,7 @@ acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(f"{O}/p*/*/*_counter_collection.csv"):
     rows = list(csv.DictReader(open(f)))
     for r in rows:
-        if "k_linear_bwd<4>" in r["Kernel_Name"] or "k_linear_bwdILi4" in r["Kernel_Name"]:
+        if "k_linear_bwd" in r["Kernel_Name"] and "<2>" not in r["Kernel_Name"] and "ILi2" not in r["Kernel_Name"]:
             a = acc[r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
 for k, (v, n) in sorted(acc.items()):
