@@ -236,9 +236,10 @@ typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 // Within every block of 16 features the images hold feature 8 hi + 4 kg + c at position 8 kg + 4 hi + c (bits 2 and 3 swapped): the 8 k values
 // the standard pack puts in one lane of an A fragment - features 4 kg + c and 8 + 4 kg + c of a 16-feature k slot - are then ONE 16-byte
 // read for the data GEMM, and the same image serves the transposed reads (whose lane i is then feature lr_sw(i) of its block).
+template <int ST>
 struct LrBuf {
-    unsigned short dz[2][32][LR_ST];    // [plane][row][position] G dz
-    unsigned short x[2][32][LR_ST];
+    unsigned short dz[2][32][ST];       // [plane][row][position] G dz
+    unsigned short x[2][32][ST];
 };
 __device__ __forceinline__ int lr_sw(int i) { return (i & 3) | ((i & 4) << 1) | ((i & 8) >> 1); }
 typedef __attribute__((address_space(1))) const char* lr_gconst;
@@ -260,23 +261,29 @@ __device__ __forceinline__ float lr_dot_ones(unsigned w, float acc) {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w), one, acc, false);
 }
 
-template <int PF>        // steps of rows in flight ahead of the one being computed (2 and 3 measured: no gain, profiles/r4/linear_bwd_gen1.txt)
-__global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) LrBuf sb[2];
-    __shared__ float gsc[8];
+// WIDTH 128: eight waves, one workgroup per CU.  WIDTH 64 (MAgNet[CNN]'s MLPs): four waves, two workgroups per CU; rows of 256 bytes, a
+// load instruction reads four of them; LDS row stride 160 B (3.0 cycles per transposed read, conflict-free 16-byte reads).
+// PF: steps of rows in flight ahead of the one being computed (2 and 3 measured: no gain, profiles/r4/linear_bwd_gen1.txt)
+template <int WIDTH, int PF>
+__global__ void __launch_bounds__(WIDTH * 4, WIDTH == 128 ? 1 : 2) k_linear_bwd_r(const LinBwdArgs a) {
+    constexpr int NW = WIDTH / 16, KT = WIDTH / 32, XB = WIDTH / 16, ST = WIDTH == 128 ? LR_ST : 80;
+    constexpr int LPR = WIDTH / 4, RPI = 64 / LPR;                            // lanes per row of a load instruction, rows per instruction
+    typedef LrBuf<ST> Buf;
+    __shared__ __attribute__((aligned(16))) Buf sb[2];
+    __shared__ float gsc[NW];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n16 = lane & 15, q4 = lane >> 4;
     float G, invG;
     {
         float m = 0.f;
-        for (int i = threadIdx.x; i < a.n_amax; i += 512) m = fmaxf(m, a.amax_in[i]);
+        for (int i = threadIdx.x; i < a.n_amax; i += 64 * NW) m = fmaxf(m, a.amax_in[i]);
 #pragma unroll
         for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if (lane == 0) gsc[wave] = m;
         __syncthreads();
         m = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) m = fmaxf(m, gsc[w]);
+        for (int w = 0; w < NW; ++w) m = fmaxf(m, gsc[w]);
         const unsigned eb = (__float_as_uint(m) >> 23) & 0xFFu;
         const bool ok = eb >= 14u && eb < 255u;
         G = ok ? __uint_as_float((267u - eb) << 23) : 1.0f;                   // 2^(140-eb): G max|dz| < 2^14
@@ -284,22 +291,22 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
         __syncthreads();
     }
     // ---- the wave's 16 in-features of W^T as A fragments (lane = in-feature, k group q4: the pack's k slots (kt, q4 >> 1, q4 & 1))
-    f16x8 wh[4], wlo[4];
+    f16x8 wh[KT], wlo[KT];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        const int idx = (((kt * 4 + (wave >> 1)) * 2 + (q4 >> 1)) * 2) * 64 + 16 * (wave & 1) + n16 + 32 * (q4 & 1);
+    for (int kt = 0; kt < KT; ++kt) {
+        const int idx = (((kt * KT + (wave >> 1)) * 2 + (q4 >> 1)) * 2) * 64 + 16 * (wave & 1) + n16 + 32 * (q4 & 1);
         wh[kt] = __builtin_bit_cast(f16x8, scale_plane_2048(a.wt[idx]));
         wlo[kt] = __builtin_bit_cast(f16x8, a.wt[idx + 64]);
     }
     const long nsteps = (a.M + 31) / 32;
-    // the two rows of a step this lane loads and splits: 4 wave + (lane >> 5) and + 2, features 4 (lane & 31) .. + 3 of each - every load
-    // instruction reads two whole 512-byte rows; the four values land at position ppos of the images (see LrBuf)
-    const int l32 = lane & 31, prow = 4 * wave + (lane >> 5);
+    // the two rows of a step this lane loads and splits: prow and prow + RPI, features 4 l32 .. + 3 of each - every load instruction reads
+    // RPI whole rows (2 x 512 bytes / 4 x 256); the four values land at position ppos of the images (see LrBuf)
+    const int l32 = lane & (LPR - 1), prow = (32 / NW) * wave + lane / LPR;
     const int ppos = 16 * (l32 >> 2) + 8 * (l32 & 1) + 4 * ((l32 >> 1) & 1);
     f32x4 dvs[PF][2], xvs[PF][2];
     auto load_rows = [&](long step, f32x4 (&dv)[2], f32x4 (&xv)[2]) {
         const long last = a.M - 1 - step * 32;
-        const int rr0 = (int)min((long)prow, last), rr1 = (int)min((long)(prow + 2), last);   // (rows past the end: clamped here, zeroed below)
+        const int rr0 = (int)min((long)prow, last), rr1 = (int)min((long)(prow + RPI), last);   // (rows past the end: clamped here, zeroed below)
         const float* bz = a.dz + step * 32 * a.ldz;
         const float* bx = a.x + step * 32 * a.ldx;
         asm volatile("" : "+s"(bz), "+s"(bx));
@@ -308,9 +315,9 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
         xv[0] = lr_ldg4(bx, ((unsigned)rr0 * (unsigned)a.ldx + 4u * l32) * 4u, 0);
         xv[1] = lr_ldg4(bx, ((unsigned)rr1 * (unsigned)a.ldx + 4u * l32) * 4u, 0);
     };
-    f32x4 accw[8];
+    f32x4 accw[XB];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) accw[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < XB; ++b) accw[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f, dxmax = 0.f;
     long step = blockIdx.x;
 #pragma unroll
@@ -318,11 +325,11 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
         if (step + (long)p * gridDim.x < nsteps) load_rows(step + (long)p * gridDim.x, dvs[p], xvs[p]);
     // one step; set = which register set holds its rows (the loop is unrolled PF times: register arrays are not indexed at run time)
     auto body = [&](long step, int buf, f32x4 (&dv)[2], f32x4 (&xv)[2]) {
-        LrBuf& B = sb[buf];
+        Buf& B = sb[buf];
         // ---- this lane's 2 x 4 values of dz and of x as fp16 planes, once for the whole workgroup
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const bool pok = step * 32 + prow + 2 * k < a.M;
+            const bool pok = step * 32 + prow + RPI * k < a.M;
             const f32x4& d = dv[k];
             const f32x4& x = xv[k];
             u32x2 zh, zl, xh, xl;
@@ -334,10 +341,10 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
                 split_f16_plain(pok ? x[2 * c] : 0.f, pok ? x[2 * c + 1] : 0.f, h, l);
                 xh[c] = h, xl[c] = l;
             }
-            *reinterpret_cast<u32x2*>(&B.dz[0][prow + 2 * k][ppos]) = zh;
-            *reinterpret_cast<u32x2*>(&B.dz[1][prow + 2 * k][ppos]) = zl;
-            *reinterpret_cast<u32x2*>(&B.x[0][prow + 2 * k][ppos]) = xh;
-            *reinterpret_cast<u32x2*>(&B.x[1][prow + 2 * k][ppos]) = xl;
+            *reinterpret_cast<u32x2*>(&B.dz[0][prow + RPI * k][ppos]) = zh;
+            *reinterpret_cast<u32x2*>(&B.dz[1][prow + RPI * k][ppos]) = zl;
+            *reinterpret_cast<u32x2*>(&B.x[0][prow + RPI * k][ppos]) = xh;
+            *reinterpret_cast<u32x2*>(&B.x[1][prow + RPI * k][ppos]) = xl;
         }
         // ---- x at this lane's dx positions (the ReLU mask; L2 hits: the rows were loaded one step ago), then the next step's rows: the
         // epilogue's wait for the mask must not include the prefetch (vmcnt retires in order)
@@ -364,7 +371,7 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
         // ---- data GEMM: acc[rb] = 2^11 G (dz W)^T for rows 16 rb .., the wave's 16 in-features
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const f16x8 zh = *reinterpret_cast<const f16x8*>(&B.dz[0][16 * rb + n16][32 * kt + 8 * q4]);
@@ -385,7 +392,7 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
             cs = lr_dot_ones(b0[0], cs), cs = lr_dot_ones(b0[1], cs), cs = lr_dot_ones(b1[0], cs), cs = lr_dot_ones(b1[1], cs);
             bsum += cs;
 #pragma unroll
-            for (int xb = 0; xb < 8; ++xb) {
+            for (int xb = 0; xb < XB; ++xb) {
                 const u32x2 p0 = lr_tr(&B.x[0][r0][16 * xb + c0]), p1 = lr_tr(&B.x[0][16 + r0][16 * xb + c0]);
                 const u32x2 q0 = lr_tr(&B.x[1][r0][16 * xb + c0]), q1 = lr_tr(&B.x[1][16 + r0][16 * xb + c0]);
                 const f16x8 xh = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p1[0], p1[1]});
@@ -423,14 +430,14 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
         }
     }
     // ---- this workgroup's partial sums
-    float* wout = a.wpart + (size_t)blockIdx.x * 128 * 128;
+    float* wout = a.wpart + (size_t)blockIdx.x * WIDTH * WIDTH;
 #pragma unroll
-    for (int xb = 0; xb < 8; ++xb)
+    for (int xb = 0; xb < XB; ++xb)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wout[(size_t)(16 * wave + lr_sw(4 * q4 + i)) * 128 + 16 * xb + lr_sw(n16)] = accw[xb][i] * invG;
+        for (int i = 0; i < 4; ++i) wout[(size_t)(16 * wave + lr_sw(4 * q4 + i)) * WIDTH + 16 * xb + lr_sw(n16)] = accw[xb][i] * invG;
     bsum += __shfl_xor(bsum, 16);
     bsum += __shfl_xor(bsum, 32);
-    if (q4 == 0) a.bpart[(size_t)blockIdx.x * 128 + 16 * wave + lr_sw(n16)] = bsum * invG;
+    if (q4 == 0) a.bpart[(size_t)blockIdx.x * WIDTH + 16 * wave + lr_sw(n16)] = bsum * invG;
     if (a.amax_out) {
 #pragma unroll
         for (int o = 32; o; o >>= 1) dxmax = fmaxf(dxmax, __shfl_xor(dxmax, o));
@@ -440,7 +447,7 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r(const LinBwdArgs a) {
         if (threadIdx.x == 0) {
             float m = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) m = fmaxf(m, gsc[w]);
+            for (int w = 0; w < NW; ++w) m = fmaxf(m, gsc[w]);
             a.amax_out[blockIdx.x] = m;
         }
     }
@@ -461,18 +468,18 @@ static int lb_grid(long M, int per_cu = 1) {
     return (int)(steps < (long)ncu * per_cu ? steps : (long)ncu * per_cu);
 }
 #define LB_AMAX_BLOCKS 256
-// which kernel serves magnet_linear_bwd128_f32: 1 (default) = k_linear_bwd_r (32-row steps, eight waves), 0 = k_linear_bwd<4>
+// which kernel serves magnet_linear_bwd128_f32 / 64: 1 (default) = k_linear_bwd_r (32-row steps, two waves per SIMD), 0 = k_linear_bwd<NT>
 static int g_lb_generation = 1;
 extern "C" int magnet_linear_bwd128_generation(int generation) {
     const int prev = g_lb_generation;
     if (generation == 0 || generation == 1) g_lb_generation = generation;
     return prev;
 }
-static int lb_grid128(long M) {
-    if (g_lb_generation == 0) return lb_grid(M);
-    const int ncu = lb_grid(1L << 40);
-    const long steps = (M + 31) / 32;
-    return (int)(steps < (long)ncu ? steps : (long)ncu);
+static int lb_grid_w(long M, int nt) {                                        // nt = width / 32
+    const int per_cu = nt == 2 ? 2 : 1;                                       // (64-wide: three per CU fit and measured 6 % slower)
+    if (g_lb_generation == 0) return lb_grid(M, per_cu);
+    const long slots = (long)lb_grid(1L << 40) * per_cu, steps = (M + 31) / 32;
+    return (int)(steps < slots ? steps : slots);
 }
 // workspace floats of magnet_linear_bwd{128,64}_f32: per-workgroup partial sums of dW and db, one set of block maxima
 extern "C" int magnet_linear_bwd128_workspace(void) { return lb_grid(1L << 40) * (128 * 128 + 128) + LB_AMAX_BLOCKS; }
@@ -484,7 +491,7 @@ static int launch_linear_bwd(const float* dz, int ldz, const float* x, int ldx, 
     (void)hipGetLastError();
     if (M <= 0) return 0;
     if (ldz < W || ldx < W || lddx < W || (ldz | ldx | lddx) % 4) return -2;
-    const int grid = NT == 4 ? lb_grid128(M) : lb_grid(M, 2);
+    const int grid = lb_grid_w(M, NT);
     LinBwdArgs a;
     a.dz = dz, a.ldz = ldz, a.x = x, a.ldx = ldx, a.wt = reinterpret_cast<const u32x4*>(wt_f16), a.dx = dx, a.lddx = lddx, a.M = M;
     a.mask = mask;
@@ -502,9 +509,8 @@ static int launch_linear_bwd(const float* dz, int ldz, const float* x, int ldx, 
         a.amax_in = own_amax, a.n_amax = nab;
     }
     a.amax_out = amax_out;
-    if (NT == 4 && g_lb_generation == 1)
-        hipLaunchKernelGGL(k_linear_bwd_r<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
-
+    if (g_lb_generation == 1)
+        hipLaunchKernelGGL((k_linear_bwd_r<W, 1>), dim3(grid), dim3(W * 4), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(k_linear_bwd<NT>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     int rc = (int)hipGetLastError();
@@ -527,5 +533,5 @@ extern "C" int magnet_linear_bwd64_f32(const float* dz, int ldz, const float* x,
     return launch_linear_bwd<2>(dz, ldz, x, ldx, wt_f16, M, mask, dx, lddx, dW, db, accumulate, amax_in, n_amax_in, amax_out, workspace,
                                 stream);
 }
-extern "C" int magnet_linear_bwd128_grid(long M) { return lb_grid128(M); }
-extern "C" int magnet_linear_bwd64_grid(long M) { return lb_grid(M, 2); }
+extern "C" int magnet_linear_bwd128_grid(long M) { return lb_grid_w(M, 4); }
+extern "C" int magnet_linear_bwd64_grid(long M) { return lb_grid_w(M, 2); }

@@ -17,9 +17,9 @@ def use(gen):
 
 def run(gen, dz, x, wt, mask, amax_in=None):
     use(gen)
-    M = dz.shape[0]
+    M, Wd = dz.shape
     ws = torch.empty(lib.magnet_linear_bwd128_workspace(), device="cuda")
-    dx, dW, db = torch.full((M, 128), 7.0, device="cuda"), torch.empty(128, 128, device="cuda"), torch.empty(128, device="cuda")
+    dx, dW, db = torch.full((M, Wd), 7.0, device="cuda"), torch.empty(Wd, Wd, device="cuda"), torch.empty(Wd, device="cuda")
     am = ops.linear_bwd128(dz, x, wt, dx, dW, db, ws, mask=mask, amax_in=amax_in)
     return dx, dW, db, am
 
@@ -29,33 +29,36 @@ def rel(a, b):
 
 
 g = torch.Generator(device="cuda").manual_seed(3)
+worst = 0.0
+for WD in (128, 64):
+    W = (torch.randn(WD, WD, device="cuda", generator=g) * 0.1)
+    wt = pack(W.t().contiguous(), None, "fp16x3")[0]
+    for M in (1, 5, 31, 32, 33, 100, 127, 129, 4097, 33000, 218752):
+        for mask in (True, False):
+            for variant in ("plain", "strided", "rows"):
+                dz = torch.randn(M, WD, device="cuda", generator=g) * 1e-7
+                xfull = torch.relu(torch.randn(M, 160, device="cuda", generator=g))
+                x = xfull[:, 16:16 + WD] if variant == "strided" else xfull[:, :WD].contiguous()
+                if variant == "rows":                                   # rows of very different magnitude (late rollout steps ~ 1e-4 of the early ones)
+                    dz = dz * torch.logspace(0, -5, M, device="cuda")[:, None]
+                ref_dx = (dz.double() @ W.double()) * ((x > 0).double() if mask else 1.0)
+                ref_dW, ref_db = dz.double().t() @ x.double(), dz.double().sum(0)
+                out = {}
+                for gen in (0, 1):
+                    dx, dW, db, am = run(gen, dz, x, wt, mask)
+                    e = (rel(dx, ref_dx), rel(dW, ref_dW), rel(db, ref_db))
+                    amax_true = dx.abs().max().item()
+                    am_ok = abs(am[0][:am[1]].max().item() - amax_true) <= 1e-12 + 1e-6 * amax_true
+                    out[gen] = (dx, dW, db, e, am_ok)
+                    # the maxima of one call feed the next: run again with amax_in = a previous layer's maxima of |dz|
+                a0, a1 = out[0], out[1]
+                flag = "" if max(a1[3]) < 2e-6 and a1[4] else "   <-- CHECK"
+                worst = max(worst, *a1[3])
+                print(f"W={WD:3d} M={M:7d} mask={int(mask)} {variant:8s} gen0 dx/dW/db {a0[3][0]:.1e} {a0[3][1]:.1e} {a0[3][2]:.1e} | gen1 {a1[3][0]:.1e} {a1[3][1]:.1e} "
+                      f"{a1[3][2]:.1e} amax_ok {a0[4]} {a1[4]} | mask zeros identical {bool(((a0[0] == 0) == (a1[0] == 0)).all())}{flag}")
+print("worst gen1 error", worst)
 W = (torch.randn(128, 128, device="cuda", generator=g) * 0.1)
 wt = pack(W.t().contiguous(), None, "fp16x3")[0]
-worst = 0.0
-for M in (1, 5, 31, 32, 33, 100, 127, 129, 4097, 33000, 218752):
-    for mask in (True, False):
-        for variant in ("plain", "strided", "rows"):
-            dz = torch.randn(M, 128, device="cuda", generator=g) * 1e-7
-            xfull = torch.relu(torch.randn(M, 160, device="cuda", generator=g))
-            x = xfull[:, 16:144] if variant == "strided" else xfull[:, :128].contiguous()
-            if variant == "rows":                                   # rows of very different magnitude (late rollout steps ~ 1e-4 of the early ones)
-                dz = dz * torch.logspace(0, -5, M, device="cuda")[:, None]
-            ref_dx = (dz.double() @ W.double()) * ((x > 0).double() if mask else 1.0)
-            ref_dW, ref_db = dz.double().t() @ x.double(), dz.double().sum(0)
-            out = {}
-            for gen in (0, 1):
-                dx, dW, db, am = run(gen, dz, x, wt, mask)
-                e = (rel(dx, ref_dx), rel(dW, ref_dW), rel(db, ref_db))
-                amax_true = dx.abs().max().item()
-                am_ok = abs(am[0][:am[1]].max().item() - amax_true) <= 1e-12 + 1e-6 * amax_true
-                out[gen] = (dx, dW, db, e, am_ok)
-                # the maxima of one call feed the next: run again with amax_in = a previous layer's maxima of |dz|
-            a0, a1 = out[0], out[1]
-            flag = "" if max(a1[3]) < 2e-6 and a1[4] else "   <-- CHECK"
-            worst = max(worst, *a1[3])
-            print(f"M={M:7d} mask={int(mask)} {variant:8s} gen0 dx/dW/db {a0[3][0]:.1e} {a0[3][1]:.1e} {a0[3][2]:.1e} | gen1 {a1[3][0]:.1e} {a1[3][1]:.1e} "
-                  f"{a1[3][2]:.1e} amax_ok {a0[4]} {a1[4]} | mask zeros identical {bool(((a0[0] == 0) == (a1[0] == 0)).all())}{flag}")
-print("worst gen1 error", worst)
 # per-row relative error of dx on the 'rows' case (generation 0 scales every row by itself, generation 1 by the launch maximum)
 M = 33000
 dz = torch.randn(M, 128, device="cuda", generator=g) * 1e-7 * torch.logspace(0, -5, M, device="cuda")[:, None]
@@ -85,12 +88,14 @@ for _ in range(20):
 print("gen1 repeat launches that differ:", bad, "of 20")
 # timing (generations 2 / 3 = generation 1 with two / three steps of rows in flight)
 GENS = tuple(int(v) for v in os.environ.get('LB_GENS', '0,1').split(','))
-for M in (2105344, 218752, 18432):
-    dz = torch.randn(M, 128, device="cuda") * 1e-7
-    x = torch.relu(torch.randn(M, 128, device="cuda"))
+for WD, M in ((128, 2105344), (128, 218752), (128, 18432), (64, 2105344), (64, 163840), (64, 40960)):
+    Wt = (torch.randn(WD, WD, device="cuda") * 0.1)
+    wt = pack(Wt.t().contiguous(), None, "fp16x3")[0]
+    dz = torch.randn(M, WD, device="cuda") * 1e-7
+    x = torch.relu(torch.randn(M, WD, device="cuda"))
     ws = torch.empty(lib.magnet_linear_bwd128_workspace(), device="cuda")
-    dx, dW, db = torch.empty(M, 128, device="cuda"), torch.empty(128, 128, device="cuda"), torch.empty(128, device="cuda")
-    line = f"M={M:8d}:"
+    dx, dW, db = torch.empty(M, WD, device="cuda"), torch.empty(WD, WD, device="cuda"), torch.empty(WD, device="cuda")
+    line = f"W={WD:3d} M={M:8d}:"
     for rep in range(3):
         for gen in GENS:
             use(gen)
