@@ -477,10 +477,12 @@ int magnet_mpnn_edge_bwd_f32(const float* A, const float* Bm, const float* dagg,
  * of the call that produced dz - or NULL (one more pass over dz; needs ldz == 128); amax_out: NULL or magnet_linear_bwd128_grid(M)
  * floats.  workspace: magnet_linear_bwd128_workspace() floats. */
 int magnet_linear_bwd128_workspace(void);
-/* Which kernel serves magnet_linear_bwd128_f32: 1 (default) = k_linear_bwd_r (32-row steps, two waves per SIMD, W^T in registers, dz / x
- * split once into fp16 planes in LDS), 0 = k_linear_bwd<4> (128-row steps, one wave per SIMD; kept for same-process A/B runs).  Returns
- * the previous value; any other argument only queries.  magnet_linear_bwd128_grid follows the choice: do not change it between a call
- * that writes amax_out and the call that reads it as amax_in. */
+/* Which kernel serves magnet_linear_bwd128_f32 / magnet_linear_bwd64_f32: 1 (default) = k_linear_bwd_r (32-row steps, two waves per SIMD,
+ * W^T in registers, dz / x split once into fp16 planes in LDS; the 128-wide one with four waves x two feature blocks and two workgroups
+ * per CU from 65 536 rows, eight waves x one block below), 0 = k_linear_bwd<NT> (128-row steps, one wave per SIMD; kept for same-process
+ * A/B runs), 2 / 3 = the two 128-wide shapes of k_linear_bwd_r at every size.  Returns the previous value; any other argument only
+ * queries.  magnet_linear_bwd128_grid / 64_grid follow the choice: do not change it between a call that writes amax_out and the call
+ * that reads it as amax_in. */
 int magnet_linear_bwd128_generation(int generation);
 int magnet_linear_bwd128_grid(long M);
 int magnet_linear_bwd128_f32(const float* dz, int ldz, const float* x, int ldx, const void* wt_f16, long M, int mask, float* dx,

@@ -261,13 +261,17 @@ __device__ __forceinline__ float lr_dot_ones(unsigned w, float acc) {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w), one, acc, false);
 }
 
-// WIDTH 128: eight waves, one workgroup per CU.  WIDTH 64 (MAgNet[CNN]'s MLPs): four waves, two workgroups per CU; rows of 256 bytes, a
-// load instruction reads four of them; LDS row stride 160 B (3.0 cycles per transposed read, conflict-free 16-byte reads).
-// PF: steps of rows in flight ahead of the one being computed (2 and 3 measured: no gain, profiles/r4/linear_bwd_gen1.txt)
-template <int WIDTH, int PF>
-__global__ void __launch_bounds__(WIDTH * 4, WIDTH == 128 ? 1 : 2) k_linear_bwd_r(const LinBwdArgs a) {
-    constexpr int NW = WIDTH / 16, KT = WIDTH / 32, XB = WIDTH / 16, ST = WIDTH == 128 ? LR_ST : 80;
+// NB = blocks of 16 features a wave owns (in-features of the data GEMM = rows of W^T in registers; dz features of the weight gradient).
+// <128, 1>: eight waves, one workgroup per CU.  <128, 2>: four waves, two workgroups per CU (W^T 64 + dW 64 registers per wave; the
+// workgroups drift apart, so one's loads and barrier waits sit under the other's MFMAs; each wave's LDS reads feed twice the MFMAs).
+// <64, 1> (MAgNet[CNN]'s MLPs): four waves, two workgroups per CU; rows of 256 bytes, a load instruction reads four of them; LDS row
+// stride 160 B (3.0 cycles per transposed read, conflict-free 16-byte reads).  More than one step of rows in flight was measured (no
+// gain, profiles/r4/linear_bwd_gen1.txt) and is not kept.
+template <int WIDTH, int NB>
+__global__ void __launch_bounds__(WIDTH * 4 / NB, WIDTH == 128 && NB == 1 ? 1 : 2) k_linear_bwd_r(const LinBwdArgs a) {
+    constexpr int NW = WIDTH / (16 * NB), KT = WIDTH / 32, XB = WIDTH / 16, ST = WIDTH == 128 ? LR_ST : 80;
     constexpr int LPR = WIDTH / 4, RPI = 64 / LPR;                            // lanes per row of a load instruction, rows per instruction
+    constexpr int NLD = 32 / NW / RPI;                                        // load instructions per array, wave and step
     typedef LrBuf<ST> Buf;
     __shared__ __attribute__((aligned(16))) Buf sb[2];
     __shared__ float gsc[NW];
@@ -290,45 +294,50 @@ __global__ void __launch_bounds__(WIDTH * 4, WIDTH == 128 ? 1 : 2) k_linear_bwd_
         invG = ok ? __uint_as_float((eb - 13u) << 23) : 1.0f;
         __syncthreads();
     }
-    // ---- the wave's 16 in-features of W^T as A fragments (lane = in-feature, k group q4: the pack's k slots (kt, q4 >> 1, q4 & 1))
-    f16x8 wh[KT], wlo[KT];
+    // ---- the wave's NB x 16 in-features of W^T as A fragments (lane = in-feature, k group q4: the pack's k slots (kt, q4 >> 1, q4 & 1))
+    f16x8 wh[NB][KT], wlo[NB][KT];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        const int idx = (((kt * KT + (wave >> 1)) * 2 + (q4 >> 1)) * 2) * 64 + 16 * (wave & 1) + n16 + 32 * (q4 & 1);
-        wh[kt] = __builtin_bit_cast(f16x8, scale_plane_2048(a.wt[idx]));
-        wlo[kt] = __builtin_bit_cast(f16x8, a.wt[idx + 64]);
-    }
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int fb = NB * wave + b;                                     // block of 16 features
+            const int idx = (((kt * KT + (fb >> 1)) * 2 + (q4 >> 1)) * 2) * 64 + 16 * (fb & 1) + n16 + 32 * (q4 & 1);
+            wh[b][kt] = __builtin_bit_cast(f16x8, scale_plane_2048(a.wt[idx]));
+            wlo[b][kt] = __builtin_bit_cast(f16x8, a.wt[idx + 64]);
+        }
     const long nsteps = (a.M + 31) / 32;
-    // the two rows of a step this lane loads and splits: prow and prow + RPI, features 4 l32 .. + 3 of each - every load instruction reads
-    // RPI whole rows (2 x 512 bytes / 4 x 256); the four values land at position ppos of the images (see LrBuf)
+    // the rows of a step this lane loads and splits: prow + RPI k, features 4 l32 .. + 3 of each - every load instruction reads RPI whole
+    // rows (2 x 512 bytes / 4 x 256); the four values land at position ppos of the images (see LrBuf)
     const int l32 = lane & (LPR - 1), prow = (32 / NW) * wave + lane / LPR;
     const int ppos = 16 * (l32 >> 2) + 8 * (l32 & 1) + 4 * ((l32 >> 1) & 1);
-    f32x4 dvs[PF][2], xvs[PF][2];
-    auto load_rows = [&](long step, f32x4 (&dv)[2], f32x4 (&xv)[2]) {
+    f32x4 dv[NLD], xv[NLD];
+    auto load_rows = [&](long step) {
         const long last = a.M - 1 - step * 32;
-        const int rr0 = (int)min((long)prow, last), rr1 = (int)min((long)(prow + RPI), last);   // (rows past the end: clamped here, zeroed below)
         const float* bz = a.dz + step * 32 * a.ldz;
         const float* bx = a.x + step * 32 * a.ldx;
         asm volatile("" : "+s"(bz), "+s"(bx));
-        dv[0] = lr_ldg4(bz, ((unsigned)rr0 * (unsigned)a.ldz + 4u * l32) * 4u, 0);
-        dv[1] = lr_ldg4(bz, ((unsigned)rr1 * (unsigned)a.ldz + 4u * l32) * 4u, 0);
-        xv[0] = lr_ldg4(bx, ((unsigned)rr0 * (unsigned)a.ldx + 4u * l32) * 4u, 0);
-        xv[1] = lr_ldg4(bx, ((unsigned)rr1 * (unsigned)a.ldx + 4u * l32) * 4u, 0);
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int rr = (int)min((long)(prow + RPI * k), last);            // (rows past the end: clamped here, zeroed below)
+            dv[k] = lr_ldg4(bz, ((unsigned)rr * (unsigned)a.ldz + 4u * l32) * 4u, 0);
+            xv[k] = lr_ldg4(bx, ((unsigned)rr * (unsigned)a.ldx + 4u * l32) * 4u, 0);
+        }
     };
-    f32x4 accw[XB];
+    f32x4 accw[NB][XB];
 #pragma unroll
-    for (int b = 0; b < XB; ++b) accw[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f, dxmax = 0.f;
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int xb = 0; xb < XB; ++xb) accw[b][xb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[NB], dxmax = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) bsum[b] = 0.f;
     long step = blockIdx.x;
+    if (step < nsteps) load_rows(step);
+    for (int it = 0; step < nsteps; step += gridDim.x, ++it) {
+        Buf& B = sb[it & 1];
+        // ---- this lane's NLD x 4 values of dz and of x as fp16 planes, once for the whole workgroup
 #pragma unroll
-    for (int p = 0; p < PF; ++p)
-        if (step + (long)p * gridDim.x < nsteps) load_rows(step + (long)p * gridDim.x, dvs[p], xvs[p]);
-    // one step; set = which register set holds its rows (the loop is unrolled PF times: register arrays are not indexed at run time)
-    auto body = [&](long step, int buf, f32x4 (&dv)[2], f32x4 (&xv)[2]) {
-        Buf& B = sb[buf];
-        // ---- this lane's 2 x 4 values of dz and of x as fp16 planes, once for the whole workgroup
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < NLD; ++k) {
             const bool pok = step * 32 + prow + RPI * k < a.M;
             const f32x4& d = dv[k];
             const f32x4& x = xv[k];
@@ -348,7 +357,7 @@ __global__ void __launch_bounds__(WIDTH * 4, WIDTH == 128 ? 1 : 2) k_linear_bwd_
         }
         // ---- x at this lane's dx positions (the ReLU mask; L2 hits: the rows were loaded one step ago), then the next step's rows: the
         // epilogue's wait for the mask must not include the prefetch (vmcnt retires in order)
-        f32x4 xm[2];
+        f32x4 xm[NB][2];
         float* const bdx = a.dx + step * 32 * a.lddx;
         unsigned odx[2];
         bool rok[2];
@@ -360,84 +369,100 @@ __global__ void __launch_bounds__(WIDTH * 4, WIDTH == 128 ? 1 : 2) k_linear_bwd_
                 const long row = step * 32 + 16 * rb + n16;
                 rok[rb] = row < a.M;
                 const int rr = (int)min((long)(16 * rb + n16), a.M - 1 - step * 32);
-                odx[rb] = ((unsigned)(16 * rb + n16) * (unsigned)a.lddx + 16u * wave + 4u * q4) * 4u;
-                if (a.mask) xm[rb] = lr_ldg4(bx, ((unsigned)rr * (unsigned)a.ldx + 16u * wave + 4u * q4) * 4u, 0);
+                odx[rb] = ((unsigned)(16 * rb + n16) * (unsigned)a.lddx + 16u * NB * wave + 4u * q4) * 4u;
+                if (a.mask) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+                        xm[b][rb] = lr_ldg4(bx, ((unsigned)rr * (unsigned)a.ldx + 16u * NB * wave + 4u * q4) * 4u, 64 * b);
+                }
             }
         }
         asm volatile("" ::: "memory");
-        if (step + (long)PF * gridDim.x < nsteps) load_rows(step + (long)PF * gridDim.x, dv, xv);
+        if (step + gridDim.x < nsteps) load_rows(step + gridDim.x);
         asm volatile("" ::: "memory");
         wg_barrier();                                                         // the step's planes are in LDS (double buffered: the only barrier)
-        // ---- data GEMM: acc[rb] = 2^11 G (dz W)^T for rows 16 rb .., the wave's 16 in-features
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        // ---- data GEMM: acc[b][rb] = 2^11 G (dz W)^T for rows 16 rb .., in-features 16 (NB wave + b) ..
+        f32x4 acc[NB][2];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b][0] = acc[b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const f16x8 zh = *reinterpret_cast<const f16x8*>(&B.dz[0][16 * rb + n16][32 * kt + 8 * q4]);
                 const f16x8 zl = *reinterpret_cast<const f16x8*>(&B.dz[1][16 * rb + n16][32 * kt + 8 * q4]);
-                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[kt], zh, acc[rb], 0, 0, 0);
-                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kt], zl, acc[rb], 0, 0, 0);
-                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kt], zh, acc[rb], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b][rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[b][kt], zh, acc[b][rb], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b][rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[b][kt], zl, acc[b][rb], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b][rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[b][kt], zh, acc[b][rb], 0, 0, 0);
             }
         // ---- dW slab += (G dz)^T x over the step's 32 rows (k order: lane group q4 takes rows 4 q4 .. + 3 and 16 + 4 q4 .. + 3), db
         {
             const int r0 = 4 * q4 + (n16 >> 2), c0 = 4 * (n16 & 3);
-            const u32x2 a0 = lr_tr(&B.dz[0][r0][16 * wave + c0]), a1 = lr_tr(&B.dz[0][16 + r0][16 * wave + c0]);
-            const u32x2 b0 = lr_tr(&B.dz[1][r0][16 * wave + c0]), b1 = lr_tr(&B.dz[1][16 + r0][16 * wave + c0]);
-            const f16x8 ah = __builtin_bit_cast(f16x8, u32x4{a0[0], a0[1], a1[0], a1[1]});
-            const f16x8 al = __builtin_bit_cast(f16x8, u32x4{b0[0], b0[1], b1[0], b1[1]});
-            float cs = lr_dot_ones(a0[0], 0.f);
-            cs = lr_dot_ones(a0[1], cs), cs = lr_dot_ones(a1[0], cs), cs = lr_dot_ones(a1[1], cs);
-            cs = lr_dot_ones(b0[0], cs), cs = lr_dot_ones(b0[1], cs), cs = lr_dot_ones(b1[0], cs), cs = lr_dot_ones(b1[1], cs);
-            bsum += cs;
+            f16x8 ah[NB], al[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int f = 16 * (NB * wave + b) + c0;
+                const u32x2 a0 = lr_tr(&B.dz[0][r0][f]), a1 = lr_tr(&B.dz[0][16 + r0][f]);
+                const u32x2 b0 = lr_tr(&B.dz[1][r0][f]), b1 = lr_tr(&B.dz[1][16 + r0][f]);
+                ah[b] = __builtin_bit_cast(f16x8, u32x4{a0[0], a0[1], a1[0], a1[1]});
+                al[b] = __builtin_bit_cast(f16x8, u32x4{b0[0], b0[1], b1[0], b1[1]});
+                float cs = lr_dot_ones(a0[0], 0.f);
+                cs = lr_dot_ones(a0[1], cs), cs = lr_dot_ones(a1[0], cs), cs = lr_dot_ones(a1[1], cs);
+                cs = lr_dot_ones(b0[0], cs), cs = lr_dot_ones(b0[1], cs), cs = lr_dot_ones(b1[0], cs), cs = lr_dot_ones(b1[1], cs);
+                bsum[b] += cs;
+            }
 #pragma unroll
             for (int xb = 0; xb < XB; ++xb) {
                 const u32x2 p0 = lr_tr(&B.x[0][r0][16 * xb + c0]), p1 = lr_tr(&B.x[0][16 + r0][16 * xb + c0]);
                 const u32x2 q0 = lr_tr(&B.x[1][r0][16 * xb + c0]), q1 = lr_tr(&B.x[1][16 + r0][16 * xb + c0]);
                 const f16x8 xh = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p1[0], p1[1]});
                 const f16x8 xl = __builtin_bit_cast(f16x8, u32x4{q0[0], q0[1], q1[0], q1[1]});
-                accw[xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh, accw[xb], 0, 0, 0);
-                accw[xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl, accw[xb], 0, 0, 0);
-                accw[xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh, accw[xb], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) accw[b][xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[b], xh, accw[b][xb], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) accw[b][xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], xl, accw[b][xb], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) accw[b][xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], xh, accw[b][xb], 0, 0, 0);
             }
         }
-        // ---- dx = (x > 0) * (dz W): C/D row 4 q4 + i = in-feature 16 wave + 4 q4 + i, column n16 = row 16 rb + n16
+        // ---- dx = (x > 0) * (dz W): C/D row 4 q4 + i = in-feature 16 (NB wave + b) + 4 q4 + i, column n16 = row 16 rb + n16
         {
             float* bo = bdx;
             asm volatile("" : "+s"(bo));
             const float sc = (1.0f / 2048.0f) * invG;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                f32x4 t;
+            for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = acc[rb][i] * sc;
-                    if (a.mask) v = xm[rb][i] > 0.f ? v : 0.f;
-                    t[i] = v;
-                    dxmax = fmaxf(dxmax, fabsf(v));
+                for (int b = 0; b < NB; ++b) {
+                    f32x4 t;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[b][rb][i] * sc;
+                        if (a.mask) v = xm[b][rb][i] > 0.f ? v : 0.f;
+                        t[i] = v;
+                        dxmax = fmaxf(dxmax, fabsf(v));
+                    }
+                    if (rok[rb]) lr_stg4(bo, odx[rb], 64 * b, t);
                 }
-                if (rok[rb]) lr_stg4(bo, odx[rb], 0, t);
-            }
-        }
-    };
-    for (int it = 0; step < nsteps; it += PF) {
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            if (step >= nsteps) break;
-            body(step, (it + p) & 1, dvs[p], xvs[p]);
-            step += gridDim.x;
         }
     }
     // ---- this workgroup's partial sums
     float* wout = a.wpart + (size_t)blockIdx.x * WIDTH * WIDTH;
 #pragma unroll
-    for (int xb = 0; xb < XB; ++xb)
+    for (int b = 0; b < NB; ++b) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wout[(size_t)(16 * wave + lr_sw(4 * q4 + i)) * WIDTH + 16 * xb + lr_sw(n16)] = accw[xb][i] * invG;
-    bsum += __shfl_xor(bsum, 16);
-    bsum += __shfl_xor(bsum, 32);
-    if (q4 == 0) a.bpart[(size_t)blockIdx.x * WIDTH + 16 * wave + lr_sw(n16)] = bsum * invG;
+        for (int xb = 0; xb < XB; ++xb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                wout[(size_t)(16 * (NB * wave + b) + lr_sw(4 * q4 + i)) * WIDTH + 16 * xb + lr_sw(n16)] = accw[b][xb][i] * invG;
+        float bs = bsum[b];
+        bs += __shfl_xor(bs, 16);
+        bs += __shfl_xor(bs, 32);
+        if (q4 == 0) a.bpart[(size_t)blockIdx.x * WIDTH + 16 * (NB * wave + b) + lr_sw(n16)] = bs * invG;
+    }
     if (a.amax_out) {
 #pragma unroll
         for (int o = 32; o; o >>= 1) dxmax = fmaxf(dxmax, __shfl_xor(dxmax, o));
@@ -468,21 +493,25 @@ static int lb_grid(long M, int per_cu = 1) {
     return (int)(steps < (long)ncu * per_cu ? steps : (long)ncu * per_cu);
 }
 #define LB_AMAX_BLOCKS 256
-// which kernel serves magnet_linear_bwd128_f32 / 64: 1 (default) = k_linear_bwd_r (32-row steps, two waves per SIMD), 0 = k_linear_bwd<NT>
+// which kernel serves magnet_linear_bwd128_f32 / 64: 1 (default) = k_linear_bwd_r (32-row steps, two waves per SIMD; 128-wide: <128, 2> from
+// 65 536 rows, <128, 1> below), 0 = k_linear_bwd<NT>; 2 / 3 = <128, 2> / <128, 1> at every size (A/B runs)
 static int g_lb_generation = 1;
 extern "C" int magnet_linear_bwd128_generation(int generation) {
     const int prev = g_lb_generation;
-    if (generation == 0 || generation == 1) g_lb_generation = generation;
+    if (generation >= 0 && generation <= 3) g_lb_generation = generation;
     return prev;
 }
+// 128-wide: four waves with two feature blocks each, two workgroups per CU (11 % faster at 2.1 M rows, 5 % at 218 k) - but twice the
+// partial sums to write and reduce, and a launch of a few hundred steps leaves them one step each (18 k rows: 22.9 against 17.2 us)
+static bool lb_two_per_cu(long M) { return g_lb_generation == 2 || (g_lb_generation == 1 && M >= 65536); }
 static int lb_grid_w(long M, int nt) {                                        // nt = width / 32
-    const int per_cu = nt == 2 ? 2 : 1;                                       // (64-wide: three per CU fit and measured 6 % slower)
+    const int per_cu = nt == 2 || lb_two_per_cu(M) ? 2 : 1;                   // (64-wide: three per CU fit and measured 6 % slower)
     if (g_lb_generation == 0) return lb_grid(M, per_cu);
     const long slots = (long)lb_grid(1L << 40) * per_cu, steps = (M + 31) / 32;
     return (int)(steps < slots ? steps : slots);
 }
 // workspace floats of magnet_linear_bwd{128,64}_f32: per-workgroup partial sums of dW and db, one set of block maxima
-extern "C" int magnet_linear_bwd128_workspace(void) { return lb_grid(1L << 40) * (128 * 128 + 128) + LB_AMAX_BLOCKS; }
+extern "C" int magnet_linear_bwd128_workspace(void) { return 2 * lb_grid(1L << 40) * (128 * 128 + 128) + LB_AMAX_BLOCKS; }   // (two workgroups per CU)
 template <int NT>
 static int launch_linear_bwd(const float* dz, int ldz, const float* x, int ldx, const void* wt_f16, long M, int mask, float* dx, int lddx,
                              float* dW, float* db, int accumulate, const float* amax_in, int n_amax_in, float* amax_out,
@@ -509,7 +538,9 @@ static int launch_linear_bwd(const float* dz, int ldz, const float* x, int ldx, 
         a.amax_in = own_amax, a.n_amax = nab;
     }
     a.amax_out = amax_out;
-    if (g_lb_generation == 1)
+    if (NT == 4 && lb_two_per_cu(M))
+        hipLaunchKernelGGL((k_linear_bwd_r<128, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else if (g_lb_generation >= 1)
         hipLaunchKernelGGL((k_linear_bwd_r<W, 1>), dim3(grid), dim3(W * 4), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(k_linear_bwd<NT>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

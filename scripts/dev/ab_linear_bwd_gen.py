@@ -8,6 +8,7 @@ from magnet_amd import _lib as L, ops
 from magnet_amd.packing import pack
 
 lib = L.lib()
+NEW = int(os.environ.get('LB_NEW', '1'))        # the generation checked against 0 (2 = <128, 2>: four waves, two workgroups per CU)
 
 
 def use(gen):
@@ -44,14 +45,14 @@ for WD in (128, 64):
                 ref_dx = (dz.double() @ W.double()) * ((x > 0).double() if mask else 1.0)
                 ref_dW, ref_db = dz.double().t() @ x.double(), dz.double().sum(0)
                 out = {}
-                for gen in (0, 1):
+                for gen in (0, NEW):
                     dx, dW, db, am = run(gen, dz, x, wt, mask)
                     e = (rel(dx, ref_dx), rel(dW, ref_dW), rel(db, ref_db))
                     amax_true = dx.abs().max().item()
                     am_ok = abs(am[0][:am[1]].max().item() - amax_true) <= 1e-12 + 1e-6 * amax_true
                     out[gen] = (dx, dW, db, e, am_ok)
                     # the maxima of one call feed the next: run again with amax_in = a previous layer's maxima of |dz|
-                a0, a1 = out[0], out[1]
+                a0, a1 = out[0], out[NEW]
                 flag = "" if max(a1[3]) < 2e-6 and a1[4] else "   <-- CHECK"
                 worst = max(worst, *a1[3])
                 print(f"W={WD:3d} M={M:7d} mask={int(mask)} {variant:8s} gen0 dx/dW/db {a0[3][0]:.1e} {a0[3][1]:.1e} {a0[3][2]:.1e} | gen1 {a1[3][0]:.1e} {a1[3][1]:.1e} "
@@ -64,12 +65,12 @@ M = 33000
 dz = torch.randn(M, 128, device="cuda", generator=g) * 1e-7 * torch.logspace(0, -5, M, device="cuda")[:, None]
 x = torch.relu(torch.randn(M, 128, device="cuda", generator=g))
 ref = dz.double() @ W.double()
-for gen in (0, 1):
+for gen in (0, NEW):
     dx = run(gen, dz, x, wt, False)[0]
     rr = (dx.double() - ref).norm(dim=1) / ref.norm(dim=1)
     print(f"gen{gen}: per-row relative error of dx: max {rr.max().item():.2e} at row {rr.argmax().item()}, median {rr.median().item():.2e}, rows 30000+: {rr[30000:].max().item():.2e}")
 # chained amax: layer 2's amax_in = layer 1's amax_out
-for gen in (0, 1):
+for gen in (0, NEW):
     dz = torch.randn(5000, 128, device="cuda", generator=g) * 1e-6
     x = torch.relu(torch.randn(5000, 128, device="cuda", generator=g))
     dx1, _, _, am = run(gen, dz, x, wt, True)
@@ -77,13 +78,13 @@ for gen in (0, 1):
     ref = ((dx1.double() @ W.double()) * (x > 0).double())
     print(f"gen{gen}: chained amax_in: dx {rel(dx2, ref):.1e} dW {rel(dW2, dx1.double().t() @ x.double()):.1e}")
 # determinism
-use(1)
+use(NEW)
 dz = torch.randn(100000, 128, device="cuda", generator=g) * 1e-7
 x = torch.relu(torch.randn(100000, 128, device="cuda", generator=g))
-a = run(1, dz, x, wt, True)
+a = run(NEW, dz, x, wt, True)
 bad = 0
 for _ in range(20):
-    b = run(1, dz, x, wt, True)
+    b = run(NEW, dz, x, wt, True)
     bad += int(not (torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])))
 print("gen1 repeat launches that differ:", bad, "of 20")
 # timing (generations 2 / 3 = generation 1 with two / three steps of rows in flight)
