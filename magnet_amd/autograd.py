@@ -396,6 +396,7 @@ class _Mlp(torch.autograd.Function):
                 dz, ln_amax = d_rows, None
             # ---- walk the Linears back
             need_dx0 = any(ctx.needs_input_grad[1 + i] for i in range(m.n_src))
+            direct = {}                                                       # source -> its gradient, written by the data GEMM itself
             ws = ops.wgrad_workspace(M, dev)
             nblk_w = min(768, (M + 31) // 32)
             dX0 = None
@@ -454,7 +455,49 @@ class _Mlp(torch.autograd.Function):
                 # (l > 0: the launch also leaves the block maxima of what it stores - the layer below, if it takes the one-kernel path,
                 # needs them for its power-of-two scale and would otherwise make a pass of its own over dX)
                 mx = torch.zeros(256, device=dev, dtype=torch.float32) if l > 0 and M >= _FUSED_LAYER_ROWS and tpacks_emit_amax else None
-                for (c0, w, G) in col_groups:
+                data_groups = col_groups
+                if l == 0:                                                      # blocks the GEMM can write straight into a source's gradient: own launches
+                    data_groups = []
+                    for (c0, w, G) in col_groups:
+                        hits = [g for g in range(G) if _dense_source_of_block(m, srcs, ctx, M, c0 + g * w, w, factored) is not None]
+                        g = 0
+                        while g < G:
+                            g1 = g + 1
+                            while g not in hits and g1 < G and g1 not in hits:
+                                g1 += 1
+                            data_groups.append((c0 + g * w, w, g1 - g))
+                            g = g1
+                for (c0, w, G) in data_groups:
+                    hit = _dense_source_of_block(m, srcs, ctx, M, c0, w, factored) if (l == 0 and G == 1) else None
+                    if hit is not None:
+                        # a source that enters as ONE dense full-width run covering exactly this column block (MAgNet's edge / node
+                        # latents): its gradient is written by the GEMM itself (a power-of-two Term scale folded into the transposed
+                        # pack), with what has to be added to it as the epilogue's residual:
+                        #  * dy, when the same tensor is the chain's residual (x' = x + MLP([agg | x]));
+                        #  * the running sum of a `grad_chain` (e_0 feeds every hop of the processor scaled by 2^k: the hops' backward
+                        #    calls run in reverse order, each adds its block to the sum and only the last hands it to autograd).
+                        # Before: the block went to dX0, a (scaled) column copy moved it out, and torch added the pieces - five passes
+                        # over an [E, 128] array per hop (7 % of a C5 training step)
+                        si, sc = hit
+                        g = torch.empty(srcs[si].shape, device=dev, dtype=torch.float32)
+                        g2 = g.view(-1, g.shape[-1])
+                        res_t = tensors[m.n_src + m.n_par] if m.has_res else None
+                        add, chain = None, None
+                        if (d_res is not None and res_t is not None and res_t.data_ptr() == srcs[si].data_ptr() and res_t.shape == srcs[si].shape
+                                and res_t.stride() == srcs[si].stride() and tuple(dy.shape) == tuple(g2.shape)):
+                            add, d_res = dy, None                              # (autograd takes None as zero: the sum is in g)
+                        elif m.grad_chain is not None and m.grad_chain[0].data_ptr() == srcs[si].data_ptr() and m.grad_chain[0].shape == srcs[si].shape:
+                            chain = m.grad_chain
+                            add = chain[1].get("g")
+                        ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), [_tpack(m, pk, l, c0, w, W, Np, Kp, scale=sc)], nl=1, ht=w // 32, ot=w // 32,
+                                act=ops.ACT_NONE, colgroups=1, y=g2, ldy=g2.stride(0), ncols=w,
+                                **(dict(epi=ops.EPI_STORE_RES, res=add.view(-1, add.shape[-1])) if add is not None else {}))
+                        direct[si] = g
+                        if chain is not None:
+                            chain[1]["g"] = g
+                            if not chain[2]:
+                                direct[si] = None                              # (not the last hop of the chain: the sum travels on)
+                        continue
                     tps = [_tpack(m, pk, l, c0 + g * w, w, W, Np, Kp) for g in range(G)]
                     if l > 0:      # ... with the ReLU mask of the layer below as the epilogue: dz_{l-1} = (X[l] > 0) ? dX : 0
                         ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), tps, nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE, colgroups=G,
@@ -480,7 +523,9 @@ class _Mlp(torch.autograd.Function):
                                 and rs[0][6] == srcs[si].shape[-1] and not ((rs[0][6] | srcs[si].shape[-1]) & 3)
                                 and srcs[si].reshape(-1, srcs[si].shape[-1]).shape[0] == M and (factored is None or not factored[rs[0][5]])}
                 for si, s in enumerate(srcs):
-                    if ctx.needs_input_grad[1 + si]:
+                    if si in direct:
+                        grads_src[si] = direct[si]                             # (None: a grad_chain's sum travels on to the next call)
+                    elif ctx.needs_input_grad[1 + si]:
                         if factored is not None and grads_src_f[si] is not None:
                             grads_src[si] = grads_src_f[si]
                         else:
@@ -488,7 +533,7 @@ class _Mlp(torch.autograd.Function):
                 pending = {}                 # (source, column, width, scale) -> gathered runs that can share launches (the taps of a convolution)
                 for (si, col, idx, scale, rdiv, kt0, width) in m.runs:
                     g = grads_src[si]
-                    if g is None or (factored is not None and factored[kt0]):      # (done at source granularity above)
+                    if g is None or si in direct or (factored is not None and factored[kt0]):   # (done at source granularity / by the GEMM above)
                         continue
                     g2 = g.view(-1, g.shape[-1])
                     if idx is None and rdiv == 1 and (scale == 1.0 or not ((width | col | g2.stride(0)) & 3)):
@@ -514,7 +559,36 @@ class _Mlp(torch.autograd.Function):
                             continue
                         for i0 in range(0, len(runs), _SEG_RUNS):
                             _segment_sum_cols_runs(dX0, runs[i0:i0 + _SEG_RUNS], c0, g2.shape[0], w, scale, g2, col + c0)
+            # (a grad_chain whose last call did not take the direct path above: hand the running sum over all the same)
+            if m.grad_chain is not None and m.grad_chain[2] and m.grad_chain[1].get("g") is not None:
+                for si, s_ in enumerate(srcs):
+                    if si not in direct and s_.data_ptr() == m.grad_chain[0].data_ptr() and s_.shape == m.grad_chain[0].shape:
+                        acc = m.grad_chain[1].pop("g")
+                        grads_src[si] = acc if grads_src[si] is None else grads_src[si] + acc
         return (None, *grads_src, *grads_par, *([d_res] if m.has_res else []))
+
+
+def _dense_source_of_block(m, srcs, ctx, M, c0, w, factored):
+    """(source, scale) when the column block [c0, c0 + w) of the first Linear's input gradient IS that source's gradient - it enters the
+    chain as one dense full-width run at exactly these columns, scaled by a power of two at most (folded into the transposed pack) -
+    so that the data GEMM can write the gradient itself; else None"""
+    hit = None
+    for r_ in m.runs:
+        kt0, width = r_[5], r_[6]
+        if kt0 * 32 < c0 + w and c0 < kt0 * 32 + width:                       # a run that overlaps the block
+            if hit is not None:
+                return None
+            hit = r_
+    if hit is None:
+        return None
+    si, col, idx, scale, rdiv, kt0, width = hit
+    s = srcs[si]
+    pow2 = scale > 0 and float(scale) == 2.0 ** round(__import__("math").log2(scale))
+    ok = (idx is None and rdiv == 1 and (scale == 1.0 or (pow2 and m.col_map is None)) and col == 0 and kt0 * 32 == c0
+          and width == w == s.shape[-1] and not (w & 31)
+          and ctx.needs_input_grad[1 + si] and sum(1 for q in m.runs if q[0] == si) == 1
+          and s.reshape(-1, s.shape[-1]).shape[0] == M and M > 0 and (factored is None or not factored[kt0]))
+    return (si, float(scale)) if ok else None
 
 
 _FUSED_LAYER_ROWS = 4096          # below this the persistent one-workgroup-per-CU kernel leaves most of the chip idle
@@ -546,14 +620,14 @@ def _tpack_recorder(pk, W, cache, key):
     return None, ("gen", gen, key)
 
 
-def _tpack(m, pk, l, c0, w, W, Np, Kp):
+def _tpack(m, pk, l, c0, w, W, Np, Kp, scale=1.0):
     """packed transpose of the padded weight block Wp[:, c0:c0+w] as a Linear [w outputs, Np inputs] (cached on pk; the pack of a
     step's weights lives as long as that step's ``pk``).  Wp is never materialised: the device packer reads W through its strides,
     W.t() is a view, and the placement of W's columns inside the padded first-layer input (col_map / first_cols) becomes the
     packer's row map."""
     from .packing import pack_device, recording, source_map
     cache = pk.__dict__.setdefault("_tpacks", {})
-    rec, key = _tpack_recorder(pk, W, cache, (l, c0, w))
+    rec, key = _tpack_recorder(pk, W, cache, (l, c0, w) if scale == 1.0 else (l, c0, w, float(scale)))
     if key not in cache:
         n, k = W.shape
         rows = None                                            # padded column c0 + r of Wp -> source column of W (identity: r < k)
@@ -566,6 +640,10 @@ def _tpack(m, pk, l, c0, w, W, Np, Kp):
         else:
             Wt = W.detach().t()[c0:c0 + w] if c0 < k else W.detach().t()[:0]
         with recording(rec):
+            if scale != 1.0:                                  # (a Term's power-of-two scale folded into the block: exact; refreshed on a pack replay)
+                from .packing import derived
+                assert rows is None
+                Wt = derived(lambda: (W.detach().t()[c0:c0 + w] * float(scale)).contiguous())
             cache[key] = pack_device(Wt, None, BWD_GEMM, w, Np, row_src=rows)
     return cache[key]
 
@@ -656,10 +734,13 @@ def conv(src, taps, taps_rev, pk, W2, bias, relu=False, res=None):
     return _Conv.apply(meta, ops._f32(src, "conv source"), W2, bias, res)
 
 
-def mlp(M, groups, pk, params, *, epi=ops.EPI_STORE, res=None, csr=None, out_rows=None, first_cols=None, final_relu=False):
+def mlp(M, groups, pk, params, *, epi=ops.EPI_STORE, res=None, csr=None, out_rows=None, first_cols=None, final_relu=False, grad_chain=None):
     """Differentiable fused MLP.  ``groups``: the arguments of ``ops.ktiles`` (Terms or (Term, Term) pairs); ``pk``: the
     packed namespace of the chain (layers, ln, ht, ot, out_dim, col_map); ``params``: [W0, b0, ..., (ln.weight, ln.bias)]
-    the torch parameters behind ``pk``.  Returns a fresh [out_rows, out_dim] tensor attached to the autograd graph."""
+    the torch parameters behind ``pk``.  Returns a fresh [out_rows, out_dim] tensor attached to the autograd graph.
+    ``grad_chain`` = (tensor, holder dict, last): ``tensor`` is a dense source of several mlp calls whose backward calls run one after the
+    other (the processor's hops); each adds its share of d(tensor) to the sum kept in ``holder`` and only the call with ``last`` (the one
+    whose backward runs last = the first hop) returns it - instead of one gradient per call and torch adding them up."""
     srcs, tiles, runs = [], [], []
     ids = {}
 
@@ -683,7 +764,7 @@ def mlp(M, groups, pk, params, *, epi=ops.EPI_STORE, res=None, csr=None, out_row
         M=int(M), tiles=tiles, runs=runs, pk=pk, epi=epi, n_src=len(srcs), n_par=len(params), has_res=res is not None,
         tgt=csr.tgt if csr is not None else None, rowptr=csr.rowptr if csr is not None else None,
         out_rows=int(out_rows if out_rows is not None else M), first_cols=first_cols, col_map=getattr(pk, "col_map", None),
-        inv_cache={}, final_relu=bool(final_relu))
+        inv_cache={}, final_relu=bool(final_relu), grad_chain=grad_chain)
     assert not (final_relu and (pk.ln is not None or epi != ops.EPI_STORE))
     srcs = [ops._f32(s, "mlp source") for s in srcs]
     extra = [ops._f32(res, "residual")] if res is not None else []

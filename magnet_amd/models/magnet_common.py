@@ -354,9 +354,10 @@ class MagnetBase(LightningModule):
         T_ = ops.Term
         x = AG.mlp(N, [T_(nf, ldn)], pk.node, pk.node.params)
         e0 = AG.mlp(E, [(T_(nf, ldn, idx=csr.src, scale=1.0), T_(nf, ldn, idx=csr.tgt, scale=-1.0))], pk.edge, pk.edge.params)
+        e0_grad = {}                    # d(e0): every hop's backward adds its share to one running sum (AG.mlp: grad_chain), hop 0 hands it over
         for k, hop in enumerate(pk.hops):
             agg = AG.mlp(E, [T_(x, D, idx=csr.tgt), T_(x, D, idx=csr.src), T_(e0, D, scale=float(2 ** k))], hop.edge,
-                         hop.edge.params, epi=ops.EPI_SEGMEAN, csr=csr, out_rows=N)
+                         hop.edge.params, epi=ops.EPI_SEGMEAN, csr=csr, out_rows=N, grad_chain=(e0, e0_grad, k == 0))
             x = AG.mlp(N, [T_(agg, D), T_(x, D)], hop.node, hop.node.params, epi=ops.EPI_STORE_RES, res=x)
         return x
 
