@@ -573,13 +573,14 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
             return loss
 
         first = float(train_step().detach())
-        barrier()
+        train_step()        # (second warm-up step: the caching allocator still grows its pool in step 1 - 0 to 90 ms of hipMalloc at 205 GiB,
+        barrier()           #  profiles/r4/steps_timeline_c5.txt - a training run does the steady-state step thousands of times)
         t0 = time.perf_counter()
         for _ in range(train_steps):
             last = train_step()
         barrier()
         t_el = max_over_ranks(time.perf_counter() - t0, dev)
-        train = {"ms_per_step": round(t_el / train_steps * 1e3, 3), "steps": train_steps, "warmup": 1,
+        train = {"ms_per_step": round(t_el / train_steps * 1e3, 3), "steps": train_steps, "warmup": 2,
                  "value": world * B * nodes * pred_steps * train_steps / t_el, "unit": "mesh-node-updates/s",
                  "what": "rollout through autograd Functions (HIP forward + backward kernels; hidden Linears walked back in one kernel, first Linear at source-row granularity, tape kept in HBM when it fits) + one gradient all-reduce + fused Adam",
                  "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],
@@ -947,6 +948,7 @@ def main():
             return loss
 
         first = float(train_step().detach())
+        train_step()        # (second warm-up step, as in bench_magnet)
         barrier()
         ar_events.clear()
         t0 = time.perf_counter()
@@ -958,7 +960,7 @@ def main():
         # DDP invariant: identical parameters on every rank after the steps (same init, same averaged gradient, same Adam)
         psum = float(sum(p_.detach().double().abs().sum() for p_ in tmodel.parameters()))
         dist_info["param_abs_sum_by_rank_after_training"] = gather_f64(psum)
-        train = {"ms_per_step": round(t_el / args.train_steps * 1e3, 3), "steps": args.train_steps, "warmup": 1,
+        train = {"ms_per_step": round(t_el / args.train_steps * 1e3, 3), "steps": args.train_steps, "warmup": 2,
                  "value": world * B * W * W * pred_steps * args.train_steps / t_el, "unit": "mesh-node-updates/s",
                  "what": "free-running rollout with tape + HIP backward + one flat RCCL gradient all-reduce + fused Adam",
                  "allreduce_ms": round(sum(s_.elapsed_time(e_) for s_, e_ in ar_events) / len(ar_events), 4),

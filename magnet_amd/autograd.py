@@ -31,6 +31,8 @@ from . import ops
 from .packing import pack, pad_to
 
 BWD_GEMM = "bf16x6"
+# MAGNET_DIRECT_SRC_GRAD=0 (development A/B): dense-source gradients through dX0 + column copies + torch adds again
+DIRECT_SRC_GRAD = __import__("os").environ.get("MAGNET_DIRECT_SRC_GRAD", "1") != "0"
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -459,7 +461,7 @@ class _Mlp(torch.autograd.Function):
                 if l == 0:                                                      # blocks the GEMM can write straight into a source's gradient: own launches
                     data_groups = []
                     for (c0, w, G) in col_groups:
-                        hits = [g for g in range(G) if _dense_source_of_block(m, srcs, ctx, M, c0 + g * w, w, factored) is not None]
+                        hits = [g for g in range(G) if DIRECT_SRC_GRAD and _dense_source_of_block(m, srcs, ctx, M, c0 + g * w, w, factored) is not None]
                         g = 0
                         while g < G:
                             g1 = g + 1
@@ -468,7 +470,7 @@ class _Mlp(torch.autograd.Function):
                             data_groups.append((c0 + g * w, w, g1 - g))
                             g = g1
                 for (c0, w, G) in data_groups:
-                    hit = _dense_source_of_block(m, srcs, ctx, M, c0, w, factored) if (l == 0 and G == 1) else None
+                    hit = _dense_source_of_block(m, srcs, ctx, M, c0, w, factored) if (l == 0 and G == 1 and DIRECT_SRC_GRAD) else None
                     if hit is not None:
                         # a source that enters as ONE dense full-width run covering exactly this column block (MAgNet's edge / node
                         # latents): its gradient is written by the GEMM itself (a power-of-two Term scale folded into the transposed
