@@ -561,7 +561,10 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
     train = None
     if train_steps > 0:
         from magnet_amd.sharding import allreduce_gradients
-        tmodel = FACTORY[name](types.SimpleNamespace(**hp)).to(dev).train()
+        # lr = 1e-6 (as in the ref_shapes legs): a few Adam steps at the configs' 1e-3 on RANDOM fields grow EDSR's feature maps past 65504
+        #  and the step would be timed in the bf16x6 fallback - which then, being process-wide, would also be what every
+        # later leg of this line runs in.  The work of a step does not depend on the learning rate; `widened_to_bf16x6` says what ran.
+        tmodel = FACTORY[name](types.SimpleNamespace(**dict(hp, lr=1e-6))).to(dev).train()
         opt = tmodel.configure_optimizers()["optimizer"]
 
         def train_step():
@@ -585,8 +588,9 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
                  "what": "rollout through autograd Functions (HIP forward + backward kernels; hidden Linears walked back in one kernel, first Linear at source-row granularity, tape kept in HBM when it fits) + one gradient all-reduce + fused Adam",
                  "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],
                  "widened_to_bf16x6": __import__("magnet_amd.packing", fromlist=["wide"]).wide(),
-                 "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
+                 "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2), "lr": 1e-6}
         del tmodel, opt, last, train_step
+        __import__("magnet_amd.packing", fromlist=["narrow"]).narrow()   # (a leg that left the fp16 range must not hand the NEXT one the wider split)
     del model, batch
     # the autograd graph of the last training step (and the ~200 GB of backward tape its Functions kept) sits in
     # reference cycles until the cyclic collector runs; the next leg decides how much tape IT may keep from what is allocated now
@@ -969,6 +973,7 @@ def main():
                  "widened_to_bf16x6": __import__("magnet_amd.packing", fromlist=["wide"]).wide(),
                  "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
         del tmodel, opt, last, train_step
+        __import__("magnet_amd.packing", fromlist=["narrow"]).narrow()   # (a leg that left the fp16 range must not hand the NEXT one the wider split)
         import gc
         gc.collect()
         torch.cuda.empty_cache()

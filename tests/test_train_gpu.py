@@ -772,3 +772,80 @@ def test_rccl_process_group_runs_the_training_collectives_on_one_rank():
     if "RCCL_INIT_FAILED" in r.stdout:
         pytest.skip("no RCCL communicator on this box: " + r.stdout.strip()[-300:])
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("W", [128, 64])
+def test_linear_bwd_generations_agree_with_fp64(W):
+    """magnet_linear_bwd128_f32 / 64 (csrc/linear_bwd.hip): k_linear_bwd_r in its shapes (generation 1 = the size rule, 2 / 3 = the two
+    128-wide shapes forced) and k_linear_bwd<NT> (generation 0) against fp64 on ragged row counts, strided x, both mask settings; block
+    maxima exact; repeat launches bit-identical"""
+    from magnet_amd import _lib as L, ops
+    from magnet_amd.packing import pack
+    lib = L.lib()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Wt = torch.randn(W, W, device="cuda", generator=g) * 0.1
+    wt = pack(Wt.t().contiguous(), None, "fp16x3")[0]
+    ws = torch.empty(lib.magnet_linear_bwd128_workspace(), device="cuda")
+    prev = lib.magnet_linear_bwd128_generation(-1)
+    try:
+        for M in (1, 33, 4097, 70001):
+            for mask in (True, False):
+                dz = torch.randn(M, W, device="cuda", generator=g) * 1e-7
+                xf = torch.relu(torch.randn(M, W + 32, device="cuda", generator=g))
+                x = xf[:, 16:16 + W]
+                want_dx = (dz.double() @ Wt.double()) * ((x > 0).double() if mask else 1.0)
+                want_dW, want_db = dz.double().t() @ x.double(), dz.double().sum(0)
+                for gen in ((0, 1, 2, 3) if W == 128 else (0, 1)):
+                    lib.magnet_linear_bwd128_generation(gen)
+                    L._QUERIES.clear()                                   # (the grid query follows the generation)
+                    out = []
+                    for _ in range(2):
+                        dx, dW, db = torch.full((M, W), 7.0, device="cuda"), torch.empty(W, W, device="cuda"), torch.empty(W, device="cuda")
+                        am, n = ops.linear_bwd128(dz, x, wt, dx, dW, db, ws, mask=mask)
+                        out.append((dx, dW, db))
+                    dx, dW, db = out[0]
+                    assert rel_l2(dx, want_dx) < 1e-6 and rel_l2(dW, want_dW) < 2e-6 and rel_l2(db, want_db) < 1e-6, (M, mask, gen)
+                    assert float(am[:n].max()) == float(dx.abs().max()), (M, mask, gen)
+                    assert all(torch.equal(a, b) for a, b in zip(out[0], out[1])), (M, mask, gen)
+    finally:
+        lib.magnet_linear_bwd128_generation(prev)
+        L._QUERIES.clear()
+
+
+def test_dense_source_gradients_written_by_the_data_gemm_equal_the_copy_and_add_path():
+    """autograd._Mlp.backward writes the gradient of a dense full-width source from the first Linear's data GEMM itself (residual dy or
+    the running sum of the processor's e0 gradient chain added in the epilogue); MAGNET_DIRECT_SRC_GRAD=0 is the old path (dX0, column
+    copies, torch adds).  Same training step, both ways: every parameter gradient equal to rounding, and the new path is the one taken"""
+    from magnet_amd import autograd as AG
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    name, hp, salt, batch, d = load_case("magnet_gnn_tiny")
+    oracle = O.build(name, hp)
+    fill_state_dict(oracle, salt)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    grads, taken = {}, {True: 0, False: 0}
+    orig = AG._dense_source_of_block
+
+    def spy(*a):
+        r = orig(*a)
+        taken[AG.DIRECT_SRC_GRAD] += r is not None
+        return r
+
+    prev = AG.DIRECT_SRC_GRAD
+    AG._dense_source_of_block = spy
+    try:
+        for direct in (True, False):
+            AG.DIRECT_SRC_GRAD = direct
+            model = FACTORY[name](hp)
+            model.load_state_dict(oracle.state_dict())
+            model = model.cuda().train()
+            loss = model.training_step(cb, 0)
+            loss.backward()
+            grads[direct] = (float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters()})
+    finally:
+        AG.DIRECT_SRC_GRAD, AG._dense_source_of_block = prev, orig
+    assert taken[True] > 0 and taken[False] == 0
+    assert grads[True][0] == grads[False][0]
+    worst = max(rel_l2(grads[True][1][n], grads[False][1][n]) for n in grads[True][1])
+    assert worst < 2e-6, worst
