@@ -575,15 +575,25 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
             opt.step()
             return loss
 
-        first = float(train_step().detach())
-        train_step()        # (second warm-up step: the caching allocator still grows its pool in step 1 - 0 to 90 ms of hipMalloc at 205 GiB,
-        barrier()           #  profiles/r4/steps_timeline_c5.txt - a training run does the steady-state step thousands of times)
+        # three warm-up steps: the caching allocator still grows its pool after step 0 - hipMalloc of GBs at 205 GiB in use, 80-120 ms in the
+        # first process on a box (profiles/r4/steps_timeline_c5.txt; `warmup_step_ms` keeps what they took) - a training run does the
+        # steady-state step thousands of times
+        warm_ms = []
+        for i in range(3):
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            l_ = train_step()
+            torch.cuda.synchronize()
+            warm_ms.append(round((time.perf_counter() - tw) * 1e3, 1))
+            if i == 0:
+                first = float(l_.detach())
+        barrier()
         t0 = time.perf_counter()
         for _ in range(train_steps):
             last = train_step()
         barrier()
         t_el = max_over_ranks(time.perf_counter() - t0, dev)
-        train = {"ms_per_step": round(t_el / train_steps * 1e3, 3), "steps": train_steps, "warmup": 2,
+        train = {"ms_per_step": round(t_el / train_steps * 1e3, 3), "steps": train_steps, "warmup": 3, "warmup_step_ms": warm_ms,
                  "value": world * B * nodes * pred_steps * train_steps / t_el, "unit": "mesh-node-updates/s",
                  "what": "rollout through autograd Functions (HIP forward + backward kernels; hidden Linears walked back in one kernel, first Linear at source-row granularity, tape kept in HBM when it fits) + one gradient all-reduce + fused Adam",
                  "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],

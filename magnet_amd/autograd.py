@@ -451,7 +451,9 @@ class _Mlp(torch.autograd.Function):
                 if l == 0 and not need_dx0:
                     break
                 # dX = dz . W   (transposed packs, column block by column block)
-                dX = torch.empty(max(M, 1), Kp, device=dev, dtype=torch.float32)
+                dX = None                                   # (allocated by the first column block that is written to it: with every block of
+                                                            #  the first Linear going straight to a source's gradient it is 3 GB nobody reads)
+                new_dX = lambda: torch.empty(max(M, 1), Kp, device=dev, dtype=torch.float32)   # noqa: E731
                 # column blocks of equal width go out as ONE launch (the kernel's column groups over gridDim.y): the nine 128-column
                 # taps of an EDSR convolution on a 64 x 64 map were nine 32-workgroup launches of 14 us each
                 # (l > 0: the launch also leaves the block maxima of what it stores - the layer below, if it takes the one-kernel path,
@@ -501,6 +503,8 @@ class _Mlp(torch.autograd.Function):
                                 direct[si] = None                              # (not the last hop of the chain: the sum travels on)
                         continue
                     tps = [_tpack(m, pk, l, c0 + g * w, w, W, Np, Kp) for g in range(G)]
+                    if dX is None:
+                        dX = new_dX()
                     if l > 0:      # ... with the ReLU mask of the layer below as the epilogue: dz_{l-1} = (X[l] > 0) ? dX : 0
                         ops.mlp(M, ops.ktiles(ops.Term(dz, Np)), tps, nl=1, ht=w // 32, ot=w // 32, act=ops.ACT_NONE, colgroups=G,
                                 epi=ops.EPI_STORE_MASK, res=X[l][:, c0:], y=dX[:, c0:], ldy=Kp, ncols=w, partials=mx)
