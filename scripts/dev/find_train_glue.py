@@ -1,5 +1,5 @@
 """Dev: which Python lines issue the small torch kernels (adds / fills / copies / zeros) inside a WARM MAgNet TRAINING step?
-usage: python scripts/dev/find_train_glue.py [magnet_cnn_2d|magnet_gnn]"""
+usage: python scripts/dev/find_train_glue.py [magnet_cnn_2d|magnet_gnn|gnn_64|gnn_512|cnn_64]"""
 import sys, types, collections, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -8,9 +8,15 @@ from magnet_amd.models.factory import FACTORY
 from magnet_amd import _lib as L
 name = sys.argv[1] if len(sys.argv) > 1 else "magnet_cnn_2d"
 torch.manual_seed(0)
-model = FACTORY[name](types.SimpleNamespace(**bench.MAGNET_HP[name])).cuda().train()
+if name in ("gnn_64", "gnn_512", "cnn_64", "c4a"):                 # the reference's own shapes (bench.ref_shape_cases)
+    mname, hp, mk = bench.ref_shape_cases()[name]
+    model = FACTORY[mname](types.SimpleNamespace(**hp)).cuda().train()
+    batch, nodes = mk(True)
+    batch = {k: v.cuda() for k, v in batch.items()}
+else:
+    model = FACTORY[name](types.SimpleNamespace(**bench.MAGNET_HP[name])).cuda().train()
+    batch, nodes = bench.synthetic_magnet_batch(name, 1, 256, 2000, "cuda")
 opt = model.configure_optimizers()["optimizer"]
-batch, nodes = bench.synthetic_magnet_batch(name, 1, 256, 2000, "cuda")
 
 
 def step():
