@@ -498,8 +498,10 @@ class _Mlp(torch.autograd.Function):
                                 **(dict(epi=ops.EPI_STORE_RES, res=add.view(-1, add.shape[-1])) if add is not None else {}))
                         direct[si] = g
                         if chain is not None:
-                            chain[1]["g"] = g
-                            if not chain[2]:
+                            if chain[2]:
+                                chain[1].pop("g", None)                        # (the last call hands the sum to autograd: nothing left to keep)
+                            else:
+                                chain[1]["g"] = g
                                 direct[si] = None                              # (not the last hop of the chain: the sum travels on)
                         continue
                     tps = [_tpack(m, pk, l, c0 + g * w, w, W, Np, Kp) for g in range(G)]
