@@ -33,6 +33,27 @@ from .packing import pack, pad_to
 BWD_GEMM = "bf16x6"
 # MAGNET_DIRECT_SRC_GRAD=0 (development A/B): dense-source gradients through dX0 + column copies + torch adds again
 DIRECT_SRC_GRAD = __import__("os").environ.get("MAGNET_DIRECT_SRC_GRAD", "1") != "0"
+# MAGNET_ACCUM_PARAM_GRADS=0 (development A/B): see accumulate_param_grads
+ACCUM_PARAM_GRADS = __import__("os").environ.get("MAGNET_ACCUM_PARAM_GRADS", "1") != "0"
+_ACCUM = {"on": False}
+
+
+class accumulate_param_grads:
+    """``with accumulate_param_grads():`` around the forward of a training step that will be differentiated with ``loss.backward()``
+    (the models' ``training_step``): the chains built inside let their one-kernel Linear backward (``ops.linear_bwd128``) ADD the weight
+    and bias gradient of a leaf parameter to ``p.grad`` in the kernel (the first contribution of a step becomes ``p.grad``) and hand
+    autograd None for it.  A rollout calls every chain once per forward, so without this torch's AccumulateGrad adds four [128, 128]
+    gradients per parameter one tiny kernel at a time: 893 ``aten::add_`` per magnet_gnn step at the reference's batch size.  Not for
+    ``torch.autograd.grad`` (which must not touch ``.grad``): outside this context the Functions return every gradient as before."""
+
+    def __enter__(self):
+        self.prev = _ACCUM["on"]
+        _ACCUM["on"] = ACCUM_PARAM_GRADS
+        return self
+
+    def __exit__(self, *exc):
+        _ACCUM["on"] = self.prev
+        return False
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -415,9 +436,19 @@ class _Mlp(torch.autograd.Function):
                     if lb_ws is None:
                         lb_ws = torch.empty(L.query("magnet_linear_bwd128_workspace"), device=dev, dtype=torch.float32)
                     dX = torch.empty(M, Np, device=dev, dtype=torch.float32)
-                    dWp, dbp = torch.empty(Np, Np, device=dev, dtype=torch.float32), torch.empty(Np, device=dev, dtype=torch.float32)
-                    amax = ops.linear_bwd128(dz, X[l], _tpack16(pk, l, W), dX, dWp, dbp, lb_ws, mask=True, amax_in=amax)
-                    grads_par[2 * l], grads_par[2 * l + 1] = dWp, dbp
+                    into = m.accum and W.is_leaf and b.is_leaf and tuple(W.shape) == (Np, Np) and tuple(b.shape) == (Np,)
+                    Wg, bg = (W.grad, b.grad) if into else (None, None)
+                    if (Wg is not None and bg is not None and Wg.dtype == bg.dtype == torch.float32 and Wg.device == bg.device == dev
+                            and Wg.is_contiguous() and bg.is_contiguous()):
+                        # (accumulate_param_grads: this call's share is added to p.grad by the kernel's own reduction)
+                        amax = ops.linear_bwd128(dz, X[l], _tpack16(pk, l, W), dX, Wg, bg, lb_ws, mask=True, amax_in=amax, accumulate=True)
+                    else:
+                        dWp, dbp = torch.empty(Np, Np, device=dev, dtype=torch.float32), torch.empty(Np, device=dev, dtype=torch.float32)
+                        amax = ops.linear_bwd128(dz, X[l], _tpack16(pk, l, W), dX, dWp, dbp, lb_ws, mask=True, amax_in=amax)
+                        if into and W.grad is None and b.grad is None:
+                            W.grad, b.grad = dWp, dbp                         # the step's first contribution IS the gradient buffer
+                        else:
+                            grads_par[2 * l], grads_par[2 * l + 1] = dWp, dbp
                     dz = dX
                     continue
                 amax = None
@@ -772,7 +803,7 @@ def mlp(M, groups, pk, params, *, epi=ops.EPI_STORE, res=None, csr=None, out_row
         M=int(M), tiles=tiles, runs=runs, pk=pk, epi=epi, n_src=len(srcs), n_par=len(params), has_res=res is not None,
         tgt=csr.tgt if csr is not None else None, rowptr=csr.rowptr if csr is not None else None,
         out_rows=int(out_rows if out_rows is not None else M), first_cols=first_cols, col_map=getattr(pk, "col_map", None),
-        inv_cache={}, final_relu=bool(final_relu), grad_chain=grad_chain)
+        inv_cache={}, final_relu=bool(final_relu), grad_chain=grad_chain, accum=_ACCUM["on"])
     assert not (final_relu and (pk.ln is not None or epi != ops.EPI_STORE))
     srcs = [ops._f32(s, "mlp source") for s in srcs]
     extra = [ops._f32(res, "residual")] if res is not None else []

@@ -138,6 +138,9 @@ class _RolloutScope:
     def __init__(self, model):
         from ..packing import deferred_weight_checks
         self.parts = (deferred_weight_checks(), model._guard.armed())
+        if torch.is_grad_enabled() and model.training:      # a training step: loss.backward() follows (autograd.accumulate_param_grads)
+            from ..autograd import accumulate_param_grads
+            self.parts += (accumulate_param_grads(),)
 
     def __enter__(self):
         for p in self.parts:

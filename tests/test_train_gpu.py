@@ -849,3 +849,42 @@ def test_dense_source_gradients_written_by_the_data_gemm_equal_the_copy_and_add_
     assert grads[True][0] == grads[False][0]
     worst = max(rel_l2(grads[True][1][n], grads[False][1][n]) for n in grads[True][1])
     assert worst < 2e-6, worst
+
+
+@pytest.mark.parametrize("tag", ["magnet_gnn_tiny", "magnet_cnn_2d"])
+def test_parameter_gradients_accumulated_by_the_kernel_equal_autograds_accumulation(tag, monkeypatch):
+    """autograd.accumulate_param_grads (entered by the models' training rollouts): the one-kernel Linear backward adds its dW / db to
+    p.grad itself instead of returning them for torch's AccumulateGrad.  Same training step with the switch off: the same loss and
+    gradients to rounding; with it on, fewer gradients travel through autograd.  (_FUSED_LAYER_ROWS lowered: the golden cases are small.)"""
+    from magnet_amd import autograd as AG
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    monkeypatch.setattr(AG, "_FUSED_LAYER_ROWS", 1)
+    name, hp, salt, batch, d = load_case(tag)
+    oracle = O.build(name, hp)
+    fill_state_dict(oracle, salt)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    calls = {True: 0, False: 0}
+    orig = AG.ops.linear_bwd128
+
+    def spy(*a, **kw):
+        calls[bool(kw.get("accumulate", False))] += 1
+        return orig(*a, **kw)
+
+    monkeypatch.setattr(AG.ops, "linear_bwd128", spy)
+    grads = {}
+    for on in (True, False):
+        monkeypatch.setattr(AG, "ACCUM_PARAM_GRADS", on)
+        calls[True] = calls[False] = 0
+        model = FACTORY[name](hp)
+        model.load_state_dict(oracle.state_dict())
+        model = model.cuda().train()
+        loss = model.training_step(cb, 0)
+        loss.backward()
+        assert all(p.grad is not None and p.grad.shape == p.shape for p in model.parameters())
+        grads[on] = (float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters()}, dict(calls))
+    assert grads[True][2][True] > 0 and grads[False][2][True] == 0, (grads[True][2], grads[False][2])
+    assert grads[True][0] == grads[False][0]
+    worst = max(rel_l2(grads[True][1][n], grads[False][1][n]) for n in grads[True][1])
+    assert worst < 2e-6, worst
