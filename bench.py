@@ -587,12 +587,18 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
             warm_ms.append(round((time.perf_counter() - tw) * 1e3, 1))
             if i == 0:
                 first = float(l_.detach())
+        # (a full collection of Python's cyclic GC walks the ~10^5 objects of a step's autograd graph: 50-100 ms of host time whenever its
+        #  counters say so.  Collect now and freeze what exists, so that the timed steps see young-generation collections only)
+        import gc
+        gc.collect()
+        gc.freeze()
         barrier()
         t0 = time.perf_counter()
         for _ in range(train_steps):
             last = train_step()
         barrier()
         t_el = max_over_ranks(time.perf_counter() - t0, dev)
+        gc.unfreeze()
         train = {"ms_per_step": round(t_el / train_steps * 1e3, 3), "steps": train_steps, "warmup": 3, "warmup_step_ms": warm_ms,
                  "value": world * B * nodes * pred_steps * train_steps / t_el, "unit": "mesh-node-updates/s",
                  "what": "rollout through autograd Functions (HIP forward + backward kernels; hidden Linears walked back in one kernel, first Linear at source-row granularity, tape kept in HBM when it fits) + one gradient all-reduce + fused Adam",
