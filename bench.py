@@ -592,14 +592,24 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
         import gc
         gc.collect()
         gc.freeze()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(train_steps):
-            last = train_step()
-        barrier()
-        t_el = max_over_ranks(time.perf_counter() - t0, dev)
+        # a timed region during which torch's allocator had to grow its pool (hipMalloc of GBs with ~210 GB in use: 50-100 ms, erratic in
+        # the first process on a box, profiles/r4/c5_leg_repeat.txt) is not the steady state: timed again, at most twice; what was
+        # discarded is reported (`discarded_ms_per_step`)
+        discarded = []
+        for attempt in range(3):
+            reserved0 = torch.cuda.memory_reserved(dev)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(train_steps):
+                last = train_step()
+            barrier()
+            t_el = max_over_ranks(time.perf_counter() - t0, dev)
+            if torch.cuda.memory_reserved(dev) - reserved0 < (256 << 20) or attempt == 2:      # (small-block pools keep growing by a few MB)
+                break
+            discarded.append(round(t_el / train_steps * 1e3, 3))
         gc.unfreeze()
         train = {"ms_per_step": round(t_el / train_steps * 1e3, 3), "steps": train_steps, "warmup": 3, "warmup_step_ms": warm_ms,
+                 "discarded_ms_per_step": discarded,
                  "value": world * B * nodes * pred_steps * train_steps / t_el, "unit": "mesh-node-updates/s",
                  "what": "rollout through autograd Functions (HIP forward + backward kernels; hidden Linears walked back in one kernel, first Linear at source-row granularity, tape kept in HBM when it fits) + one gradient all-reduce + fused Adam",
                  "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],
