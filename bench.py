@@ -60,7 +60,9 @@ Extra objects on the JSON line:
                   enqueued kernel by kernel and replayed from one hipGraph; rank 0, N = 1 only.
   training_step - the same workload trained: rollout with tape, HIP backward
                   kernels, ONE flat gradient all-reduce over RCCL, fused Adam; ms per step and the node-updates/s it
-                  corresponds to (all ranks), `--train-steps` timed steps after one warm-up.  Never part of `value`.
+                  corresponds to (all ranks), `--train-steps` timed steps after two warm-up steps (mpnn_2d) / three (`c4b`, `c5`:
+                  `warmup_step_ms`; lr = 1e-6 there as in `ref_shapes`; a timed region during which torch's allocator grew its pool
+                  by >= 256 MB is timed again, `discarded_ms_per_step`).  Never part of `value`.
 """
 from __future__ import annotations
 
