@@ -216,19 +216,21 @@ __global__ void __launch_bounds__(256, NT == 2 ? 2 : 1) k_linear_bwd(const LinBw
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// Generation 1 of the 128-wide kernel (k_linear_bwd_r; profiles/r4/linear_bwd_ablations.txt is why).  Generation 0 above runs one wave per
-// SIMD with 64 KiB of W planes + 72 KiB of staging in LDS; its compute (0.65 ms at 2.1 M rows) and its memory traffic (0.70 ms) take
-// turns.  Here: eight waves (two per SIMD) on 32-row steps.
+// Generation 1 (k_linear_bwd_r; profiles/r4/linear_bwd_ablations.txt is why).  Generation 0 above runs one wave per SIMD with 64 KiB of W
+// planes + 72 KiB of staging in LDS; its compute (0.65 ms at 2.1 M rows) and its memory traffic (0.70 ms) take turns.  Here: two waves per
+// SIMD on 32-row steps (the shapes: see the template's comment below); with NB = 1, W = 128:
 //  * W^T lives in REGISTERS: wave w owns in-features 16 w .. + 15 of the data GEMM (dx^T = W^T dz^T, v_mfma_f32_16x16x32_f16; its 4 k tiles
 //    x 2 planes of A fragments are 32 registers, read once from the standard pack) - no W in LDS at all;
-//  * dz and x are split into fp16 planes ONCE, by the wave that loaded them (4 rows per wave, a lane = 2 x 4 features: 512-byte coalesced
-//    rows), and written row-major [row][position] to LDS: ONE image of G dz and one of x.  The data GEMM's B operand (lane = row) is one
-//    ds_read_b128 per k slot and plane; the weight gradient's operands (lane = feature, registers = rows) come out of
-//    ds_read_b64_tr_b16 (profiles/r4/tr_read_probe.txt) - no v_perm, no split on the reading side;
+//  * dz and x are split into fp16 planes ONCE, by the wave that loaded them (4 rows per wave, a lane = 4 features of 2 rows: every load
+//    instruction reads whole 512-byte rows), and written row-major [row][position] to LDS: ONE image of G dz and one of x.  The data GEMM's
+//    B operand (lane = row) is one ds_read_b128 per k slot and plane; the weight gradient's operands (lane = feature, registers = rows)
+//    come out of ds_read_b64_tr_b16 (profiles/r4/tr_read_probe.txt) - no v_perm, no split on the reading side;
+//  * the ReLU mask of dx travels as 4 bits per lane and row through LDS (LrBuf::pos): x is read from HBM once;
 //  * wave w owns rows 16 w .. + 15 of dW (dz features) x all 128 columns: 8 accumulators of 4 registers;
 //  * the step's operands are double buffered: ONE barrier per step; the next step's rows are loaded while this step's GEMMs run.
 // G dz serves both GEMMs (generation 0 scaled the data GEMM's rows one by one): a row 2^16 times smaller than the launch maximum still has
-// 22 bits, below that its error is bounded by 2^-38 of the launch maximum.
+// 22 bits, below that its error is bounded by 2^-38 of the launch maximum.  Measured: profiles/r4/linear_bwd_gen1.txt (0.615 ms at 2.1 M
+// rows = 5.3 TB/s against 0.90-0.96), traffic_linear_bwd.txt (HBM reads = the algorithmic 2.157 GB), stress_linear_bwd.txt.
 #define LR_ST 144                       // halfwords per row: 288 B = 72 banks - the 8 rows of a transposed read's 32-lane group tile the 64 banks
                                         // (3.0 LDS cycles per read, the floor: scripts/dev/tr_bank_probe.cpp), and so do the 16-lane groups of the
                                         // data GEMM's ds_read_b128
