@@ -100,12 +100,15 @@ _QUERIES = {}
 
 
 def query(name: str, *args) -> int:
-    """value of a pure query entry point (``*_supported``, ``*_workspace``, ``*_grid``: functions of their integer arguments only),
+    """value of a query entry point; ``*_supported`` / ``*_workspace`` are pure functions of their integer arguments and
     cached: a MAgNet training step at the reference's batch sizes is host bound and asks these ~600 times per step"""
+    if name.endswith("_grid"):
+        # NOT cached: magnet_linear_bwd{128,64}_grid follows the kernel generation (magnet_linear_bwd128_generation, a development
+        # switch) - a stale value would size the caller's amax_out for another launch shape.  (These take the row count as a C long.)
+        return int(getattr(lib(), name)(*[C.c_long(a) for a in args]))
     key = (name, args)
     if key not in _QUERIES:
-        long_arg = name.endswith("_grid")                      # (these take the row count as a C long)
-        _QUERIES[key] = int(getattr(lib(), name)(*[C.c_long(a) if long_arg else a for a in args]))
+        _QUERIES[key] = int(getattr(lib(), name)(*args))
     return _QUERIES[key]
 
 

@@ -436,7 +436,10 @@ class _Mlp(torch.autograd.Function):
                     if lb_ws is None:
                         lb_ws = torch.empty(L.query("magnet_linear_bwd128_workspace"), device=dev, dtype=torch.float32)
                     dX = torch.empty(M, Np, device=dev, dtype=torch.float32)
-                    into = m.accum and W.is_leaf and b.is_leaf and tuple(W.shape) == (Np, Np) and tuple(b.shape) == (Np,)
+                    # (a frozen Linear - requires_grad=False tensors are leaves too - must not get a .grad from here: autograd drops
+                    #  what backward returns for it, an optimizer built over self.parameters() would not drop an assigned .grad)
+                    into = (m.accum and W.is_leaf and b.is_leaf and W.requires_grad and b.requires_grad
+                            and W.dtype == b.dtype == torch.float32 and tuple(W.shape) == (Np, Np) and tuple(b.shape) == (Np,))
                     Wg, bg = (W.grad, b.grad) if into else (None, None)
                     if (Wg is not None and bg is not None and Wg.dtype == bg.dtype == torch.float32 and Wg.device == bg.device == dev
                             and Wg.is_contiguous() and bg.is_contiguous()):

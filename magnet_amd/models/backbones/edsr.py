@@ -55,6 +55,11 @@ class EDSR(nn.Module):
         self._pack_id = 0
         self._pack_replay = __import__("os").environ.get("MAGNET_PACK_REPLAY", "1") != "0"      # A/B knob (packing.PackRecorder)
 
+    def __getstate__(self):
+        """pickle / copy.deepcopy: parameters travel, the per-instance device caches (packed weights, tap tables, launch plans) do not"""
+        from ...packing import state_without_device_caches
+        return state_without_device_caches(self)
+
     # ------------------------------------------------------------------ packed weights / tap tables (cached)
     def packed(self, mode=None):
         mode = mode or default_gemm()

@@ -156,6 +156,12 @@ class MagnetBase(LightningModule):
     """Graph building + encode-process on HIP, shared by the three MAgNet models."""
     TOPOLOGY_KEYS = ()          # batch entries that determine the graph topology (set by the models)
 
+    def __getstate__(self):
+        """pickle / copy.deepcopy: parameters and hparams travel, the per-instance device caches (packed weights, their recorder and
+        launch plans, topology caches, captured rollouts) do not - the copy rebuilds them on first use"""
+        from ..packing import state_without_device_caches
+        return state_without_device_caches(self)
+
     def _graphed(self, fn, batch, keys, rows):
         """run ``fn(batch)`` (an inference rollout returning a tuple of tensors) - replayed from one hipGraph when the graph
         is small (launch bound), else directly"""

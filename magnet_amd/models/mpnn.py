@@ -131,6 +131,12 @@ class MPNN(LightningModule):
         self.fused_node_stats = bool(getattr(hparams, "fused_node_stats", os.environ.get("MAGNET_FUSED_STATS", "0") != "0"))
         self._rollout_graph = RolloutGraph(topology_keys=("x",))
 
+
+    def __getstate__(self):
+        """pickle / copy.deepcopy: parameters and hparams travel, the per-instance device caches (packed weights, their recorder and
+        launch plans, topology caches, captured rollouts) do not - the copy rebuilds them on first use"""
+        from ..packing import state_without_device_caches
+        return state_without_device_caches(self)
     # ------------------------------------------------------------------ arithmetic of the Linears
     @property
     def edge_gemm(self):

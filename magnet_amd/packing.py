@@ -410,6 +410,16 @@ class PackRecorder:
     def backed(self, t) -> bool:
         return t is None or t.untyped_storage().data_ptr() in self.storages
 
+    # the launches hold ctypes function pointers and argument blocks of ONE model instance's buffers: a copy.deepcopy / pickle of a
+    # model (EMA / best-model snapshots, spawn-style launchers) gets a dead recorder and rebuilds its packs on first use
+    def __deepcopy__(self, memo):
+        dead = PackRecorder([], None)
+        dead.ok = False
+        return dead
+
+    def __getstate__(self):
+        return {"params": [], "storages": set(), "launches": [], "derived": [], "ok": False, "key": None, "generation": 0}
+
     def usable(self) -> bool:
         """the parameters still live where they lived when the launches were recorded (.to() / load_state_dict(assign=True) move them)"""
         return self.ok and all(p.untyped_storage().data_ptr() in self.storages for p in self.params)
@@ -427,6 +437,20 @@ class PackRecorder:
 
 
 _active_recorder = None
+
+# per-instance device caches of the models (packed weights with their recorder and the launch plans cached on them, parameter lists,
+# EDSR tap tables / plans): never part of a copy or a pickle - the copy rebuilds them on first use
+_DEVICE_CACHE_ATTRS = {"_pack": None, "_pack_key": None, "_pack_rec": None, "_plist": None, "_plan_key": None, "_plan_val": None,
+                       "_taps": {}, "_topo": None}
+
+
+def state_without_device_caches(module) -> dict:
+    """``__getstate__`` of the model classes (used by pickle AND copy.deepcopy): the instance dict with the device caches reset"""
+    st = dict(module.__dict__)
+    for k, v in _DEVICE_CACHE_ATTRS.items():
+        if k in st:
+            st[k] = type(v)() if v is not None else None
+    return st
 
 
 class recording:

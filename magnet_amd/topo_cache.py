@@ -35,6 +35,12 @@ class TopologyCache:
     def clear(self) -> None:
         self._entries.clear()
 
+    def __deepcopy__(self, memo):                      # topologies belong to one model instance's tensors: a copy starts empty
+        return TopologyCache(self.capacity)
+
+    def __getstate__(self):
+        return {"capacity": self.capacity, "_entries": []}
+
     def __len__(self) -> int:
         return len(self._entries)
 

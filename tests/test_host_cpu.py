@@ -238,6 +238,28 @@ def test_factory_lists_all_five_models():
     assert sorted(FACTORY) == ["magnet_cnn", "magnet_cnn_2d", "magnet_gnn", "mpnn", "mpnn_2d"]
 
 
+def test_shim_package_shadows_models_factory():
+    """with <repo>/shim first on PYTHONPATH the reference's own import line (run.py:8,
+    `from models.factory import FACTORY`) resolves to magnet_amd's factory, and FACTORY[name](params) builds the model the way
+    run.py:49-50 does - in a fresh interpreter, so that no `models` package imported earlier in this process can answer instead"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import types\n"
+            "from models.factory import FACTORY\n"
+            "import models.factory as mf, magnet_amd.models.factory as af\n"
+            "assert FACTORY is af.FACTORY and 'shim' in mf.__file__\n"
+            "hp = types.SimpleNamespace(lr=1e-3, weight_decay=0.0, factor=0.3, step_size=50, loss='l1', hidden_features=128,\n"
+            "                           hidden_layer=5, time_window=10, teacher_forcing=False, neighbors=4)\n"
+            "m = FACTORY['mpnn_2d'](hp)\n"
+            "print(type(m).__name__, sorted(FACTORY))\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "shim"), root]))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/tmp", timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == "MPNN_2d", out.stdout
+
+
 def test_large_graph_node_kernel_gate():
     """host-side gate of the persistent node kernels (models/mpnn.py `fused_nodes`): shapes outside it take the generic launches"""
     from magnet_amd import ops

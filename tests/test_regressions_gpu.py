@@ -572,3 +572,23 @@ def test_bench_eight_ranks_on_one_gpu_over_gloo():
     t = line["training_step"]
     assert t["ms_per_step"] > 0 and t["allreduce_ms"] > 0 and t["allreduce_bytes"] > 2_000_000
     assert t["loss_first_last"][1] != t["loss_first_last"][0]
+
+
+# ------------------------------------------------------------------------------------------- copies of a warm model
+@pytest.mark.parametrize("tag", ["mpnn_2d", "magnet_gnn_tiny", "magnet_cnn_2d"])
+def test_deepcopy_and_pickle_of_a_model_after_its_first_forward(tag):
+    """EMA / best-model snapshots and spawn-style launchers copy a model that has already run: the packed-weight caches hold ctypes
+    function pointers and argument blocks (packing.PackRecorder), captured rollouts, launch plans.  A copy must carry the parameters
+    only, rebuild its caches on first use and give the same prediction bit for bit; the original keeps working."""
+    import copy
+    import pickle
+    name, hp, batch, d, oracle, model = _pair(tag)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    first = model.validation_step(cb, 0)
+    first = [t.clone() for t in (first if isinstance(first, (tuple, list)) else (first,))]
+    twin = copy.deepcopy(model)
+    revived = pickle.loads(pickle.dumps(model))
+    for other in (twin, revived, model):
+        got = other.validation_step(cb, 0)
+        got = got if isinstance(got, (tuple, list)) else (got,)
+        assert all(torch.equal(a, b) for a, b in zip(first, got))

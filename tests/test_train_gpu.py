@@ -888,3 +888,41 @@ def test_parameter_gradients_accumulated_by_the_kernel_equal_autograds_accumulat
     assert grads[True][0] == grads[False][0]
     worst = max(rel_l2(grads[True][1][n], grads[False][1][n]) for n in grads[True][1])
     assert worst < 2e-6, worst
+
+
+def test_a_frozen_hidden_linear_gets_no_gradient_from_the_accumulating_backward(monkeypatch):
+    """requires_grad=False parameters are leaves too.  With autograd.accumulate_param_grads the one-kernel Linear
+    backward must not assign / add to the .grad of a frozen Linear (torch.optim.Adam(self.parameters()) would then update it);
+    every other parameter keeps the gradient it has without the freeze."""
+    from magnet_amd import autograd as AG
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    monkeypatch.setattr(AG, "_FUSED_LAYER_ROWS", 1)
+    name, hp, salt, batch, d = load_case("magnet_gnn_tiny")
+    oracle = O.build(name, hp)
+    fill_state_dict(oracle, salt)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    grads = {}
+    for frozen in (False, True):
+        model = FACTORY[name](hp)
+        model.load_state_dict(oracle.state_dict())
+        model = model.cuda().train()
+        hidden = model._processor.gnn_stacks[0].edge_fn[0].layers[2]          # a hidden Linear of a 5-Linear chain
+        assert hidden.weight.shape[0] == hidden.weight.shape[1]
+        if frozen:
+            hidden.weight.requires_grad_(False)
+            hidden.bias.requires_grad_(False)
+        before = hidden.weight.detach().clone()
+        loss = model.training_step(cb, 0)
+        loss.backward()
+        grads[frozen] = {n: (None if p.grad is None else p.grad.clone()) for n, p in model.named_parameters()}
+        if frozen:
+            assert hidden.weight.grad is None and hidden.bias.grad is None
+            opt = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=1e-2)
+            opt.step()
+            assert torch.equal(hidden.weight.detach(), before)
+    frozen_names = {n for n, g in grads[True].items() if g is None}
+    assert len(frozen_names) == 2, frozen_names
+    worst = max(rel_l2(grads[True][n], grads[False][n]) for n in grads[True] if n not in frozen_names)
+    assert worst < 2e-6, worst
