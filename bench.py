@@ -580,11 +580,17 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
         tmodel = FACTORY[name](types.SimpleNamespace(**dict(hp, lr=1e-6))).to(dev).train()
         opt = tmodel.configure_optimizers()["optimizer"]
 
+        ar_events = []
+
         def train_step():
             opt.zero_grad(set_to_none=True)
             loss = tmodel.training_step(batch, 0)
             loss.backward()
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
             allreduce_gradients(tmodel.parameters())
+            e_.record()
+            ar_events.append((s_, e_))
             opt.step()
             return loss
 
@@ -612,6 +618,7 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
         for attempt in range(3):
             reserved0 = torch.cuda.memory_reserved(dev)
             barrier()
+            ar_events.clear()
             t0 = time.perf_counter()
             for _ in range(train_steps):
                 last = train_step()
@@ -630,7 +637,13 @@ def bench_magnet(name, B, K, Wm, Wq, train_steps, dev, rank, world, dist, max_ov
                  "what": "rollout through autograd Functions (HIP forward + backward kernels; hidden Linears walked back in one kernel, first Linear at source-row granularity, tape kept in HBM when it fits) + one gradient all-reduce + fused Adam",
                  "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],
                  "widened_to_bf16x6": __import__("magnet_amd.packing", fromlist=["wide"]).wide(),
-                 "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2), "lr": 1e-6}
+                 "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2), "lr": 1e-6,
+                 # the one flat gradient all-reduce of the step (10.3 MB for magnet_gnn, 21.5 MB for magnet_cnn_2d), HIP events
+                 # around it; and the DDP invariant - the same parameters on every rank after the steps
+                 "allreduce_ms": round(sum(s_.elapsed_time(e_) for s_, e_ in ar_events) / max(len(ar_events), 1), 4),
+                 "allreduce_bytes": 4 * sum(p_.numel() for p_ in tmodel.parameters()),
+                 "param_abs_sum_max_over_ranks": max_over_ranks(float(sum(p_.detach().double().abs().sum() for p_ in tmodel.parameters())), dev),
+                 "param_abs_sum_min_over_ranks": -max_over_ranks(-float(sum(p_.detach().double().abs().sum() for p_ in tmodel.parameters())), dev)}
         del tmodel, opt, last, train_step
         __import__("magnet_amd.packing", fromlist=["narrow"]).narrow()   # (a leg that left the fp16 range must not hand the NEXT one the wider split)
     del model, batch

@@ -218,13 +218,31 @@ int magnet_mpnn_edge_fp16x3_ws_f32(const float* A, const float* Bm, const int32_
 int magnet_mpnn_edge_rows_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const void* tiles, int n_tiles,
                                      const int32_t* strag_ptr, const int32_t* strag_row, const int32_t* strag_src,
                                      const void* w2_t32, const float* b2, float* agg, int a_bm_log2e_scaled, void* stream);
-/* The tile plan of a CSR graph for the kernel above.  _count, per row r: has_tile[r] = (deg_r >= pmin); has_strag[r] = the row has a
+/* The same op with message_net_2's planes resident in the accumulation half of the register file (k_mpnn_edge_rowsr, generation 12;
+ * DESIGN.md 14.2): no LDS weight-fragment reads, one wave per SIMD.  Arguments and contract exactly as
+ * magnet_mpnn_edge_rows_fp16x3_f32. */
+int magnet_mpnn_edge_rowsr_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const void* tiles, int n_tiles,
+                                      const int32_t* strag_ptr, const int32_t* strag_row, const int32_t* strag_src,
+                                      const void* w2_t32, const float* b2, float* agg, int a_bm_log2e_scaled, void* stream);
+/* Generation 12b (k_mpnn_edge_rowsg): as magnet_mpnn_edge_rowsr_fp16x3_f32 with the stragglers GROUPED WITH THEIR ROWS - every wave
+ * runs the 33rd edges of its next 32 rows as one tile right in front of those rows' tiles and parks their messages in LDS; the
+ * straggler lists are not needed (a tile descriptor with exactly one edge outside the tile says where that edge is: first edge + 32).
+ * has_stragglers = 0: no row has one (the straggler tiles are left out).  Rows with two or more edges outside their tile: the mean
+ * over those in agg[row] on entry, as for the two kernels above. */
+int magnet_mpnn_edge_rowsg_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const void* tiles, int n_tiles,
+                                      int has_stragglers, const void* w2_t32, const float* b2, float* agg, int a_bm_log2e_scaled,
+                                      void* stream);
+/* The tile plan of a CSR graph for the three kernels above.  _count, per row r: has_tile[r] = (deg_r >= pmin); has_strag[r] = the row has a
  * tile and exactly one edge beyond it; n_rem[r] = its edges for the remainder pass (those outside the tile unless that is the one
  * straggler; all of them without a tile).  _fill: given the exclusive prefix sums tile_ptr / strag_ptr / rem_ptr [n_rows + 1] of the
  * three arrays, writes the descriptors, the straggler list and the remainder edge list
  * (src_rem, tgt_rem; still sorted by target, rem_ptr is its rowptr). */
 int magnet_row_tiles_count(const int32_t* rowptr, int n_rows, int pmin, int32_t* has_tile, int32_t* has_strag, int32_t* n_rem,
                            void* stream);
+/* The plan's three prefix arrays in one call (no host-side scans): ptrs [3][n_rows + 1] int32 receives the exclusive prefix sums of the
+ * per-row has_tile / has_strag / n_rem of magnet_row_tiles_count; ptrs[k][n_rows] = number of tiles / stragglers / remainder edges.
+ * Feed ptrs, ptrs + (n_rows + 1), ptrs + 2 (n_rows + 1) to magnet_row_tiles_fill. */
+int magnet_row_tiles_ptrs(const int32_t* rowptr, int n_rows, int pmin, int32_t* ptrs, void* stream);
 int magnet_row_tiles_fill(const int32_t* rowptr, const int32_t* src, int n_rows, const int32_t* tile_ptr, const int32_t* strag_ptr,
                           const int32_t* rem_ptr, void* tiles, int32_t* strag_row, int32_t* strag_src, int32_t* src_rem,
                           int32_t* tgt_rem, void* stream);

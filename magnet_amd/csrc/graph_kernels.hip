@@ -126,7 +126,8 @@ __global__ void k_kept(const int32_t* __restrict__ nbr, const int32_t* __restric
 
 // in-place exclusive scan of n ints by one 1024-thread block: 4096-int chunks, 16 coalesced bytes per thread, the next
 // chunk's load in flight while the current one is scanned (wave scan by __shfl_up, 16 wave totals through LDS)
-__global__ void __launch_bounds__(1024) k_exclusive_scan(int32_t* __restrict__ v, int n) {
+__global__ void __launch_bounds__(1024) k_exclusive_scan(int32_t* __restrict__ v, int n, long array_stride = 0) {
+    v += (size_t)blockIdx.x * array_stride;                // one block per array (magnet_launch_exclusive_scans)
     __shared__ int wsum[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nch = (n + 4095) / 4096;
@@ -466,6 +467,13 @@ extern "C" int magnet_radius_search_bbox_f32(const float* x, int dim, int n_node
     hipLaunchKernelGGL(k_radius_bbox, dim3(nb(n_nodes, 4)), dim3(256), 0, S_, x, dim, n_nodes, graph_ptr, chunk_ptr,
                        n_graphs, bbox_scratch, r2, cap, nbr, cnt);
     LAUNCH_CHECK();
+}
+
+// in-place exclusive scans of `narrays` arrays of n ints, `array_stride` ints apart, one 1024-thread block each (C++ linkage: the
+// tile plan of mpnn_edge_rows.hip scans its three per-row counts in one launch)
+int magnet_launch_exclusive_scans(int32_t* v, int n, int narrays, long array_stride, void* stream) {
+    if (n > 0 && narrays > 0) hipLaunchKernelGGL(k_exclusive_scan, dim3(narrays), dim3(1024), 0, S_, v, n, array_stride);
+    return (int)hipGetLastError();
 }
 
 // qptr[n_nodes + 1] <- exclusive scan of the kept-neighbour counts; qptr[n_nodes] = E

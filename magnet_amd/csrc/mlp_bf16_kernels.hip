@@ -778,6 +778,11 @@ __global__ void __launch_bounds__(256, 1) k_node_update(NodeUpdateArgs a) {
 #pragma unroll
     for (int i = 0; i < NKT; ++i) request(tile, kseq(i));
     int par = 0;                                                      // LDS slot of the chunk of first-layer step 0 of this tile
+    // bl[0] (written by waves 0 and 1) is read by EVERY wave's init_bias below, before the first barrier of the tile loop: without this
+    // one a wave that got ahead read what the previous kernel had left at that LDS address - a 32-row block of a launch came out with a
+    // neighbouring hop's bias now and then (scripts/stress_precision_leg.py).  It drains the same loads the first
+    // barrier of the loop would drain: no extra wait.
+    __syncthreads();
     for (; tile < ntiles; tile += gridDim.x) {
         const long row0 = tile * 128 + wave * 32;
         const int gid = norm ? (int)(min(row0 + j, a.n - 1) / a.rows_per_graph) : 0;
@@ -1101,6 +1106,11 @@ __global__ void __launch_bounds__(256, 2) k_node_update2(NodeUpdateArgs a) {
     // prologue: rows of steps 0 .. 2 of the first tile
 #pragma unroll
     for (int i = 0; i < 3; ++i) request(i, rows_of(tile), kseq(i));
+    // bl[0] (written by waves 0 and 1) is read by every wave's init_bias at the top of body(), BEFORE the tile's first barrier: this
+    // barrier was missing (round 4) and a wave that got ahead of wave 0 / 1 started its first tile from whatever the previous kernel
+    // had left at that LDS address - one 32-row block of ~1 in 100 launches off by ~1e-2 (found by scripts/stress_precision_leg.py +
+    // scripts/dev/find_flaky_kernel.py).  It drains the loads the loop's first barrier would drain anyway.
+    __syncthreads();
     for (; tile < ntiles; tile += gridDim.x) body();
 }
 

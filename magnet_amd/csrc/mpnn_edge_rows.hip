@@ -557,8 +557,9 @@ extern "C" int magnet_mpnn_edge_rows_fp16x3_f32(const float* A, const float* Bm,
 // outside the tile unless it is that one straggler; the whole row without a tile)
 __global__ void __launch_bounds__(256) k_row_tiles_count(const int32_t* __restrict__ rowptr, int n_rows, int pmin,
                                                          int32_t* __restrict__ has_tile, int32_t* __restrict__ has_strag,
-                                                         int32_t* __restrict__ n_rem) {
+                                                         int32_t* __restrict__ n_rem, int write_tail = 0) {
     const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r == n_rows && write_tail) has_tile[r] = has_strag[r] = n_rem[r] = 0;      // element n_rows of [n_rows + 1] arrays (scanned next)
     if (r >= n_rows) return;
     const int d = rowptr[r + 1] - rowptr[r];
     const int has = d >= pmin && d > 0;
@@ -601,6 +602,20 @@ extern "C" int magnet_row_tiles_count(const int32_t* rowptr, int n_rows, int pmi
         hipLaunchKernelGGL(k_row_tiles_count, dim3((n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, rowptr, n_rows, pmin, has_tile,
                            has_strag, n_rem);
     return (int)hipGetLastError();
+}
+
+int magnet_launch_exclusive_scans(int32_t* v, int n, int narrays, long array_stride, void* stream);      // graph_kernels.hip
+
+// The three prefix arrays of the plan in two launches: ptrs [3][n_rows + 1] int32 receives the exclusive prefix sums of has_tile /
+// has_strag / n_rem (ptrs[k][n_rows] = the totals: tiles, stragglers, remainder edges) - what magnet_row_tiles_count + three
+// host-side cumulative sums produced (0.66 ms per plan through torch; the bench rebuilds the plan with the graph in every rollout).
+extern "C" int magnet_row_tiles_ptrs(const int32_t* rowptr, int n_rows, int pmin, int32_t* ptrs, void* stream) {
+    (void)hipGetLastError();
+    if (n_rows < 0) return -2;
+    const long ld = (long)n_rows + 1;
+    hipLaunchKernelGGL(k_row_tiles_count, dim3((n_rows + 256) / 256), dim3(256), 0, (hipStream_t)stream, rowptr, n_rows, pmin, ptrs,
+                       ptrs + ld, ptrs + 2 * ld, 1);
+    return magnet_launch_exclusive_scans(ptrs, n_rows + 1, 3, ld, stream);
 }
 
 extern "C" int magnet_row_tiles_fill(const int32_t* rowptr, const int32_t* src, int n_rows, const int32_t* tile_ptr,

@@ -75,7 +75,7 @@ class RolloutGraph:
         return RolloutGraph(self.topology_keys, self.max_entries)
 
     def __getstate__(self):
-        return {"topology_keys": self.topology_keys, "max_entries": self.max_entries, "_entries": {}}
+        return {"topology_keys": self.topology_keys, "max_entries": self.max_entries, "_entries": {}, "_churn": {}}
 
     def __call__(self, fn, batch: dict, generation):
         """``fn(batch: dict) -> tuple of tensors`` runs one rollout with no host synchronisation once its caches are warm"""

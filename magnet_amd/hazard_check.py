@@ -324,6 +324,131 @@ def sgpr_and_lane_hazards(kernels) -> list[tuple[str, int, int, str, str]]:
     return bad
 
 
+# ------------------------------------------------------------------------------------------------ every control-flow path
+# The walks above are linear (+ the seams of backward branches).  A FORWARD branch that skips code makes the executed distance between
+# a writer in front of it and a reader behind its target SHORTER than the linear one: the skipped instructions are no wait states (an
+# `if (run ends here) { emit }` between an asm-written plane word and the MFMA that reads it).  path_hazards() therefore repeats the
+# register rules on the control-flow graph: from every reader it walks BACKWARDS along every path (fall-through and taken branches),
+# counting the wait states that path really executes, until the rule's distance is covered or a write of the register is found.
+def _cfg(ins):
+    """predecessors of every instruction: the previous one unless that is an unconditional branch / s_endpgm, plus every branch that
+    targets it"""
+    n = len(ins)
+    addr, target = getattr(ins, "addr", None) or [None] * n, getattr(ins, "target", None) or [None] * n
+    index_of = {a: i for i, a in enumerate(addr) if a is not None}
+    preds = [[] for _ in range(n)]
+    for i in range(n):
+        op = ins[i].split()[0]
+        if i + 1 < n and not op.startswith(("s_branch", "s_endpgm", "s_setpc", "s_trap")):
+            preds[i + 1].append(i)
+        if target[i] is not None and target[i] in index_of:
+            preds[index_of[target[i]]].append(i)
+    return preds
+
+
+def _parse(line):
+    op = line.split()[0]
+    args = [a.strip() for a in re.split(r",\s*", line[len(op):].strip())] if len(line) > len(op) else []
+    return op, args
+
+
+def _v_writes(op, args):
+    """VGPR / AGPR registers an instruction writes (loads included: they end a VALU-written state)"""
+    if not args:
+        return []
+    if op.startswith(("v_cmp", "v_readlane", "v_readfirstlane", "v_nop")):
+        return []
+    if op.startswith("v_permlane") and "swap" in op:
+        return _regs(args[0]) + (_regs(args[1]) if len(args) > 1 else [])
+    if op.startswith("v_") or op.startswith(("ds_read", "ds_load", "global_load", "buffer_load", "scratch_load", "flat_load")):
+        return _regs(args[0])
+    return []
+
+
+def _weight(op, args, mfma_passes=False):
+    if op == "s_nop":
+        return int(args[0], 0) + 1
+    if mfma_passes and op.startswith(("v_mfma", "v_smfmac")):
+        return _passes(op)
+    return 1
+
+
+def path_hazards(kernels) -> list[tuple[str, int, int, str, str]]:
+    """(kernel, index of the reader, wait states on the shortest offending path, the writer, the reader) for
+      * VALU write -> MFMA read (SrcA / SrcB / SrcC): 2 wait states;
+      * MFMA result -> VALU / LDS / VMEM read: passes + 2;
+      * transcendental result -> non-transcendental VALU read: 1;
+      * VALU write -> v_permlane* read: 2, -> v_readlane / v_readfirstlane read: 1
+    evaluated along EVERY path of the control-flow graph."""
+    bad = []
+    for name, ins in kernels:
+        parsed = [_parse(l) for l in ins]
+        writes = [set(_v_writes(op, a)) for op, a in parsed]
+        preds = _cfg(ins)
+
+        def search(k, regs, need, writer_ok, mfma_passes):
+            """shortest-path wait states from a hazardous writer of any of `regs` to instruction k; None when every path is long enough"""
+            worst = None
+            stack = [(p, 0, frozenset(regs)) for p in preds[k]]
+            seen = {}
+            while stack:
+                i, ws, live = stack.pop()
+                if ws >= need or not live:
+                    continue
+                key = (i, live)
+                if seen.get(key, 1 << 30) <= ws:
+                    continue
+                seen[key] = ws
+                op, a = parsed[i]
+                hit = writes[i] & live
+                if hit:
+                    if writer_ok(op):
+                        if worst is None or ws < worst[0]:
+                            worst = (ws, i)
+                    live = live - hit                  # any write ends the search for that register on this path
+                    if not live:
+                        continue
+                ws2 = ws + _weight(op, a, mfma_passes)
+                for p in preds[i]:
+                    stack.append((p, ws2, live))
+            return worst
+
+        is_mfma = lambda o: o.startswith(("v_mfma", "v_smfmac"))          # noqa: E731
+        is_valu = lambda o: o.startswith("v_") and not is_mfma(o)        # noqa: E731
+        for k, (op, a) in enumerate(parsed):
+            if is_mfma(op):
+                regs = [r for tok in a[1:4] for r in _regs(tok)]
+                w = search(k, regs, MIN_WAIT_STATES, is_valu, False)
+                if w:
+                    bad.append((name, k, w[0], ins[w[1]], ins[k]))
+                continue
+            reads = []
+            if op.startswith("v_permlane"):
+                reads = [r for tok in a[:2] for r in _regs(tok)]
+                w = search(k, reads, 2, is_valu, False)
+                if w:
+                    bad.append((name, k, w[0], ins[w[1]], ins[k]))
+            elif op.startswith(("v_readlane", "v_readfirstlane")):
+                reads = [r for tok in a[1:2] for r in _regs(tok)]
+                w = search(k, reads, 1, is_valu, False)
+                if w:
+                    bad.append((name, k, w[0], ins[w[1]], ins[k]))
+            if op.startswith("v_") or op.startswith(("ds_write", "ds_store", "global_store", "buffer_store", "flat_store", "scratch_store")):
+                srcs = a[1:] if op.startswith("v_") else a
+                regs = [r for tok in srcs for r in _regs(tok.split()[0] if tok else tok)]
+                if regs:
+                    # MFMA results: the longest rule first (the distance depends on the writer's passes: search with the 16-pass
+                    # bound and compare with what the writer found needs)
+                    w = search(k, regs, 18, is_mfma, True)
+                    if w and w[0] < _passes(parsed[w[1]][0]) + 2:
+                        bad.append((name, k, w[0], ins[w[1]], ins[k]))
+                    if op.startswith("v_") and not op.startswith(_TRANS):
+                        w = search(k, regs, 1, lambda o: o.startswith(_TRANS), False)
+                        if w:
+                            bad.append((name, k, w[0], ins[w[1]], ins[k]))
+    return bad
+
+
 def check(lib: str | None = None) -> list:
     """every violation of every rule in the linked library, loop seams included - [] is what ships"""
     from . import _lib
@@ -340,6 +465,11 @@ def check_kernels(k) -> list:
                 + sgpr_and_lane_hazards(body)):
         n, i, ws, w, m = hit
         if i >= first_behind[n] and (w, m) not in seen:       # the reader sits behind the seam: a pair the linear walk cannot see
+            found.append(hit)
+    seen = {(w, m) for _, _, _, w, m in found}
+    for hit in path_hazards(k):                               # ... and the pairs only a taken forward branch brings close enough
+        if (hit[3], hit[4]) not in seen:
+            seen.add((hit[3], hit[4]))
             found.append(hit)
     return found
 

@@ -103,7 +103,10 @@ class MPNN(LightningModule):
         self.edge_t32 = int(os.environ.get("MAGNET_EDGE_T32", "0")) if getattr(hparams, "edge_t32", True) else 0
         # fp16x3: the row-aligned kernel (k_mpnn_edge_rows32, generation 11) where the graph's rows are long enough to own tiles
         # (2-D meshes: 30 .. 33 edges per row); A/B knob, DESIGN.md 11.1
-        self.edge_rows = bool(int(os.environ.get("MAGNET_EDGE_ROWS", "0"))) and bool(getattr(hparams, "edge_rows", True))
+        # (2 = generation 12, k_mpnn_edge_rowsr: the same tiles with W2's planes resident in the accumulation registers; 3 = generation 12b,
+        #  k_mpnn_edge_rowsg: that + the rows' 33rd edges grouped with their rows - DESIGN.md 14.2)
+        self.edge_rows = int(getattr(hparams, "edge_rows", None) if getattr(hparams, "edge_rows", None) is not None
+                             else os.environ.get("MAGNET_EDGE_ROWS", "0"))
         self.node_update2 = bool(int(os.environ.get("MAGNET_NODE_UPDATE2", "1"))) and bool(getattr(hparams, "node_update2", True))
         # small batches (<= 128 rows): update + InstanceNorm of a hop in one launch (A/B knob)
         self.fused_small_norm = bool(int(os.environ.get("MAGNET_SMALL_NORM", "1"))) and bool(getattr(hparams, "fused_small_norm", True))
@@ -285,7 +288,7 @@ class MPNN(LightningModule):
             plan = self._row_plan(topo) if hasattr(lyr, "msg2_rows") else None
             if plan is not None:                  # tiles aligned to CSR rows (+ the remainder edges through k_mpnn_edge16)
                 ops.mpnn_edge_rows(A, Bm, csr, plan, lyr.msg2_t16[0], lyr.msg2_rows[0], lyr.msg2_t16[1], agg, partials, l2e=l2e,
-                                   single16=lyr.msg2_t16_single)
+                                   single16=lyr.msg2_t16_single, wreg=max(self.edge_rows - 1, 0))
             elif hasattr(lyr, "msg2_t32"):        # training forward too (plain halves: l2e is False with a tape)
                 ops.mpnn_edge32t(A, Bm, csr, lyr.msg2_t32[0], lyr.msg2_t32[1], agg, partials, l2e=l2e, paired=self.edge_t32 == 2)
             elif hasattr(lyr, "msg2_t16"):

@@ -337,8 +337,8 @@ EDGE_ENTRY = {torch.float16: "magnet_mpnn_edge_fp16x3_f32", torch.int16: "magnet
 EDGE_ENTRY_L2E = {torch.float16: "magnet_mpnn_edge_fp16x3_l2e_f32", torch.bfloat16: "magnet_mpnn_edge_bf16_l2e_f32"}
 # fp16x3 entry points with their own weight packs (ops.mpnn_edge16 ...), and the kernel behind every entry (bench.py names it)
 EDGE_ENTRY_EXTRA = ("magnet_mpnn_edge_fp16x3_t16_f32", "magnet_mpnn_edge_fp16x3_t32_f32", "magnet_mpnn_edge_fp16x3_ws_f32",
-                    "magnet_mpnn_edge_rows_fp16x3_f32")
-EDGE_KERNEL_OF_ENTRY = {"magnet_mpnn_edge_rows_fp16x3_f32": "k_mpnn_edge_rows32", "magnet_mpnn_edge_fp16x3_t16_f32": "k_mpnn_edge16", "magnet_mpnn_edge_fp16x3_t32_f32": "k_mpnn_edge32t", "magnet_mpnn_edge_fp16x3_ws_f32": "k_mpnn_edge_ws", "magnet_mpnn_edge_fp16x3_f32": "k_mpnn_edge7",
+                    "magnet_mpnn_edge_rows_fp16x3_f32", "magnet_mpnn_edge_rowsr_fp16x3_f32", "magnet_mpnn_edge_rowsg_fp16x3_f32")
+EDGE_KERNEL_OF_ENTRY = {"magnet_mpnn_edge_rowsg_fp16x3_f32": "k_mpnn_edge_rowsg", "magnet_mpnn_edge_rowsr_fp16x3_f32": "k_mpnn_edge_rowsr", "magnet_mpnn_edge_rows_fp16x3_f32": "k_mpnn_edge_rows32", "magnet_mpnn_edge_fp16x3_t16_f32": "k_mpnn_edge16", "magnet_mpnn_edge_fp16x3_t32_f32": "k_mpnn_edge32t", "magnet_mpnn_edge_fp16x3_ws_f32": "k_mpnn_edge_ws", "magnet_mpnn_edge_fp16x3_f32": "k_mpnn_edge7",
                         "magnet_mpnn_edge_fp16x3_l2e_f32": "k_mpnn_edge7", "magnet_mpnn_edge_bf16_f32": "k_mpnn_edge7",
                         "magnet_mpnn_edge_bf16_l2e_f32": "k_mpnn_edge7", "magnet_mpnn_edge_bf16x6_f32": "k_mpnn_edge6",
                         "magnet_mpnn_edge_f32": "k_mpnn_edge2"}
@@ -415,14 +415,10 @@ ROW_TILE_PMIN = 20                 # a partial tile costs a full one: shorter ro
 
 
 def row_tiles(csr: "CSR", pmin: int = ROW_TILE_PMIN) -> RowTiles:
-    """build the tile plan on the device (two launches, three prefix sums, one host read of the three counts)"""
+    """build the tile plan on the device (three launches - counts, their three prefix sums, the fill - and one host read of the counts)"""
     n, dev = csr.N, csr.rowptr.device
-    cnt = torch.empty(3, max(n, 1), dtype=torch.int32, device=dev)
-    L.check(L.lib().magnet_row_tiles_count(_p(csr.rowptr), n, int(pmin), _p(cnt[0]), _p(cnt[1]), _p(cnt[2]), _stream()),
-            "row_tiles_count")
-    ptr = torch.zeros(3, n + 1, dtype=torch.int32, device=dev)
-    if n:
-        ptr[:, 1:] = torch.cumsum(cnt[:, :n], 1, dtype=torch.int32)
+    ptr = torch.empty(3, n + 1, dtype=torch.int32, device=dev)
+    L.check(L.lib().magnet_row_tiles_ptrs(_p(csr.rowptr), n, int(pmin), _p(ptr), _stream()), "row_tiles_ptrs")   # counts + their scans
     n_tiles, n_strag, n_rem = (int(v) for v in ptr[:, -1].tolist())         # one host sync per plan
     tiles = torch.empty(max(n_tiles, 1), 4, dtype=torch.int32, device=dev)
     strag_row, strag_src = (torch.empty(max(n_strag, 1), dtype=torch.int32, device=dev) for _ in range(2))
@@ -434,7 +430,7 @@ def row_tiles(csr: "CSR", pmin: int = ROW_TILE_PMIN) -> RowTiles:
                     n_rem > 0 or n_tiles < n)
 
 
-def mpnn_edge_rows(A, Bm, csr, plan: RowTiles, w2_t16, w2_t32, b2, agg, partials, l2e=False, single16=False):
+def mpnn_edge_rows(A, Bm, csr, plan: RowTiles, w2_t16, w2_t32, b2, agg, partials, l2e=False, single16=False, wreg=False):
     """the fused edge op by the row-aligned kernel (k_mpnn_edge_rows32).  Up to three launches: the remainder edges through
     k_mpnn_edge16 (leaves their mean in agg and zeros in the rows it has no edge for; skipped when every row has a tile and nothing
     is left over - every 2-D MPNN mesh), then ONE launch in which every wave first sends the stragglers of its rows through the
@@ -444,7 +440,13 @@ def mpnn_edge_rows(A, Bm, csr, plan: RowTiles, w2_t16, w2_t32, b2, agg, partials
     assert w2_t32.dtype == torch.float16
     if plan.rem_pass:
         mpnn_edge16(A, Bm, plan.rem, w2_t16, b2, agg, partials, l2e=l2e, single=single16)
-    L.check(L.lib().magnet_mpnn_edge_rows_fp16x3_f32(_p(A), _p(Bm), _p(csr.src), _p(plan.tiles), plan.n_tiles,
+    if wreg == 2:     # generation 12b (k_mpnn_edge_rowsg): W2 in registers AND the stragglers grouped with their rows (no straggler lists)
+        L.check(L.lib().magnet_mpnn_edge_rowsg_fp16x3_f32(_p(A), _p(Bm), _p(csr.src), _p(plan.tiles), plan.n_tiles, int(plan.n_strag > 0),
+                                                          _p(w2_t32), _p(b2), _p(agg), int(l2e), _stream()), "mpnn_edge_rowsg_fp16x3")
+        return agg
+    # wreg: generation 12 (k_mpnn_edge_rowsr: W2's planes in the accumulation registers, one wave per SIMD) - same arguments
+    entry = L.lib().magnet_mpnn_edge_rowsr_fp16x3_f32 if wreg else L.lib().magnet_mpnn_edge_rows_fp16x3_f32
+    L.check(entry(_p(A), _p(Bm), _p(csr.src), _p(plan.tiles), plan.n_tiles,
                                                      _p(plan.strag_ptr) if plan.n_strag else None, _p(plan.strag_row), _p(plan.strag_src),
                                                      _p(w2_t32), _p(b2), _p(agg), int(l2e), _stream()),
             "mpnn_edge_rows_fp16x3")

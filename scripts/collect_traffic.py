@@ -21,8 +21,11 @@ KERNELS = {"k_mpnn_edge16": ("k_mpnn_edge16", True), "k_mpnn_edge7": ("k_mpnn_ed
            "k_segment_mean<128>": ("k_segment_mean<128>", False),
            "magnet_gnn:edge_mlp": ("k_mlp_bf16<1, 5, 4, 4, 2, false, true, 2", True),       # fp16x3, 5 Linears 128-wide, LN, CSR mean
            "magnet_cnn_2d:edge_mlp": ("k_mlp_bf16<3, 5, 2, 1, 2, false, true, 2", True),    # one-accumulator fp16x3s, 64-wide hidden, 32-wide output
-           "k_mpnn_edge_rows32": ("k_mpnn_edge_rows32", True), "k_node_update2": ("k_node_update2<9, true>", False),
-           "k_node_halves": ("k_node_halves<5>", False)}
+           "k_mpnn_edge_rows32": ("k_mpnn_edge_rows32", True), "k_mpnn_edge_rowsr": ("k_mpnn_edge_rowsr", True),
+           "k_mpnn_edge_rowsg": ("k_mpnn_edge_rowsg", True),
+           # the node-level kernels run on every mesh of the line (c1's 100 rows, the reference shapes, 48 x 48 ...): the headline launch
+           # is the one with the largest grid - averaged over all of them the figure was 47 MB for a 0.40 GB launch
+           "k_node_update2": ("k_node_update2<9, true>", True), "k_node_halves": ("k_node_halves<5>", True)}
 
 
 def mean_per_launch(d, counter):
@@ -40,7 +43,7 @@ def mean_per_launch(d, counter):
         if largest and v:
             g = max(x[0] for x in v)
             v = [x for x in v if x[0] == g]
-        out[k] = (sum(x[1] for x in v) / len(v) if v else None, len(v))
+        out[k] = (sum(x[1] for x in v) / len(v) if v else None, len(v), sorted({x[0] for x in v}))
     return out
 
 
@@ -54,7 +57,8 @@ def main():
         if fs[k][0] is None or ws[k][0] is None:
             continue
         rd, wr = 2.0 * fs[k][0] * 1024.0, ws[k][0] * 1024.0
-        res["kernels"][k] = {"read_bytes": rd, "write_bytes": wr, "traffic": rd + wr, "launches": [fs[k][1], ws[k][1]]}
+        res["kernels"][k] = {"read_bytes": rd, "write_bytes": wr, "traffic": rd + wr, "launches": [fs[k][1], ws[k][1]],
+                             "grid_sizes": fs[k][2], "largest_grid_only": KERNELS[k][1]}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 

@@ -9,7 +9,8 @@
 #   * headline only (rollout, no data-path collective):  ms per rollout per rank, world size the process group saw, distinct trajectory
 #     seeds / input checksums per rank, aggregate node-updates/s and its ratio to N x the N = 1 value;
 #   * three training steps: ms per step, allreduce_ms (one flat 2.1 MB gradient buffer: SURVEY.md 5 estimates ~35 us at 2 GPUs,
-#     ~250 us ring-bound at 8), and EQUAL parameter checksums on every rank after the last step (same averaged gradient, same Adam step).
+#     ~250 us ring-bound at 8), and EQUAL parameter checksums on every rank after the last step (same averaged gradient, same Adam step);
+#   * two training steps of the C5 case (magnet_gnn, 256 LR nodes + 256^2 queries): the same with a 10.3 MB gradient buffer.
 # Exit code 1 when any of that fails.
 set -u
 cd "$(dirname "$0")/.."
@@ -25,6 +26,9 @@ for N in 1 2 4 8; do
       > "$OUT/headline_n$N.json" 2> "$OUT/headline_n$N.err" || { echo "N=$N headline run FAILED (see $OUT/headline_n$N.err)"; rc=1; continue; }
   python bench.py --gpus $N --steps 2 --warmup 1 --no-cpu-baseline --no-extra-cases --no-precision-modes --train-steps 3 \
       > "$OUT/train_n$N.json" 2> "$OUT/train_n$N.err" || { echo "N=$N training run FAILED (see $OUT/train_n$N.err)"; rc=1; continue; }
+  # the larger gradient buffer: magnet_gnn C5 (2.57 M parameters = 10.3 MB per all-reduce; SURVEY.md 5 estimates 35 us direct / 250 us ring at 8)
+  python bench.py --gpus $N --workload magnet_gnn --traj 1 --steps 2 --warmup 1 --train-steps 2 \
+      > "$OUT/train_c5_n$N.json" 2> "$OUT/train_c5_n$N.err" || { echo "N=$N C5 training run FAILED (see $OUT/train_c5_n$N.err)"; rc=1; continue; }
 done
 python - "$OUT" <<'PY' || rc=1
 import glob, json, os, sys
@@ -48,6 +52,13 @@ for n in (1, 2, 4, 8):
         tr, sums = t["training_step"], t["dist"].get("param_abs_sum_by_rank_after_training", [])
         same = len(set(sums)) <= 1
         print(f"      training: {tr['ms_per_step']} ms/step, allreduce_ms {tr.get('allreduce_ms')}, parameter checksums equal on all ranks: {same}")
+        ok = ok and same
+    cp = os.path.join(out, f"train_c5_n{n}.json")
+    if os.path.exists(cp) and os.path.getsize(cp):
+        c = json.loads(open(cp).read().strip().splitlines()[-1])["training_step"]
+        same = c.get("param_abs_sum_max_over_ranks") == c.get("param_abs_sum_min_over_ranks")
+        print(f"      C5 (magnet_gnn) training: {c['ms_per_step']} ms/step, allreduce_ms {c.get('allreduce_ms')} for {c.get('allreduce_bytes')} bytes, "
+              f"parameter checksums equal on all ranks: {same}")
         ok = ok and same
 print("OK" if ok else "FAILED")
 sys.exit(0 if ok else 1)

@@ -349,3 +349,30 @@ def test_hazard_rules_for_sgprs_lane_ops_m0_and_loop_seams():
     assert len(hits) == 1 and "v_fma_mixhi_f16 v101" in hits[0][3]
     k2 = H.Kernel(body[:4] + ["s_nop 0", body[4]], addr=[0x100, 0x108, 0x10c, 0x110, 0x118, 0x11c], target=[None] * 5 + [0x100])
     assert [h for n, i, f in H.loop_seams([("k", k2)]) for h in H.violations([(n, i)]) if h[1] >= f] == []     # s_nop 0 + the branch = 2
+
+
+def test_hazard_rules_follow_taken_forward_branches():
+    """round 5: a FORWARD branch that skips code shortens the executed distance between a writer in front of it and a reader behind its
+    target - `plane word written by asm; if (run ends) { ... 30 instructions ... }; MFMA reads the word` passes a linear walk and is
+    one wait state short when the branch is taken.  path_hazards() walks the control-flow graph."""
+    from magnet_amd import hazard_check as H
+    body = ["v_fma_mixhi_f16 v101, v53, s7, 0",                                   # 0x100 writes an MFMA operand
+            "s_cbranch_scc0 8",                                                   # 0x108 -> 0x120: skips the two fillers
+            "v_add_f32_e32 v1, v2, v3",                                           # 0x10c
+            "v_add_f32_e32 v4, v2, v3",                                           # 0x110
+            "v_mfma_f32_32x32x16_f16 v[32:47], v[56:59], v[100:103], v[32:47]"]   # 0x120 reads it
+    k = H.Kernel(body, addr=[0x100, 0x108, 0x10c, 0x110, 0x120], target=[None, 0x120, None, None, None])
+    assert H.violations([("k", k)]) == []                                         # linear: branch + 2 fillers = 3 wait states
+    hits = H.path_hazards([("k", k)])
+    assert len(hits) == 1 and hits[0][2] == 1 and "v_fma_mixhi_f16 v101" in hits[0][3]      # taken: the branch alone
+    assert H.check_kernels([("k", k)])                                            # ... and check() reports it
+    k2 = H.Kernel([body[0], "s_nop 0"] + body[1:], addr=[0x100, 0x104, 0x108, 0x10c, 0x110, 0x120], target=[None, None, 0x120, None, None, None])
+    assert H.path_hazards([("k", k2)]) == []                                      # s_nop 0 + the branch = 2
+    # a load into the register in between ends the VALU-written state on that path
+    k3 = H.Kernel([body[0], "ds_read_b32 v101, v9"] + body[1:], addr=[0x100, 0x104, 0x108, 0x10c, 0x110, 0x120],
+                  target=[None, None, 0x120, None, None, None])
+    assert H.path_hazards([("k", k3)]) == []
+    # an MFMA result read by a VALU instruction behind a taken branch: passes + 2 wait states on THAT path
+    mf = ["v_mfma_f32_16x16x32_f16 v[0:3], v[8:11], v[12:15], v[0:3]", "s_cbranch_scc0 8"] + ["v_mov_b32_e32 v20, v21"] * 6 + ["v_add_f32_e32 v5, v0, v1"]
+    k4 = H.Kernel(mf, addr=[0x100, 0x108] + [0x10c + 4 * i for i in range(6)] + [0x130], target=[None, 0x130] + [None] * 7)
+    assert H.mfma_result_reads([("k", k4)]) == [] and len(H.path_hazards([("k", k4)])) == 1

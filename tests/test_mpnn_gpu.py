@@ -8,6 +8,10 @@ pytestmark = pytest.mark.gpu
 
 OUT_TOL = 1e-5      # relative L2 on the forward output (BASELINE.json north_star)
 INC_TOL = 1e-4      # relative L2 on the increment out - u_last ("hard parts")
+# what the fp32-class GEMM modes actually deliver on a 4-call rollout against the oracle is 5e-8 (bit-stable from run to run); the
+# tests that run a whole rollout hold them to 10 x that, not to the north-star bar - round 4 shipped a kernel that was off by 4e-6 .. 9e-6
+# in one rollout of ten (a missing barrier in k_node_update2) and every `< 1e-5` assertion let it through
+ROLLOUT_TOL = 5e-7
 
 
 def _models(tag, edge_gemm="fp16x3"):
@@ -48,11 +52,11 @@ def test_forward_and_rollout_match(tag, edge_gemm):
     assert rel_l2(y2, ref) < OUT_TOL
     # free-running rollout (validation_step semantics)
     pred = model.validation_step(cb, 0)
-    assert rel_l2(pred, d["val_pred"]) < 5 * OUT_TOL
+    assert rel_l2(pred, d["val_pred"]) < ROLLOUT_TOL
     assert abs(float(model.logged["val_mae_loss"]) - float(d["val_mae_loss"])) < 1e-5
     # and against the oracle run here
     with torch.no_grad():
-        assert rel_l2(pred, oracle.validation_step(batch)) < 5 * OUT_TOL
+        assert rel_l2(pred, oracle.validation_step(batch)) < ROLLOUT_TOL
 
 
 def test_forward_is_deterministic():
@@ -179,7 +183,54 @@ def test_large_graph_node_kernels_match_the_oracle_rollout():
     pred = model.validation_step({k: v.cuda() for k, v in batch.items()}, 0)
     with torch.no_grad():
         want = oracle.validation_step(batch)
-    assert rel_l2(pred, want) < 1e-5
+    err = rel_l2(pred, want)
+    print("48 x 48, B = 2 rollout vs oracle:", err)
+    assert err < ROLLOUT_TOL
+
+
+def test_repeated_large_graph_rollouts_are_bitwise_identical():
+    """the regression test of VERDICT round 4 item 1: k_node_update2 read its bias from LDS before the barrier that publishes it, and one
+    32-row block of about one launch in a hundred came out with a stale bias (rollout errors of 4e-6 .. 9e-6 in ~10 % of the 48 x 48
+    rollouts, found by scripts/stress_precision_leg.py).  150 rollouts on the same batch: every one bitwise equal to the first, in
+    both node-update kernels (the one-accumulator k_node_update2 and the two-accumulator k_node_update behind node_update2=False)."""
+    import types
+    import bench
+    from magnet_amd.models.factory import FACTORY
+    for knob in (True, False):
+        torch.manual_seed(0)
+        model = FACTORY["mpnn_2d"](types.SimpleNamespace(**bench.HP, hip_graph=False, node_update2=knob)).cuda().eval()
+        batch = {k: v.cuda() for k, v in bench.synthetic_batch(48, 1, 5, "cpu").items()}
+        first = model.validation_step(batch, 0).clone()
+        bad = [r for r in range(150) if not torch.equal(model.validation_step(batch, 0), first)]
+        assert not bad, (knob, bad)
+
+
+def test_gemm_modes_agree_on_a_reused_model_with_a_rebuilt_graph():
+    """bench.py's precision leg as a test: a model that has just replayed a LARGER captured rollout (hip_graph="rebuild") runs a 48 x 48
+    batch - first capture of a new shape, first replay - and must agree with a fresh eager bf16x6 model on the same weights to 1e-6,
+    and with the oracle to ROLLOUT_TOL; three times (capture, replay, replay)."""
+    import types
+    import bench
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    torch.manual_seed(0)
+    model = FACTORY["mpnn_2d"](types.SimpleNamespace(**bench.HP, hip_graph="rebuild")).cuda().eval()
+    big = {k: v.cuda() for k, v in bench.synthetic_batch(96, 2, 3, "cpu").items()}
+    for _ in range(3):
+        model.validation_step(big, 0)
+    wide = FACTORY["mpnn_2d"](types.SimpleNamespace(**dict(bench.HP, edge_gemm="bf16x6", gemm="bf16x6"), hip_graph=False)).cuda().eval()
+    wide.load_state_dict(model.state_dict())
+    oracle = O.build("mpnn_2d", types.SimpleNamespace(**bench.HP)).eval()
+    oracle.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    small = bench.synthetic_batch(48, 1, 5, "cpu")
+    with torch.no_grad():
+        want = oracle.validation_step(small)
+    sd = {k: v.cuda() for k, v in small.items()}
+    ref = wide.validation_step(sd, 0)
+    for _ in range(3):
+        got = model.validation_step(sd, 0)
+        assert rel_l2(got, ref) < 1e-6
+        assert rel_l2(got, want) < ROLLOUT_TOL
 
 
 # ------------------------------------------------------------------------------------------- the reference's own batch sizes
@@ -211,7 +262,7 @@ def test_mpnn_1d_batch_32_matches_the_oracle(hip_graph):
     pred = model.validation_step({k: v.cuda() for k, v in batch.items()}, 0)
     with torch.no_grad():
         want = oracle.validation_step(batch)
-    assert pred.shape == want.shape and rel_l2(pred, want) < OUT_TOL
+    assert pred.shape == want.shape and rel_l2(pred, want) < ROLLOUT_TOL
 
 
 def test_mpnn_2d_batch_8_at_64x64_matches_the_oracle():
@@ -232,7 +283,7 @@ def test_mpnn_2d_batch_8_at_64x64_matches_the_oracle():
     pred = model.validation_step({k: v.cuda() for k, v in batch.items()}, 0)
     with torch.no_grad():
         want = oracle.validation_step(batch)
-    assert rel_l2(pred, want) < OUT_TOL
+    assert rel_l2(pred, want) < ROLLOUT_TOL
 
 
 def test_more_than_eight_large_graphs_cross_the_node_kernel_boundary():
@@ -257,7 +308,7 @@ def test_more_than_eight_large_graphs_cross_the_node_kernel_boundary():
     pred = model.validation_step(cb, 0)
     with torch.no_grad():
         want = oracle.validation_step({k: v[:3] for k, v in batch.items()})     # three samples are enough for the CPU side
-    assert rel_l2(pred[:3], want) < OUT_TOL
+    assert rel_l2(pred[:3], want) < ROLLOUT_TOL
     halves = torch.cat([model.validation_step({k: v[i:i + 5] for k, v in cb.items()}, 0) for i in (0, 5)], 0)
     assert rel_l2(pred, halves) < 2e-6
 
