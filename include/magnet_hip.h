@@ -232,7 +232,14 @@ int magnet_mpnn_edge_rowsr_fp16x3_f32(const float* A, const float* Bm, const int
 int magnet_mpnn_edge_rowsg_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const void* tiles, int n_tiles,
                                       int has_stragglers, const void* w2_t32, const float* b2, float* agg, int a_bm_log2e_scaled,
                                       void* stream);
-/* The tile plan of a CSR graph for the three kernels above.  _count, per row r: has_tile[r] = (deg_r >= pmin); has_strag[r] = the row has a
+/* Generation 13 (k_mpnn_edge_rowsp): W2's planes in the accumulation registers, one wave per SIMD, the tile's 96 MFMAs in
+ * four sub-phases with the previous tile's epilogue and the next tile's input production between them; every row parks the activations
+ * of its 33rd edge in LDS and a group's 32 parked edges run as one tile behind the group.  Arguments and contract as
+ * magnet_mpnn_edge_rowsg_fp16x3_f32. */
+int magnet_mpnn_edge_rowsp_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const void* tiles, int n_tiles,
+                                      int has_stragglers, const void* w2_t32, const float* b2, float* agg, int a_bm_log2e_scaled,
+                                      void* stream);
+/* The tile plan of a CSR graph for the four kernels above.  _count, per row r: has_tile[r] = (deg_r >= pmin); has_strag[r] = the row has a
  * tile and exactly one edge beyond it; n_rem[r] = its edges for the remainder pass (those outside the tile unless that is the one
  * straggler; all of them without a tile).  _fill: given the exclusive prefix sums tile_ptr / strag_ptr / rem_ptr [n_rows + 1] of the
  * three arrays, writes the descriptors, the straggler list and the remainder edge list

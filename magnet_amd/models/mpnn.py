@@ -104,7 +104,8 @@ class MPNN(LightningModule):
         # fp16x3: the row-aligned kernel (k_mpnn_edge_rows32, generation 11) where the graph's rows are long enough to own tiles
         # (2-D meshes: 30 .. 33 edges per row); A/B knob, DESIGN.md 11.1
         # (2 = generation 12, k_mpnn_edge_rowsr: the same tiles with W2's planes resident in the accumulation registers; 3 = generation 12b,
-        #  k_mpnn_edge_rowsg: that + the rows' 33rd edges grouped with their rows - DESIGN.md 14.2)
+        #  k_mpnn_edge_rowsg: that + the rows' 33rd edges grouped with their rows; 4 = generation 13, k_mpnn_edge_rowsp: one software
+        #  pipeline per wave - DESIGN.md 14.2)
         self.edge_rows = int(getattr(hparams, "edge_rows", None) if getattr(hparams, "edge_rows", None) is not None
                              else os.environ.get("MAGNET_EDGE_ROWS", "0"))
         self.node_update2 = bool(int(os.environ.get("MAGNET_NODE_UPDATE2", "1"))) and bool(getattr(hparams, "node_update2", True))

@@ -337,8 +337,8 @@ EDGE_ENTRY = {torch.float16: "magnet_mpnn_edge_fp16x3_f32", torch.int16: "magnet
 EDGE_ENTRY_L2E = {torch.float16: "magnet_mpnn_edge_fp16x3_l2e_f32", torch.bfloat16: "magnet_mpnn_edge_bf16_l2e_f32"}
 # fp16x3 entry points with their own weight packs (ops.mpnn_edge16 ...), and the kernel behind every entry (bench.py names it)
 EDGE_ENTRY_EXTRA = ("magnet_mpnn_edge_fp16x3_t16_f32", "magnet_mpnn_edge_fp16x3_t32_f32", "magnet_mpnn_edge_fp16x3_ws_f32",
-                    "magnet_mpnn_edge_rows_fp16x3_f32", "magnet_mpnn_edge_rowsr_fp16x3_f32", "magnet_mpnn_edge_rowsg_fp16x3_f32")
-EDGE_KERNEL_OF_ENTRY = {"magnet_mpnn_edge_rowsg_fp16x3_f32": "k_mpnn_edge_rowsg", "magnet_mpnn_edge_rowsr_fp16x3_f32": "k_mpnn_edge_rowsr", "magnet_mpnn_edge_rows_fp16x3_f32": "k_mpnn_edge_rows32", "magnet_mpnn_edge_fp16x3_t16_f32": "k_mpnn_edge16", "magnet_mpnn_edge_fp16x3_t32_f32": "k_mpnn_edge32t", "magnet_mpnn_edge_fp16x3_ws_f32": "k_mpnn_edge_ws", "magnet_mpnn_edge_fp16x3_f32": "k_mpnn_edge7",
+                    "magnet_mpnn_edge_rows_fp16x3_f32", "magnet_mpnn_edge_rowsr_fp16x3_f32", "magnet_mpnn_edge_rowsg_fp16x3_f32", "magnet_mpnn_edge_rowsp_fp16x3_f32")
+EDGE_KERNEL_OF_ENTRY = {"magnet_mpnn_edge_rowsp_fp16x3_f32": "k_mpnn_edge_rowsp", "magnet_mpnn_edge_rowsg_fp16x3_f32": "k_mpnn_edge_rowsg", "magnet_mpnn_edge_rowsr_fp16x3_f32": "k_mpnn_edge_rowsr", "magnet_mpnn_edge_rows_fp16x3_f32": "k_mpnn_edge_rows32", "magnet_mpnn_edge_fp16x3_t16_f32": "k_mpnn_edge16", "magnet_mpnn_edge_fp16x3_t32_f32": "k_mpnn_edge32t", "magnet_mpnn_edge_fp16x3_ws_f32": "k_mpnn_edge_ws", "magnet_mpnn_edge_fp16x3_f32": "k_mpnn_edge7",
                         "magnet_mpnn_edge_fp16x3_l2e_f32": "k_mpnn_edge7", "magnet_mpnn_edge_bf16_f32": "k_mpnn_edge7",
                         "magnet_mpnn_edge_bf16_l2e_f32": "k_mpnn_edge7", "magnet_mpnn_edge_bf16x6_f32": "k_mpnn_edge6",
                         "magnet_mpnn_edge_f32": "k_mpnn_edge2"}
@@ -440,8 +440,10 @@ def mpnn_edge_rows(A, Bm, csr, plan: RowTiles, w2_t16, w2_t32, b2, agg, partials
     assert w2_t32.dtype == torch.float16
     if plan.rem_pass:
         mpnn_edge16(A, Bm, plan.rem, w2_t16, b2, agg, partials, l2e=l2e, single=single16)
-    if wreg == 2:     # generation 12b (k_mpnn_edge_rowsg): W2 in registers AND the stragglers grouped with their rows (no straggler lists)
-        L.check(L.lib().magnet_mpnn_edge_rowsg_fp16x3_f32(_p(A), _p(Bm), _p(csr.src), _p(plan.tiles), plan.n_tiles, int(plan.n_strag > 0),
+    if wreg >= 2:     # generation 12b (k_mpnn_edge_rowsg): W2 in registers AND the stragglers grouped with their rows (no straggler lists);
+        #               3 = generation 13 (k_mpnn_edge_rowsp): that as one software pipeline per wave (epilogue / production between the MFMAs)
+        entry = L.lib().magnet_mpnn_edge_rowsp_fp16x3_f32 if wreg == 3 else L.lib().magnet_mpnn_edge_rowsg_fp16x3_f32
+        L.check(entry(_p(A), _p(Bm), _p(csr.src), _p(plan.tiles), plan.n_tiles, int(plan.n_strag > 0),
                                                           _p(w2_t32), _p(b2), _p(agg), int(l2e), _stream()), "mpnn_edge_rowsg_fp16x3")
         return agg
     # wreg: generation 12 (k_mpnn_edge_rowsr: W2's planes in the accumulation registers, one wave per SIMD) - same arguments

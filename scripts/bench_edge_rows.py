@@ -54,7 +54,10 @@ for pmin in [int(v) for v in os.environ.get("PMIN", "20").split(",")]:
         ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e)
         err = float((agg - ref).norm() / ref.norm())
         nan = int(torch.isnan(agg).sum())
-        res = {"edge16": [], "rows": [], "rows_tiles_only": [], "rowsr": [], "rowsr_tiles_only": [], "rowsg": []}
+        res = {"edge16": [], "rows": [], "rows_tiles_only": [], "rowsr": [], "rowsr_tiles_only": [], "rowsg": [], "rowsp": []}
+        agg.fill_(float("nan"))
+        ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e, wreg=3)
+        err_p, nan_p = float((agg - ref).norm() / ref.norm()), int(torch.isnan(agg).sum())
         agg.fill_(float("nan"))
         ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e, wreg=2)
         err_g, nan_g = float((agg - ref).norm() / ref.norm()), int(torch.isnan(agg).sum())
@@ -79,11 +82,12 @@ for pmin in [int(v) for v in os.environ.get("PMIN", "20").split(",")]:
             res["rowsr"].append(timeit(lambda: ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e, wreg=True)))
             res["rowsr_tiles_only"].append(timeit(tiles_only_r))
             res["rowsg"].append(timeit(lambda: ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e, wreg=2)))
+            res["rowsp"].append(timeit(lambda: ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e, wreg=3)))
         fl = 2 * E * H * H * 3
         line = "  ".join(f"{k} " + "/".join(f"{v:.4f}" for v in vs) for k, vs in res.items())
         best = min(res["rows"])
-        print(f"  l2e={l2e}: rel-diff vs fp32 kernel {err:.2e} nan={nan} (rowsr {err_r:.2e} nan={nan_r}, rowsg {err_g:.2e} nan={nan_g}) | ms per launch: {line} | frac of 2.5 PF: "
-              f"rows {fl / best / 1e12 / 2500:.3f}, rowsr {fl / min(res['rowsr']) / 1e12 / 2500:.3f}, rowsg {fl / min(res['rowsg']) / 1e12 / 2500:.3f}, edge16 {fl / min(res['edge16']) / 1e12 / 2500:.3f}")
+        print(f"  l2e={l2e}: rel-diff vs fp32 kernel {err:.2e} nan={nan} (rowsr {err_r:.2e} nan={nan_r}, rowsg {err_g:.2e} nan={nan_g}, rowsp {err_p:.2e} nan={nan_p}) | ms per launch: {line} | frac of 2.5 PF: "
+              f"rows {fl / best / 1e12 / 2500:.3f}, rowsr {fl / min(res['rowsr']) / 1e12 / 2500:.3f}, rowsg {fl / min(res['rowsg']) / 1e12 / 2500:.3f}, rowsp {fl / min(res['rowsp']) / 1e12 / 2500:.3f}, edge16 {fl / min(res['edge16']) / 1e12 / 2500:.3f}")
 
 if os.environ.get("MAGNET_DEV_LIB", "0") == "1":          # ablations of the main kernel (development library; results invalid)
     import ctypes as C

@@ -297,7 +297,7 @@ def test_mpnn_edge_log2e_scaled_inputs_give_the_same_mean():
 @pytest.mark.parametrize("case", ["ragged", "no_edges", "under_one_tile", "one_row_owns_everything", "every_row_one_edge",
                                   "small_values", "mpnn_like"])
 @pytest.mark.parametrize("l2e", [False, True])
-@pytest.mark.parametrize("kernel", ["edge16", "edge16s", "edge32t", "edge32p", "edgews", "rows", "rowsr", "rowsg"])
+@pytest.mark.parametrize("kernel", ["edge16", "edge16s", "edge32t", "edge32p", "edgews", "rows", "rowsr", "rowsg", "rowsp"])
 def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
     """k_mpnn_edge16 (16-edge tiles, v_mfma_f32_16x16x32_f16, two waves per SIMD, its own weight fragment order) and k_mpnn_edge32t
     (generation 9: transposed 32-edge tiles, lane = output feature, one accumulator, unscaled fp16-subnormal low pieces) against a
@@ -342,7 +342,7 @@ def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
     if kernel in ("edge16", "edge16s"):       # edge16s: the one-accumulator variant (planes pre-scaled by 2^11)
         w, b = pack_edge16_fp16x2(lin.weight.cuda(), lin.bias.cuda(), scaled=kernel == "edge16s")
         ops.mpnn_edge16(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e, single=kernel == "edge16s")
-    elif kernel in ("rows", "rowsr", "rowsg"):         # generation 11: tiles aligned to CSR rows + the remainder edges through k_mpnn_edge16
+    elif kernel in ("rows", "rowsr", "rowsg", "rowsp"):         # generation 11: tiles aligned to CSR rows + the remainder edges through k_mpnn_edge16
         # (rowsr: generation 12, the same tiles with W2's planes resident in the accumulation registers; rowsg: 12b, + grouped stragglers)
         w16, b = pack_edge16_fp16x2(lin.weight.cuda(), lin.bias.cuda())
         w32, _ = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
@@ -352,7 +352,7 @@ def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
         left = deg - torch.where(has, deg.clamp(max=32), 0)
         strag = has & (left == 1)
         assert plan.n_tiles == int(has.sum()) and plan.n_strag == int(strag.sum()) and plan.rem.E == int(left[~strag].sum())
-        ops.mpnn_edge_rows(A.cuda() * scale, Bm.cuda() * scale, csr, plan, w16, w32, b, agg, partials, l2e=l2e, wreg={"rows": 0, "rowsr": 1, "rowsg": 2}[kernel])
+        ops.mpnn_edge_rows(A.cuda() * scale, Bm.cuda() * scale, csr, plan, w16, w32, b, agg, partials, l2e=l2e, wreg={"rows": 0, "rowsr": 1, "rowsg": 2, "rowsp": 3}[kernel])
     elif kernel == "edgews":                  # generation 10: wave-specialised (gather / GEMM / epilogue waves through LDS)
         w, b = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
         ops.mpnn_edge_ws(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e)
