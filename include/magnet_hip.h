@@ -475,6 +475,10 @@ int magnet_euler_update_bwd_f32(const float* dout, const float* t, int t_ld, int
  * workspace: (2*n_graphs*ceil(rows/128) + 2*n_graphs)*H floats */
 int magnet_instance_norm_bwd_f32(const float* dy, const float* yhat, const float* var, int n_graphs, int rows_per_graph,
                                  int H, float eps, float* dx, float* workspace, void* stream);
+/* ... for graphs of unequal size: graph g owns rows gptr[g] .. gptr[g + 1] (PyG's InstanceNorm(x, batch), models/mpnn.py:63,70); yhat and var
+ * [n_graphs][H] as magnet_instance_norm_ragged_f32 left them.  No workspace. */
+int magnet_instance_norm_ragged_bwd_f32(const float* dy, const float* yhat, const float* var, const int32_t* gptr, int n_graphs, int H,
+                                        float eps, float* dx, void* stream);
 /* backward of the Conv1d read-out + Euler update (mpnn.py:197-201): dh [n,128], du_last [n] (= d u[:, tw-1]),
  * gpart [min(1024, ceil(n/4))][8*k1+8+8*k2+1] partial gradients laid out [dw1 | db1 | dw2 | db2] */
 int magnet_mpnn_readout_bwd_f32(const float* h, const float* dout, int n, int tw, const float* w1, const float* b1,

@@ -895,6 +895,51 @@ extern "C" int magnet_instance_norm_bwd_f32(const float* dy, const float* yhat, 
                        eps, total, dx);
     END();
 }
+// The same for graphs of UNEQUAL size (graph g = rows gptr[g] .. gptr[g + 1]; PyG's InstanceNorm(x, batch) takes any batch vector,
+// models/mpnn.py:63,70): one workgroup per (graph, 32-channel window), 32 row groups x 32 channels, two passes over the graph's rows -
+// the column means of dy and of dy * yhat in a fixed summation order, then dx = (dy - mean(dy) - yhat mean(dy yhat)) / sqrt(var + eps).
+__global__ void __launch_bounds__(1024) k_instance_norm_ragged_bwd(const float* __restrict__ dy, const float* __restrict__ yhat,
+                                                                   const float* __restrict__ var, const int32_t* __restrict__ gptr, int H,
+                                                                   float eps, float* __restrict__ dx) {
+    __shared__ float s1[32][33], s2[32][33];
+    __shared__ float stat[2][32];
+    const int g = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, grp = threadIdx.x >> 5;
+    const int r0 = gptr[g], nr = gptr[g + 1] - r0;
+    if (nr <= 0) return;
+    const float* dg = dy + (size_t)r0 * H;
+    const float* yg = yhat + (size_t)r0 * H;
+    float a1 = 0.f, a2 = 0.f;
+    if (c < H)
+        for (int r = grp; r < nr; r += 32) {
+            const float d = dg[(size_t)r * H + c];
+            a1 += d;
+            a2 = fmaf(d, yg[(size_t)r * H + c], a2);
+        }
+    s1[grp][cl] = a1, s2[grp][cl] = a2;
+    __syncthreads();
+    if (grp == 0) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) t1 += s1[q][cl], t2 += s2[q][cl];
+        stat[0][cl] = t1 / (float)nr, stat[1][cl] = t2 / (float)nr;
+    }
+    __syncthreads();
+    if (c < H) {
+        const float m1 = stat[0][cl], m2 = stat[1][cl], is = 1.0f / sqrtf(var[(size_t)g * H + c] + eps);
+        float* xg = dx + (size_t)r0 * H;
+        for (int r = grp; r < nr; r += 32) {
+            const size_t o = (size_t)r * H + c;
+            xg[o] = (dg[o] - m1 - yg[o] * m2) * is;
+        }
+    }
+}
+extern "C" int magnet_instance_norm_ragged_bwd_f32(const float* dy, const float* yhat, const float* var, const int32_t* gptr, int n_graphs,
+                                                   int H, float eps, float* dx, void* stream) {
+    BEGIN();
+    if (n_graphs <= 0) return 0;
+    hipLaunchKernelGGL(k_instance_norm_ragged_bwd, dim3(n_graphs, nb(H, 32)), dim3(1024), 0, S_, dy, yhat, var, gptr, H, eps, dx);
+    END();
+}
 // gpart: [min(1024, ceil(n/4))][8*k1 + 8 + 8*k2 + 1] partial parameter gradients (reduce with magnet_reduce_partials_f32)
 extern "C" int magnet_mpnn_readout_bwd_f32(const float* h, const float* dout, int n, int tw, const float* w1, const float* b1,
                                            int k1, int s1, const float* w2, int k2, int use_swish, const float* dt, float* dh,

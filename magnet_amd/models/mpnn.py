@@ -228,9 +228,18 @@ class MPNN(LightningModule):
         return P
 
     # ------------------------------------------------------------------ forward (mpnn.py:175-203)
-    @torch.no_grad()
     def forward(self, data, L, tmax, dt):
-        return self._forward(data, L, tmax, dt, None)
+        """mpnn.py:175-203.  With gradients enabled (and parameters that want one) the result carries a grad_fn, as the reference's
+        does: ``loss.backward()`` runs the HIP backward of this one call (models/mpnn_backward.py) and fills the parameters' ``.grad``
+        and the gradient of ``data.x`` - custom training loops that call the model directly (in ``train()`` mode), foreign PyG-style Data
+        included (graphs of unequal size too).  training_step / validation_step do not come through here."""
+        # (train() mode only: eval-mode calls - validation, benchmarks - keep the inference kernels and the hipGraph replay even when
+        #  the caller has not wrapped them in torch.no_grad())
+        if self.training and torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or data.x.requires_grad):
+            from .mpnn_backward import forward_with_grad
+            return forward_with_grad(self, data, L, tmax, dt)
+        with torch.no_grad():
+            return self._forward(data, L, tmax, dt, None)
 
     def _forward(self, data, L, tmax, dt, tape):
         """``tape`` (training only): a namespace that receives what the backward needs - per layer the input h, the
@@ -243,8 +252,6 @@ class MPNN(LightningModule):
         topo = self._topology_of(data, N)
         csr, B, Ns = topo.csr, topo.n_graphs, topo.nodes_per_graph
         gptr = getattr(topo, "gptr", None)                     # set only for batches of UNEQUAL graphs (foreign PyG Data)
-        if gptr is not None and tape is not None:
-            raise NotImplementedError("training on a batch of unequal graphs: the InstanceNorm backward assumes equal blocks")
         P = self._packed()
         as_t = lambda v: v.to(dev).float().reshape(-1) if torch.is_tensor(v) else torch.tensor([float(v)], device=dev)  # noqa: E731
         Lv, tm, dtv = as_t(L), as_t(tmax), as_t(dt)
@@ -260,7 +267,7 @@ class MPNN(LightningModule):
         T = ops.Term
         ops.mlp(N, ops.ktiles(T(node_in, kin)), P.emb, nl=2, ht=4, ot=4, act=ops.ACT_SWISH, last_act=True, y=h)
         if tape is not None:
-            tape.topo, tape.node_in, tape.u, tape.dt, tape.layers = topo, node_in, u, dtv, []
+            tape.topo, tape.node_in, tape.u, tape.dt, tape.layers, tape.gptr = topo, node_in, u, dtv, [], gptr
         # large graphs, inference: the InstanceNorm of hop l is never applied as a pass of its own - hop l+1's per-node-halves
         # kernel and its update kernel normalise the raw update output while they load it (ops.mpnn_node_halves: weights resident
         # in LDS; ops.mpnn_node_update: persistent, W2 resident); only the statistics are computed in between, and the last hop's
@@ -318,8 +325,13 @@ class MPNN(LightningModule):
                 keep = (new(), new()) if tape is not None and lyr.upd1[0].dtype in (torch.float16, torch.int16) else None
                 ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
                         act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g, hid=list(keep) if keep else None)
-            if gptr is not None:
+            if gptr is not None and tape is None:
                 ops.instance_norm_ragged(g, gptr, out=h)
+            elif gptr is not None:          # unequal graphs with a tape: the same record, the backward takes its rows from gptr
+                h_in = h
+                h, var = ops.instance_norm_ragged(g, gptr, out=new(), return_var=True)
+                tape.layers.append(types.SimpleNamespace(h_in=h_in, A=A, Bm=Bm, agg=agg, var=var, h_out=h,
+                                                         r1=keep[0] if keep else None, z2=keep[1] if keep else None))
             elif tape is None:
                 ops.instance_norm(g, B, Ns, out=h)
             else:
@@ -459,7 +471,8 @@ class MPNN(LightningModule):
                 tapes.append(types.SimpleNamespace())
                 y = self._forward(graph, x[0, -1], t[0, -1], dt, tapes[-1])
             else:
-                y = self.forward(graph, x[0, -1], t[0, -1], dt)
+                with torch.no_grad():
+                    y = self._forward(graph, x[0, -1], t[0, -1], dt, None)
             y_hat = y.reshape(B, N, -1).permute(0, 2, 1)
             u_hat.append(y_hat)
             nxt = u[:, (i + 1) * tw:(i + 2) * tw] if teacher_forcing else y_hat

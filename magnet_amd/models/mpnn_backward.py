@@ -153,7 +153,10 @@ def backward_call(m, tape, dout, G, ws):
     lbw = None
     for li in reversed(range(len(P.layers))):
         lyr, qb, tp, g = P.layers[li], Q.layers[li], tape.layers[li], G.layers[li]
-        dg = ops.instance_norm_bwd(dh, tp.h_out, tp.var, B, Ns)
+        if getattr(tape, "gptr", None) is not None:                      # foreign Data with graphs of unequal size
+            dg = ops.instance_norm_ragged_bwd(dh, tp.h_out, tp.var, tape.gptr)
+        else:
+            dg = ops.instance_norm_bwd(dh, tp.h_out, tp.var, B, Ns)
         # ---- update MLP (recomputed pre-activations)                                 mpnn.py:81-90
         lin(N, ops.ktiles(T(tp.h_in, H), T(tp.agg, H), T(nin, kin)), lyr.upd1, z1)
         if getattr(tp, "r1", None) is not None:                           # kept by the forward launch
@@ -313,3 +316,39 @@ def rollout_with_grad(m, batch, teacher_forcing=False):
     u_hat = _Rollout.apply(m, batch, teacher_forcing, *m.parameters())
     target, m._last_target = m._last_target, None
     return u_hat, target
+
+
+class _Forward(torch.autograd.Function):
+    """out = forward(data, L, tmax, dt) with a grad_fn: the backward of ONE forward call (the reference's forward is an ordinary
+    differentiable torch function, models/mpnn.py:175-203; Lightning never calls it with gradients on, a custom loop may)."""
+
+    @staticmethod
+    def forward(ctx, m, data, L_, tmax, dt, x, *params):
+        tape = types.SimpleNamespace()
+        with torch.no_grad():
+            out = m._forward(data, L_, tmax, dt, tape)
+        why = m._guard.tripped()
+        if why:                                # out of the fp16 pieces' range: the same forward (and its tape) in the full-range split
+            m._widen(why)
+            tape = types.SimpleNamespace()
+            with torch.no_grad():
+                out = m._forward(data, L_, tmax, dt, tape)
+        ctx.m, ctx.tape = m, tape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        m, tape = ctx.m, ctx.tape
+        dev = dout.device
+        with torch.no_grad():
+            G = _grad_buffers(m, dev)
+            csr = tape.topo.csr
+            ws = ops.wgrad_workspace(max(csr.N, csr.E), dev)
+            du = backward_call(m, tape, dout.float().contiguous(), G, ws)
+            grads = parameter_grads(m, G)
+        ctx.tape = None
+        return (None, None, None, None, None, du if ctx.needs_input_grad[5] else None, *grads)
+
+
+def forward_with_grad(m, data, L_, tmax, dt):
+    return _Forward.apply(m, data, L_, tmax, dt, data.x, *m.parameters())

@@ -490,7 +490,7 @@ def instance_norm(x, n_graphs, rows_per_graph, eps=1e-5, out=None, return_var=Fa
     return out
 
 
-def instance_norm_ragged(x, gptr, eps=1e-5, out=None):
+def instance_norm_ragged(x, gptr, eps=1e-5, out=None, return_var=False):
     """per-graph InstanceNorm for graphs of unequal size: graph g owns rows gptr[g] .. gptr[g + 1] (int32, device)"""
     x = _f32(x, "x")
     ng, h = gptr.numel() - 1, x.shape[1]
@@ -498,6 +498,13 @@ def instance_norm_ragged(x, gptr, eps=1e-5, out=None):
     stats = torch.empty(2, max(ng, 1), h, device=x.device, dtype=torch.float32)
     L.check(L.lib().magnet_instance_norm_ragged_f32(_p(x), _p(_i32(gptr)), ng, h, C.c_float(float(eps)), _p(out), _p(stats[0]),
                                                     _p(stats[1]), _stream()), "instance_norm_ragged")
+    return (out, stats[1]) if return_var else out           # (biased variance [n_graphs, h]: kept for the backward)
+
+
+def instance_norm_ragged_bwd(dy, yhat, var, gptr, eps=1e-5, out=None):
+    out = torch.empty_like(dy) if out is None else out
+    L.check(L.lib().magnet_instance_norm_ragged_bwd_f32(_p(dy), _p(yhat), _p(var), _p(_i32(gptr)), gptr.numel() - 1, dy.shape[1],
+                                                        C.c_float(float(eps)), _p(out), _stream()), "instance_norm_ragged_bwd")
     return out
 
 

@@ -926,3 +926,53 @@ def test_a_frozen_hidden_linear_gets_no_gradient_from_the_accumulating_backward(
     assert len(frozen_names) == 2, frozen_names
     worst = max(rel_l2(grads[True][n], grads[False][n]) for n in grads[True] if n not in frozen_names)
     assert worst < 2e-6, worst
+
+
+@pytest.mark.parametrize("unequal", [False, True])
+def test_forward_is_differentiable_like_the_reference(unequal):
+    """models/mpnn.py:175-203 is an ordinary differentiable torch function: a custom loop may call model(data, L, tmax, dt) in train()
+    mode and backpropagate a loss of its own.  Here: parameter gradients and the gradient of data.x of ONE forward call against torch
+    autograd through the oracle, on the golden 1-D graph and on a foreign Data of three graphs of UNEQUAL size (PyG's
+    InstanceNorm(x, batch) takes any batch vector; training on such a batch raised NotImplementedError before round 5)."""
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.pyg_semantics import radius_graph
+    from oracle.weightgen import fill_state_dict
+    name, hp, salt, batch, d = load_case("mpnn_1d")
+    oracle = O.build(name, hp)
+    fill_state_dict(oracle, salt)
+    model = FACTORY[name](hp)
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda().train()
+    tw = hp.time_window
+    g = torch.Generator().manual_seed(4)
+    sizes = [37, 64, 21] if unequal else [40, 40]
+    xs = [torch.linspace(0, 16, n) for n in sizes]
+    pos_x = torch.cat(xs)
+    bvec = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(sizes)])
+    u = torch.cat([torch.sin(0.5 * x[:, None] + torch.linspace(0, 1, tw)[None, :] * 3 + i) for i, x in enumerate(xs)])
+    u = u + 0.01 * torch.randn(u.shape, generator=g)
+    pos = torch.cat([torch.full((pos_x.numel(), 1), 0.25), pos_x[:, None]], 1)
+    ei = radius_graph(pos_x[:, None], r=3 * float(xs[0][1] - xs[0][0]) + 1e-4, batch=bvec, loop=False)
+    L_, tmax, dt = torch.tensor(16.0), torch.tensor(4.0), torch.tensor(0.016)
+    wgt = torch.randn(u.shape[0], tw, generator=g)                       # a loss that weighs every output differently
+    # oracle: fp64 autograd
+    o64 = O.build(name, hp).double()
+    o64.load_state_dict({k: v.double() for k, v in oracle.state_dict().items()})
+    ux = u.double().requires_grad_(True)
+    data = types.SimpleNamespace(x=ux, pos=pos.double(), batch=bvec, edge_index=ei)
+    want = o64(data, L_.double(), tmax.double(), dt.double())
+    (want * wgt.double()).sum().backward()
+    want_g = {n: p.grad.float() for n, p in o64.named_parameters()}
+    # HIP
+    uc = u.cuda().requires_grad_(True)
+    cdata = types.SimpleNamespace(x=uc, pos=pos.cuda(), batch=bvec.cuda(), edge_index=ei.cuda())
+    got = model(cdata, L_.cuda(), tmax.cuda(), dt.cuda())
+    assert got.grad_fn is not None and rel_l2(got.detach(), want.detach().float()) < 1e-5
+    (got * wgt.cuda()).sum().backward()
+    worst = max(rel_l2(p.grad, want_g[n]) for n, p in model.named_parameters())
+    assert worst < 2e-4, worst
+    assert rel_l2(uc.grad, ux.grad.float()) < 2e-4
+    # eval mode: the inference path, no graph
+    model.eval()
+    assert model(cdata, L_.cuda(), tmax.cuda(), dt.cuda()).grad_fn is None
