@@ -71,6 +71,10 @@ def lib() -> C.CDLL:
         for name in declared_symbols():
             fn = getattr(_lib, name)          # AttributeError if the .so does not export it
             fn.restype = C.c_int
+            if name.endswith("_generation"):
+                # a development switch between kernel generations changes what the *_grid / *_workspace queries answer: every call
+                # through this handle drops the cached answers
+                setattr(_lib, name, _forgetting(fn))
         if DEV:
             for name in ("magnet_debug_set_variant", "magnet_debug_set_mlp_ablation", "magnet_debug_set_mlp_trace",
                          "magnet_debug_set_edge_bwd_ablation"):
@@ -99,16 +103,21 @@ def _check_variant(path: str) -> None:
 _QUERIES = {}
 
 
+def _forgetting(fn):
+    def call(*args):
+        _QUERIES.clear()
+        return fn(*args)
+    return call
+
+
 def query(name: str, *args) -> int:
-    """value of a query entry point; ``*_supported`` / ``*_workspace`` are pure functions of their integer arguments and
-    cached: a MAgNet training step at the reference's batch sizes is host bound and asks these ~600 times per step"""
-    if name.endswith("_grid"):
-        # NOT cached: magnet_linear_bwd{128,64}_grid follows the kernel generation (magnet_linear_bwd128_generation, a development
-        # switch) - a stale value would size the caller's amax_out for another launch shape.  (These take the row count as a C long.)
-        return int(getattr(lib(), name)(*[C.c_long(a) for a in args]))
+    """value of a query entry point; ``*_supported`` / ``*_workspace`` / ``*_grid`` are pure functions of their integer arguments
+    (and of the kernel generation: the ``*_generation`` switches clear the cache, see lib()) and cached: a MAgNet training step at the
+    reference's batch sizes is host bound and asks these ~1 000 times per step.  (``*_grid`` take the row count as a C long.)"""
     key = (name, args)
     if key not in _QUERIES:
-        _QUERIES[key] = int(getattr(lib(), name)(*args))
+        cargs = [C.c_long(a) for a in args] if name.endswith("_grid") else args
+        _QUERIES[key] = int(getattr(lib(), name)(*cargs))
     return _QUERIES[key]
 
 
