@@ -239,6 +239,21 @@ int magnet_mpnn_edge_rowsg_fp16x3_f32(const float* A, const float* Bm, const int
 int magnet_mpnn_edge_rowsp_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const void* tiles, int n_tiles,
                                       int has_stragglers, const void* w2_t32, const float* b2, float* agg, int a_bm_log2e_scaled,
                                       void* stream);
+/* Generation 14 (k_mpnn_edge_stream32, csrc/mpnn_edge_stream.hip): the same op (models/mpnn.py:73-79,46 /
+ * models/mpnn_2d.py:73-79,46) with 32-edge tiles cut from the edge STREAM of row-aligned chunks - a tile holds the tail of row r and the
+ * head of row r + 1, a wave carries the open row's sum from tile to tile - so that no edge is left to a straggler / remainder pass.
+ * tiles [n_chunks][tpc] int4 + chunk_ntiles [n_chunks] from magnet_stream_tiles_plan; n_chunks a multiple of 8.  Rows without edges
+ * are not written (the plan's flags say whether there are any: zero-fill agg first). */
+int magnet_mpnn_edge_stream_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const void* tiles,
+                                       const int32_t* chunk_ntiles, int n_chunks, int tpc, int n_rows, const void* w2_t32,
+                                       const float* b2, float* agg, int a_bm_log2e_scaled, void* stream);
+/* The plan of the kernel above: the rows are cut into n_chunks ranges of about equal edge count (chunk c starts at the first row whose
+ * edges begin at or after c E / n_chunks); every chunk's edges are cut into tiles of 32 consecutive edges that touch at most two rows
+ * (descriptor: x = first edge, y = row of that edge, z = cnt | split << 8 | ends0 << 16 | ends1 << 17, w = deg(row) | deg(row + 1) << 16).
+ * flags [2]: [0] bit 0 = some chunk needs more than tpc tiles (its chunk_ntiles is 0: do not launch), bit 1 = some row has no edge,
+ * bit 2 = some row has 65 536 edges or more (do not launch); [1] = the number of tiles of all chunks. */
+int magnet_stream_tiles_plan(const int32_t* rowptr, int n_rows, int n_chunks, int tpc, void* tiles, int32_t* chunk_ntiles,
+                             int32_t* flags, void* stream);
 /* The tile plan of a CSR graph for the four kernels above.  _count, per row r: has_tile[r] = (deg_r >= pmin); has_strag[r] = the row has a
  * tile and exactly one edge beyond it; n_rem[r] = its edges for the remainder pass (those outside the tile unless that is the one
  * straggler; all of them without a tile).  _fill: given the exclusive prefix sums tile_ptr / strag_ptr / rem_ptr [n_rows + 1] of the

@@ -455,6 +455,47 @@ def mpnn_edge_rows(A, Bm, csr, plan: RowTiles, w2_t16, w2_t32, b2, agg, partials
     return agg
 
 
+@dataclass
+class StreamTiles:
+    """Tile plan of k_mpnn_edge_stream32 (generation 14): the rows cut into n_chunks row-aligned ranges of about equal edge count, every
+    chunk's edge stream cut into 32-edge tiles that touch at most two rows."""
+    tiles: torch.Tensor            # [n_chunks, tpc, 4] int32 descriptors (include/magnet_hip.h)
+    ntiles: torch.Tensor           # [n_chunks] int32
+    n_chunks: int
+    tpc: int
+    zero_fill: bool                # some rows have no edge: the kernel does not write them
+    n_tiles: int = 0               # tiles of all chunks (fill = E / (32 n_tiles))
+
+
+def stream_tiles(csr: "CSR"):
+    """build the plan on the device (one launch + one host read of its flags); None when the graph does not fit the kernel (a row with
+    65 536 edges or more, a chunk that would need more tiles than planned for: very uneven rows)"""
+    n, dev = csr.N, csr.rowptr.device
+    if n <= 0 or csr.E <= 0:
+        return None
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    n_chunks = 8 * max(1, min((csr.E + 255) // 256, ncu))
+    tpc = (csr.E + 32 * n_chunks - 1) // (32 * n_chunks) + 8          # a chunk overshoots its share by less than one row (+ cuts)
+    tiles = torch.empty(n_chunks, tpc, 4, dtype=torch.int32, device=dev)
+    ntiles = torch.empty(n_chunks, dtype=torch.int32, device=dev)
+    flags = torch.empty(2, dtype=torch.int32, device=dev)
+    L.check(L.lib().magnet_stream_tiles_plan(_p(csr.rowptr), n, n_chunks, tpc, _p(tiles), _p(ntiles), _p(flags), _stream()), "stream_tiles_plan")
+    fl, total = (int(v) for v in flags.tolist())                       # one host sync per plan
+    if fl & 5:
+        return None
+    return StreamTiles(tiles, ntiles, n_chunks, tpc, bool(fl & 2), total)
+
+
+def mpnn_edge_stream(A, Bm, csr, plan: StreamTiles, w2_t32, b2, agg, l2e=False):
+    """the fused edge op by k_mpnn_edge_stream32 (generation 14): ONE launch, no remainder pass, no straggler lists"""
+    assert w2_t32.dtype == torch.float16
+    if plan.zero_fill:
+        agg.zero_()
+    L.check(L.lib().magnet_mpnn_edge_stream_fp16x3_f32(_p(A), _p(Bm), _p(csr.src), _p(plan.tiles), _p(plan.ntiles), plan.n_chunks, plan.tpc,
+                                                       csr.N, _p(w2_t32), _p(b2), _p(agg), int(l2e), _stream()), "mpnn_edge_stream_fp16x3")
+    return agg
+
+
 mpnn_edge_bf16x6 = mpnn_edge     # kept for scripts: the weights' dtype decides
 
 

@@ -61,6 +61,9 @@ print(f"graph: N={N} E={E} degree histogram (top): {torch.bincount(deg)[-6:].tol
 for pmin in [int(v) for v in os.environ.get("PMIN", "20").split(",")]:
     t_plan = timeit(lambda: ops.row_tiles(csr, pmin), reps=5)
     plan = ops.row_tiles(csr, pmin)
+    t_splan = timeit(lambda: ops.stream_tiles(csr), reps=5)
+    sp = ops.stream_tiles(csr)
+    print(f"stream plan: {sp.n_chunks} chunks x <= {sp.tpc} tiles, {int(sp.ntiles.sum())} tiles ({int(sp.ntiles.min())}-{int(sp.ntiles.max())} per chunk), zero_fill {sp.zero_fill}, build {t_splan * 1e3:.0f} us")
     print(f"pmin={pmin}: {plan.n_tiles} tiles, {plan.n_strag} stragglers, {plan.rem.E} remainder edges ({100.0 * plan.rem.E / E:.2f} %), "
           f"remainder pass {plan.rem_pass}, plan build {t_plan * 1e3:.0f} us")
     for l2e in (True, False):
@@ -69,7 +72,11 @@ for pmin in [int(v) for v in os.environ.get("PMIN", "20").split(",")]:
         ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e)
         err = float((agg - ref).norm() / ref.norm())
         nan = int(torch.isnan(agg).sum())
-        res = {"edge16": [], "rows": [], "rows_tiles_only": [], "rowsr": [], "rowsr_tiles_only": [], "rowsg": [], "rowsp": []}
+        res = {"edge16": [], "rows": [], "rows_tiles_only": [], "rowsr": [], "rowsr_tiles_only": [], "rowsg": [], "rowsp": [], "stream": []}
+        splan = ops.stream_tiles(csr)
+        agg.fill_(float("nan"))
+        ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e)
+        err_s, nan_s = float((agg - ref).norm() / ref.norm()), int(torch.isnan(agg).sum())
         agg.fill_(float("nan"))
         ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e, wreg=3)
         err_p, nan_p = float((agg - ref).norm() / ref.norm()), int(torch.isnan(agg).sum())
@@ -98,11 +105,12 @@ for pmin in [int(v) for v in os.environ.get("PMIN", "20").split(",")]:
             res["rowsr_tiles_only"].append(timeit(tiles_only_r))
             res["rowsg"].append(timeit(lambda: ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e, wreg=2)))
             res["rowsp"].append(timeit(lambda: ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e, wreg=3)))
+            res["stream"].append(timeit(lambda: ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e)))
         fl = 2 * E * H * H * 3
         line = "  ".join(f"{k} " + "/".join(f"{v:.4f}" for v in vs) for k, vs in res.items())
         best = min(res["rows"])
-        print(f"  l2e={l2e}: rel-diff vs fp32 kernel {err:.2e} nan={nan} (rowsr {err_r:.2e} nan={nan_r}, rowsg {err_g:.2e} nan={nan_g}, rowsp {err_p:.2e} nan={nan_p}) | ms per launch: {line} | frac of 2.5 PF: "
-              f"rows {fl / best / 1e9 / 2500:.3f}, rowsr {fl / min(res['rowsr']) / 1e9 / 2500:.3f}, rowsg {fl / min(res['rowsg']) / 1e9 / 2500:.3f}, rowsp {fl / min(res['rowsp']) / 1e9 / 2500:.3f}, edge16 {fl / min(res['edge16']) / 1e9 / 2500:.3f}")
+        print(f"  l2e={l2e}: rel-diff vs fp32 kernel {err:.2e} nan={nan} (rowsr {err_r:.2e} nan={nan_r}, rowsg {err_g:.2e} nan={nan_g}, rowsp {err_p:.2e} nan={nan_p}, stream {err_s:.2e} nan={nan_s}) | ms per launch: {line} | frac of 2.5 PF: "
+              f"stream {fl / min(res['stream']) / 1e9 / 2500:.3f}, rows {fl / best / 1e9 / 2500:.3f}, rowsr {fl / min(res['rowsr']) / 1e9 / 2500:.3f}, rowsg {fl / min(res['rowsg']) / 1e9 / 2500:.3f}, rowsp {fl / min(res['rowsp']) / 1e9 / 2500:.3f}, edge16 {fl / min(res['edge16']) / 1e9 / 2500:.3f}")
 
 if os.environ.get("MAGNET_DEV_LIB", "0") == "1":          # ablations of the main kernel (development library; results invalid)
     import ctypes as C

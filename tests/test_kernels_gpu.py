@@ -297,7 +297,7 @@ def test_mpnn_edge_log2e_scaled_inputs_give_the_same_mean():
 @pytest.mark.parametrize("case", ["ragged", "no_edges", "under_one_tile", "one_row_owns_everything", "every_row_one_edge",
                                   "small_values", "mpnn_like"])
 @pytest.mark.parametrize("l2e", [False, True])
-@pytest.mark.parametrize("kernel", ["edge16", "edge16s", "edge32t", "edge32p", "edgews", "rows", "rowsr", "rowsg", "rowsp"])
+@pytest.mark.parametrize("kernel", ["edge16", "edge16s", "edge32t", "edge32p", "edgews", "rows", "rowsr", "rowsg", "rowsp", "stream"])
 def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
     """k_mpnn_edge16 (16-edge tiles, v_mfma_f32_16x16x32_f16, two waves per SIMD, its own weight fragment order) and k_mpnn_edge32t
     (generation 9: transposed 32-edge tiles, lane = output feature, one accumulator, unscaled fp16-subnormal low pieces) against a
@@ -353,6 +353,21 @@ def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
         strag = has & (left == 1)
         assert plan.n_tiles == int(has.sum()) and plan.n_strag == int(strag.sum()) and plan.rem.E == int(left[~strag].sum())
         ops.mpnn_edge_rows(A.cuda() * scale, Bm.cuda() * scale, csr, plan, w16, w32, b, agg, partials, l2e=l2e, wreg={"rows": 0, "rowsr": 1, "rowsg": 2, "rowsp": 3}[kernel])
+    elif kernel == "stream":                  # generation 14: 32-edge tiles cut from the edge stream of row-aligned chunks (two rows per tile)
+        w16, b = pack_edge16_fp16x2(lin.weight.cuda(), lin.bias.cuda())
+        w32, _ = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
+        plan = ops.stream_tiles(csr)
+        # (no plan: no edges, one row owning 1 250 tiles or a few rows far longer than a chunk's share, rows of one or two edges - a tile
+        #  never touches a third row - : the model then runs k_mpnn_edge16, and so does this test)
+        assert plan is not None or case != "mpnn_like"
+        assert plan is None or case not in ("no_edges", "one_row_owns_everything", "every_row_one_edge")
+        if plan is None:
+            ops.mpnn_edge16(A.cuda() * scale, Bm.cuda() * scale, csr, w16, b, agg, partials, l2e=l2e)
+        else:
+            assert plan.zero_fill == bool(((csr.rowptr[1:] - csr.rowptr[:-1]) == 0).any())
+            nt = plan.ntiles.cpu()
+            assert int(nt.sum()) == plan.n_tiles and int(nt.max()) <= plan.tpc
+            ops.mpnn_edge_stream(A.cuda() * scale, Bm.cuda() * scale, csr, plan, w32, b, agg, l2e=l2e)
     elif kernel == "edgews":                  # generation 10: wave-specialised (gather / GEMM / epilogue waves through LDS)
         w, b = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
         ops.mpnn_edge_ws(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e)
@@ -365,6 +380,94 @@ def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
         assert rel_l2(agg, want) < (3e-6 if case == "one_row_owns_everything" else 1e-6), rel_l2(agg, want)
     else:
         assert float(agg.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("pattern", ["all33", "all32", "30to33", "all64", "all65", "17to40", "mesh_with_holes", "long_and_short", "tiny"])
+@pytest.mark.parametrize("l2e", [False, True])
+def test_mpnn_edge_stream_degree_patterns(pattern, l2e):
+    """k_mpnn_edge_stream32 (generation 14): 32-edge tiles cut from the edge stream, two rows per tile, the open row's sum carried from tile
+    to tile.  Degree patterns that move the split through every position (33), never split (32, 64), split rows over three tiles (65),
+    force cuts in front of a third row (17 .. 40), leave rows empty, and a graph smaller than one workgroup's chunks - against a host
+    evaluation in fp64; the plan itself is checked edge by edge (every edge in exactly one tile, at most two rows per tile, chunks
+    aligned to rows)."""
+    from magnet_amd import ops
+    from magnet_amd.packing import pack_edge16_fp16x2, pack_edge32t_fp16x2
+    from oracle.pyg_semantics import scatter_mean
+    g = torch.Generator().manual_seed(23)
+    H = 128
+    n = {"tiny": 7, "long_and_short": 900}.get(pattern, 3000)
+    if pattern == "all33":
+        deg = torch.full((n,), 33)
+    elif pattern == "all32":
+        deg = torch.full((n,), 32)
+    elif pattern == "30to33":
+        deg = torch.randint(30, 34, (n,), generator=g)
+    elif pattern == "all64":
+        deg = torch.full((n,), 64)
+    elif pattern == "all65":
+        deg = torch.full((n,), 65)
+    elif pattern == "17to40":
+        deg = torch.randint(17, 41, (n,), generator=g)
+    elif pattern == "mesh_with_holes":
+        deg = torch.where(torch.rand(n, generator=g) < 0.9, torch.full((n,), 33), torch.randint(20, 33, (n,), generator=g))
+        deg[torch.randint(0, n, (25,), generator=g)] = 0
+        deg[0] = 0
+        deg[-1] = 0
+    elif pattern == "long_and_short":
+        deg = torch.where(torch.rand(n, generator=g) < 0.5, torch.randint(90, 130, (n,), generator=g), torch.randint(8, 20, (n,), generator=g))
+    else:
+        deg = torch.tensor([33, 5, 0, 31, 33, 2, 40])
+    rowptr = torch.zeros(n + 1, dtype=torch.int32)
+    rowptr[1:] = deg.cumsum(0)
+    tgt = torch.repeat_interleave(torch.arange(n), deg)
+    E = tgt.numel()
+    src = torch.randint(0, n, (E,), generator=g)
+    A, Bm = torch.randn(n, H, generator=g), torch.randn(n, H, generator=g)
+    lin = torch.nn.Linear(H, H)
+    sw = lambda x: x * torch.sigmoid(x)  # noqa: E731
+    with torch.no_grad():
+        m = sw(lin.double()(sw((A[tgt.long()] + Bm[src.long()]).double())))
+    want = scatter_mean(m, tgt.long(), n)
+    csr = ops.CSR(rowptr.int().cuda(), src.int().cuda(), tgt.int().cuda(), n, E)
+    plan = ops.stream_tiles(csr)
+    assert plan is not None
+    # ---- the plan, edge by edge
+    tiles, nt = plan.tiles.cpu(), plan.ntiles.cpu()
+    covered = torch.zeros(E, dtype=torch.int32)
+    rp = rowptr.long()
+    next_row_start = 0
+    for c in range(plan.n_chunks):
+        for k in range(int(nt[c])):
+            e0, r, z, w = (int(v) for v in tiles[c, k])
+            cnt, split, ends0, ends1 = z & 0xFF, (z >> 8) & 0xFF, bool(z & (1 << 16)), bool(z & (1 << 17))
+            assert 1 <= cnt <= 32 and 1 <= split <= cnt
+            covered[e0:e0 + cnt] += 1
+            assert rp[r] <= e0 < rp[r + 1] and split == min(int(rp[r + 1]) - e0, cnt)
+            assert (w & 0xFFFF) == int(deg[r])
+            assert ends0 == (int(rp[r + 1]) <= e0 + cnt)
+            if split < cnt:                              # a second row: it is row r + 1 and nothing beyond it is touched
+                assert int(deg[r + 1]) > 0 and e0 + cnt <= int(rp[r + 2]) and (w >> 16) == int(deg[r + 1])
+                assert ends1 == (int(rp[r + 2]) == e0 + cnt)
+            else:
+                assert not ends1
+            if k == 0:                                   # a chunk begins where a row begins ...
+                assert e0 == int(rp[r]) and e0 == next_row_start
+            if k == int(nt[c]) - 1:                      # ... and ends where a row ends
+                assert ends1 if split < cnt else ends0
+                next_row_start = e0 + cnt
+    assert bool((covered == 1).all()) and next_row_start == E
+    assert plan.zero_fill == bool((deg == 0).any())
+    # ---- the kernel
+    w32, _ = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
+    _, b = pack_edge16_fp16x2(lin.weight.cuda(), lin.bias.cuda())
+    scale = ops.LOG2E if l2e else 1.0
+    agg = torch.full((n, H), float("nan"), device="cuda")
+    ops.mpnn_edge_stream(A.cuda() * scale, Bm.cuda() * scale, csr, plan, w32, b, agg, l2e=l2e)
+    assert not torch.isnan(agg).any()
+    assert rel_l2(agg, want) < 1e-6, rel_l2(agg, want)
+    again = torch.full((n, H), float("nan"), device="cuda")
+    ops.mpnn_edge_stream(A.cuda() * scale, Bm.cuda() * scale, csr, plan, w32, b, again, l2e=l2e)
+    assert torch.equal(agg, again)
 
 
 @pytest.mark.parametrize("case", ["no_edges", "under_one_tile", "one_row_owns_everything", "empty_rows_at_both_ends"])
