@@ -13,7 +13,7 @@
 //   * transposed GEMM, lane = output feature: the tile's sum is a sum over the lane's 16 accumulator registers.  The lane <-> edge
 //     map inside a tile is chosen so that register i of the two half-waves holds edges 2 i and 2 i + 1: the first `split` edges are
 //     then registers 0 .. split / 2 - 1 (plus half a register when split is odd), i.e. the two-segment sum is the running sum with
-//     ONE snapshot at register split / 2 - a uniform branch per register, 12 extra VALU instructions per tile;
+//     ONE snapshot in front of register split / 2 - a uniform branch per register, nine VALU instructions once or twice per tile;
 //   * A[i]: two 512-byte rows per tile parked in LDS (a tile's second row is the next tile's first), the lane picks its row by
 //     comparing its edge with `split` - still one A row fetched per tile;
 //   * a row's sum is finished by the wave that started it (carry registers between consecutive tiles; chunks begin and end at row
@@ -193,31 +193,28 @@ __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restr
         const int zf = __builtin_amdgcn_readfirstlane(d0.z);
         float acc[4] = {0.f, 0.f, 0.f, 0.f}, snap[4] = {0.f, 0.f, 0.f, 0.f};
         if (cnt == 32) {
-            // register i = edges 2 i (lower half-wave) and 2 i + 1 (upper): registers below split / 2 belong to row r, the ones above to
-            // row r + 1, register split / 2 to both when split is odd.  Running sum with ONE snapshot: at that register
-            // snap = acc + s m, acc = s (1 - m) with m = 1 for the lanes whose edge is still row r's (exact for m in {0, 1})
-            const int n0 = split >> 1;
-            const float m = ((split & 1) && half == 0) ? 1.0f : 0.0f;
+            // register i = edges 2 i (lower half-wave) and 2 i + 1 (upper): a lane's values belong to row r up to register p - 1 and to
+            // row r + 1 from register p on, p = split / 2 (+ 1 in the lower half-wave when split is odd).  The running sum is
+            // snapshotted (snap = acc, acc = 0) by the lanes with p == i right before register i is added: a uniform branch around
+            // nine VALU instructions, taken once (twice: odd split) per tile - nothing else in the sum knows about rows.
+            const int n0 = split >> 1, odd = split & 1;
+            const unsigned at = (1u << n0) | ((unsigned)odd << (n0 + 1));       // the registers in front of which some lanes snapshot (bit 16: after the last)
+            const int p = n0 + ((odd && half == 0) ? 1 : 0);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (i == n0) {
+            for (int i = 0; i <= 16; ++i) {
+                if (__builtin_expect((at & (1u << i)) != 0, 0)) {
+                    asm volatile("" ::: "memory");      // (a real branch: hipcc otherwise turns the 17 blocks into 136 unconditional selects)
+                    const bool me = p == i;
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        const float s = swish2(out[nt][i], bl[nt]);
-                        snap[nt] = fmaf(s, m, acc[nt]);
-                        acc[nt] = fmaf(-s, m, s);
-                    }
-                } else {
+                    for (int nt = 0; nt < 4; ++nt) snap[nt] = me ? acc[nt] : snap[nt], acc[nt] = me ? 0.f : acc[nt];
+                }
+                if (i < 16) {
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         const float y = fmaf(out[nt][i], 1.0f / R_SCALE, bl[nt]);
                         acc[nt] = fmaf(y, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(L2E ? -y : -y * MAGNET_LOG2E)), acc[nt]);
                     }
                 }
-            }
-            if (n0 >= 16) {                    // the whole tile is row r's
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) snap[nt] = acc[nt], acc[nt] = 0.f;
             }
         } else {                               // a short tile (the end of a chunk, a cut in front of a third row): every value masked
 #pragma unroll

@@ -105,9 +105,12 @@ class MPNN(LightningModule):
         # (2-D meshes: 30 .. 33 edges per row); A/B knob, DESIGN.md 11.1
         # (2 = generation 12, k_mpnn_edge_rowsr: the same tiles with W2's planes resident in the accumulation registers; 3 = generation 12b,
         #  k_mpnn_edge_rowsg: that + the rows' 33rd edges grouped with their rows; 4 = generation 13, k_mpnn_edge_rowsp: one software
-        #  pipeline per wave - DESIGN.md 14.2)
+        #  pipeline per wave - DESIGN.md 14.2; 5 = generation 14, k_mpnn_edge_stream32: 32-edge tiles cut from the edge stream of row-aligned
+        #  chunks, two rows per tile, no stragglers and no remainder pass - DESIGN.md 14.6)
+        #  DEFAULT since round 5: 5 where the graph suits it (rows of 17 edges and more on average, tiles >= 85 % full: every 2-D MPNN
+        #  mesh), k_mpnn_edge16 elsewhere; 0 = k_mpnn_edge16 everywhere.
         self.edge_rows = int(getattr(hparams, "edge_rows", None) if getattr(hparams, "edge_rows", None) is not None
-                             else os.environ.get("MAGNET_EDGE_ROWS", "0"))
+                             else os.environ.get("MAGNET_EDGE_ROWS", "5"))
         self.node_update2 = bool(int(os.environ.get("MAGNET_NODE_UPDATE2", "1"))) and bool(getattr(hparams, "node_update2", True))
         # small batches (<= 128 rows): update + InstanceNorm of a hop in one launch (A/B knob)
         self.fused_small_norm = bool(int(os.environ.get("MAGNET_SMALL_NORM", "1"))) and bool(getattr(hparams, "fused_small_norm", True))
@@ -294,7 +297,9 @@ class MPNN(LightningModule):
                 ops.mlp(N, ops.ktiles(T(h, H), T(node_in, kin)), [pa, pb], nl=1, ht=4, ot=4,
                         act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2, groups_in_block=True, y_group_stride=N * H)
             plan = self._row_plan(topo) if hasattr(lyr, "msg2_rows") else None
-            if plan is not None:                  # tiles aligned to CSR rows (+ the remainder edges through k_mpnn_edge16)
+            if isinstance(plan, ops.StreamTiles):  # generation 14: one launch over the whole edge stream
+                ops.mpnn_edge_stream(A, Bm, csr, plan, lyr.msg2_rows[0], lyr.msg2_t16[1], agg, l2e=l2e)
+            elif plan is not None:                # tiles aligned to CSR rows (+ the remainder edges through k_mpnn_edge16)
                 ops.mpnn_edge_rows(A, Bm, csr, plan, lyr.msg2_t16[0], lyr.msg2_rows[0], lyr.msg2_t16[1], agg, partials, l2e=l2e,
                                    single16=lyr.msg2_t16_single, wreg=max(self.edge_rows - 1, 0))
             elif hasattr(lyr, "msg2_t32"):        # training forward too (plain halves: l2e is False with a tape)
@@ -359,9 +364,15 @@ class MPNN(LightningModule):
         None when fewer than half of the edges would land in tiles (1-D meshes: 6 edges per row - k_mpnn_edge16 alone is better)"""
         plan = getattr(topo, "row_plan", False)
         if plan is False:
-            plan = ops.row_tiles(topo.csr)
-            if 2 * (plan.rem.E) > topo.csr.E:
-                plan = None
+            if self.edge_rows == 5:                # generation 14: kept when its tiles are at least 85 % full (rows of 17 edges and more:
+                # a tile never touches a third row, short rows mean short tiles; 1-D meshes have 6 edges per row and are not even planned)
+                plan = ops.stream_tiles(topo.csr) if topo.csr.E >= 17 * topo.csr.N else None
+                if plan is not None and 100 * topo.csr.E < 85 * 32 * plan.n_tiles:
+                    plan = None
+            else:
+                plan = ops.row_tiles(topo.csr)
+                if 2 * (plan.rem.E) > topo.csr.E:
+                    plan = None
             topo.row_plan = plan
         return plan
 
@@ -534,7 +545,11 @@ class MPNN(LightningModule):
             pairs = [(held.csr.rowptr, fresh.csr.rowptr), (held.csr.src, fresh.csr.src), (held.csr.tgt, fresh.csr.tgt),
                      (held.coords, fresh.coords)]
             hp = getattr(held, "row_plan", None)
-            if hp:                             # the tile plan is part of the graph: rebuilt from the fresh CSR like the CSR itself
+            if isinstance(hp, ops.StreamTiles):
+                fp = ops.stream_tiles(fresh.csr)
+                if fp is not None and (fp.n_chunks, fp.tpc, fp.zero_fill) == (hp.n_chunks, hp.tpc, hp.zero_fill):
+                    pairs += [(hp.tiles, fp.tiles), (hp.ntiles, fp.ntiles)]
+            elif hp:                           # the tile plan is part of the graph: rebuilt from the fresh CSR like the CSR itself
                 fp = ops.row_tiles(fresh.csr, hp.pmin)
                 if (fp.n_tiles, fp.n_strag, fp.rem.E) == (hp.n_tiles, hp.n_strag, hp.rem.E):
                     pairs += [(hp.tiles, fp.tiles), (hp.strag_ptr, fp.strag_ptr), (hp.strag_row, fp.strag_row),

@@ -337,8 +337,8 @@ EDGE_ENTRY = {torch.float16: "magnet_mpnn_edge_fp16x3_f32", torch.int16: "magnet
 EDGE_ENTRY_L2E = {torch.float16: "magnet_mpnn_edge_fp16x3_l2e_f32", torch.bfloat16: "magnet_mpnn_edge_bf16_l2e_f32"}
 # fp16x3 entry points with their own weight packs (ops.mpnn_edge16 ...), and the kernel behind every entry (bench.py names it)
 EDGE_ENTRY_EXTRA = ("magnet_mpnn_edge_fp16x3_t16_f32", "magnet_mpnn_edge_fp16x3_t32_f32", "magnet_mpnn_edge_fp16x3_ws_f32",
-                    "magnet_mpnn_edge_rows_fp16x3_f32", "magnet_mpnn_edge_rowsr_fp16x3_f32", "magnet_mpnn_edge_rowsg_fp16x3_f32", "magnet_mpnn_edge_rowsp_fp16x3_f32")
-EDGE_KERNEL_OF_ENTRY = {"magnet_mpnn_edge_rowsp_fp16x3_f32": "k_mpnn_edge_rowsp", "magnet_mpnn_edge_rowsg_fp16x3_f32": "k_mpnn_edge_rowsg", "magnet_mpnn_edge_rowsr_fp16x3_f32": "k_mpnn_edge_rowsr", "magnet_mpnn_edge_rows_fp16x3_f32": "k_mpnn_edge_rows32", "magnet_mpnn_edge_fp16x3_t16_f32": "k_mpnn_edge16", "magnet_mpnn_edge_fp16x3_t32_f32": "k_mpnn_edge32t", "magnet_mpnn_edge_fp16x3_ws_f32": "k_mpnn_edge_ws", "magnet_mpnn_edge_fp16x3_f32": "k_mpnn_edge7",
+                    "magnet_mpnn_edge_rows_fp16x3_f32", "magnet_mpnn_edge_rowsr_fp16x3_f32", "magnet_mpnn_edge_rowsg_fp16x3_f32", "magnet_mpnn_edge_rowsp_fp16x3_f32", "magnet_mpnn_edge_stream_fp16x3_f32")
+EDGE_KERNEL_OF_ENTRY = {"magnet_mpnn_edge_stream_fp16x3_f32": "k_mpnn_edge_stream32", "magnet_mpnn_edge_rowsp_fp16x3_f32": "k_mpnn_edge_rowsp", "magnet_mpnn_edge_rowsg_fp16x3_f32": "k_mpnn_edge_rowsg", "magnet_mpnn_edge_rowsr_fp16x3_f32": "k_mpnn_edge_rowsr", "magnet_mpnn_edge_rows_fp16x3_f32": "k_mpnn_edge_rows32", "magnet_mpnn_edge_fp16x3_t16_f32": "k_mpnn_edge16", "magnet_mpnn_edge_fp16x3_t32_f32": "k_mpnn_edge32t", "magnet_mpnn_edge_fp16x3_ws_f32": "k_mpnn_edge_ws", "magnet_mpnn_edge_fp16x3_f32": "k_mpnn_edge7",
                         "magnet_mpnn_edge_fp16x3_l2e_f32": "k_mpnn_edge7", "magnet_mpnn_edge_bf16_f32": "k_mpnn_edge7",
                         "magnet_mpnn_edge_bf16_l2e_f32": "k_mpnn_edge7", "magnet_mpnn_edge_bf16x6_f32": "k_mpnn_edge6",
                         "magnet_mpnn_edge_f32": "k_mpnn_edge2"}

@@ -22,7 +22,7 @@ KERNELS = {"k_mpnn_edge16": ("k_mpnn_edge16", True), "k_mpnn_edge7": ("k_mpnn_ed
            "magnet_gnn:edge_mlp": ("k_mlp_bf16<1, 5, 4, 4, 2, false, true, 2", True),       # fp16x3, 5 Linears 128-wide, LN, CSR mean
            "magnet_cnn_2d:edge_mlp": ("k_mlp_bf16<3, 5, 2, 1, 2, false, true, 2", True),    # one-accumulator fp16x3s, 64-wide hidden, 32-wide output
            "k_mpnn_edge_rows32": ("k_mpnn_edge_rows32", True), "k_mpnn_edge_rowsr": ("k_mpnn_edge_rowsr", True),
-           "k_mpnn_edge_rowsg": ("k_mpnn_edge_rowsg", True),
+           "k_mpnn_edge_rowsg": ("k_mpnn_edge_rowsg", True), "k_mpnn_edge_stream32": ("k_mpnn_edge_stream32", True),
            # the node-level kernels run on every mesh of the line (c1's 100 rows, the reference shapes, 48 x 48 ...): the headline launch
            # is the one with the largest grid - averaged over all of them the figure was 47 MB for a 0.40 GB launch
            "k_node_update2": ("k_node_update2<9, true>", True), "k_node_halves": ("k_node_halves<5>", True)}
