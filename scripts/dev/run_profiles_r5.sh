@@ -29,7 +29,7 @@ import csv, glob, sys
 O, V = sys.argv[1:3]
 for name in ("fetch", "write"):     # keep only the roofline kernels' rows of the raw counter files (the full files are tens of MB)
     f = glob.glob(f"{O}/{name}/*/*_counter_collection.csv")[0]
-    keep = ("k_mpnn_edge16", "k_mpnn_edge_rows32", "k_mpnn_edge_rowsr", "k_mpnn_edge_rowsg", "k_node_halves<5>", "k_segment_mean", "k_mlp_bf16<1, 5, 4, 4, 2, false, true, 2", "k_mlp_bf16<3, 5, 2, 1, 2, false, true, 2",
+    keep = ("k_mpnn_edge16", "k_mpnn_edge_stream32", "k_mpnn_edge_rows32", "k_mpnn_edge_rowsr", "k_mpnn_edge_rowsg", "k_node_halves<5>", "k_segment_mean", "k_mlp_bf16<1, 5, 4, 4, 2, false, true, 2", "k_mlp_bf16<3, 5, 2, 1, 2, false, true, 2",
             "k_node_update2<9, true>")
     rows = list(csv.reader(open(f)))
     gi = rows[0].index("Grid_Size")
