@@ -349,6 +349,12 @@ int magnet_colstat_final_f32(const float* part_sum, const float* part_m2, int n_
 int magnet_mpnn_node_halves_f32(const float* h, const float* node_in, int kin, long n_rows, const float* mean, const float* var,
                                 float eps, int n_graphs, int rows_per_graph, const void* wa_f16, const float* ba,
                                 const void* wb_f16, const float* bb, float* A, float* Bm, float* h_norm, void* stream);
+/* The same launch on two waves per SIMD (k_node_halves2, round 5): wa_f16s / wb_f16s and ba_s / bb_s are the packs of packing mode "fp16x3s"
+ * (one accumulator per output block: planes and biases times 2^11, |w| < 31.98; magnet_pack_linear_f32 mode 4 flags larger weights).
+ * Same arguments, same results to the last bits of the fp16x3 split (models/mpnn.py:73-79 / models/mpnn_2d.py:73-79). */
+int magnet_mpnn_node_halves2_f32(const float* h, const float* node_in, int kin, long n_rows, const float* mean, const float* var,
+                                float eps, int n_graphs, int rows_per_graph, const void* wa_f16s, const float* ba_s,
+                                const void* wb_f16s, const float* bb_s, float* A, float* Bm, float* h_norm, void* stream);
 
 /* ---- neighbour search / CSR (torch_cluster radius_graph / knn call sites: models/mpnn.py:245,
  *      models/magnet_gnn.py:247,293) ---- */

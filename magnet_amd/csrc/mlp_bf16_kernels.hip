@@ -683,6 +683,139 @@ extern "C" int magnet_mpnn_node_halves_f32(const float* h, const float* node_in,
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------- MPNN per-node halves, two waves per SIMD (round 5)
+// k_node_halves above runs ONE wave per SIMD (two accumulator sets + two tiles of prefetched rows: ~400 registers), so every wait of
+// that wave - the LDS round trip of a weight fragment, the tail of a row load, the transposition tile of the stores - is paid in full
+// (DESIGN.md 10 rule 9): 103 us for 0.44 GB, 4.2 TB/s.  This variant is k_node_update2's recipe applied to it: EIGHT waves per
+// workgroup (two per SIMD, <= 256 registers) share the same resident planes - ONE accumulator per output block (GEMM_FP16X3S:
+// planes pre-scaled by 2^11, |w| < 31.98 - the caller keeps k_node_halves otherwise) and one tile of rows per wave, refilled k tile by
+// k tile for the wave's next tile as the registers are consumed.  Same pack layout, same arithmetic as the one-accumulator chains.
+template <int NKT>
+__global__ void __launch_bounds__(512, 1) k_node_halves2(NodeHalvesArgs a) {
+    constexpr int MODE = GEMM_FP16X3S;
+    constexpr int NW = 8;
+    __shared__ __attribute__((aligned(16))) u32x4 wl[NKT * 1024];
+    __shared__ __attribute__((aligned(16))) float st[2][NH_MAX_GRAPHS][128];          // mean, 1 / sqrt(var + eps)
+    __shared__ __attribute__((aligned(16))) float tls[NW][32 * NH_TS];                // per-wave transposition tile
+    __shared__ __attribute__((aligned(16))) float bl[128];                            // 2^11 bias (as the pack holds it)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    float* tl = tls[wave];
+    // blockIdx -> (XCD, slot); slot parity = column group, so that the two groups of a row range share an L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int grp = slot & 1;
+    const int wi = (slot >> 1) * 8 + xcd, nwg = gridDim.x >> 1;
+    {
+        const u32x4* g = reinterpret_cast<const u32x4*>(a.w[grp]);
+        constexpr int NQ = NKT * 1024 / (NW * 64);
+        u32x4 wv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) wv[q] = g[q * (NW * 64) + threadIdx.x];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) wl[q * (NW * 64) + threadIdx.x] = wv[q];
+        if (threadIdx.x < 128) bl[threadIdx.x] = a.b[grp][threadIdx.x];
+        if (a.mean)
+            for (int i = threadIdx.x; i < a.n_graphs * 128; i += NW * 64) {
+                st[0][i >> 7][i & 127] = a.mean[i];
+                st[1][i >> 7][i & 127] = 1.0f / sqrtf(a.var[i] + a.eps);
+            }
+    }
+    __syncthreads();                                   // (weights, bias and statistics in place before any wave's first tile)
+    const bool norm = a.mean != nullptr;
+    const bool write_h = norm && grp == 0 && a.h_norm;
+    const long ntiles = (a.n + 31) / 32;
+    const long stride = (long)nwg * NW;
+    long t = (long)wi * NW + wave;
+    if (t >= ntiles) return;
+    f32x4 xa[NKT][4];
+    // two base pointers per tile (this lane's row of h / node_in), every load at a compile-time offset from one of them; the row index is
+    // made opaque per tile (left alone hipcc turns each of the 20 load addresses into an induction variable of its own and spills)
+    struct Rows { const float* h; const float* nin; };
+    auto rows_of = [&](long tile) {
+        long r = min(min(tile, ntiles - 1) * 32 + j, a.n - 1);            // clamped: the last iterations prefetch rows they drop
+        asm volatile("" : "+v"(r));
+        Rows p;
+        p.h = a.h + r * 128 + 4 * half;
+        p.nin = a.node_in + r * a.kin + 4 * half;
+        return p;
+    };
+    auto request = [&](const Rows& rw, int kt) {
+        const float* p = kt < 4 ? rw.h + kt * 32 : rw.nin + (kt - 4) * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xa[kt][g] = *reinterpret_cast<const f32x4*>(p + 8 * g);
+    };
+    {
+        const Rows first = rows_of(t);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) request(first, kt);
+    }
+    float* y = a.y[grp];
+    for (; t < ntiles; t += stride) {
+        const Rows nxt = rows_of(t + stride);
+        const long row = t * 32 + j;
+        const int gid = norm ? (int)(min(row, a.n - 1) / a.rows_per_graph) : 0;
+        f32x16 acc[4], accc[4];
+        init_bias<4>(acc, bl, half);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x16 x;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[4 * g + c] = xa[kt][g][c];
+            if (kt < 4 && norm) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 m = *reinterpret_cast<const f32x4*>(&st[0][gid][kt * 32 + 8 * g + 4 * half]);
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(&st[1][gid][kt * 32 + 8 * g + 4 * half]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[4 * g + c] = (x[4 * g + c] - m[c]) * r[c];
+                }
+            }
+            request(nxt, kt);                          // into the registers this k tile has just released
+            if (write_h && kt < 4) store_tile_lines(x, tl, a.h_norm, kt * 32, t * 32, a.n, lane);
+            mma_chunk<4, MODE, false>(x, acc, accc, wl + kt * 1024, lane);
+        }
+        fold_tiles<4, MODE>(acc, accc);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) store_tile_lines(acc[nt], tl, y, nt * 32, t * 32, a.n, lane);
+    }
+}
+
+// As magnet_mpnn_node_halves_f32 with the packs of the one-accumulator mode (packing mode "fp16x3s": planes and biases times 2^11,
+// |w| < 31.98).
+extern "C" int magnet_mpnn_node_halves2_f32(const float* h, const float* node_in, int kin, long n_rows, const float* mean,
+                                            const float* var, float eps, int n_graphs, int rows_per_graph, const void* wa_f16s,
+                                            const float* ba_s, const void* wb_f16s, const float* bb_s, float* A, float* Bm,
+                                            float* h_norm, void* stream) {
+    (void)hipGetLastError();
+    if (n_rows <= 0) return 0;
+    if (kin != 0 && kin != 32 && kin != 64) return -2;
+    if (mean && (n_graphs > NH_MAX_GRAPHS || n_graphs < 1 || rows_per_graph % 32 || !var)) return -2;
+    NodeHalvesArgs a;
+    a.h = h, a.node_in = node_in, a.mean = mean, a.var = var;
+    a.w[0] = reinterpret_cast<const f32x4*>(wa_f16s), a.w[1] = reinterpret_cast<const f32x4*>(wb_f16s);
+    a.b[0] = ba_s, a.b[1] = bb_s, a.y[0] = A, a.y[1] = Bm, a.h_norm = h_norm;
+    a.n = n_rows, a.rows_per_graph = rows_per_graph, a.n_graphs = n_graphs, a.kin = kin, a.eps = eps;
+    static int ncu = 0;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        int dev;
+        hipGetDevice(&dev);
+        hipGetDeviceProperties(&prop, dev);
+        ncu = prop.multiProcessorCount;
+    }
+    const long ntiles = (n_rows + 31) / 32;
+    long pairs = (ntiles + 7) / 8;                                   // workgroup pairs that have at least one tile per wave
+    int grid = (int)(pairs * 2 < ncu ? pairs * 2 : ncu);
+    grid = (grid + 15) / 16 * 16;                                    // whole (XCD, slot pair) blocks
+    hipStream_t s = (hipStream_t)stream;
+    if (kin == 0) hipLaunchKernelGGL(k_node_halves2<4>, dim3(grid), dim3(512), 0, s, a);
+    else if (kin == 32) hipLaunchKernelGGL(k_node_halves2<5>, dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(k_node_halves2<6>, dim3(grid), dim3(512), 0, s, a);
+    return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------- MPNN node update, persistent
 // g = h + Swish(W2 Swish(W1 [h | agg | node_in] + b1) + b2)   (GNN_Layer.update, models/mpnn.py:81-90 / mpnn_2d.py:81-91, residual
 // branch in_features == out_features) for the large-graph inference path.  Same lessons as k_node_halves, for a chain whose

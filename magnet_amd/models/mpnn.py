@@ -112,6 +112,8 @@ class MPNN(LightningModule):
         self.edge_rows = int(getattr(hparams, "edge_rows", None) if getattr(hparams, "edge_rows", None) is not None
                              else os.environ.get("MAGNET_EDGE_ROWS", "5"))
         self.node_update2 = bool(int(os.environ.get("MAGNET_NODE_UPDATE2", "1"))) and bool(getattr(hparams, "node_update2", True))
+        # (k_node_halves2, two waves per SIMD on one-accumulator packs: 99.9 us against 103 and no difference per rollout - opt-in)
+        self.node_halves2 = bool(int(os.environ.get("MAGNET_NODE_HALVES2", "0"))) and bool(getattr(hparams, "node_halves2", True))
         # small batches (<= 128 rows): update + InstanceNorm of a hop in one launch (A/B knob)
         self.fused_small_norm = bool(int(os.environ.get("MAGNET_SMALL_NORM", "1"))) and bool(getattr(hparams, "fused_small_norm", True))
         assert self.edge_gemm in GEMM_MODES
@@ -190,6 +192,11 @@ class MPNN(LightningModule):
             if self.edge_l2e and self.edge_gemm in ("fp16x3", "bf16"):
                 L.pre_a_l2e = pack(wa * ops.LOG2E, m1.bias.detach() * ops.LOG2E, self.gemm, k_pad=H + kin)
                 L.pre_b_l2e = pack(wb * ops.LOG2E, None, self.gemm, k_pad=H + kin)
+                # large graphs, inference: the same halves in the one-accumulator form for k_node_halves2, two waves per SIMD (planes x
+                # 2^11, |w| < 31.98 flagged on the device like the update net's below; A/B knob MAGNET_NODE_HALVES2)
+                if self.node_halves2 and self.gemm == "fp16x3" and kin == 32:
+                    L.pre_a_l2e_s = pack(wa * ops.LOG2E, m1.bias.detach() * ops.LOG2E, "fp16x3s", k_pad=H + kin)
+                    L.pre_b_l2e_s = pack(wb * ops.LOG2E, None, "fp16x3s", k_pad=H + kin)
             L.msg2 = pack(m2.weight, m2.bias, self.edge_gemm)
             if self.edge_t16 and self.edge_gemm == "fp16x3":
                 try:                            # one-accumulator variant (planes pre-scaled by 2^11); |w| >= 31.98 keeps the two-accumulator one
@@ -291,7 +298,9 @@ class MPNN(LightningModule):
             # each workgroup so that the second group reads [h | node_in] from L2 (fp32 kernels: two workgroup columns)
             l2e = tape is None and hasattr(lyr, "pre_a_l2e")
             pa, pb = (lyr.pre_a_l2e, lyr.pre_b_l2e) if l2e else (lyr.pre_a, lyr.pre_b)
-            if fused_nodes or small_nodes:
+            if fused_nodes and l2e and hasattr(lyr, "pre_a_l2e_s"):
+                ops.mpnn_node_halves(h, node_in, lyr.pre_a_l2e_s, lyr.pre_b_l2e_s, A, Bm, stats=stats, rows_per_graph=Ns)
+            elif fused_nodes or small_nodes:
                 ops.mpnn_node_halves(h, node_in, pa, pb, A, Bm, stats=stats, rows_per_graph=Ns)
             else:
                 ops.mlp(N, ops.ktiles(T(h, H), T(node_in, kin)), [pa, pb], nl=1, ht=4, ot=4,

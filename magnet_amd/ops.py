@@ -573,9 +573,12 @@ def mpnn_node_halves(h, node_in, pre_a, pre_b, A, Bm, stats=None, rows_per_graph
     n, kin = h.shape[0], (node_in.shape[1] if node_in is not None else 0)
     mean, var = stats if stats is not None else (None, None)
     ng = mean.shape[0] if mean is not None else 0
-    L.check(L.lib().magnet_mpnn_node_halves_f32(_p(h), _p(node_in), kin, C.c_long(n), _p(mean), _p(var), C.c_float(float(eps)), ng,
-                                                int(rows_per_graph), _p(pre_a[0]), _p(pre_a[1]), _p(pre_b[0]), _p(pre_b[1]),
-                                                _p(A), _p(Bm), _p(h_norm), _stream()), "mpnn_node_halves")
+    # one-accumulator packs (packing mode "fp16x3s"): k_node_halves2, two waves per SIMD; else the two-accumulator k_node_halves
+    single = isinstance(pre_a[0], SinglePlanes) and isinstance(pre_b[0], SinglePlanes)
+    entry = L.lib().magnet_mpnn_node_halves2_f32 if single else L.lib().magnet_mpnn_node_halves_f32
+    L.check(entry(_p(h), _p(node_in), kin, C.c_long(n), _p(mean), _p(var), C.c_float(float(eps)), ng,
+                  int(rows_per_graph), _p(pre_a[0]), _p(pre_a[1]), _p(pre_b[0]), _p(pre_b[1]),
+                  _p(A), _p(Bm), _p(h_norm), _stream()), "mpnn_node_halves")
 
 
 def mpnn_node_update(h, agg, node_in, upd1, upd2, y, stats=None, rows_per_graph=0, eps=1e-5, stats_out_graphs=0):

@@ -577,10 +577,12 @@ def test_resize_linear_matches_interpolate(d, shape, out):
     assert rel_l2(got, want) < 1e-6
 
 
+@pytest.mark.parametrize("mode", ["fp16x3", "fp16x3s"])
 @pytest.mark.parametrize("kin,n_graphs,rows,with_norm", [(32, 4, 4096, True), (64, 2, 2144, True), (32, 1, 1013, False),
-                                                          (32, 8, 32, True)])
-def test_node_halves_resident_kernel_matches_norm_plus_generic_mlp(kin, n_graphs, rows, with_norm):
-    """magnet_mpnn_node_halves_f32 (InstanceNorm apply on load + both per-node halves + normalised h, weights resident in LDS)
+                                                          (32, 8, 32, True), (32, 4, 16384, True)])
+def test_node_halves_resident_kernel_matches_norm_plus_generic_mlp(kin, n_graphs, rows, with_norm, mode):
+    """magnet_mpnn_node_halves_f32 (InstanceNorm apply on load + both per-node halves + normalised h, weights resident in LDS;
+    mode "fp16x3s": magnet_mpnn_node_halves2_f32, the one-accumulator packs on two waves per SIMD)
     == magnet_instance_norm_f32 followed by the generic one-Linear launch, and both against fp64 on the host."""
     from magnet_amd import ops
     from magnet_amd.packing import pack
@@ -590,7 +592,7 @@ def test_node_halves_resident_kernel_matches_norm_plus_generic_mlp(kin, n_graphs
     ba = torch.randn(H, generator=g)
     h_raw = (torch.randn(n, H, generator=g) * 2 + 1).cuda()
     node_in = torch.randn(n, kin, generator=g).cuda()
-    pa, pb = pack(wa.cuda(), ba.cuda(), "fp16x3", k_pad=H + kin), pack(wb.cuda(), None, "fp16x3", k_pad=H + kin)
+    pa, pb = pack(wa.cuda(), ba.cuda(), mode, k_pad=H + kin), pack(wb.cuda(), None, mode, k_pad=H + kin)
     A, Bm, hn = (torch.full((n, H), float("nan"), device="cuda") for _ in range(3))
     assert ops.node_halves_supported(kin, n_graphs, rows) or not with_norm
     if with_norm:
@@ -609,7 +611,8 @@ def test_node_halves_resident_kernel_matches_norm_plus_generic_mlp(kin, n_graphs
         h_ref, h64 = h_raw, h_raw.double()
     AB = torch.empty(2, n, H, device="cuda")
     T = ops.Term
-    ops.mlp(n, ops.ktiles(T(h_ref, H), T(node_in, kin)), [pa, pb], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2,
+    ga, gb = (pa, pb) if mode == "fp16x3" else (pack(wa.cuda(), ba.cuda(), "fp16x3", k_pad=H + kin), pack(wb.cuda(), None, "fp16x3", k_pad=H + kin))
+    ops.mlp(n, ops.ktiles(T(h_ref, H), T(node_in, kin)), [ga, gb], nl=1, ht=4, ot=4, act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2,
             groups_in_block=True, y_group_stride=n * H)
     assert rel_l2(A, AB[0]) < 5e-7 and rel_l2(Bm, AB[1]) < 5e-7
     x64 = torch.cat([h64, node_in.double()], 1)
