@@ -64,7 +64,10 @@ __device__ __forceinline__ void half_swap(float& a, float& b) {
 // last edge in this tile), w = deg(r) | deg(r + 1) << 16.
 constexpr int ST_ENDS0 = 1 << 16, ST_ENDS1 = 1 << 17;
 
-template <bool L2E>
+// LBD: gather sets in flight - 2: generation 11's schedule (the Bm columns of k step ks are requested two double groups before they are
+// turned into pieces); 3 / 4: four / six double groups ahead (the first k steps of a tile already in the previous tile's epilogue),
+// eight registers more per set
+template <bool L2E, int LBD = 2>
 __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restrict__ A, const float* __restrict__ Bm,
                                                             const int32_t* __restrict__ csr_src, const int4* __restrict__ tiles,
                                                             const int32_t* __restrict__ chunk_ntiles, int tpc, int n_chunks, int n_rows,
@@ -118,6 +121,11 @@ __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restr
     int idx1;
     f32x2 an0, an1;                        // A rows of the next tile (on their way to LDS)
     float carry[4] = {0.f, 0.f, 0.f, 0.f}; // this half-wave's part of the sum over the edges of the row that is still open
+    f32x4 lb[LBD][2];                      // gathered Bm columns 16 ks + 8 half + 0..7 of one k step per set (set = ks % LBD)
+    auto request = [&](int ks, const float* pb) {
+        lb[ks % LBD][0] = *reinterpret_cast<const f32x4*>(pb + 16 * ks);
+        lb[ks % LBD][1] = *reinterpret_cast<const f32x4*>(pb + 16 * ks + 4);
+    };
 
     auto swish2 = [&](float o, float bias) {
         const float y = fmaf(o, 1.0f / R_SCALE, bias);
@@ -135,11 +143,6 @@ __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restr
 
     // ---- one iteration: GEMM + epilogue of the current tile, input production of the next one, index / A-row prefetch of the one after
     auto step = [&](int k) __attribute__((always_inline)) {
-        f32x4 lb[2][2];                        // gathered Bm columns 16 ks + 8 half + 0..7 of one k step per set
-        auto request = [&](int set, int ks, const float* pb) {
-            lb[set][0] = *reinterpret_cast<const f32x4*>(pb + 16 * ks);
-            lb[set][1] = *reinterpret_cast<const f32x4*>(pb + 16 * ks + 4);
-        };
         // the next tile's A rows -> LDS (the previous pair was last read by the previous iteration's epilogue phase)
         park(d1, an0, an1);
         const float* const arl = arl_of(d1);
@@ -178,8 +181,10 @@ __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restr
             out[n1] = mfma_xw(xl[ks], wr[bsel][1][0], out[n1]);
             out[n0] = mfma_xw(xh[ks], wr[bsel][0][0], out[n0]);
             out[n1] = mfma_xw(xh[ks], wr[bsel][1][0], out[n1]);
-            if (dg >= 2) pieces4((dg - 2) >> 1, dg & 1, la_now, lb[((dg - 2) >> 1) & 1][dg & 1]);
-            if (q == 0) request(ks & 1, ks, pb);            // set ks & 1 was drained by double groups 2 ks - 2, 2 ks - 1
+            if (dg >= 2) pieces4((dg - 2) >> 1, dg & 1, la_now, lb[((dg - 2) >> 1) % LBD][dg & 1]);
+            // k step ks + LBD - 2: its set was drained by double groups 2 ks - 2, 2 ks - 1 (the first LBD - 2 k steps of a tile are
+            // requested in the previous tile's epilogue)
+            if (q == 0 && ks + LBD - 2 < 8) request(ks + LBD - 2, pb);
             if (dg == 6) {                                  // the tile after next (d2 has arrived by now)
                 idx2 = src_of(d2);
                 a_rows(d2, an0, an1);
@@ -187,8 +192,13 @@ __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restr
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- epilogue phase: k step 7 of the next tile's inputs, then Swish of this tile's 64 outputs per lane
-        pieces4(7, 0, la, lb[1][0]);
-        pieces4(7, 1, lds_a(16 * 7 + 4), lb[1][1]);
+        pieces4(7, 0, la, lb[7 % LBD][0]);
+        pieces4(7, 1, lds_a(16 * 7 + 4), lb[7 % LBD][1]);
+        if (LBD > 2) {                         // the first k steps of the tile after next: in flight through this epilogue
+            const float* pb2 = Bm + (size_t)idx2 * 128 + 8 * half;
+#pragma unroll
+            for (int ks = 0; ks < LBD - 2; ++ks) request(ks, pb2);
+        }
         const int cnt = __builtin_amdgcn_readfirstlane(cnt_of(d0)), split = __builtin_amdgcn_readfirstlane(split_of(d0));
         const int zf = __builtin_amdgcn_readfirstlane(d0.z);
         float acc[4] = {0.f, 0.f, 0.f, 0.f}, snap[4] = {0.f, 0.f, 0.f, 0.f};
@@ -286,6 +296,11 @@ __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restr
     }
     idx1 = src_of(d1);
     a_rows(d1, an0, an1);
+    if (LBD > 2) {
+        const float* pb1 = Bm + (size_t)idx1 * 128 + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < LBD - 2; ++ks) request(ks, pb1);
+    }
     for (int k = 0; k < K; ++k) step(k);
 }
 
@@ -303,8 +318,18 @@ extern "C" int magnet_mpnn_edge_stream_fp16x3_f32(const float* A, const float* B
     const int4* td = reinterpret_cast<const int4*>(tiles);
     const u32x4* ws = reinterpret_cast<const u32x4*>(w2_t32);
     hipStream_t s = (hipStream_t)stream;
-    if (a_bm_log2e_scaled & 1) hipLaunchKernelGGL((k_mpnn_edge_stream32<true>), g, b, 0, s, A, Bm, src, td, chunk_ntiles, tpc, n_chunks, n_rows, ws, b2, agg);
-    else hipLaunchKernelGGL((k_mpnn_edge_stream32<false>), g, b, 0, s, A, Bm, src, td, chunk_ntiles, tpc, n_chunks, n_rows, ws, b2, agg);
+    const int depth = 2 + ((a_bm_log2e_scaled >> 1) & 3);     // bits 1-2 (development): gather sets in flight (2 .. 4)
+#define STREAM_LAUNCH(L2E_, LBD_) hipLaunchKernelGGL((k_mpnn_edge_stream32<L2E_, LBD_>), g, b, 0, s, A, Bm, src, td, chunk_ntiles, tpc, n_chunks, n_rows, ws, b2, agg)
+    if (a_bm_log2e_scaled & 1) {
+        if (depth == 2) STREAM_LAUNCH(true, 2);
+        else if (depth == 3) STREAM_LAUNCH(true, 3);
+        else STREAM_LAUNCH(true, 4);
+    } else {
+        if (depth == 2) STREAM_LAUNCH(false, 2);
+        else if (depth == 3) STREAM_LAUNCH(false, 3);
+        else STREAM_LAUNCH(false, 4);
+    }
+#undef STREAM_LAUNCH
     return (int)hipGetLastError();
 }
 

@@ -455,6 +455,9 @@ def mpnn_edge_rows(A, Bm, csr, plan: RowTiles, w2_t16, w2_t32, b2, agg, partials
     return agg
 
 
+STREAM_DEEP = int(__import__("os").environ.get("MAGNET_STREAM_DEEP", "1"))      # gather sets in flight beyond two (0 .. 2)
+
+
 @dataclass
 class StreamTiles:
     """Tile plan of k_mpnn_edge_stream32 (generation 14): the rows cut into n_chunks row-aligned ranges of about equal edge count, every
@@ -486,13 +489,16 @@ def stream_tiles(csr: "CSR"):
     return StreamTiles(tiles, ntiles, n_chunks, tpc, bool(fl & 2), total)
 
 
-def mpnn_edge_stream(A, Bm, csr, plan: StreamTiles, w2_t32, b2, agg, l2e=False):
-    """the fused edge op by k_mpnn_edge_stream32 (generation 14): ONE launch, no remainder pass, no straggler lists"""
+def mpnn_edge_stream(A, Bm, csr, plan: StreamTiles, w2_t32, b2, agg, l2e=False, deep=None):
+    """the fused edge op by k_mpnn_edge_stream32 (generation 14): ONE launch, no remainder pass, no straggler lists.
+    ``deep``: gather sets in flight beyond two (0, 1 = default, 2; MAGNET_STREAM_DEEP, A/B knob - bitwise the same result)"""
+    if deep is None:
+        deep = STREAM_DEEP
     assert w2_t32.dtype == torch.float16
     if plan.zero_fill:
         agg.zero_()
     L.check(L.lib().magnet_mpnn_edge_stream_fp16x3_f32(_p(A), _p(Bm), _p(csr.src), _p(plan.tiles), _p(plan.ntiles), plan.n_chunks, plan.tpc,
-                                                       csr.N, _p(w2_t32), _p(b2), _p(agg), int(l2e), _stream()), "mpnn_edge_stream_fp16x3")
+                                                       csr.N, _p(w2_t32), _p(b2), _p(agg), int(l2e) | (int(deep) << 1), _stream()), "mpnn_edge_stream_fp16x3")
     return agg
 
 

@@ -72,11 +72,18 @@ for pmin in [int(v) for v in os.environ.get("PMIN", "20").split(",")]:
         ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e)
         err = float((agg - ref).norm() / ref.norm())
         nan = int(torch.isnan(agg).sum())
-        res = {"edge16": [], "rows": [], "rows_tiles_only": [], "rowsr": [], "rowsr_tiles_only": [], "rowsg": [], "rowsp": [], "stream": []}
+        res = {"edge16": [], "rows": [], "rows_tiles_only": [], "rowsr": [], "rowsr_tiles_only": [], "rowsg": [], "rowsp": [], "stream": [], "stream_deep": [], "stream_deep2": []}
         splan = ops.stream_tiles(csr)
         agg.fill_(float("nan"))
-        ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e)
+        ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e, deep=0)
         err_s, nan_s = float((agg - ref).norm() / ref.norm()), int(torch.isnan(agg).sum())
+        keep = agg.clone()
+        agg.fill_(float("nan"))
+        ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e, deep=1)
+        same1 = bool(torch.equal(agg, keep))
+        agg.fill_(float("nan"))
+        ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e, deep=2)
+        print(f"  stream deep 1 / 2 == stream bitwise: {same1} / {bool(torch.equal(agg, keep))}")
         agg.fill_(float("nan"))
         ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e, wreg=3)
         err_p, nan_p = float((agg - ref).norm() / ref.norm()), int(torch.isnan(agg).sum())
@@ -105,7 +112,9 @@ for pmin in [int(v) for v in os.environ.get("PMIN", "20").split(",")]:
             res["rowsr_tiles_only"].append(timeit(tiles_only_r))
             res["rowsg"].append(timeit(lambda: ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e, wreg=2)))
             res["rowsp"].append(timeit(lambda: ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e, wreg=3)))
-            res["stream"].append(timeit(lambda: ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e)))
+            res["stream"].append(timeit(lambda: ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e, deep=0)))
+            res["stream_deep"].append(timeit(lambda: ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e, deep=1)))
+            res["stream_deep2"].append(timeit(lambda: ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e, deep=2)))
         fl = 2 * E * H * H * 3
         line = "  ".join(f"{k} " + "/".join(f"{v:.4f}" for v in vs) for k, vs in res.items())
         best = min(res["rows"])

@@ -465,9 +465,10 @@ def test_mpnn_edge_stream_degree_patterns(pattern, l2e):
     ops.mpnn_edge_stream(A.cuda() * scale, Bm.cuda() * scale, csr, plan, w32, b, agg, l2e=l2e)
     assert not torch.isnan(agg).any()
     assert rel_l2(agg, want) < 1e-6, rel_l2(agg, want)
-    again = torch.full((n, H), float("nan"), device="cuda")
-    ops.mpnn_edge_stream(A.cuda() * scale, Bm.cuda() * scale, csr, plan, w32, b, again, l2e=l2e)
-    assert torch.equal(agg, again)
+    for deep in (None, 0, 1, 2):                  # repeatable; two / three / four gather sets in flight: the same bits
+        again = torch.full((n, H), float("nan"), device="cuda")
+        ops.mpnn_edge_stream(A.cuda() * scale, Bm.cuda() * scale, csr, plan, w32, b, again, l2e=l2e, deep=deep)
+        assert torch.equal(agg, again), deep
 
 
 @pytest.mark.parametrize("case", ["no_edges", "under_one_tile", "one_row_owns_everything", "empty_rows_at_both_ends"])
