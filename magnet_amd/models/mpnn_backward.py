@@ -263,8 +263,15 @@ def parameter_grads(m, G):
     by_name[f"output_mlp.{last}.weight"] = c[8 * k1 + 8:8 * k1 + 8 + 8 * k2].view(1, 8, k2)
     by_name[f"output_mlp.{last}.bias"] = c[8 * k1 + 8 + 8 * k2:]
     # one flat buffer in parameter order (what FusedAdam and the gradient all-reduce consume without a gather)
-    from ..optim import FlatGrads
-    fg = FlatGrads(list(m.parameters()))
+    from ..optim import FlatGrads, flat_gradient
+    params = list(m.parameters())
+    if flat_gradient(params) is not None:
+        # FusedAdam.zero_grad has left every p.grad as a (zeroed, or partly accumulated) view of ONE flat buffer: add this call's
+        # share in place and hand autograd nothing - the same ~60 launches as the copies below, and no AccumulateGrad adds behind them
+        for (n, p_) in m.named_parameters():
+            p_.grad.add_(by_name[n].reshape(p_.grad.shape))
+        return [None] * len(params)
+    fg = FlatGrads(params)
     for (n, _), view in zip(m.named_parameters(), fg.views):
         view.copy_(by_name[n].reshape(view.shape))
     return fg.views

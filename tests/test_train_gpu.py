@@ -306,6 +306,42 @@ def test_training_step_is_deterministic_and_optimizer_steps():
     assert float(model.training_step(cb, 0).detach()) < l0          # a few Adam steps on one batch reduce its loss
 
 
+@pytest.mark.parametrize("tag", ["mpnn_2d", "magnet_gnn_tiny", "magnet_cnn_2d"])
+def test_fused_adam_zero_grad_keeps_one_flat_gradient_buffer(tag, monkeypatch):
+    """FusedAdam.zero_grad leaves every p.grad as a zeroed view of ONE flat buffer (no ~230 copy_ launches to gather the gradients for
+    the Adam kernel / the all-reduce; autograd and the accumulating backward kernels add in place).  The gradients are the same bits
+    as with torch's zero_grad (MAGNET_FLAT_GRADS=0), two backward calls accumulate, and step() reads the flat buffer itself."""
+    from magnet_amd.optim import flat_gradient
+    grads = {}
+    for flat in ("1", "0"):
+        monkeypatch.setenv("MAGNET_FLAT_GRADS", flat)
+        hp, batch, oracle, model = _pair(tag)
+        cb = {k: v.cuda() for k, v in batch.items()}
+        model.train()
+        opt = model.configure_optimizers()["optimizer"]
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt.zero_grad()
+        if flat == "1":
+            fg = flat_gradient(params)
+            assert fg is not None and fg.numel() == sum(p.numel() for p in params) and float(fg.abs().max()) == 0.0
+            assert all(p.grad is not None and p.grad.shape == p.shape for p in params)
+        else:
+            assert all(p.grad is None for p in params)
+        torch.manual_seed(5)
+        model.training_step(cb, 0).backward()
+        grads[flat] = [p.grad.clone() for p in params]
+        if flat == "1":
+            fg = flat_gradient(params)
+            assert fg is not None and opt._gradient().data_ptr() == fg.data_ptr()     # step() consumes it without a gather
+            torch.manual_seed(5)
+            model.training_step(cb, 0).backward()                                     # a second backward accumulates
+            # (g + g up to the rounding of the in-kernel additions: a kernel that adds its partial sums onto what is there rounds differently)
+            assert all(rel_l2(p.grad, 2 * g) < 1e-6 for p, g in zip(params, grads[flat]) if float(g.abs().max()) > 0)
+            opt.zero_grad()
+            assert float(flat_gradient(params).abs().max()) == 0.0
+    assert all(torch.equal(a, b) for a, b in zip(grads["1"], grads["0"]))
+
+
 def test_fused_adam_matches_torch_adam():
     """magnet_adam_f32 on the flat buffer vs torch.optim.Adam (+ StepLR) on the same gradients, several steps."""
     from magnet_amd.optim import FusedAdam
