@@ -84,7 +84,9 @@ __global__ void __launch_bounds__(256) k_pack16(PackSrc s, int NT, int KT, unsig
     if ((MODE == PACK_FP16X2 || MODE == PACK_FP16X2S) && status && bad) atomicOr(status, range_bit);
     // range_bit << 1: a weight in [31.98, 65504) - harmless for this pack, but the one-kernel backward of a hidden Linear and the edge
     // backward keep 2^11 x the fp16 high plane of the SAME weight; a training step reads this before its backward runs (packing.bad_weights)
-    else if (MODE == PACK_FP16X2 && status && big) atomicOr(status, range_bit << 1);
+    // (square 128- / 64-wide Linears only: message_net_2 and the hidden Linears of the chains are what those kernels take - a first layer
+    //  or a 32-wide output Linear with such a weight must not widen the whole process)
+    else if (MODE == PACK_FP16X2 && status && big && s.n == s.k && (s.n == 128 || s.n == 64)) atomicOr(status, range_bit << 1);
 }
 
 // fp32 fragments [kt][nt][g][lane 64][4]:  W[nt*32 + (lane & 31)][kt*32 + 8 g + 4 (lane >> 5) + c]

@@ -1064,6 +1064,23 @@ def test_one_accumulator_pack_flags_weights_out_of_its_range():
     packing.raise_if_bad_weights(w.device)
 
 
+def test_the_training_note_for_weights_over_31_98_is_left_by_square_hidden_linears_only():
+    """a weight in [31.98, 65504) fits the forward's two-accumulator planes; what cannot hold it are the 2^11-scaled planes of
+    linear_bwd128 / 64 and of the edge backward, which take square 128- / 64-wide Linears only.  The pack kernel's note (read by
+    bad_weights(training=True)) comes from those shapes - a first layer or a 32-wide output Linear with such a weight does not widen
+    the process"""
+    from magnet_amd import packing
+    dev = torch.device("cuda", torch.cuda.current_device())
+    packing.bad_weights(dev, training=True)                         # (clear what earlier tests left)
+    for shape, noted in (((128, 160), False), ((32, 128), False), ((128, 128), True), ((64, 64), True), ((64, 128), False)):
+        w = torch.randn(*shape, device="cuda") * 0.1
+        w[1, 2] = 40.0
+        packing.pack(w, None, "fp16x3")
+        assert not packing.bad_weights(dev) or False, shape         # inference: 40 is fine (and the read clears the word)
+        packing.pack(w, None, "fp16x3")
+        assert packing.bad_weights(dev, training=True) == noted, shape
+
+
 @pytest.mark.parametrize("n_graphs,rows", [(2, 50), (1, 128), (3, 37), (2, 32), (1, 7), (4, 32)])
 def test_small_update_with_fused_instance_norm_equals_the_two_launches(n_graphs, rows):
     """magnet_mpnn_node_update_norm_small_f32 (the update of a hop and its InstanceNorm in one launch when the whole batch fits one
