@@ -139,9 +139,27 @@ __global__ void __launch_bounds__(256) k_segment_sum128(const float* __restrict_
     const int s = rowptr[r], e = rowptr[r + 1];
     const int sub = lane >> 5, col = (lane & 31) * 4;
     f32x4 acc = {0, 0, 0, 0};
-    for (int k = s + sub; k < e; k += 2) {
-        const long row = perm ? perm[k] : k;
-        acc += *reinterpret_cast<const f32x4*>(x + row * 128 + col);
+    // The permuted positions of up to 64 edges of the row are fetched by ONE load (lane i: edge base + i) and handed out with
+    // ds_bpermute, so that the row loads of a half-wave do not wait for an index load each (round 5: a dependent pair of loads per
+    // 512 bytes kept this kernel at 4.8 TB/s).  Same edges per half-wave in the same order as before: same bits.
+    for (int base = s; base < e; base += 64) {
+        const int cnt = min(64, e - base);
+        const int mine = lane < cnt ? (perm ? perm[base + lane] : base + lane) : 0;
+        for (int k0 = 0; k0 < cnt; k0 += 8) {                    // four edges per half-wave in flight (uniform trip count: all lanes shuffle)
+            f32x4 v[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k0 + sub + 2 * u;
+                ok[u] = kk < cnt;
+                const long row = __shfl(mine, ok[u] ? kk : 0);
+                v[u] = *reinterpret_cast<const f32x4*>(x + row * 128 + col);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] += ok[u] ? v[u][c] : 0.f;
+        }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], 32);
