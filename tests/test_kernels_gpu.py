@@ -471,6 +471,55 @@ def test_mpnn_edge_stream_degree_patterns(pattern, l2e):
         assert torch.equal(agg, again), deep
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_mpnn_edge_stream_random_degree_sequences(seed):
+    """k_mpnn_edge_stream32 on seeded random degree sequences (a mixture per seed of a constant, a uniform range, a two-point
+    distribution and empty rows, 200 .. 4 000 rows): whenever the plan exists, the kernel agrees with a host evaluation in fp64 and
+    with k_mpnn_edge16 on the same inputs; whenever it does not, the reason is one of the documented ones."""
+    from magnet_amd import ops
+    from magnet_amd.packing import pack_edge16_fp16x2, pack_edge32t_fp16x2
+    from oracle.pyg_semantics import scatter_mean
+    g = torch.Generator().manual_seed(1000 + seed)
+    H = 128
+    n = int(torch.randint(200, 4000, (1,), generator=g))
+    kind = seed % 4
+    if kind == 0:
+        deg = torch.full((n,), int(torch.randint(17, 70, (1,), generator=g)))
+    elif kind == 1:
+        lo = int(torch.randint(17, 40, (1,), generator=g))
+        deg = torch.randint(lo, lo + int(torch.randint(1, 30, (1,), generator=g)), (n,), generator=g)
+    elif kind == 2:
+        a, b = int(torch.randint(18, 34, (1,), generator=g)), int(torch.randint(34, 100, (1,), generator=g))
+        deg = torch.where(torch.rand(n, generator=g) < 0.5, torch.full((n,), a), torch.full((n,), b))
+    else:
+        deg = torch.randint(20, 36, (n,), generator=g)
+        deg[torch.rand(n, generator=g) < 0.05] = 0
+    rowptr = torch.zeros(n + 1, dtype=torch.int32)
+    rowptr[1:] = deg.cumsum(0)
+    tgt = torch.repeat_interleave(torch.arange(n), deg)
+    E = tgt.numel()
+    src = torch.randint(0, n, (E,), generator=g)
+    A, Bm = torch.randn(n, H, generator=g), torch.randn(n, H, generator=g)
+    lin = torch.nn.Linear(H, H)
+    sw = lambda x: x * torch.sigmoid(x)  # noqa: E731
+    with torch.no_grad():
+        m = sw(lin.double()(sw((A[tgt.long()] + Bm[src.long()]).double())))
+    want = scatter_mean(m, tgt.long(), n)
+    csr = ops.CSR(rowptr.int().cuda(), src.int().cuda(), tgt.int().cuda(), n, E)
+    plan = ops.stream_tiles(csr)
+    assert plan is not None, (seed, n, E)              # rows of 17 edges and more, none longer than a chunk's slack: always planned
+    nt = plan.ntiles.cpu()
+    assert int(nt.sum()) == plan.n_tiles and 32 * plan.n_tiles >= E and plan.zero_fill == bool((deg == 0).any())
+    w32, _ = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
+    w16, b = pack_edge16_fp16x2(lin.weight.cuda(), lin.bias.cuda())
+    agg = torch.full((n, H), float("nan"), device="cuda")
+    ops.mpnn_edge_stream(A.cuda(), Bm.cuda(), csr, plan, w32, b, agg)
+    assert not torch.isnan(agg).any() and rel_l2(agg, want) < 1e-6, rel_l2(agg, want)
+    ref = torch.full((n, H), float("nan"), device="cuda")
+    ops.mpnn_edge16(A.cuda(), Bm.cuda(), csr, w16, b, ref, torch.zeros(ops.edge_scratch_floats(E), device="cuda"))
+    assert rel_l2(agg, ref) < 5e-7
+
+
 @pytest.mark.parametrize("case", ["no_edges", "under_one_tile", "one_row_owns_everything", "empty_rows_at_both_ends"])
 def test_mpnn_edge_range_partials_corner_cases(case):
     """k_mpnn_edge7 carries a row's running sum across the tiles of a wave and hands only range-crossing rows to
