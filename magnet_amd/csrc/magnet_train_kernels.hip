@@ -252,10 +252,27 @@ __global__ void __launch_bounds__(256) k_segment_sum_cols(const float* __restric
     for (int c0 = 0; c0 < q4; c0 += 64) {                            // (W <= 256: one pass)
         f32x4 acc = {0, 0, 0, 0};
         const int cc = c0 + c4;
-        if (sub < per && cc < q4) {
-            for (int k = s + sub; k < e; k += per) {
-                const long row = perm ? perm[k] : k;
-                acc += *reinterpret_cast<const f32x4*>(x + row * ldx + xcol + 4 * cc);
+        // (as k_segment_sum128: the permuted positions of up to 64 entries of the row come from ONE load and are handed out with
+        //  ds_bpermute, four row loads in flight per lane group - not an index load in front of every row load; same entries per
+        //  lane group in the same order)
+        const bool on = sub < per && cc < q4;
+        for (int base = s; base < e; base += 64) {
+            const int cnt = min(64, e - base);
+            const int mine = lane < cnt ? (perm ? perm[base + lane] : base + lane) : 0;
+            for (int k0 = 0; k0 < cnt; k0 += 4 * per) {
+                f32x4 v[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = k0 + sub + u * per;
+                    ok[u] = on && kk < cnt;
+                    const long row = __shfl(mine, ok[u] ? kk : 0);
+                    v[u] = *reinterpret_cast<const f32x4*>(x + row * ldx + xcol + 4 * (cc < q4 ? cc : 0));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] += ok[u] ? v[u][c] : 0.f;
             }
         }
         // combine the `per` partial sums (lanes c4 + q4 * sub)
