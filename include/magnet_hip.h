@@ -361,7 +361,8 @@ int magnet_mpnn_node_halves2_f32(const float* h, const float* node_in, int kin, 
 /* nbr[q*cap + 0..cnt[q]) = first `cap` nodes (ascending index, same graph) with dist^2 < r2 */
 int magnet_radius_search_f32(const float* x, int dim, int n_nodes, const int32_t* graph_ptr, int n_graphs, float r2,
                              int cap, int32_t* nbr, int32_t* cnt, void* stream);
-/* identical output, chunk-bounding-box pruning (chunk_ptr[g] = first 64-node chunk of graph g) */
+/* identical output, two-level bounding-box pruning (chunk_ptr[g] = first 64-node chunk of graph g; bbox_scratch:
+ * (n_chunks + ceil(n_chunks / 64)) * 6 floats - one box per chunk, then one per 64 chunks) */
 int magnet_radius_search_bbox_f32(const float* x, int dim, int n_nodes, const int32_t* graph_ptr,
                                   const int32_t* chunk_ptr, int n_graphs, int n_chunks, float r2, int cap,
                                   float* bbox_scratch, int32_t* nbr, int32_t* cnt, void* stream);

@@ -842,7 +842,7 @@ def radius_search(x: torch.Tensor, r, gptr: torch.Tensor, cap: int, brute_force:
         assert n % max(ng, 1) == 0, "equal-sized graphs expected (pass ragged=True otherwise)"
         cptr = torch.arange(0, (ng + 1) * per, max(per, 1), dtype=torch.int32, device=x.device)[: ng + 1]
         nchunks = ng * per
-    bbox = torch.empty(max(nchunks, 1) * 6, dtype=torch.float32, device=x.device)
+    bbox = torch.empty((max(nchunks, 1) + (nchunks + 63) // 64 + 1) * 6, dtype=torch.float32, device=x.device)   # chunk boxes + one box per 64 chunks
     L.check(L.lib().magnet_radius_search_bbox_f32(_p(x), dim, n, _p(_i32(gptr)), _p(cptr), ng, nchunks, C.c_float(r2), cap,
                                                   _p(bbox), _p(nbr), _p(cnt), _stream()), "radius_search_bbox")
     return nbr, cnt
