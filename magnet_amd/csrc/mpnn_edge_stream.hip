@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restr
                                                             const int32_t* __restrict__ csr_src, const int4* __restrict__ tiles,
                                                             const int32_t* __restrict__ chunk_ntiles, int tpc, int n_chunks, int n_rows,
                                                             const u32x4* __restrict__ w2p /* [8 ks][4 nt][2 planes][64] */,
-                                                            const float* __restrict__ b2, float* __restrict__ agg) {
+                                                            const float* __restrict__ b2, float* __restrict__ agg, int young_prio) {
     constexpr float l2e = L2E ? MAGNET_LOG2E : 1.0f;                       // the Swish outputs carry log2 e when the inputs do
     __shared__ __attribute__((aligned(16))) u32x4 wl[8 * 4 * 2 * 64];      // 64 KiB: both planes of W2, resident
     __shared__ __attribute__((aligned(16))) float arow[8][2 * AR_STRIDE];  // per wave: the two A rows of the tile whose inputs are in production
@@ -296,6 +296,9 @@ __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restr
     }
     idx1 = src_of(d1);
     a_rows(d1, an0, an1);
+    // static priority for the second-dispatched wave of every SIMD (waves 4-7): at equal priority the issue arbiter serves the OLDER
+    // wave first, and the younger one is the loser of every phase (MI355X_MICROARCH.md, "static priority for the younger half")
+    if (young_prio && wave >= 4) __builtin_amdgcn_s_setprio(1);
     if (LBD > 2) {
         const float* pb1 = Bm + (size_t)idx1 * 128 + 8 * half;
 #pragma unroll
@@ -319,7 +322,8 @@ extern "C" int magnet_mpnn_edge_stream_fp16x3_f32(const float* A, const float* B
     const u32x4* ws = reinterpret_cast<const u32x4*>(w2_t32);
     hipStream_t s = (hipStream_t)stream;
     const int depth = 2 + ((a_bm_log2e_scaled >> 1) & 3);     // bits 1-2 (development): gather sets in flight (2 .. 4)
-#define STREAM_LAUNCH(L2E_, LBD_) hipLaunchKernelGGL((k_mpnn_edge_stream32<L2E_, LBD_>), g, b, 0, s, A, Bm, src, td, chunk_ntiles, tpc, n_chunks, n_rows, ws, b2, agg)
+    const int young_prio = (a_bm_log2e_scaled >> 3) & 1;      // bit 3 (development): s_setprio 1 for the younger wave of every SIMD
+#define STREAM_LAUNCH(L2E_, LBD_) hipLaunchKernelGGL((k_mpnn_edge_stream32<L2E_, LBD_>), g, b, 0, s, A, Bm, src, td, chunk_ntiles, tpc, n_chunks, n_rows, ws, b2, agg, young_prio)
     if (a_bm_log2e_scaled & 1) {
         if (depth == 2) STREAM_LAUNCH(true, 2);
         else if (depth == 3) STREAM_LAUNCH(true, 3);

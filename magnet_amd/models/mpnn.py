@@ -111,6 +111,7 @@ class MPNN(LightningModule):
         #  mesh), k_mpnn_edge16 elsewhere; 0 = k_mpnn_edge16 everywhere.
         self.edge_rows = int(getattr(hparams, "edge_rows", None) if getattr(hparams, "edge_rows", None) is not None
                              else os.environ.get("MAGNET_EDGE_ROWS", "5"))
+        self.stream_deep = getattr(hparams, "stream_deep", None)      # generation 14's development bits (ops.mpnn_edge_stream: deep); None = default
         self.node_update2 = bool(int(os.environ.get("MAGNET_NODE_UPDATE2", "1"))) and bool(getattr(hparams, "node_update2", True))
         # (k_node_halves2, two waves per SIMD on one-accumulator packs: 99.9 us against 103 and no difference per rollout - opt-in)
         self.node_halves2 = bool(int(os.environ.get("MAGNET_NODE_HALVES2", "0"))) and bool(getattr(hparams, "node_halves2", True))
@@ -307,7 +308,7 @@ class MPNN(LightningModule):
                         act=ops.ACT_NONE, y=AB, ldy=H, colgroups=2, groups_in_block=True, y_group_stride=N * H)
             plan = self._row_plan(topo) if hasattr(lyr, "msg2_rows") else None
             if isinstance(plan, ops.StreamTiles):  # generation 14: one launch over the whole edge stream
-                ops.mpnn_edge_stream(A, Bm, csr, plan, lyr.msg2_rows[0], lyr.msg2_t16[1], agg, l2e=l2e)
+                ops.mpnn_edge_stream(A, Bm, csr, plan, lyr.msg2_rows[0], lyr.msg2_t16[1], agg, l2e=l2e, deep=self.stream_deep)
             elif plan is not None:                # tiles aligned to CSR rows (+ the remainder edges through k_mpnn_edge16)
                 ops.mpnn_edge_rows(A, Bm, csr, plan, lyr.msg2_t16[0], lyr.msg2_rows[0], lyr.msg2_t16[1], agg, partials, l2e=l2e,
                                    single16=lyr.msg2_t16_single, wreg=max(self.edge_rows - 1, 0))

@@ -455,7 +455,7 @@ def mpnn_edge_rows(A, Bm, csr, plan: RowTiles, w2_t16, w2_t32, b2, agg, partials
     return agg
 
 
-STREAM_DEEP = int(__import__("os").environ.get("MAGNET_STREAM_DEEP", "1"))      # gather sets in flight beyond two (0 .. 2)
+STREAM_DEEP = int(__import__("os").environ.get("MAGNET_STREAM_DEEP", "1"))      # gather sets in flight beyond two (0 .. 2); + 4: s_setprio 1 for the younger waves
 
 
 @dataclass

@@ -72,7 +72,7 @@ for pmin in [int(v) for v in os.environ.get("PMIN", "20").split(",")]:
         ops.mpnn_edge_rows(Ax, Bx, csr, plan, w16[0], w32t[0], w16[1], agg, partials, l2e=l2e)
         err = float((agg - ref).norm() / ref.norm())
         nan = int(torch.isnan(agg).sum())
-        res = {"edge16": [], "rows": [], "rows_tiles_only": [], "rowsr": [], "rowsr_tiles_only": [], "rowsg": [], "rowsp": [], "stream": [], "stream_deep": [], "stream_deep2": []}
+        res = {"edge16": [], "rows": [], "rows_tiles_only": [], "rowsr": [], "rowsr_tiles_only": [], "rowsg": [], "rowsp": [], "stream": [], "stream_deep": [], "stream_deep2": [], "stream_prio": []}
         splan = ops.stream_tiles(csr)
         agg.fill_(float("nan"))
         ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e, deep=0)
@@ -115,6 +115,7 @@ for pmin in [int(v) for v in os.environ.get("PMIN", "20").split(",")]:
             res["stream"].append(timeit(lambda: ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e, deep=0)))
             res["stream_deep"].append(timeit(lambda: ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e, deep=1)))
             res["stream_deep2"].append(timeit(lambda: ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e, deep=2)))
+            res["stream_prio"].append(timeit(lambda: ops.mpnn_edge_stream(Ax, Bx, csr, splan, w32t[0], w16[1], agg, l2e=l2e, deep=5)))
         fl = 2 * E * H * H * 3
         line = "  ".join(f"{k} " + "/".join(f"{v:.4f}" for v in vs) for k, vs in res.items())
         best = min(res["rows"])
