@@ -378,7 +378,9 @@ def edge_roofline(model, batch, dev, W, B, passes=3):
             "note": "fp32-class GEMM: operands split into 16-bit pieces on the matrix cores "
                     f"({nprod} MFMA products per fp32 product, fp32 accumulate); peak = 2500 / {nprod}.  The kernel runs at the near-additive "
                     "sum of its matrix-pipe time, its LDS weight-fragment reads, its gathers and its two Swish per edge-feature "
-                    "(ablations: profiles/r4/edge_rows.txt, DESIGN.md 11.1), so the fraction is the matrix pipe's share of that sum; "
+                    "(ablations: profiles/r4/edge_rows.txt, DESIGN.md 11.1; SQ counters of generation 14: profiles/r5/pmc_stream_sq_counters.txt, "
+                    "DESIGN.md 14.12 - a SIMD executes an instruction of one of its two waves 98 % of the time), so the fraction is the matrix "
+                    "pipe's share of that sum; "
                     "measured before the training leg"}
     if clk:
         roof["peak_at_clock"] = round(peak * clk / PEAK_CLOCK_MHZ, 1)
