@@ -24,6 +24,10 @@
 #include "split_single.cuh"
 #include "wgrad_private.cuh"
 
+#ifndef EB_SPLIT_TWICE
+#define EB_SPLIT_TWICE 0           // 1: round 4's per-edge power of two for GEMM 2's operand (a second split of dq)
+#endif
+
 namespace {
 
 __device__ __forceinline__ float sigmoid_wp(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -171,7 +175,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd_wp(const float* __rest
             for (int i = 0; i < 16; ++i) {
                 const float v = gd[b][i] * inv_deg * dswish_wp(acc[b][i] * (1.0f / 2048.0f));
                 acc[b][i] = v;
-                mx = fmaxf(mx, fabsf(v));
+                if (EB_SPLIT_TWICE) mx = fmaxf(mx, fabsf(v));
             }
         load_gd(1);
         {
@@ -186,12 +190,22 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd_wp(const float* __rest
             for (int i = 0; i < 16; ++i) {
                 const float v = gd[b][i] * inv_deg * dswish_wp(acc[2 + b][i] * (1.0f / 2048.0f));
                 acc[2 + b][i] = v;
-                mx = fmaxf(mx, fabsf(v));
+                if (EB_SPLIT_TWICE) mx = fmaxf(mx, fabsf(v));
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const unsigned eb = (__float_as_uint(mx) >> 23) & 0xFFu;
-        const float sc = __uint_as_float((254u - eb) << 23);
-        const float usc = __uint_as_float(eb << 23) * (1.0f / 2048.0f);
+        // GEMM 2's operand scale.  Round 5: the launch-wide power of two G (the scale of the weight gradient's operand) serves GEMM 2 as
+        // well - ONE split of dq instead of two (-294 of the 2 734 plain VALU instructions of a tile: the second split, its 64 multiplies
+        // and the per-edge maximum), as k_linear_bwd_r does since round 4.  An edge 1e5 below the launch maximum keeps ~7e-7 instead of
+        // 2.6e-7 relative in its ds1; its share of dA / dBm is 1e-5 of the largest.  EB_SPLIT_TWICE=1: the per-edge scale.
+        float sc, usc;
+        if (EB_SPLIT_TWICE) {
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const unsigned eb = (__float_as_uint(mx) >> 23) & 0xFFu;
+            sc = __uint_as_float((254u - eb) << 23);
+            usc = __uint_as_float(eb << 23) * (1.0f / 2048.0f);
+        } else {
+            sc = G;
+            usc = invG * (1.0f / 2048.0f);
+        }
         // ---- dW2 += (G dq)^T s1, db2 += colsum(G dq): s1 through the block first (its planes die here), then dq block by block
         u32x4 Bh[4][2], Bl[4][2];
 #pragma unroll
@@ -209,7 +223,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd_wp(const float* __rest
                 split_f16_plain(acc[a][2 * w] * G, acc[a][2 * w + 1] * G, h, l);
                 th[w >> 2][w & 3] = h;
                 tl[w >> 2][w & 3] = l;
-                split_f16_plain(acc[a][2 * w] * sc, acc[a][2 * w + 1] * sc, h, l);
+                if (EB_SPLIT_TWICE) split_f16_plain(acc[a][2 * w] * sc, acc[a][2 * w + 1] * sc, h, l);
                 dh[2 * a + (w >> 2)][w & 3] = h;
                 dl[2 * a + (w >> 2)][w & 3] = l;
             }
