@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd_wp(const float* __rest
                 pp[2 * w] = s0 * (1.0f + v0 * (1.0f - s0));
                 pp[2 * w + 1] = s1 * (1.0f + v1 * (1.0f - s1));
                 unsigned h, l;
-                split_f16_plain(v0 * s0, v1 * s1, h, l);
+                split_f16_prod(v0, s0, v1, s1, h, l);
                 xh[2 * kt + (w >> 2)][w & 3] = h;
                 xl[2 * kt + (w >> 2)][w & 3] = l;
             }
@@ -160,6 +160,9 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd_wp(const float* __rest
             }
         }
         const float inv_deg = e_ok ? 1.0f / (float)(re - rs) : 0.0f;          // (invalid lanes: dq = 0)
+        // one split: 1 / deg rides in the split's own multiplier (Gd = G / deg; acc holds dagg Swish'(q) only) - 64 multiplies less
+        const float dq_inv = EB_SPLIT_TWICE ? inv_deg : 1.0f;
+        const float Gd = EB_SPLIT_TWICE ? G : G * inv_deg;
         // ---- GEMM 1 (2^11 q = 2^11 (W2 s1 + b2)) and dq = dagg[i] / deg * Swish'(q), two output blocks at a time
         f32x16 acc[4];
         float mx = 0.f;
@@ -173,7 +176,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd_wp(const float* __rest
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float v = gd[b][i] * inv_deg * dswish_wp(acc[b][i] * (1.0f / 2048.0f));
+                const float v = gd[b][i] * dq_inv * dswish_wp(acc[b][i] * (1.0f / 2048.0f));
                 acc[b][i] = v;
                 if (EB_SPLIT_TWICE) mx = fmaxf(mx, fabsf(v));
             }
@@ -188,7 +191,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd_wp(const float* __rest
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float v = gd[b][i] * inv_deg * dswish_wp(acc[2 + b][i] * (1.0f / 2048.0f));
+                const float v = gd[b][i] * dq_inv * dswish_wp(acc[2 + b][i] * (1.0f / 2048.0f));
                 acc[2 + b][i] = v;
                 if (EB_SPLIT_TWICE) mx = fmaxf(mx, fabsf(v));
             }
@@ -220,7 +223,7 @@ __global__ void __launch_bounds__(256, 1) k_mpnn_edge_bwd_wp(const float* __rest
 #pragma unroll
             for (int w = 0; w < 8; ++w) {
                 unsigned h, l;
-                split_f16_plain(acc[a][2 * w] * G, acc[a][2 * w + 1] * G, h, l);
+                split_f16_prod(acc[a][2 * w], Gd, acc[a][2 * w + 1], Gd, h, l);
                 th[w >> 2][w & 3] = h;
                 tl[w >> 2][w & 3] = l;
                 if (EB_SPLIT_TWICE) split_f16_plain(acc[a][2 * w] * sc, acc[a][2 * w + 1] * sc, h, l);

@@ -12,6 +12,20 @@ __device__ __forceinline__ void split_f16_plain(float a0, float a1, unsigned& h,
     asm("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(l) : "v"(d0));
     asm("v_fma_mixhi_f16 %0, %1, 1.0, 0" MAGNET_MIX_TAIL : "+v"(l) : "v"(d1));    // (wait states: common.cuh, MAGNET_MIX_TAIL)
 }
+// the same planes of the PRODUCTS a0 m0, a1 m1 in four instructions instead of two multiplies + five: v_fma_mix multiplies, subtracts the
+// high piece and converts in one step (h = RNE fp16(a m); l = RNE fp16(a m - h) with the product exact inside the fma) - the
+// forward edge kernels' construction (mpnn_edge_rows.hip: swish_pieces)
+__device__ __forceinline__ void split_f16_prod(float a0, float m0, float a1, float m1, unsigned& h, unsigned& l) {
+    unsigned hh, ll;
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %5, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %5, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]" MAGNET_MIX_TAIL
+        : "=&v"(hh), "=&v"(ll)
+        : "v"(a0), "v"(a1), "v"(m0), "v"(m1));
+    h = hh;
+    l = ll;
+}
 // 8 consecutive edges of one staged feature row -> the two planes of an MFMA operand
 __device__ __forceinline__ float stage_operand(const float* __restrict__ row, f16x8& hi, f16x8& lo) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(row), b = *reinterpret_cast<const f32x4*>(row + 4);
