@@ -21,7 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmagnet_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", *os.environ.get("MAGNET_BUILD_DEFS", "").split()]   # MAGNET_BUILD_DEFS: extra -D... of an experiment build
 # per-source additions: the lane-per-node read-out is one fully unrolled block; below the default pragma-unroll threshold
 # hipcc unrolls it partially, indexes the row registers dynamically and puts them in scratch
 # mpnn_edge_rows.hip: hipcc's SLP vectoriser pairs the epilogue's per-value fma into v_pk_fma_f32 and pays two v_mov per pair to line the
