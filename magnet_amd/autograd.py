@@ -22,6 +22,7 @@ tape-only launch.  The backward then walks the chain back:
 from __future__ import annotations
 
 import ctypes as C
+import os
 import types
 
 import torch
@@ -133,7 +134,7 @@ def _recompute_tape(M, kts, pk, nl, x0, X, zL, K0, x0_skip=0):
     2. else, for a LayerNorm chain, ONE launch of its own (nl, ht, ot, LN) variant (the normalised output goes to a scratch array);
     3. else layer by layer: a materialisation pass for x0, then one single-Linear launch per layer (any shape the library can
        run forward can be recomputed this way)."""
-    dev = x0.device
+    dev = X[1].device if x0 is None else x0.device          # (x0 = None: the caller's backward reads the sources instead, _x0_not_needed)
     Dp = pk.ot * 32
     lnflag = 1 if pk.ln is not None else 0
     tape_only = pk.layers[0][0].dtype in (torch.float16, torch.int16)      # y = None: the chain's own output is not needed, not written
@@ -249,6 +250,34 @@ def _x0_skip_mask(m, srcs, M, np_):
     return sum(1 << kt for kt, f in enumerate(_factored_first_layer(m, srcs, M)) if f)
 
 
+def _x0_not_needed(m, srcs, M, np_, fk=None):
+    """-> {k tile: (source index, source column, scale)} when the backward can do WITHOUT the assembled first-layer input x0, else None.
+    Every k tile of the first Linear must be either factored (walked back at source-row granularity: _factored_first_layer) or ONE dense
+    Term (no index, rdiv = 1, a source of exactly M rows): its columns of x0 are a scaled copy of columns the source tensor holds
+    anyway, and dW[:, tile] = scale dz^T source[:, columns].  MAgNet's edge chains are all of this kind ([x_i | x_j | e] gathered +
+    dense, or the factored P / Q products + e): their x0 was a quarter (C4b) / a sixth (C5) of the whole tape (round 5)."""
+    # (only where it pays: a step at the reference's batch sizes is host bound and its whole tape is a few GB - there the extra launches
+    #  and the Python of this path cost more than the memory is worth.  MAGNET_X0_FREE_MIN_MB: x0 of at least this size, default 256;
+    #  MAGNET_X0_FREE=0: never)
+    if os.environ.get("MAGNET_X0_FREE", "1") == "0" or 4 * M * len(m.tiles) * 32 < float(os.environ.get("MAGNET_X0_FREE_MIN_MB", "256")) * 2 ** 20:
+        return None
+    if fk is None:
+        fk = _factored_first_layer(m, srcs, M) if (M >= _FUSED_LAYER_ROWS and np_ in (32, 64, 128)) else [False] * len(m.tiles)
+    dense = {}
+    for kt, tile in enumerate(m.tiles):
+        if fk[kt]:
+            continue
+        if len(tile) != 1:
+            return None
+        si, col, idx, scale, rdiv = tile[0]
+        s2 = srcs[si]
+        if idx is not None or rdiv != 1 or s2.dim() < 2 or s2.reshape(-1, s2.shape[-1]).shape[0] != M or not s2.is_contiguous() \
+                or col + 32 > s2.shape[-1]:
+            return None
+        dense[kt] = (si, col, float(scale))
+    return dense
+
+
 def _tile_groups(width):
     """_tiles_of with runs of equal-width blocks merged: (first column, block width, number of blocks)"""
     out = []
@@ -332,12 +361,19 @@ class _Mlp(torch.autograd.Function):
         # one more launch of the chain in the backward
         tape = ()
         K0 = len(m.tiles) * 32
-        if nl > 1 and not m.final_relu and pk.layers[0][0].dtype in (torch.float16, torch.int16) and m.M > 0 and \
-                any(ctx.needs_input_grad[1:]) and _keep_tape(4 * m.M * (K0 + (nl - 1) * pk.ht * 32 + pk.ot * 32), y.device):
+        wants_tape = nl > 1 and not m.final_relu and pk.layers[0][0].dtype in (torch.float16, torch.int16) and m.M > 0 and \
+            any(ctx.needs_input_grad[1:])
+        if wants_tape:
+            # (no x0 at all when every k tile is factored or a dense copy of a source: an empty placeholder keeps the tuple's layout)
+            np0 = pk.ht * 32
+            fk = _factored_first_layer(m, srcs, m.M) if (m.M >= _FUSED_LAYER_ROWS and np0 in (32, 64, 128)) else [False] * len(m.tiles)
+            x0_free = _x0_not_needed(m, srcs, m.M, np0, fk) is not None
+            K0t = 0 if x0_free else K0
+        if wants_tape and _keep_tape(4 * m.M * (K0t + (nl - 1) * pk.ht * 32 + pk.ot * 32), y.device):
             new = lambda w: torch.empty(m.M, w, device=y.device, dtype=torch.float32)  # noqa: E731
-            tape = (new(K0), *[new(pk.ht * 32) for _ in range(nl - 1)], *([new(pk.ot * 32)] if pk.ln is not None else []))
-            seg = dict(seg, x0_out=tape[0], hid=list(tape[1:nl]) + [tape[nl] if pk.ln is not None else None],
-                       x0_skip=_x0_skip_mask(m, srcs, m.M, pk.ht * 32))
+            tape = (new(K0t), *[new(pk.ht * 32) for _ in range(nl - 1)], *([new(pk.ot * 32)] if pk.ln is not None else []))
+            seg = dict(seg, x0_out=None if x0_free else tape[0], hid=list(tape[1:nl]) + [tape[nl] if pk.ln is not None else None],
+                       x0_skip=sum(1 << kt for kt, f in enumerate(fk) if f))
         ops.mlp(m.M, kts, pk.layers, nl=nl, ht=pk.ht, ot=pk.ot, act=ops.ACT_RELU if (nl > 1 or m.final_relu) else ops.ACT_NONE,
                 last_act=m.final_relu, ln=pk.ln, epi=m.epi, y=y, res=res, ncols=pk.out_dim, **seg)
         if m.epi == ops.EPI_SEGMEAN:
@@ -387,11 +423,18 @@ class _Mlp(torch.autograd.Function):
                    for tile in m.tiles]
             grads_par = [None] * m.n_par
             zL = None
+            x0_dense = None                                               # {k tile: (source, column, scale)} when x0 does not exist
             if tape:                                                      # kept by the forward launch
                 x0, X = tape[0], list(tape[:nl])
                 zL = tape[nl] if pk.ln is not None else None
+                if x0.numel() == 0 and M > 0:
+                    x0_dense = _x0_not_needed(m, srcs, M, pk.ht * 32)
+                    assert x0_dense is not None
             elif nl > 1:
-                x0 = torch.empty(max(M, 1), K0, device=dev, dtype=torch.float32)
+                one_launch = _tape_variant_ok(nl, pk) or (pk.ln is not None and bool(
+                    L.query("magnet_mlp_supported", nl, pk.ht, pk.ot, ops.ACT_RELU, 0, 1, ops.EPI_STORE)))
+                x0_dense = _x0_not_needed(m, srcs, M, pk.ht * 32) if (one_launch and M > 0) else None
+                x0 = None if x0_dense is not None else torch.empty(max(M, 1), K0, device=dev, dtype=torch.float32)
                 X = [x0] + [torch.empty(max(M, 1), pk.ht * 32, device=dev, dtype=torch.float32) for _ in range(nl - 1)]
                 zL = torch.empty(max(M, 1), Dp, device=dev, dtype=torch.float32) if pk.ln is not None else None
                 _recompute_tape(M, kts, pk, nl, x0, X, zL, K0, x0_skip=_x0_skip_mask(m, srcs, M, pk.ht * 32))
@@ -428,7 +471,7 @@ class _Mlp(torch.autograd.Function):
             for l in range(nl - 1, -1, -1):
                 W, b = params[2 * l], params[2 * l + 1]
                 n, k = W.shape
-                Np, Kp = dz.shape[1], X[l].shape[1]
+                Np, Kp = dz.shape[1], (K0 if (l == 0 and x0_dense is not None) else X[l].shape[1])
                 # a hidden 128 -> 128 (or 64 -> 64) Linear over many rows: data gradient + ReLU mask + weight and bias gradients in ONE kernel
                 # (csrc/linear_bwd.hip: dz and X[l] are read once instead of twice, no partial-sum passes over [M, 128] arrays)
                 if (l > 0 and n == k == Np == Kp and Np in (128, 64) and M >= _FUSED_LAYER_ROWS and pk.layers[0][0].dtype == torch.float16
@@ -472,6 +515,27 @@ class _Mlp(torch.autograd.Function):
                     need = G * nblk_w * Np * w + nblk_w * Np + G * Np * w
                     if ws.numel() < need:
                         ws = torch.empty(need, device=dev, dtype=torch.float32)
+                    if l == 0 and x0_dense is not None:
+                        # no assembled input: these columns are a scaled copy of a source's - read the source (one launch per run of
+                        # consecutive columns of one source, else per k tile), scale the block of dW afterwards
+                        # (block by block of the SAME width w as the launch over x0 had: the same kernel instantiation and the same order
+                        #  of partial sums, i.e. the same bits; a block that is not w consecutive columns of one source: k tile by k tile)
+                        spans = []
+                        for g_ in range(G):
+                            kts_b = list(range((c0 + g_ * w) // 32, (c0 + (g_ + 1) * w) // 32))
+                            si0, col0, sc0 = x0_dense[kts_b[0]]
+                            if all(x0_dense[kt] == (si0, col0 + 32 * i, sc0) for i, kt in enumerate(kts_b)):
+                                spans.append((c0 + g_ * w, w, 1, si0, col0, sc0))
+                            else:
+                                spans += [(32 * kt, 32, 1, *x0_dense[kt]) for kt in kts_b]
+                        for q, (cc, ww, GG, si_, col_, sc_) in enumerate(spans):
+                            xs = srcs[si_].reshape(-1, srcs[si_].shape[-1])
+                            L.check(L.lib().magnet_wgrad_tiles_f32(ops._p(dz), Np, Np, ops._p(xs), xs.shape[1], col_, ww, GG, C.c_long(M),
+                                                                   ops._p(dWp), Kp, cc, ops._p(dbp if (j == 0 and q == 0) else None), ops._p(ws),
+                                                                   0, ops._stream()), "wgrad_tiles")
+                            if sc_ != 1.0:
+                                dWp[:, cc:cc + ww * GG].mul_(sc_)
+                        continue
                     L.check(L.lib().magnet_wgrad_tiles_f32(ops._p(dz), Np, Np, ops._p(X[l]), Kp, c0, w, G, C.c_long(M), ops._p(dWp), Kp,
                                                            c0, ops._p(dbp if j == 0 else None), ops._p(ws), 0, ops._stream()), "wgrad_tiles")
                 if l == 0 and m.first_cols is not None:

@@ -342,6 +342,33 @@ def test_fused_adam_zero_grad_keeps_one_flat_gradient_buffer(tag, monkeypatch):
     assert all(torch.equal(a, b) for a, b in zip(grads["1"], grads["0"]))
 
 
+@pytest.mark.parametrize("case", ["gnn_512", "gnn_64"])
+def test_the_tape_without_the_assembled_first_layer_input_gives_the_same_gradients(case, monkeypatch):
+    """MAgNet's edge chains take [x_i | x_j | e] (gathered + dense) or the factored P / Q products + e: every k tile of their first Linear
+    is walked back at source-row granularity or is a scaled copy of a source tensor, so the backward reads the sources and the tape
+    keeps no x0 (autograd._x0_not_needed; C4b 177 -> 142 GB, C5 211 -> 147 GB at B = 1).  The same sums (the scales are powers of two)
+    in a slightly different blocking where two sources share a launch group ([agg | x] of the node chains: one weight-gradient launch
+    per source instead of one for both, the row blocks are dealt out per launch) - equal to the last few bits.  By default only for
+    x0 of 256 MB and more (there the chains have ONE dense source: same bits) - forced on here."""
+    import bench
+    from magnet_amd.models.factory import FACTORY
+    name, hp, mk = bench.ref_shape_cases()[case]
+    batch, _ = mk(True)
+    batch = {k: v.cuda() for k, v in batch.items()}
+    grads = {}
+    for free in ("1", "0"):
+        monkeypatch.setenv("MAGNET_X0_FREE", free)
+        monkeypatch.setenv("MAGNET_X0_FREE_MIN_MB", "0")
+        torch.manual_seed(0)
+        model = FACTORY[name](types.SimpleNamespace(**hp)).cuda().train()
+        torch.manual_seed(5)
+        model.training_step(batch, 0).backward()
+        grads[free] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert grads["1"].keys() == grads["0"].keys() and len(grads["1"]) > 50
+    assert all(rel_l2(grads["1"][n], grads["0"][n]) < 1e-6 for n in grads["1"] if float(grads["0"][n].abs().max()) > 0)
+    assert sum(torch.equal(grads["1"][n], grads["0"][n]) for n in grads["1"]) > len(grads["1"]) // 2       # (most of them to the bit)
+
+
 def test_fused_adam_matches_torch_adam():
     """magnet_adam_f32 on the flat buffer vs torch.optim.Adam (+ StepLR) on the same gradients, several steps."""
     from magnet_amd.optim import FusedAdam
