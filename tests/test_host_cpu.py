@@ -376,3 +376,40 @@ def test_hazard_rules_follow_taken_forward_branches():
     mf = ["v_mfma_f32_16x16x32_f16 v[0:3], v[8:11], v[12:15], v[0:3]", "s_cbranch_scc0 8"] + ["v_mov_b32_e32 v20, v21"] * 6 + ["v_add_f32_e32 v5, v0, v1"]
     k4 = H.Kernel(mf, addr=[0x100, 0x108] + [0x10c + 4 * i for i in range(6)] + [0x130], target=[None, 0x130] + [None] * 7)
     assert H.mfma_result_reads([("k", k4)]) == [] and len(H.path_hazards([("k", k4)])) == 1
+
+
+def test_x0_free_tape_decision(monkeypatch):
+    """autograd._x0_not_needed (host logic, no GPU): a chain keeps no assembled first-layer input on the tape exactly when every k tile is
+    either a gathered run the backward factors (index, far fewer source rows than M) or ONE dense Term of M rows - and only from the
+    size threshold on."""
+    import types
+    import torch
+    from magnet_amd import autograd as AG
+    M = 100_000
+    x = torch.zeros(1000, 64)                      # node latents (gathered)
+    e = torch.zeros(M, 32)                         # edge latents (dense)
+    idx = torch.zeros(M, dtype=torch.int32)
+
+    def meta(tiles, runs):
+        return types.SimpleNamespace(tiles=tiles, runs=runs)
+
+    # [x_i | x_j | 4 e]: two gathered 64-wide runs (k tiles 0-1, 2-3) + one dense 32-wide run (k tile 4)
+    runs = [(0, 0, idx, 1.0, 1, 0, 64), (0, 0, idx, 1.0, 1, 2, 64), (1, 0, None, 4.0, 1, 4, 32)]
+    tiles = [[(0, 0, idx, 1.0, 1)], [(0, 32, idx, 1.0, 1)], [(0, 0, idx, 1.0, 1)], [(0, 32, idx, 1.0, 1)], [(1, 0, None, 4.0, 1)]]
+    m = meta(tiles, runs)
+    monkeypatch.setenv("MAGNET_X0_FREE_MIN_MB", "0")
+    assert AG._factored_first_layer(m, [x, e], M) == [True, True, True, True, False]
+    assert AG._x0_not_needed(m, [x, e], M, 128) == {4: (1, 0, 4.0)}
+    monkeypatch.setenv("MAGNET_X0_FREE_MIN_MB", "256")          # x0 would be 100 000 x 160 x 4 B = 64 MB: below the threshold
+    assert AG._x0_not_needed(m, [x, e], M, 128) is None
+    monkeypatch.setenv("MAGNET_X0_FREE_MIN_MB", "0")
+    monkeypatch.setenv("MAGNET_X0_FREE", "0")
+    assert AG._x0_not_needed(m, [x, e], M, 128) is None
+    monkeypatch.setenv("MAGNET_X0_FREE", "1")
+    # a k tile that is the SUM of two Terms (x_i - x_j), a dense source with other than M rows, a divided gather: x0 stays
+    two = meta([[(0, 0, idx, 1.0, 1), (0, 0, idx, -1.0, 1)]] + tiles[1:], runs)
+    assert AG._x0_not_needed(two, [x, e], M, 128) is None or 0 not in AG._x0_not_needed(two, [x, e], M, 128)
+    short = torch.zeros(M // 2, 32)
+    assert AG._x0_not_needed(m, [x, short], M, 128) is None
+    rd = meta(tiles[:4] + [[(1, 0, None, 1.0, 2)]], runs[:2] + [(1, 0, None, 1.0, 2, 4, 32)])
+    assert AG._x0_not_needed(rd, [x, e], M, 128) is None
