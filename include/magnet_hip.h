@@ -189,64 +189,21 @@ int magnet_mpnn_edge_bf16_l2e_f32(const float* A_l2e, const float* Bm_l2e, const
 int magnet_mpnn_edge_fp16x3_t16_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
                                     const int32_t* rowptr, int n_edges, int n_rows, const void* w2_t16, const float* b2,
                                     float* agg, float* partials, int a_bm_log2e_scaled, void* stream);
-/* The fp16x3 edge op by the TRANSPOSED 32-edge-tile kernel (k_mpnn_edge32t, generation 9): the tile's edges are
- * the rows of the 32x32x16 MFMA, a lane owns an output feature, the per-target mean is a running sum over accumulator registers
- * (no LDS transposition), and the three products of the split share ONE accumulator.  Same result contract as
- * magnet_mpnn_edge_fp16x3_f32.  w2_t32: fp16 planes [8 k slots][4 output blocks][2 planes][64 lanes][8 fp16], both pre-scaled by
- * 2^11 (magnet_amd/packing.py:pack_edge32t_fp16x2; needs |w| < 31.98); b2 the plain bias; a_bm_log2e_scaled as for _t16.
- * partials: scratch, ceil(n_edges / 32) * 2 * 128 floats (two rows per wave range, at most one range per tile). */
-int magnet_mpnn_edge_fp16x3_t32_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
-                                    const int32_t* rowptr, int n_edges, int n_rows, const void* w2_t32, const float* b2,
-                                    float* agg, float* partials, int a_bm_log2e_scaled, void* stream);
-/* The same op, WAVE-SPECIALISED (k_mpnn_edge_ws, generation 10): eight lean waves per workgroup - two gather whole
- * rows and apply the first Swish, four run the transposed GEMM with their slice of W2 resident in registers, two apply the second
- * Swish and the running mean - pipelined over consecutive tiles through LDS, two workgroups per CU.  Arguments and result contract
- * as magnet_mpnn_edge_fp16x3_t32_f32 (w2_t32 from packing.pack_edge32t_fp16x2; a_bm_log2e_scaled 0 / 1). */
-int magnet_mpnn_edge_fp16x3_ws_f32(const float* A, const float* Bm, const int32_t* src, const int32_t* tgt,
-                                   const int32_t* rowptr, int n_edges, int n_rows, const void* w2_t32, const float* b2,
-                                   float* agg, float* partials, int a_bm_log2e_scaled, void* stream);
-/* The fp16x3 edge op on tiles ALIGNED TO CSR ROWS (k_mpnn_edge_rows32, generation 11) - GNN_Layer.message + the mean
- * of models/mpnn.py:73-79,46 for the rows that own a tile.  tiles: n_tiles descriptors of four int32 {first edge, row, edges in the
- * tile (1..32) | (edges of the row outside the tile) << 8, degree of the row}, at most one per row, rows ascending.  strag_row /
- * strag_src: the STRAGGLERS - (target, source) of the one edge a row has beyond its tile when there is exactly one (the 33rd edge of
- * an MPNN row) - rows ascending, strag_ptr[r] = stragglers of the rows before r ([n_rows + 1]; NULL = none); every wave sends the
- * stragglers of its own rows through the same pipeline first and leaves their messages in agg[row].  Rows whose tile leaves two or more edges outside must hold the MEAN over those edges in agg[row] on entry
- * (magnet_mpnn_edge_fp16x3_t16_f32 on the remainder edge list leaves exactly that).  On return agg[row] is the mean over all of the
- * row's edges for every row with a tile; rows without a tile are not touched.  src: the full CSR's sources [n_edges];
- * w2_t32 / b2 / a_bm_log2e_scaled (bit 0) as for magnet_mpnn_edge_fp16x3_t32_f32.  No scratch.
- * magnet_row_tiles_count / _fill build the plan. */
-int magnet_mpnn_edge_rows_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const void* tiles, int n_tiles,
-                                     const int32_t* strag_ptr, const int32_t* strag_row, const int32_t* strag_src,
-                                     const void* w2_t32, const float* b2, float* agg, int a_bm_log2e_scaled, void* stream);
-/* The same op with message_net_2's planes resident in the accumulation half of the register file (k_mpnn_edge_rowsr, generation 12;
- * DESIGN.md 14.2): no LDS weight-fragment reads, one wave per SIMD.  Arguments and contract exactly as
- * magnet_mpnn_edge_rows_fp16x3_f32. */
-int magnet_mpnn_edge_rowsr_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const void* tiles, int n_tiles,
-                                      const int32_t* strag_ptr, const int32_t* strag_row, const int32_t* strag_src,
-                                      const void* w2_t32, const float* b2, float* agg, int a_bm_log2e_scaled, void* stream);
-/* Generation 12b (k_mpnn_edge_rowsg): as magnet_mpnn_edge_rowsr_fp16x3_f32 with the stragglers GROUPED WITH THEIR ROWS - every wave
- * runs the 33rd edges of its next 32 rows as one tile right in front of those rows' tiles and parks their messages in LDS; the
- * straggler lists are not needed (a tile descriptor with exactly one edge outside the tile says where that edge is: first edge + 32).
- * has_stragglers = 0: no row has one (the straggler tiles are left out).  Rows with two or more edges outside their tile: the mean
- * over those in agg[row] on entry, as for the two kernels above. */
-int magnet_mpnn_edge_rowsg_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const void* tiles, int n_tiles,
-                                      int has_stragglers, const void* w2_t32, const float* b2, float* agg, int a_bm_log2e_scaled,
-                                      void* stream);
-/* Generation 13 (k_mpnn_edge_rowsp): W2's planes in the accumulation registers, one wave per SIMD, the tile's 96 MFMAs in
- * four sub-phases with the previous tile's epilogue and the next tile's input production between them; every row parks the activations
- * of its 33rd edge in LDS and a group's 32 parked edges run as one tile behind the group.  Arguments and contract as
- * magnet_mpnn_edge_rowsg_fp16x3_f32. */
-int magnet_mpnn_edge_rowsp_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const void* tiles, int n_tiles,
-                                      int has_stragglers, const void* w2_t32, const float* b2, float* agg, int a_bm_log2e_scaled,
-                                      void* stream);
 /* Generation 14 (k_mpnn_edge_stream32, csrc/mpnn_edge_stream.hip): the same op (models/mpnn.py:73-79,46 /
  * models/mpnn_2d.py:73-79,46) with 32-edge tiles cut from the edge STREAM of row-aligned chunks - a tile holds the tail of row r and the
  * head of row r + 1, a wave carries the open row's sum from tile to tile - so that no edge is left to a straggler / remainder pass.
  * tiles [n_chunks][tpc] int4 + chunk_ntiles [n_chunks] from magnet_stream_tiles_plan; n_chunks a multiple of 8.  Rows without edges
- * are not written (the plan's flags say whether there are any: zero-fill agg first). */
+ * are not written (the plan's flags say whether there are any: zero-fill agg first).
+ * w2_t32: fp16 planes [8 k slots][4 output blocks][2 planes][64 lanes][8 fp16], both pre-scaled by 2^11
+ * (magnet_amd/packing.py:pack_edge32t_fp16x2; needs |w| < 31.98); b2 the plain bias.
+ * flags: MAGNET_STREAM_L2E (bit 0) = A and Bm carry the factor log2(e), as for the _l2e entry points;
+ *        MAGNET_STREAM_GATHER3 (bit 1) = three sets of gathered Bm columns in flight instead of two (what magnet_amd passes);
+ *        every other bit must be 0 in the product library (-2); the development library (include/magnet_hip_dev.h) defines two more. */
+#define MAGNET_STREAM_L2E 1
+#define MAGNET_STREAM_GATHER3 2
 int magnet_mpnn_edge_stream_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const void* tiles,
                                        const int32_t* chunk_ntiles, int n_chunks, int tpc, int n_rows, const void* w2_t32,
-                                       const float* b2, float* agg, int a_bm_log2e_scaled, void* stream);
+                                       const float* b2, float* agg, int flags, void* stream);
 /* The plan of the kernel above: the rows are cut into n_chunks ranges of about equal edge count (chunk c starts at the first row whose
  * edges begin at or after c E / n_chunks); every chunk's edges are cut into tiles of 32 consecutive edges that touch at most two rows
  * (descriptor: x = first edge, y = row of that edge, z = cnt | split << 8 | ends0 << 16 | ends1 << 17, w = deg(row) | deg(row + 1) << 16).
@@ -254,20 +211,6 @@ int magnet_mpnn_edge_stream_fp16x3_f32(const float* A, const float* Bm, const in
  * bit 2 = some row has 65 536 edges or more (do not launch); [1] = the number of tiles of all chunks. */
 int magnet_stream_tiles_plan(const int32_t* rowptr, int n_rows, int n_chunks, int tpc, void* tiles, int32_t* chunk_ntiles,
                              int32_t* flags, void* stream);
-/* The tile plan of a CSR graph for the four kernels above.  _count, per row r: has_tile[r] = (deg_r >= pmin); has_strag[r] = the row has a
- * tile and exactly one edge beyond it; n_rem[r] = its edges for the remainder pass (those outside the tile unless that is the one
- * straggler; all of them without a tile).  _fill: given the exclusive prefix sums tile_ptr / strag_ptr / rem_ptr [n_rows + 1] of the
- * three arrays, writes the descriptors, the straggler list and the remainder edge list
- * (src_rem, tgt_rem; still sorted by target, rem_ptr is its rowptr). */
-int magnet_row_tiles_count(const int32_t* rowptr, int n_rows, int pmin, int32_t* has_tile, int32_t* has_strag, int32_t* n_rem,
-                           void* stream);
-/* The plan's three prefix arrays in one call (no host-side scans): ptrs [3][n_rows + 1] int32 receives the exclusive prefix sums of the
- * per-row has_tile / has_strag / n_rem of magnet_row_tiles_count; ptrs[k][n_rows] = number of tiles / stragglers / remainder edges.
- * Feed ptrs, ptrs + (n_rows + 1), ptrs + 2 (n_rows + 1) to magnet_row_tiles_fill. */
-int magnet_row_tiles_ptrs(const int32_t* rowptr, int n_rows, int pmin, int32_t* ptrs, void* stream);
-int magnet_row_tiles_fill(const int32_t* rowptr, const int32_t* src, int n_rows, const int32_t* tile_ptr, const int32_t* strag_ptr,
-                          const int32_t* rem_ptr, void* tiles, int32_t* strag_row, int32_t* strag_src, int32_t* src_rem,
-                          int32_t* tgt_rem, void* stream);
 /* out[n][k] = u[n][tw-1] + dt*(k+1) * Conv1d(8->1,k2)([Swish](Conv1d(1->8,k1,stride s1)(h[n])))[k];
  * models/mpnn.py:197-201 with the conv specs of :140-163. */
 int magnet_mpnn_readout_f32(const float* h, const float* u, int n, int tw, const float* w1, const float* b1, int k1,

@@ -48,9 +48,12 @@ class MlpArgs(C.Structure):
                 ("status", C.c_void_p), ("status_bit", C.c_int32), ("pad2_", C.c_int32)]
 
 
-def declared_symbols() -> list[str]:
-    """every function name declared in include/magnet_hip.h"""
-    txt = open(HEADER).read()
+DEV_HEADER = os.path.join(os.path.dirname(HERE), "include", "magnet_hip_dev.h")
+
+
+def declared_symbols(header: str = HEADER) -> list[str]:
+    """every function name declared in include/magnet_hip.h (or the development header)"""
+    txt = open(header).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\bint\s+(magnet_\w+)\s*\(", txt)))
 
@@ -76,8 +79,7 @@ def lib() -> C.CDLL:
                 # through this handle drops the cached answers
                 setattr(_lib, name, _forgetting(fn))
         if DEV:
-            for name in ("magnet_debug_set_variant", "magnet_debug_set_mlp_ablation", "magnet_debug_set_mlp_trace",
-                         "magnet_debug_set_edge_bwd_ablation"):
+            for name in declared_symbols(DEV_HEADER):   # the development library's extra entries (include/magnet_hip_dev.h)
                 getattr(_lib, name).restype = C.c_int
     return _lib
 

@@ -39,17 +39,38 @@ ACCUM_PARAM_GRADS = __import__("os").environ.get("MAGNET_ACCUM_PARAM_GRADS", "1"
 _ACCUM = {"on": False}
 
 
+def in_ddp_forward() -> bool:
+    """True while a ``DistributedDataParallel`` wrapper is running its module's forward (Lightning's DDP strategy routes
+    ``training_step`` through it): the reducer's hooks sit on the AccumulateGrad nodes and must see every parameter gradient."""
+    try:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        return DDP._get_active_ddp_module() is not None
+    except Exception:                                   # no distributed build: no DDP
+        return False
+
+
+def takes_inplace_grad(p) -> bool:
+    """a leaf parameter whose gradient may be added to ``p.grad`` behind autograd's back: nothing hangs on it that would notice"""
+    return (p.is_leaf and p.requires_grad and not getattr(p, "_backward_hooks", None)
+            and not getattr(p, "_post_accumulate_grad_hooks", None))
+
+
 class accumulate_param_grads:
     """``with accumulate_param_grads():`` around the forward of a training step that will be differentiated with ``loss.backward()``
     (the models' ``training_step``): the chains built inside let their one-kernel Linear backward (``ops.linear_bwd128``) ADD the weight
     and bias gradient of a leaf parameter to ``p.grad`` in the kernel (the first contribution of a step becomes ``p.grad``) and hand
     autograd None for it.  A rollout calls every chain once per forward, so without this torch's AccumulateGrad adds four [128, 128]
     gradients per parameter one tiny kernel at a time: 893 ``aten::add_`` per magnet_gnn step at the reference's batch size.  Not for
-    ``torch.autograd.grad`` (which must not touch ``.grad``): outside this context the Functions return every gradient as before."""
+    ``torch.autograd.grad`` (which must not touch ``.grad``): outside this context the Functions return every gradient as before.
+
+    A gradient that never passes through autograd's AccumulateGrad fires none of the hooks that hang on it: DistributedDataParallel's
+    reducer (Lightning ``strategy='ddp'``, the reference's multi-GPU mode, README.md:124-125), ``Tensor.register_hook`` and
+    ``register_post_accumulate_grad_hook``.  So the scope switches itself OFF inside a DDP forward (``in_ddp_forward``), and a
+    parameter that carries a hook is always handed to autograd (``takes_inplace_grad``)."""
 
     def __enter__(self):
         self.prev = _ACCUM["on"]
-        _ACCUM["on"] = ACCUM_PARAM_GRADS
+        _ACCUM["on"] = ACCUM_PARAM_GRADS and not in_ddp_forward()
         return self
 
     def __exit__(self, *exc):
@@ -254,7 +275,8 @@ def _x0_not_needed(m, srcs, M, np_, fk=None):
     """-> {k tile: (source index, source column, scale)} when the backward can do WITHOUT the assembled first-layer input x0, else None.
     Every k tile of the first Linear must be either factored (walked back at source-row granularity: _factored_first_layer) or ONE dense
     Term (no index, rdiv = 1, a source of exactly M rows): its columns of x0 are a scaled copy of columns the source tensor holds
-    anyway, and dW[:, tile] = scale dz^T source[:, columns].  MAgNet's edge chains are all of this kind ([x_i | x_j | e] gathered +
+    anyway, and dW[:, tile] = scale dz^T source[:, columns] (dW is scaled AFTER the reduction: the same bits as scaling x0 before it
+    only for the power-of-two scales MAgNet's chains use - else equal to rounding).  MAgNet's edge chains are all of this kind ([x_i | x_j | e] gathered +
     dense, or the factored P / Q products + e): their x0 was a quarter (C4b) / a sixth (C5) of the whole tape (round 5)."""
     # (only where it pays: a step at the reference's batch sizes is host bound and its whole tape is a few GB - there the extra launches
     #  and the Python of this path cost more than the memory is worth.  MAGNET_X0_FREE_MIN_MB: x0 of at least this size, default 256;
@@ -271,7 +293,7 @@ def _x0_not_needed(m, srcs, M, np_, fk=None):
             return None
         si, col, idx, scale, rdiv = tile[0]
         s2 = srcs[si]
-        if idx is not None or rdiv != 1 or s2.dim() < 2 or s2.reshape(-1, s2.shape[-1]).shape[0] != M or not s2.is_contiguous() \
+        if idx is not None or rdiv != 1 or s2.dtype != torch.float32 or s2.dim() < 2 or s2.reshape(-1, s2.shape[-1]).shape[0] != M or not s2.is_contiguous() \
                 or col + 32 > s2.shape[-1]:
             return None
         dense[kt] = (si, col, float(scale))
@@ -367,7 +389,8 @@ class _Mlp(torch.autograd.Function):
             # (no x0 at all when every k tile is factored or a dense copy of a source: an empty placeholder keeps the tuple's layout)
             np0 = pk.ht * 32
             fk = _factored_first_layer(m, srcs, m.M) if (m.M >= _FUSED_LAYER_ROWS and np0 in (32, 64, 128)) else [False] * len(m.tiles)
-            x0_free = _x0_not_needed(m, srcs, m.M, np0, fk) is not None
+            m.x0_dense = _x0_not_needed(m, srcs, m.M, np0, fk)        # the decision travels with the tape (not re-derived from the
+            x0_free = m.x0_dense is not None                          # environment in the backward)
             K0t = 0 if x0_free else K0
         if wants_tape and _keep_tape(4 * m.M * (K0t + (nl - 1) * pk.ht * 32 + pk.ot * 32), y.device):
             new = lambda w: torch.empty(m.M, w, device=y.device, dtype=torch.float32)  # noqa: E731
@@ -428,7 +451,7 @@ class _Mlp(torch.autograd.Function):
                 x0, X = tape[0], list(tape[:nl])
                 zL = tape[nl] if pk.ln is not None else None
                 if x0.numel() == 0 and M > 0:
-                    x0_dense = _x0_not_needed(m, srcs, M, pk.ht * 32)
+                    x0_dense = m.x0_dense                                 # what the forward decided when it left x0 out of the tape
                     assert x0_dense is not None
             elif nl > 1:
                 one_launch = _tape_variant_ok(nl, pk) or (pk.ln is not None and bool(
@@ -481,7 +504,7 @@ class _Mlp(torch.autograd.Function):
                     dX = torch.empty(M, Np, device=dev, dtype=torch.float32)
                     # (a frozen Linear - requires_grad=False tensors are leaves too - must not get a .grad from here: autograd drops
                     #  what backward returns for it, an optimizer built over self.parameters() would not drop an assigned .grad)
-                    into = (m.accum and W.is_leaf and b.is_leaf and W.requires_grad and b.requires_grad
+                    into = (m.accum and takes_inplace_grad(W) and takes_inplace_grad(b)
                             and W.dtype == b.dtype == torch.float32 and tuple(W.shape) == (Np, Np) and tuple(b.shape) == (Np,))
                     Wg, bg = (W.grad, b.grad) if into else (None, None)
                     if (Wg is not None and bg is not None and Wg.dtype == bg.dtype == torch.float32 and Wg.device == bg.device == dev

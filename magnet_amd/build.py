@@ -30,15 +30,21 @@ EXTRA_FLAGS = {"readout_kernels.hip": ["-mllvm", "-pragma-unroll-threshold=20000
                "mpnn_edge_rows.hip": ["-fno-slp-vectorize"], "mpnn_edge_stream.hip": ["-fno-slp-vectorize"], "mpnn_edge_rowsr.hip": ["-fno-slp-vectorize"], "mpnn_edge_rowsp.hip": ["-fno-slp-vectorize"], "mpnn_edge_bwd_wp.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
-def sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+# earlier generations of the fused MPNN edge op (9-13): measured slower than or equal to k_mpnn_edge16 / k_mpnn_edge_stream32 and reached
+# by no default path - compiled into the development library only (their entries: include/magnet_hip_dev.h, wrappers: dev_ops.py)
+DEV_ONLY = ("mpnn_edge32t.hip", "mpnn_edge_ws.hip", "mpnn_edge_rows.hip", "mpnn_edge_rowsr.hip", "mpnn_edge_rowsp.hip")
+
+
+def sources(dev: bool = True):
+    every = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    return every if dev else [s for s in every if os.path.basename(s) not in DEV_ONLY]
 
 
 def needs_build(lib: str = LIB) -> bool:
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.cuh"))
+    deps = sources(lib != LIB) + glob.glob(os.path.join(CSRC, "*.cuh"))
     return any(os.path.getmtime(p) > t for p in deps)
 
 
@@ -62,7 +68,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
     lib = DEV_LIB if dev else LIB
     if not force and not needs_build(lib):
         return lib
-    srcs = sources()
+    srcs = sources(dev)
     if force:
         for s in srcs:
             o = os.path.splitext(s)[0] + (".dev.o" if dev else ".o")

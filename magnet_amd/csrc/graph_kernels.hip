@@ -160,9 +160,11 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan(int32_t* __restrict__ v
     __shared__ int wsum[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nch = (n + 4095) / 4096;
+    // 16-byte accesses only from a 16-byte aligned array (the stride of a multi-array launch need not be a multiple of four ints)
+    const bool vec = (reinterpret_cast<uintptr_t>(v) & 15) == 0;
     auto load = [&](int ch, int (&x)[4]) {
         const int b = ch * 4096 + t * 4;
-        if (b + 3 < n) {
+        if (vec && b + 3 < n) {
             const int4 q = *reinterpret_cast<const int4*>(v + b);
             x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
         } else {
@@ -194,7 +196,7 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan(int32_t* __restrict__ v
         __syncthreads();
         int run = carry + before + inc - s;
         const int b = ch * 4096 + t * 4;
-        if (b + 3 < n) {
+        if (vec && b + 3 < n) {
             int4 q;
             q.x = run, q.y = run + x[0], q.z = run + x[0] + x[1], q.w = run + x[0] + x[1] + x[2];
             *reinterpret_cast<int4*>(v + b) = q;

@@ -307,31 +307,41 @@ __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restr
     for (int k = 0; k < K; ++k) step(k);
 }
 
-// A, Bm [n_rows, 128] fp32 (times log2 e when a_bm_log2e_scaled & 1); src [n_edges] the CSR's sources; tiles [n_chunks][tpc] int4 and
+// A, Bm [n_rows, 128] fp32 (times log2 e when flags & MAGNET_STREAM_L2E); src [n_edges] the CSR's sources; tiles [n_chunks][tpc] int4 and
 // chunk_ntiles [n_chunks] from magnet_stream_tiles_plan (n_chunks a multiple of 8); w2_t32 / b2 from packing.pack_edge32t_fp16x2.
 // agg [n_rows, 128] receives the mean over the edges of every row that has edges; rows without edges are NOT written (the plan reports
-// them: the caller zero-fills agg first).
+// them: the caller zero-fills agg first).  flags: include/magnet_hip.h (bit 0 log2(e)-scaled inputs, bit 1 three gather sets in flight);
+// the development library adds bit 2 (four gather sets) and bit 3 (s_setprio 1 for the younger wave of every SIMD), include/magnet_hip_dev.h.
 extern "C" int magnet_mpnn_edge_stream_fp16x3_f32(const float* A, const float* Bm, const int32_t* src, const void* tiles,
                                                   const int32_t* chunk_ntiles, int n_chunks, int tpc, int n_rows, const void* w2_t32,
-                                                  const float* b2, float* agg, int a_bm_log2e_scaled, void* stream) {
+                                                  const float* b2, float* agg, int flags, void* stream) {
     (void)hipGetLastError();
+#ifdef MAGNET_DEV_VARIANTS
+    if (flags & ~15) return -2;
+#else
+    if (flags & ~3) return -2;
+#endif
     if (n_chunks <= 0 || n_rows <= 0) return 0;
     if (n_chunks % 8 || tpc <= 0) return -2;
     const dim3 g(n_chunks / 8), b(512);
     const int4* td = reinterpret_cast<const int4*>(tiles);
     const u32x4* ws = reinterpret_cast<const u32x4*>(w2_t32);
     hipStream_t s = (hipStream_t)stream;
-    const int depth = 2 + ((a_bm_log2e_scaled >> 1) & 3);     // bits 1-2 (development): gather sets in flight (2 .. 4)
-    const int young_prio = (a_bm_log2e_scaled >> 3) & 1;      // bit 3 (development): s_setprio 1 for the younger wave of every SIMD
+    const int depth = (flags & 4) ? 4 : (flags & 2) ? 3 : 2;      // gather sets in flight
+    const int young_prio = (flags >> 3) & 1;
 #define STREAM_LAUNCH(L2E_, LBD_) hipLaunchKernelGGL((k_mpnn_edge_stream32<L2E_, LBD_>), g, b, 0, s, A, Bm, src, td, chunk_ntiles, tpc, n_chunks, n_rows, ws, b2, agg, young_prio)
-    if (a_bm_log2e_scaled & 1) {
+    if (flags & 1) {
         if (depth == 2) STREAM_LAUNCH(true, 2);
         else if (depth == 3) STREAM_LAUNCH(true, 3);
+#ifdef MAGNET_DEV_VARIANTS
         else STREAM_LAUNCH(true, 4);
+#endif
     } else {
         if (depth == 2) STREAM_LAUNCH(false, 2);
         else if (depth == 3) STREAM_LAUNCH(false, 3);
+#ifdef MAGNET_DEV_VARIANTS
         else STREAM_LAUNCH(false, 4);
+#endif
     }
 #undef STREAM_LAUNCH
     return (int)hipGetLastError();

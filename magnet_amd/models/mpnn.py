@@ -21,7 +21,7 @@ import types
 import torch
 from torch import nn
 
-from .. import ops
+from .. import _lib, ops
 from ..lightning_compat import LightningModule
 from ..packing import GEMM_MODES, default_gemm, pack, pack_edge16_fp16x2, pack_edge32t_fp16x2, pad_to, param_list
 from ..packing import effective as effective_gemm
@@ -98,19 +98,21 @@ class MPNN(LightningModule):
         self.edge_t16 = bool(int(os.environ.get("MAGNET_EDGE_T16", "1"))) and bool(getattr(hparams, "edge_t16", True))
         # fp16x3, 16-edge tiles: one accumulator for the three products of the split (weight planes pre-scaled by 2^11; A/B knob)
         self.edge_single = bool(int(os.environ.get("MAGNET_EDGE_SINGLE", "0"))) and bool(getattr(hparams, "edge_single", True))
-        # fp16x3: the transposed 32-edge-tile kernel (k_mpnn_edge32t, generation 9) instead of k_mpnn_edge16 (A/B knob)
-        # (2 = its two-waves-per-SIMD sibling k_mpnn_edge32p)
+        # The fused edge op's kernel on fp16x3.  ``hparams.edge_rows``: True / None = the default - generation 14 (k_mpnn_edge_stream32: 32-edge
+        # tiles cut from the edge stream of row-aligned chunks) where the graph suits it (rows of 17 edges and more on
+        # average, tiles >= 85 % full: every 2-D MPNN mesh), k_mpnn_edge16 elsewhere; False / 0 = k_mpnn_edge16 everywhere.
+        # MAGNET_EDGE_ROWS (or an int hparam) 1 .. 4 and MAGNET_EDGE_T32 select the earlier generations 11, 12, 12b, 13 / 9 for A/Bs - they
+        # exist in the DEVELOPMENT library only (MAGNET_DEV_LIB=1, magnet_amd/dev_ops.py).
+        er = getattr(hparams, "edge_rows", None)
+        if er is None:
+            er = int(os.environ.get("MAGNET_EDGE_ROWS", "5"))
+        elif isinstance(er, bool):
+            er = 5 if er else 0
+        self.edge_rows = int(er)
         self.edge_t32 = int(os.environ.get("MAGNET_EDGE_T32", "0")) if getattr(hparams, "edge_t32", True) else 0
-        # fp16x3: the row-aligned kernel (k_mpnn_edge_rows32, generation 11) where the graph's rows are long enough to own tiles
-        # (2-D meshes: 30 .. 33 edges per row); A/B knob, DESIGN.md 11.1
-        # (2 = generation 12, k_mpnn_edge_rowsr: the same tiles with W2's planes resident in the accumulation registers; 3 = generation 12b,
-        #  k_mpnn_edge_rowsg: that + the rows' 33rd edges grouped with their rows; 4 = generation 13, k_mpnn_edge_rowsp: one software
-        #  pipeline per wave - DESIGN.md 14.2; 5 = generation 14, k_mpnn_edge_stream32: 32-edge tiles cut from the edge stream of row-aligned
-        #  chunks, two rows per tile, no stragglers and no remainder pass - DESIGN.md 14.6)
-        #  DEFAULT since round 5: 5 where the graph suits it (rows of 17 edges and more on average, tiles >= 85 % full: every 2-D MPNN
-        #  mesh), k_mpnn_edge16 elsewhere; 0 = k_mpnn_edge16 everywhere.
-        self.edge_rows = int(getattr(hparams, "edge_rows", None) if getattr(hparams, "edge_rows", None) is not None
-                             else os.environ.get("MAGNET_EDGE_ROWS", "5"))
+        if (self.edge_rows not in (0, 5) or self.edge_t32) and not _lib.DEV:
+            raise RuntimeError(f"edge_rows = {self.edge_rows} / edge_t32 = {self.edge_t32}: generations 9-13 of the edge kernel are in the "
+                               "development library only (python -m magnet_amd.build --dev; MAGNET_DEV_LIB=1)")
         self.stream_deep = getattr(hparams, "stream_deep", None)      # generation 14's development bits (ops.mpnn_edge_stream: deep); None = default
         self.node_update2 = bool(int(os.environ.get("MAGNET_NODE_UPDATE2", "1"))) and bool(getattr(hparams, "node_update2", True))
         # (k_node_halves2, two waves per SIMD on one-accumulator packs: 99.9 us against 103 and no difference per rollout - opt-in)
@@ -310,10 +312,12 @@ class MPNN(LightningModule):
             if isinstance(plan, ops.StreamTiles):  # generation 14: one launch over the whole edge stream
                 ops.mpnn_edge_stream(A, Bm, csr, plan, lyr.msg2_rows[0], lyr.msg2_t16[1], agg, l2e=l2e, deep=self.stream_deep)
             elif plan is not None:                # tiles aligned to CSR rows (+ the remainder edges through k_mpnn_edge16)
-                ops.mpnn_edge_rows(A, Bm, csr, plan, lyr.msg2_t16[0], lyr.msg2_rows[0], lyr.msg2_t16[1], agg, partials, l2e=l2e,
-                                   single16=lyr.msg2_t16_single, wreg=max(self.edge_rows - 1, 0))
+                from .. import dev_ops
+                dev_ops.mpnn_edge_rows(A, Bm, csr, plan, lyr.msg2_t16[0], lyr.msg2_rows[0], lyr.msg2_t16[1], agg, partials, l2e=l2e,
+                                       single16=lyr.msg2_t16_single, wreg=max(self.edge_rows - 1, 0))
             elif hasattr(lyr, "msg2_t32"):        # training forward too (plain halves: l2e is False with a tape)
-                ops.mpnn_edge32t(A, Bm, csr, lyr.msg2_t32[0], lyr.msg2_t32[1], agg, partials, l2e=l2e, paired=self.edge_t32 == 2)
+                from .. import dev_ops
+                dev_ops.mpnn_edge32t(A, Bm, csr, lyr.msg2_t32[0], lyr.msg2_t32[1], agg, partials, l2e=l2e, paired=self.edge_t32 == 2)
             elif hasattr(lyr, "msg2_t16"):
                 ops.mpnn_edge16(A, Bm, csr, lyr.msg2_t16[0], lyr.msg2_t16[1], agg, partials, l2e=l2e, single=lyr.msg2_t16_single)
             else:
@@ -380,7 +384,8 @@ class MPNN(LightningModule):
                 if plan is not None and 100 * topo.csr.E < 85 * 32 * plan.n_tiles:
                     plan = None
             else:
-                plan = ops.row_tiles(topo.csr)
+                from .. import dev_ops
+                plan = dev_ops.row_tiles(topo.csr)
                 if 2 * (plan.rem.E) > topo.csr.E:
                     plan = None
             topo.row_plan = plan
@@ -560,7 +565,8 @@ class MPNN(LightningModule):
                 if fp is not None and (fp.n_chunks, fp.tpc, fp.zero_fill) == (hp.n_chunks, hp.tpc, hp.zero_fill):
                     pairs += [(hp.tiles, fp.tiles), (hp.ntiles, fp.ntiles)]
             elif hp:                           # the tile plan is part of the graph: rebuilt from the fresh CSR like the CSR itself
-                fp = ops.row_tiles(fresh.csr, hp.pmin)
+                from .. import dev_ops
+                fp = dev_ops.row_tiles(fresh.csr, hp.pmin)
                 if (fp.n_tiles, fp.n_strag, fp.rem.E) == (hp.n_tiles, hp.n_strag, hp.rem.E):
                     pairs += [(hp.tiles, fp.tiles), (hp.strag_ptr, fp.strag_ptr), (hp.strag_row, fp.strag_row),
                               (hp.strag_src, fp.strag_src), (hp.rem.rowptr, fp.rem.rowptr), (hp.rem.src, fp.rem.src),

@@ -238,8 +238,9 @@ def backward_call(m, tape, dout, G, ws):
     return du
 
 
-def parameter_grads(m, G):
-    """kernel-layout gradient buffers -> one tensor per parameter, in ``m.parameters()`` order."""
+def parameter_grads(m, G, inplace=False):
+    """kernel-layout gradient buffers -> one tensor per parameter, in ``m.parameters()`` order.  ``inplace`` (only what
+    ``training_step`` decided in its forward, see ``_Rollout.forward``): add to the flat ``p.grad`` views instead and return Nones."""
     H, tw, dp = m.hidden_features, m.time_window, m.dpos
     nin = tw + dp + 1
     k1, _, k2 = _READOUT[tw]
@@ -265,9 +266,12 @@ def parameter_grads(m, G):
     # one flat buffer in parameter order (what FusedAdam and the gradient all-reduce consume without a gather)
     from ..optim import FlatGrads, flat_gradient
     params = list(m.parameters())
-    if flat_gradient(params) is not None:
+    from ..autograd import takes_inplace_grad
+    if inplace and flat_gradient(params) is not None and all(takes_inplace_grad(p_) for p_ in params):
         # FusedAdam.zero_grad has left every p.grad as a (zeroed, or partly accumulated) view of ONE flat buffer: add this call's
-        # share in place and hand autograd nothing - the same ~60 launches as the copies below, and no AccumulateGrad adds behind them
+        # share in place and hand autograd nothing - the same ~60 launches as the copies below, and no AccumulateGrad adds behind them.
+        # Nothing that hangs on AccumulateGrad fires on this path, so it is taken only for a ``training_step`` outside a DDP forward
+        # whose parameters carry no hooks (autograd.accumulate_param_grads); ``torch.autograd.grad`` on that loss would get Nones.
         for (n, p_) in m.named_parameters():
             p_.grad.add_(by_name[n].reshape(p_.grad.shape))
         return [None] * len(params)
@@ -292,6 +296,8 @@ class _Rollout(torch.autograd.Function):
             with torch.no_grad():
                 u_hat, target = m.rollout(batch, teacher_forcing, tapes=tapes)
         ctx.m, ctx.tapes, ctx.tf = m, tapes, teacher_forcing
+        from ..autograd import ACCUM_PARAM_GRADS, in_ddp_forward
+        ctx.inplace = ACCUM_PARAM_GRADS and not in_ddp_forward()    # decided where DDP's forward is still on the stack
         m._last_target = target
         return u_hat.contiguous()
 
@@ -313,7 +319,7 @@ class _Rollout(torch.autograd.Function):
                     ops.axpy(dout, carry, 1.0, out=dout)
                 du = backward_call(m, tapes[i], dout, G, ws)
                 carry = None if ctx.tf else du
-            grads = parameter_grads(m, G)
+            grads = parameter_grads(m, G, inplace=ctx.inplace)
         ctx.tapes = None
         return (None, None, None, *grads)
 

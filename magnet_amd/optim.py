@@ -86,13 +86,25 @@ class FusedAdam(torch.optim.Optimizer):
         import os
         if os.environ.get("MAGNET_FLAT_GRADS", "1") == "0":
             return super().zero_grad(set_to_none=set_to_none)
-        if self._gbuf is None:
-            self._gbuf = FlatGrads(self._params)
+        # (``set_to_none`` is not honoured on this path: a None gradient would break the flat layout.  Code that tells "no gradient
+        #  this step" from ``p.grad is None`` sees zeros instead; a parameter frozen AFTER construction is the exception below.)
+        gb = self._gbuf
+        if gb is None or any(v.device != p_.device or v.shape != p_.shape or p_.dtype != torch.float32
+                             for p_, v in zip(self._params, gb.views)):
+            gb = self._gbuf = FlatGrads(self._params)          # first call, or the model moved / changed dtype since: stale views
         else:
-            self._gbuf.flat.zero_()
-        for p_, v in zip(self._params, self._gbuf.views):
-            if p_.grad is not v:
+            gb.flat.zero_()
+        for p_, v in zip(self._params, gb.views):
+            if not p_.requires_grad:                           # frozen after construction: no gradient, and (zero slice) no Adam motion
+                p_.grad = None                                 # beyond what its decaying moments still carry - as torch's Adam skips it
+            elif p_.grad is not v:
                 p_.grad = v
+
+    def _spans(self):
+        o = 0
+        for p in self._params:
+            yield o, p.numel()
+            o += p.numel()
 
     def _gradient(self):
         g = flat_gradient(self._params)
@@ -186,10 +198,16 @@ class FusedAdam(torch.optim.Optimizer):
         grp = self.param_groups[0]
         g = self._gradient()
         self.steps += 1
+        frozen = [(o, k) for (o, k), p_ in zip(self._spans(), self._params) if not p_.requires_grad]
+        keep = [(o, k, self.flat_p[o:o + k].clone(), self.flat_m[o:o + k].clone(), self.flat_v[o:o + k].clone()) for o, k in frozen]
         L.check(L.lib().magnet_adam_f32(ops._p(self.flat_p), ops._p(g), ops._p(self.flat_m), ops._p(self.flat_v),
                                         C.c_long(self.flat_p.numel()), C.c_float(grp["lr"]), C.c_float(grp["betas"][0]),
                                         C.c_float(grp["betas"][1]), C.c_float(grp["eps"]), C.c_float(grp["weight_decay"]),
                                         self.steps, ops._stream()), "adam")
+        for o, k, p0, m0, v0 in keep:                          # frozen after construction: torch's Adam skips a parameter without
+            self.flat_p[o:o + k].copy_(p0)                     # a gradient - value and moments stay as they were
+            self.flat_m[o:o + k].copy_(m0)
+            self.flat_v[o:o + k].copy_(v0)
         if self.on_step is not None:                           # the kernel wrote behind torch's version counters:
             self.on_step()                                     # tell the model its packed-weight caches are stale
         return loss

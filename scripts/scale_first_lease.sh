@@ -56,7 +56,8 @@ for n in (1, 2, 4, 8):
     cp = os.path.join(out, f"train_c5_n{n}.json")
     if os.path.exists(cp) and os.path.getsize(cp):
         c = json.loads(open(cp).read().strip().splitlines()[-1])["training_step"]
-        same = c.get("param_abs_sum_max_over_ranks") == c.get("param_abs_sum_min_over_ranks")
+        hi, lo = c.get("param_abs_sum_max_over_ranks"), c.get("param_abs_sum_min_over_ranks")
+        same = hi is not None and lo is not None and hi == lo          # (absent keys are a failure, not None == None)
         print(f"      C5 (magnet_gnn) training: {c['ms_per_step']} ms/step, allreduce_ms {c.get('allreduce_ms')} for {c.get('allreduce_bytes')} bytes, "
               f"parameter checksums equal on all ranks: {same}")
         ok = ok and same

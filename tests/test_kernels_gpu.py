@@ -303,9 +303,13 @@ def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
     (generation 9: transposed 32-edge tiles, lane = output feature, one accumulator, unscaled fp16-subnormal low pieces) against a
     host evaluation on a ragged graph (empty rows, rows across many tiles, E % 16 != 0), the range-partials corner cases, a
     graph whose every tile is full of run ends, and inputs small enough that every low piece is an fp16 subnormal."""
-    from magnet_amd import ops
+    from magnet_amd import _lib, ops
     from magnet_amd.packing import pack_edge16_fp16x2, pack_edge32t_fp16x2
     from oracle.pyg_semantics import scatter_mean
+    if kernel not in ("edge16", "edge16s", "stream"):
+        if not _lib.DEV:                       # generations 9-13 live in the development library only (include/magnet_hip_dev.h)
+            pytest.skip("development-library kernel: MAGNET_DEV_LIB=1 after `python -m magnet_amd.build --dev`")
+        from magnet_amd import dev_ops
     torch.manual_seed(3)
     H = 128
     if case in ("ragged", "small_values"):
@@ -346,13 +350,13 @@ def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
         # (rowsr: generation 12, the same tiles with W2's planes resident in the accumulation registers; rowsg: 12b, + grouped stragglers)
         w16, b = pack_edge16_fp16x2(lin.weight.cuda(), lin.bias.cuda())
         w32, _ = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
-        plan = ops.row_tiles(csr)
+        plan = dev_ops.row_tiles(csr)
         deg = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
         has = deg >= plan.pmin
         left = deg - torch.where(has, deg.clamp(max=32), 0)
         strag = has & (left == 1)
         assert plan.n_tiles == int(has.sum()) and plan.n_strag == int(strag.sum()) and plan.rem.E == int(left[~strag].sum())
-        ops.mpnn_edge_rows(A.cuda() * scale, Bm.cuda() * scale, csr, plan, w16, w32, b, agg, partials, l2e=l2e, wreg={"rows": 0, "rowsr": 1, "rowsg": 2, "rowsp": 3}[kernel])
+        dev_ops.mpnn_edge_rows(A.cuda() * scale, Bm.cuda() * scale, csr, plan, w16, w32, b, agg, partials, l2e=l2e, wreg={"rows": 0, "rowsr": 1, "rowsg": 2, "rowsp": 3}[kernel])
     elif kernel == "stream":                  # generation 14: 32-edge tiles cut from the edge stream of row-aligned chunks (two rows per tile)
         w16, b = pack_edge16_fp16x2(lin.weight.cuda(), lin.bias.cuda())
         w32, _ = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
@@ -370,10 +374,10 @@ def test_mpnn_edge16_matches_host_evaluation(case, l2e, kernel):
             ops.mpnn_edge_stream(A.cuda() * scale, Bm.cuda() * scale, csr, plan, w32, b, agg, l2e=l2e)
     elif kernel == "edgews":                  # generation 10: wave-specialised (gather / GEMM / epilogue waves through LDS)
         w, b = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
-        ops.mpnn_edge_ws(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e)
+        dev_ops.mpnn_edge_ws(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e)
     else:
         w, b = pack_edge32t_fp16x2(lin.weight.cuda(), lin.bias.cuda())
-        ops.mpnn_edge32t(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e, paired=kernel == "edge32p")
+        dev_ops.mpnn_edge32t(A.cuda() * scale, Bm.cuda() * scale, csr, w, b, agg, partials, l2e=l2e, paired=kernel == "edge32p")
     assert not torch.isnan(agg).any()
     if E:
         # a 40 001-term fp32 running sum (one row owning every edge) carries ~1e-6 of rounding by itself

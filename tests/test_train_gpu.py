@@ -837,6 +837,54 @@ def test_rccl_process_group_runs_the_training_collectives_on_one_rank():
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_ddp_wrapper_sees_every_parameter_gradient():
+    """the backward kernels' in-place parameter gradients (autograd.accumulate_param_grads, the MPNN rollout's flat
+    buffer) bypass AccumulateGrad - and with it DistributedDataParallel's reducer hooks.  Inside a DDP forward the shortcut must be
+    off: scripts/ddp_wrapper_check.py wraps training_step of an MPNN and a MAgNet model in torch DDP (one rank, RCCL), runs two steps,
+    counts the post-accumulate hooks and compares the gradients with the un-wrapped model's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29548")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "ddp_wrapper_check.py")], capture_output=True, text=True,
+                       timeout=900, env=env)
+    if "RCCL_INIT_FAILED" in r.stdout:
+        pytest.skip("no RCCL communicator on this box: " + r.stdout.strip()[-300:])
+    assert r.returncode == 0 and "DDP_WRAPPER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("tag", ["mpnn_2d", "magnet_gnn_tiny", "magnet_cnn_2d"])
+def test_parameter_hooks_fire_after_fused_adam_zero_grad(tag):
+    """A parameter that carries a hook is never given its gradient behind autograd's back (autograd.takes_inplace_grad): after
+    ``FusedAdam.zero_grad`` (flat views installed - the in-place path's precondition) ``Tensor.register_hook`` and
+    ``register_post_accumulate_grad_hook`` fire once per parameter and the gradients are the hook-free model's bits."""
+    hp, batch, oracle, model = _pair(tag)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    model.train()
+    opt = model.configure_optimizers()["optimizer"]
+    params = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    opt.zero_grad()
+    torch.manual_seed(5)
+    model.training_step(cb, 0).backward()
+    want = {n: p.grad.clone() for n, p in params}
+    seen_grad, seen_post = {}, {}
+    handles = []
+    for n, p in params:
+        handles.append(p.register_hook(lambda g, n=n: seen_grad.__setitem__(n, seen_grad.get(n, 0) + 1)))
+        handles.append(p.register_post_accumulate_grad_hook(lambda p_, n=n: seen_post.__setitem__(n, seen_post.get(n, 0) + 1)))
+    opt.zero_grad()
+    torch.manual_seed(5)
+    model.training_step(cb, 0).backward()
+    assert all(seen_post.get(n, 0) == 1 for n, _ in params), [n for n, _ in params if seen_post.get(n, 0) != 1][:5]
+    assert all(seen_grad.get(n, 0) >= 1 for n, _ in params), [n for n, _ in params if not seen_grad.get(n)][:5]
+    assert all(rel_l2(p.grad, want[n]) < 1e-6 for n, p in params if float(want[n].abs().max()) > 0)
+    for h in handles:
+        h.remove()
+
+
 @pytest.mark.parametrize("W", [128, 64])
 def test_linear_bwd_generations_agree_with_fp64(W):
     """magnet_linear_bwd128_f32 / 64 (csrc/linear_bwd.hip): k_linear_bwd_r in its shapes (generation 1 = the size rule, 2 / 3 = the two
