@@ -27,7 +27,8 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-re
 # mpnn_edge_rows.hip: hipcc's SLP vectoriser pairs the epilogue's per-value fma into v_pk_fma_f32 and pays two v_mov per pair to line the
 # operands up - packed fp32 beside MFMAs is slower than the scalar form to begin with
 EXTRA_FLAGS = {"readout_kernels.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
-               "mpnn_edge_rows.hip": ["-fno-slp-vectorize"], "mpnn_edge_stream.hip": ["-fno-slp-vectorize"], "mpnn_edge_rowsr.hip": ["-fno-slp-vectorize"], "mpnn_edge_rowsp.hip": ["-fno-slp-vectorize"], "mpnn_edge_bwd_wp.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
+               "mpnn_edge_rows.hip": ["-fno-slp-vectorize"], "mpnn_edge_stream.hip": ["-fno-slp-vectorize"], "mpnn_edge_rowsr.hip": ["-fno-slp-vectorize"], "mpnn_edge_rowsp.hip": ["-fno-slp-vectorize"], "mpnn_edge_bwd_wp.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "mpnn_edge_bwd_co.hip": ["-fno-slp-vectorize"]}
 
 
 # earlier generations of the fused MPNN edge op (9-13): measured slower than or equal to k_mpnn_edge16 / k_mpnn_edge_stream32 and reached

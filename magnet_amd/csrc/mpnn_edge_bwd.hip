@@ -638,12 +638,17 @@ int magnet_launch_edge_bwd_wp(const float* A, const float* Bm, const float* dagg
                               const int32_t* rowptr, int n_edges, const void* w2_f16, const void* w2t_f16, const float* b2, float* dp,
                               float* dA, float* partials, const float* amax, int n_amax, float* wpart, float* bpart, float* pscr,
                               int grid, void* stream);
-// 1 (default): k_mpnn_edge_bwd_wp; 0: k_mpnn_edge_bwd_w (the shared-slab kernel of round 3, kept for A/B runs) - same results up to
-// the order of the fp32 additions of dW2 / db2
-static int g_ebw_generation = 1;
+// mpnn_edge_bwd_co.hip: generation 3 (eight co-operating waves per tile, a wave owns 16 features; two waves per SIMD)
+int magnet_launch_edge_bwd_co(const float* A, const float* Bm, const float* dagg, const int32_t* src, const int32_t* tgt,
+                              const int32_t* rowptr, int n_edges, const void* w2_f16, const void* w2t_f16, const float* b2, float* dp,
+                              float* dA, float* partials, const float* amax, int n_amax, float* wpart, float* bpart, int grid,
+                              void* stream);
+// 2 (default): k_mpnn_edge_bwd_co; 1: k_mpnn_edge_bwd_wp (round 4); 0: k_mpnn_edge_bwd_w (the shared-slab kernel of round 3) - kept for
+// A/B runs; same results up to the order of the fp32 additions
+static int g_ebw_generation = 2;
 extern "C" int magnet_mpnn_edge_bwd_w_generation(int generation) {
     const int was = g_ebw_generation;
-    if (generation == 0 || generation == 1) g_ebw_generation = generation;
+    if (generation >= 0 && generation <= 2) g_ebw_generation = generation;
     return was;
 }
 extern "C" int magnet_mpnn_edge_bwd_w_workspace(void) {
@@ -685,7 +690,7 @@ extern "C" int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, 
             ncu = prop.multiProcessorCount;
         }
         const int tiles = (n_edges + 31) / 32;
-        const int grid = min((tiles + 3) / 4, ncu);
+        const int grid = g_ebw_generation == 2 ? min(tiles, ncu) : min((tiles + 3) / 4, ncu);
         float* wpart = workspace;
         float* bpart = wpart + (size_t)ncu * 128 * 128;
         float* amax = bpart + (size_t)ncu * 128;
@@ -700,7 +705,10 @@ extern "C" int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, 
         const u32x4* w = reinterpret_cast<const u32x4*>(w2_f16);
         const u32x4* wT = reinterpret_cast<const u32x4*>(w2t_f16);
         float* pscr = bpart + (size_t)ncu * 128 + EBW_AMAX_BLOCKS;
-        if (g_ebw_generation == 1)
+        if (g_ebw_generation == 2)
+            magnet_launch_edge_bwd_co(A, Bm, dagg, src, tgt, rowptr, n_edges, w2_f16, w2t_f16, b2, dp, dA, partials, amax, nab, wpart, bpart,
+                                      grid, stream);
+        else if (g_ebw_generation == 1)
             magnet_launch_edge_bwd_wp(A, Bm, dagg, src, tgt, rowptr, n_edges, w2_f16, w2t_f16, b2, dp, dA, partials, amax, nab, wpart, bpart,
                                       pscr, grid, stream);
         else

@@ -1,0 +1,446 @@
+// Fused backward of the MPNN edge block, generation 3 (k_mpnn_edge_bwd_co): the workgroup's eight waves CO-OPERATE on one 32-edge tile per
+// step and every wave owns 16 FEATURES of everything - the construction of k_linear_bwd_r (linear_bwd.hip) applied to the three GEMMs of
+// this block.  Same arguments and outputs as k_mpnn_edge_bwd_wp (generation 2, mpnn_edge_bwd_wp.hip).
+// Reference: torch autograd through GNN_Layer.message / aggr='mean', models/mpnn.py:73-79,46.
+//
+// Why (profiles/r5/pmc_edge_bwd_wp_sq_counters.txt): generation 2 keeps the whole [128 x 128] fp32 accumulator of dW2 in
+// every wave - 256 registers, hence ONE wave per SIMD, which executes an instruction only 50 % of the time (its own waits).  Here
+//  * wave w owns features 16 w .. 16 w + 15: rows a of q = W2 s1 (GEMM 1), rows b of ds1 = W2^T dq (GEMM 2), rows a of dW2 = dq^T s1; its
+//    A fragments of W2 and of W2^T (4 k tiles x 2 planes each: 32 + 32 registers, read once from the standard fp16x3 packs) and its
+//    [16 x 128] slab of dW2 (32 registers) are resident - 96 registers, no weights in LDS, two waves per SIMD;
+//  * everything element-wise happens in the C/D layout of v_mfma_f32_16x16x32_f16 - lane (n16, q4) = edges 2 n16 and 2 n16 + 1 of the tile,
+//    features 16 w + 4 q4 .. + 3: p = A[i] + Bm[j] (64-byte pieces of the rows: the eight waves together read every row once), s1,
+//    Swish'(p) (kept in 8 registers until the dp phase: no parking block), dagg[i] / deg, dq, dp, and the row sums dA over the 16-lane DPP
+//    rows (24 instructions per wave and tile instead of 640);
+//  * only the fp16 planes of s1 and of G dq go through LDS, split ONCE by the wave that formed them, row-major [edge][position] (LR_ST of
+//    linear_bwd.hip: 288-byte rows): the B operands of GEMM 1 / GEMM 2 are one ds_read_b128 per k slot and plane, the operands of the
+//    weight gradient (lane = feature, registers = edges) come out of ds_read_b64_tr_b16;
+//  * the planes are double buffered: TWO workgroup barriers per tile (s1 staged / dq staged).
+// Arithmetic as generation 2: fp16 split with one accumulator (W planes 2^11 hw, 2^11 lw), G = one power of two per launch for dq (serves
+// GEMM 2 and the weight gradient), fixed summation orders (bit-identical repeats).
+#include "common.cuh"
+#include "split_single.cuh"
+
+#define CO_ST 144                       // halfwords per LDS row: 288 B (see LR_ST in linear_bwd.hip)
+#ifndef CO_PACKED
+#define CO_PACKED 1                     // element-wise arithmetic on whole f32x4 vectors (v_pk_*_f32) / 0: value by value
+#endif
+#ifndef CO_PRODUCE_LATE
+#define CO_PRODUCE_LATE 1               // 1: the next tile's s1 at the end of the iteration, every wave in the same order; 0: behind the second
+#endif                                  //    barrier with the waves of a SIMD in opposite orders (measured: 4.13 ms against 3.82, profiles/r6)
+#ifndef CO_ABL
+#define CO_ABL 0                        // development ablations (timing only, results invalid): 1 no barriers, 2 no dW2 MFMAs, 4 no GEMM 1 / 2
+#endif                                  //   MFMAs, 8 no dp stores, 16 no transcendentals, 32 gathers from 64 fixed rows (cache resident), 64 no LDS reads, 128 no role skew
+
+namespace {
+
+typedef short co_s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(1))) const char* co_gconst;
+typedef __attribute__((address_space(1))) char* co_gbytes;
+
+struct CoBuf {
+    unsigned short s1[2][32][CO_ST];    // [plane][edge row][position]: within every block of 16 features, feature 8 hi + 4 kg + c sits at
+    unsigned short dq[2][32][CO_ST];    // position 8 kg + 4 hi + c (the k order of the standard pack's A fragments; linear_bwd.hip LrBuf)
+};
+
+__device__ __forceinline__ int co_sw(int i) { return (i & 3) | ((i & 4) << 1) | ((i & 8) >> 1); }
+__device__ __forceinline__ f32x4 co_ldg4(const float* base, unsigned off) {
+    return *reinterpret_cast<__attribute__((address_space(1))) const f32x4*>((co_gconst)(base) + off);
+}
+__device__ __forceinline__ void co_stg4(float* base, unsigned off, const f32x4& v) {
+    *reinterpret_cast<__attribute__((address_space(1))) f32x4*>((co_gbytes)(base) + off) = v;
+}
+__device__ __forceinline__ int co_ldi(const int32_t* base, unsigned off) {
+    return *reinterpret_cast<__attribute__((address_space(1))) const int*>((co_gconst)(base) + off);
+}
+__device__ __forceinline__ u32x2 co_tr(const unsigned short* p) {
+    if (CO_ABL & 64) return u32x2{(unsigned)(size_t)p, 0x3c003c00u};
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) co_s16x4*)(p)));
+}
+__device__ __forceinline__ float co_dot_ones(unsigned w, float acc) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w), one, acc, false);
+}
+__device__ __forceinline__ float co_sigmoid(float x) {
+    if (CO_ABL & 16) return x * 0.25f;
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+// 1 / (1 + 2^x) of four values (x = -log2(e) * the sigmoid's argument)
+__device__ __forceinline__ f32x4 co_sigmoid4(const f32x4& x) {
+    if (CO_ABL & 16) return x * 0.25f;
+    f32x4 e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(x[i]);
+    e = e + 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_rcpf(e[i]);
+    return e;
+}
+__device__ __forceinline__ void co_barrier() {
+    if (!(CO_ABL & 1)) wg_barrier();
+}
+#define DPP_SHL1 0x101
+
+struct CoIdx {                          // one tile's indices of this lane: edges 2 n16 (A) and 2 n16 + 1 (B), clamped to the last edge
+    int tA, tB, sA, sB;
+};
+
+// acc[rb] += 2^11 W x for the wave's 16 output features x the tile's edges 16 rb + n16: ALL sixteen operand reads of the phase are issued
+// first (hipcc's own order waited lgkmcnt(0) two reads after the barrier and chained up to twelve dependent MFMAs on one accumulator),
+// the MFMAs then alternate between the two accumulators
+__device__ __forceinline__ void co_gemm(const unsigned short (&img)[2][32][CO_ST], const f16x8 (&wh)[4], const f16x8 (&wl)[4], f32x4 (&acc)[2],
+                                        int n16, int q4) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {                                          // two batches of eight reads (sixteen at once: 64 registers, spills)
+        f16x8 zh[2][2], zl[2][2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int kt = 2 * hf + k2;
+                if (CO_ABL & 64) { zh[k2][rb] = wh[kt], zl[k2][rb] = wl[(kt + rb) & 3]; continue; }
+                zh[k2][rb] = *reinterpret_cast<const f16x8*>(&img[0][16 * rb + n16][32 * kt + 8 * q4]);
+                zl[k2][rb] = *reinterpret_cast<const f16x8*>(&img[1][16 * rb + n16][32 * kt + 8 * q4]);
+            }
+#ifdef CO_GEMM_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int kt = 2 * hf + k2;
+            if (CO_ABL & 4) {
+                acc[0][0] += (float)zh[k2][0][0] + (float)zl[k2][0][1], acc[1][0] += (float)zh[k2][1][0] + (float)zl[k2][1][1];
+                continue;
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[kt], zh[k2][rb], acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kt], zl[k2][rb], acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kt], zh[k2][rb], acc[rb], 0, 0, 0);
+        }
+    }
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                             const float* __restrict__ dagg, const int32_t* __restrict__ src,
+                                                             const int32_t* __restrict__ tgt, const int32_t* __restrict__ rowptr,
+                                                             int E, const u32x4* __restrict__ w2s, const u32x4* __restrict__ w2ts,
+                                                             const float* __restrict__ b2, float* __restrict__ dp_out,
+                                                             float* __restrict__ dA, float* __restrict__ partials,
+                                                             const float* __restrict__ amax_part, int n_amax,
+                                                             float* __restrict__ wpart, float* __restrict__ bpart) {
+    __shared__ __attribute__((aligned(16))) CoBuf sb[2];
+    __shared__ float gsc[8];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n16 = lane & 15, q4 = lane >> 4;
+    float G, invG;
+    {
+        float m = 0.f;
+        for (int i = threadIdx.x; i < n_amax; i += 512) m = fmaxf(m, amax_part[i]);
+#pragma unroll
+        for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) gsc[wave] = m;
+        __syncthreads();
+        m = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) m = fmaxf(m, gsc[w]);
+        const unsigned eb = (__float_as_uint(m) >> 23) & 0xFFu;               // max|dagg| in [2^(eb-127), 2^(eb-126))
+        const bool ok = eb >= 14u && eb < 255u;
+        G = ok ? __uint_as_float((267u - eb) << 23) : 1.0f;                   // 2^(140-eb): G * 1.1 max|dagg| < 2^15
+        invG = ok ? __uint_as_float((eb - 13u) << 23) : 1.0f;
+    }
+    // ---- the wave's 16 rows of W2 (GEMM 1: q features) and of W2^T (GEMM 2: s1 features) as A fragments: lane = row n16, k group q4 =
+    // the pack's k slots (kt, q4 >> 1, q4 & 1)
+    f16x8 w1h[4], w1l[4], w2h[4], w2l[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        const int idx = (((kt * 4 + (wave >> 1)) * 2 + (q4 >> 1)) * 2) * 64 + 16 * (wave & 1) + n16 + 32 * (q4 & 1);
+        w1h[kt] = __builtin_bit_cast(f16x8, scale_plane_2048(w2s[idx]));
+        w1l[kt] = __builtin_bit_cast(f16x8, w2s[idx + 64]);
+        w2h[kt] = __builtin_bit_cast(f16x8, scale_plane_2048(w2ts[idx]));
+        w2l[kt] = __builtin_bit_cast(f16x8, w2ts[idx + 64]);
+    }
+    const unsigned fcol = 16u * (unsigned)wave + 4u * (unsigned)q4;           // this lane's first feature
+    f32x4 bq;                                                                 // 2^11 b2 of its four q features
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bq[i] = b2[fcol + i] * 2048.0f;
+    const int ppos = 16 * wave + 8 * (q4 & 1) + 4 * (q4 >> 1);                // where its four features sit in an LDS row
+    // ---- the workgroup's contiguous range of tiles (consecutive workgroups of an XCD take consecutive ranges)
+    const int ntiles = (E + 31) / 32;
+    const int nb8 = gridDim.x / 8;
+    const int vb = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * nb8 + blockIdx.x / 8 : blockIdx.x;
+    const int tpw = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int tile0 = vb * tpw;
+    const int nsteps = __builtin_amdgcn_readfirstlane(max(0, min(tpw, ntiles - tile0)));
+
+    // every per-lane address is a wave-uniform base (SGPR pair, made opaque) + a 32-bit byte offset (DESIGN.md 10 rule 1)
+    auto load_idx = [&](int tile_) {
+        CoIdx x;
+        const int ea = min(min(tile_, ntiles - 1) * 32 + 2 * n16, E - 1), eb = min(ea + 1, E - 1);
+        const int32_t *pt = tgt, *ps = src;
+        asm volatile("" : "+s"(pt), "+s"(ps));
+        x.tA = co_ldi(pt, 4u * (unsigned)ea), x.tB = co_ldi(pt, 4u * (unsigned)eb);
+        x.sA = co_ldi(ps, 4u * (unsigned)ea), x.sB = co_ldi(ps, 4u * (unsigned)eb);
+        if (CO_ABL & 32) x.tA &= 63, x.tB &= 63, x.sA &= 63, x.sB &= 63;
+        return x;
+    };
+    // Rows in flight: pa / pb = A[i], Bm[j] of the tile whose s1 is produced in THIS iteration (tile + 1), qa / qb = the same of tile + 2
+    // (requested at the top of the iteration, consumed a step and a half later), gv / rs / re = dagg[i] and the row bounds of the tile
+    // whose dq is formed in the next iteration.
+    f32x4 pa[2], pb[2], qa[2], qb[2], gv[2];
+    int rs[2], re[2];
+    auto load_ab = [&](const CoIdx& x, f32x4 (&a_)[2], f32x4 (&b_)[2]) {
+        const float *ba = A, *bb = Bm;
+        asm volatile("" : "+s"(ba), "+s"(bb));
+        a_[0] = co_ldg4(ba, (unsigned)x.tA * 512u + 4u * fcol), a_[1] = co_ldg4(ba, (unsigned)x.tB * 512u + 4u * fcol);
+        b_[0] = co_ldg4(bb, (unsigned)x.sA * 512u + 4u * fcol), b_[1] = co_ldg4(bb, (unsigned)x.sB * 512u + 4u * fcol);
+    };
+    auto load_g = [&](const CoIdx& x) {
+        const float* pg = dagg;
+        const int32_t* pr = rowptr;
+        asm volatile("" : "+s"(pg), "+s"(pr));
+        gv[0] = co_ldg4(pg, (unsigned)x.tA * 512u + 4u * fcol), gv[1] = co_ldg4(pg, (unsigned)x.tB * 512u + 4u * fcol);
+        rs[0] = co_ldi(pr, 4u * (unsigned)x.tA), re[0] = co_ldi(pr, 4u * (unsigned)x.tA + 4u);
+        rs[1] = co_ldi(pr, 4u * (unsigned)x.tB), re[1] = co_ldi(pr, 4u * (unsigned)x.tB + 4u);
+    };
+    // ---- phase A of a tile: s1 = Swish(p) as fp16 planes into LDS buffer `B`, Swish'(p) into `sp` (registers)
+    auto produce = [&](CoBuf& B, const f32x4 (&a_)[2], const f32x4 (&b_)[2], f32x4 (&sp)[2]) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            // (whole-vector arithmetic: v_pk_add / v_pk_mul / v_pk_fma_f32 take two of the lane's four values per instruction)
+#if CO_PACKED
+            const f32x4 v = a_[rb] + b_[rb];
+            const f32x4 s = co_sigmoid4(v * (-1.4426950408889634f));
+            const f32x4 t = v * s;
+            sp[rb] = (s + t) - t * s;                                           // s (1 + v (1 - s))
+#else
+            f32x4 v, s;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = a_[rb][i] + b_[rb][i];
+                s[i] = co_sigmoid(v[i]);
+                sp[rb][i] = s[i] * (1.0f + v[i] * (1.0f - s[i]));
+            }
+#endif
+            unsigned h0, l0, h1, l1;
+            split_f16_prod(v[0], s[0], v[1], s[1], h0, l0);
+            split_f16_prod(v[2], s[2], v[3], s[3], h1, l1);
+            const u32x2 h = {h0, h1}, l = {l0, l1};
+            *reinterpret_cast<u32x2*>(&B.s1[0][16 * rb + n16][ppos]) = h;
+            *reinterpret_cast<u32x2*>(&B.s1[1][16 * rb + n16][ppos]) = l;
+        }
+    };
+    // ---- prologue: tile 0's s1 staged, its dagg rows and tile 1's A / Bm rows requested
+    f32x4 spp[2], sppn[2];
+    CoIdx i0 = load_idx(tile0), i1 = load_idx(tile0 + 1), i2 = load_idx(tile0 + 2);
+    int ctA = i0.tA, ctB = i0.tB;                                             // targets of the current tile's two edges
+    if (nsteps > 0) {
+        load_ab(i0, pa, pb);
+        load_g(i0);
+        produce(sb[0], pa, pb, spp);
+        load_ab(i1, pa, pb);
+    }
+
+    // dW2 in an 2 x 4 arrangement of 16 x 16 blocks per wave - rows (dq features) 32 wr .., columns (s1 features) 64 wc .. - so that a wave
+    // reads 2 + 4 transposed operand blocks per tile instead of 1 + 8
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x4 accw[2][4];                                                         // G dW2[32 wr + 16 a + co_sw(4 q4 + i)][64 wc + 16 b + co_sw(n16)]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) accw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[2] = {0.f, 0.f};
+    const float usc = invG * (1.0f / 2048.0f);
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int tile = tile0 + step;
+        CoBuf& B = sb[step & 1];
+        const int e0 = tile * 32, eA = e0 + 2 * n16;
+        const bool okA = eA < E, okB = eA + 1 < E;
+        // what the dq / dA phases need of this tile's bookkeeping, before the registers are handed to the next tile's loads
+        const float idA = okA ? __builtin_amdgcn_rcpf((float)(re[0] - rs[0])) : 0.0f;     // (1 / deg to 1 ulp; invalid edges: dq = 0)
+        const float idB = okB ? __builtin_amdgcn_rcpf((float)(re[1] - rs[1])) : 0.0f;
+        const int tA = okA ? ctA : (-16 - 2 * n16), tB = okB ? ctB : (-17 - 2 * n16);
+        const int rsA = rs[0], reA = re[0], rsB = rs[1], reB = re[1];
+        // ---- requests: A / Bm rows of tile + 2, indices of tile + 3 (past the range: the clamped last tile again, unused)
+        asm volatile("" ::: "memory");
+        load_ab(i2, qa, qb);
+        const CoIdx inext = i1;
+        ctA = i1.tA, ctB = i1.tB;
+        i1 = i2;
+        i2 = load_idx(tile + 3);
+        asm volatile("" ::: "memory");
+        co_barrier();                                                         // s1 of the tile staged (by the previous iteration)
+        // ---- GEMM 1: 2^11 q = 2^11 (W2 s1 + b2) for the wave's 16 q features x 32 edges; dq = dagg[i] / deg * Swish'(q)
+        f32x4 acc[2] = {bq, bq};
+        co_gemm(B.s1, w1h, w1l, acc, n16, q4);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const float Gd = G * (rb ? idB : idA);                            // 1 / deg rides in the split's multiplier
+            // Swish'(q) with q = acc / 2^11: the scale rides in the constants
+#if CO_PACKED
+            const f32x4 s = co_sigmoid4(acc[rb] * (-1.4426950408889634f / 2048.0f));
+            const f32x4 t = (acc[rb] * (1.0f / 2048.0f)) * s;
+            const f32x4 d = gv[rb] * ((s + t) - t * s);
+#else
+            f32x4 d;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float s = (CO_ABL & 16) ? acc[rb][i] * 1e-4f
+                                              : __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[rb][i] * (-1.4426950408889634f / 2048.0f)));
+                const float u = acc[rb][i] * (1.0f - s);
+                d[i] = (gv[rb][i] * s) * __builtin_fmaf(u, 1.0f / 2048.0f, 1.0f);
+            }
+#endif
+            unsigned h0, l0, h1, l1;
+            split_f16_prod(d[0], Gd, d[1], Gd, h0, l0);
+            split_f16_prod(d[2], Gd, d[3], Gd, h1, l1);
+            const u32x2 h = {h0, h1}, l = {l0, l1};
+            *reinterpret_cast<u32x2*>(&B.dq[0][16 * rb + n16][ppos]) = h;
+            *reinterpret_cast<u32x2*>(&B.dq[1][16 * rb + n16][ppos]) = l;
+        }
+        asm volatile("" ::: "memory");
+        load_g(inext);                                                        // dagg rows / row bounds of tile + 1: into the registers dq has just released
+        asm volatile("" ::: "memory");
+        co_barrier();                                                         // G dq of the tile staged
+        // ---- behind the second barrier: the matrix part (GEMM 2 + the weight gradient: 48 MFMAs) and the vector part (the NEXT tile's s1 /
+        // Swish'(p) into the other LDS buffer - its last readers passed this iteration's first barrier).  The waves run in lock step, so
+        // the two waves of a SIMD would both sit in the matrix part and then both in the vector part: waves 4 .. 7 (the second wave of
+        // every SIMD) take the vector part FIRST.
+        f32x4 x2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        auto matrix_part = [&]() {
+            // GEMM 2: 2^11 G ds1 = 2^11 W2^T (G dq) for the wave's 16 s1 features
+            co_gemm(B.dq, w2h, w2l, x2, n16, q4);
+            // dW2 blocks += (G dq)^T s1 over the tile's 32 edges (k order: lane group q4 takes LDS rows 4 q4 .. + 3 and 16 + 4 q4 .. + 3), db2
+            const int r0 = 4 * q4 + (n16 >> 2), c0 = 4 * (n16 & 3);
+            f16x8 ah[2], al[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int f = 32 * wr + 16 * a + c0;
+                const u32x2 a0 = co_tr(&B.dq[0][r0][f]), a1 = co_tr(&B.dq[0][16 + r0][f]);
+                const u32x2 b0 = co_tr(&B.dq[1][r0][f]), b1 = co_tr(&B.dq[1][16 + r0][f]);
+                ah[a] = __builtin_bit_cast(f16x8, u32x4{a0[0], a0[1], a1[0], a1[1]});
+                al[a] = __builtin_bit_cast(f16x8, u32x4{b0[0], b0[1], b1[0], b1[1]});
+                float cs = co_dot_ones(a0[0], 0.f);                           // (both waves of a pair sum the same rows; wc = 0 stores)
+                cs = co_dot_ones(a0[1], cs), cs = co_dot_ones(a1[0], cs), cs = co_dot_ones(a1[1], cs);
+                cs = co_dot_ones(b0[0], cs), cs = co_dot_ones(b0[1], cs), cs = co_dot_ones(b1[0], cs), cs = co_dot_ones(b1[1], cs);
+                bsum[a] += cs;
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int f = 64 * wc + 16 * b + c0;
+                const u32x2 p0 = co_tr(&B.s1[0][r0][f]), p1 = co_tr(&B.s1[0][16 + r0][f]);
+                const u32x2 q0 = co_tr(&B.s1[1][r0][f]), q1 = co_tr(&B.s1[1][16 + r0][f]);
+                const f16x8 xh = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p1[0], p1[1]});
+                const f16x8 xl = __builtin_bit_cast(f16x8, u32x4{q0[0], q0[1], q1[0], q1[1]});
+                if (CO_ABL & 2) { accw[0][b][0] += (float)xh[0] + (float)xl[1]; continue; }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) accw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], xh, accw[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) accw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], xl, accw[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) accw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], xh, accw[a][b], 0, 0, 0);
+            }
+        };
+#if CO_PRODUCE_LATE
+        matrix_part();
+#else
+        if (wave < 4 || (CO_ABL & 128)) {
+            matrix_part();
+            __builtin_amdgcn_sched_barrier(0);
+            produce(sb[(step + 1) & 1], pa, pb, sppn);
+        } else {
+            produce(sb[(step + 1) & 1], pa, pb, sppn);
+            __builtin_amdgcn_sched_barrier(0);
+            matrix_part();
+        }
+#endif
+        // ---- dp = ds1 * Swish'(p)
+        {
+            float* dpt = dp_out + (size_t)tile * 4096;
+            asm volatile("" : "+s"(dpt));
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                x2[rb] = x2[rb] * usc * spp[rb];
+                unsigned off = (unsigned)(2 * n16 + rb) * 512u + 4u * fcol;
+                asm volatile("" : "+v"(off));                                 // (a loop-invariant offset becomes a hoisted - and spilled - 64-bit address)
+                if (!(CO_ABL & 8) && (rb ? okB : okA)) co_stg4(dpt, off, x2[rb]);
+            }
+        }
+        // ---- dA[i] = sum of dp over the row's edges: segmented inclusive sums over the tile's 32 edges (edge 2 n16 + rb: in the lane first,
+        // then along the 16-lane DPP row), the last edge of every run stores - whole rows to dA, runs cut by a tile boundary to `partials`
+        // (slot 0: entered from the previous tile, 1: continues into the next; k_segsum_fixup adds them up in tile order)
+        {
+            const int tp1 = dpp_i<DPP_SHR1, 0xF>(tB), tp2 = dpp_i<DPP_SHR2, 0xF>(tB), tp4 = dpp_i<DPP_SHR4, 0xF>(tB);
+            const int tp8 = dpp_i<DPP_SHR8, 0xF>(tB);
+            const int tn1 = dpp_i<DPP_SHL1, 0xF>(tA);                         // target of the edge after edge B (lane n16 + 1's edge A)
+            const float m01 = tA == tB ? 1.f : 0.f;
+            const float m1 = ((n16 >= 1) & (tp1 == tB)) ? 1.f : 0.f, m2 = ((n16 >= 2) & (tp2 == tB)) ? 1.f : 0.f;
+            const float m4 = ((n16 >= 4) & (tp4 == tB)) ? 1.f : 0.f, m8 = ((n16 >= 8) & (tp8 == tB)) ? 1.f : 0.f;
+            const float mC = ((n16 >= 1) & (tp1 == tA)) ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float x0 = x2[0][i], x1 = x2[1][i];
+                x1 += m01 * x0;
+                x1 += m1 * dpp_f<DPP_SHR1, 0xF>(x1);
+                x1 += m2 * dpp_f<DPP_SHR2, 0xF>(x1);
+                x1 += m4 * dpp_f<DPP_SHR4, 0xF>(x1);
+                x1 += m8 * dpp_f<DPP_SHR8, 0xF>(x1);
+                x0 += mC * dpp_f<DPP_SHR1, 0xF>(x1);
+                x2[0][i] = x0, x2[1][i] = x1;
+            }
+            const bool endA = okA && tB != tA;
+            const bool endB = okB && (n16 == 15 || tn1 != tB);
+            float *pd = dA, *pp = partials + (size_t)tile * 256;
+            asm volatile("" : "+s"(pd), "+s"(pp));
+            if (endA) {
+                const bool complete = rsA >= e0 && reA <= e0 + 32;
+                if (complete) co_stg4(pd, (unsigned)tA * 512u + 4u * fcol, x2[0]);
+                else co_stg4(pp, (rsA < e0 ? 0u : 512u) + 4u * fcol, x2[0]);
+            }
+            if (endB) {
+                const bool complete = rsB >= e0 && reB <= e0 + 32;
+                if (complete) co_stg4(pd, (unsigned)tB * 512u + 4u * fcol, x2[1]);
+                else co_stg4(pp, (rsB < e0 ? 0u : 512u) + 4u * fcol, x2[1]);
+            }
+        }
+#if CO_PRODUCE_LATE
+        produce(sb[(step + 1) & 1], pa, pb, sppn);                            // (the next tile's s1: the last thing before its first barrier)
+#endif
+        // ---- hand the pipeline registers on (the rows of tile + 2 were requested at the top of this iteration)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) pa[rb] = qa[rb], pb[rb] = qb[rb], spp[rb] = sppn[rb];
+    }
+    // ---- this workgroup's partial sums of dW2 / db2
+    float* wout = wpart + (size_t)blockIdx.x * 128 * 128;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                wout[(size_t)(32 * wr + 16 * a + co_sw(4 * q4 + i)) * 128 + 64 * wc + 16 * b + co_sw(n16)] = accw[a][b][i] * invG;
+    if (wc == 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float bs = bsum[a];
+            bs += __shfl_xor(bs, 16);
+            bs += __shfl_xor(bs, 32);
+            if (q4 == 0) bpart[(size_t)blockIdx.x * 128 + 32 * wr + 16 * a + co_sw(n16)] = bs * invG;
+        }
+    }
+}
+
+int magnet_launch_edge_bwd_co(const float* A, const float* Bm, const float* dagg, const int32_t* src, const int32_t* tgt,
+                              const int32_t* rowptr, int n_edges, const void* w2_f16, const void* w2t_f16, const float* b2, float* dp,
+                              float* dA, float* partials, const float* amax, int n_amax, float* wpart, float* bpart, int grid,
+                              void* stream) {
+    hipLaunchKernelGGL(k_mpnn_edge_bwd_co, dim3(grid), dim3(512), 0, (hipStream_t)stream, A, Bm, dagg, src, tgt, rowptr, n_edges,
+                       reinterpret_cast<const u32x4*>(w2_f16), reinterpret_cast<const u32x4*>(w2t_f16), b2, dp, dA, partials, amax, n_amax,
+                       wpart, bpart);
+    return (int)hipGetLastError();
+}
