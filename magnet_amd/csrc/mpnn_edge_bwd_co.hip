@@ -15,7 +15,13 @@
 //  * only the fp16 planes of s1 and of G dq go through LDS, split ONCE by the wave that formed them, row-major [edge][position] (LR_ST of
 //    linear_bwd.hip: 288-byte rows): the B operands of GEMM 1 / GEMM 2 are one ds_read_b128 per k slot and plane, the operands of the
 //    weight gradient (lane = feature, registers = edges) come out of ds_read_b64_tr_b16;
-//  * the planes are double buffered: TWO workgroup barriers per tile (s1 staged / dq staged).
+//  * ONE workgroup barrier per tile: the dq planes are double buffered, the s1 planes have THREE images - the next tile's s1 is staged in
+//    front of the tile's barrier, which publishes it together with the tile's dq (two barriers on two images: 3.83 ms against 3.72);
+//  * the older wave of a SIMD wins every arbitration (priority, then age) and would idle ~2 000 cycles at the barrier while its partner
+//    finishes alone: waves 4 .. 7 run at priority 1, waves 0 .. 3 at 2 behind the barrier and at 0 from the end of the matrix part
+//    (CO_FLIP_PRIO; 3.59 ms against 3.68 with a static priority, phase traces in profiles/r6/edge_bwd_co_trace_*.txt).
+// The kernel issues ~670 instructions per wave and tile (8 waves: 5 400 per tile; generation 2: 4 900 in one wave) and fills about 75 % of
+// its SIMDs' issue slots (generation 2: 50 %) - DESIGN.md 15.1 has the measurements.
 // Arithmetic as generation 2: fp16 split with one accumulator (W planes 2^11 hw, 2^11 lw), G = one power of two per launch for dq (serves
 // GEMM 2 and the weight gradient), fixed summation orders (bit-identical repeats).
 #include "common.cuh"
@@ -25,12 +31,26 @@
 #ifndef CO_PACKED
 #define CO_PACKED 1                     // element-wise arithmetic on whole f32x4 vectors (v_pk_*_f32) / 0: value by value
 #endif
-#ifndef CO_PRODUCE_LATE
-#define CO_PRODUCE_LATE 1               // 1: the next tile's s1 at the end of the iteration, every wave in the same order; 0: behind the second
-#endif                                  //    barrier with the waves of a SIMD in opposite orders (measured: 4.13 ms against 3.82, profiles/r6)
+#ifndef CO_ONE_BARRIER
+#define CO_ONE_BARRIER 1                // 1: three s1 images, the next tile's s1 staged in front of the tile's only barrier; 0: two barriers
+#endif
+#ifndef CO_FLIP_PRIO
+#define CO_FLIP_PRIO 1
+#endif
+#ifndef CO_YOUNG_PRIO
+#define CO_YOUNG_PRIO 0
+#endif
 #ifndef CO_ABL
 #define CO_ABL 0                        // development ablations (timing only, results invalid): 1 no barriers, 2 no dW2 MFMAs, 4 no GEMM 1 / 2
-#endif                                  //   MFMAs, 8 no dp stores, 16 no transcendentals, 32 gathers from 64 fixed rows (cache resident), 64 no LDS reads, 128 no role skew
+#endif                                  //   MFMAs, 8 no dp stores, 16 no transcendentals, 32 gathers from 64 fixed rows (cache resident), 64 no LDS reads
+
+#ifdef CO_TRACE                         // development: s_memtime stamps of workgroup 0's waves at the phase boundaries of 32 steps
+__device__ long long g_co_trace[8][32][10];
+extern "C" int magnet_debug_co_trace(long long* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_co_trace), sizeof(g_co_trace)); }
+#define CO_STAMP(k) do { if (tr_on) tr[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CO_STAMP(k) do { } while (0)
+#endif
 
 namespace {
 
@@ -38,10 +58,9 @@ typedef short co_s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(1))) const char* co_gconst;
 typedef __attribute__((address_space(1))) char* co_gbytes;
 
-struct CoBuf {
-    unsigned short s1[2][32][CO_ST];    // [plane][edge row][position]: within every block of 16 features, feature 8 hi + 4 kg + c sits at
-    unsigned short dq[2][32][CO_ST];    // position 8 kg + 4 hi + c (the k order of the standard pack's A fragments; linear_bwd.hip LrBuf)
-};
+// One fp16-plane image of a tile: [plane][edge row][position]; within every block of 16 features, feature 8 hi + 4 kg + c sits at position
+// 8 kg + 4 hi + c (the k order of the standard pack's A fragments; linear_bwd.hip LrBuf)
+typedef unsigned short CoImg[2][32][CO_ST];
 
 __device__ __forceinline__ int co_sw(int i) { return (i & 3) | ((i & 4) << 1) | ((i & 8) >> 1); }
 __device__ __forceinline__ f32x4 co_ldg4(const float* base, unsigned off) {
@@ -133,7 +152,8 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
                                                              float* __restrict__ dA, float* __restrict__ partials,
                                                              const float* __restrict__ amax_part, int n_amax,
                                                              float* __restrict__ wpart, float* __restrict__ bpart) {
-    __shared__ __attribute__((aligned(16))) CoBuf sb[2];
+    __shared__ __attribute__((aligned(16))) CoImg s1b[CO_ONE_BARRIER ? 3 : 2];    // s1 planes of tiles t, t + 1 (, t + 2)
+    __shared__ __attribute__((aligned(16))) CoImg dqb[2];                         // G dq planes
     __shared__ float gsc[8];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n16 = lane & 15, q4 = lane >> 4;
@@ -208,7 +228,7 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
         rs[1] = co_ldi(pr, 4u * (unsigned)x.tB), re[1] = co_ldi(pr, 4u * (unsigned)x.tB + 4u);
     };
     // ---- phase A of a tile: s1 = Swish(p) as fp16 planes into LDS buffer `B`, Swish'(p) into `sp` (registers)
-    auto produce = [&](CoBuf& B, const f32x4 (&a_)[2], const f32x4 (&b_)[2], f32x4 (&sp)[2]) {
+    auto produce = [&](CoImg& S, const f32x4 (&a_)[2], const f32x4 (&b_)[2], f32x4 (&sp)[2]) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             // (whole-vector arithmetic: v_pk_add / v_pk_mul / v_pk_fma_f32 take two of the lane's four values per instruction)
@@ -230,8 +250,8 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
             split_f16_prod(v[0], s[0], v[1], s[1], h0, l0);
             split_f16_prod(v[2], s[2], v[3], s[3], h1, l1);
             const u32x2 h = {h0, h1}, l = {l0, l1};
-            *reinterpret_cast<u32x2*>(&B.s1[0][16 * rb + n16][ppos]) = h;
-            *reinterpret_cast<u32x2*>(&B.s1[1][16 * rb + n16][ppos]) = l;
+            *reinterpret_cast<u32x2*>(&S[0][16 * rb + n16][ppos]) = h;
+            *reinterpret_cast<u32x2*>(&S[1][16 * rb + n16][ppos]) = l;
         }
     };
     // ---- prologue: tile 0's s1 staged, its dagg rows and tile 1's A / Bm rows requested
@@ -241,8 +261,11 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
     if (nsteps > 0) {
         load_ab(i0, pa, pb);
         load_g(i0);
-        produce(sb[0], pa, pb, spp);
+        produce(s1b[0], pa, pb, spp);
         load_ab(i1, pa, pb);
+#if CO_ONE_BARRIER
+        co_barrier();                                                         // (tile 0's s1: every later tile's is published by the loop's barrier)
+#endif
     }
 
     // dW2 in an 2 x 4 arrangement of 16 x 16 blocks per wave - rows (dq features) 32 wr .., columns (s1 features) 64 wc .. - so that a wave
@@ -256,9 +279,35 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
     float bsum[2] = {0.f, 0.f};
     const float usc = invG * (1.0f / 2048.0f);
 
+#if CO_FLIP_PRIO
+    // The older wave of a SIMD wins every arbitration (priority, then age), reaches the tile's barrier ~2 000 cycles early and idles there while
+    // its partner finishes ALONE (a lone in-order wave fills about half of the issue slots; trace: profiles/r6/edge_bwd_co_trace_*.txt).
+    // Waves 4 .. 7 sit at priority 1; waves 0 .. 3 take priority 2 behind the barrier and drop to 0 at CO_FLIP_PRIO's point of the
+    // iteration (1: behind the matrix part, 2: behind dp / scan, 3: behind the next tile's s1), so that the partner catches up while both
+    // still have work.
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#elif CO_YOUNG_PRIO
+    // the second-dispatched half of the workgroup loses every arbitration against its older SIMD partner (priority, then age): it reaches
+    // the barriers ~2 500 cycles late and the older half waits there (trace: profiles/r6/edge_bwd_co_trace_v1.txt) - static priority 1
+    if (wave >= 4) __builtin_amdgcn_s_setprio(CO_YOUNG_PRIO);
+#endif
+    int k3 = 0;
     for (int step = 0; step < nsteps; ++step) {
         const int tile = tile0 + step;
-        CoBuf& B = sb[step & 1];
+#if CO_ONE_BARRIER
+        CoImg& S = s1b[k3];
+        CoImg& Sn = s1b[k3 == 2 ? 0 : k3 + 1];
+        k3 = k3 == 2 ? 0 : k3 + 1;
+#else
+        CoImg& S = s1b[step & 1];
+        CoImg& Sn = s1b[(step + 1) & 1];
+#endif
+        CoImg& D = dqb[step & 1];
+#ifdef CO_TRACE
+        const bool tr_on = blockIdx.x == 0 && step >= 100 && step < 132;
+        long long tr[10];
+#endif
+        CO_STAMP(0);
         const int e0 = tile * 32, eA = e0 + 2 * n16;
         const bool okA = eA < E, okB = eA + 1 < E;
         // what the dq / dA phases need of this tile's bookkeeping, before the registers are handed to the next tile's loads
@@ -274,10 +323,22 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
         i1 = i2;
         i2 = load_idx(tile + 3);
         asm volatile("" ::: "memory");
+        CO_STAMP(1);
+#if CO_ONE_BARRIER
+        // ONE barrier per tile: the next tile's s1 is staged HERE, in front of this tile's only barrier (which publishes it together with
+        // this tile's dq), into the third s1 image - its last readers (the weight gradient of tile - 2) passed the previous barrier
+        produce(Sn, pa, pb, sppn);
+#else
         co_barrier();                                                         // s1 of the tile staged (by the previous iteration)
+#endif
+        CO_STAMP(2);
+#if CO_FLIP_PRIO == 3
+        if (wave < 4) __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- GEMM 1: 2^11 q = 2^11 (W2 s1 + b2) for the wave's 16 q features x 32 edges; dq = dagg[i] / deg * Swish'(q)
         f32x4 acc[2] = {bq, bq};
-        co_gemm(B.s1, w1h, w1l, acc, n16, q4);
+        co_gemm(S, w1h, w1l, acc, n16, q4);
+        CO_STAMP(3);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const float Gd = G * (rb ? idB : idA);                            // 1 / deg rides in the split's multiplier
@@ -300,29 +361,31 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
             split_f16_prod(d[0], Gd, d[1], Gd, h0, l0);
             split_f16_prod(d[2], Gd, d[3], Gd, h1, l1);
             const u32x2 h = {h0, h1}, l = {l0, l1};
-            *reinterpret_cast<u32x2*>(&B.dq[0][16 * rb + n16][ppos]) = h;
-            *reinterpret_cast<u32x2*>(&B.dq[1][16 * rb + n16][ppos]) = l;
+            *reinterpret_cast<u32x2*>(&D[0][16 * rb + n16][ppos]) = h;
+            *reinterpret_cast<u32x2*>(&D[1][16 * rb + n16][ppos]) = l;
         }
         asm volatile("" ::: "memory");
         load_g(inext);                                                        // dagg rows / row bounds of tile + 1: into the registers dq has just released
         asm volatile("" ::: "memory");
+        CO_STAMP(4);
         co_barrier();                                                         // G dq of the tile staged
-        // ---- behind the second barrier: the matrix part (GEMM 2 + the weight gradient: 48 MFMAs) and the vector part (the NEXT tile's s1 /
-        // Swish'(p) into the other LDS buffer - its last readers passed this iteration's first barrier).  The waves run in lock step, so
-        // the two waves of a SIMD would both sit in the matrix part and then both in the vector part: waves 4 .. 7 (the second wave of
-        // every SIMD) take the vector part FIRST.
+        CO_STAMP(5);
+#if CO_FLIP_PRIO
+        if (wave < 4) __builtin_amdgcn_s_setprio(2);
+#endif
+        // ---- behind the barrier: the matrix part (GEMM 2 + the weight gradient: 48 MFMAs)
         f32x4 x2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         auto matrix_part = [&]() {
             // GEMM 2: 2^11 G ds1 = 2^11 W2^T (G dq) for the wave's 16 s1 features
-            co_gemm(B.dq, w2h, w2l, x2, n16, q4);
+            co_gemm(D, w2h, w2l, x2, n16, q4);
             // dW2 blocks += (G dq)^T s1 over the tile's 32 edges (k order: lane group q4 takes LDS rows 4 q4 .. + 3 and 16 + 4 q4 .. + 3), db2
             const int r0 = 4 * q4 + (n16 >> 2), c0 = 4 * (n16 & 3);
             f16x8 ah[2], al[2];
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int f = 32 * wr + 16 * a + c0;
-                const u32x2 a0 = co_tr(&B.dq[0][r0][f]), a1 = co_tr(&B.dq[0][16 + r0][f]);
-                const u32x2 b0 = co_tr(&B.dq[1][r0][f]), b1 = co_tr(&B.dq[1][16 + r0][f]);
+                const u32x2 a0 = co_tr(&D[0][r0][f]), a1 = co_tr(&D[0][16 + r0][f]);
+                const u32x2 b0 = co_tr(&D[1][r0][f]), b1 = co_tr(&D[1][16 + r0][f]);
                 ah[a] = __builtin_bit_cast(f16x8, u32x4{a0[0], a0[1], a1[0], a1[1]});
                 al[a] = __builtin_bit_cast(f16x8, u32x4{b0[0], b0[1], b1[0], b1[1]});
                 float cs = co_dot_ones(a0[0], 0.f);                           // (both waves of a pair sum the same rows; wc = 0 stores)
@@ -333,8 +396,8 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int f = 64 * wc + 16 * b + c0;
-                const u32x2 p0 = co_tr(&B.s1[0][r0][f]), p1 = co_tr(&B.s1[0][16 + r0][f]);
-                const u32x2 q0 = co_tr(&B.s1[1][r0][f]), q1 = co_tr(&B.s1[1][16 + r0][f]);
+                const u32x2 p0 = co_tr(&S[0][r0][f]), p1 = co_tr(&S[0][16 + r0][f]);
+                const u32x2 q0 = co_tr(&S[1][r0][f]), q1 = co_tr(&S[1][16 + r0][f]);
                 const f16x8 xh = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p1[0], p1[1]});
                 const f16x8 xl = __builtin_bit_cast(f16x8, u32x4{q0[0], q0[1], q1[0], q1[1]});
                 if (CO_ABL & 2) { accw[0][b][0] += (float)xh[0] + (float)xl[1]; continue; }
@@ -346,18 +409,10 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
                 for (int a = 0; a < 2; ++a) accw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], xh, accw[a][b], 0, 0, 0);
             }
         };
-#if CO_PRODUCE_LATE
         matrix_part();
-#else
-        if (wave < 4 || (CO_ABL & 128)) {
-            matrix_part();
-            __builtin_amdgcn_sched_barrier(0);
-            produce(sb[(step + 1) & 1], pa, pb, sppn);
-        } else {
-            produce(sb[(step + 1) & 1], pa, pb, sppn);
-            __builtin_amdgcn_sched_barrier(0);
-            matrix_part();
-        }
+        CO_STAMP(6);
+#if CO_FLIP_PRIO == 1
+        if (wave < 4) __builtin_amdgcn_s_setprio(0);
 #endif
         // ---- dp = ds1 * Swish'(p)
         {
@@ -408,8 +463,17 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
                 else co_stg4(pp, (rsB < e0 ? 0u : 512u) + 4u * fcol, x2[1]);
             }
         }
-#if CO_PRODUCE_LATE
-        produce(sb[(step + 1) & 1], pa, pb, sppn);                            // (the next tile's s1: the last thing before its first barrier)
+        CO_STAMP(7);
+#if CO_FLIP_PRIO == 2
+        if (wave < 4) __builtin_amdgcn_s_setprio(0);
+#endif
+#if !CO_ONE_BARRIER
+        produce(Sn, pa, pb, sppn);                                            // (the next tile's s1: the last thing before its first barrier)
+#endif
+        CO_STAMP(8);
+#ifdef CO_TRACE
+        if (tr_on && lane == 0)
+            for (int k = 0; k < 9; ++k) g_co_trace[wave][step - 100][k] = tr[k];
 #endif
         // ---- hand the pipeline registers on (the rows of tile + 2 were requested at the top of this iteration)
 #pragma unroll
