@@ -606,3 +606,21 @@ def test_training_gradients_and_rollouts_repeat_bitwise_under_a_busy_second_stre
     summary, failed = stress_determinism.run("c1,cnn_1d,gnn_1d,c4a", reps=12, gap_every=5, gap=0.1, log=lambda *a, **k: lines.append(" ".join(map(str, a))))
     assert not failed, "\n".join(lines)
     assert all(v["train"]["reps"] == 12 and v["rollout"]["reps"] == 12 and v["train"]["grad_elements"] > 1000 for v in summary.values())
+
+
+@pytest.mark.gpu
+def test_third_party_restatement_is_pinned_wherever_the_wheels_exist():
+    """any box that ever has torch_cluster / torch_scatter / torch_geometric 2.0.3 pins oracle/pyg_semantics.py (SURVEY 8
+    row a22) without anyone remembering to: scripts/pin_third_party.py --device cuda must print PINNED (or SKIPPED where the wheels are
+    absent - this image) and exit 0; a mismatch (exit 1, "NOT PINNED") fails the suite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "pin_third_party.py"), "--device", "cuda"], capture_output=True,
+                       text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and ("PINNED" in r.stdout or "SKIPPED" in r.stdout) and "NOT PINNED" not in r.stdout, out[-3000:]
+    if "SKIPPED" in r.stdout:
+        pytest.skip("torch_geometric / torch_cluster / torch_scatter are not installed here: a22 stays parity-unpinned (" +
+                    r.stdout.strip().splitlines()[-1][:200] + ")")

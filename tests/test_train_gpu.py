@@ -636,11 +636,13 @@ def test_magnet_gnn_training_step_gradients(teacher_forcing):
         assert p.grad is not None, n
         errs[n] = rel_l2(p.grad, want[n])
         cos = float((p.grad.double().cpu().flatten() @ want[n].double().flatten()) / (p.grad.double().norm().cpu() * want[n].double().norm()).clamp_min(1e-300))
-        assert errs[n] < 0.1 and cos > 0.995, (n, errs[n], cos)
+        # (kink-limited: ONE of the step's 3.15e7 units takes the other branch in the fp64 run - tests/test_mask_sync_gpu.py counts them - and the
+        #  L1 sign of a few entries; the well-posed comparison, 3e-6 on every parameter, is made there.  Measured worst here: 1.3e-3)
+        assert errs[n] < 1e-2 and cos > 0.9999, (n, errs[n], cos)
         norm, sample, stride = gold[n]
-        assert abs(float(p.grad.norm()) - norm) < 0.1 * norm, n
+        assert abs(float(p.grad.norm()) - norm) < 1e-2 * norm, n
         if sample.numel() >= 16:                                     # a handful of samples of a 64-entry bias is noise
-            assert rel_l2(p.grad.flatten()[::stride], sample) < 0.1, n
+            assert rel_l2(p.grad.flatten()[::stride], sample) < 1e-2, n
     upstream = [e for n, e in errs.items() if n.startswith(("encoder.", "processor.", "proj_head", "projector."))]
     assert len(upstream) > 90 and max(upstream) < 2e-5, max(upstream)
 
@@ -726,9 +728,9 @@ def test_magnet_cnn_training_step_gradients(tag, teacher_forcing):
         assert p.grad is not None, n
         errs[n] = rel_l2(p.grad, want[n])
         cos = float((p.grad.double().cpu().flatten() @ want[n].double().flatten()) / (p.grad.double().norm().cpu() * want[n].double().norm()).clamp_min(1e-300))
-        assert errs[n] < 0.1 and cos > 0.995, (n, errs[n], cos)
+        assert errs[n] < 1e-2 and cos > 0.9999, (n, errs[n], cos)         # (kink-limited; tests/test_mask_sync_gpu.py has the well-posed 3e-6)
         norm, sample, stride = gold[n]
-        assert abs(float(p.grad.norm()) - norm) < 0.1 * norm, n
+        assert abs(float(p.grad.norm()) - norm) < 1e-2 * norm, n
     assert sorted(errs.values())[len(errs) // 2] < 1e-5 and max(errs.values()) < 1e-2       # measured: 6e-7 ... 2e-6, 1.3e-3
 
 
