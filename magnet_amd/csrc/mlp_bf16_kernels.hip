@@ -156,7 +156,10 @@ __device__ int g_mlp_trace_wg = 0;
 #define TRACE_INIT int tr_n = 0; const bool tr_on = g_mlp_trace && (int)blockIdx.x == g_mlp_trace_wg && threadIdx.x == 0;
 #define TRACE(tag) if (tr_on && tr_n < 500) { g_mlp_trace[2 * tr_n] = __builtin_readcyclecounter(); g_mlp_trace[2 * tr_n + 1] = (tag); ++tr_n; }
 #else
-#define MLP_ABL_INIT constexpr int abl = 0;
+#ifndef MLP_ABL_STATIC
+#define MLP_ABL_STATIC 0                // (experiment builds: the same flags at compile time - the product kernel's own code with a piece left out)
+#endif
+#define MLP_ABL_INIT constexpr int abl = MLP_ABL_STATIC;
 #define TRACE_INIT
 #define TRACE(tag)
 #endif

@@ -208,9 +208,9 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
         if (CO_ABL & 32) x.tA &= 63, x.tB &= 63, x.sA &= 63, x.sB &= 63;
         return x;
     };
-    // Rows in flight: pa / pb = A[i], Bm[j] of the tile whose s1 is produced in THIS iteration (tile + 1), qa / qb = the same of tile + 2
-    // (requested at the top of the iteration, consumed a step and a half later), gv / rs / re = dagg[i] and the row bounds of the tile
-    // whose dq is formed in the next iteration.
+    // Rows in flight: pa / pb = A[i], Bm[j] of the tile whose s1 is produced in THIS iteration (tile + 1) - re-requested for tile + 2 as
+    // soon as the production has read them (two barriers: a second set qa / qb, requested at the top of the iteration) -, gv / rs / re =
+    // dagg[i] and the row bounds of the tile whose dq is formed in the next iteration.
     f32x4 pa[2], pb[2], qa[2], qb[2], gv[2];
     int rs[2], re[2];
     auto load_ab = [&](const CoIdx& x, f32x4 (&a_)[2], f32x4 (&b_)[2]) {
@@ -317,8 +317,10 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
         const int rsA = rs[0], reA = re[0], rsB = rs[1], reB = re[1];
         // ---- requests: A / Bm rows of tile + 2, indices of tile + 3 (past the range: the clamped last tile again, unused)
         asm volatile("" ::: "memory");
+#if !CO_ONE_BARRIER
         load_ab(i2, qa, qb);
-        const CoIdx inext = i1;
+#endif
+        const CoIdx inext = i1, iab = i2;
         ctA = i1.tA, ctB = i1.tB;
         i1 = i2;
         i2 = load_idx(tile + 3);
@@ -328,6 +330,9 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
         // ONE barrier per tile: the next tile's s1 is staged HERE, in front of this tile's only barrier (which publishes it together with
         // this tile's dq), into the third s1 image - its last readers (the weight gradient of tile - 2) passed the previous barrier
         produce(Sn, pa, pb, sppn);
+        asm volatile("" ::: "memory");
+        load_ab(iab, pa, pb);                                                 // tile + 2's rows: into the registers the production has just released
+        asm volatile("" ::: "memory");                                        // (a whole iteration ahead of their use; no second register set, no copies)
 #else
         co_barrier();                                                         // s1 of the tile staged (by the previous iteration)
 #endif
@@ -437,17 +442,40 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
             const float m1 = ((n16 >= 1) & (tp1 == tB)) ? 1.f : 0.f, m2 = ((n16 >= 2) & (tp2 == tB)) ? 1.f : 0.f;
             const float m4 = ((n16 >= 4) & (tp4 == tB)) ? 1.f : 0.f, m8 = ((n16 >= 8) & (tp8 == tB)) ? 1.f : 0.f;
             const float mC = ((n16 >= 1) & (tp1 == tA)) ? 1.f : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float x0 = x2[0][i], x1 = x2[1][i];
-                x1 += m01 * x0;
-                x1 += m1 * dpp_f<DPP_SHR1, 0xF>(x1);
-                x1 += m2 * dpp_f<DPP_SHR2, 0xF>(x1);
-                x1 += m4 * dpp_f<DPP_SHR4, 0xF>(x1);
-                x1 += m8 * dpp_f<DPP_SHR8, 0xF>(x1);
-                x0 += mC * dpp_f<DPP_SHR1, 0xF>(x1);
-                x2[0][i] = x0, x2[1][i] = x1;
-            }
+            // x1 += m01 x0, four levels of x1 += m_d * x1[lane - d], x0 += mC * x1[lane - 1]: v_fmac_f32 with the DPP row shift on its own
+            // source (hipcc emits v_mov_b32_dpp + v_fmac_f32: 44 instead of 24 instructions).  The four values are interleaved, so every
+            // DPP read is three VALU instructions behind the write of its register (the hazard needs two wait states); lanes shifted in
+            // from outside the 16-lane row read 0 (bound_ctrl) and their mask is 0 as well.
+            float x00 = x2[0][0], x01 = x2[0][1], x02 = x2[0][2], x03 = x2[0][3];
+            float x10 = x2[1][0], x11 = x2[1][1], x12 = x2[1][2], x13 = x2[1][3];
+#define CO_L4(op) op(x10) "\n\t" op(x11) "\n\t" op(x12) "\n\t" op(x13) "\n\t"
+            asm volatile("v_fmac_f32 %4, %8, %0\n\tv_fmac_f32 %5, %8, %1\n\tv_fmac_f32 %6, %8, %2\n\tv_fmac_f32 %7, %8, %3\n\t"
+                         "v_fmac_f32_dpp %4, %4, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %5, %5, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %6, %6, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %7, %7, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %4, %4, %10 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %5, %5, %10 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %6, %6, %10 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %7, %7, %10 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %4, %4, %11 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %5, %5, %11 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %6, %6, %11 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %7, %7, %11 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %4, %4, %12 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %5, %5, %12 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %6, %6, %12 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %7, %7, %12 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %0, %4, %13 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %1, %5, %13 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %2, %6, %13 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_fmac_f32_dpp %3, %7, %13 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "s_nop 1"
+                         : "+v"(x00), "+v"(x01), "+v"(x02), "+v"(x03), "+v"(x10), "+v"(x11), "+v"(x12), "+v"(x13)
+                         : "v"(m01), "v"(m1), "v"(m2), "v"(m4), "v"(m8), "v"(mC));
+#undef CO_L4
+            x2[0] = f32x4{x00, x01, x02, x03};
+            x2[1] = f32x4{x10, x11, x12, x13};
             const bool endA = okA && tB != tA;
             const bool endB = okB && (n16 == 15 || tn1 != tB);
             float *pd = dA, *pp = partials + (size_t)tile * 256;
@@ -477,7 +505,12 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
 #endif
         // ---- hand the pipeline registers on (the rows of tile + 2 were requested at the top of this iteration)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) pa[rb] = qa[rb], pb[rb] = qb[rb], spp[rb] = sppn[rb];
+        for (int rb = 0; rb < 2; ++rb) {
+#if !CO_ONE_BARRIER
+            pa[rb] = qa[rb], pb[rb] = qb[rb];
+#endif
+            spp[rb] = sppn[rb];
+        }
     }
     // ---- this workgroup's partial sums of dW2 / db2
     float* wout = wpart + (size_t)blockIdx.x * 128 * 128;

@@ -142,9 +142,12 @@ __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restr
     };
 
     // ---- one iteration: GEMM + epilogue of the current tile, input production of the next one, index / A-row prefetch of the one after
-    auto step = [&](int k) __attribute__((always_inline)) {
+    // ES_ROLES (development ablation, results invalid; profiles/r6/edge_stream_roles.txt): DO_M = this wave issues the tile's MFMAs (and their
+    // weight-fragment reads), DO_V = everything else (gathers, input production, epilogue)
+    auto step = [&](int k, auto do_m, auto do_v) __attribute__((always_inline)) {
+        constexpr bool DO_M = decltype(do_m)::value, DO_V = decltype(do_v)::value;
         // the next tile's A rows -> LDS (the previous pair was last read by the previous iteration's epilogue phase)
-        park(d1, an0, an1);
+        if (DO_V) park(d1, an0, an1);
         const float* const arl = arl_of(d1);
         auto lds_a = [&](int off) { return *reinterpret_cast<const f32x4*>(arl + off); };
         const int4 d2 = desc_at(k + 2);
@@ -160,27 +163,33 @@ __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restr
                 wr[d % 2][u][1] = wlane[((k1 * 4 + 2 * q1 + u) * 2 + 1) * 64];
             }
         };
-        wload(0);
+        if (DO_M) wload(0);
         // ---- GEMM phase (generation 11's): double group dg = 2 ks + q handles k step ks for the output blocks 2 q and 2 q + 1
 #pragma unroll
         for (int dg = 0; dg < 16; ++dg) {
             const int ks = dg >> 1, q = dg & 1, n0 = 2 * q, n1 = 2 * q + 1, bsel = dg % 2;
-            if (dg + 1 < 16) wload(dg + 1);
+            if (DO_M && dg + 1 < 16) wload(dg + 1);
             const f32x4 la_now = la;
-            if (dg >= 1) la = lds_a(16 * ((dg - 1) >> 1) + 4 * ((dg - 1) & 1));   // for double group dg + 1
+            if (DO_V && dg >= 1) la = lds_a(16 * ((dg - 1) >> 1) + 4 * ((dg - 1) & 1));   // for double group dg + 1
             __builtin_amdgcn_sched_barrier(0);    // LDS requests first
-            if (ks == 0) {
-                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                out[n0] = mfma_xw(xh[0], wr[bsel][0][1], z);
-                out[n1] = mfma_xw(xh[0], wr[bsel][1][1], z);
-            } else {
-                out[n0] = mfma_xw(xh[ks], wr[bsel][0][1], out[n0]);
-                out[n1] = mfma_xw(xh[ks], wr[bsel][1][1], out[n1]);
+            if (DO_M) {
+                if (ks == 0) {
+                    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    out[n0] = mfma_xw(xh[0], wr[bsel][0][1], z);
+                    out[n1] = mfma_xw(xh[0], wr[bsel][1][1], z);
+                } else {
+                    out[n0] = mfma_xw(xh[ks], wr[bsel][0][1], out[n0]);
+                    out[n1] = mfma_xw(xh[ks], wr[bsel][1][1], out[n1]);
+                }
+                out[n0] = mfma_xw(xl[ks], wr[bsel][0][0], out[n0]);
+                out[n1] = mfma_xw(xl[ks], wr[bsel][1][0], out[n1]);
+                out[n0] = mfma_xw(xh[ks], wr[bsel][0][0], out[n0]);
+                out[n1] = mfma_xw(xh[ks], wr[bsel][1][0], out[n1]);
             }
-            out[n0] = mfma_xw(xl[ks], wr[bsel][0][0], out[n0]);
-            out[n1] = mfma_xw(xl[ks], wr[bsel][1][0], out[n1]);
-            out[n0] = mfma_xw(xh[ks], wr[bsel][0][0], out[n0]);
-            out[n1] = mfma_xw(xh[ks], wr[bsel][1][0], out[n1]);
+            if (!DO_V) {
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             if (dg >= 2) pieces4((dg - 2) >> 1, dg & 1, la_now, lb[((dg - 2) >> 1) % LBD][dg & 1]);
             // k step ks + LBD - 2: its set was drained by double groups 2 ks - 2, 2 ks - 1 (the first LBD - 2 k steps of a tile are
             // requested in the previous tile's epilogue)
@@ -191,9 +200,21 @@ __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restr
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (!DO_V) {                           // (ablation: the matrix stream alone - its results stay alive, nothing reads them)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(out[nt]));
+            d0 = d1, d1 = d2;
+            return;
+        }
         // ---- epilogue phase: k step 7 of the next tile's inputs, then Swish of this tile's 64 outputs per lane
         pieces4(7, 0, la, lb[7 % LBD][0]);
         pieces4(7, 1, lds_a(16 * 7 + 4), lb[7 % LBD][1]);
+        if (!DO_M) {                           // (ablation: everything but the matrix stream - the pieces nobody multiplies stay alive, the
+#pragma unroll                                 //  accumulators the epilogue reads are "new" every tile)
+            for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(xh[ks]), "+v"(xl[ks]));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(out[nt]));
+        }
         if (LBD > 2) {                         // the first k steps of the tile after next: in flight through this epilogue
             const float* pb2 = Bm + (size_t)idx2 * 128 + 8 * half;
 #pragma unroll
@@ -304,7 +325,20 @@ __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restr
 #pragma unroll
         for (int ks = 0; ks < LBD - 2; ++ks) request(ks, pb1);
     }
-    for (int k = 0; k < K; ++k) step(k);
+#ifndef ES_ROLES
+#define ES_ROLES 0
+#endif
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (ES_ROLES == 0) {
+        for (int k = 0; k < K; ++k) step(k, T_{}, T_{});
+    } else if ((ES_ROLES == 4 && wave >= 4) || (ES_ROLES == 5 && wave < 4)) {
+        return;                                                          // 4 / 5: the matrix stream / the rest with the SIMD partner absent
+    } else if (ES_ROLES == 2 || ((ES_ROLES == 1 || ES_ROLES == 4) && wave < 4)) {   // 1: waves 0 .. 3 the matrix stream, their SIMD partners 4 .. 7 the rest
+        for (int k = 0; k < K; ++k) step(k, T_{}, F_{});
+    } else {
+        for (int k = 0; k < K; ++k) step(k, F_{}, T_{});
+    }
 }
 
 // A, Bm [n_rows, 128] fp32 (times log2 e when flags & MAGNET_STREAM_L2E); src [n_edges] the CSR's sources; tiles [n_chunks][tpc] int4 and

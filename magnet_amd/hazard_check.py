@@ -378,7 +378,7 @@ def path_hazards(kernels) -> list[tuple[str, int, int, str, str]]:
       * VALU write -> MFMA read (SrcA / SrcB / SrcC): 2 wait states;
       * MFMA result -> VALU / LDS / VMEM read: passes + 2;
       * transcendental result -> non-transcendental VALU read: 1;
-      * VALU write -> v_permlane* read: 2, -> v_readlane / v_readfirstlane read: 1
+      * VALU write -> v_permlane* read: 2, -> v_readlane / v_readfirstlane read: 1; -> the DPP source of a *_dpp instruction: 2
     evaluated along EVERY path of the control-flow graph."""
     bad = []
     for name, ins in kernels:
@@ -431,6 +431,13 @@ def path_hazards(kernels) -> list[tuple[str, int, int, str, str]]:
             elif op.startswith(("v_readlane", "v_readfirstlane")):
                 reads = [r for tok in a[1:2] for r in _regs(tok)]
                 w = search(k, reads, 1, is_valu, False)
+                if w:
+                    bad.append((name, k, w[0], ins[w[1]], ins[k]))
+            elif op.endswith("_dpp") and len(a) > 1:
+                # a DPP instruction reads its first source from OTHER lanes: a VALU write of that register needs two wait states in front of
+                # it (hipcc spaces its own; the hand-written v_fmac_f32_dpp scan of mpnn_edge_bwd_co.hip interleaves four values instead)
+                reads = _regs(a[1].split()[0])
+                w = search(k, reads, 2, is_valu, False)
                 if w:
                     bad.append((name, k, w[0], ins[w[1]], ins[k]))
             if op.startswith("v_") or op.startswith(("ds_write", "ds_store", "global_store", "buffer_store", "flat_store", "scratch_store")):

@@ -351,6 +351,18 @@ def test_hazard_rules_for_sgprs_lane_ops_m0_and_loop_seams():
     assert [h for n, i, f in H.loop_seams([("k", k2)]) for h in H.violations([(n, i)]) if h[1] >= f] == []     # s_nop 0 + the branch = 2
 
 
+def test_hazard_rule_for_dpp_sources():
+    """round 6: the hand-written v_fmac_f32_dpp scan of k_mpnn_edge_bwd_co - a VALU write of the register a DPP instruction reads from
+    other lanes needs two wait states in front of it (path_hazards)"""
+    from magnet_amd import hazard_check as H
+    dpp = "v_fmac_f32_dpp v10, v10, v3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+    mk = lambda mid: [("k", H.Kernel(["v_fmac_f32_e32 v10, v1, v2"] + mid + [dpp]))]      # noqa: E731
+    assert len(H.path_hazards(mk([]))) == 1 and len(H.path_hazards(mk(["v_fmac_f32_e32 v11, v1, v2"]))) == 1
+    assert H.path_hazards(mk(["v_fmac_f32_e32 v11, v1, v2", "v_fmac_f32_e32 v12, v1, v2"])) == [] and H.path_hazards(mk(["s_nop 1"])) == []
+    # the multiplier (second source) is read in place: no distance needed
+    assert H.path_hazards([("k", H.Kernel(["v_mov_b32_e32 v3, v1", dpp]))]) == []
+
+
 def test_hazard_rules_follow_taken_forward_branches():
     """round 5: a FORWARD branch that skips code shortens the executed distance between a writer in front of it and a reader behind its
     target - `plane word written by asm; if (run ends) { ... 30 instructions ... }; MFMA reads the word` passes a linear walk and is
