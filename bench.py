@@ -809,6 +809,28 @@ def bench_ref_shapes(dev):
                         "lr": 1e-6, "widened_to_bf16x6": packing.wide()}
         del tm, opt, train_step
         packing.narrow()
+        # ---- the same step replayed from ONE hipGraph (magnet_amd.graphs.TrainStepGraph: forward + tape + backward + the in-place re-pack
+        # captured; gradient zero fill, range words and the Adam launch outside) - what a custom training loop can use; bit-equal losses
+        # (tests/test_train_gpu.py).  It removes the host's share of a step, not the kernels': GPU-bound shapes do not move.
+        try:
+            from magnet_amd.graphs import TrainStepGraph
+            torch.manual_seed(0)
+            gm = FACTORY[name](types.SimpleNamespace(**dict(hp, lr=1e-6))).to(dev).train()
+            gstep = TrainStepGraph(gm, gm.configure_optimizers()["optimizer"])
+            for _ in range(3):
+                gstep(batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                gstep(batch)
+            torch.cuda.synchronize()
+            res["train"]["ms_per_step_hip_graph"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+            res["train"]["hip_graph_replays"] = gstep.replays
+            del gm, gstep
+        except Exception as ex:  # noqa: BLE001  (an extra: never costs the line)
+            res["train"]["ms_per_step_hip_graph"] = None
+            res["train"]["hip_graph_error"] = f"{type(ex).__name__}: {str(ex)[:120]}"
+        packing.narrow()
         # ---- validation rollout: kernel by kernel, and replayed from one hipGraph
         batch, nodes = mk(False)
         batch = {k: v.to(dev) for k, v in batch.items()}

@@ -15,6 +15,8 @@ import types
 
 import torch
 
+from ..graphs import capturing
+
 from .. import _lib as L
 from .. import ops
 from ..packing import pad_to, param_list
@@ -199,7 +201,7 @@ class MAgNetCNN(MagnetBase):
                     hr_last = out_hr[:, -1]
         pred, hr_hat = torch.cat(outs, dim=1), torch.cat(hrs, dim=1)
         target = torch.cat([fut, self._lr_as_nodes(u[:, T:])], dim=2)
-        why = self._range_trip()
+        why = None if capturing() else self._range_trip()      # (a captured step - graphs.TrainStepGraph - reads the words behind its replay)
         if why:                                 # out of the fp16 pieces' range: the same step in the full-range split
             self._widen(why)
             return self.training_step(train_batch, batch_idx)

@@ -248,7 +248,12 @@ class MagnetBase(LightningModule):
                 self.__dict__["_pack_rec"] = rec
                 _tag_recorder(self._pack, rec)
             self._pack_key = key
-            if capturing() or weights_check_due(params[0].device):    # (else: read at the end of the rollout, _range_trip)
+            if capturing() and torch.is_grad_enabled():
+                # a training step under capture (graphs.TrainStepGraph): its re-pack is part of the graph; the packers' word is read
+                # behind every replay (_range_trip -> pending_weight_check)
+                from ..packing import note_unchecked
+                note_unchecked(params[0].device)
+            elif capturing() or weights_check_due(params[0].device):    # (else: read at the end of the rollout, _range_trip)
                 why = self._weights_trip()
                 if why:
                     self._widen(why)

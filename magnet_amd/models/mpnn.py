@@ -229,7 +229,7 @@ class MPNN(LightningModule):
                   c2.weight.detach().reshape(-1).contiguous(), c2.bias.detach().contiguous())
         assert nin <= kin
         self._pack_key, self._pack = key, P
-        if dev.type == "cuda":
+        if dev.type == "cuda" and not capturing():      # (a captured training step reads the word behind its replay: graphs.TrainStepGraph)
             from ..packing import bad_weights
             if bad_weights(dev):               # the fp16x3 packs' range check: ONE host read per re-pack (not one per Linear)
                 self._pack_key = None

@@ -84,7 +84,8 @@ def _packed_bwd(m):
     Q.e1t = pack(e1.t(), None, mode)
     Q.e0t = pack(padk(e0).t(), None, mode)                               # [kin, H]
     m._pack_bwd, m._pack_bwd_key = Q, m._pack_key
-    if dev.type == "cuda" and f16_planes:
+    from ..graphs import capturing
+    if dev.type == "cuda" and f16_planes and not capturing():      # (a captured step - graphs.TrainStepGraph - reads the word behind its replay)
         from ..packing import bad_weights
         if bad_weights(dev):                   # the fp16 planes of the fused backward kernels: one host read per re-pack
             # |w| >= 31.98 in message_net_2 / update_net_2 / the agg block of update_net_1 (or >= 65504 anywhere): the planes those
@@ -289,7 +290,8 @@ class _Rollout(torch.autograd.Function):
         tapes = []
         with torch.no_grad():
             u_hat, target = m.rollout(batch, teacher_forcing, tapes=tapes)
-        why = m._guard.tripped()
+        from ..graphs import capturing
+        why = None if capturing() else m._guard.tripped()      # (a captured step - graphs.TrainStepGraph - reads the word behind its replay)
         if why:                                # out of the fp16 pieces' range: the same forward (and its tapes) in the full-range split
             m._widen(why)
             tapes = []

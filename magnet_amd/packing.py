@@ -84,6 +84,18 @@ def pack_linear_bf16x3(w: torch.Tensor, b: torch.Tensor | None, k_pad: int | Non
     return out.view(-1), bp
 
 
+def _too_large_for_scaled_plane(w, h) -> bool:
+    """does 2^11 fp16(w) leave the fp16 range (|w| >= 31.98)?  One host read - except while a training step is being CAPTURED
+    (graphs.TrainStepGraph: the re-pack of the weights is part of the captured step and nothing in it may synchronise): then the
+    verdict goes to the device status word (flag_if_abs_reaches), the packer carries on as if the weight fitted, and the step's
+    owner reads the word behind the replay - a trip repeats the step in the full-range split."""
+    from .graphs import capturing
+    if w.is_cuda and capturing():
+        flag_if_abs_reaches(w, 31.98)
+        return False
+    return float(h.float().abs().max()) * 2048.0 >= 65504.0
+
+
 def split_fp16x2(w: torch.Tensor):
     """Two-piece fp16 split: w ~= h + l / 2048 with h = fp16(w), l = fp16((w - h) * 2048) (both round-to-nearest;
     the remainder is exact in fp32 and the 2^11 scaling keeps it a normal fp16).  |w| must be < 65504."""
@@ -127,7 +139,7 @@ def pack_edge16_fp16x2(w: torch.Tensor, b: torch.Tensor | None, scaled: bool = F
     assert tuple(w.shape) == (128, 128), w.shape
     h, lo = split_fp16x2(w)
     if scaled:     # the single-accumulator variant of the kernel: plane 0 = 2^11 fp16(w) (exact while |w| < 31.98), see pack_edge32t_fp16x2
-        if float(h.float().abs().max()) * 2048.0 >= 65504.0:
+        if _too_large_for_scaled_plane(w, h):
             raise ValueError("pack_edge16_fp16x2(scaled=True): |w| >= 31.98 does not survive the 2^11 pre-scaling of the high plane")
         h = (h.float() * 2048.0).half()
     planes = [pl.view(8, 16, 4, 4, 8).permute(2, 0, 3, 1, 4).reshape(4, 8, 64, 8) for pl in (h, lo)]
@@ -147,7 +159,7 @@ def pack_edge32t_fp16x2(w: torch.Tensor, b: torch.Tensor | None):
     (|w| >= 31.98): the caller keeps the 16-edge kernel then."""
     assert tuple(w.shape) == (128, 128), w.shape
     h, lo = split_fp16x2(w)
-    if float(h.float().abs().max()) * 2048.0 >= 65504.0:
+    if _too_large_for_scaled_plane(w, h):
         raise ValueError("pack_edge32t_fp16x2: |w| >= 31.98 does not survive the 2^11 pre-scaling of the high plane")
     hs = (h.float() * 2048.0).half()                      # exact: a power-of-two scaling inside the fp16 range
     planes = [pl.view(4, 32, 8, 2, 8).permute(2, 0, 3, 1, 4).reshape(8, 4, 64, 8) for pl in (hs, lo)]
@@ -349,6 +361,11 @@ def weights_check_due(dev) -> bool:
         _unchecked.add(torch.device(dev))
         return False
     return True
+
+
+def note_unchecked(dev) -> None:
+    """packs were made on ``dev`` and nobody has read the status word yet (pending_weight_check will say so)"""
+    _unchecked.add(torch.device(dev))
 
 
 def pending_weight_check(dev) -> bool:

@@ -839,6 +839,40 @@ def test_rccl_process_group_runs_the_training_collectives_on_one_rank():
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("tag", ["mpnn_2d", "magnet_gnn_tiny", "magnet_cnn_2d"])
+def test_training_step_replayed_from_one_hip_graph_equals_the_eager_steps(tag):
+    """graphs.TrainStepGraph: training_step + backward captured once, replayed - including the in-place re-pack of
+    the weights the optimizer moved; the zero fill of the gradients, the range words, the Adam launch stay outside.  Six steps: the same
+    losses and the same final parameters as six eager steps, bit for bit; every step after the first capture is a replay; the host
+    generator ends where the eager run leaves it (MAgNet[GNN] draws its input noise there)."""
+    from magnet_amd.graphs import TrainStepGraph
+    runs = {}
+    for mode in ("eager", "graph"):
+        hp, batch, oracle, model = _pair(tag, lr=1e-4)
+        cb = {k: v.cuda() for k, v in batch.items()}
+        model.train()
+        opt = model.configure_optimizers()["optimizer"]
+        step = TrainStepGraph(model, opt) if mode == "graph" else None
+        torch.manual_seed(3)
+        losses = []
+        for _ in range(6):
+            if step is not None:
+                losses.append(float(step(cb).detach()))
+            else:
+                opt.zero_grad()
+                loss = model.training_step(cb, 0)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+        runs[mode] = (losses, [p.detach().clone() for p in model.parameters()], torch.get_rng_state().clone())
+        if step is not None:
+            assert step.replays == 6 and step.eager_steps == 0, (step.replays, step.eager_steps)
+    assert runs["eager"][0] == runs["graph"][0], (runs["eager"][0], runs["graph"][0])
+    assert all(torch.equal(a, b) for a, b in zip(runs["eager"][1], runs["graph"][1]))
+    assert torch.equal(runs["eager"][2], runs["graph"][2])
+    assert runs["eager"][0][-1] < runs["eager"][0][0]
+
+
 def test_ddp_wrapper_sees_every_parameter_gradient():
     """the backward kernels' in-place parameter gradients (autograd.accumulate_param_grads, the MPNN rollout's flat
     buffer) bypass AccumulateGrad - and with it DistributedDataParallel's reducer hooks.  Inside a DDP forward the shortcut must be
