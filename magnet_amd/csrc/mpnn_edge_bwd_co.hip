@@ -133,7 +133,10 @@ __device__ __forceinline__ void co_gemm(const unsigned short (&img)[2][32][CO_ST
                 continue;
             }
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[kt], zh[k2][rb], acc[rb], 0, 0, 0);
+            for (int rb = 0; rb < 2; ++rb) {                                  // (the chain's first product starts from the inline constant 0:
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};                      //  a zeroed accumulator variable costs four v_mov per block)
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[kt], zh[k2][rb], kt == 0 ? zero : acc[rb], 0, 0, 0);
+            }
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kt], zl[k2][rb], acc[rb], 0, 0, 0);
 #pragma unroll
@@ -185,9 +188,9 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
         w2l[kt] = __builtin_bit_cast(f16x8, w2ts[idx + 64]);
     }
     const unsigned fcol = 16u * (unsigned)wave + 4u * (unsigned)q4;           // this lane's first feature
-    f32x4 bq;                                                                 // 2^11 b2 of its four q features
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bq[i] = b2[fcol + i] * 2048.0f;
+    f32x4 bq, bql;                                                            // b2 of its four q features, and - log2(e) b2: the bias joins q in the
+#pragma unroll                                                                // two fused multiply-adds that take 2^11 q apart (the MFMAs start from 0)
+    for (int i = 0; i < 4; ++i) bq[i] = b2[fcol + i], bql[i] = b2[fcol + i] * -1.4426950408889634f;
     const int ppos = 16 * wave + 8 * (q4 & 1) + 4 * (q4 >> 1);                // where its four features sit in an LDS row
     // ---- the workgroup's contiguous range of tiles (consecutive workgroups of an XCD take consecutive ranges)
     const int ntiles = (E + 31) / 32;
@@ -227,6 +230,8 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
         rs[0] = co_ldi(pr, 4u * (unsigned)x.tA), re[0] = co_ldi(pr, 4u * (unsigned)x.tA + 4u);
         rs[1] = co_ldi(pr, 4u * (unsigned)x.tB), re[1] = co_ldi(pr, 4u * (unsigned)x.tB + 4u);
     };
+    f32x4 vone = {1.0f, 1.0f, 1.0f, 1.0f}, vmone = {-1.0f, -1.0f, -1.0f, -1.0f};
+    asm volatile("" : "+v"(vone), "+v"(vmone));                               // (in registers: hipcc scalarises packed arithmetic on literals / negations)
     // ---- phase A of a tile: s1 = Swish(p) as fp16 planes into LDS buffer `B`, Swish'(p) into `sp` (registers)
     auto produce = [&](CoImg& S, const f32x4 (&a_)[2], const f32x4 (&b_)[2], f32x4 (&sp)[2]) {
 #pragma unroll
@@ -236,7 +241,7 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
             const f32x4 v = a_[rb] + b_[rb];
             const f32x4 s = co_sigmoid4(v * (-1.4426950408889634f));
             const f32x4 t = v * s;
-            sp[rb] = (s + t) - t * s;                                           // s (1 + v (1 - s))
+            sp[rb] = t * (s * vmone + vone) + s;                                // s (1 + v (1 - s)): two v_pk_fma (a literal 1 - s is taken apart)
 #else
             f32x4 v, s;
 #pragma unroll
@@ -271,12 +276,12 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
     // dW2 in an 2 x 4 arrangement of 16 x 16 blocks per wave - rows (dq features) 32 wr .., columns (s1 features) 64 wc .. - so that a wave
     // reads 2 + 4 transposed operand blocks per tile instead of 1 + 8
     const int wr = wave >> 1, wc = wave & 1;
-    f32x4 accw[2][4];                                                         // G dW2[32 wr + 16 a + co_sw(4 q4 + i)][64 wc + 16 b + co_sw(n16)]
+    f32x4 accw[2][4];                                                         // G dW2[32 wr + 16 (a ^ wc) + co_sw(4 q4 + i)][64 wc + 16 b + co_sw(n16)]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) accw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum[2] = {0.f, 0.f};
+    float bsum = 0.f;                                                         // G db2[32 wr + 16 wc + co_sw(n16)], this lane's edges
     const float usc = invG * (1.0f / 2048.0f);
 
 #if CO_FLIP_PRIO
@@ -341,7 +346,7 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
         if (wave < 4) __builtin_amdgcn_s_setprio(0);
 #endif
         // ---- GEMM 1: 2^11 q = 2^11 (W2 s1 + b2) for the wave's 16 q features x 32 edges; dq = dagg[i] / deg * Swish'(q)
-        f32x4 acc[2] = {bq, bq};
+        f32x4 acc[2];
         co_gemm(S, w1h, w1l, acc, n16, q4);
         CO_STAMP(3);
 #pragma unroll
@@ -349,17 +354,16 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
             const float Gd = G * (rb ? idB : idA);                            // 1 / deg rides in the split's multiplier
             // Swish'(q) with q = acc / 2^11: the scale rides in the constants
 #if CO_PACKED
-            const f32x4 s = co_sigmoid4(acc[rb] * (-1.4426950408889634f / 2048.0f));
-            const f32x4 t = (acc[rb] * (1.0f / 2048.0f)) * s;
-            const f32x4 d = gv[rb] * ((s + t) - t * s);
+            const f32x4 s = co_sigmoid4(acc[rb] * (-1.4426950408889634f / 2048.0f) + bql);
+            const f32x4 t = (acc[rb] * (1.0f / 2048.0f) + bq) * s;
+            const f32x4 d = gv[rb] * (t * (s * vmone + vone) + s);
 #else
             f32x4 d;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float s = (CO_ABL & 16) ? acc[rb][i] * 1e-4f
-                                              : __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[rb][i] * (-1.4426950408889634f / 2048.0f)));
-                const float u = acc[rb][i] * (1.0f - s);
-                d[i] = (gv[rb][i] * s) * __builtin_fmaf(u, 1.0f / 2048.0f, 1.0f);
+                const float q = __builtin_fmaf(acc[rb][i], 1.0f / 2048.0f, bq[i]);
+                const float s = (CO_ABL & 16) ? q * 0.25f : __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(q * -1.4426950408889634f));
+                d[i] = (gv[rb][i] * s) * __builtin_fmaf(q, 1.0f - s, 1.0f);
             }
 #endif
             unsigned h0, l0, h1, l1;
@@ -379,7 +383,7 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
         if (wave < 4) __builtin_amdgcn_s_setprio(2);
 #endif
         // ---- behind the barrier: the matrix part (GEMM 2 + the weight gradient: 48 MFMAs)
-        f32x4 x2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 x2[2];
         auto matrix_part = [&]() {
             // GEMM 2: 2^11 G ds1 = 2^11 W2^T (G dq) for the wave's 16 s1 features
             co_gemm(D, w2h, w2l, x2, n16, q4);
@@ -387,16 +391,18 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
             const int r0 = 4 * q4 + (n16 >> 2), c0 = 4 * (n16 & 3);
             f16x8 ah[2], al[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int f = 32 * wr + 16 * a + c0;
+            for (int a = 0; a < 2; ++a) {                                     // accw[a] = row block a ^ wc: the pair's two waves start on different blocks
+                const int f = 32 * wr + 16 * (a ^ wc) + c0;
                 const u32x2 a0 = co_tr(&D[0][r0][f]), a1 = co_tr(&D[0][16 + r0][f]);
                 const u32x2 b0 = co_tr(&D[1][r0][f]), b1 = co_tr(&D[1][16 + r0][f]);
                 ah[a] = __builtin_bit_cast(f16x8, u32x4{a0[0], a0[1], a1[0], a1[1]});
                 al[a] = __builtin_bit_cast(f16x8, u32x4{b0[0], b0[1], b1[0], b1[1]});
-                float cs = co_dot_ones(a0[0], 0.f);                           // (both waves of a pair sum the same rows; wc = 0 stores)
-                cs = co_dot_ones(a0[1], cs), cs = co_dot_ones(a1[0], cs), cs = co_dot_ones(a1[1], cs);
-                cs = co_dot_ones(b0[0], cs), cs = co_dot_ones(b0[1], cs), cs = co_dot_ones(b1[0], cs), cs = co_dot_ones(b1[1], cs);
-                bsum[a] += cs;
+                if (a == 0) {                                                 // db2 = colsum(G dq) of block wc: each wave of the pair sums one block
+                    float cs = co_dot_ones(a0[0], 0.f);
+                    cs = co_dot_ones(a0[1], cs), cs = co_dot_ones(a1[0], cs), cs = co_dot_ones(a1[1], cs);
+                    cs = co_dot_ones(b0[0], cs), cs = co_dot_ones(b0[1], cs), cs = co_dot_ones(b1[0], cs), cs = co_dot_ones(b1[1], cs);
+                    bsum += cs;
+                }
             }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -520,15 +526,12 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                wout[(size_t)(32 * wr + 16 * a + co_sw(4 * q4 + i)) * 128 + 64 * wc + 16 * b + co_sw(n16)] = accw[a][b][i] * invG;
-    if (wc == 0) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            float bs = bsum[a];
-            bs += __shfl_xor(bs, 16);
-            bs += __shfl_xor(bs, 32);
-            if (q4 == 0) bpart[(size_t)blockIdx.x * 128 + 32 * wr + 16 * a + co_sw(n16)] = bs * invG;
-        }
+                wout[(size_t)(32 * wr + 16 * (a ^ wc) + co_sw(4 * q4 + i)) * 128 + 64 * wc + 16 * b + co_sw(n16)] = accw[a][b][i] * invG;
+    {
+        float bs = bsum;
+        bs += __shfl_xor(bs, 16);
+        bs += __shfl_xor(bs, 32);
+        if (q4 == 0) bpart[(size_t)blockIdx.x * 128 + 32 * wr + 16 * wc + co_sw(n16)] = bs * invG;
     }
 }
 
