@@ -25,6 +25,10 @@
 
 typedef unsigned int u32;
 
+#ifndef ES_PACKED
+#define ES_PACKED 0                     // 1: packed fp32 adds in the input production (1 + e, A + Bm; same bits) - measured SLOWER beside
+#endif                                  //    the MFMAs: 1.001 ms against 0.989 (round 6, DESIGN.md 10 rule 4 again)
+
 namespace {
 
 constexpr float R_SCALE = 2048.0f;         // every MFMA product carries 2^11 (host-scaled weight planes)
@@ -39,7 +43,12 @@ __device__ __forceinline__ f32x16 mfma_xw(const u32x4& x, const u32x4& w, const 
 template <bool L2E>
 __device__ __forceinline__ void swish_pieces(float v0, float v1, u32& hw, u32& lw) {
     const float e0 = __builtin_amdgcn_exp2f(L2E ? -v0 : -v0 * MAGNET_LOG2E), e1 = __builtin_amdgcn_exp2f(L2E ? -v1 : -v1 * MAGNET_LOG2E);
+#if ES_PACKED
+    const f32x2 d = f32x2{e0, e1} + 1.0f;                                     // (one v_pk_add_f32 for the pair: same bits, one issue slot less)
+    const float r0 = __builtin_amdgcn_rcpf(d[0]), r1 = __builtin_amdgcn_rcpf(d[1]);
+#else
     const float r0 = __builtin_amdgcn_rcpf(1.0f + e0), r1 = __builtin_amdgcn_rcpf(1.0f + e1);
+#endif
     u32 h, l;
     asm("s_nop 0\n\t"
         "v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
@@ -135,8 +144,14 @@ __global__ void __launch_bounds__(512) k_mpnn_edge_stream32(const float* __restr
     // four values of a tile's input: columns 16 ks + 8 half + 4 part + 0..3  ->  words 2 part, 2 part + 1 of both planes
     auto pieces4 = [&](int ks, int part, const f32x4& a, const f32x4& b) {
         u32 h0, l0, h1, l1;
+#if ES_PACKED
+        const f32x4 v = a + b;                                                // two v_pk_add_f32
+        swish_pieces<L2E>(v[0], v[1], h0, l0);
+        swish_pieces<L2E>(v[2], v[3], h1, l1);
+#else
         swish_pieces<L2E>(a[0] + b[0], a[1] + b[1], h0, l0);
         swish_pieces<L2E>(a[2] + b[2], a[3] + b[3], h1, l1);
+#endif
         xh[ks][2 * part] = h0, xh[ks][2 * part + 1] = h1;
         xl[ks][2 * part] = l0, xl[ks][2 * part + 1] = l1;
     };
