@@ -1044,6 +1044,41 @@ def main():
         barrier()
         t_el = max_over_ranks(time.perf_counter() - t0, dev)
         n_grad = sum(p_.numel() for p_ in tmodel.parameters())
+        # ---- the dominant kernel of the step - the fused backward of the edge block (GNN_Layer.message + mean walked back, models/mpnn.py:
+        # 73-79,46; generation 3: k_mpnn_edge_bwd_co) - timed live with HIP events on its launch stream in ONE more (untimed) step
+        ebw = None
+        if True:                                   # (every rank: the extra step contains the gradient all-reduce)
+            from magnet_amd import ops as _ops
+            lib_ = _ops.L.lib()
+            ev_, orig_ = [], lib_.magnet_mpnn_edge_bwd_w_amax_f32
+
+            def timed_bwd(*a):
+                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record()
+                rc = orig_(*a)
+                e_.record()
+                ev_.append((s_, e_))
+                return rc
+
+            _ops.L._lib.magnet_mpnn_edge_bwd_w_amax_f32 = timed_bwd
+            try:
+                train_step()
+                torch.cuda.synchronize()
+            finally:
+                _ops.L._lib.magnet_mpnn_edge_bwd_w_amax_f32 = orig_
+            if ev_ and getattr(tmodel, "_topo", None) is not None:
+                E_ = tmodel._topo.csr.E
+                ms_ = sum(s_.elapsed_time(e_) for s_, e_ in ev_) / len(ev_)
+                fl_ = 3 * 2.0 * E_ * 128 * 128                    # GEMM 1 (q = W2 s1), GEMM 2 (ds1 = W2^T dq), the weight gradient (dq^T s1)
+                gen_ = int(lib_.magnet_mpnn_edge_bwd_w_generation(-1))
+                ebw = {"kernel": {2: "k_mpnn_edge_bwd_co", 1: "k_mpnn_edge_bwd_wp", 0: "k_mpnn_edge_bwd_w"}.get(gen_, "?"),
+                       "what": "entry magnet_mpnn_edge_bwd_w_amax_f32 = the edge kernel + the reduction of its per-workgroup dW2 / db2 partials + "
+                               "the fix-up of the rows cut by tile boundaries",
+                       "launch_ms": round(ms_, 4), "launches_timed": len(ev_), "flops_per_launch": fl_, "bound": "mfma",
+                       "achieved": round(fl_ / (ms_ * 1e-3) / 1e12, 2), "peak": round(MFMA_BF16_PEAK_TFLOPS / 3, 1), "unit": "TFLOP/s",
+                       "frac": round(fl_ / (ms_ * 1e-3) / 1e12 / (MFMA_BF16_PEAK_TFLOPS / 3), 4),
+                       "algorithmic_hbm_bytes": E_ * 128 * 4 + 4 * tmodel._topo.csr.N * 128 * 4 + 2 * E_ * 4,
+                       "share_of_step": round(len(ev_) * ms_ / (t_el / args.train_steps * 1e3), 3)}
         # DDP invariant: identical parameters on every rank after the steps (same init, same averaged gradient, same Adam)
         psum = float(sum(p_.detach().double().abs().sum() for p_ in tmodel.parameters()))
         dist_info["param_abs_sum_by_rank_after_training"] = gather_f64(psum)
@@ -1054,7 +1089,7 @@ def main():
                  "allreduce_bytes": 4 * n_grad,
                  "loss_first_last": [round(first, 6), round(float(last.detach()), 6)],
                  "widened_to_bf16x6": __import__("magnet_amd.packing", fromlist=["wide"]).wide(),
-                 "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
+                 "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2), "edge_backward": ebw}
         del tmodel, opt, last, train_step
         __import__("magnet_amd.packing", fromlist=["narrow"]).narrow()   # (a leg that left the fp16 range must not hand the NEXT one the wider split)
         import gc

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # no single test may hold the box: a collective mismatch in a multi-rank subprocess test once hung the GPU suite for 40 minutes
+    # (pytest-timeout is in the image; without it this is a no-op)
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 1200
 
 
 @pytest.fixture(scope="session")
