@@ -690,7 +690,7 @@ extern "C" int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, 
             ncu = prop.multiProcessorCount;
         }
         const int tiles = (n_edges + 31) / 32;
-        const int grid = g_ebw_generation == 2 ? min(tiles, ncu) : min((tiles + 3) / 4, ncu);
+        const int grid = (g_ebw_generation == 2 && (size_t)n_nodes * 512 < ((size_t)1 << 32)) ? min(tiles, ncu) : min((tiles + 3) / 4, ncu);
         float* wpart = workspace;
         float* bpart = wpart + (size_t)ncu * 128 * 128;
         float* amax = bpart + (size_t)ncu * 128;
@@ -705,10 +705,12 @@ extern "C" int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, 
         const u32x4* w = reinterpret_cast<const u32x4*>(w2_f16);
         const u32x4* wT = reinterpret_cast<const u32x4*>(w2t_f16);
         float* pscr = bpart + (size_t)ncu * 128 + EBW_AMAX_BLOCKS;
-        if (g_ebw_generation == 2)
+        // (generation 3 addresses the node rows with 32-bit byte offsets: graphs of 8 M nodes and more take generation 2)
+        const bool co_ok = (size_t)n_nodes * 512 < ((size_t)1 << 32);
+        if (g_ebw_generation == 2 && co_ok)
             magnet_launch_edge_bwd_co(A, Bm, dagg, src, tgt, rowptr, n_edges, w2_f16, w2t_f16, b2, dp, dA, partials, amax, nab, wpart, bpart,
                                       grid, stream);
-        else if (g_ebw_generation == 1)
+        else if (g_ebw_generation >= 1)
             magnet_launch_edge_bwd_wp(A, Bm, dagg, src, tgt, rowptr, n_edges, w2_f16, w2t_f16, b2, dp, dA, partials, amax, nab, wpart, bpart,
                                       pscr, grid, stream);
         else

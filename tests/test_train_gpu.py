@@ -182,17 +182,33 @@ def test_fused_edge_backward_matches_autograd():
     assert rel_l2(s1, sw(A64[t] + B64[s]).detach()) < 1e-6
 
 
-@pytest.mark.parametrize("case", ["random", "one_tile", "many_tiles_per_wave", "tiny_gradients", "accumulate"])
-def test_fused_edge_backward_with_weight_gradient_matches_autograd(case):
+@pytest.mark.parametrize("generation", [2, 1])
+@pytest.mark.parametrize("case", ["random", "one_tile", "many_tiles_per_wave", "tiny_gradients", "accumulate", "rows_over_many_tiles", "empty_rows"])
+def test_fused_edge_backward_with_weight_gradient_matches_autograd(case, generation):
     """magnet_mpnn_edge_bwd_w_f32 (dW2 / db2 formed inside the kernel, s1 / dq never written) against torch autograd (fp64) of the
     same edge block and against the kernel that writes s1 / dq (bit-identical dp and dA: the data path is the same code)."""
     from magnet_amd import ops
     from magnet_amd.packing import pack
     torch.manual_seed(11)
-    N, E = {"one_tile": (9, 20), "many_tiles_per_wave": (3000, 150001)}.get(case, (500, 7001))
+    # (generation 2 = k_mpnn_edge_bwd_co, the default; 1 = k_mpnn_edge_bwd_wp.  rows_over_many_tiles: rows of 100 - 300 edges - whole
+    #  32-edge tiles inside one row; empty_rows: two thirds of the rows have no edge at all)
+    from magnet_amd import _lib
+    N, E = {"one_tile": (9, 20), "many_tiles_per_wave": (3000, 150001), "rows_over_many_tiles": (60, 12001)}.get(case, (500, 7001))
     scale = 1e-12 if case == "tiny_gradients" else 1e-7
     src = torch.randint(0, N, (E,), dtype=torch.int32, device="cuda")
     tgt = torch.randint(0, max(N - 3, 1), (E,), dtype=torch.int32, device="cuda")
+    if case == "empty_rows":
+        tgt = tgt - tgt % 3
+    was = _lib.lib().magnet_mpnn_edge_bwd_w_generation(generation)
+    try:
+        _edge_backward_case(case, N, E, scale, src, tgt)
+    finally:
+        _lib.lib().magnet_mpnn_edge_bwd_w_generation(was)
+
+
+def _edge_backward_case(case, N, E, scale, src, tgt):
+    from magnet_amd import ops
+    from magnet_amd.packing import pack
     csr = ops.csr_by_target(src, tgt, N)
     A, Bm = torch.randn(N, 128, device="cuda"), torch.randn(N, 128, device="cuda")
     W2 = torch.randn(128, 128, device="cuda") / 11
