@@ -193,10 +193,15 @@ class TrainStepGraph:
         e = self._entries.get(key)
         if e is not None:
             for k in topo:                                     # the capture bakes the graph topology in: same coordinates?
-                if k in batch and not (e["seen"].get(k) is batch[k] or bool(torch.equal(e["static"][k], batch[k].to(e["static"][k].dtype)))):
+                if k not in batch:
+                    continue
+                seen = e["seen"].get(k)                        # (tensor kept alive, its identity - address, shape, version - when compared)
+                if seen is not None and seen[0] is batch[k] and seen[1] == _ident(batch[k]):
+                    continue
+                if not bool(torch.equal(e["static"][k], batch[k].to(e["static"][k].dtype))):
                     e = None
                     break
-                e["seen"][k] = batch[k]
+                e["seen"][k] = (batch[k], _ident(batch[k]))
         if e is None:
             e = self._capture(batch, key, topo)
             if e is None:
@@ -249,6 +254,12 @@ class TrainStepGraph:
             torch.cuda.synchronize()
             torch.set_rng_state(state)                         # (the warm-up steps are not steps of the run)
             self.opt.zero_grad()
+            from .optim import flat_gradient
+            if flat_gradient([p for p in self.model.parameters() if p.requires_grad]) is None:
+                # the replay ADDS into the gradient tensors the capture saw: they must be the optimizer's persistent flat views
+                # (FusedAdam.zero_grad; MAGNET_FLAT_GRADS=0 or a foreign optimizer set .grad to None every step)
+                self._bad.add(key)
+                return None
             if hasattr(self.model, "_weights_changed"):        # the captured forward must RE-PACK the weights (in place, from the parameters'
                 self.model._weights_changed()                  # current values): every replay follows an optimizer step
             graph = torch.cuda.CUDAGraph()
@@ -273,6 +284,7 @@ class TrainStepGraph:
             _holders.pop()
         if len(self._entries) >= self.max_entries:
             self._entries.pop(next(iter(self._entries)))
-        e = {"graph": graph, "static": static, "loss": loss.detach(), "keep": keep, "draws": draws, "seen": {k: batch[k] for k in topo if k in batch}}
+        e = {"graph": graph, "static": static, "loss": loss.detach(), "keep": keep, "draws": draws,
+             "seen": {k: (batch[k], _ident(batch[k])) for k in topo if k in batch}}
         self._entries[key] = e
         return e

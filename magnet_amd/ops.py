@@ -837,6 +837,9 @@ _DEV_NAMES = ("mpnn_edge32t", "mpnn_edge_ws", "RowTiles", "row_tiles", "mpnn_edg
 def __getattr__(name):
     """the development library's wrappers under their old names (scripts/dev, scripts/bench_edge*.py): magnet_amd/dev_ops.py"""
     if name in _DEV_NAMES:
-        from . import dev_ops
+        try:
+            from . import dev_ops
+        except ImportError as e:                    # (hasattr(ops, ...) must answer False with the product library, not raise)
+            raise AttributeError(str(e)) from None
         return getattr(dev_ops, name)
     raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
