@@ -210,8 +210,12 @@ def _pair(tag, teacher_forcing):
     return name, hp, batch, oracle, model.cuda().train()
 
 
-@pytest.mark.parametrize("teacher_forcing", [False, True])
-@pytest.mark.parametrize("tag", ["magnet_gnn_tiny", "magnet_cnn_1d", "magnet_cnn_2d"])
+@pytest.mark.parametrize("tag,teacher_forcing", [("magnet_gnn_tiny", False), ("magnet_gnn_tiny", True), ("magnet_cnn_1d", False),
+                                                 ("magnet_cnn_1d", True), ("magnet_cnn_2d", False), ("magnet_cnn_2d", True),
+                                                 # the shipped hyper-parameters (128-wide chains, 5 / 10 hops, 16 residual blocks): the backward kernels
+                                                 # of the production shapes - one-kernel Linear backward, first Linear at source rows, x0-free tape
+                                                 ("magnet_gnn_full", False), ("magnet_gnn_c5_reduced", False), ("magnet_cnn_1d_shipped", True),
+                                                 ("magnet_cnn_2d_shipped", False)])
 def test_every_parameter_gradient_against_mask_synchronised_fp64_autograd(tag, teacher_forcing):
     name, hp, batch, oracle, model = _pair(tag, teacher_forcing)
     cb = {k: v.cuda() for k, v in batch.items()}
