@@ -809,6 +809,44 @@ def test_mpnn_training_gradients_other_time_windows(tw, dim):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("teacher_forcing", [False, True])
+def test_mpnn_2d_training_gradients_on_a_mesh_of_the_benchmark_kind(teacher_forcing):
+    """The golden mpnn_2d fixture is a 12 x 12 mesh: small-graph kernels.  Here the paths the benchmark's training step takes - the
+    stream-tiled forward edge kernel (rows of 33 edges), the fused backward of the edge block (k_mpnn_edge_bwd_co: rows over two and
+    three tiles, the by-source sum of dp), the one-kernel Linear backward of the node update (>= 4096 rows) - on a 72 x 72 mesh, B = 2:
+    every parameter gradient of training_step against fp64 autograd through the oracle (models/mpnn_2d.py:254-297)."""
+    import types
+    from magnet_amd.models.factory import FACTORY
+    from oracle import models as O
+    from oracle.weightgen import fill_state_dict
+    hp = types.SimpleNamespace(lr=1e-3, weight_decay=0.0, factor=0.3, step_size=50, loss="l2", hidden_features=128, hidden_layer=5,
+                               time_window=10, teacher_forcing=teacher_forcing, neighbors=4)
+    W, B, nt = 72, 2, 30
+    g = torch.Generator().manual_seed(72)
+    lin = torch.linspace(0, 1, W)
+    xy = torch.stack(torch.meshgrid(lin, lin, indexing="ij"), -1).reshape(-1, 2)
+    # smooth fields (a rollout on noise saturates nothing but gives gradients of 1e-9: keep them at the size a real step has)
+    k = torch.randn(B, 1, 4, generator=g)
+    u = torch.sin(6.28 * (xy[None, :, :1] * k[..., :1] + xy[None, :, 1:] * k[..., 1:2]) + k[..., 2:3]) + 0.1 * torch.randn(B, W * W, 1, generator=g)
+    u = u * torch.linspace(1.0, 0.7, nt)[None, None, :] + 0.05 * torch.randn(B, W * W, nt, generator=g)
+    batch = {"u": u.float(), "x": xy[None].repeat(B, 1, 1), "t": torch.linspace(0, 1, nt)[None].repeat(B, 1)}
+    oracle = O.build("mpnn_2d", hp)
+    fill_state_dict(oracle, 72)
+    model = FACTORY["mpnn_2d"](hp)
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda().train()
+    want_loss, want = oracle_grads(oracle, batch, teacher_forcing, hp.loss)
+    loss = model.training_step({k_: v.cuda() for k_, v in batch.items()}, 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - want_loss) < 1e-5 * max(1.0, abs(want_loss))
+    errs = {n: rel_l2(p.grad, want[n]) for n, p in model.named_parameters()}
+    worst = max(errs, key=errs.get)
+    print(f"[mpnn_2d 72 x 72, tf={teacher_forcing}] worst parameter gradient {worst}: {errs[worst]:.2e}")
+    bad = {n: e for n, e in errs.items() if not e < GRAD_TOL}
+    assert not bad, bad
+    assert model._topo.csr.E > 30 * B * W * W and model._topo.csr.N == B * W * W      # (rows of ~33 edges: the stream / co-operative kernels ran)
+
+
 def test_differentiable_mlp_shared_rows_source():
     """a dense source shared by ``rdiv`` consecutive rows (row r reads t[r // rdiv]): forward and the fixed-size segment sum
     of its backward, vs torch autograd"""
