@@ -24,6 +24,9 @@
 // its SIMDs' issue slots (generation 2: 50 %) - DESIGN.md 15.1 has the measurements.
 // Arithmetic as generation 2: fp16 split with one accumulator (W planes 2^11 hw, 2^11 lw), G = one power of two per launch for dq (serves
 // GEMM 2 and the weight gradient), fixed summation orders (bit-identical repeats).
+// (the plane words this kernel forms in inline asm go to LDS, never straight into an MFMA: the two wait states that MAGNET_MIX_TAIL appends
+//  for hipcc's blind spot - DESIGN.md 10.10 - are eight wasted issue slots per tile here; hazard_check.py polices the build as always)
+#define MAGNET_MIX_TAIL ""
 #include "common.cuh"
 #include "split_single.cuh"
 
