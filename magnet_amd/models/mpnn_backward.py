@@ -130,6 +130,15 @@ def backward_call(m, tape, dout, G, ws):
     T = ops.Term
     nin = tape.node_in
     lin = lambda rows, kts, layer, y, o=4: ops.mlp(rows, kts, [layer], nl=1, ht=o, ot=o, act=ops.ACT_NONE, y=y)  # noqa: E731
+    # ... the same with y = res + x W in the GEMM's own epilogue (no separate add pass over [N, width]) where that instantiation exists
+    def lin_add(rows, kts, layer, acc, tmp, o=4):
+        """acc += x W"""
+        try:
+            ops.mlp(rows, kts, [layer], nl=1, ht=o, ot=o, act=ops.ACT_NONE, y=acc, epi=ops.EPI_STORE_RES, res=acc)
+        except NotImplementedError:
+            lin(rows, kts, layer, tmp, o)
+            ops.axpy(acc, tmp, 1.0, out=acc)
+        return acc
     new = lambda: torch.empty(N, H, device=dev, dtype=torch.float32)  # noqa: E731
     enew = lambda: torch.empty(max(E, 1), H, device=dev, dtype=torch.float32)  # noqa: E731
 
@@ -215,10 +224,8 @@ def backward_call(m, tape, dout, G, ws):
         ops.wgrad(dA, nin, 0, kin, g.w1a, H, None, ws)
         ops.wgrad(dBm, tp.h_in, 0, H, g.w1b, 0, None, ws)
         ops.wgrad(dBm, nin, 0, kin, g.w1b, H, None, ws)
-        lin(N, ops.ktiles(T(dz1, H), T(dA, H), T(dBm, H)), qb.dh, t1)
-        dh = ops.axpy(dg, t1, 1.0, out=dg)
-        lin(N, ops.ktiles(T(dA, H), T(dBm, H)), qb.dnin, dnin_l, o_k)
-        ops.axpy(dnin, dnin_l, 1.0, out=dnin)
+        dh = lin_add(N, ops.ktiles(T(dz1, H), T(dA, H), T(dBm, H)), qb.dh, dg, t1)
+        lin_add(N, ops.ktiles(T(dA, H), T(dBm, H)), qb.dnin, dnin, dnin_l, o_k)
 
     # ---- embedding MLP                                                                mpnn.py:131-136
     lin(N, ops.ktiles(T(nin, kin)), P.emb[0], z1)
@@ -230,8 +237,7 @@ def backward_call(m, tape, dout, G, ws):
     lin(N, ops.ktiles(T(dz2, H)), Q.e1t, t2)
     dz1 = ops.swish_bwd(t2, z1, t2)
     ops.wgrad(dz1, nin, 0, kin, G.e0, 0, G.be0, ws)
-    lin(N, ops.ktiles(T(dz1, H)), Q.e0t, dnin_l, o_k)
-    ops.axpy(dnin, dnin_l, 1.0, out=dnin)
+    lin_add(N, ops.ktiles(T(dz1, H)), Q.e0t, dnin, dnin_l, o_k)
 
     du = torch.empty(N, tw, device=dev, dtype=torch.float32)
     ops.copy_cols(dnin, 0, du, 0, tw)
