@@ -16,6 +16,17 @@
 #ifndef MAGNET_BIAS_LDS
 #define MAGNET_BIAS_LDS 1
 #endif
+// Tape of a training forward (args.hid[]): 1 = the activations a layer hands on are stored tile by tile inside the NEXT layer's k loop,
+// four 16-byte stores per k tile behind the weight request, and the loop's waits are counted past them; 0 = all 16 stores of a layer
+// at its end, drained by the next k tile's vmcnt(0) (rounds 3-5).
+#ifndef MLP_TAPE_SPREAD
+#define MLP_TAPE_SPREAD 1
+#endif
+// ... 1 = and as whole 128-byte lines through a wave-private LDS tile (eight rows x one line per store instruction instead of 32 rows x
+// a quarter line)
+#ifndef MLP_TAPE_LINES
+#define MLP_TAPE_LINES 1
+#endif
 
 template <int A, int B>
 struct MaxI { static constexpr int v = A > B ? A : B; };
@@ -34,6 +45,14 @@ __device__ __forceinline__ void dma_chunk(const f32x4* __restrict__ gw, u32x4* l
         __builtin_amdgcn_global_load_lds(g + p * 64 + lane, l + p * 64, 16, 0, 0);
     }
 }
+// The workgroup barrier of the weight ring.  __syncthreads() is a fence + s_barrier and hipcc drains EVERY outstanding vector memory
+// operation in front of it (s_waitcnt vmcnt(0): it cannot know which LDS-DMA loads the barrier is to publish) - which turns every counted
+// wait of this file into vmcnt(0) and exposes the full latency of the tape's stores.  What the barrier has to order is (a) this wave's
+// DMA pieces of the chunk about to be read - the counted wait right before it - and (b) this wave's LDS traffic (bias staging, the
+// fragment reads of the slot about to be overwritten): lgkmcnt(0).
+__device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // wait until at most the PW loads of the youngest chunk are outstanding
 template <int NPIECES>
 __device__ __forceinline__ void wait_all_but_one_chunk() {
@@ -197,7 +216,10 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
     // 10.10 - nothing to do with the biases) and ships it.  MAGNET_BIAS_LDS=0: biases from global memory (the variants of the
     // root-cause hunt, profiles/r3/bias_lds_root_cause.txt, lived here under values 2 .. 10)
     constexpr int BIAS_F = (NL > 1 ? NL - 1 : 1) * NTMAX * 32;
-    __shared__ __attribute__((aligned(16))) u32x4 smem[SMEM_U4 + BIAS_F / 4];
+    // (tape, MLP_TAPE_LINES: one 32 x 32 transposition tile per wave behind the biases - store_tile_lines)
+    constexpr bool TAPE_LINES = MLP_TAPE_LINES && MLP_TAPE_SPREAD && NL > 1 && HT == 4;
+    constexpr int TL_F = TAPE_LINES ? 32 * NH_TS : 0;
+    __shared__ __attribute__((aligned(16))) u32x4 smem[SMEM_U4 + BIAS_F / 4 + 4 * TL_F / 4];
     float* sbias = reinterpret_cast<float*>(smem + SMEM_U4);
     if (NL > 1) {
         for (int t = threadIdx.x; t < BIAS_F; t += 256) {
@@ -213,6 +235,9 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
+#if MAGNET_BIAS_LDS
+    float* tl = sbias + BIAS_F + wave * TL_F;
+#endif
     // XCD-aware row order: workgroups are dispatched round-robin over the 8 XCDs (each with its own L2); consecutive row
     // tiles - target-sorted edges gather neighbouring rows - go to the same XCD
     const int g8 = gridDim.x / 8;
@@ -221,6 +246,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
     const int row_raw = tile * 32 + (lane & 31);
     const bool row_ok = row_raw < a.M;
     const int row = row_ok ? row_raw : (a.M - 1);
+    const bool any_ok = tile * 32 + 32 <= a.M;          // (uniform) a whole tile: every row-masked store of the wave is an instruction that issues
     TileMeta md;                                        // CSR-mean epilogue: requested now, hidden behind the GEMMs
     if (EPI == EPI_SEGMEAN) md = tile_meta(tile, a.M, a.tgt, a.rowptr, lane & 31);
 
@@ -271,7 +297,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                 else if (NL > 1) wait_all_but_one_chunk<NT1 * PPN>();
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 TRACE(11)
-                if (!(abl & 8)) __syncthreads();
+                if (!(abl & 8)) ring_barrier();
                 TRACE(12)
                 const f32x16 x = ktile_finish(a.kt[kt], xr);               // x tile kt has landed: scales / sum of the sources now
                 if (pre_init && kt == 0) {
@@ -310,7 +336,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                     h0[t < HT ? t : 0] = acc[t];
                     if (TRACK_SAT) track_abs_max(acc[t], sat);
                 }
-                if (a.hid[0]) store_rows<HT, 0>(h0, a.hid[0], HT * 32, HT * 32, nullptr, 0, row, row_ok, half);
+                if (!MLP_TAPE_SPREAD && a.hid[0]) store_rows<HT, 0>(h0, a.hid[0], HT * 32, HT * 32, nullptr, 0, row, row_ok, half);
             }
         }
         // ---------------- layers 1 .. NL-1, activations in registers (fully unrolled: static register indices)
@@ -342,11 +368,24 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                 const bool has_next = (kt + 1 < HT) || (l + 1 < NL);
                 const bool next_is_last_layer = (kt + 1 < HT) ? last : (l + 1 == NL - 1);
                 TRACE(20)
-                if (!has_next || DIST == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (next_is_last_layer) wait_all_but_one_chunk<OT * PPN>();
-                else wait_all_but_one_chunk<HT * PPN>();
+                // (tape, MLP_TAPE_SPREAD: the iteration before this one issued the four stores of one 32-column tile of its layer's input
+                // BEHIND the request of this chunk - memory operations complete in order, so vmcnt(4) says the chunk has landed and
+                // leaves those stores in flight for a whole k tile instead of exposing the write latency to every wave)
+                const bool prev_stored = MLP_TAPE_SPREAD && any_ok &&
+                                         (kt > 0 ? a.hid[l - 1] != nullptr : (l >= 2 && a.hid[l >= 2 ? l - 2 : 0] != nullptr));
+                constexpr int PWH = (HT * PPN + 3) / 4, PWO = (OT * PPN + 3) / 4;      // loads per wave of a chunk (dma_chunk)
+                if (!has_next || DIST == 1) {
+                    if (prev_stored) wait_vm<4>();
+                    else wait_vm<0>();
+                } else if (next_is_last_layer) {
+                    if (prev_stored) wait_vm<PWO + 4>();
+                    else wait_vm<PWO>();
+                } else {
+                    if (prev_stored) wait_vm<PWH + 4>();
+                    else wait_vm<PWH>();
+                }
                 TRACE(21)
-                if (!(abl & 8)) __syncthreads();
+                if (!(abl & 8)) ring_barrier();
                 TRACE(22)
                 // chunk c+2
                 if (!(abl & 2)) {
@@ -359,6 +398,13 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                         if (l + 1 == NL - 1) dma_chunk<OT * PPN>(a.layer[l + 1 < NL ? l + 1 : l].w + (size_t)k3 * OT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
                         else dma_chunk<HT * PPN>(a.layer[l + 1 < NL ? l + 1 : l].w + (size_t)k3 * HT * PPN * 64, wbuf + ((c + DIST) % NBUF) * CH, wave, lane);
                     }
+                }
+                if (MLP_TAPE_SPREAD && a.hid[l - 1]) {
+#if MAGNET_BIAS_LDS
+                    if constexpr (TAPE_LINES) store_tile_lines(src0 ? h0[kt] : h1[kt], tl, a.hid[l - 1], kt * 32, (long)tile * 32, a.M, lane);
+                    else
+#endif
+                    store_ktile(src0 ? h0[kt] : h1[kt], a.hid[l - 1], HT * 32, kt * 32, row, row_ok, half);
                 }
                 TRACE(23)
                 if (abl & 1) {
@@ -377,13 +423,21 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                     else apply_act<ACT>(h0[t]);
                     if (TRACK_SAT) track_abs_max(src0 ? h1[t] : h0[t], sat);
                 }
-                if (a.hid[l]) {
+                if (!MLP_TAPE_SPREAD && a.hid[l]) {
                     if (src0) store_rows<HT, 0>(h1, a.hid[l], HT * 32, HT * 32, nullptr, 0, row, row_ok, half);
                     else store_rows<HT, 0>(h0, a.hid[l], HT * 32, HT * 32, nullptr, 0, row, row_ok, half);
                 }
             }
         }
-        if (NL > 1 && a.hid[NL - 1]) store_rows<OT, 0>(out, a.hid[NL - 1], OT * 32, OT * 32, nullptr, 0, row, row_ok, half);
+        if (NL > 1 && a.hid[NL - 1]) {
+#if MAGNET_BIAS_LDS
+            if constexpr (TAPE_LINES && OT == 4) {
+#pragma unroll
+                for (int t = 0; t < OT; ++t) store_tile_lines(out[t], tl, a.hid[NL - 1], t * 32, (long)tile * 32, a.M, lane);
+            } else
+#endif
+            store_rows<OT, 0>(out, a.hid[NL - 1], OT * 32, OT * 32, nullptr, 0, row, row_ok, half);
+        }
         if (LAST_ACT) {
     #pragma unroll
             for (int t = 0; t < OT; ++t) apply_act<ACT>(out[t]);

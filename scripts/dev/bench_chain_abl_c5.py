@@ -28,8 +28,12 @@ PQ = torch.randn(2, N, H, device="cuda")
 kts = ops.ktiles(ops.Term(e0, D))
 
 
+TAPE = "--tape" in sys.argv          # the training forward: four hidden activations + the pre-LayerNorm row written per edge (2 560 B)
+hid = [torch.empty(E, H, device="cuda") for _ in range(5)] if TAPE else None
+
+
 def run():
-    run_mlp(E, kts, pk, agg, epi=ops.EPI_SEGMEAN, tgt=tgt, rowptr=rowptr, partials=partials, pre=[(PQ[0], tgt), (PQ[1], src)])
+    run_mlp(E, kts, pk, agg, epi=ops.EPI_SEGMEAN, tgt=tgt, rowptr=rowptr, partials=partials, pre=[(PQ[0], tgt), (PQ[1], src)], hid=hid)
 
 
 def timeit(reps=10):
@@ -48,7 +52,7 @@ flops = 2.0 * E * (D * H + 3 * H * H + H * D)
 if not _lib.DEV:                      # a compile-time ablation build (-DMLP_ABL_STATIC=..., MAGNET_LIB_PATH) or the product library
     for rnd in range(3):
         ms = timeit()
-        print(f"{os.path.basename(_lib.LIB_PATH)}: {ms:.4f} ms  {flops / ms / 1e9:.0f} TFLOP/s fp32-equivalent = {flops / ms / 1e9 / 833:.3f} of 833")
+        print(f"{os.path.basename(_lib.LIB_PATH)}{' tape' if TAPE else ''}: {ms:.4f} ms  {flops / ms / 1e9:.0f} TFLOP/s fp32-equivalent = {flops / ms / 1e9 / 833:.3f} of 833")
     sys.exit(0)
 names = {0: "as shipped", 8: "no barriers", 2: "no weight DMA", 10: "no barriers, no weight DMA", 1: "no MFMAs", 4: "no epilogue", 16: "no input loads",
          31: "everything off"}
