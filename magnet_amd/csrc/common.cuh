@@ -629,6 +629,7 @@ __device__ __forceinline__ void store_rows(const f32x16 (&v)[NT], float* __restr
 // (used by the node kernels of mlp_bf16_kernels.hip and the fused edge backward)
 // One 32-row x 32-column tile from the accumulator layout (lane = row, 16 B pieces at a 512 B stride: 32 quarter lines per store
 // instruction) through a wave-private LDS tile to whole 128-byte lines (lane l -> row 8 it + l / 8, 16 B piece l % 8)
+template <int LDY = 128>
 __device__ __forceinline__ void store_tile_lines(const f32x16& v, float* __restrict__ tl, float* __restrict__ y, int col0, long row0,
                                                  long n, int lane) {
     const int j = lane & 31, half = lane >> 5;
@@ -641,7 +642,7 @@ __device__ __forceinline__ void store_tile_lines(const f32x16& v, float* __restr
     for (int it = 0; it < 4; ++it) {
         const int r = 8 * it + (lane >> 3);
         const f32x4 t = *reinterpret_cast<const f32x4*>(tl + r * NH_TS + 4 * (lane & 7));
-        if (row0 + r < n) *reinterpret_cast<f32x4*>(y + (row0 + r) * 128 + col0 + 4 * (lane & 7)) = t;
+        if (row0 + r < n) *reinterpret_cast<f32x4*>(y + (row0 + r) * LDY + col0 + 4 * (lane & 7)) = t;
     }
 }
 

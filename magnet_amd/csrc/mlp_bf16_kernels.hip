@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
     // root-cause hunt, profiles/r3/bias_lds_root_cause.txt, lived here under values 2 .. 10)
     constexpr int BIAS_F = (NL > 1 ? NL - 1 : 1) * NTMAX * 32;
     // (tape, MLP_TAPE_LINES: one 32 x 32 transposition tile per wave behind the biases - store_tile_lines)
-    constexpr bool TAPE_LINES = MLP_TAPE_LINES && MLP_TAPE_SPREAD && NL > 1 && HT == 4;
+    constexpr bool TAPE_LINES = MLP_TAPE_LINES && MLP_TAPE_SPREAD && NL > 1;
     constexpr int TL_F = TAPE_LINES ? 32 * NH_TS : 0;
     __shared__ __attribute__((aligned(16))) u32x4 smem[SMEM_U4 + BIAS_F / 4 + 4 * TL_F / 4];
     float* sbias = reinterpret_cast<float*>(smem + SMEM_U4);
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
                 }
                 if (MLP_TAPE_SPREAD && a.hid[l - 1]) {
 #if MAGNET_BIAS_LDS
-                    if constexpr (TAPE_LINES) store_tile_lines(src0 ? h0[kt] : h1[kt], tl, a.hid[l - 1], kt * 32, (long)tile * 32, a.M, lane);
+                    if constexpr (TAPE_LINES) store_tile_lines<HT * 32>(src0 ? h0[kt] : h1[kt], tl, a.hid[l - 1], kt * 32, (long)tile * 32, a.M, lane);
                     else
 #endif
                     store_ktile(src0 ? h0[kt] : h1[kt], a.hid[l - 1], HT * 32, kt * 32, row, row_ok, half);
@@ -431,9 +431,9 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
         }
         if (NL > 1 && a.hid[NL - 1]) {
 #if MAGNET_BIAS_LDS
-            if constexpr (TAPE_LINES && OT == 4) {
+            if constexpr (TAPE_LINES) {
 #pragma unroll
-                for (int t = 0; t < OT; ++t) store_tile_lines(out[t], tl, a.hid[NL - 1], t * 32, (long)tile * 32, a.M, lane);
+                for (int t = 0; t < OT; ++t) store_tile_lines<OT * 32>(out[t], tl, a.hid[NL - 1], t * 32, (long)tile * 32, a.M, lane);
             } else
 #endif
             store_rows<OT, 0>(out, a.hid[NL - 1], OT * 32, OT * 32, nullptr, 0, row, row_ok, half);
