@@ -595,6 +595,33 @@ __global__ void __launch_bounds__(256) k_segsum_fixup(const int32_t* __restrict_
     }
 }
 
+// generation 3 (k_mpnn_edge_bwd_co carries the open row from tile to tile): only the rows cut by a WORKGROUP's range of tpw tiles have
+// pieces - partials[range][0] = the range's part of the row that entered it, [range][1] = of the row that leaves it (and did not enter
+// it).  The wave of the first boundary a row crosses adds them up in range order; every thread also zeroes one row without edges.
+__global__ void __launch_bounds__(256) k_segsum_fixup_wg(const int32_t* __restrict__ rowptr, int N, const int32_t* __restrict__ tgt, int E,
+                                                         int tpw, int nwg, const float* __restrict__ partials, float* __restrict__ out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < N && rowptr[r] == rowptr[r + 1]) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < 128; f += 4) *reinterpret_cast<f32x4*>(out + (size_t)r * 128 + f) = z;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave + 1;                                 // the boundary in front of range b
+    if (b >= nwg) return;
+    const long eb = (long)b * tpw * 32;
+    if (eb >= E) return;
+    const int t = tgt[eb];
+    const int s = rowptr[t], e = rowptr[t + 1];
+    if (s >= eb) return;                                                     // the row starts with the range
+    const int ws = (s >> 5) / tpw, we = ((e - 1) >> 5) / tpw;
+    if (ws != b - 1) return;                                                 // (a row longer than a range: its first boundary does the work)
+    for (int f = lane; f < 128; f += 64) {
+        float acc = partials[((size_t)ws * 2 + 1) * 128 + f];
+        for (int w = ws + 1; w <= we; ++w) acc += partials[((size_t)w * 2 + 0) * 128 + f];
+        out[(size_t)t * 128 + f] = acc;
+    }
+}
+
 // w2_f16 / w2t_f16: fp16 planes of W2 and of W2^T (magnet_amd/packing.py:pack_linear_fp16x2); partials: ceil(E/32)*2*128
 // floats.  s1, dq, dp: [E][128]; dA: [n_nodes][128] (every row is written).
 extern "C" int magnet_mpnn_edge_bwd_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src,
@@ -717,6 +744,12 @@ extern "C" int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, 
             hipLaunchKernelGGL(k_mpnn_edge_bwd_w, dim3(grid), dim3(256), 0, s, A, Bm, dagg, src, tgt, rowptr, n_edges, w, wT, b2, dp, dA,
                                partials, amax, nab, wpart, bpart);
         magnet_launch_reduce_partials2(wpart, 128L * 128, dW2, bpart, 128L, db2, grid, 1.0f, accumulate, stream);
+        if (g_ebw_generation == 2 && co_ok) {
+            const int tpw = (tiles + grid - 1) / grid;
+            hipLaunchKernelGGL(k_segsum_fixup_wg, dim3(max((n_nodes + 255) / 256, (grid + 2) / 4)), dim3(256), 0, s, rowptr, n_nodes, tgt,
+                               n_edges, tpw, grid, partials, dA);
+            return (int)hipGetLastError();
+        }
     }
     hipLaunchKernelGGL(k_segsum_fixup, dim3((n_nodes + 3) / 4), dim3(256), 0, s, rowptr, n_nodes, partials, dA);
     return (int)hipGetLastError();

@@ -299,6 +299,11 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
     // the barriers ~2 500 cycles late and the older half waits there (trace: profiles/r6/edge_bwd_co_trace_v1.txt) - static priority 1
     if (wave >= 4) __builtin_amdgcn_s_setprio(CO_YOUNG_PRIO);
 #endif
+    // the sum of the row that is open at a tile's end travels to the next tile in registers (lane 15 of every 16-lane row holds it behind
+    // the scan); only the rows cut by the WORKGROUP's range go through `partials` ([workgroup range][2][128]: slot 0 = the range's part of
+    // the row that entered it, 1 = of the row that leaves it) and k_segsum_fixup_wg
+    const int e00 = tile0 * 32;
+    f32x4 carry = {0.f, 0.f, 0.f, 0.f};
     int k3 = 0;
     for (int step = 0; step < nsteps; ++step) {
         const int tile = tile0 + step;
@@ -441,8 +446,7 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
             }
         }
         // ---- dA[i] = sum of dp over the row's edges: segmented inclusive sums over the tile's 32 edges (edge 2 n16 + rb: in the lane first,
-        // then along the 16-lane DPP row), the last edge of every run stores - whole rows to dA, runs cut by a tile boundary to `partials`
-        // (slot 0: entered from the previous tile, 1: continues into the next; k_segsum_fixup adds them up in tile order)
+        // then along the 16-lane DPP row), the last edge of every run stores - to dA, or, rows cut by the workgroup's range, to `partials`
         {
             const int tp1 = dpp_i<DPP_SHR1, 0xF>(tB), tp2 = dpp_i<DPP_SHR2, 0xF>(tB), tp4 = dpp_i<DPP_SHR4, 0xF>(tB);
             const int tp8 = dpp_i<DPP_SHR8, 0xF>(tB);
@@ -458,7 +462,13 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
             float x00 = x2[0][0], x01 = x2[0][1], x02 = x2[0][2], x03 = x2[0][3];
             float x10 = x2[1][0], x11 = x2[1][1], x12 = x2[1][2], x13 = x2[1][3];
 #define CO_L4(op) op(x10) "\n\t" op(x11) "\n\t" op(x12) "\n\t" op(x13) "\n\t"
-            asm volatile("v_fmac_f32 %4, %8, %0\n\tv_fmac_f32 %5, %8, %1\n\tv_fmac_f32 %6, %8, %2\n\tv_fmac_f32 %7, %8, %3\n\t"
+            // (first: the tile's edge 0 takes what the previous tile left of its row - lane 15's sum, one lane round the 16-lane row)
+            const float mIn = (n16 == 0 && step > 0 && rsA < e0) ? 1.f : 0.f;
+            asm volatile("v_fmac_f32_dpp %0, %15, %14 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f32_dpp %1, %16, %14 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f32_dpp %2, %17, %14 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f32_dpp %3, %18, %14 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f32 %4, %8, %0\n\tv_fmac_f32 %5, %8, %1\n\tv_fmac_f32 %6, %8, %2\n\tv_fmac_f32 %7, %8, %3\n\t"
                          "v_fmac_f32_dpp %4, %4, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                          "v_fmac_f32_dpp %5, %5, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                          "v_fmac_f32_dpp %6, %6, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -481,23 +491,23 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
                          "v_fmac_f32_dpp %3, %7, %13 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                          "s_nop 1"
                          : "+v"(x00), "+v"(x01), "+v"(x02), "+v"(x03), "+v"(x10), "+v"(x11), "+v"(x12), "+v"(x13)
-                         : "v"(m01), "v"(m1), "v"(m2), "v"(m4), "v"(m8), "v"(mC));
+                         : "v"(m01), "v"(m1), "v"(m2), "v"(m4), "v"(m8), "v"(mC), "v"(mIn), "v"(carry[0]), "v"(carry[1]), "v"(carry[2]), "v"(carry[3]));
 #undef CO_L4
             x2[0] = f32x4{x00, x01, x02, x03};
             x2[1] = f32x4{x10, x11, x12, x13};
+            carry = x2[1];
             const bool endA = okA && tB != tA;
-            const bool endB = okB && (n16 == 15 || tn1 != tB);
-            float *pd = dA, *pp = partials + (size_t)tile * 256;
+            const bool openB = n16 == 15 && reB > e0 + 32;                    // the tile's last edge, and its row goes on in the next tile
+            const bool endB = okB && (n16 == 15 ? (!openB || step + 1 == nsteps) : tn1 != tB);
+            float *pd = dA, *pp = partials + (size_t)vb * 256;
             asm volatile("" : "+s"(pd), "+s"(pp));
-            if (endA) {
-                const bool complete = rsA >= e0 && reA <= e0 + 32;
-                if (complete) co_stg4(pd, (unsigned)tA * 512u + 4u * fcol, x2[0]);
-                else co_stg4(pp, (rsA < e0 ? 0u : 512u) + 4u * fcol, x2[0]);
+            if (endA) {                                                       // (edge B follows in the tile or does not exist: never open)
+                if (rsA >= e00) co_stg4(pd, (unsigned)tA * 512u + 4u * fcol, x2[0]);
+                else co_stg4(pp, 4u * fcol, x2[0]);
             }
             if (endB) {
-                const bool complete = rsB >= e0 && reB <= e0 + 32;
-                if (complete) co_stg4(pd, (unsigned)tB * 512u + 4u * fcol, x2[1]);
-                else co_stg4(pp, (rsB < e0 ? 0u : 512u) + 4u * fcol, x2[1]);
+                if (!openB && rsB >= e00) co_stg4(pd, (unsigned)tB * 512u + 4u * fcol, x2[1]);
+                else co_stg4(pp, (rsB < e00 ? 0u : 512u) + 4u * fcol, x2[1]);
             }
         }
         CO_STAMP(7);
