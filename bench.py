@@ -1073,7 +1073,7 @@ def main():
                 gen_ = int(lib_.magnet_mpnn_edge_bwd_w_generation(-1))
                 ebw = {"kernel": {2: "k_mpnn_edge_bwd_co", 1: "k_mpnn_edge_bwd_wp", 0: "k_mpnn_edge_bwd_w"}.get(gen_, "?"),
                        "what": "entry magnet_mpnn_edge_bwd_w_amax_f32 = the edge kernel + the reduction of its per-workgroup dW2 / db2 partials + "
-                               "the fix-up of the rows cut by tile boundaries",
+                               "the fix-up of the rows cut by the workgroups' tile ranges",
                        "launch_ms": round(ms_, 4), "launches_timed": len(ev_), "flops_per_launch": fl_, "bound": "mfma",
                        "achieved": round(fl_ / (ms_ * 1e-3) / 1e12, 2), "peak": round(MFMA_BF16_PEAK_TFLOPS / 3, 1), "unit": "TFLOP/s",
                        "frac": round(fl_ / (ms_ * 1e-3) / 1e12 / (MFMA_BF16_PEAK_TFLOPS / 3), 4),

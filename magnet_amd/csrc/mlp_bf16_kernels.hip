@@ -24,6 +24,10 @@
 #endif
 // ... 1 = and as whole 128-byte lines through a wave-private LDS tile (eight rows x one line per store instruction instead of 32 rows x
 // a quarter line)
+// chunks of lead of the 5-Linear chains' weight ring (experiment builds; see DIST below)
+#ifndef MLP_DIST5
+#define MLP_DIST5 1
+#endif
 #ifndef MLP_TAPE_LINES
 #define MLP_TAPE_LINES 1
 #endif
@@ -503,7 +507,7 @@ typedef void (*mlp_fn)(const MagnetMlpArgs);
 
 #define MLP_CASE(NL_, HT_, OT_, ACT_, LA_, LN_, EPI_)                                              \
     if (nl == NL_ && ht == HT_ && ot == OT_ && act == ACT_ && last_act == LA_ && ln == LN_ && epi == EPI_) \
-        fn = k_mlp_bf16<MODE, NL_, HT_, OT_, ACT_, LA_, LN_, EPI_>;
+        fn = k_mlp_bf16<MODE, NL_, HT_, OT_, ACT_, LA_, LN_, EPI_, (NL_ >= 5 ? MLP_DIST5 : 1)>;
 // the same with two chunks of lead, for launches of at most one workgroup per CU (MPNN node-level kernels of the small configs)
 #define MLP_CASE_SMALL(NL_, HT_, OT_, ACT_, LA_, LN_, EPI_)                                        \
     if (small && nl == NL_ && ht == HT_ && ot == OT_ && act == ACT_ && last_act == LA_ && ln == LN_ && epi == EPI_) \
