@@ -84,7 +84,8 @@ typedef struct {
     float* x0_out;           /* optional (NULL = off) tape outputs for a training backward (no reference counterpart: torch autograd
                               * keeps these tensors alive instead): the first Linear's assembled input rows [M][nkt*32], */
     float* hid[MAGNET_MAX_LAYERS]; /* ... hid[l], l < nl-1: layer l's output after its activation [M][ht*32]; hid[nl-1]: the last
-                              * Linear's raw output before last_act / LayerNorm [M][ot*32] */
+                              * Linear's raw output before last_act / LayerNorm [M][ot*32]; nl == 2 (split-GEMM kernels): hid[2] =
+                              * the hidden layer's PRE-activation [M][ht*32] (the MPNN update net's backward needs Swish'(z1)) */
     uint64_t x0_skip;        /* bit kt set: k tile kt of x0_out is NOT written (a backward that walks gathered k tiles back at
                               * source-row granularity never reads them) */
     int32_t* status;         /* fp16x3 / fp16x3s kernels, NULL = off: device status word that receives `status_bit` (atomic OR) when an

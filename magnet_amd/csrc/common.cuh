@@ -71,6 +71,7 @@ struct MagnetMlpArgs {
     MagnetSrc pre[2];              // gathered rows added to the first Linear's pre-activation (split-GEMM kernels), p == nullptr: off
     float* x0_out;                 // tape outputs (training backward), nullptr = off: assembled first-layer input rows [M][nkt*32]
     float* hid[MAGNET_MAX_LAYERS]; // hid[l]: layer l's activated output [M][HT*32]; hid[NL-1]: raw output of the last Linear [M][OT*32]
+                                   // (NL == 2: hid[2] = the hidden layer's pre-activation)
     uint64_t x0_skip;              // bit kt set: k tile kt of x0_out is not written
     int32_t* status;               // fp16 split modes, NL > 1, nullptr = off: `status_bit` is OR-ed in when a HIDDEN activation reaches 65504
     int32_t status_bit;

@@ -336,6 +336,13 @@ __global__ void __launch_bounds__(256, 2) k_mlp_bf16(const MagnetMlpArgs a) {
             } else {
     #pragma unroll
                 for (int t = 0; t < NT0; ++t) {
+                    if (NL == 2 && a.hid[2]) {             // (two-Linear launches: the hidden layer's PRE-activation too - magnet_hip.h)
+#if MAGNET_BIAS_LDS
+                        if constexpr (TAPE_LINES) store_tile_lines<HT * 32>(acc[t], tl, a.hid[2], t * 32, (long)tile * 32, a.M, lane);
+                        else
+#endif
+                        store_ktile(acc[t], a.hid[2], HT * 32, t * 32, row, row_ok, half);
+                    }
                     apply_act<ACT>(acc[t]);
                     h0[t < HT ? t : 0] = acc[t];
                     if (TRACK_SAT) track_abs_max(acc[t], sat);

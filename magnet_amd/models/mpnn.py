@@ -29,6 +29,7 @@ from ..graphs import _ident as _graph_ident
 from ..graphs import RolloutGraph, capturing, hold, wants_graph
 from ..topo_cache import TopologyCache
 
+_KEEP_Z1 = os.environ.get("MAGNET_KEEP_Z1", "1") != "0"      # A/B knob: 0 = the backward recomputes the update net's hidden pre-activation
 _READOUT = {10: (16, 6, 10), 16: (16, 5, 8), 20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}  # mpnn.py:140-163
 
 
@@ -339,9 +340,12 @@ class MPNN(LightningModule):
             if small_nodes:
                 ops.mpnn_node_update(h, agg, node_in, lyr.upd1, lyr.upd2, g)
             else:
-                # with a tape: the launch also leaves Swish(z1) and z2 (the update net's hidden activation and its raw output) for the
-                # backward, which then recomputes only z1 (two [N, 128] arrays per hop against a GEMM launch and a Swish pass)
-                keep = (new(), new()) if tape is not None and lyr.upd1[0].dtype in (torch.float16, torch.int16) else None
+                # with a tape: the launch also leaves Swish(z1), z2 and z1 (the update net's hidden activation, its raw output and the
+                # hidden pre-activation) for the backward, which then recomputes nothing of the update net (three [N, 128] arrays per
+                # hop against two GEMM launches and a Swish pass)
+                keep = (new(), new(), new()) if tape is not None and lyr.upd1[0].dtype in (torch.float16, torch.int16) else None
+                if keep and not _KEEP_Z1:
+                    keep = keep[:2]
                 ops.mlp(N, ops.ktiles(T(h, H), T(agg, H), T(node_in, kin)), [lyr.upd1, lyr.upd2], nl=2, ht=4, ot=4,
                         act=ops.ACT_SWISH, last_act=True, epi=ops.EPI_STORE_RES, res=h, y=g, hid=list(keep) if keep else None)
             if gptr is not None and tape is None:
@@ -350,14 +354,16 @@ class MPNN(LightningModule):
                 h_in = h
                 h, var = ops.instance_norm_ragged(g, gptr, out=new(), return_var=True)
                 tape.layers.append(types.SimpleNamespace(h_in=h_in, A=A, Bm=Bm, agg=agg, var=var, h_out=h,
-                                                         r1=keep[0] if keep else None, z2=keep[1] if keep else None))
+                                                         r1=keep[0] if keep else None, z2=keep[1] if keep else None,
+                                                         z1=keep[2] if keep and len(keep) > 2 else None))
             elif tape is None:
                 ops.instance_norm(g, B, Ns, out=h)
             else:
                 h_in = h
                 h, var = ops.instance_norm(g, B, Ns, out=new(), return_var=True)
                 tape.layers.append(types.SimpleNamespace(h_in=h_in, A=A, Bm=Bm, agg=agg, var=var, h_out=h,
-                                                         r1=keep[0] if keep else None, z2=keep[1] if keep else None))
+                                                         r1=keep[0] if keep else None, z2=keep[1] if keep else None,
+                                                         z1=keep[2] if keep and len(keep) > 2 else None))
         if tape is not None:
             tape.h = h
         k1, s1, k2 = _READOUT[tw]

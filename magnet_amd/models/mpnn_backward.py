@@ -148,7 +148,7 @@ def backward_call(m, tape, dout, G, ws):
     ops.reduce_partials(gp, gp.shape[0], gp.shape[1], G.conv)
     dnin = torch.zeros(N, kin, device=dev, dtype=torch.float32)
     dnin_l = torch.empty_like(dnin)
-    z1, r1_buf, z2_buf, t1, t2, dagg, dA, dBm = (new() for _ in range(8))
+    z1_buf, r1_buf, z2_buf, t1, t2, dagg, dA, dBm = (new() for _ in range(8))
     r1, z2 = r1_buf, z2_buf
     has_f16 = hasattr(Q.layers[0], "w2_f16") if Q.layers else False       # not after packing.widen (see _packed_bwd)
     fused = m.edge_bwd in ("fused", "fused_w") and has_f16
@@ -168,7 +168,10 @@ def backward_call(m, tape, dout, G, ws):
         else:
             dg = ops.instance_norm_bwd(dh, tp.h_out, tp.var, B, Ns)
         # ---- update MLP (recomputed pre-activations)                                 mpnn.py:81-90
-        lin(N, ops.ktiles(T(tp.h_in, H), T(tp.agg, H), T(nin, kin)), lyr.upd1, z1)
+        z1 = getattr(tp, "z1", None)
+        if z1 is None:
+            z1 = z1_buf
+            lin(N, ops.ktiles(T(tp.h_in, H), T(tp.agg, H), T(nin, kin)), lyr.upd1, z1)
         if getattr(tp, "r1", None) is not None:                           # kept by the forward launch
             r1, z2 = tp.r1, tp.z2
         else:
@@ -228,6 +231,7 @@ def backward_call(m, tape, dout, G, ws):
         lin_add(N, ops.ktiles(T(dA, H), T(dBm, H)), qb.dnin, dnin, dnin_l, o_k)
 
     # ---- embedding MLP                                                                mpnn.py:131-136
+    z1 = z1_buf                                                          # (not the last layer's tape entry)
     lin(N, ops.ktiles(T(nin, kin)), P.emb[0], z1)
     r1, z2 = r1_buf, z2_buf
     ops.swish_fwd(z1, r1)
