@@ -495,10 +495,11 @@ int magnet_linear_bwd64_f32(const float* dz, int ldz, const float* x, int ldx, c
  * never written to memory; dp [n_edges][128] and dA [n_nodes][128] as above.  workspace: magnet_mpnn_edge_bwd_w_workspace() floats
  * (per-workgroup partial sums, added in workgroup order: deterministic). */
 int magnet_mpnn_edge_bwd_w_workspace(void);
-/* Which kernel serves the two entry points below: 1 (default) = k_mpnn_edge_bwd_wp (csrc/mpnn_edge_bwd_wp.hip: every wave forms the
- * weight gradient of its own tiles in the accumulator half of the register file, no workgroup barrier in the loop), 0 =
- * k_mpnn_edge_bwd_w (the shared-slab kernel, kept for same-process A/B runs).  Returns the previous value; any other argument only
- * queries.  The results differ in the order of the fp32 additions of dW2 / db2 only. */
+/* Which kernel serves the entry points below: 2 (default) = k_mpnn_edge_bwd_co (csrc/mpnn_edge_bwd_co.hip: the workgroup's eight waves
+ * co-operate on one 32-edge tile, a wave owns 16 features of all three GEMMs; graphs of 8 M nodes and more take generation 1),
+ * 1 = k_mpnn_edge_bwd_wp (csrc/mpnn_edge_bwd_wp.hip: every wave forms the weight gradient of its own tiles in the accumulator half of
+ * the register file), 0 = k_mpnn_edge_bwd_w (the shared-slab kernel) - both kept for same-process A/B runs.  Returns the previous
+ * value; any other argument only queries.  The results differ in the order of the fp32 additions only. */
 int magnet_mpnn_edge_bwd_w_generation(int generation);
 int magnet_mpnn_edge_bwd_w_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src, const int32_t* tgt,
                                const int32_t* rowptr, int n_nodes, int n_edges, const void* w2_f16, const void* w2t_f16,
@@ -510,6 +511,16 @@ int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, const float
                                     const int32_t* rowptr, int n_nodes, int n_edges, const void* w2_f16, const void* w2t_f16,
                                     const float* b2, float* dp, float* dA, float* partials, float* dW2, float* db2, int accumulate,
                                     float* workspace, const float* amax_in, int n_amax_in, void* stream);
+/* the same with `flags`: MAGNET_EDGE_BWD_AB_LOG2E = A / Bm are the training forward's log2(e)-scaled halves (what
+ * magnet_mpnn_edge_stream_fp16x3_f32 takes with MAGNET_STREAM_L2E: the backward reads the forward's own arrays); dp / dA / dW2 / db2
+ * are the gradients of the unscaled block (p = ln 2 (A' + Bm')) all the same.  Generation 2 only: -2 where
+ * magnet_mpnn_edge_bwd_w_takes_flags(n_nodes) is 0; unknown bits: -2. */
+#define MAGNET_EDGE_BWD_AB_LOG2E 1
+int magnet_mpnn_edge_bwd_w_takes_flags(int n_nodes);
+int magnet_mpnn_edge_bwd_w_flags_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src, const int32_t* tgt,
+                                     const int32_t* rowptr, int n_nodes, int n_edges, const void* w2_f16, const void* w2t_f16,
+                                     const float* b2, float* dp, float* dA, float* partials, float* dW2, float* db2, int accumulate,
+                                     float* workspace, const float* amax_in, int n_amax_in, int flags, void* stream);
 
 /* Weight packing on the device (magnet_amd/packing.py: the same layouts as torch index shuffles; no reference counterpart - the
  * reference hands its nn.Linear weights to cuBLAS as they are).  Padded position (r, c) of the [np x kp] matrix takes

@@ -668,7 +668,7 @@ int magnet_launch_edge_bwd_wp(const float* A, const float* Bm, const float* dagg
 // mpnn_edge_bwd_co.hip: generation 3 (eight co-operating waves per tile, a wave owns 16 features; two waves per SIMD)
 int magnet_launch_edge_bwd_co(const float* A, const float* Bm, const float* dagg, const int32_t* src, const int32_t* tgt,
                               const int32_t* rowptr, int n_edges, const void* w2_f16, const void* w2t_f16, const float* b2, float* dp,
-                              float* dA, float* partials, const float* amax, int n_amax, float* wpart, float* bpart, int grid,
+                              float* dA, float* partials, const float* amax, int n_amax, float* wpart, float* bpart, int ab_l2e, int grid,
                               void* stream);
 // 2 (default): k_mpnn_edge_bwd_co; 1: k_mpnn_edge_bwd_wp (round 4); 0: k_mpnn_edge_bwd_w (the shared-slab kernel of round 3) - kept for
 // A/B runs; same results up to the order of the fp32 additions
@@ -690,6 +690,11 @@ extern "C" int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, 
                                                const void* w2_f16, const void* w2t_f16, const float* b2, float* dp, float* dA,
                                                float* partials, float* dW2, float* db2, int accumulate, float* workspace,
                                                const float* amax_in, int n_amax_in, void* stream);
+extern "C" int magnet_mpnn_edge_bwd_w_flags_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src,
+                                                const int32_t* tgt, const int32_t* rowptr, int n_nodes, int n_edges,
+                                                const void* w2_f16, const void* w2t_f16, const float* b2, float* dp, float* dA,
+                                                float* partials, float* dW2, float* db2, int accumulate, float* workspace,
+                                                const float* amax_in, int n_amax_in, int flags, void* stream);
 extern "C" int magnet_mpnn_edge_bwd_w_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src,
                                           const int32_t* tgt, const int32_t* rowptr, int n_nodes, int n_edges,
                                           const void* w2_f16, const void* w2t_f16, const float* b2, float* dp, float* dA,
@@ -704,7 +709,23 @@ extern "C" int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, 
                                                const void* w2_f16, const void* w2t_f16, const float* b2, float* dp, float* dA,
                                                float* partials, float* dW2, float* db2, int accumulate, float* workspace,
                                                const float* amax_in, int n_amax_in, void* stream) {
+    return magnet_mpnn_edge_bwd_w_flags_f32(A, Bm, dagg, src, tgt, rowptr, n_nodes, n_edges, w2_f16, w2t_f16, b2, dp, dA, partials, dW2, db2,
+                                            accumulate, workspace, amax_in, n_amax_in, 0, stream);
+}
+// flags bit 0 (MAGNET_EDGE_BWD_AB_LOG2E): A / Bm are the forward's log2(e)-scaled halves (magnet_mpnn_edge_stream_fp16x3_f32 with
+// MAGNET_STREAM_L2E); dp / dA / dW2 / db2 are the gradients of the unscaled block all the same.  Generation 3 only (-2 otherwise:
+// magnet_mpnn_edge_bwd_w_takes_flags says beforehand whether a graph of n_nodes would take it).
+extern "C" int magnet_mpnn_edge_bwd_w_takes_flags(int n_nodes) {
+    return g_ebw_generation == 2 && (size_t)n_nodes * 512 < ((size_t)1 << 32);
+}
+extern "C" int magnet_mpnn_edge_bwd_w_flags_f32(const float* A, const float* Bm, const float* dagg, const int32_t* src,
+                                                const int32_t* tgt, const int32_t* rowptr, int n_nodes, int n_edges,
+                                                const void* w2_f16, const void* w2t_f16, const float* b2, float* dp, float* dA,
+                                                float* partials, float* dW2, float* db2, int accumulate, float* workspace,
+                                                const float* amax_in, int n_amax_in, int flags, void* stream) {
     (void)hipGetLastError();
+    if (flags & ~1) return -2;
+    if ((flags & 1) && !magnet_mpnn_edge_bwd_w_takes_flags(n_nodes)) return -2;
     if (n_nodes <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     if (n_edges > 0) {
@@ -736,7 +757,7 @@ extern "C" int magnet_mpnn_edge_bwd_w_amax_f32(const float* A, const float* Bm, 
         const bool co_ok = (size_t)n_nodes * 512 < ((size_t)1 << 32);
         if (g_ebw_generation == 2 && co_ok)
             magnet_launch_edge_bwd_co(A, Bm, dagg, src, tgt, rowptr, n_edges, w2_f16, w2t_f16, b2, dp, dA, partials, amax, nab, wpart, bpart,
-                                      grid, stream);
+                                      flags & 1, grid, stream);
         else if (g_ebw_generation >= 1)
             magnet_launch_edge_bwd_wp(A, Bm, dagg, src, tgt, rowptr, n_edges, w2_f16, w2t_f16, b2, dp, dA, partials, amax, nab, wpart, bpart,
                                       pscr, grid, stream);

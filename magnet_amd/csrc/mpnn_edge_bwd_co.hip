@@ -99,6 +99,17 @@ __device__ __forceinline__ f32x4 co_sigmoid4(const f32x4& x) {
     for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_rcpf(e[i]);
     return e;
 }
+// 1 / (1 + 2^-x): the negation rides in v_exp_f32's source modifier
+__device__ __forceinline__ f32x4 co_sigmoid4n(const f32x4& x) {
+    if (CO_ABL & 16) return x * -0.25f;
+    f32x4 e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(-x[i]);
+    e = e + 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_rcpf(e[i]);
+    return e;
+}
 __device__ __forceinline__ void co_barrier() {
     if (!(CO_ABL & 1)) wg_barrier();
 }
@@ -150,6 +161,8 @@ __device__ __forceinline__ void co_gemm(const unsigned short (&img)[2][32][CO_ST
 
 }  // namespace
 
+// AB_L2E: the rows of A / Bm carry the factor log2(e) (the forward's halves for the exp2-based Swish: A' + Bm' = log2(e) p)
+template <bool AB_L2E>
 __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __restrict__ A, const float* __restrict__ Bm,
                                                              const float* __restrict__ dagg, const int32_t* __restrict__ src,
                                                              const int32_t* __restrict__ tgt, const int32_t* __restrict__ rowptr,
@@ -241,15 +254,16 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
         for (int rb = 0; rb < 2; ++rb) {
             // (whole-vector arithmetic: v_pk_add / v_pk_mul / v_pk_fma_f32 take two of the lane's four values per instruction)
 #if CO_PACKED
-            const f32x4 v = a_[rb] + b_[rb];
-            const f32x4 s = co_sigmoid4(v * (-1.4426950408889634f));
+            const f32x4 vs = a_[rb] + b_[rb];
+            const f32x4 v = AB_L2E ? vs * 0.6931471805599453f : vs;            // p
+            const f32x4 s = AB_L2E ? co_sigmoid4n(vs) : co_sigmoid4(vs * (-1.4426950408889634f));
             const f32x4 t = v * s;
             sp[rb] = t * (s * vmone + vone) + s;                                // s (1 + v (1 - s)): two v_pk_fma (a literal 1 - s is taken apart)
 #else
             f32x4 v, s;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                v[i] = a_[rb][i] + b_[rb][i];
+                v[i] = (a_[rb][i] + b_[rb][i]) * (AB_L2E ? 0.6931471805599453f : 1.0f);
                 s[i] = co_sigmoid(v[i]);
                 sp[rb][i] = s[i] * (1.0f + v[i] * (1.0f - s[i]));
             }
@@ -550,9 +564,14 @@ __global__ void __launch_bounds__(512, 1) k_mpnn_edge_bwd_co(const float* __rest
 
 int magnet_launch_edge_bwd_co(const float* A, const float* Bm, const float* dagg, const int32_t* src, const int32_t* tgt,
                               const int32_t* rowptr, int n_edges, const void* w2_f16, const void* w2t_f16, const float* b2, float* dp,
-                              float* dA, float* partials, const float* amax, int n_amax, float* wpart, float* bpart, int grid,
+                              float* dA, float* partials, const float* amax, int n_amax, float* wpart, float* bpart, int ab_l2e, int grid,
                               void* stream) {
-    hipLaunchKernelGGL(k_mpnn_edge_bwd_co, dim3(grid), dim3(512), 0, (hipStream_t)stream, A, Bm, dagg, src, tgt, rowptr, n_edges,
+    if (ab_l2e)
+        hipLaunchKernelGGL(k_mpnn_edge_bwd_co<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream, A, Bm, dagg, src, tgt, rowptr, n_edges,
+                           reinterpret_cast<const u32x4*>(w2_f16), reinterpret_cast<const u32x4*>(w2t_f16), b2, dp, dA, partials, amax,
+                           n_amax, wpart, bpart);
+    else
+    hipLaunchKernelGGL(k_mpnn_edge_bwd_co<false>, dim3(grid), dim3(512), 0, (hipStream_t)stream, A, Bm, dagg, src, tgt, rowptr, n_edges,
                        reinterpret_cast<const u32x4*>(w2_f16), reinterpret_cast<const u32x4*>(w2t_f16), b2, dp, dA, partials, amax, n_amax,
                        wpart, bpart);
     return (int)hipGetLastError();

@@ -29,6 +29,7 @@ from ..graphs import _ident as _graph_ident
 from ..graphs import RolloutGraph, capturing, hold, wants_graph
 from ..topo_cache import TopologyCache
 
+_TAPE_L2E = os.environ.get("MAGNET_TAPE_L2E", "1") != "0"    # A/B knob: 0 = a training forward computes plain halves (the edge kernel scales them)
 _KEEP_Z1 = os.environ.get("MAGNET_KEEP_Z1", "1") != "0"      # A/B knob: 0 = the backward recomputes the update net's hidden pre-activation
 _READOUT = {10: (16, 6, 10), 16: (16, 5, 8), 20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}  # mpnn.py:140-163
 
@@ -294,13 +295,19 @@ class MPNN(LightningModule):
         small_nodes = (tape is None and gptr is None and self.gemm == "fp16x3" and Ns <= ops.NORM_SMALL_ROWS and kin in (32, 64) and H == 128
                        and self.fused_node_halves)
         stats = None                                                        # (mean, var) of h when h is still un-normalised
+        tape_l2e = False
+        if tape is not None:
+            tape_l2e = tape.l2e = bool(_TAPE_L2E and self.edge_bwd == "fused_w" and self.gemm == "fp16x3" and csr.E > 0
+                                       and ops.mpnn_edge_bwd_w_takes_l2e(N))
         for li, lyr in enumerate(P.layers):
             if tape is not None:
                 AB, agg = torch.empty(2, N, H, device=dev, dtype=torch.float32), new()
             A, Bm = AB[0], AB[1]
             # A = W1a.[h | node_in] + b1 and Bm = W1b.[h | node_in]: two column groups of one launch, run back to back inside
             # each workgroup so that the second group reads [h | node_in] from L2 (fp32 kernels: two workgroup columns)
-            l2e = tape is None and hasattr(lyr, "pre_a_l2e")
+            # (with a tape: the scaled halves too when the edge backward that will read them takes them - generation 3 of the fused
+            #  kernel; the tape says which it holds)
+            l2e = hasattr(lyr, "pre_a_l2e") and (tape is None or tape_l2e)
             pa, pb = (lyr.pre_a_l2e, lyr.pre_b_l2e) if l2e else (lyr.pre_a, lyr.pre_b)
             if fused_nodes and l2e and hasattr(lyr, "pre_a_l2e_s"):
                 ops.mpnn_node_halves(h, node_in, lyr.pre_a_l2e_s, lyr.pre_b_l2e_s, A, Bm, stats=stats, rows_per_graph=Ns)

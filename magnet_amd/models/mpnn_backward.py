@@ -200,17 +200,23 @@ def backward_call(m, tape, dout, G, ws):
             ops.wgrad(dz1, tp.agg, 0, H, g.w3, H, None, ws)
             lin(N, ops.ktiles(T(dz1, H)), qb.dagg, dagg)
         # ---- mean aggregation + message MLP at edge granularity                      mpnn.py:73-79, :46
+        tA, tBm = tp.A, tp.Bm
+        l2e = bool(getattr(tape, "l2e", False))                          # the tape holds the forward's log2(e)-scaled halves
+        if l2e and not (E > 0 and fused_w and ops.mpnn_edge_bwd_w_takes_l2e(N)):
+            # (the forward expected generation 3 of the fused kernel and something changed in between - the process was widened, the
+            #  generation knob moved: the other paths read plain halves)
+            tA, tBm, l2e = tp.A * 0.6931471805599453, tp.Bm * 0.6931471805599453, False
         if E > 0 and fused_w:
-            ops.mpnn_edge_bwd_w(tp.A, tp.Bm, dagg, csr, qb.w2_f16[0], qb.w2t_f16[0], qb.w2_f16[1], d2, dA, partials, g.w2, g.b2, ews,
-                                amax_in=dagg_amax)
+            ops.mpnn_edge_bwd_w(tA, tBm, dagg, csr, qb.w2_f16[0], qb.w2t_f16[0], qb.w2_f16[1], d2, dA, partials, g.w2, g.b2, ews,
+                                amax_in=dagg_amax, l2e=l2e)
             ops.segment_sum128(d2, bs.rowptr, N, perm=bs.perm, out=dBm)
         elif E > 0 and fused:
-            ops.mpnn_edge_bwd(tp.A, tp.Bm, dagg, csr, qb.w2_f16[0], qb.w2t_f16[0], qb.w2_f16[1], sp, d1, d2, dA, partials)
+            ops.mpnn_edge_bwd(tA, tBm, dagg, csr, qb.w2_f16[0], qb.w2t_f16[0], qb.w2_f16[1], sp, d1, d2, dA, partials)
             ops.wgrad(d1, sp, 0, H, g.w2, 0, g.b2, ws, M=E)
             ops.segment_sum128(d2, bs.rowptr, N, perm=bs.perm, out=dBm)
         elif E > 0:
             ops.edge_mean_bwd(dagg, csr, d1)
-            ops.edge_pre(tp.A, tp.Bm, csr, p)
+            ops.edge_pre(tA, tBm, csr, p)
             ops.swish_fwd(p, sp)
             lin(E, ops.ktiles(T(sp, H)), lyr.msg2, q)
             dq = ops.swish_bwd(d1, q, d1)

@@ -653,20 +653,31 @@ def mpnn_edge_bwd(A, Bm, dagg, csr, w2_f16, w2t_f16, b2, s1, dq, dp, dA, partial
 _EDGE_BWD_GEN = __import__("os").environ.get("MAGNET_EDGE_BWD_GEN")      # A/B knob: 2 (default) k_mpnn_edge_bwd_co, 1 k_mpnn_edge_bwd_wp, 0 k_mpnn_edge_bwd_w
 
 
-def mpnn_edge_bwd_w(A, Bm, dagg, csr, w2_f16, w2t_f16, b2, dp, dA, partials, dW2, db2, ws=None, accumulate=True, amax_in=None):
-    """fused backward of the edge block with message_net_2's weight gradient formed in the kernel: fills dp [E,128] and dA [N,128],
-    dW2 [128,128] (+)= dq^T s1, db2 [128] (+)= colsum(dq); s1 / dq are never materialised"""
-    assert dW2.is_contiguous() and dW2.shape == (128, 128) and db2.is_contiguous()
+def _edge_bwd_gen_knob():
     global _EDGE_BWD_GEN
     if _EDGE_BWD_GEN is not None:
         L.lib().magnet_mpnn_edge_bwd_w_generation(int(_EDGE_BWD_GEN))
         _EDGE_BWD_GEN = None
+
+
+def mpnn_edge_bwd_w_takes_l2e(n_nodes):
+    """whether mpnn_edge_bwd_w would read log2(e)-scaled halves for a graph of n_nodes (the kernel generation that serves it does)"""
+    _edge_bwd_gen_knob()
+    return bool(L.lib().magnet_mpnn_edge_bwd_w_takes_flags(int(n_nodes)))
+
+
+def mpnn_edge_bwd_w(A, Bm, dagg, csr, w2_f16, w2t_f16, b2, dp, dA, partials, dW2, db2, ws=None, accumulate=True, amax_in=None, l2e=False):
+    """fused backward of the edge block with message_net_2's weight gradient formed in the kernel: fills dp [E,128] and dA [N,128],
+    dW2 [128,128] (+)= dq^T s1, db2 [128] (+)= colsum(dq); s1 / dq are never materialised.  ``l2e``: A / Bm are the forward's
+    log2(e)-scaled halves"""
+    assert dW2.is_contiguous() and dW2.shape == (128, 128) and db2.is_contiguous()
+    _edge_bwd_gen_knob()
     if ws is None:
         ws = torch.empty(L.lib().magnet_mpnn_edge_bwd_w_workspace(), device=A.device, dtype=torch.float32)
-    L.check(L.lib().magnet_mpnn_edge_bwd_w_amax_f32(_p(A), _p(Bm), _p(dagg), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.N, csr.E,
-                                                    _p(w2_f16), _p(w2t_f16), _p(b2), _p(dp), _p(dA), _p(partials), _p(dW2), _p(db2),
-                                                    int(accumulate), _p(ws), _p(amax_in[0]) if amax_in else None,
-                                                    int(amax_in[1]) if amax_in else 0, _stream()), "mpnn_edge_bwd_w")
+    L.check(L.lib().magnet_mpnn_edge_bwd_w_flags_f32(_p(A), _p(Bm), _p(dagg), _p(csr.src), _p(csr.tgt), _p(csr.rowptr), csr.N, csr.E,
+                                                     _p(w2_f16), _p(w2t_f16), _p(b2), _p(dp), _p(dA), _p(partials), _p(dW2), _p(db2),
+                                                     int(accumulate), _p(ws), _p(amax_in[0]) if amax_in else None,
+                                                     int(amax_in[1]) if amax_in else 0, int(bool(l2e)), _stream()), "mpnn_edge_bwd_w")
     return dA
 
 

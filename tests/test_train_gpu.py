@@ -183,7 +183,8 @@ def test_fused_edge_backward_matches_autograd():
 
 
 @pytest.mark.parametrize("generation", [2, 1])
-@pytest.mark.parametrize("case", ["random", "one_tile", "many_tiles_per_wave", "tiny_gradients", "accumulate", "rows_over_many_tiles", "empty_rows"])
+@pytest.mark.parametrize("case", ["random", "one_tile", "many_tiles_per_wave", "tiny_gradients", "accumulate", "rows_over_many_tiles", "empty_rows",
+                                  "log2e_halves"])
 def test_fused_edge_backward_with_weight_gradient_matches_autograd(case, generation):
     """magnet_mpnn_edge_bwd_w_f32 (dW2 / db2 formed inside the kernel, s1 / dq never written) against torch autograd (fp64) of the
     same edge block and against the kernel that writes s1 / dq (bit-identical dp and dA: the data path is the same code)."""
@@ -201,6 +202,13 @@ def test_fused_edge_backward_with_weight_gradient_matches_autograd(case, generat
         tgt = tgt - tgt % 3
     was = _lib.lib().magnet_mpnn_edge_bwd_w_generation(generation)
     try:
+        if case == "log2e_halves" and generation != 2:       # (the training forward's scaled halves: generation 3 of the kernel only)
+            assert not ops.mpnn_edge_bwd_w_takes_l2e(N)
+            z = torch.zeros(1, device="cuda")
+            with pytest.raises(RuntimeError):
+                ops.mpnn_edge_bwd_w(z, z, z, ops.csr_by_target(src, tgt, N), z, z, z, z, z, z, torch.zeros(128, 128, device="cuda"),
+                                    torch.zeros(128, device="cuda"), l2e=True)
+            return
         _edge_backward_case(case, N, E, scale, src, tgt)
     finally:
         _lib.lib().magnet_mpnn_edge_bwd_w_generation(was)
@@ -230,7 +238,11 @@ def _edge_backward_case(case, N, E, scale, src, tgt):
     gW0, gb0 = (torch.randn(128, 128, device="cuda") * scale, torch.randn(128, device="cuda") * scale) if case == "accumulate" else \
         (torch.zeros(128, 128, device="cuda"), torch.zeros(128, device="cuda"))
     gW, gb = gW0.clone(), gb0.clone()
-    ops.mpnn_edge_bwd_w(A, Bm, dagg, csr, w2p[0], w2tp[0], w2p[1], dp, dA, partials, gW, gb)
+    if case == "log2e_halves":       # A' = log2(e) A, Bm' = log2(e) Bm in, the gradients of the unscaled block out
+        LOG2E = 1.4426950408889634
+        ops.mpnn_edge_bwd_w(A * LOG2E, Bm * LOG2E, dagg, csr, w2p[0], w2tp[0], w2p[1], dp, dA, partials, gW, gb, l2e=True)
+    else:
+        ops.mpnn_edge_bwd_w(A, Bm, dagg, csr, w2p[0], w2tp[0], w2p[1], dp, dA, partials, gW, gb)
     assert rel_l2(gW - gW0, W64.grad) < 2e-6 and rel_l2(gb - gb0, b64.grad) < 2e-6
     assert rel_l2(dA, A64.grad) < 2e-6
     s1, dq, dp_ref = (torch.empty(E, 128, device="cuda") for _ in range(3))
@@ -238,7 +250,10 @@ def _edge_backward_case(case, N, E, scale, src, tgt):
     ops.mpnn_edge_bwd(A, Bm, dagg, csr, w2p[0], w2tp[0], w2p[1], s1, dq, dp_ref, dA_ref, partials)
     assert rel_l2(dp, dp_ref) < 1e-6 and rel_l2(dA, dA_ref) < 1e-6     # (Swish'(p) comes from another evaluation order: not bitwise)
     gW2, gb2 = gW0.clone(), gb0.clone()                                # twice the same launch: bit-identical
-    ops.mpnn_edge_bwd_w(A, Bm, dagg, csr, w2p[0], w2tp[0], w2p[1], dp_ref, dA_ref, partials, gW2, gb2)
+    if case == "log2e_halves":
+        ops.mpnn_edge_bwd_w(A * LOG2E, Bm * LOG2E, dagg, csr, w2p[0], w2tp[0], w2p[1], dp_ref, dA_ref, partials, gW2, gb2, l2e=True)
+    else:
+        ops.mpnn_edge_bwd_w(A, Bm, dagg, csr, w2p[0], w2tp[0], w2p[1], dp_ref, dA_ref, partials, gW2, gb2)
     assert torch.equal(gW, gW2) and torch.equal(gb, gb2) and torch.equal(dp, dp_ref) and torch.equal(dA, dA_ref)
 
 
