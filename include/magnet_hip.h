@@ -379,6 +379,11 @@ int magnet_edge_mean_bwd_f32(const float* dagg, const int32_t* tgt, const int32_
 /* out[r] = sum_{k in row r} x[perm ? perm[k] : k], 128 columns (scatter-add of edge gradients to nodes) */
 int magnet_segment_sum128_f32(const float* x, const int32_t* rowptr, const int32_t* perm, int n_rows, float* out,
                               void* stream);
+/* Two column blocks of one Linear's weight gradient in one pass over dY (torch autograd of a Linear over torch.cat([h, node_in]),
+ * models/mpnn.py:73-90): dW[0:128, wcol : wcol+128] (+)= dY^T X[:, xcol : xcol+128] and dW[0:128, wcol2 : wcol2+32] (+)= dY^T X2[:, x2col :
+ * x2col+32]; db (+)= colsum(dY) (db may be NULL).  workspace: nblk * (128 * 160 + 128) + 128 * 160 floats, nblk = min(768, ceil(M / 32)). */
+int magnet_wgrad_pair_f32(const float* dY, int ldy, const float* X, int ldx, int xcol, const float* X2, int ldx2, int x2col, long M,
+                          float* dW, int ldw, int wcol, int wcol2, float* db, float* workspace, int accumulate, void* stream);
 /* dW[0:128, wcol:wcol+kc] (+)= dY[M,128]^T X[M, xcol:xcol+kc]; db[128] (+)= column sums of dY (db may be null);
  * kc in {32,64,96,128}; workspace: nblk*(128*kc+128) + 128*kc floats, nblk = min(768, ceil(M/32)) */
 int magnet_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, int xcol, int kc, long M, float* dW, int ldw,

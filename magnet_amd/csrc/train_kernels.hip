@@ -257,11 +257,15 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_partial(const float* __restric
 //     pieces to LDS in fragment order [stage][ks][piece][h][column][8 rows] (16-byte writes and reads, conflict-free); one barrier
 //     per slab, two stages;
 //   * the loads of slab s + 1 are issued before the MFMAs of slab s (32 staging registers).
-template <int KT>
-__global__ void __launch_bounds__(256, 3) k_wgrad_split(const float* __restrict__ dY, int ldy, int N, const float* __restrict__ X,
+// KT2 = 1: one more 32-column k tile from a SECOND array X2 (the MPNN node-level Linears read [h | node_in]: the pair of launches that
+// took dY^T h and dY^T node_in read - and split - dY twice); the tile is converted by wave 0 beside its own, partial is [grid][N][(KT+1)*32].
+template <int KT, int KT2 = 0>
+__global__ void __launch_bounds__(256, KT2 ? 2 : 3) k_wgrad_split(const float* __restrict__ dY, int ldy, int N, const float* __restrict__ X,
                                                         int ldx, int xcol, long M, float* __restrict__ partial /* [grid][N][KT*32] */,
-                                                        float* __restrict__ bpartial /* [grid][N] or null */) {
-    constexpr int KC = KT * 32;
+                                                        float* __restrict__ bpartial /* [grid][N] or null */,
+                                                        const float* __restrict__ X2 = nullptr, int ldx2 = 0, int x2col = 0) {
+    constexpr int KTT = KT + KT2;
+    constexpr int KC = KTT * 32;
     __shared__ __attribute__((aligned(16))) u32x4 pb[2][2 * 3 * 2 * KC];        // [stage][ks][piece][h][column]: 12 KiB per k tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, half = lane >> 5;
@@ -271,11 +275,13 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_split(const float* __restrict_
     if (blockIdx.y) bpartial = nullptr;
     const bool active = wave * 32 < N;                                  // one 32-column n tile of dY per wave
     const bool conv = wave < KT;                                        // ... and one k tile of X to convert
-    f32x16 acc[KT];
-    zero_tiles<KT>(acc);
+    const bool conv2 = KT2 && wave == 0;                                // (... and the tile of X2)
+    f32x16 acc[KTT];
+    zero_tiles<KTT>(acc);
     float bsum = 0.f;
     const long nslabs = (M + WG_SLAB - 1) / WG_SLAB;
     float ra[16], rb[16];                                               // raw values of the slab about to be consumed
+    float rc[KT2 ? 16 : 1];
     auto load = [&](long sl) {
         const long m0 = sl * WG_SLAB;
 #pragma unroll
@@ -286,6 +292,10 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_split(const float* __restrict_
             const float vb = conv ? X[mc * ldx + xcol + wave * 32 + i] : 0.f;
             ra[q] = m < M ? va : 0.f;
             rb[q] = m < M ? vb : 0.f;
+            if constexpr (KT2 != 0) {
+                const float vc = conv2 ? X2[mc * ldx2 + x2col + i] : 0.f;
+                rc[q] = m < M ? vc : 0.f;
+            }
         }
     };
     long sl = blockIdx.x;
@@ -313,6 +323,18 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_split(const float* __restrict_
                 d[2 * KC] = __builtin_bit_cast(u32x4, m_);
                 d[4 * KC] = __builtin_bit_cast(u32x4, l_);
             }
+            if constexpr (KT2 != 0) {
+                if (conv2) {
+                    bf16x8 h_, m_, l_;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = rc[8 * ks + c];
+                    split_bf16x3(v, h_, m_, l_);
+                    u32x4* d = st + ((ks * 3) * 2 + half) * KC + KT * 32 + i;
+                    d[0] = __builtin_bit_cast(u32x4, h_);
+                    d[2 * KC] = __builtin_bit_cast(u32x4, m_);
+                    d[4 * KC] = __builtin_bit_cast(u32x4, l_);
+                }
+            }
         }
         __syncthreads();                                                // every k tile's pieces of this slab are in LDS; the other
                                                                         // stage is free (all waves finished the previous slab)
@@ -322,15 +344,15 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_split(const float* __restrict_
             // the six products of a k step alternate between TWO accumulators: consecutive MFMAs never write the same one (a dependent
             // accumulate right behind its producer stalls the matrix pipe); all KT at once would need 36 more registers and spill at
             // three workgroups per CU
-            constexpr int G = KT >= 2 ? 2 : 1;
+            constexpr int G = KTT >= 2 ? 2 : 1;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int k0 = 0; k0 < KT; k0 += G) {
+                for (int k0 = 0; k0 < KTT; k0 += G) {
                     bf16x8 xh[G], xm[G], xl[G];
 #pragma unroll
                     for (int q = 0; q < G; ++q) {
-                        if (k0 + q >= KT) continue;                       // (odd KT: the last group has one member)
+                        if (k0 + q >= KTT) continue;                       // (odd KT: the last group has one member)
                         const u32x4* f = st + ((ks * 3) * 2 + half) * KC + (k0 + q) * 32 + i;
                         xh[q] = __builtin_bit_cast(bf16x8, f[0]);
                         xm[q] = __builtin_bit_cast(bf16x8, f[2 * KC]);
@@ -338,29 +360,29 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_split(const float* __restrict_
                     }
 #pragma unroll
                     for (int q = 0; q < G; ++q)
-                        if (k0 + q < KT) acc[k0 + q] = mfma_bf16(am[ks], xm[q], acc[k0 + q]);
+                        if (k0 + q < KTT) acc[k0 + q] = mfma_bf16(am[ks], xm[q], acc[k0 + q]);
 #pragma unroll
                     for (int q = 0; q < G; ++q)
-                        if (k0 + q < KT) acc[k0 + q] = mfma_bf16(al[ks], xh[q], acc[k0 + q]);
+                        if (k0 + q < KTT) acc[k0 + q] = mfma_bf16(al[ks], xh[q], acc[k0 + q]);
 #pragma unroll
                     for (int q = 0; q < G; ++q)
-                        if (k0 + q < KT) acc[k0 + q] = mfma_bf16(ah[ks], xl[q], acc[k0 + q]);
+                        if (k0 + q < KTT) acc[k0 + q] = mfma_bf16(ah[ks], xl[q], acc[k0 + q]);
 #pragma unroll
                     for (int q = 0; q < G; ++q)
-                        if (k0 + q < KT) acc[k0 + q] = mfma_bf16(am[ks], xh[q], acc[k0 + q]);
+                        if (k0 + q < KTT) acc[k0 + q] = mfma_bf16(am[ks], xh[q], acc[k0 + q]);
 #pragma unroll
                     for (int q = 0; q < G; ++q)
-                        if (k0 + q < KT) acc[k0 + q] = mfma_bf16(ah[ks], xm[q], acc[k0 + q]);
+                        if (k0 + q < KTT) acc[k0 + q] = mfma_bf16(ah[ks], xm[q], acc[k0 + q]);
 #pragma unroll
                     for (int q = 0; q < G; ++q)
-                        if (k0 + q < KT) acc[k0 + q] = mfma_bf16(ah[ks], xh[q], acc[k0 + q]);
+                        if (k0 + q < KTT) acc[k0 + q] = mfma_bf16(ah[ks], xh[q], acc[k0 + q]);
                 }
         }
     }
     if (!active) return;
     float* out = partial + (size_t)blockIdx.x * N * KC;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int kt = 0; kt < KTT; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // C/D row = A's i = n
@@ -869,6 +891,26 @@ extern "C" int magnet_wgrad_tiles_f32(const float* dY, int ldy, int n_out, const
     }
     hipLaunchKernelGGL(k_reduce_partials, dim3(nb((long)N * kc, 32), ntile), dim3(256), 0, S_, part, nblk, (long)N * kc, 1.0f, tiles, 0);
     hipLaunchKernelGGL(k_place_tiles, dim3(nb((long)ntile * N * kc, 256)), dim3(256), 0, S_, tiles, ntile, N, kc, dW, ldw, wcol, accumulate);
+    if (db) hipLaunchKernelGGL(k_reduce_partials, dim3(nb(N, 32)), dim3(256), 0, S_, bpart, nblk, (long)N, 1.0f, db, accumulate);
+    END();
+}
+// Two column blocks of one Linear's weight gradient in ONE pass over dY: dW[0:128, wcol : wcol+128] (+)= dY^T X[:, xcol : xcol+128] and
+// dW[0:128, wcol2 : wcol2+32] (+)= dY^T X2[:, x2col : x2col+32] (the MPNN node-level Linears over [h | node_in], models/mpnn.py:73-90),
+// db (+)= colsum(dY) (may be null).  workspace: nblk * (128 * 160 + 128) + 128 * 160 floats, nblk = min(768, ceil(M / 32)).
+extern "C" int magnet_wgrad_pair_f32(const float* dY, int ldy, const float* X, int ldx, int xcol, const float* X2, int ldx2, int x2col,
+                                     long M, float* dW, int ldw, int wcol, int wcol2, float* db, float* workspace, int accumulate,
+                                     void* stream) {
+    BEGIN();
+    if (M <= 0) return 0;
+    constexpr int N = 128, KC = 160;
+    const int nblk = (int)((M + WG_SLAB - 1) / WG_SLAB < 768 ? (M + WG_SLAB - 1) / WG_SLAB : 768);
+    float* part = workspace;
+    float* bpart = db ? workspace + (size_t)nblk * N * KC : nullptr;
+    hipLaunchKernelGGL((k_wgrad_split<4, 1>), dim3(nblk), dim3(256), 0, S_, dY, ldy, N, X, ldx, xcol, M, part, bpart, X2, ldx2, x2col);
+    float* tile = workspace + (size_t)nblk * (N * KC + N);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nb((long)N * KC, 32)), dim3(256), 0, S_, part, nblk, (long)N * KC, 1.0f, tile, 0);
+    hipLaunchKernelGGL(k_copy_cols, dim3(nb((long)N * 128, 256)), dim3(256), 0, S_, tile, KC, 0, dW, ldw, wcol, 128, (long)N, accumulate);
+    hipLaunchKernelGGL(k_copy_cols, dim3(nb((long)N * 32, 256)), dim3(256), 0, S_, tile, KC, 128, dW, ldw, wcol2, 32, (long)N, accumulate);
     if (db) hipLaunchKernelGGL(k_reduce_partials, dim3(nb(N, 32)), dim3(256), 0, S_, bpart, nblk, (long)N, 1.0f, db, accumulate);
     END();
 }

@@ -109,6 +109,7 @@ def _grad_buffers(m, dev):
 
 
 _NODE_ONE_KERNEL = __import__("os").environ.get("MAGNET_NODE_ONE_KERNEL", "1") != "0"      # A/B knob
+_WGRAD_PAIR = __import__("os").environ.get("MAGNET_WGRAD_PAIR", "1") != "0"                # A/B knob: 0 = two launches per [h | node_in] weight gradient
 
 
 def _source_csr(topo):
@@ -139,6 +140,13 @@ def backward_call(m, tape, dout, G, ws):
             lin(rows, kts, layer, tmp, o)
             ops.axpy(acc, tmp, 1.0, out=acc)
         return acc
+    def wg2(dz, x, dW, wcol, wcol_nin, db):
+        """dW[:, wcol ..] += dz^T x and dW[:, wcol_nin ..] += dz^T node_in: one pass over dz where node_in is one k tile wide"""
+        if kin == 32 and H == 128 and _WGRAD_PAIR:
+            ops.wgrad_pair(dz, x, 0, nin, 0, dW, wcol, wcol_nin, db, ws)
+        else:
+            ops.wgrad(dz, x, 0, H, dW, wcol, db, ws)
+            ops.wgrad(dz, nin, 0, kin, dW, wcol_nin, None, ws)
     new = lambda: torch.empty(N, H, device=dev, dtype=torch.float32)  # noqa: E731
     enew = lambda: torch.empty(max(E, 1), H, device=dev, dtype=torch.float32)  # noqa: E731
 
@@ -190,8 +198,7 @@ def backward_call(m, tape, dout, G, ws):
             ops.wgrad(dz2, r1, 0, H, g.w4, 0, g.b4, ws)
             lin(N, ops.ktiles(T(dz2, H)), qb.w4t, t2)
         dz1 = ops.swish_bwd(t2, z1, t2, amax=am[1] if one_kernel else None)
-        ops.wgrad(dz1, tp.h_in, 0, H, g.w3, 0, g.b3, ws)
-        ops.wgrad(dz1, nin, 0, kin, g.w3, 2 * H, None, ws)
+        wg2(dz1, tp.h_in, g.w3, 0, 2 * H, g.b3)
         if one_kernel:                                                   # dagg = dz1 W3[:, agg block], dW3[:, agg block] += dz1^T agg
             dagg_amax = ops.linear_bwd128(dz1, tp.agg, qb.daggt_f16, dagg, lbw[1], lbw[2], lbw[0], mask=False, amax_in=(am[1], 256))
             ops.copy_cols(lbw[1], 0, g.w3, H, H, accumulate=True)
@@ -229,10 +236,8 @@ def backward_call(m, tape, dout, G, ws):
             dA.zero_()
             dBm.zero_()
         # ---- per-node halves of message_net_1
-        ops.wgrad(dA, tp.h_in, 0, H, g.w1a, 0, g.b1, ws)
-        ops.wgrad(dA, nin, 0, kin, g.w1a, H, None, ws)
-        ops.wgrad(dBm, tp.h_in, 0, H, g.w1b, 0, None, ws)
-        ops.wgrad(dBm, nin, 0, kin, g.w1b, H, None, ws)
+        wg2(dA, tp.h_in, g.w1a, 0, H, g.b1)
+        wg2(dBm, tp.h_in, g.w1b, 0, H, None)
         dh = lin_add(N, ops.ktiles(T(dz1, H), T(dA, H), T(dBm, H)), qb.dh, dg, t1)
         lin_add(N, ops.ktiles(T(dA, H), T(dBm, H)), qb.dnin, dnin, dnin_l, o_k)
 

@@ -704,7 +704,7 @@ def segment_sum128(x, rowptr, n_rows, perm=None, out=None):
 
 def wgrad_workspace(M, device):
     nblk = min(768, (M + 31) // 32)
-    return torch.empty(nblk * (128 * 128 + 128) + 128 * 128, device=device, dtype=torch.float32)
+    return torch.empty(nblk * (128 * 160 + 128) + 128 * 160, device=device, dtype=torch.float32)      # (160: wgrad_pair's five k tiles)
 
 
 def wgrad(dY, X, xcol, kc, dW, wcol, db, ws, accumulate=True, M=None):
@@ -713,6 +713,15 @@ def wgrad(dY, X, xcol, kc, dW, wcol, db, ws, accumulate=True, M=None):
     assert dY.shape[1] == 128 and dW.shape[0] == 128 and dY.is_contiguous()
     L.check(L.lib().magnet_wgrad_f32(_p(dY), dY.stride(0), _p(X), X.stride(0), xcol, kc, C.c_long(M), _p(dW), dW.stride(0),
                                      wcol, _p(db), _p(ws), int(accumulate), _stream()), "wgrad")
+
+
+def wgrad_pair(dY, X, xcol, X2, x2col, dW, wcol, wcol2, db, ws, accumulate=True):
+    """dW[:, wcol:wcol+128] (+)= dY^T X[:, xcol:xcol+128] and dW[:, wcol2:wcol2+32] (+)= dY^T X2[:, x2col:x2col+32] in one pass over dY;
+    db (+)= colsum(dY) (db may be None).  ``ws``: wgrad_workspace."""
+    assert dY.shape[1] == 128 and dW.shape[0] == 128 and dY.is_contiguous()
+    L.check(L.lib().magnet_wgrad_pair_f32(_p(dY), dY.stride(0), _p(X), X.stride(0), xcol, _p(X2), X2.stride(0), x2col,
+                                          C.c_long(dY.shape[0]), _p(dW), dW.stride(0), wcol, wcol2, _p(db), _p(ws), int(accumulate),
+                                          _stream()), "wgrad_pair")
 
 
 def reduce_partials(partial, nblk, n, out, scale=1.0, accumulate=True):

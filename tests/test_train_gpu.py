@@ -57,6 +57,33 @@ def test_wgrad_matches_matmul(M, kc, xcol):
     assert torch.all(dW2[:, :8] == 7.0)
 
 
+@pytest.mark.parametrize("M", [1, 33, 4097, 70001])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_wgrad_pair_matches_two_launches(M, with_bias):
+    """magnet_wgrad_pair_f32 (dY^T h and dY^T node_in in one pass over dY): the two blocks land where two magnet_wgrad_f32 launches put
+    them, bit for bit (the same slabs, pieces and accumulation order per block), and match fp64."""
+    from magnet_amd import ops
+    torch.manual_seed(2)
+    dY = torch.randn(M, 128, device="cuda") * 1e-7                  # (gradients of a mean loss)
+    X, X2 = torch.randn(M, 128, device="cuda"), torch.randn(M, 32, device="cuda")
+    dW = torch.randn(128, 288, device="cuda") * 1e-7
+    db = torch.randn(128, device="cuda") * 1e-7 if with_bias else None
+    ws = ops.wgrad_workspace(M, "cuda")
+    a, ab = dW.clone(), (db.clone() if with_bias else None)
+    ops.wgrad_pair(dY, X, 0, X2, 0, a, 0, 256, ab, ws)
+    b, bb = dW.clone(), (db.clone() if with_bias else None)
+    ops.wgrad(dY, X, 0, 128, b, 0, bb, ws)
+    ops.wgrad(dY, X2, 0, 32, b, 256, None, ws)
+    assert torch.equal(a, b) and (not with_bias or torch.equal(ab, bb))
+    want = dW.double()
+    want[:, :128] += dY.double().t() @ X.double()
+    want[:, 256:] += dY.double().t() @ X2.double()
+    assert rel_l2(a, want) < 1e-6 and torch.equal(a[:, 128:256], dW[:, 128:256])
+    c = torch.full_like(dW, 7.0)
+    ops.wgrad_pair(dY, X, 0, X2, 0, c, 0, 256, None, ws, accumulate=False)
+    assert rel_l2(c[:, :128], dY.double().t() @ X.double()) < 1e-6 and torch.all(c[:, 128:256] == 7.0)
+
+
 def test_instance_norm_backward():
     from magnet_amd import ops
     from oracle import pyg_semantics as S
