@@ -1050,7 +1050,7 @@ def main():
         if True:                                   # (every rank: the extra step contains the gradient all-reduce)
             from magnet_amd import ops as _ops
             lib_ = _ops.L.lib()
-            ev_, orig_ = [], lib_.magnet_mpnn_edge_bwd_w_amax_f32
+            ev_, orig_ = [], lib_.magnet_mpnn_edge_bwd_w_flags_f32
 
             def timed_bwd(*a):
                 s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1060,19 +1060,21 @@ def main():
                 ev_.append((s_, e_))
                 return rc
 
-            _ops.L._lib.magnet_mpnn_edge_bwd_w_amax_f32 = timed_bwd
+            _ops.L._lib.magnet_mpnn_edge_bwd_w_flags_f32 = timed_bwd
             try:
                 train_step()
                 torch.cuda.synchronize()
             finally:
-                _ops.L._lib.magnet_mpnn_edge_bwd_w_amax_f32 = orig_
+                _ops.L._lib.magnet_mpnn_edge_bwd_w_flags_f32 = orig_
+            if not ev_:
+                print("bench.py: training_step.edge_backward - the timed C-ABI entry was not called by the step", file=sys.stderr)
             if ev_ and getattr(tmodel, "_topo", None) is not None:
                 E_ = tmodel._topo.csr.E
                 ms_ = sum(s_.elapsed_time(e_) for s_, e_ in ev_) / len(ev_)
                 fl_ = 3 * 2.0 * E_ * 128 * 128                    # GEMM 1 (q = W2 s1), GEMM 2 (ds1 = W2^T dq), the weight gradient (dq^T s1)
                 gen_ = int(lib_.magnet_mpnn_edge_bwd_w_generation(-1))
                 ebw = {"kernel": {2: "k_mpnn_edge_bwd_co", 1: "k_mpnn_edge_bwd_wp", 0: "k_mpnn_edge_bwd_w"}.get(gen_, "?"),
-                       "what": "entry magnet_mpnn_edge_bwd_w_amax_f32 = the edge kernel + the reduction of its per-workgroup dW2 / db2 partials + "
+                       "what": "entry magnet_mpnn_edge_bwd_w_flags_f32 = the edge kernel + the reduction of its per-workgroup dW2 / db2 partials + "
                                "the fix-up of the rows cut by the workgroups' tile ranges",
                        "launch_ms": round(ms_, 4), "launches_timed": len(ev_), "flops_per_launch": fl_, "bound": "mfma",
                        "achieved": round(fl_ / (ms_ * 1e-3) / 1e12, 2), "peak": round(MFMA_BF16_PEAK_TFLOPS / 3, 1), "unit": "TFLOP/s",
