@@ -29,6 +29,7 @@ from ..graphs import _ident as _graph_ident
 from ..graphs import RolloutGraph, capturing, hold, wants_graph
 from ..topo_cache import TopologyCache
 
+_REPLICATE_GRAPH = os.environ.get("MAGNET_REPLICATE_GRAPH", "1") != "0"    # A/B knob: 0 = the radius search runs over all B copies of the mesh
 _TAPE_L2E = os.environ.get("MAGNET_TAPE_L2E", "1") != "0"    # A/B knob: 0 = a training forward computes plain halves (the edge kernel scales them)
 _KEEP_Z1 = os.environ.get("MAGNET_KEEP_Z1", "1") != "0"      # A/B knob: 0 = the backward recomputes the update net's hidden pre-activation
 _READOUT = {10: (16, 6, 10), 16: (16, 5, 8), 20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}  # mpnn.py:140-163
@@ -416,8 +417,18 @@ class MPNN(LightningModule):
         """radius graph of sample 0's mesh replicated for the B samples (Q8), as CSR by target."""
         Ns = x0.shape[0]
         coords = x0.reshape(Ns, -1).repeat(B, 1)
-        gptr = ops.graph_ptr(B, Ns, x0.device)
-        found, query, qptr, E = ops.radius_pairs(coords, self._radius(x0, Ns), gptr, loop=False)
+        if B > 1 and _REPLICATE_GRAPH:
+            # the B graphs are copies of ONE mesh by construction (Q8): search it once and shift the copies' node numbers - the edge list of
+            # the batched search, bit for bit (query-major, ascending source within a query, graph after graph), at 1 / B of the search
+            f0, q0, p0, E0 = ops.radius_pairs(coords[:Ns], self._radius(x0, Ns), ops.graph_ptr(1, Ns, x0.device), loop=False)
+            node0 = torch.arange(B, dtype=torch.int32, device=x0.device)[:, None] * Ns
+            found, query = (f0[None, :] + node0).reshape(-1), (q0[None, :] + node0).reshape(-1)
+            qptr = torch.cat([(p0[None, :-1] + torch.arange(B, dtype=torch.int32, device=x0.device)[:, None] * E0).reshape(-1),
+                              torch.full((1,), B * E0, dtype=torch.int32, device=x0.device)])
+            E = B * E0
+        else:
+            gptr = ops.graph_ptr(B, Ns, x0.device)
+            found, query, qptr, E = ops.radius_pairs(coords, self._radius(x0, Ns), gptr, loop=False)
         csr = ops.CSR(qptr, found, query, B * Ns, E)          # query-major == sorted by target already
         return types.SimpleNamespace(csr=csr, n_graphs=B, nodes_per_graph=Ns, edge_index=None, coords=coords)
 

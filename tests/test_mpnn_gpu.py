@@ -361,3 +361,31 @@ def test_rollout_replayed_with_a_rebuilt_radius_graph_equals_eager():
         got = graph.validation_step(batch, 0)
         assert torch.equal(got, want)
     assert graph._topo.csr.E > 0
+
+
+@pytest.mark.parametrize("name,Ns,B", [("mpnn_2d", 24 * 24, 3), ("mpnn_2d", 48 * 48, 4), ("mpnn", 100, 5), ("mpnn_2d", 7 * 7, 2)])
+def test_replicated_radius_graph_equals_the_batched_search(name, Ns, B, monkeypatch):
+    """_build_topology searches sample 0's mesh once and shifts the copies (the B graphs of a batch are one mesh by construction, Q8 of
+    SURVEY 8-Q; models/mpnn_2d.py:237-246): the CSR of the search over all B copies, bit for bit - also on a perturbed (irregular) mesh."""
+    import types
+    import bench
+    from magnet_amd.models import mpnn as mpnn_mod
+    from magnet_amd.models.factory import FACTORY
+    hp = dict(bench.HP, hip_graph=False) if name == "mpnn_2d" else dict(bench.HP, hip_graph=False, neighbors=3)
+    model = FACTORY[name](types.SimpleNamespace(**hp)).cuda().eval()
+    torch.manual_seed(3)
+    if name == "mpnn_2d":
+        w = int(Ns ** 0.5)
+        g = torch.linspace(0, 1, w)
+        x0 = torch.stack(torch.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2).cuda()
+        x0 = x0 + 0.2 / w * torch.rand_like(x0)                       # (jittered: rows of unequal length)
+    else:
+        x0 = torch.linspace(0, 16, Ns).cuda()
+    topos = []
+    for flag in (True, False):
+        monkeypatch.setattr(mpnn_mod, "_REPLICATE_GRAPH", flag)
+        topos.append(model._build_topology(x0, B).csr)
+    a, b = topos
+    assert a.E == b.E and a.N == b.N and a.E > 0
+    assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.src, b.src) and torch.equal(a.tgt, b.tgt)
+    assert a.rowptr.dtype == b.rowptr.dtype and a.src.dtype == b.src.dtype
