@@ -205,10 +205,12 @@ class MAgNetCNN(MagnetBase):
         if why:                                 # out of the fp16 pieces' range: the same step in the full-range split
             self._widen(why)
             return self.training_step(train_batch, batch_idx)
-        loss = self.criterion(pred, target) + self.criterion(hr_hat, vals[:, :-T])
+        l_pred, l_interp = self.criterion(pred, target), self.criterion(hr_hat, vals[:, :-T])
+        loss = l_pred + l_interp
         self.log("train_loss", loss, prog_bar=True)
-        self.log("train_mae_loss", self.mae_criterion(pred, target), prog_bar=True)
-        self.log("train_interp_loss", self.mae_criterion(hr_hat, vals[:, :-T]), prog_bar=True)
+        same = getattr(self, "loss", None) == "l1"          # (the criterion IS the mean absolute error: logged once computed)
+        self.log("train_mae_loss", l_pred.detach() if same else self.mae_criterion(pred, target), prog_bar=True)
+        self.log("train_interp_loss", l_interp.detach() if same else self.mae_criterion(hr_hat, vals[:, :-T]), prog_bar=True)
         return loss
 
     def _inference_rollout(self, val_batch):
@@ -237,6 +239,8 @@ class MAgNetCNN(MagnetBase):
         u = val_batch["lr_frames"]
         rows = u.shape[0] * (u.shape[-1] ** self.DIM + val_batch["coords"].shape[1])
         pred, fut = self._graphed(self._inference_rollout, val_batch, keys, rows)
-        self.log("val_loss", self.criterion(pred, fut), prog_bar=True)
-        self.log("val_mae_loss", self.mae_criterion(pred, fut), prog_bar=True)
+        val = self.criterion(pred, fut)
+        self.log("val_loss", val, prog_bar=True)
+        # (loss = 'l1', every shipped config: the criterion IS the mean absolute error - logged once computed)
+        self.log("val_mae_loss", val if getattr(self, "loss", None) == "l1" else self.mae_criterion(pred, fut), prog_bar=True)
         return pred

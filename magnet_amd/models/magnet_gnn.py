@@ -217,10 +217,12 @@ class MAgNetGNN(MagnetBase):
     def training_step(self, train_batch, batch_idx):
         pred, target, hr_hat, vals = self._rollout(train_batch, self.teacher_forcing, noise=True)
         T = self.time_slice
-        loss = self.criterion(pred, target) + self.criterion(hr_hat, vals[:, :-T])
+        l_pred, l_interp = self.criterion(pred, target), self.criterion(hr_hat, vals[:, :-T])
+        loss = l_pred + l_interp
         self.log("train_loss", loss, prog_bar=True)
-        self.log("train_mae_loss", self.mae_criterion(pred, target), prog_bar=True)
-        self.log("train_interp_loss", self.mae_criterion(hr_hat, vals[:, :-T]), prog_bar=True)
+        same = getattr(self, "loss", None) == "l1"          # (the criterion IS the mean absolute error: logged once computed)
+        self.log("train_mae_loss", l_pred.detach() if same else self.mae_criterion(pred, target), prog_bar=True)
+        self.log("train_interp_loss", l_interp.detach() if same else self.mae_criterion(hr_hat, vals[:, :-T]), prog_bar=True)
         return loss
 
     @torch.no_grad()          # validation never differentiates (Lightning runs it under no_grad as well)
@@ -228,6 +230,8 @@ class MAgNetGNN(MagnetBase):
         keys = ("t", "lr_frames", "hr_points", "coords_hr", "coords_lr")
         rows = val_batch["lr_frames"].shape[0] * (val_batch["lr_frames"].shape[-1] + val_batch["coords_hr"].shape[1])
         pred, target = self._graphed(lambda b: self._rollout(b)[:2], val_batch, keys, rows)
-        self.log("val_loss", self.criterion(pred, target), prog_bar=True)
-        self.log("val_mae_loss", self.mae_criterion(pred, target), prog_bar=True)
+        val = self.criterion(pred, target)
+        self.log("val_loss", val, prog_bar=True)
+        # (loss = 'l1', every shipped config: the criterion IS the mean absolute error - logged once computed)
+        self.log("val_mae_loss", val if getattr(self, "loss", None) == "l1" else self.mae_criterion(pred, target), prog_bar=True)
         return pred

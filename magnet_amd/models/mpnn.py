@@ -544,7 +544,8 @@ class MPNN(LightningModule):
             u_hat, target = self.rollout(train_batch, self.teacher_forcing)
         loss = self.criterion(u_hat, target)
         self.log("train_loss", loss, prog_bar=True)
-        self.log("train_mae_loss", self.mae_criterion(u_hat.detach(), target), prog_bar=True)
+        # (loss = 'l1', every shipped config: criterion IS the mean absolute error - the same op on the same tensors, logged once computed)
+        self.log("train_mae_loss", loss.detach() if self.loss == "l1" else self.mae_criterion(u_hat.detach(), target), prog_bar=True)
         return loss
 
     def _inference_rollout(self, batch):
@@ -606,6 +607,7 @@ class MPNN(LightningModule):
 
     def validation_step(self, val_batch, batch_idx):
         u_hat, target = self._inference_rollout(val_batch)
-        self.log("val_loss", self.criterion(u_hat, target), prog_bar=True)
-        self.log("val_mae_loss", self.mae_criterion(u_hat, target), prog_bar=True)
+        val = self.criterion(u_hat, target)
+        self.log("val_loss", val, prog_bar=True)
+        self.log("val_mae_loss", val if self.loss == "l1" else self.mae_criterion(u_hat, target), prog_bar=True)
         return u_hat
