@@ -488,6 +488,15 @@ int magnet_linear_bwd128_grid(long M);
 int magnet_linear_bwd128_f32(const float* dz, int ldz, const float* x, int ldx, const void* wt_f16, long M, int mask, float* dx,
                              int lddx, float* dW, float* db, int accumulate, const float* amax_in, int n_amax_in, float* amax_out,
                              float* workspace, void* stream);
+/* TWO consecutive hidden 128 -> 128 Linears of a chain walked back in one kernel (models/backbones/mlp.py:9-28, Linear -> ReLU -> Linear ->
+ * ReLU): layer A (gradient dz at its output, its input x1, wtA = planes of W_A^T) and the layer below it, B (its input x2, wtB):
+ *   dx [M][lddx] = (x2 > 0) * (((x1 > 0) * (dz W_A)) W_B),  dW_A (+)= dz^T x1,  db_A (+)= colsum(dz),  dW_B (+)= dzB^T x2,  db_B (+)= colsum(dzB)
+ * - the gradient between the two layers never leaves the chip (four [M, 128] array passes instead of six).  Arguments as
+ * magnet_linear_bwd128_f32 (same workspace function); amax_out: NULL or room for magnet_linear_bwd128_pair_grid(M) floats. */
+int magnet_linear_bwd128_pair_grid(long M);
+int magnet_linear_bwd128_pair_f32(const float* dz, int ldz, const float* x1, int ldx1, const float* x2, int ldx2, const void* wtA_f16,
+                                  const void* wtB_f16, long M, float* dx, int lddx, float* dWA, float* dbA, float* dWB, float* dbB,
+                                  int accumulate, const float* amax_in, int n_amax_in, float* amax_out, float* workspace, void* stream);
 /* the same for a 64 -> 64 Linear (dW [64][64], db [64]; the hidden width of MAgNet[CNN]'s MLPs); same workspace function, amax_out:
  * magnet_linear_bwd64_grid(M) floats */
 int magnet_linear_bwd64_grid(long M);

@@ -491,10 +491,57 @@ class _Mlp(torch.autograd.Function):
             dX0 = None
             amax, lb_ws = ((ln_amax, nblk) if ln_amax is not None else None), None
             tpacks_emit_amax = BWD_GEMM == "bf16x6"                       # (the split-GEMM kernels' masked store can emit block maxima)
+            def fused_ok(l_, Np_):
+                """layer l_ (W [Np_][Np_], input X[l_]) can be walked back by csrc/linear_bwd.hip"""
+                W_ = params[2 * l_]
+                return (l_ > 0 and tuple(W_.shape) == (Np_, Np_) and X[l_].shape[1] == Np_ and Np_ in (128, 64) and M >= _FUSED_LAYER_ROWS
+                        and pk.layers[0][0].dtype == torch.float16 and X[l_].is_contiguous())
+
+            def grad_dest(W_, b_, Np_):
+                """(dW, db, accumulate, into): the parameter's own .grad when accumulate_param_grads lets the kernel's reduction add to it"""
+                # (a frozen Linear - requires_grad=False tensors are leaves too - must not get a .grad from here: autograd drops
+                #  what backward returns for it, an optimizer built over self.parameters() would not drop an assigned .grad)
+                into_ = (m.accum and takes_inplace_grad(W_) and takes_inplace_grad(b_)
+                         and W_.dtype == b_.dtype == torch.float32 and tuple(W_.shape) == (Np_, Np_) and tuple(b_.shape) == (Np_,))
+                Wg_, bg_ = (W_.grad, b_.grad) if into_ else (None, None)
+                if (Wg_ is not None and bg_ is not None and Wg_.dtype == bg_.dtype == torch.float32 and Wg_.device == bg_.device == dev
+                        and Wg_.is_contiguous() and bg_.is_contiguous()):
+                    return Wg_, bg_, True, into_
+                return (torch.empty(Np_, Np_, device=dev, dtype=torch.float32), torch.empty(Np_, device=dev, dtype=torch.float32), False, into_)
+
+            def grad_place(l_, W_, b_, dWp_, dbp_, accumulated, into_):
+                if accumulated:
+                    return
+                if into_ and W_.grad is None and b_.grad is None:
+                    W_.grad, b_.grad = dWp_, dbp_                       # the step's first contribution IS the gradient buffer
+                else:
+                    grads_par[2 * l_], grads_par[2 * l_ + 1] = dWp_, dbp_
+
+            skip = False
             for l in range(nl - 1, -1, -1):
+                if skip:                                                  # (walked back together with the layer above it)
+                    skip = False
+                    continue
                 W, b = params[2 * l], params[2 * l + 1]
                 n, k = W.shape
                 Np, Kp = dz.shape[1], (K0 if (l == 0 and x0_dense is not None) else X[l].shape[1])
+                # two consecutive hidden 128 -> 128 Linears in ONE kernel: the gradient between them never leaves the chip (four [M, 128]
+                # array passes instead of six; magnet_linear_bwd128_pair_f32)
+                if (_LINEAR_BWD_PAIR and Np == 128 and n == k == Kp == 128 and dz.is_contiguous() and fused_ok(l, 128) and fused_ok(l - 1, 128)):
+                    Wb, bb = params[2 * (l - 1)], params[2 * (l - 1) + 1]
+                    dA_, dbA_, accA, intoA = grad_dest(W, b, 128)
+                    dB_, dbB_, accB, intoB = grad_dest(Wb, bb, 128)
+                    if accA == accB:
+                        if lb_ws is None:
+                            lb_ws = torch.empty(L.query("magnet_linear_bwd128_workspace"), device=dev, dtype=torch.float32)
+                        dX = torch.empty(M, 128, device=dev, dtype=torch.float32)
+                        amax = ops.linear_bwd128_pair(dz, X[l], X[l - 1], _tpack16(pk, l, W), _tpack16(pk, l - 1, Wb), dX, dA_, dbA_, dB_, dbB_,
+                                                      lb_ws, amax_in=amax, accumulate=accA)
+                        grad_place(l, W, b, dA_, dbA_, accA, intoA)
+                        grad_place(l - 1, Wb, bb, dB_, dbB_, accB, intoB)
+                        dz = dX
+                        skip = True
+                        continue
                 # a hidden 128 -> 128 (or 64 -> 64) Linear over many rows: data gradient + ReLU mask + weight and bias gradients in ONE kernel
                 # (csrc/linear_bwd.hip: dz and X[l] are read once instead of twice, no partial-sum passes over [M, 128] arrays)
                 if (l > 0 and n == k == Np == Kp and Np in (128, 64) and M >= _FUSED_LAYER_ROWS and pk.layers[0][0].dtype == torch.float16
@@ -720,6 +767,7 @@ def _dense_source_of_block(m, srcs, ctx, M, c0, w, factored):
     return (si, float(scale)) if ok else None
 
 
+_LINEAR_BWD_PAIR = os.environ.get("MAGNET_LINEAR_BWD_PAIR", "1") != "0"     # A/B knob: 0 = every hidden Linear of a chain walked back by its own launch
 _FUSED_LAYER_ROWS = 4096          # below this the persistent one-workgroup-per-CU kernel leaves most of the chip idle
 
 

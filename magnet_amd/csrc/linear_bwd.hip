@@ -471,6 +471,282 @@ __global__ void __launch_bounds__(WIDTH * 4 / NB, WIDTH == 128 && NB == 1 ? 1 : 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// TWO consecutive hidden 128 -> 128 Linears walked back in one kernel (k_linear_bwd_r<128, 1>'s construction, eight waves, one workgroup per
+// CU): layer A (dz, x1 = its input, W_A) and the layer below it, B (x2 = its input, W_B):
+//     dzB = (x1 > 0) * (dz W_A)      dW_A += dz^T x1      db_A += colsum(dz)
+//     dx  = (x2 > 0) * (dzB W_B)     dW_B += dzB^T x2     db_B += colsum(dzB)
+// dzB never leaves the chip: 4 [M, 128] array passes (dz, x1, x2 in, dx out) instead of 6 - both single-layer launches are HBM-bound (dz + x
+// in, dx out at 5.2 TB/s).  dzB goes from the data GEMM's accumulators (lane = 4 consecutive in-features of one row) through the ReLU mask
+// and ONE fp16 split straight into the LDS image the second data GEMM and the second weight gradient read.  Its scale G2 cannot come from
+// its own maximum (nobody has seen it): it comes from the bound max|dzB| <= max|dz| * max_j sum_i |W_A[i][j]|, formed here from the wave's
+// own fragments of W_A^T (the fp16 high plane: within 2^-11 of the sum) - a few bits of headroom more than the measured maximum would
+// give, out of the 22 + 16 the split offers (k_linear_bwd_r's header).
+struct LinBwd2Args {
+    const float* dz;                    // [M][ldz] gradient at layer A's output
+    const float* x1;                    // [M][ldx1] layer A's input (= layer B's activated output)
+    const float* x2;                    // [M][ldx2] layer B's input
+    const u32x4* wtA;                   // fp16x3 planes of W_A^T / W_B^T packed as Linears [128 in][128 out]
+    const u32x4* wtB;
+    float* dx;                          // [M][lddx]
+    float* wpartA;                      // [grid][128][128] per-workgroup partial sums of dW_A / dW_B, [grid][128] of db_A / db_B
+    float* bpartA;
+    float* wpartB;
+    float* bpartB;
+    const float* amax_in;               // n_amax block maxima of |dz|
+    float* amax_out;                    // [grid] block maxima of |dx| (nullptr: not wanted)
+    long M;
+    int ldz, ldx1, ldx2, lddx, n_amax;
+};
+struct Lr2Buf {
+    unsigned short dz[2][32][LR_ST];    // [plane][row][position] G dz
+    unsigned short x1[2][32][LR_ST];
+    unsigned short x2[2][32][LR_ST];
+    unsigned short zb[2][32][LR_ST];    // G2 dzB (written behind the first data GEMM)
+    unsigned char pos1[32][32];         // ReLU masks of x1 / x2 (4 bits per lane and row, see LrBuf::pos)
+    unsigned char pos2[32][32];
+};
+__global__ void __launch_bounds__(512, 1) k_linear_bwd_r2(const LinBwd2Args a) {
+    constexpr int NW = 8, KT = 4, XB = 8, LPR = 32, RPI = 2, NLD = 2;
+    __shared__ __attribute__((aligned(16))) Lr2Buf sb[2];
+    __shared__ float gsc[NW];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n16 = lane & 15, q4 = lane >> 4;
+    float G, invG, amax_dz;
+    {
+        float m = 0.f;
+        for (int i = threadIdx.x; i < a.n_amax; i += 64 * NW) m = fmaxf(m, a.amax_in[i]);
+#pragma unroll
+        for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) gsc[wave] = m;
+        __syncthreads();
+        m = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) m = fmaxf(m, gsc[w]);
+        amax_dz = m;
+        const unsigned eb = (__float_as_uint(m) >> 23) & 0xFFu;
+        const bool ok = eb >= 14u && eb < 255u;
+        G = ok ? __uint_as_float((267u - eb) << 23) : 1.0f;                   // 2^(140-eb): G max|dz| < 2^14
+        invG = ok ? __uint_as_float((eb - 13u) << 23) : 1.0f;
+        G = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(G)));          // (uniform: scalar registers)
+        invG = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(invG)));
+        __syncthreads();
+    }
+    // ---- the wave's 16 in-features of W_A^T and W_B^T as A fragments (k_linear_bwd_r); on the way: sum_i |W_A[i][j]| of its in-features
+    f16x8 wAh[KT], wAl[KT], wBh[KT], wBl[KT];
+    float G2, invG2;
+    {
+        float colsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int idx = (((kt * KT + (wave >> 1)) * 2 + (q4 >> 1)) * 2) * 64 + 16 * (wave & 1) + n16 + 32 * (q4 & 1);
+            const u32x4 hA = a.wtA[idx];
+            const f16x8 hv = __builtin_bit_cast(f16x8, hA);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) colsum += fabsf((float)hv[c]);
+            wAh[kt] = __builtin_bit_cast(f16x8, scale_plane_2048(hA));
+            wAl[kt] = __builtin_bit_cast(f16x8, a.wtA[idx + 64]);
+            wBh[kt] = __builtin_bit_cast(f16x8, scale_plane_2048(a.wtB[idx]));
+            wBl[kt] = __builtin_bit_cast(f16x8, a.wtB[idx + 64]);
+        }
+        colsum += __shfl_xor(colsum, 16);                                     // the four k groups of an in-feature
+        colsum += __shfl_xor(colsum, 32);
+#pragma unroll
+        for (int o = 8; o; o >>= 1) colsum = fmaxf(colsum, __shfl_xor(colsum, o));   // the wave's 16 in-features
+        if (lane == 0) gsc[wave] = colsum;
+        __syncthreads();
+        float c = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) c = fmaxf(c, gsc[w]);
+        const float bound = amax_dz * c * 1.01f;                               // >= max|dzB|
+        const unsigned eb = (__float_as_uint(bound) >> 23) & 0xFFu;
+        const bool ok = eb >= 14u && eb < 255u;
+        G2 = ok ? __uint_as_float((267u - eb) << 23) : 1.0f;
+        invG2 = ok ? __uint_as_float((eb - 13u) << 23) : 1.0f;
+        G2 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(G2)));
+        invG2 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(invG2)));
+        __syncthreads();
+    }
+    const long nsteps = (a.M + 31) / 32;
+    const int l32 = lane & (LPR - 1), prow = (32 / NW) * wave + lane / LPR;
+    const int ppos = 16 * (l32 >> 2) + 8 * (l32 & 1) + 4 * ((l32 >> 1) & 1);
+    const int zpos = 16 * wave + 8 * (q4 & 1) + 4 * (q4 >> 1);                 // where this lane's four in-features sit in an image row
+    f32x4 dv[NLD], x1v[NLD], x2v[NLD];
+    auto load_rows = [&](long step) {
+        const long last = a.M - 1 - step * 32;
+        const float* bz = a.dz + step * 32 * a.ldz;
+        const float* b1 = a.x1 + step * 32 * a.ldx1;
+        const float* b2 = a.x2 + step * 32 * a.ldx2;
+        asm volatile("" : "+s"(bz), "+s"(b1), "+s"(b2));
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int rr = (int)min((long)(prow + RPI * k), last);            // (rows past the end: clamped here, zeroed below)
+            dv[k] = lr_ldg4(bz, ((unsigned)rr * (unsigned)a.ldz + 4u * l32) * 4u, 0);
+            x1v[k] = lr_ldg4(b1, ((unsigned)rr * (unsigned)a.ldx1 + 4u * l32) * 4u, 0);
+            x2v[k] = lr_ldg4(b2, ((unsigned)rr * (unsigned)a.ldx2 + 4u * l32) * 4u, 0);
+        }
+    };
+    f32x4 accwA[XB], accwB[XB];
+#pragma unroll
+    for (int xb = 0; xb < XB; ++xb) accwA[xb] = accwB[xb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsumA = 0.f, bsumB = 0.f, dxmax = 0.f;
+    long step = blockIdx.x;
+    if (step < nsteps) load_rows(step);
+    // dW slab += Z^T X over the step's 32 rows, colsum(Z) (k_linear_bwd_r's weight-gradient block)
+    auto wgrad = [&](const unsigned short (&Z)[2][32][LR_ST], const unsigned short (&X)[2][32][LR_ST], f32x4 (&accw)[XB], float& bsum) {
+        const int r0 = 4 * q4 + (n16 >> 2), c0 = 4 * (n16 & 3);
+        const int f = 16 * wave + c0;
+        const u32x2 a0 = lr_tr(&Z[0][r0][f]), a1 = lr_tr(&Z[0][16 + r0][f]);
+        const u32x2 b0 = lr_tr(&Z[1][r0][f]), b1 = lr_tr(&Z[1][16 + r0][f]);
+        const f16x8 ah = __builtin_bit_cast(f16x8, u32x4{a0[0], a0[1], a1[0], a1[1]});
+        const f16x8 al = __builtin_bit_cast(f16x8, u32x4{b0[0], b0[1], b1[0], b1[1]});
+        float cs = lr_dot_ones(a0[0], 0.f);
+        cs = lr_dot_ones(a0[1], cs), cs = lr_dot_ones(a1[0], cs), cs = lr_dot_ones(a1[1], cs);
+        cs = lr_dot_ones(b0[0], cs), cs = lr_dot_ones(b0[1], cs), cs = lr_dot_ones(b1[0], cs), cs = lr_dot_ones(b1[1], cs);
+        bsum += cs;
+#pragma unroll
+        for (int xb = 0; xb < XB; ++xb) {
+            const u32x2 p0 = lr_tr(&X[0][r0][16 * xb + c0]), p1 = lr_tr(&X[0][16 + r0][16 * xb + c0]);
+            const u32x2 q0 = lr_tr(&X[1][r0][16 * xb + c0]), q1 = lr_tr(&X[1][16 + r0][16 * xb + c0]);
+            const f16x8 xh = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p1[0], p1[1]});
+            const f16x8 xl = __builtin_bit_cast(f16x8, u32x4{q0[0], q0[1], q1[0], q1[1]});
+            accw[xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh, accw[xb], 0, 0, 0);
+            accw[xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl, accw[xb], 0, 0, 0);
+            accw[xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh, accw[xb], 0, 0, 0);
+        }
+    };
+    // acc[rb] = 2^11 (Z W)^T for rows 16 rb .., in-features 16 wave ..
+    auto gemm = [&](const unsigned short (&Z)[2][32][LR_ST], const f16x8 (&wh)[KT], const f16x8 (&wl)[KT], f32x4 (&acc)[2]) {
+        acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const f16x8 zh = *reinterpret_cast<const f16x8*>(&Z[0][16 * rb + n16][32 * kt + 8 * q4]);
+                const f16x8 zl = *reinterpret_cast<const f16x8*>(&Z[1][16 * rb + n16][32 * kt + 8 * q4]);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[kt], zh, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kt], zl, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[kt], zh, acc[rb], 0, 0, 0);
+            }
+    };
+    for (int it = 0; step < nsteps; step += gridDim.x, ++it) {
+        Lr2Buf& B = sb[it & 1];
+        // ---- this lane's NLD x 4 values of dz, x1, x2 as fp16 planes, once for the whole workgroup
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const bool pok = step * 32 + prow + RPI * k < a.M;
+            const f32x4 &d = dv[k], &u = x1v[k], &v = x2v[k];
+            u32x2 zh, zl, uh, ul, vh, vl;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                unsigned h, l;
+                split_f16_plain(pok ? d[2 * c] * G : 0.f, pok ? d[2 * c + 1] * G : 0.f, h, l);
+                zh[c] = h, zl[c] = l;
+                split_f16_plain(pok ? u[2 * c] : 0.f, pok ? u[2 * c + 1] : 0.f, h, l);
+                uh[c] = h, ul[c] = l;
+                split_f16_plain(pok ? v[2 * c] : 0.f, pok ? v[2 * c + 1] : 0.f, h, l);
+                vh[c] = h, vl[c] = l;
+            }
+            const int r = prow + RPI * k;
+            *reinterpret_cast<u32x2*>(&B.dz[0][r][ppos]) = zh;
+            *reinterpret_cast<u32x2*>(&B.dz[1][r][ppos]) = zl;
+            *reinterpret_cast<u32x2*>(&B.x1[0][r][ppos]) = uh;
+            *reinterpret_cast<u32x2*>(&B.x1[1][r][ppos]) = ul;
+            *reinterpret_cast<u32x2*>(&B.x2[0][r][ppos]) = vh;
+            *reinterpret_cast<u32x2*>(&B.x2[1][r][ppos]) = vl;
+            B.pos1[r][l32] = (unsigned char)((u[0] > 0.f ? 1 : 0) | (u[1] > 0.f ? 2 : 0) | (u[2] > 0.f ? 4 : 0) | (u[3] > 0.f ? 8 : 0));
+            B.pos2[r][l32] = (unsigned char)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) | (v[3] > 0.f ? 8 : 0));
+        }
+        float* const bdx = a.dx + step * 32 * a.lddx;
+        unsigned odx[2];
+        bool rok[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            rok[rb] = step * 32 + 16 * rb + n16 < a.M;
+            odx[rb] = ((unsigned)(16 * rb + n16) * (unsigned)a.lddx + 16u * wave + 4u * q4) * 4u;
+        }
+        asm volatile("" ::: "memory");
+        if (step + gridDim.x < nsteps) load_rows(step + gridDim.x);
+        asm volatile("" ::: "memory");
+        wg_barrier();                                                         // the step's planes of dz, x1, x2 are in LDS
+        // ---- layer A: data GEMM, then dzB = mask1 * (dz W_A) as planes into the image; its weight gradient
+        f32x4 acc[2];
+        gemm(B.dz, wAh, wAl, acc);
+        {
+            const float sc = (1.0f / 2048.0f) * invG * G2;                    // 2^11 G (dz W)  ->  G2 dzB
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const unsigned pm = B.pos1[16 * rb + n16][4 * wave + q4];      // in-features 16 wave + 4 q4 ..
+                float t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = ((pm >> i) & 1u) && rok[rb] ? acc[rb][i] * sc : 0.f;
+                unsigned h0, l0, h1, l1;
+                split_f16_plain(t[0], t[1], h0, l0);
+                split_f16_plain(t[2], t[3], h1, l1);
+                const u32x2 h = {h0, h1}, l = {l0, l1};
+                *reinterpret_cast<u32x2*>(&B.zb[0][16 * rb + n16][zpos]) = h;
+                *reinterpret_cast<u32x2*>(&B.zb[1][16 * rb + n16][zpos]) = l;
+            }
+        }
+        wgrad(B.dz, B.x1, accwA, bsumA);
+        wg_barrier();                                                         // dzB of all 128 in-features staged
+        // ---- layer B
+        gemm(B.zb, wBh, wBl, acc);
+        wgrad(B.zb, B.x2, accwB, bsumB);
+        {
+            float* bo = bdx;
+            asm volatile("" : "+s"(bo));
+            const float sc = (1.0f / 2048.0f) * invG2;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const unsigned pm = B.pos2[16 * rb + n16][4 * wave + q4];
+                f32x4 t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = acc[rb][i] * sc;
+                    v = (pm >> i) & 1u ? v : 0.f;
+                    t[i] = v;
+                    dxmax = fmaxf(dxmax, fabsf(v));
+                }
+                if (rok[rb]) lr_stg4(bo, odx[rb], 0, t);
+            }
+        }
+    }
+    // ---- this workgroup's partial sums
+    float* woA = a.wpartA + (size_t)blockIdx.x * 128 * 128;
+    float* woB = a.wpartB + (size_t)blockIdx.x * 128 * 128;
+#pragma unroll
+    for (int xb = 0; xb < XB; ++xb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t o = (size_t)(16 * wave + lr_sw(4 * q4 + i)) * 128 + 16 * xb + lr_sw(n16);
+            woA[o] = accwA[xb][i] * invG;
+            woB[o] = accwB[xb][i] * invG2;
+        }
+    {
+        float ba = bsumA, bb = bsumB;
+        ba += __shfl_xor(ba, 16), bb += __shfl_xor(bb, 16);
+        ba += __shfl_xor(ba, 32), bb += __shfl_xor(bb, 32);
+        if (q4 == 0) {
+            a.bpartA[(size_t)blockIdx.x * 128 + 16 * wave + lr_sw(n16)] = ba * invG;
+            a.bpartB[(size_t)blockIdx.x * 128 + 16 * wave + lr_sw(n16)] = bb * invG2;
+        }
+    }
+    if (a.amax_out) {
+#pragma unroll
+        for (int o = 32; o; o >>= 1) dxmax = fmaxf(dxmax, __shfl_xor(dxmax, o));
+        __syncthreads();
+        if (lane == 0) gsc[wave] = dxmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) m = fmaxf(m, gsc[w]);
+            a.amax_out[blockIdx.x] = m;
+        }
+    }
+}
+
 int magnet_launch_reduce_partials2(const float* pa, long na, float* oa, const float* pb, long nb_, float* ob, int nblk, float scale,
                                    int accumulate, void* stream);      // train_kernels.hip: both reductions in one launch
 
@@ -556,6 +832,49 @@ extern "C" int magnet_linear_bwd64_f32(const float* dz, int ldz, const float* x,
                                        int n_amax_in, float* amax_out, float* workspace, void* stream) {
     return launch_linear_bwd<2>(dz, ldz, x, ldx, wt_f16, M, mask, dx, lddx, dW, db, accumulate, amax_in, n_amax_in, amax_out, workspace,
                                 stream);
+}
+// Two consecutive hidden 128 -> 128 Linears in one kernel (k_linear_bwd_r2 above): layer A (dz, its input x1, W_A) and the layer below,
+// B (its input x2, W_B) - dx [M][lddx] = (x2 > 0) * (((x1 > 0) * (dz W_A)) W_B), dW_A (+)= dz^T x1, db_A (+)= colsum(dz), dW_B (+)= dzB^T x2,
+// db_B (+)= colsum(dzB).  wt*_f16, amax_in / amax_out (room for magnet_linear_bwd128_pair_grid(M) floats), workspace
+// (magnet_linear_bwd128_workspace floats) as magnet_linear_bwd128_f32.
+static int lb_pair_grid(long M) {
+    const long slots = lb_grid(1L << 40), steps = (M + 31) / 32;
+    return (int)(steps < slots ? steps : slots);
+}
+extern "C" int magnet_linear_bwd128_pair_grid(long M) { return lb_pair_grid(M); }
+extern "C" int magnet_linear_bwd128_pair_f32(const float* dz, int ldz, const float* x1, int ldx1, const float* x2, int ldx2,
+                                             const void* wtA_f16, const void* wtB_f16, long M, float* dx, int lddx, float* dWA, float* dbA,
+                                             float* dWB, float* dbB, int accumulate, const float* amax_in, int n_amax_in, float* amax_out,
+                                             float* workspace, void* stream) {
+    (void)hipGetLastError();
+    if (M <= 0) return 0;
+    if (ldz < 128 || ldx1 < 128 || ldx2 < 128 || lddx < 128 || (ldz | ldx1 | ldx2 | lddx) % 4) return -2;
+    const int grid = lb_pair_grid(M);
+    LinBwd2Args a;
+    a.dz = dz, a.ldz = ldz, a.x1 = x1, a.ldx1 = ldx1, a.x2 = x2, a.ldx2 = ldx2, a.dx = dx, a.lddx = lddx, a.M = M;
+    a.wtA = reinterpret_cast<const u32x4*>(wtA_f16), a.wtB = reinterpret_cast<const u32x4*>(wtB_f16);
+    a.wpartA = workspace;
+    a.bpartA = a.wpartA + (size_t)grid * 128 * 128;
+    a.wpartB = a.bpartA + (size_t)grid * 128;
+    a.bpartB = a.wpartB + (size_t)grid * 128 * 128;
+    float* own_amax = workspace + (size_t)2 * lb_grid(1L << 40) * (128 * 128 + 128);
+    if (amax_in) {
+        a.amax_in = amax_in, a.n_amax = n_amax_in;
+    } else {
+        if (ldz != 128) return -2;
+        const long n4 = M * 32;
+        const int nab = (int)(n4 / 256 + 1 < LB_AMAX_BLOCKS ? n4 / 256 + 1 : LB_AMAX_BLOCKS);
+        const int rc = magnet_launch_absmax_partial(dz, n4, own_amax, nab, stream);
+        if (rc) return rc;
+        a.amax_in = own_amax, a.n_amax = nab;
+    }
+    a.amax_out = amax_out;
+    hipLaunchKernelGGL(k_linear_bwd_r2, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    rc = magnet_launch_reduce_partials2(a.wpartA, 128L * 128, dWA, a.bpartA, 128L, dbA, grid, 1.0f, accumulate, stream);
+    if (rc) return rc;
+    return magnet_launch_reduce_partials2(a.wpartB, 128L * 128, dWB, a.bpartB, 128L, dbB, grid, 1.0f, accumulate, stream);
 }
 extern "C" int magnet_linear_bwd128_grid(long M) { return lb_grid_w(M, 4); }
 extern "C" int magnet_linear_bwd64_grid(long M) { return lb_grid_w(M, 2); }

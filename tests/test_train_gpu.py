@@ -1055,6 +1055,61 @@ def test_linear_bwd_generations_agree_with_fp64(W):
         L._QUERIES.clear()
 
 
+def test_linear_bwd_pair_agrees_with_fp64_and_with_two_single_layer_launches():
+    """magnet_linear_bwd128_pair_f32 (k_linear_bwd_r2: two consecutive hidden Linears, the gradient between them stays on the chip) against
+    fp64 and against two magnet_linear_bwd128_f32 launches, ragged row counts, strided x, accumulate, amax handed in / computed, and a
+    second layer whose gradient is 2^20 times smaller than the bound its scale comes from; block maxima exact; repeats bit-identical"""
+    from magnet_amd import _lib as L, ops
+    from magnet_amd.packing import pack
+    lib = L.lib()
+    g = torch.Generator(device="cuda").manual_seed(6)
+    ws = torch.empty(lib.magnet_linear_bwd128_workspace(), device="cuda")
+    for case in ("plain", "small_wa"):
+        WA = torch.randn(128, 128, device="cuda", generator=g) * (0.1 if case == "plain" else 1e-3)
+        if case == "small_wa":
+            WA[3, 5] = 20.0                                   # one large weight: the column-sum bound is far above what dzB reaches
+        WB = torch.randn(128, 128, device="cuda", generator=g) * 0.1
+        wtA, wtB = pack(WA.t().contiguous(), None, "fp16x3")[0], pack(WB.t().contiguous(), None, "fp16x3")[0]
+        for M in (1, 33, 4097, 70001):
+            dz = torch.randn(M, 128, device="cuda", generator=g) * 1e-7
+            x1f = torch.relu(torch.randn(M, 160, device="cuda", generator=g))
+            x1 = x1f[:, 16:144]
+            x2 = torch.relu(torch.randn(M, 128, device="cuda", generator=g))
+            dzB = (dz.double() @ WA.double()) * (x1 > 0).double()
+            want_dx = (dzB @ WB.double()) * (x2 > 0).double()
+            want = (want_dx, dz.double().t() @ x1.double(), dz.double().sum(0), dzB.t() @ x2.double(), dzB.sum(0))
+            # (sums of terms of both signs: an error is measured against the sum of the terms' magnitudes - 'small_wa' makes one column of dzB
+            #  2e4 times larger than the rest and its column sum a thousandth of that)
+            scale = (want_dx.abs(), dz.double().abs().t() @ x1.double(), dz.double().abs().sum(0), dzB.abs().t() @ x2.double(), dzB.abs().sum(0))
+            out = []
+            for rep in range(2):
+                dx = torch.full((M, 128), 7.0, device="cuda")
+                dWA, dbA, dWB, dbB = (torch.empty(128, 128, device="cuda"), torch.empty(128, device="cuda"),
+                                      torch.empty(128, 128, device="cuda"), torch.empty(128, device="cuda"))
+                am, n = ops.linear_bwd128_pair(dz, x1, x2, wtA, wtB, dx, dWA, dbA, dWB, dbB, ws)
+                out.append((dx, dWA, dbA, dWB, dbB))
+            for got, w_, sc_, tol in zip(out[0], want, scale, (1e-6, 2e-6, 1e-6, 3e-6, 2e-6)):
+                if case == "plain":
+                    assert rel_l2(got, w_) < tol, (case, M, rel_l2(got, w_))
+                err = float((got.double() - w_).norm() / sc_.norm().clamp_min(1e-300))
+                assert err < 3e-7, (case, M, err)
+            assert float(am[:n].max()) == float(out[0][0].abs().max()), (case, M)
+            assert all(torch.equal(a, b) for a, b in zip(out[0], out[1])), (case, M)
+            # against the two single-layer launches, with the maxima handed in and accumulation into what is there
+            mid, dW1, db1 = torch.empty(M, 128, device="cuda"), torch.ones(128, 128, device="cuda"), torch.ones(128, device="cuda")
+            dx2, dW2, db2 = torch.empty(M, 128, device="cuda"), torch.ones(128, 128, device="cuda"), torch.ones(128, device="cuda")
+            am1 = ops.linear_bwd128(dz, x1, wtA, mid, dW1, db1, ws, mask=True, accumulate=True)
+            ops.linear_bwd128(mid, x2, wtB, dx2, dW2, db2, ws, mask=True, amax_in=am1, accumulate=True)
+            dx, a1, a2, a3, a4 = (torch.empty(M, 128, device="cuda"), torch.ones(128, 128, device="cuda"), torch.ones(128, device="cuda"),
+                                  torch.ones(128, 128, device="cuda"), torch.ones(128, device="cuda"))
+            amx = torch.zeros(256, device="cuda")
+            amx[0] = dz.abs().max()
+            ops.linear_bwd128_pair(dz, x1, x2, wtA, wtB, dx, a1, a2, a3, a4, ws, amax_in=(amx, 256), want_amax=False, accumulate=True)
+            for got, ref, sc_ in zip((dx, a1 - 1, a2 - 1, a3 - 1, a4 - 1), (dx2, dW1 - 1, db1 - 1, dW2 - 1, db2 - 1), scale):
+                # (the `+ 1 - 1` of the accumulate check costs 6e-8 absolute: gradients of 1e-7 drown in it - compared on that scale)
+                assert float((got - ref).abs().max()) < 5e-7 + 1e-6 * float(sc_.max()), (case, M)
+
+
 def test_dense_source_gradients_written_by_the_data_gemm_equal_the_copy_and_add_path():
     """autograd._Mlp.backward writes the gradient of a dense full-width source from the first Linear's data GEMM itself (residual dy or
     the running sum of the processor's e0 gradient chain added in the epilogue); MAGNET_DIRECT_SRC_GRAD=0 is the old path (dX0, column
