@@ -494,6 +494,10 @@ int magnet_linear_bwd128_f32(const float* dz, int ldz, const float* x, int ldx, 
  * - the gradient between the two layers never leaves the chip (four [M, 128] array passes instead of six).  Arguments as
  * magnet_linear_bwd128_f32 (same workspace function); amax_out: NULL or room for magnet_linear_bwd128_pair_grid(M) floats. */
 int magnet_linear_bwd128_pair_grid(long M);
+int magnet_linear_bwd64_pair_grid(long M);      /* ... and the 64 -> 64 twin (dW [64][64], db [64]; the hidden width of MAgNet[CNN]'s MLPs) */
+int magnet_linear_bwd64_pair_f32(const float* dz, int ldz, const float* x1, int ldx1, const float* x2, int ldx2, const void* wtA_f16,
+                                 const void* wtB_f16, long M, float* dx, int lddx, float* dWA, float* dbA, float* dWB, float* dbB,
+                                 int accumulate, const float* amax_in, int n_amax_in, float* amax_out, float* workspace, void* stream);
 int magnet_linear_bwd128_pair_f32(const float* dz, int ldz, const float* x1, int ldx1, const float* x2, int ldx2, const void* wtA_f16,
                                   const void* wtB_f16, long M, float* dx, int lddx, float* dWA, float* dbA, float* dWB, float* dbB,
                                   int accumulate, const float* amax_in, int n_amax_in, float* amax_out, float* workspace, void* stream);

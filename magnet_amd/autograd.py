@@ -525,16 +525,16 @@ class _Mlp(torch.autograd.Function):
                 W, b = params[2 * l], params[2 * l + 1]
                 n, k = W.shape
                 Np, Kp = dz.shape[1], (K0 if (l == 0 and x0_dense is not None) else X[l].shape[1])
-                # two consecutive hidden 128 -> 128 Linears in ONE kernel: the gradient between them never leaves the chip (four [M, 128]
+                # two consecutive hidden 128 -> 128 (64 -> 64) Linears in ONE kernel: the gradient between them never leaves the chip (four [M, W]
                 # array passes instead of six; magnet_linear_bwd128_pair_f32)
-                if (_LINEAR_BWD_PAIR and Np == 128 and n == k == Kp == 128 and dz.is_contiguous() and fused_ok(l, 128) and fused_ok(l - 1, 128)):
+                if (_LINEAR_BWD_PAIR and Np in (128, 64) and n == k == Kp == Np and dz.is_contiguous() and fused_ok(l, Np) and fused_ok(l - 1, Np)):
                     Wb, bb = params[2 * (l - 1)], params[2 * (l - 1) + 1]
-                    dA_, dbA_, accA, intoA = grad_dest(W, b, 128)
-                    dB_, dbB_, accB, intoB = grad_dest(Wb, bb, 128)
+                    dA_, dbA_, accA, intoA = grad_dest(W, b, Np)
+                    dB_, dbB_, accB, intoB = grad_dest(Wb, bb, Np)
                     if accA == accB:
                         if lb_ws is None:
                             lb_ws = torch.empty(L.query("magnet_linear_bwd128_workspace"), device=dev, dtype=torch.float32)
-                        dX = torch.empty(M, 128, device=dev, dtype=torch.float32)
+                        dX = torch.empty(M, Np, device=dev, dtype=torch.float32)
                         amax = ops.linear_bwd128_pair(dz, X[l], X[l - 1], _tpack16(pk, l, W), _tpack16(pk, l - 1, Wb), dX, dA_, dbA_, dB_, dbB_,
                                                       lb_ws, amax_in=amax, accumulate=accA)
                         grad_place(l, W, b, dA_, dbA_, accA, intoA)

@@ -498,17 +498,24 @@ struct LinBwd2Args {
     long M;
     int ldz, ldx1, ldx2, lddx, n_amax;
 };
+template <int ST, int LPR>
 struct Lr2Buf {
-    unsigned short dz[2][32][LR_ST];    // [plane][row][position] G dz
-    unsigned short x1[2][32][LR_ST];
-    unsigned short x2[2][32][LR_ST];
-    unsigned short zb[2][32][LR_ST];    // G2 dzB (written behind the first data GEMM)
-    unsigned char pos1[32][32];         // ReLU masks of x1 / x2 (4 bits per lane and row, see LrBuf::pos)
-    unsigned char pos2[32][32];
+    unsigned short dz[2][32][ST];       // [plane][row][position] G dz
+    unsigned short x1[2][32][ST];
+    unsigned short x2[2][32][ST];
+    unsigned char pos1[32][LPR];        // ReLU masks of x1 / x2 (4 bits per lane and row, see LrBuf::pos)
+    unsigned char pos2[32][LPR];
 };
-__global__ void __launch_bounds__(512, 1) k_linear_bwd_r2(const LinBwd2Args a) {
-    constexpr int NW = 8, KT = 4, XB = 8, LPR = 32, RPI = 2, NLD = 2;
-    __shared__ __attribute__((aligned(16))) Lr2Buf sb[2];
+// WIDTH = 128: eight waves, one workgroup per CU; 64 (MAgNet[CNN]'s chains): four waves, two workgroups per CU (k_linear_bwd_r<64, 1>'s shape)
+template <int WIDTH>
+__global__ void __launch_bounds__(WIDTH * 4, WIDTH == 128 ? 1 : 2) k_linear_bwd_r2(const LinBwd2Args a) {
+    constexpr int NW = WIDTH / 16, KT = WIDTH / 32, XB = WIDTH / 16, ST = WIDTH == 128 ? LR_ST : 80;
+    constexpr int LPR = WIDTH / 4, RPI = 64 / LPR, NLD = 32 / NW / RPI;
+    typedef Lr2Buf<ST, LPR> Buf;
+    typedef unsigned short Img[2][32][ST];
+    __shared__ __attribute__((aligned(16))) Buf sb[2];
+    __shared__ __attribute__((aligned(16))) Img zbuf;                          // G2 dzB (written behind the first data GEMM; one image:
+                                                                              //  its next writer has passed the step's first barrier)
     __shared__ float gsc[NW];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n16 = lane & 15, q4 = lane >> 4;
@@ -593,7 +600,7 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r2(const LinBwd2Args a) {
     long step = blockIdx.x;
     if (step < nsteps) load_rows(step);
     // dW slab += Z^T X over the step's 32 rows, colsum(Z) (k_linear_bwd_r's weight-gradient block)
-    auto wgrad = [&](const unsigned short (&Z)[2][32][LR_ST], const unsigned short (&X)[2][32][LR_ST], f32x4 (&accw)[XB], float& bsum) {
+    auto wgrad = [&](const Img& Z, const Img& X, f32x4 (&accw)[XB], float& bsum) {
         const int r0 = 4 * q4 + (n16 >> 2), c0 = 4 * (n16 & 3);
         const int f = 16 * wave + c0;
         const u32x2 a0 = lr_tr(&Z[0][r0][f]), a1 = lr_tr(&Z[0][16 + r0][f]);
@@ -616,7 +623,7 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r2(const LinBwd2Args a) {
         }
     };
     // acc[rb] = 2^11 (Z W)^T for rows 16 rb .., in-features 16 wave ..
-    auto gemm = [&](const unsigned short (&Z)[2][32][LR_ST], const f16x8 (&wh)[KT], const f16x8 (&wl)[KT], f32x4 (&acc)[2]) {
+    auto gemm = [&](const Img& Z, const f16x8 (&wh)[KT], const f16x8 (&wl)[KT], f32x4 (&acc)[2]) {
         acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
@@ -630,7 +637,7 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r2(const LinBwd2Args a) {
             }
     };
     for (int it = 0; step < nsteps; step += gridDim.x, ++it) {
-        Lr2Buf& B = sb[it & 1];
+        Buf& B = sb[it & 1];
         // ---- this lane's NLD x 4 values of dz, x1, x2 as fp16 planes, once for the whole workgroup
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
@@ -684,15 +691,15 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r2(const LinBwd2Args a) {
                 split_f16_plain(t[0], t[1], h0, l0);
                 split_f16_plain(t[2], t[3], h1, l1);
                 const u32x2 h = {h0, h1}, l = {l0, l1};
-                *reinterpret_cast<u32x2*>(&B.zb[0][16 * rb + n16][zpos]) = h;
-                *reinterpret_cast<u32x2*>(&B.zb[1][16 * rb + n16][zpos]) = l;
+                *reinterpret_cast<u32x2*>(&zbuf[0][16 * rb + n16][zpos]) = h;
+                *reinterpret_cast<u32x2*>(&zbuf[1][16 * rb + n16][zpos]) = l;
             }
         }
         wgrad(B.dz, B.x1, accwA, bsumA);
         wg_barrier();                                                         // dzB of all 128 in-features staged
         // ---- layer B
-        gemm(B.zb, wBh, wBl, acc);
-        wgrad(B.zb, B.x2, accwB, bsumB);
+        gemm(zbuf, wBh, wBl, acc);
+        wgrad(zbuf, B.x2, accwB, bsumB);
         {
             float* bo = bdx;
             asm volatile("" : "+s"(bo));
@@ -713,13 +720,13 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r2(const LinBwd2Args a) {
         }
     }
     // ---- this workgroup's partial sums
-    float* woA = a.wpartA + (size_t)blockIdx.x * 128 * 128;
-    float* woB = a.wpartB + (size_t)blockIdx.x * 128 * 128;
+    float* woA = a.wpartA + (size_t)blockIdx.x * WIDTH * WIDTH;
+    float* woB = a.wpartB + (size_t)blockIdx.x * WIDTH * WIDTH;
 #pragma unroll
     for (int xb = 0; xb < XB; ++xb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const size_t o = (size_t)(16 * wave + lr_sw(4 * q4 + i)) * 128 + 16 * xb + lr_sw(n16);
+            const size_t o = (size_t)(16 * wave + lr_sw(4 * q4 + i)) * WIDTH + 16 * xb + lr_sw(n16);
             woA[o] = accwA[xb][i] * invG;
             woB[o] = accwB[xb][i] * invG2;
         }
@@ -728,8 +735,8 @@ __global__ void __launch_bounds__(512, 1) k_linear_bwd_r2(const LinBwd2Args a) {
         ba += __shfl_xor(ba, 16), bb += __shfl_xor(bb, 16);
         ba += __shfl_xor(ba, 32), bb += __shfl_xor(bb, 32);
         if (q4 == 0) {
-            a.bpartA[(size_t)blockIdx.x * 128 + 16 * wave + lr_sw(n16)] = ba * invG;
-            a.bpartB[(size_t)blockIdx.x * 128 + 16 * wave + lr_sw(n16)] = bb * invG2;
+            a.bpartA[(size_t)blockIdx.x * WIDTH + 16 * wave + lr_sw(n16)] = ba * invG;
+            a.bpartB[(size_t)blockIdx.x * WIDTH + 16 * wave + lr_sw(n16)] = bb * invG2;
         }
     }
     if (a.amax_out) {
@@ -837,44 +844,60 @@ extern "C" int magnet_linear_bwd64_f32(const float* dz, int ldz, const float* x,
 // B (its input x2, W_B) - dx [M][lddx] = (x2 > 0) * (((x1 > 0) * (dz W_A)) W_B), dW_A (+)= dz^T x1, db_A (+)= colsum(dz), dW_B (+)= dzB^T x2,
 // db_B (+)= colsum(dzB).  wt*_f16, amax_in / amax_out (room for magnet_linear_bwd128_pair_grid(M) floats), workspace
 // (magnet_linear_bwd128_workspace floats) as magnet_linear_bwd128_f32.
-static int lb_pair_grid(long M) {
-    const long slots = lb_grid(1L << 40), steps = (M + 31) / 32;
+static int lb_pair_grid(long M, int per_cu = 1) {
+    const long slots = (long)lb_grid(1L << 40) * per_cu, steps = (M + 31) / 32;
     return (int)(steps < slots ? steps : slots);
 }
 extern "C" int magnet_linear_bwd128_pair_grid(long M) { return lb_pair_grid(M); }
-extern "C" int magnet_linear_bwd128_pair_f32(const float* dz, int ldz, const float* x1, int ldx1, const float* x2, int ldx2,
+extern "C" int magnet_linear_bwd64_pair_grid(long M) { return lb_pair_grid(M, 2); }
+template <int W>
+static int launch_linear_bwd_pair(const float* dz, int ldz, const float* x1, int ldx1, const float* x2, int ldx2,
                                              const void* wtA_f16, const void* wtB_f16, long M, float* dx, int lddx, float* dWA, float* dbA,
                                              float* dWB, float* dbB, int accumulate, const float* amax_in, int n_amax_in, float* amax_out,
                                              float* workspace, void* stream) {
     (void)hipGetLastError();
     if (M <= 0) return 0;
-    if (ldz < 128 || ldx1 < 128 || ldx2 < 128 || lddx < 128 || (ldz | ldx1 | ldx2 | lddx) % 4) return -2;
-    const int grid = lb_pair_grid(M);
+    if (ldz < W || ldx1 < W || ldx2 < W || lddx < W || (ldz | ldx1 | ldx2 | lddx) % 4) return -2;
+    const int grid = lb_pair_grid(M, W == 128 ? 1 : 2);
     LinBwd2Args a;
     a.dz = dz, a.ldz = ldz, a.x1 = x1, a.ldx1 = ldx1, a.x2 = x2, a.ldx2 = ldx2, a.dx = dx, a.lddx = lddx, a.M = M;
     a.wtA = reinterpret_cast<const u32x4*>(wtA_f16), a.wtB = reinterpret_cast<const u32x4*>(wtB_f16);
     a.wpartA = workspace;
-    a.bpartA = a.wpartA + (size_t)grid * 128 * 128;
-    a.wpartB = a.bpartA + (size_t)grid * 128;
-    a.bpartB = a.wpartB + (size_t)grid * 128 * 128;
+    a.bpartA = a.wpartA + (size_t)grid * W * W;
+    a.wpartB = a.bpartA + (size_t)grid * W;
+    a.bpartB = a.wpartB + (size_t)grid * W * W;
     float* own_amax = workspace + (size_t)2 * lb_grid(1L << 40) * (128 * 128 + 128);
     if (amax_in) {
         a.amax_in = amax_in, a.n_amax = n_amax_in;
     } else {
-        if (ldz != 128) return -2;
-        const long n4 = M * 32;
+        if (ldz != W) return -2;
+        const long n4 = M * (W / 4);
         const int nab = (int)(n4 / 256 + 1 < LB_AMAX_BLOCKS ? n4 / 256 + 1 : LB_AMAX_BLOCKS);
         const int rc = magnet_launch_absmax_partial(dz, n4, own_amax, nab, stream);
         if (rc) return rc;
         a.amax_in = own_amax, a.n_amax = nab;
     }
     a.amax_out = amax_out;
-    hipLaunchKernelGGL(k_linear_bwd_r2, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_linear_bwd_r2<W>, dim3(grid), dim3(W * 4), 0, (hipStream_t)stream, a);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
-    rc = magnet_launch_reduce_partials2(a.wpartA, 128L * 128, dWA, a.bpartA, 128L, dbA, grid, 1.0f, accumulate, stream);
+    rc = magnet_launch_reduce_partials2(a.wpartA, (long)W * W, dWA, a.bpartA, (long)W, dbA, grid, 1.0f, accumulate, stream);
     if (rc) return rc;
-    return magnet_launch_reduce_partials2(a.wpartB, 128L * 128, dWB, a.bpartB, 128L, dbB, grid, 1.0f, accumulate, stream);
+    return magnet_launch_reduce_partials2(a.wpartB, (long)W * W, dWB, a.bpartB, (long)W, dbB, grid, 1.0f, accumulate, stream);
+}
+extern "C" int magnet_linear_bwd128_pair_f32(const float* dz, int ldz, const float* x1, int ldx1, const float* x2, int ldx2,
+                                             const void* wtA_f16, const void* wtB_f16, long M, float* dx, int lddx, float* dWA, float* dbA,
+                                             float* dWB, float* dbB, int accumulate, const float* amax_in, int n_amax_in, float* amax_out,
+                                             float* workspace, void* stream) {
+    return launch_linear_bwd_pair<128>(dz, ldz, x1, ldx1, x2, ldx2, wtA_f16, wtB_f16, M, dx, lddx, dWA, dbA, dWB, dbB, accumulate, amax_in,
+                                       n_amax_in, amax_out, workspace, stream);
+}
+extern "C" int magnet_linear_bwd64_pair_f32(const float* dz, int ldz, const float* x1, int ldx1, const float* x2, int ldx2,
+                                            const void* wtA_f16, const void* wtB_f16, long M, float* dx, int lddx, float* dWA, float* dbA,
+                                            float* dWB, float* dbB, int accumulate, const float* amax_in, int n_amax_in, float* amax_out,
+                                            float* workspace, void* stream) {
+    return launch_linear_bwd_pair<64>(dz, ldz, x1, ldx1, x2, ldx2, wtA_f16, wtB_f16, M, dx, lddx, dWA, dbA, dWB, dbB, accumulate, amax_in,
+                                      n_amax_in, amax_out, workspace, stream);
 }
 extern "C" int magnet_linear_bwd128_grid(long M) { return lb_grid_w(M, 4); }
 extern "C" int magnet_linear_bwd64_grid(long M) { return lb_grid_w(M, 2); }

@@ -697,16 +697,17 @@ def linear_bwd128(dz, x, wt_f16, dx, dW, db, ws, mask=True, amax_in=None, want_a
 
 
 def linear_bwd128_pair(dz, x1, x2, wtA_f16, wtB_f16, dx, dWA, dbA, dWB, dbB, ws, amax_in=None, want_amax=True, accumulate=False):
-    """two consecutive hidden 128 -> 128 Linears (A above B) walked back in one kernel: dx = (x2 > 0) * (((x1 > 0) * (dz W_A)) W_B), the two
+    """two consecutive hidden W -> W Linears (A above B; W = dz.shape[1]: 128 or 64) walked back in one kernel: dx = (x2 > 0) * (((x1 > 0) * (dz W_A)) W_B), the two
     weight / bias gradients written (or added to with ``accumulate``); ``amax_in`` / return value as linear_bwd128"""
     M, W = dz.shape
-    assert W == 128 and x1.shape[1] >= 128 and x2.shape[1] >= 128
+    assert W in (128, 64) and x1.shape[1] >= W and x2.shape[1] >= W
     for t in (dWA, dWB):
-        assert t.is_contiguous() and t.shape == (128, 128)
+        assert t.is_contiguous() and t.shape == (W, W)
     assert dbA.is_contiguous() and dbB.is_contiguous()
-    n_out = L.query("magnet_linear_bwd128_pair_grid", int(M))
+    n_out = L.query("magnet_linear_bwd128_pair_grid" if W == 128 else "magnet_linear_bwd64_pair_grid", int(M))
     amax_out = torch.empty(max(n_out, 1), device=dz.device, dtype=torch.float32) if want_amax else None
-    L.check(L.lib().magnet_linear_bwd128_pair_f32(_p(dz), dz.stride(0), _p(x1), x1.stride(0), _p(x2), x2.stride(0), _p(wtA_f16), _p(wtB_f16),
+    fn = L.lib().magnet_linear_bwd128_pair_f32 if W == 128 else L.lib().magnet_linear_bwd64_pair_f32
+    L.check(fn(_p(dz), dz.stride(0), _p(x1), x1.stride(0), _p(x2), x2.stride(0), _p(wtA_f16), _p(wtB_f16),
                                                   C.c_long(M), _p(dx), dx.stride(0), _p(dWA), _p(dbA), _p(dWB), _p(dbB), int(bool(accumulate)),
                                                   _p(amax_in[0]) if amax_in else None, int(amax_in[1]) if amax_in else 0, _p(amax_out),
                                                   _p(ws), _stream()), "linear_bwd_pair")

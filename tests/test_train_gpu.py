@@ -1055,7 +1055,8 @@ def test_linear_bwd_generations_agree_with_fp64(W):
         L._QUERIES.clear()
 
 
-def test_linear_bwd_pair_agrees_with_fp64_and_with_two_single_layer_launches():
+@pytest.mark.parametrize("W", [128, 64])
+def test_linear_bwd_pair_agrees_with_fp64_and_with_two_single_layer_launches(W):
     """magnet_linear_bwd128_pair_f32 (k_linear_bwd_r2: two consecutive hidden Linears, the gradient between them stays on the chip) against
     fp64 and against two magnet_linear_bwd128_f32 launches, ragged row counts, strided x, accumulate, amax handed in / computed, and a
     second layer whose gradient is 2^20 times smaller than the bound its scale comes from; block maxima exact; repeats bit-identical"""
@@ -1065,16 +1066,16 @@ def test_linear_bwd_pair_agrees_with_fp64_and_with_two_single_layer_launches():
     g = torch.Generator(device="cuda").manual_seed(6)
     ws = torch.empty(lib.magnet_linear_bwd128_workspace(), device="cuda")
     for case in ("plain", "small_wa"):
-        WA = torch.randn(128, 128, device="cuda", generator=g) * (0.1 if case == "plain" else 1e-3)
+        WA = torch.randn(W, W, device="cuda", generator=g) * (0.1 if case == "plain" else 1e-3)
         if case == "small_wa":
             WA[3, 5] = 20.0                                   # one large weight: the column-sum bound is far above what dzB reaches
-        WB = torch.randn(128, 128, device="cuda", generator=g) * 0.1
+        WB = torch.randn(W, W, device="cuda", generator=g) * 0.1
         wtA, wtB = pack(WA.t().contiguous(), None, "fp16x3")[0], pack(WB.t().contiguous(), None, "fp16x3")[0]
         for M in (1, 33, 4097, 70001):
-            dz = torch.randn(M, 128, device="cuda", generator=g) * 1e-7
-            x1f = torch.relu(torch.randn(M, 160, device="cuda", generator=g))
-            x1 = x1f[:, 16:144]
-            x2 = torch.relu(torch.randn(M, 128, device="cuda", generator=g))
+            dz = torch.randn(M, W, device="cuda", generator=g) * 1e-7
+            x1f = torch.relu(torch.randn(M, W + 32, device="cuda", generator=g))
+            x1 = x1f[:, 16:16 + W]
+            x2 = torch.relu(torch.randn(M, W, device="cuda", generator=g))
             dzB = (dz.double() @ WA.double()) * (x1 > 0).double()
             want_dx = (dzB @ WB.double()) * (x2 > 0).double()
             want = (want_dx, dz.double().t() @ x1.double(), dz.double().sum(0), dzB.t() @ x2.double(), dzB.sum(0))
@@ -1083,9 +1084,9 @@ def test_linear_bwd_pair_agrees_with_fp64_and_with_two_single_layer_launches():
             scale = (want_dx.abs(), dz.double().abs().t() @ x1.double(), dz.double().abs().sum(0), dzB.abs().t() @ x2.double(), dzB.abs().sum(0))
             out = []
             for rep in range(2):
-                dx = torch.full((M, 128), 7.0, device="cuda")
-                dWA, dbA, dWB, dbB = (torch.empty(128, 128, device="cuda"), torch.empty(128, device="cuda"),
-                                      torch.empty(128, 128, device="cuda"), torch.empty(128, device="cuda"))
+                dx = torch.full((M, W), 7.0, device="cuda")
+                dWA, dbA, dWB, dbB = (torch.empty(W, W, device="cuda"), torch.empty(W, device="cuda"),
+                                      torch.empty(W, W, device="cuda"), torch.empty(W, device="cuda"))
                 am, n = ops.linear_bwd128_pair(dz, x1, x2, wtA, wtB, dx, dWA, dbA, dWB, dbB, ws)
                 out.append((dx, dWA, dbA, dWB, dbB))
             for got, w_, sc_, tol in zip(out[0], want, scale, (1e-6, 2e-6, 1e-6, 3e-6, 2e-6)):
@@ -1096,12 +1097,12 @@ def test_linear_bwd_pair_agrees_with_fp64_and_with_two_single_layer_launches():
             assert float(am[:n].max()) == float(out[0][0].abs().max()), (case, M)
             assert all(torch.equal(a, b) for a, b in zip(out[0], out[1])), (case, M)
             # against the two single-layer launches, with the maxima handed in and accumulation into what is there
-            mid, dW1, db1 = torch.empty(M, 128, device="cuda"), torch.ones(128, 128, device="cuda"), torch.ones(128, device="cuda")
-            dx2, dW2, db2 = torch.empty(M, 128, device="cuda"), torch.ones(128, 128, device="cuda"), torch.ones(128, device="cuda")
+            mid, dW1, db1 = torch.empty(M, W, device="cuda"), torch.ones(W, W, device="cuda"), torch.ones(W, device="cuda")
+            dx2, dW2, db2 = torch.empty(M, W, device="cuda"), torch.ones(W, W, device="cuda"), torch.ones(W, device="cuda")
             am1 = ops.linear_bwd128(dz, x1, wtA, mid, dW1, db1, ws, mask=True, accumulate=True)
             ops.linear_bwd128(mid, x2, wtB, dx2, dW2, db2, ws, mask=True, amax_in=am1, accumulate=True)
-            dx, a1, a2, a3, a4 = (torch.empty(M, 128, device="cuda"), torch.ones(128, 128, device="cuda"), torch.ones(128, device="cuda"),
-                                  torch.ones(128, 128, device="cuda"), torch.ones(128, device="cuda"))
+            dx, a1, a2, a3, a4 = (torch.empty(M, W, device="cuda"), torch.ones(W, W, device="cuda"), torch.ones(W, device="cuda"),
+                                  torch.ones(W, W, device="cuda"), torch.ones(W, device="cuda"))
             amx = torch.zeros(256, device="cuda")
             amx[0] = dz.abs().max()
             ops.linear_bwd128_pair(dz, x1, x2, wtA, wtB, dx, a1, a2, a3, a4, ws, amax_in=(amx, 256), want_amax=False, accumulate=True)
