@@ -573,20 +573,24 @@ def test_differentiable_fused_mlp_matches_torch_autograd(hidden, D, epi):
         assert rel_l2(a_, b_) < tol, i
 
 
+@pytest.mark.parametrize("pair", [True, False])
 @pytest.mark.parametrize("hidden,D,epi", [(128, 128, "segmean"), (128, 128, "res"), (128, 1, "store"), (64, 32, "segmean"), (64, 10, "store")])
-def test_differentiable_fused_mlp_with_the_one_kernel_layer_backward(hidden, D, epi, monkeypatch):
-    """the same comparison with the hidden 128 -> 128 Linears walked back by k_linear_bwd128 (ops.linear_bwd128; the models take that
-    path from 4096 rows on): forced on at these row counts, and checked that it really ran"""
+def test_differentiable_fused_mlp_with_the_one_kernel_layer_backward(hidden, D, epi, pair, monkeypatch):
+    """the same comparison with the hidden 128 -> 128 Linears walked back by csrc/linear_bwd.hip (ops.linear_bwd128_pair: two layers per
+    launch; ops.linear_bwd128: one, ``pair`` off or an odd layer left over; the models take that path from 4096 rows on): forced on at
+    these row counts, and checked that it really ran"""
     from magnet_amd import autograd as AG, ops
     calls = []
-    orig = ops.linear_bwd128
+    orig, orig_pair = ops.linear_bwd128, ops.linear_bwd128_pair
     monkeypatch.setattr(AG, "_FUSED_LAYER_ROWS", 1)
+    monkeypatch.setattr(AG, "_LINEAR_BWD_PAIR", pair)
     monkeypatch.setattr(ops, "linear_bwd128", lambda *a, **k: (calls.append(a[0].shape[0]), orig(*a, **k))[1])
+    monkeypatch.setattr(ops, "linear_bwd128_pair", lambda *a, **k: (calls.extend([a[0].shape[0]] * 2), orig_pair(*a, **k))[1])
     fact = []
     orig_f = AG._first_layer_at_source_rows
     monkeypatch.setattr(AG, "_first_layer_at_source_rows", lambda *a, **k: (fact.append(sum(a[6])), orig_f(*a, **k))[1])
     test_differentiable_fused_mlp_matches_torch_autograd(hidden, D, epi)
-    assert len(calls) == (4 if D == hidden else 3), calls            # layers 4..1 (the last Linear only when it is square)
+    assert len(calls) == (4 if D == hidden else 3), calls            # layers 4..1 (the last Linear only when it is square); a pair counts twice
     # the gathered node terms of the edge chain ([x_i | x_j | e]: 2 of 3 blocks) took the source-granularity first layer
     assert fact == ([2 * (128 if hidden == 128 else 32) // 32] if epi == "segmean" else []), fact
 
