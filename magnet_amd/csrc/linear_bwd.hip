@@ -756,6 +756,8 @@ __global__ void __launch_bounds__(WIDTH * 4, WIDTH == 128 ? 1 : 2) k_linear_bwd_
 
 int magnet_launch_reduce_partials2(const float* pa, long na, float* oa, const float* pb, long nb_, float* ob, int nblk, float scale,
                                    int accumulate, void* stream);      // train_kernels.hip: both reductions in one launch
+int magnet_launch_reduce_partials2x2(const float* pa, long na, float* oa, const float* pb, long nb_, float* ob, const float* pa2, float* oa2,
+                                     const float* pb2, float* ob2, int nblk, float scale, int accumulate, void* stream);
 
 static int lb_grid(long M, int per_cu = 1) {
     static int ncu = 0;
@@ -881,9 +883,8 @@ static int launch_linear_bwd_pair(const float* dz, int ldz, const float* x1, int
     hipLaunchKernelGGL(k_linear_bwd_r2<W>, dim3(grid), dim3(W * 4), 0, (hipStream_t)stream, a);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
-    rc = magnet_launch_reduce_partials2(a.wpartA, (long)W * W, dWA, a.bpartA, (long)W, dbA, grid, 1.0f, accumulate, stream);
-    if (rc) return rc;
-    return magnet_launch_reduce_partials2(a.wpartB, (long)W * W, dWB, a.bpartB, (long)W, dbB, grid, 1.0f, accumulate, stream);
+    return magnet_launch_reduce_partials2x2(a.wpartA, (long)W * W, dWA, a.bpartA, (long)W, dbA, a.wpartB, dWB, a.bpartB, dbB, grid, 1.0f,
+                                            accumulate, stream);
 }
 extern "C" int magnet_linear_bwd128_pair_f32(const float* dz, int ldz, const float* x1, int ldx1, const float* x2, int ldx2,
                                              const void* wtA_f16, const void* wtB_f16, long M, float* dx, int lddx, float* dWA, float* dbA,

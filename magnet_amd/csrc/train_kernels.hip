@@ -428,10 +428,14 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict
 // Two reductions of the same partial count in ONE launch (a Linear's dW [n_a] and db [n_b]: the second was four workgroups of 5 us of
 // launch latency - 1 150 of the 2 050 launches of a magnet_gnn training step at the reference's batch size were reductions).  Workgroups
 // [0, ceil(n_a / 32)) serve a, the rest b; same summation order as k_reduce_partials.
+// (gridDim.y = 2: a second pair of arrays of the same sizes - the two Linears of magnet_linear_bwd128_pair_f32 in one launch)
 __global__ void __launch_bounds__(256) k_reduce_partials2(const float* __restrict__ pa, long na, float* __restrict__ oa,
                                                           const float* __restrict__ pb, long nb_, float* __restrict__ ob, int nblk,
-                                                          float scale, int accumulate) {
+                                                          float scale, int accumulate, const float* __restrict__ pa2 = nullptr,
+                                                          float* __restrict__ oa2 = nullptr, const float* __restrict__ pb2 = nullptr,
+                                                          float* __restrict__ ob2 = nullptr) {
     __shared__ float sm[8][32];
+    if (blockIdx.y) pa = pa2, oa = oa2, pb = pb2, ob = ob2;
     const int blocks_a = (int)((na + 31) / 32);
     const bool second = (int)blockIdx.x >= blocks_a;
     const float* p = second ? pb : pa;
@@ -931,7 +935,17 @@ int magnet_launch_reduce_partials2(const float* pa, long na, float* oa, const fl
                                    int accumulate, void* stream) {
     BEGIN();
     if (na <= 0 || nb_ <= 0) return -2;
-    hipLaunchKernelGGL(k_reduce_partials2, dim3(nb(na, 32) + nb(nb_, 32)), dim3(256), 0, S_, pa, na, oa, pb, nb_, ob, nblk, scale, accumulate);
+    hipLaunchKernelGGL(k_reduce_partials2, dim3(nb(na, 32) + nb(nb_, 32)), dim3(256), 0, S_, pa, na, oa, pb, nb_, ob, nblk, scale, accumulate,
+                       nullptr, nullptr, nullptr, nullptr);
+    END();
+}
+// the same for TWO Linears (two [nblk][na] / [nblk][nb] pairs) in one launch
+int magnet_launch_reduce_partials2x2(const float* pa, long na, float* oa, const float* pb, long nb_, float* ob, const float* pa2, float* oa2,
+                                     const float* pb2, float* ob2, int nblk, float scale, int accumulate, void* stream) {
+    BEGIN();
+    if (na <= 0 || nb_ <= 0) return -2;
+    hipLaunchKernelGGL(k_reduce_partials2, dim3(nb(na, 32) + nb(nb_, 32), 2), dim3(256), 0, S_, pa, na, oa, pb, nb_, ob, nblk, scale, accumulate,
+                       pa2, oa2, pb2, ob2);
     END();
 }
 // dx = InstanceNorm backward of dy given the normalised output yhat and the biased variance var [n_graphs][H]
