@@ -6,7 +6,8 @@
 //     (2.7x fewer matrix-pipe cycles, fp32-class accuracy);
 //   * the split weight planes do not come from L2 per tile: the 4 waves of a workgroup walk the layers in
 //     lockstep and the planes of one k tile (NT * 6 KiB) are DMA'd (global_load_lds, no VGPR round trip) into
-//     an LDS ring one or two k tiles ahead (counted s_waitcnt) - one __syncthreads per k tile;
+//     an LDS ring one or two k tiles ahead (counted s_waitcnt) - one workgroup barrier per k tile (ring_barrier: a raw s_barrier,
+//     because __syncthreads() drains every outstanding memory operation and with it the counted waits);
 //   * activations are split per 8-k slot right before use, so the split's VALU work sits in MFMA shadows.
 // layer[l].w points at that layer's planes in fragment order [kt][nt][m][plane][64 lanes][8 bf16]
 // (packing.pack_linear_bf16x3), layer[l].b at the zero-padded fp32 bias.
