@@ -446,6 +446,10 @@ int magnet_euler_update_bwd_f32(const float* dout, const float* t, int t_ld, int
  * workspace: (2*n_graphs*ceil(rows/128) + 2*n_graphs)*H floats */
 int magnet_instance_norm_bwd_f32(const float* dy, const float* yhat, const float* var, int n_graphs, int rows_per_graph,
                                  int H, float eps, float* dx, float* workspace, void* stream);
+/* ... with the Swish backward of the layer whose output was normalised in the same pass (mpnn.py:81-90, :63): dx as above, dz = dx * Swish'(z);
+ * amax256: NULL or 256 zeroed floats that receive the block maxima of |dz| (as magnet_swish_bwd_amax_f32).  dx has the bits of magnet_instance_norm_bwd_f32's, dz is within a few ulp of the two calls'. */
+int magnet_instance_norm_bwd_swish_f32(const float* dy, const float* yhat, const float* var, int n_graphs, int rows_per_graph, int H,
+                                       float eps, const float* z, float* dx, float* dz, float* amax256, float* workspace, void* stream);
 /* ... for graphs of unequal size: graph g owns rows gptr[g] .. gptr[g + 1] (PyG's InstanceNorm(x, batch), models/mpnn.py:63,70); yhat and var
  * [n_graphs][H] as magnet_instance_norm_ragged_f32 left them.  No workspace. */
 int magnet_instance_norm_ragged_bwd_f32(const float* dy, const float* yhat, const float* var, const int32_t* gptr, int n_graphs, int H,

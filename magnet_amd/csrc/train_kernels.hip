@@ -500,6 +500,47 @@ __global__ void k_instnorm_bwd_apply(const float* __restrict__ dy, const float* 
     *reinterpret_cast<f32x4*>(dx + i4) = o;
 }
 
+// ... and the Swish backward of the layer below it in the same pass (MPNN: x = h + update_net(..) is normalised, so the gradient of the
+// norm's input IS the gradient at update_net_2's Swish output): dz = dx * Swish'(z), block maxima of |dz| as k_swish_bwd_amax leaves them.
+// Same arithmetic as k_instnorm_bwd_apply followed by k_swish_bwd_amax (dx is stored and used as the fp32 value it is): dx has the same
+// bits, dz differs by the compiler's choice of fused multiply-adds (a few ulp).
+__global__ void __launch_bounds__(256) k_instnorm_bwd_apply_swish(const float* __restrict__ dy, const float* __restrict__ yhat,
+                                                                  const float* __restrict__ m1, const float* __restrict__ m2,
+                                                                  const float* __restrict__ var, int rows_per_graph, int H, float eps,
+                                                                  long total, float* __restrict__ dx, const float* __restrict__ z,
+                                                                  float* __restrict__ dz, float* __restrict__ amax) {
+    __shared__ float wm[4];
+    const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    float m = 0.f;
+    if (i4 < total) {
+        const int c = (int)(i4 % H);
+        const int g = (int)((i4 / H) / rows_per_graph);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + i4), y = *reinterpret_cast<const f32x4*>(yhat + i4);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(m1 + (size_t)g * H + c), b = *reinterpret_cast<const f32x4*>(m2 + (size_t)g * H + c);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(var + (size_t)g * H + c);
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + i4);
+        f32x4 o, q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[k] = (d[k] - a[k] - y[k] * b[k]) / sqrtf(v[k] + eps);
+            const float s = sigmoidf_fast(zz[k]);
+            q[k] = o[k] * s * (1.0f + zz[k] * (1.0f - s));
+            m = fmaxf(m, fabsf(q[k]));
+        }
+        *reinterpret_cast<f32x4*>(dx + i4) = o;
+        *reinterpret_cast<f32x4*>(dz + i4) = q;
+    }
+    if (!amax) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        atomicMax(reinterpret_cast<unsigned*>(amax) + (blockIdx.x & 255), __float_as_uint(m));
+    }
+}
+
 // ---- read-out backward: out[n,k] = u[n,tw-1] + dt (k+1) conv2(act(conv1(h[n])))[k]
 // one wave per node, workgroups stride over the nodes; weight / bias gradients are accumulated per wave in LDS and
 // written once per workgroup as partials [grid][GP], GP = [dw1 8*k1 | db1 8 | dw2 8*k2 | db2 1].
@@ -967,6 +1008,29 @@ extern "C" int magnet_instance_norm_bwd_f32(const float* dy, const float* yhat, 
     hipLaunchKernelGGL(k_reduce_partials, dim3(nb(H, 32), n_graphs), dim3(256), 0, S_, p2, nchunks, (long)H, inv, m2, 0);
     hipLaunchKernelGGL(k_instnorm_bwd_apply, dim3(nb(total / 4, 256)), dim3(256), 0, S_, dy, yhat, m1, m2, var, rows_per_graph, H,
                        eps, total, dx);
+    END();
+}
+// The same with the Swish backward of the producing layer in the apply pass: dx as above, dz = dx * Swish'(z) (z [rows][H]: the
+// pre-activation whose Swish output was normalised), amax256: NULL or 256 floats zeroed by the caller that receive the block maxima of |dz|
+// (magnet_swish_bwd_amax_f32's).  dx bit-identical to magnet_instance_norm_bwd_f32's, dz within a few ulp of magnet_swish_bwd(_amax)_f32's.
+extern "C" int magnet_instance_norm_bwd_swish_f32(const float* dy, const float* yhat, const float* var, int n_graphs, int rows_per_graph,
+                                                  int H, float eps, const float* z, float* dx, float* dz, float* amax256, float* workspace,
+                                                  void* stream) {
+    BEGIN();
+    const long total = (long)n_graphs * rows_per_graph * H;
+    if (total <= 0) return 0;
+    if (H % 4) return -2;
+    const int nchunks = (rows_per_graph + STAT_CHUNK - 1) / STAT_CHUNK;
+    float* p1 = workspace;
+    float* p2 = p1 + (size_t)n_graphs * nchunks * H;
+    float* m1 = p2 + (size_t)n_graphs * nchunks * H;
+    float* m2 = m1 + (size_t)n_graphs * H;
+    hipLaunchKernelGGL(k_colstat2_partial, dim3(nchunks, n_graphs), dim3(128), 0, S_, dy, yhat, rows_per_graph, H, p1, p2);
+    const float inv = 1.0f / (float)rows_per_graph;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nb(H, 32), n_graphs), dim3(256), 0, S_, p1, nchunks, (long)H, inv, m1, 0);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nb(H, 32), n_graphs), dim3(256), 0, S_, p2, nchunks, (long)H, inv, m2, 0);
+    hipLaunchKernelGGL(k_instnorm_bwd_apply_swish, dim3(nb(total / 4, 256)), dim3(256), 0, S_, dy, yhat, m1, m2, var, rows_per_graph, H,
+                       eps, total, dx, z, dz, amax256);
     END();
 }
 // The same for graphs of UNEQUAL size (graph g = rows gptr[g] .. gptr[g + 1]; PyG's InstanceNorm(x, batch) takes any batch vector,

@@ -109,6 +109,7 @@ def _grad_buffers(m, dev):
 
 
 _NODE_ONE_KERNEL = __import__("os").environ.get("MAGNET_NODE_ONE_KERNEL", "1") != "0"      # A/B knob
+_NORM_SWISH = __import__("os").environ.get("MAGNET_NORM_SWISH", "1") != "0"                # A/B knob: 0 = InstanceNorm backward and Swish backward as two passes
 _WGRAD_PAIR = __import__("os").environ.get("MAGNET_WGRAD_PAIR", "1") != "0"                # A/B knob: 0 = two launches per [h | node_in] weight gradient
 
 
@@ -171,9 +172,11 @@ def backward_call(m, tape, dout, G, ws):
     lbw = None
     for li in reversed(range(len(P.layers))):
         lyr, qb, tp, g = P.layers[li], Q.layers[li], tape.layers[li], G.layers[li]
-        if getattr(tape, "gptr", None) is not None:                      # foreign Data with graphs of unequal size
+        ragged = getattr(tape, "gptr", None) is not None                 # foreign Data with graphs of unequal size
+        fuse_swish = not ragged and _NORM_SWISH and getattr(tp, "z2", None) is not None
+        if ragged:
             dg = ops.instance_norm_ragged_bwd(dh, tp.h_out, tp.var, tape.gptr)
-        else:
+        elif not fuse_swish:
             dg = ops.instance_norm_bwd(dh, tp.h_out, tp.var, B, Ns)
         # ---- update MLP (recomputed pre-activations)                                 mpnn.py:81-90
         z1 = getattr(tp, "z1", None)
@@ -188,7 +191,10 @@ def backward_call(m, tape, dout, G, ws):
             lin(N, ops.ktiles(T(r1, H)), lyr.upd2, z2)
         one_kernel = N >= 4096 and hasattr(qb, "w4t_f16") and _NODE_ONE_KERNEL     # data + weight + bias gradient of a 128 x 128 Linear in one kernel
         am = torch.zeros(2, 256, device=dev, dtype=torch.float32) if one_kernel else None     # block maxima of |dz2|, |dz1| from the Swish backward
-        dz2 = ops.swish_bwd(dg, z2, t1, amax=am[0] if one_kernel else None)
+        if fuse_swish:                                                    # the norm's backward and update_net_2's Swish backward in one apply pass
+            dg, dz2 = ops.instance_norm_bwd_swish(dh, tp.h_out, tp.var, B, Ns, z2, t1, amax=am[0] if one_kernel else None)
+        else:
+            dz2 = ops.swish_bwd(dg, z2, t1, amax=am[0] if one_kernel else None)
         if one_kernel:
             if lbw is None:
                 lbw = (torch.empty(L.lib().magnet_linear_bwd128_workspace(), device=dev, dtype=torch.float32),

@@ -757,6 +757,17 @@ def instance_norm_bwd(dy, yhat, var, n_graphs, rows_per_graph, eps=1e-5, out=Non
     return out
 
 
+def instance_norm_bwd_swish(dy, yhat, var, n_graphs, rows_per_graph, z, dz, amax=None, eps=1e-5, out=None):
+    """instance_norm_bwd and swish_bwd(., z) in one apply pass: returns (dx, dz); ``amax`` as swish_bwd's"""
+    h = dy.shape[1]
+    nchunks = (rows_per_graph + 127) // 128
+    ws = torch.empty((2 * n_graphs * nchunks + 2 * n_graphs) * h, device=dy.device, dtype=torch.float32)
+    out = torch.empty_like(dy) if out is None else out
+    L.check(L.lib().magnet_instance_norm_bwd_swish_f32(_p(dy), _p(yhat), _p(var), n_graphs, rows_per_graph, h, C.c_float(float(eps)),
+                                                       _p(z), _p(out), _p(dz), _p(amax), _p(ws), _stream()), "instance_norm_bwd_swish")
+    return out, dz
+
+
 def mpnn_readout_bwd(h, dout, tw, w1, b1, k1, s1, w2, k2, use_swish, dt):
     """-> (dh [n,128], du_last [n], gpart [min(1024, ceil(n/4)), 8*k1+8+8*k2+1])"""
     n = h.shape[0]

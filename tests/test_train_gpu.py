@@ -1279,3 +1279,26 @@ def test_forward_is_differentiable_like_the_reference(unequal):
     # eval mode: the inference path, no graph
     model.eval()
     assert model(cdata, L_.cuda(), tmax.cuda(), dt.cuda()).grad_fn is None
+
+
+@pytest.mark.parametrize("B,Ns", [(1, 100), (3, 257), (4, 4096)])
+def test_instance_norm_bwd_with_the_swish_backward_in_its_apply_pass_equals_the_two_calls(B, Ns):
+    """magnet_instance_norm_bwd_swish_f32: dx bit-identical to instance_norm_bwd, dz = dx * Swish'(z) equal to swish_bwd of it up to the
+    compiler's choice of fused multiply-adds (a few ulp), the block maxima of |dz| exact"""
+    from magnet_amd import ops
+    torch.manual_seed(7)
+    N, H = B * Ns, 128
+    dy, z = torch.randn(N, H, device="cuda") * 1e-7, torch.randn(N, H, device="cuda")
+    x = torch.randn(N, H, device="cuda")
+    yhat, var = ops.instance_norm(x, B, Ns, out=torch.empty_like(x), return_var=True)
+    dx0 = ops.instance_norm_bwd(dy, yhat, var, B, Ns)
+    am0 = torch.zeros(256, device="cuda")
+    dz0 = ops.swish_bwd(dx0, z, torch.empty_like(z), amax=am0)
+    am1 = torch.zeros(256, device="cuda")
+    dx1, dz1 = ops.instance_norm_bwd_swish(dy, yhat, var, B, Ns, z, torch.empty_like(z), amax=am1)
+    assert torch.equal(dx0, dx1) and rel_l2(dz1, dz0) < 2e-7 and float((dz1 - dz0).abs().max()) <= 4e-7 * float(dz0.abs().max())
+    assert float(am1.max()) == float(dz1.abs().max())
+    dx2, dz2 = ops.instance_norm_bwd_swish(dy, yhat, var, B, Ns, z, torch.empty_like(z))
+    assert torch.equal(dx1, dx2) and torch.equal(dz1, dz2)                 # (with and without the maxima: the same pass)
+    want = dx0.double() * (torch.sigmoid(z.double()) * (1 + z.double() * (1 - torch.sigmoid(z.double()))))
+    assert rel_l2(dz1, want) < 3e-7
